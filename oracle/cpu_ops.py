@@ -1,0 +1,285 @@
+"""CPU ORACLE bindings (test infrastructure, NOT product code).
+
+ctypes wrapper over oracle/libp2pb_oracle.so that exposes the SAME function names and argument
+order as the reference's CUDA extension modules, but on CPU torch tensors:
+
+  * `pointnet2_batch_cuda` API  (third_party/openpoints/cpp/pointnet2_batch/src/pointnet2_api.cpp:31-47)
+  * `chamfer_3D` API            (metrics/chamfer3D/chamfer_cuda.cpp:17-32)
+  * `emd_cuda` API              (metrics/PyTorchEMD/cuda/emd.cpp:8-26)
+  * `emd_assignment` API        (metrics/emd_assignment/emd_assignment/emd.cpp:14-30)
+
+Only tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg and tools/make_golden.py import
+this module. The product package `p2p_bridge_amd` never does.
+"""
+import ctypes
+import os
+import subprocess
+import types
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libp2pb_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "p2pb_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_auction_fwd.restype = ctypes.c_int
+    return _lib
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(t, dtype):
+    assert t.device.type == "cpu" and t.is_contiguous() and t.dtype == dtype, (t.device, t.dtype, t.is_contiguous())
+
+
+F32, I32 = torch.float32, torch.int32
+_f = ctypes.c_float
+_i = ctypes.c_int
+
+# --------------------------------------------------------------------------------- voxel coords
+
+
+def voxel_coords(coords, r, normalize=True, eps=0.0):
+    """Deterministic Voxelization.forward normalisation (models/pvcnn.py:215-228)."""
+    _chk(coords, F32)
+    b, _, n = coords.shape
+    norm = torch.empty_like(coords)
+    vox = torch.empty(b, 3, n, dtype=I32)
+    lib().orc_voxel_coords(_i(b), _i(n), _i(r), _i(int(normalize)), _f(eps), _p(coords), _p(norm), _p(vox))
+    return norm, vox
+
+
+# -------------------------------------------------------------------- pointnet2_batch_cuda API
+
+
+def avg_voxelize_forward(features, coords, resolution):
+    _chk(features, F32), _chk(coords, I32)
+    b, c, n = features.shape
+    r = int(resolution)
+    r3 = r ** 3
+    out = torch.zeros(b, c, r3)
+    ind = torch.zeros(b, n, dtype=I32)
+    cnt = torch.zeros(b, r3, dtype=I32)
+    lib().orc_avg_voxelize_fwd(_i(b), _i(c), _i(n), _i(r), _p(coords), _p(features), _p(ind), _p(cnt), _p(out))
+    return [out, ind, cnt]
+
+
+def avg_voxelize_backward(grad_y, indices, cnt):
+    _chk(grad_y, F32), _chk(indices, I32), _chk(cnt, I32)
+    b, c, s = grad_y.shape
+    n = indices.shape[1]
+    gx = torch.zeros(b, c, n)
+    lib().orc_avg_voxelize_bwd(_i(b), _i(c), _i(n), _i(s), _p(indices), _p(cnt), _p(grad_y), _p(gx))
+    return gx
+
+
+def trilinear_devoxelize_forward(r, is_training, coords, features):
+    _chk(coords, F32), _chk(features, F32)
+    b, c = features.shape[:2]
+    n = coords.shape[2]
+    outs = torch.zeros(b, c, n)
+    if is_training:
+        inds = torch.zeros(b, 8, n, dtype=I32)
+        wgts = torch.zeros(b, 8, n)
+    else:
+        inds = torch.zeros(1, dtype=I32)
+        wgts = torch.zeros(1)
+    lib().orc_trilinear_devox_fwd(_i(b), _i(c), _i(n), _i(int(r)), _i(int(bool(is_training))), _p(coords),
+                                  _p(features), _p(inds), _p(wgts), _p(outs))
+    return [outs, inds, wgts]
+
+
+def trilinear_devoxelize_backward(grad_y, indices, weights, r):
+    _chk(grad_y, F32), _chk(indices, I32), _chk(weights, F32)
+    b, c, n = grad_y.shape
+    r3 = int(r) ** 3
+    gx = torch.zeros(b, c, r3)
+    lib().orc_trilinear_devox_bwd(_i(b), _i(c), _i(n), _i(r3), _p(indices), _p(weights), _p(grad_y), _p(gx))
+    return gx
+
+
+def ball_query(centers_coords, points_coords, radius, num_neighbors):
+    _chk(centers_coords, F32), _chk(points_coords, F32)
+    b, _, m = centers_coords.shape
+    n = points_coords.shape[2]
+    rf = ctypes.c_float(radius).value  # pybind double -> const float
+    r2 = ctypes.c_float(rf * rf).value  # float * float, pvcnn_ball_query.cpp:25
+    idx = torch.zeros(b, m, num_neighbors, dtype=I32)
+    lib().orc_ball_query(_i(b), _i(n), _i(m), _f(r2), _i(num_neighbors), _p(centers_coords), _p(points_coords),
+                         _p(idx))
+    return idx
+
+
+def grouping_forward(features, indices):
+    _chk(features, F32), _chk(indices, I32)
+    b, c, n = features.shape
+    _, m, u = indices.shape
+    out = torch.zeros(b, c, m, u)
+    lib().orc_grouping_fwd(_i(b), _i(c), _i(n), _i(m), _i(u), _p(features), _p(indices), _p(out))
+    return out
+
+
+def grouping_backward(grad_y, indices, n):
+    _chk(grad_y, F32), _chk(indices, I32)
+    b, c, m, u = grad_y.shape
+    gx = torch.zeros(b, c, n)
+    lib().orc_grouping_bwd(_i(b), _i(c), _i(n), _i(m), _i(u), _p(grad_y), _p(indices), _p(gx))
+    return gx
+
+
+def gather_features_forward(features, indices):
+    _chk(features, F32), _chk(indices, I32)
+    b, c, n = features.shape
+    m = indices.shape[1]
+    out = torch.zeros(b, c, m)
+    lib().orc_gather_fwd(_i(b), _i(c), _i(n), _i(m), _p(features), _p(indices), _p(out))
+    return out
+
+
+def gather_features_backward(grad_y, indices, n):
+    _chk(grad_y, F32), _chk(indices, I32)
+    b, c, m = grad_y.shape
+    gx = torch.zeros(b, c, n)
+    lib().orc_gather_bwd(_i(b), _i(c), _i(n), _i(m), _p(grad_y), _p(indices), _p(gx))
+    return gx
+
+
+def furthest_point_sampling_forward(coords, num_samples):
+    _chk(coords, F32)
+    b, _, n = coords.shape
+    idx = torch.zeros(b, num_samples, dtype=I32)
+    dist = torch.empty(b, n)
+    lib().orc_fps(_i(b), _i(n), _i(num_samples), _p(coords), _p(dist), _p(idx))
+    return idx
+
+
+def three_nearest_neighbors_interpolate_forward(points_coords, centers_coords, centers_features):
+    _chk(points_coords, F32), _chk(centers_coords, F32), _chk(centers_features, F32)
+    b, c, m = centers_features.shape
+    n = points_coords.shape[2]
+    idx = torch.zeros(b, 3, n, dtype=I32)
+    w = torch.zeros(b, 3, n)
+    out = torch.zeros(b, c, n)
+    lib().orc_three_nn(_i(b), _i(n), _i(m), _p(points_coords), _p(centers_coords), _p(w), _p(idx))
+    lib().orc_three_interp_fwd(_i(b), _i(c), _i(m), _i(n), _p(centers_features), _p(idx), _p(w), _p(out))
+    return [out, idx, w]
+
+
+def three_nearest_neighbors_interpolate_backward(grad_y, indices, weights, m):
+    _chk(grad_y, F32), _chk(indices, I32), _chk(weights, F32)
+    b, c, n = grad_y.shape
+    gx = torch.zeros(b, c, m)
+    lib().orc_three_interp_bwd(_i(b), _i(c), _i(n), _i(m), _p(grad_y), _p(indices), _p(weights), _p(gx))
+    return gx
+
+
+pointnet2_batch_cuda = types.SimpleNamespace(
+    avg_voxelize_forward=avg_voxelize_forward,
+    avg_voxelize_backward=avg_voxelize_backward,
+    trilinear_devoxelize_forward=trilinear_devoxelize_forward,
+    trilinear_devoxelize_backward=trilinear_devoxelize_backward,
+    ball_query=ball_query,
+    grouping_forward=grouping_forward,
+    grouping_backward=grouping_backward,
+    gather_features_forward=gather_features_forward,
+    gather_features_backward=gather_features_backward,
+    furthest_point_sampling_forward=furthest_point_sampling_forward,
+    three_nearest_neighbors_interpolate_forward=three_nearest_neighbors_interpolate_forward,
+    three_nearest_neighbors_interpolate_backward=three_nearest_neighbors_interpolate_backward,
+)
+
+# ------------------------------------------------------------------------------ chamfer_3D API
+
+
+def chamfer_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+    for t in (xyz1, xyz2, dist1, dist2):
+        _chk(t, F32)
+    _chk(idx1, I32), _chk(idx2, I32)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    lib().orc_chamfer_fwd(_i(b), _i(n), _i(m), _p(xyz1), _p(xyz2), _p(dist1), _p(dist2), _p(idx1), _p(idx2))
+    return 1
+
+
+def chamfer_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    lib().orc_chamfer_bwd(_i(b), _i(n), _i(m), _p(xyz1), _p(xyz2), _p(gradxyz1), _p(gradxyz2), _p(graddist1),
+                          _p(graddist2), _p(idx1), _p(idx2))
+    return 1
+
+
+chamfer_3D = types.SimpleNamespace(forward=chamfer_forward, backward=chamfer_backward)
+
+# -------------------------------------------------------------------------------- emd_cuda API
+
+
+def approxmatch_forward(xyz1, xyz2):
+    _chk(xyz1, F32), _chk(xyz2, F32)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    match = torch.zeros(b, m, n)
+    temp = torch.zeros(b, (n + m) * 2)
+    lib().orc_approxmatch(_i(b), _i(n), _i(m), _p(xyz1), _p(xyz2), _p(match), _p(temp))
+    return match
+
+
+def matchcost_forward(xyz1, xyz2, match):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    cost = torch.zeros(b)
+    lib().orc_matchcost(_i(b), _i(n), _i(m), _p(xyz1), _p(xyz2), _p(match), _p(cost))
+    return cost
+
+
+def matchcost_backward(grad_cost, xyz1, xyz2, match):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    g1 = torch.zeros(b, n, 3)
+    g2 = torch.zeros(b, m, 3)
+    lib().orc_matchcost_bwd(_i(b), _i(n), _i(m), _p(grad_cost.contiguous()), _p(xyz1), _p(xyz2), _p(match), _p(g1),
+                            _p(g2))
+    return [g1, g2]
+
+
+emd_cuda = types.SimpleNamespace(approxmatch_forward=approxmatch_forward, matchcost_forward=matchcost_forward,
+                                 matchcost_backward=matchcost_backward)
+
+# -------------------------------------------------------------------------- emd_assignment API
+
+
+def auction_forward(xyz1, xyz2, dist, assignment, price, assignment_inv, bid, bid_increments, max_increments,
+                    unass_idx, unass_cnt, unass_cnt_sum, cnt_tmp, max_idx, eps, iters):
+    b, n, _ = xyz1.shape
+    if xyz2.shape[1] != n:
+        return -1
+    return lib().orc_auction_fwd(_i(b), _i(n), _p(xyz1), _p(xyz2), _p(dist), _p(assignment), _p(price),
+                                 _p(assignment_inv), _p(bid), _p(bid_increments), _p(max_increments), _p(max_idx),
+                                 _f(eps), _i(iters))
+
+
+def auction_backward(xyz1, xyz2, gradxyz, graddist, idx):
+    b, n, _ = xyz1.shape
+    lib().orc_auction_bwd(_i(b), _i(n), _p(xyz1), _p(xyz2), _p(gradxyz), _p(graddist), _p(idx))
+    return 1
+
+
+emd_assignment = types.SimpleNamespace(forward=auction_forward, backward=auction_backward)

@@ -1,0 +1,195 @@
+"""The CPU oracle against the golden vectors captured from the reference's own Python model
+(tools/make_golden.py), and against the reference's known-answer tests. CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ops, net_ref
+
+from conftest import GOLDEN
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    cfg = json.load(open(os.path.join(GOLDEN, "tiny_cfg.json")))
+    w = _load("tiny_weights.npz")
+    sd = {k: _t(w[k]).float() for k in w.files}
+    return cfg, sd, _load("tiny_run.npz")
+
+
+def test_schedule_and_steps():
+    g = _load("schedule.npz")
+    for name, beta_end in (("PVDS_PUNet", 0.02), ("PVDL_SNPP", 3e-4)):
+        diff = dict(timesteps=1000, beta_start=1e-4, beta_end=beta_end, t0=1e-4, T=1.0)
+        sch = net_ref.make_schedule(diff)
+        for k, v in sch.items():
+            assert np.array_equal(v.numpy(), g[f"{name}.{k}"]), (name, k)
+    for T in (5, 10, 30):
+        assert net_ref.space_indices(1000, T + 1) == g[f"space_indices.{T}"].tolist()
+
+
+def test_timestep_embedding():
+    g = _load("temb.npz")
+    e = net_ref.timestep_embedding(_t(g["t"]), 64)
+    assert np.array_equal(e.numpy(), g["emb"])
+
+
+OPS = {
+    "avg_voxelize_forward": lambda a: cpu_ops.avg_voxelize_forward(a[0], a[1], int(a[2])),
+    "trilinear_devoxelize_forward": lambda a: cpu_ops.trilinear_devoxelize_forward(int(a[0]), bool(a[1]), a[2], a[3]),
+    "ball_query": lambda a: [cpu_ops.ball_query(a[0], a[1], float(a[2]), int(a[3]))],
+    "grouping_forward": lambda a: [cpu_ops.grouping_forward(a[0], a[1])],
+    "gather_features_forward": lambda a: [cpu_ops.gather_features_forward(a[0], a[1])],
+    "furthest_point_sampling_forward": lambda a: [cpu_ops.furthest_point_sampling_forward(a[0], int(a[1]))],
+    "three_nearest_neighbors_interpolate_forward":
+        lambda a: cpu_ops.three_nearest_neighbors_interpolate_forward(a[0], a[1], a[2]),
+}
+
+
+@pytest.mark.parametrize("op", sorted(OPS))
+def test_native_op_fixtures(tiny, op):
+    """Per-op inputs/outputs captured at the reference's extension boundary: bit-exact replay."""
+    _, _, run = tiny
+    for call in (0, 1):
+        ins = []
+        i = 0
+        while f"op.{op}.{call}.in{i}" in run.files:
+            a = run[f"op.{op}.{call}.in{i}"]
+            ins.append(_t(a) if a.ndim > 0 else a.item())
+            i += 1
+        if not ins:
+            continue
+        outs = OPS[op](ins)
+        for oi, o in enumerate(outs):
+            exp = run[f"op.{op}.{call}.out{oi}"]
+            assert np.array_equal(o.numpy(), exp), (op, call, oi)
+
+
+def test_tiny_net_and_sampler_bit_exact(tiny):
+    """oracle net (vox_mode='torch') == the reference's PVCNN2Unet / P2PB.sample on CPU, bit for bit."""
+    cfg, sd, run = tiny
+    net = net_ref.RefNet(cfg, sd, vox_mode="torch")
+    with torch.no_grad():
+        out = net(_t(run["x_start"]), _t(run["t"]))
+    assert np.array_equal(out.numpy(), run["net_out"])
+    s = net_ref.sample(net, cfg, _t(run["x_start"]), steps=5, log_count=5)
+    assert np.array_equal(s["x_pred"].numpy(), run["x_pred_T5"])
+    assert np.array_equal(s["x_chain"].numpy(), run["x_chain_T5"])
+
+
+def test_tiny_net_tree_mode_close(tiny):
+    """the build's deterministic voxel normalisation stays within fp32 noise of the reference's."""
+    cfg, sd, run = tiny
+    net = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    with torch.no_grad():
+        out = net(_t(run["x_start"]), _t(run["t"]))
+    assert np.abs(out.numpy() - run["net_out"]).max() < 1e-4
+
+
+def test_training_loss_and_grads(tiny):
+    """P2PB.forward (q_sample -> target -> MSE) and backward through the oracle's grad ops."""
+    cfg, sd, run = tiny
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    net = net_ref.RefNet(cfg, {}, vox_mode="torch")
+    net.sd = sd
+    net.training = True
+    sch = net_ref.make_schedule(cfg["diffusion"])
+    steps = _t(run["loss_steps"])
+    x0, x1 = _t(run["clean"]), _t(run["x_start"])
+    e = lambda a: a[steps].view(-1, 1, 1)
+    xt = e(sch["mu_x0"]) * x0 + e(sch["mu_x1"]) * x1
+    gt = (xt - x0) / e(sch["std_fwd"])
+    pred = net(xt, sch["noise_levels"][steps])
+    loss = ((pred - gt) ** 2).mean(dim=(1, 2)).mean()
+    assert abs(loss.item() - float(run["loss"])) <= 1e-6 * abs(float(run["loss"]))
+    loss.backward()
+    for k in ("classifier.2.weight", "embedf.0.weight"):
+        g = sd[k].grad.numpy()
+        exp = run["grad_" + k]
+        assert np.abs(g - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max()), k
+    norms = json.load(open(os.path.join(GOLDEN, "tiny_gradnorms.json")))
+    for k, v in norms.items():
+        assert abs(sd[k].grad.norm().item() - v) <= 2e-4 * max(v, 1e-3), k
+
+
+def test_manifest_matches_plan():
+    """the oracle's layer plan touches exactly the parameter names the reference creates."""
+    import yaml  # noqa: F401
+
+    man = json.load(open(os.path.join(GOLDEN, "manifest_PVDS.json")))
+    cfg = json.load(open(os.path.join(GOLDEN, "tiny_cfg.json")))
+    cfg["model"]["PVD"].update(channels=[32, 64, 128, 256, 512], voxel_resolutions=[32, 16, 8, 8], feat_embed_dim=32,
+                               out_mlp=128, global_embedding_dim=1024)
+    cfg["data"]["npoints"] = 2048
+    torch.manual_seed(1)
+    sd = {k: torch.randn(*s) * 0.05 for k, s in man.items()}
+
+    class Spy(dict):
+        used = set()
+
+        def __getitem__(self, k):
+            Spy.used.add(k)
+            return dict.__getitem__(self, k)
+
+    net = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    net.sd = Spy(net.sd)
+    x, _ = net_ref.synthetic_patches(1, 1024, seed=3)
+    with torch.no_grad():
+        out = net(x, torch.tensor([10.0]))
+    assert out.shape == (1, 3, 1024)
+    assert Spy.used == set(man), (set(man) - Spy.used, Spy.used - set(man))
+
+
+def test_emd_known_answer():
+    """metrics/PyTorchEMD/test_emd_loss.py: crossed 2-point clouds; cost and grads are analytic."""
+    g = _load("emd_kat.npz")
+    p1, p2 = _t(g["p1"]), _t(g["p2"])
+    match = cpu_ops.approxmatch_forward(p1, p2)
+    cost = cpu_ops.matchcost_forward(p1, p2, match)
+    assert np.allclose(cost.numpy(), g["cost"], rtol=1e-4)
+    gc = torch.tensor([0.5, 2.0, 1.0 / 3.0])
+    g1, g2 = cpu_ops.matchcost_backward(gc, p1, p2, match)
+    assert np.allclose(g1.numpy(), g["g1"], rtol=1e-3, atol=1e-4)
+    assert np.allclose(g2.numpy(), g["g2"], rtol=1e-3, atol=1e-4)
+
+
+def test_auction_invariant():
+    """metrics/emd_assignment/emd_module.py:98-117: dist[i] == |x1[i]-x2[assignment[i]]|^2, and the
+    assignment is (nearly) a bijection."""
+    torch.manual_seed(0)
+    b, n = 2, 256
+    x1, x2 = torch.rand(b, n, 3), torch.rand(b, n, 3)
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt)
+    dist, assignment, inv = z(b, n), z(b, n, dt=torch.int32) - 1, z(b, n, dt=torch.int32) - 1
+    rc = cpu_ops.auction_forward(x1, x2, dist, assignment, z(b, n), inv, z(b, n, dt=torch.int32), z(b, n), z(b, n),
+                                 z(b * n, dt=torch.int32), z(512, dt=torch.int32), z(512, dt=torch.int32),
+                                 z(512, dt=torch.int32), z(b * n, dt=torch.int32), 0.01, 100)
+    assert rc == 1
+    a = assignment.long()
+    assert a.min() >= 0 and a.max() < n
+    x2a = torch.gather(x2, 1, a.unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.allclose(((x1 - x2a) ** 2).sum(-1), dist, atol=1e-6)
+    for bi in range(b):
+        assert a[bi].unique().numel() >= int(0.97 * n)
+
+
+def test_chamfer_matches_bruteforce():
+    torch.manual_seed(0)
+    a, b_ = torch.rand(2, 300, 3), torch.rand(2, 200, 3)
+    d1, d2 = torch.zeros(2, 300), torch.zeros(2, 200)
+    i1, i2 = torch.zeros(2, 300, dtype=torch.int32), torch.zeros(2, 200, dtype=torch.int32)
+    cpu_ops.chamfer_forward(a, b_, d1, d2, i1, i2)
+    D = ((a.double()[:, :, None] - b_.double()[:, None]) ** 2).sum(-1)
+    assert torch.equal(i1.long(), D.argmin(2)) and torch.equal(i2.long(), D.argmin(1))
+    assert torch.allclose(d1.double(), D.min(2).values, atol=1e-6)
