@@ -1,0 +1,138 @@
+/*
+ * p2pb_hip.h -- C ABI of libp2pb_hip.so, the MI355X (gfx950) implementation of the P2P-Bridge hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one launcher of the reference's CUDA
+ * extensions (the closest thing the reference has to a C interface are the raw-pointer launcher
+ * prototypes in its .cuh files; the pybind layer above them only allocates outputs and checks dtypes).
+ * Reference paths are relative to the reference repository root;
+ *   PN2 = third_party/openpoints/cpp/pointnet2_batch/src.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM), fp32 / int32, contiguous, layouts exactly as the
+ *     reference's tensors: point tensors channel-major [B,C,N], coords [B,3,N], metric clouds [B,N,3];
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). Every kernel is enqueued
+ *     on it; nothing synchronises, allocates or touches the host, so a sequence of calls is
+ *     hipGraph-capturable (the reference launches vox/devox/FPS/metrics on the legacy default
+ *     stream: PN2/vox_gpu.cu:125, PN2/trilinear_devox_gpu.cu:175, PN2/pvcnn_sampling_gpu.cu:189);
+ *   - outputs are fully written by the callee (no pre-zeroing needed) unless stated;
+ *   - workspaces are caller-provided (sizes via the *_ws_bytes helpers);
+ *   - return value: 0 on success, a hipError_t value on launch failure, negative on invalid
+ *     arguments (P2PB_EINVAL). The reference exit(-1)s (PN2/cuda_utils.cuh:30-39) or returns 0/1.
+ */
+#ifndef P2PB_HIP_H
+#define P2PB_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2PB_EINVAL (-22)
+
+/* library / device info --------------------------------------------------------------------- */
+int p2pb_version(void);            /* ABI version, bumps on signature change */
+const char *p2pb_target_arch(void); /* "gfx950" */
+
+/* Voxelization.forward normalisation (models/pvcnn.py:215-228): centre on the mean, divide by
+ * 2*max-norm (+eps), +0.5, *r, clamp [0,r-1]; also the half-to-even rounded int voxel coords.
+ * The reference does this with torch reductions; the build fixes the summation order
+ * (DESIGN.md "voxel_coords") so CPU oracle and HIP agree bit-for-bit.
+ *   coords f32[b,3,n] -> norm f32[b,3,n], vox i32[b,3,n] */
+int p2pb_voxel_coords(int b, int n, int r, int normalize, float eps, const float *coords, float *norm,
+                      int *vox, void *stream);
+
+/* avg_voxelize forward: replaces avg_voxelize() PN2/vox.cuh:5-6 (kernels PN2/vox_gpu.cu:18,50),
+ * called from avg_voxelize_forward PN2/vox.cpp:17.
+ *   coords i32[b,3,n], feat f32[b,c,n] -> ind i32[b,n], cnt i32[b,r^3], out f32[b,c,r^3]
+ * Deterministic: each voxel sums its points in ascending point index (the reference's float
+ * atomicAdd order is arbitrary). ws: p2pb_avg_voxelize_ws_bytes(b,n,r) bytes. */
+size_t p2pb_avg_voxelize_ws_bytes(int b, int n, int r);
+int p2pb_avg_voxelize_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind,
+                              int *cnt, float *out, void *ws, void *stream);
+/* replaces avg_voxelize_grad() PN2/vox.cuh:7-8 (kernel PN2/vox_gpu.cu:92) */
+int p2pb_avg_voxelize_backward(int b, int c, int n, int r3, const int *ind, const int *cnt,
+                               const float *grad_y, float *grad_x, void *stream);
+
+/* trilinear devoxelize: replaces trilinear_devoxelize() / _grad() PN2/trilinear_devox.cuh:5-11
+ * (kernels PN2/trilinear_devox_gpu.cu:21,123). inds i32[b,8,n] / wgts f32[b,8,n] are written only
+ * when is_training != 0 (may be NULL otherwise).
+ *   coords f32[b,3,n] (voxel units), feat f32[b,c,r^3] -> outs f32[b,c,n] */
+int p2pb_trilinear_devoxelize_forward(int b, int c, int n, int r, int is_training, const float *coords,
+                                      const float *feat, int *inds, float *wgts, float *outs, void *stream);
+/* grad_x f32[b,c,r^3] is zero-filled by the callee, then scatter-added (fp32 atomics) */
+int p2pb_trilinear_devoxelize_backward(int b, int c, int n, int r3, const int *inds, const float *wgts,
+                                       const float *grad_y, float *grad_x, void *stream);
+
+/* ball query: replaces ball_query() PN2/pvcnn_ball_query.cuh:4-6 (kernel PN2/pvcnn_ball_query_gpu.cu:19).
+ * r2 = radius*radius (float product, PN2/pvcnn_ball_query.cpp:25).
+ *   centers f32[b,3,m], points f32[b,3,n] -> idx i32[b,m,u]: first u points (ascending index) with
+ *   d2 < r2, remaining slots padded with the first hit; all zero when nothing is in range. */
+int p2pb_ball_query(int b, int n, int m, float r2, int u, const float *centers, const float *points, int *idx,
+                    void *stream);
+
+/* grouping: replaces grouping() / grouping_grad() PN2/pvcnn_grouping.cuh:4-7
+ * (kernels PN2/pvcnn_grouping_gpu.cu:18,62).  feat f32[b,c,n], idx i32[b,m,u] -> out f32[b,c,m,u] */
+int p2pb_grouping_forward(int b, int c, int n, int m, int u, const float *feat, const int *idx, float *out,
+                          void *stream);
+int p2pb_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *idx,
+                           float *grad_x, void *stream);
+
+/* gather: replaces gather_features() / _grad() PN2/pvcnn_sampling.cuh:4-7
+ * (kernels PN2/pvcnn_sampling_gpu.cu:17,55).  feat f32[b,c,n], idx i32[b,m] -> out f32[b,c,m] */
+int p2pb_gather_features_forward(int b, int c, int n, int m, const float *feat, const int *idx, float *out,
+                                 void *stream);
+int p2pb_gather_features_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
+                                  float *grad_x, void *stream);
+
+/* furthest point sampling: replaces furthest_point_sampling() PN2/pvcnn_sampling.cuh:8-9
+ * (kernel PN2/pvcnn_sampling_gpu.cu:92). Starts at index 0; ties resolve exactly like the
+ * reference's 512-thread block: (d desc, k mod 512 asc, k asc).
+ *   coords f32[b,3,n] -> idx i32[b,m].  dist_ws f32[b,n] is scratch (running min distances),
+ *   required (non-NULL) only when n > 16384; initialised by the callee. */
+int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float *dist_ws, int *idx,
+                                 void *stream);
+
+/* 3-NN inverse-squared-distance interpolation: replaces three_nearest_neighbors_interpolate() /
+ * _grad() PN2/pvcnn_neighbor_interpolate.cuh:4-14 (kernels PN2/pvcnn_neighbor_interpolate_gpu.cu:20,96,154).
+ *   points f32[b,3,n], centers f32[b,3,m], cfeat f32[b,c,m] -> idx i32[b,3,n], w f32[b,3,n], out f32[b,c,n] */
+int p2pb_three_nn_interpolate_forward(int b, int c, int m, int n, const float *points, const float *centers,
+                                      const float *cfeat, int *idx, float *w, float *out, void *stream);
+int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
+                                       const float *w, float *grad_x, void *stream);
+
+/* chamfer_3D: replaces chamfer_cuda_forward/backward (metrics/chamfer3D/chamfer3D.cu:135,176;
+ * kernels :12,:155). xyz are POINT-major f32[b,n,3] / f32[b,m,3]. Lowest index wins distance ties.
+ * backward ACCUMULATES into gradxyz1/2 (caller zero-fills, metrics/chamfer3D/dist_chamfer_3D.py:77-83). */
+int p2pb_chamfer_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2,
+                         int *idx1, int *idx2, void *stream);
+int p2pb_chamfer_backward(int b, int n, int m, const float *xyz1, const float *xyz2, float *gradxyz1,
+                          float *gradxyz2, const float *graddist1, const float *graddist2, const int *idx1,
+                          const int *idx2, void *stream);
+
+/* PyTorchEMD: replaces ApproxMatchForward / MatchCostForward / MatchCostBackward
+ * (metrics/PyTorchEMD/cuda/emd_kernel.cu:177,264,377; kernels :33,:211,:300,:347).
+ *   xyz1 f32[b,n,3], xyz2 f32[b,m,3] -> match f32[b,m,n]; temp f32[b,2(n+m)] scratch */
+int p2pb_approxmatch_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                             float *temp, void *stream);
+int p2pb_matchcost_forward(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                           float *cost, void *stream);
+int p2pb_matchcost_backward(int b, int n, int m, const float *grad_cost, const float *xyz1, const float *xyz2,
+                            const float *match, float *grad1, float *grad2, void *stream);
+
+/* emd_assignment (auction): replaces emd_cuda_forward / emd_cuda_backward
+ * (metrics/emd_assignment/emd_assignment/emd_cuda.cu:228,305; kernels :23-226,:284). Buffers as
+ * allocated by emd_module.py:43-54; assignment/assignment_inv must be -1-filled, price and
+ * max_increments zero-filled by the caller, as the reference's Python does.
+ * Returns 1 on success (the reference's convention), -1 on n != m / n % 128 / b > 512 (:236-249). */
+int p2pb_auction_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *assignment,
+                         float *price, int *assignment_inv, int *bid, float *bid_increments,
+                         float *max_increments, int *unass_idx, int *unass_cnt, int *unass_cnt_sum, int *cnt_tmp,
+                         int *max_idx, float eps, int iters, void *stream);
+int p2pb_auction_backward(int b, int n, const float *xyz1, const float *xyz2, float *gradxyz,
+                          const float *graddist, const int *idx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2PB_HIP_H */

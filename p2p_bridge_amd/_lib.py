@@ -1,0 +1,68 @@
+"""ctypes loader for libp2pb_hip.so (the C ABI declared in include/p2pb_hip.h).
+
+There is NO CPU fallback: if the library is missing, was not built for gfx950, or a tensor is not on
+a HIP device, the call raises. (tests/ check this; the CPU oracle under oracle/ is never imported here.)
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp2pb_hip.so")
+
+# every symbol include/p2pb_hip.h declares (tests/test_abi.py checks the two lists agree)
+SYMBOLS = [
+    "p2pb_version", "p2pb_target_arch", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
+    "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_trilinear_devoxelize_forward",
+    "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward",
+    "p2pb_gather_features_forward", "p2pb_gather_features_backward", "p2pb_furthest_point_sampling",
+    "p2pb_three_nn_interpolate_forward", "p2pb_three_nn_interpolate_backward", "p2pb_chamfer_forward",
+    "p2pb_chamfer_backward", "p2pb_approxmatch_forward", "p2pb_matchcost_forward", "p2pb_matchcost_backward",
+    "p2pb_auction_forward", "p2pb_auction_backward",
+]
+
+_lib = None
+
+
+class P2PBError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise P2PBError(
+                f"{LIB_PATH} not found: build it with `python -m p2p_bridge_amd.build` "
+                "(p2p_bridge_amd has no CPU / eager fallback)")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.p2pb_target_arch.restype = ctypes.c_char_p
+        _lib.p2pb_avg_voxelize_ws_bytes.restype = ctypes.c_size_t
+        for s in SYMBOLS:
+            getattr(_lib, s)  # AttributeError here = stale library
+    return _lib
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def check(t, dtype, name):
+    """Same preconditions as the reference's CHECK_CUDA / CHECK_CONTIGUOUS / CHECK_IS_* (PN2/utils.hpp:7-18)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be a {'float' if dtype == torch.float32 else 'int'} tensor")
+
+
+def call(fn_name, *args):
+    rc = getattr(lib(), fn_name)(*args)
+    if rc != 0:
+        raise P2PBError(f"{fn_name} failed with code {rc}")

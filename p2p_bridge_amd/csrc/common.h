@@ -1,0 +1,26 @@
+// common.h -- shared device helpers for the gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p2pb_hip.h"
+
+#define P2PB_WAVE 64
+
+static inline int p2pb_launch_status() { return (int)hipGetLastError(); }
+
+static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+
+// Squared distance with the arithmetic contract of DESIGN.md: nvcc contracts
+// dx*dx + dy*dy + dz*dz into  fma(dz,dz, fma(dy,dy, dx*dx)); the sources are compiled with
+// -ffp-contract=off and the sequence is spelled out (identical in oracle/p2pb_oracle.c).
+__device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+  return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int mbcnt(unsigned long long mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}

@@ -1,0 +1,208 @@
+// sampling.hip -- furthest point sampling for gfx950 (PN2/pvcnn_sampling_gpu.cu:92-184).
+//
+// FPS is M-1 strictly dependent rounds; only the B clouds are independent, so the kernel is
+// latency-bound by construction: one workgroup per cloud, and everything a round touches stays on
+// the CU. Each thread owns PPT points: coordinates AND running min-distances live in VGPRs for the
+// whole kernel (the reference re-reads a global `distances` array and a 3072-point shared cache
+// every round). A round is: PPT fused distance updates per lane, a 64-bit (distance, tie-key)
+// max-reduction with DPP row shifts/broadcasts inside each wave, one LDS slot per wave, ONE
+// s_barrier, and a 16-entry row reduction that every wave repeats redundantly (cheaper than a
+// second barrier). The winner's coordinates come from an LDS copy of the cloud when it fits.
+//
+// Tie-break parity: the reference's block is 512 threads, thread t scans k = t, t+512, ... and keeps
+// the first strict maximum, then a shared-memory tree keeps the LEFT operand on ties (:170). The
+// net order is (d desc, k mod 512 asc, k asc); it is encoded in the low word of the key so any
+// thread layout reproduces it.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u64 dpp_max_step(u64 v) {
+  const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, ROW_MASK, 0xf, false);
+  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, ROW_MASK, 0xf, false);
+  const u64 o = ((u64)ohi << 32) | olo;
+  return o > v ? o : v;
+}
+
+// max over the 64 lanes; result valid in lane 63, returned broadcast to all lanes
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+  v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row max
+  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave max
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+  return ((u64)hi << 32) | lo;
+}
+
+// max over each 16-lane row; valid in lane 15 of the row
+__device__ __forceinline__ u64 row_max_u64(u64 v) {
+  v = dpp_max_step<0x111, 0xf>(v);
+  v = dpp_max_step<0x112, 0xf>(v);
+  v = dpp_max_step<0x114, 0xf>(v);
+  v = dpp_max_step<0x118, 0xf>(v);
+  return v;
+}
+
+__device__ __forceinline__ u64 fps_key(float best, int k) {
+  // best >= 0 for any real point; threads without points carry best = -1 -> lowest key
+  const unsigned hi = best >= 0.0f ? (__float_as_uint(best) + 1u) : 0u;
+  const unsigned sec = ((unsigned)(k & 511) << 20) | (unsigned)(k >> 9);  // lower is better
+  return ((u64)hi << 32) | (u64)(~sec);
+}
+
+__device__ __forceinline__ int fps_key_index(u64 key) {
+  const unsigned sec = ~(unsigned)key;
+  return (int)(((sec & 0xFFFFFu) << 9) | (sec >> 20));
+}
+
+template <int THREADS, int PPT, bool LDS_XYZ>
+__global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float *__restrict__ coords,
+                                                      int *__restrict__ indices) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = THREADS / 64;
+  u64 *slots = (u64 *)smem;                       // [2][16]
+  float *sxyz = (float *)(smem + 2 * 16 * sizeof(u64));  // [3][n] when LDS_XYZ
+  const int t = threadIdx.x;
+  const float *c = coords + (size_t)blockIdx.x * 3 * n;
+  int *out = indices + (size_t)blockIdx.x * m;
+
+  float x[PPT], y[PPT], z[PPT], dist[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = t + i * THREADS;
+    const bool ok = k < n;
+    x[i] = ok ? c[k] : 0.0f;
+    y[i] = ok ? c[k + n] : 0.0f;
+    z[i] = ok ? c[k + 2 * n] : 0.0f;
+    dist[i] = ok ? 1e38f : -1.0f;  // PN2/pvcnn_sampling.cpp:56 ; -1 = "no point here", never selected
+    if (LDS_XYZ && ok) {
+      sxyz[k] = x[i];
+      sxyz[n + k] = y[i];
+      sxyz[2 * n + k] = z[i];
+    }
+  }
+  if (t < 32) slots[t] = 0;
+  if (t == 0) out[0] = 0;
+  __syncthreads();
+
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    float x1, y1, z1;
+    if (LDS_XYZ) {
+      x1 = sxyz[old];
+      y1 = sxyz[n + old];
+      z1 = sxyz[2 * n + old];
+    } else {
+      x1 = c[old];
+      y1 = c[old + n];
+      z1 = c[old + 2 * n];
+    }
+    float best = -1.0f;
+    int bi = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sqdist3(x[i] - x1, y[i] - y1, z[i] - z1);
+      const float d2 = fminf(d, dist[i]);
+      dist[i] = d2;
+      if (d2 > best) {
+        best = d2;
+        bi = i;
+      }
+    }
+    u64 key = wave_max_u64(fps_key(best, t + bi * THREADS));
+    if (NW > 1) {
+      u64 *sl = slots + (j & 1) * 16;
+      if ((t & 63) == 0) sl[t >> 6] = key;
+      __syncthreads();
+      u64 v = sl[t & 15];  // entries >= NW stay 0 (identity)
+      v = row_max_u64(v);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 15);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
+      key = ((u64)hi << 32) | lo;
+    }
+    old = fps_key_index(key);
+    if (t == 0) out[j] = old;
+  }
+}
+
+// n > 16384: running distances in global scratch, coordinates streamed from L2 each round.
+__global__ __launch_bounds__(1024) void fps_big_kernel(int n, int m, const float *__restrict__ coords,
+                                                       float *__restrict__ dist_ws, int *__restrict__ indices) {
+  __shared__ u64 slots[2][16];
+  const int t = threadIdx.x;
+  const float *c = coords + (size_t)blockIdx.x * 3 * n;
+  float *dist = dist_ws + (size_t)blockIdx.x * n;
+  int *out = indices + (size_t)blockIdx.x * m;
+  for (int k = t; k < n; k += 1024) dist[k] = 1e38f;
+  if (t < 32) slots[t >> 4][t & 15] = 0;
+  if (t == 0) out[0] = 0;
+  __syncthreads();
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = c[old], y1 = c[old + n], z1 = c[old + 2 * n];
+    float best = -1.0f;
+    int bk = 0;
+    for (int k = t; k < n; k += 1024) {
+      const float d = sqdist3(c[k] - x1, c[k + n] - y1, c[k + 2 * n] - z1);
+      const float d2 = fminf(d, dist[k]);
+      dist[k] = d2;
+      if (d2 > best) {
+        best = d2;
+        bk = k;
+      }
+    }
+    u64 key = wave_max_u64(fps_key(best, bk));
+    if ((t & 63) == 0) slots[j & 1][t >> 6] = key;
+    __syncthreads();
+    u64 v = row_max_u64(slots[j & 1][t & 15]);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 15);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
+    old = fps_key_index(((u64)hi << 32) | lo);
+    if (t == 0) out[j] = old;
+  }
+}
+
+template <int THREADS, int PPT>
+static void fps_launch(int b, int n, int m, const float *coords, int *idx, hipStream_t s) {
+  const size_t base = 2 * 16 * sizeof(u64);
+  const size_t xyz = (size_t)3 * n * sizeof(float);
+  if (base + xyz <= 144 * 1024) {
+    hipLaunchKernelGGL((fps_kernel<THREADS, PPT, true>), dim3(b), dim3(THREADS), base + xyz, s, n, m, coords, idx);
+  } else {
+    hipLaunchKernelGGL((fps_kernel<THREADS, PPT, false>), dim3(b), dim3(THREADS), base, s, n, m, coords, idx);
+  }
+}
+
+extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float *dist_ws, int *idx,
+                                            void *stream) {
+  if (b <= 0 || n <= 0 || m < 0) return P2PB_EINVAL;
+  if (m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {  // allow > 64 KiB of dynamic LDS for the coordinate cache
+    const int big = 160 * 1024;
+    (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    attr_set = true;
+  }
+  if (n <= 64) fps_launch<64, 1>(b, n, m, coords, idx, s);
+  else if (n <= 128) fps_launch<64, 2>(b, n, m, coords, idx, s);
+  else if (n <= 256) fps_launch<64, 4>(b, n, m, coords, idx, s);
+  else if (n <= 512) fps_launch<256, 2>(b, n, m, coords, idx, s);
+  else if (n <= 1024) fps_launch<256, 4>(b, n, m, coords, idx, s);
+  else if (n <= 2048) fps_launch<256, 8>(b, n, m, coords, idx, s);
+  else if (n <= 4096) fps_launch<1024, 4>(b, n, m, coords, idx, s);
+  else if (n <= 8192) fps_launch<1024, 8>(b, n, m, coords, idx, s);
+  else if (n <= 16384) fps_launch<1024, 16>(b, n, m, coords, idx, s);
+  else {
+    if (!dist_ws) return P2PB_EINVAL;
+    hipLaunchKernelGGL(fps_big_kernel, dim3(b), dim3(1024), 0, s, n, m, coords, dist_ws, idx);
+  }
+  return p2pb_launch_status();
+}

@@ -1,0 +1,338 @@
+// voxelize.hip -- point <-> voxel kernels for gfx950.
+//   p2pb_voxel_coords                 (models/pvcnn.py:215-228)
+//   p2pb_avg_voxelize_forward/backward (PN2/vox_gpu.cu:18,50,92)
+//   p2pb_trilinear_devoxelize_*        (PN2/trilinear_devox_gpu.cu:21,123)
+// All of these are HBM-bound: the dominant traffic is the dense [C, r^3] grid (written once by
+// voxelize including its zeros, read once by devoxelize); the N x (3+C) point tensor is read with
+// lane-consecutive (coalesced) accesses, the grid is written lane-consecutive over the voxel index.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// voxel_coords: one workgroup per cloud. Summation order is part of the contract (see oracle):
+// 256 lane-strided double partials, then a fixed binary tree.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_coords_kernel(int n, int r, int normalize, float eps,
+                                                           const float *__restrict__ coords,
+                                                           float *__restrict__ norm, int *__restrict__ vox) {
+  __shared__ double part[3][256];
+  __shared__ float smax[256];
+  const int t = threadIdx.x;
+  const float *c = coords + (size_t)blockIdx.x * 3 * n;
+  float *o = norm + (size_t)blockIdx.x * 3 * n;
+  int *v = vox + (size_t)blockIdx.x * 3 * n;
+  for (int a = 0; a < 3; ++a) {
+    double s = 0.0;
+    for (int k = t; k < n; k += 256) s += (double)c[a * n + k];
+    part[a][t] = s;
+  }
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) {
+      part[0][t] += part[0][t + s];
+      part[1][t] += part[1][t + s];
+      part[2][t] += part[2][t + s];
+    }
+    __syncthreads();
+  }
+  const float m0 = (float)(part[0][0] / (double)n);
+  const float m1 = (float)(part[1][0] / (double)n);
+  const float m2 = (float)(part[2][0] / (double)n);
+  float mx = 0.0f;
+  for (int k = t; k < n; k += 256) {
+    float s = sqdist3(c[k] - m0, c[n + k] - m1, c[2 * n + k] - m2);
+    mx = s > mx ? s : mx;
+  }
+  smax[t] = mx;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) smax[t] = smax[t + s] > smax[t] ? smax[t + s] : smax[t];
+    __syncthreads();
+  }
+  const float denom = __fsqrt_rn(smax[0]) * 2.0f + eps;
+  const float mean[3] = {m0, m1, m2};
+  const float rf = (float)r, hi = (float)(r - 1);
+  for (int a = 0; a < 3; ++a)
+    for (int k = t; k < n; k += 256) {
+      float x = c[a * n + k] - mean[a];
+      if (normalize)
+        x = __fdiv_rn(x, denom) + 0.5f;
+      else
+        x = __fdiv_rn(x + 1.0f, 2.0f);
+      x = x * rf;
+      x = fminf(fmaxf(x, 0.0f), hi);
+      o[a * n + k] = x;
+      v[a * n + k] = (int)rintf(x);
+    }
+}
+
+extern "C" int p2pb_voxel_coords(int b, int n, int r, int normalize, float eps, const float *coords, float *norm,
+                                 int *vox, void *stream) {
+  if (b <= 0 || n <= 0 || r <= 0) return P2PB_EINVAL;
+  hipLaunchKernelGGL(voxel_coords_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, r, normalize, eps, coords,
+                     norm, vox);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// avg_voxelize forward, deterministic:
+//   1 count : ind[i] = x*r2 + y*r + z ; cnt[ind]++           (int atomics: order independent)
+//   2 scan  : cur[v] = exclusive prefix of cnt over the cloud  (one workgroup per cloud)
+//   3 fill  : list[cur[v]++] = i                              (order inside a voxel arbitrary ...)
+//   4 sort  : ... so every voxel's few point ids are sorted ascending
+//   5 gather: out[c,v] = sum_{i in voxel v, ascending} feat[c,i] * (1/cnt)  and zeros elsewhere
+// Step 5 writes the whole [C,r^3] grid with lane-consecutive stores (the dominant HBM traffic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vox_count_kernel(int n, int r, const int *__restrict__ coords,
+                                                        int *__restrict__ ind, int *__restrict__ cnt) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int *c = coords + (size_t)b * 3 * n;
+  const int v = c[i] * r * r + c[i + n] * r + c[i + 2 * n];
+  ind[(size_t)b * n + i] = v;
+  atomicAdd(cnt + (size_t)b * r * r * r + v, 1);
+}
+
+__global__ __launch_bounds__(1024) void vox_scan_kernel(int r3, const int *__restrict__ cnt, int *__restrict__ cur) {
+  __shared__ int wsum[16];
+  const int t = threadIdx.x;
+  const int *c = cnt + (size_t)blockIdx.x * r3;
+  int *o = cur + (size_t)blockIdx.x * r3;
+  const int per = (r3 + 1023) / 1024;
+  const int beg = t * per, end = min(beg + per, r3);
+  int s = 0;
+  for (int k = beg; k < end; ++k) s += c[k];
+  // inclusive wave scan of s
+  int x = s;
+  for (int d = 1; d < 64; d <<= 1) {
+    int y = __shfl_up(x, d);
+    if ((t & 63) >= d) x += y;
+  }
+  if ((t & 63) == 63) wsum[t >> 6] = x;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
+  int run = base + x - s;  // exclusive prefix of this thread's chunk
+  for (int k = beg; k < end; ++k) {
+    o[k] = run;
+    run += c[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void vox_fill_kernel(int n, int r3, const int *__restrict__ ind,
+                                                       int *__restrict__ cur, int *__restrict__ list) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int v = ind[(size_t)b * n + i];
+  const int pos = atomicAdd(cur + (size_t)b * r3 + v, 1);
+  list[(size_t)b * n + pos] = i;
+}
+
+__global__ __launch_bounds__(256) void vox_sort_kernel(int n, int r3, const int *__restrict__ cnt,
+                                                       const int *__restrict__ cur, int *__restrict__ list) {
+  const int b = blockIdx.y;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= r3) return;
+  const int c = cnt[(size_t)b * r3 + v];
+  if (c < 2) return;
+  int *seg = list + (size_t)b * n + (cur[(size_t)b * r3 + v] - c);  // cur now points at the segment end
+  for (int a = 1; a < c; ++a) {
+    int key = seg[a], q = a - 1;
+    while (q >= 0 && seg[q] > key) {
+      seg[q + 1] = seg[q];
+      --q;
+    }
+    seg[q + 1] = key;
+  }
+}
+
+template <int CC>
+__global__ __launch_bounds__(256) void vox_gather_kernel(int c, int n, int r3, const int *__restrict__ cnt,
+                                                         const int *__restrict__ cur, const int *__restrict__ list,
+                                                         const float *__restrict__ feat, float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= r3) return;
+  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
+  const float *f = feat + (size_t)b * c * n;
+  float *o = out + (size_t)b * c * r3 + v;
+  const int cn = cnt[(size_t)b * r3 + v];
+  if (cn == 0) {
+    for (int j = c0; j < c1; ++j) o[(size_t)j * r3] = 0.0f;
+    return;
+  }
+  const int *seg = list + (size_t)b * n + (cur[(size_t)b * r3 + v] - cn);
+  const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
+  int ids[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ids[q] = q < cn ? seg[q] : 0;
+  for (int j = c0; j < c1; ++j) {
+    const float *fj = f + (size_t)j * n;
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q < cn) acc += fj[ids[q]] * div;
+    for (int q = 8; q < cn; ++q) acc += fj[seg[q]] * div;
+    o[(size_t)j * r3] = acc;
+  }
+}
+
+extern "C" size_t p2pb_avg_voxelize_ws_bytes(int b, int n, int r) {
+  return sizeof(int) * ((size_t)b * r * r * r + (size_t)b * n);
+}
+
+extern "C" int p2pb_avg_voxelize_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind,
+                                         int *cnt, float *out, void *ws, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || !ws) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int r3 = r * r * r;
+  int *cur = (int *)ws;
+  int *list = cur + (size_t)b * r3;
+  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)b * r3, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(vox_count_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r, coords, ind, cnt);
+  hipLaunchKernelGGL(vox_scan_kernel, dim3(b), dim3(1024), 0, s, r3, cnt, cur);
+  hipLaunchKernelGGL(vox_fill_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r3, ind, cur, list);
+  hipLaunchKernelGGL(vox_sort_kernel, dim3(cdiv(r3, 256), b), dim3(256), 0, s, n, r3, cnt, cur, list);
+  constexpr int CC = 16;
+  hipLaunchKernelGGL(vox_gather_kernel<CC>, dim3(cdiv(r3, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n, r3, cnt, cur,
+                     list, feat, out);
+  return p2pb_launch_status();
+}
+
+template <int CC>
+__global__ __launch_bounds__(256) void vox_grad_kernel(int c, int n, int r3, const int *__restrict__ ind,
+                                                       const int *__restrict__ cnt, const float *__restrict__ gy,
+                                                       float *__restrict__ gx) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
+  const int pos = ind[(size_t)b * n + i];
+  const int cn = cnt[(size_t)b * r3 + pos];
+  const float div = cn > 0 ? (float)(1.0 / (double)(float)cn) : 0.0f;
+  const float *g = gy + (size_t)b * c * r3 + pos;
+  float *o = gx + (size_t)b * c * n + i;
+  for (int j = c0; j < c1; ++j) o[(size_t)j * n] = cn > 0 ? g[(size_t)j * r3] * div : 0.0f;
+}
+
+extern "C" int p2pb_avg_voxelize_backward(int b, int c, int n, int r3, const int *ind, const int *cnt,
+                                          const float *grad_y, float *grad_x, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r3 <= 0) return P2PB_EINVAL;
+  constexpr int CC = 16;
+  hipLaunchKernelGGL(vox_grad_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c, n,
+                     r3, ind, cnt, grad_y, grad_x);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// trilinear devoxelize
+// ------------------------------------------------------------------------------------------------
+struct Corners {
+  int idx[8];
+  float w[8];
+};
+
+__device__ __forceinline__ Corners devox_corners(float x, float y, float z, int r) {
+  Corners k;
+  const int r2 = r * r;
+  const float xl = floorf(x), yl = floorf(y), zl = floorf(z);
+  const float xd1 = x - xl, yd1 = y - yl, zd1 = z - zl;
+  const float xd0 = 1.0f - xd1, yd0 = 1.0f - yd1, zd0 = 1.0f - zd1;
+  k.w[0] = xd0 * yd0 * zd0;
+  k.w[1] = xd0 * yd0 * zd1;
+  k.w[2] = xd0 * yd1 * zd0;
+  k.w[3] = xd0 * yd1 * zd1;
+  k.w[4] = xd1 * yd0 * zd0;
+  k.w[5] = xd1 * yd0 * zd1;
+  k.w[6] = xd1 * yd1 * zd0;
+  k.w[7] = xd1 * yd1 * zd1;
+  const int xlo = (int)xl, ylo = (int)yl, zlo = (int)zl;
+  const int xhi = (xd1 > 0) ? -1 : 0, yhi = (yd1 > 0) ? -1 : 0, zhi = (zd1 > 0) ? 1 : 0;
+  k.idx[0] = xlo * r2 + ylo * r + zlo;
+  k.idx[1] = k.idx[0] + zhi;
+  k.idx[2] = k.idx[0] + (yhi & r);
+  k.idx[3] = k.idx[2] + zhi;
+  k.idx[4] = k.idx[0] + (xhi & r2);
+  k.idx[5] = k.idx[4] + zhi;
+  k.idx[6] = k.idx[4] + (yhi & r);
+  k.idx[7] = k.idx[6] + zhi;
+  return k;
+}
+
+template <int CC>
+__global__ __launch_bounds__(256) void devox_kernel(int c, int n, int r, int training,
+                                                    const float *__restrict__ coords, const float *__restrict__ feat,
+                                                    int *__restrict__ inds, float *__restrict__ wgts,
+                                                    float *__restrict__ outs) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int r3 = r * r * r;
+  const float *co = coords + (size_t)b * 3 * n;
+  const Corners k = devox_corners(co[i], co[i + n], co[i + 2 * n], r);
+  if (training && blockIdx.y == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      wgts[(size_t)b * 8 * n + (size_t)q * n + i] = k.w[q];
+      inds[(size_t)b * 8 * n + (size_t)q * n + i] = k.idx[q];
+    }
+  }
+  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
+  const float *f = feat + (size_t)b * c * r3;
+  float *o = outs + (size_t)b * c * n + i;
+  for (int j = c0; j < c1; ++j) {
+    const float *fj = f + (size_t)j * r3;
+    float acc = k.w[0] * fj[k.idx[0]];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) acc = __fmaf_rn(k.w[q], fj[k.idx[q]], acc);
+    o[(size_t)j * n] = acc;
+  }
+}
+
+extern "C" int p2pb_trilinear_devoxelize_forward(int b, int c, int n, int r, int is_training, const float *coords,
+                                                 const float *feat, int *inds, float *wgts, float *outs,
+                                                 void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r <= 0) return P2PB_EINVAL;
+  if (is_training && (!inds || !wgts)) return P2PB_EINVAL;
+  constexpr int CC = 16;
+  hipLaunchKernelGGL(devox_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c, n, r,
+                     is_training, coords, feat, inds, wgts, outs);
+  return p2pb_launch_status();
+}
+
+template <int CC>
+__global__ __launch_bounds__(256) void devox_grad_kernel(int c, int n, int r3, const int *__restrict__ inds,
+                                                         const float *__restrict__ wgts,
+                                                         const float *__restrict__ gy, float *__restrict__ gx) {
+  const int b = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int idx[8];
+  float w[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    idx[q] = inds[(size_t)b * 8 * n + (size_t)q * n + i];
+    w[q] = wgts[(size_t)b * 8 * n + (size_t)q * n + i];
+  }
+  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
+  for (int j = c0; j < c1; ++j) {
+    const float g = gy[((size_t)b * c + j) * n + i];
+    float *o = gx + ((size_t)b * c + j) * r3;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) atomicAdd(o + idx[q], w[q] * g);
+  }
+}
+
+extern "C" int p2pb_trilinear_devoxelize_backward(int b, int c, int n, int r3, const int *inds, const float *wgts,
+                                                  const float *grad_y, float *grad_x, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r3 <= 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)b * c * r3, s);
+  if (e != hipSuccess) return (int)e;
+  constexpr int CC = 16;
+  hipLaunchKernelGGL(devox_grad_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n, r3, inds, wgts,
+                     grad_y, grad_x);
+  return p2pb_launch_status();
+}
