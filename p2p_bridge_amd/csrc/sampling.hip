@@ -60,6 +60,18 @@ __device__ __forceinline__ int fps_key_index(u64 key) {
   return (int)(((sec & 0xFFFFFu) << 9) | (sec >> 20));
 }
 
+// Point index owned by (thread t, slot i). A thread must visit its points in ascending
+// (k mod 512, k) so that "first strict maximum" inside the thread agrees with the global tie order.
+// With >= 512 threads (or <= 512 points in total) the natural strided order already does; with 256
+// threads and more than 512 points a thread owns 2 residue classes and walks them class-major.
+template <int THREADS, int PPT>
+__device__ __forceinline__ int fps_point(int t, int i) {
+  if (THREADS >= 512 || THREADS * PPT <= 512) return t + i * THREADS;
+  constexpr int CPT = THREADS < 512 ? 512 / THREADS : 1;  // residue classes per thread
+  constexpr int PPC = PPT >= CPT ? PPT / CPT : 1;         // points per class
+  return t + (i / PPC) * THREADS + 512 * (i % PPC);
+}
+
 template <int THREADS, int PPT, bool LDS_XYZ>
 __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float *__restrict__ coords,
                                                       int *__restrict__ indices) {
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float 
   float x[PPT], y[PPT], z[PPT], dist[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int k = t + i * THREADS;
+    const int k = fps_point<THREADS, PPT>(t, i);
     const bool ok = k < n;
     x[i] = ok ? c[k] : 0.0f;
     y[i] = ok ? c[k + n] : 0.0f;
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float 
         bi = i;
       }
     }
-    u64 key = wave_max_u64(fps_key(best, t + bi * THREADS));
+    u64 key = wave_max_u64(fps_key(best, fps_point<THREADS, PPT>(t, bi)));
     if (NW > 1) {
       u64 *sl = slots + (j & 1) * 16;
       if ((t & 63) == 0) sl[t >> 6] = key;
