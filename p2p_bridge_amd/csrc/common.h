@@ -24,3 +24,6 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ int mbcnt(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
+
+// zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
+int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);

@@ -128,8 +128,8 @@ extern "C" int p2pb_approxmatch_forward(int b, int n, int m, const float *xyz1, 
                                         float *temp, void *stream) {
   if (b <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(match, 0, sizeof(float) * (size_t)b * n * m, s);
-  if (e != hipSuccess) return (int)e;
+  int e = p2pb_zero_async(match, sizeof(float) * (size_t)b * n * m, s);
+  if (e != 0) return e;
   const float multiL = n >= m ? 1.0f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.0f;
   // temp holds the same four work arrays as the reference (emd_kernel.cu:34), laid out array-major:
   //   temp = remainL[b][n] | remainR[b][m] | ratioL[b][n] | ratioR[b][m]      (2(n+m) floats per cloud)
@@ -187,8 +187,8 @@ extern "C" int p2pb_matchcost_forward(int b, int n, int m, const float *xyz1, co
                                       float *cost, void *stream) {
   if (b <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(cost, 0, sizeof(float) * b, s);
-  if (e != hipSuccess) return (int)e;
+  int e = p2pb_zero_async(cost, sizeof(float) * b, s);
+  if (e != 0) return e;
   hipLaunchKernelGGL(matchcost_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, xyz1, xyz2, match, cost);
   return p2pb_launch_status();
 }

@@ -104,8 +104,8 @@ extern "C" int p2pb_grouping_backward(int b, int c, int n, int m, int u, const f
                                       float *grad_x, void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)b * c * n, s);
-  if (e != hipSuccess) return (int)e;
+  int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * n, s);
+  if (e != 0) return e;
   constexpr int CC = 8;
   hipLaunchKernelGGL(grouping_grad_kernel<CC>, dim3(cdiv((long)m * u, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n,
                      m * u, grad_y, idx, grad_x);
@@ -143,8 +143,8 @@ extern "C" int p2pb_gather_features_backward(int b, int c, int n, int m, const f
                                              float *grad_x, void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)b * c * n, s);
-  if (e != hipSuccess) return (int)e;
+  int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * n, s);
+  if (e != 0) return e;
   hipLaunchKernelGGL(gather_grad_kernel, dim3(cdiv(m, 256), c, b), dim3(256), 0, s, c, n, m, grad_y, idx, grad_x);
   return p2pb_launch_status();
 }
@@ -270,8 +270,8 @@ extern "C" int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, co
                                                   const float *w, float *grad_x, void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)b * c * m, s);
-  if (e != hipSuccess) return (int)e;
+  int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * m, s);
+  if (e != 0) return e;
   constexpr int CC = 16;
   hipLaunchKernelGGL(three_interp_grad_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n, m,
                      grad_y, idx, w, grad_x);

@@ -189,8 +189,8 @@ extern "C" int p2pb_avg_voxelize_forward(int b, int c, int n, int r, const int *
   const int r3 = r * r * r;
   int *cur = (int *)ws;
   int *list = cur + (size_t)b * r3;
-  hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)b * r3, s);
-  if (e != hipSuccess) return (int)e;
+  int e = p2pb_zero_async(cnt, sizeof(int) * (size_t)b * r3, s);
+  if (e != 0) return e;
   hipLaunchKernelGGL(vox_count_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r, coords, ind, cnt);
   hipLaunchKernelGGL(vox_scan_kernel, dim3(b), dim3(1024), 0, s, r3, cnt, cur);
   hipLaunchKernelGGL(vox_fill_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r3, ind, cur, list);
@@ -329,8 +329,8 @@ extern "C" int p2pb_trilinear_devoxelize_backward(int b, int c, int n, int r3, c
                                                   const float *grad_y, float *grad_x, void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || r3 <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_x, 0, sizeof(float) * (size_t)b * c * r3, s);
-  if (e != hipSuccess) return (int)e;
+  int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * r3, s);
+  if (e != 0) return e;
   constexpr int CC = 16;
   hipLaunchKernelGGL(devox_grad_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n, r3, inds, wgts,
                      grad_y, grad_x);

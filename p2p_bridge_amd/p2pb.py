@@ -271,12 +271,18 @@ class P2PB(nn.Module):
             s_x = xt.clone()
             s_c = torch.zeros(4, device=xt.device)
             s_cond = None if x_cond is None else x_cond.clone()
+            # lazy one-time initialisation (MIOpen solver selection, BLAS handles, kernel attributes) must
+            # not happen inside the capture: one eager step on the current stream, then two on a side
+            # stream (the documented torch.cuda.graph warm-up), then capture.
+            self._one_step(net, s_x, s_c, None, s_cond, clip)
+            torch.cuda.synchronize()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):  # warm up allocator / lazy inits outside capture
+            with torch.cuda.stream(side):
                 for _ in range(2):
                     self._one_step(net, s_x, s_c, None, s_cond, clip)
             torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 o_x, o_0 = self._one_step(net, s_x, s_c, None, s_cond, clip)
