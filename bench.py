@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- denoised points/sec of the P2P-Bridge sampler on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: `P2PB.sample` of B=32 synthetic PU-Net-shaped
+patches of 8192 points through T=30 bridge steps of the PVDS_PUNet network (BASELINE config 2,
+data.npoints=8192, seeded random weights -- no checkpoints/datasets offline). Inputs are resident in HBM
+before the timed region. With --gpus N (launched by torch.distributed.run) every rank denoises its own
+B patches: patch-level sharding, no data-path collective, weak scaling; time = max over ranks.
+
+Prints ONE JSON line (rank 0) with the driver's fields + "roofline" (dominant kernel, live HIP-event
+timing) + "cpu_baseline" (the CPU oracle timed on this host on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # CPU-baseline leg: two OpenMP runtimes (torch, oracle) must not spin
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PVDS = dict(
+    data=dict(npoints=8192),
+    diffusion=dict(timesteps=1000, sampling_timesteps=30, objective="pred_noise", sampling_strategy="DDPM",
+                   loss_type="mse", beta_start=1e-4, beta_end=0.02, t0=1e-4, T=1.0, ot_ode=True),
+    model=dict(type="PVD", ema=False, in_dim=3, extra_feature_channels=0, out_dim=3, time_embed_dim=64, dropout=0.15,
+               PVD=dict(use_global_embedding=True, global_embedding_dim=1024, feat_embed_dim=32,
+                        attention_type="linear", attention_heads=4, attentions=[0, 0, 0, 1],
+                        channels=[32, 64, 128, 256, 512], voxel_resolutions=[32, 16, 8, 8], n_sa_blocks=[1, 2, 1, 1],
+                        n_fp_blocks=[1, 2, 1, 1], radius=[0.1, 0.2, 0.4, 0.8], out_mlp=128)))
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample per network evaluation (PVDS)
+
+
+def conv_roofline(model, B, reps=10):
+    """Dominant kernel = the 3x3x3 voxel convolution. Time the largest one (fp_layers.3.1 conv: C 64->64,
+    r=32, 29.0 GFLOP... per launch at this B) with HIP events on the stream it is launched on."""
+    pv = model.model.fp_layers[3][1]
+    conv = pv.voxel_layers[4]
+    C, r = conv.in_channels, pv.resolution
+    x = torch.randn(B, C, r, r, r, device="cuda")
+    flops = 2.0 * B * r ** 3 * 27 * conv.in_channels * conv.out_channels
+    with torch.no_grad():
+        for _ in range(3):
+            conv(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            conv(x)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": f"conv3d 3x3x3 C{conv.in_channels}->{conv.out_channels} r{r} B{B} (fp_layers.3.1)",
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def cpu_baseline(sd, n_points, T, steps_sampled=2):
+    """The CPU oracle (C ops + torch CPU dense layers, all host threads) on ONE patch, `steps_sampled` of
+    the T bridge steps (every step costs the same: one network evaluation + an elementwise update)."""
+    from oracle import net_ref
+
+    x, _ = net_ref.synthetic_patches(1, n_points, seed=0)
+    net = net_ref.RefNet(PVDS, sd, vox_mode="tree")
+    cores = min(os.cpu_count() or 1, 32)  # beyond ~32 threads these small per-patch ops only contend
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    from oracle import cpu_ops
+
+    cpu_ops.set_threads(cores)
+    net_ref.sample(net, PVDS, x, steps=1, log_count=1)  # warm-up
+    t0 = time.perf_counter()
+    net_ref.sample(net, PVDS, x, steps=steps_sampled, log_count=1)
+    dt = (time.perf_counter() - t0) / steps_sampled
+    return {"value": round(n_points / (dt * T), 2), "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"1 patch x {n_points} pts, {steps_sampled} of T={T} bridge steps timed after 1 warm-up step "
+                      f"({dt:.2f} s/step), extrapolated to T={T}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--T", type=int, default=30)
+    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from oracle import net_ref  # synthetic input generator only (bench leg of the oracle rules)
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
+
+    import copy
+
+    cfg = copy.deepcopy(PVDS)
+    cfg["data"]["npoints"] = args.points
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in PVCNN2Unet(cfg).state_dict().items()}
+    model = product.build_model(cfg, sd, device=f"cuda:{local_rank}")
+    x_start, _ = net_ref.synthetic_patches(args.batch, args.points, seed=rank)
+    x_start = x_start.cuda()
+
+    def one():
+        return model.sample(x_start=x_start, steps=args.T, log_count=1, verbose=False, graph=bool(args.graph))
+
+    for _ in range(args.warmup):
+        out = one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    assert torch.isfinite(out["x_pred"]).all()
+
+    pts = world * args.batch * args.points * args.steps
+    res = {
+        "metric": "denoised points/sec (8192-pt patches, T=30)", "value": round(pts / dt, 1), "unit": "points/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"PVDS_PUNet xyz-only, {args.points}-pt patches, T={args.T} bridge steps, batch "
+                               f"{args.batch} per GPU (BASELINE configs[1])", "patches_per_gpu": args.batch,
+                   "points_per_patch": args.points, "bridge_steps": args.T, "parallelism": f"patch-shard x{world}",
+                   "hipgraph": bool(args.graph), "weights": "seeded random init (26.44 M params)"},
+    }
+    if rank == 0:
+        res["roofline"] = conv_roofline(model, args.batch)
+        evals = args.T
+        res["roofline"]["sampler_dense_tflops"] = round(
+            61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, args.points, args.T)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,6 +132,56 @@ int p2pb_auction_forward(int b, int n, int m, const float *xyz1, const float *xy
 int p2pb_auction_backward(int b, int n, const float *xyz1, const float *xyz2, float *gradxyz,
                           const float *graddist, const int *idx, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused voxel-branch kernels. These have no counterpart in the reference's extension modules: they
+ * replace the torch.nn / cuDNN calls between avg_voxelize and trilinear_devoxelize inside PVConv
+ * (models/pvcnn.py:265-286,318-324: Conv3d, AdaGN, Swish, Conv3d, AdaGN, SE3d) for inference.
+ * ------------------------------------------------------------------------------------------- */
+
+/* 3x3x3, stride 1, pad 1 convolution (nn.Conv3d of models/pvcnn.py:266-282) on the fp32 matrix cores.
+ * Weights are pre-packed once: w f32[cout,cin,3,3,3] -> wt_packed f32[p2pb_conv3d_k3_packed_floats()]. */
+size_t p2pb_conv3d_k3_packed_floats(int cout, int cin);
+int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, float *wt_packed, void *stream);
+/* out[b,cout,r,r,r] = conv(xf(in[b,cin,r,r,r])) + bias;  xf(x) = x when in_scale == NULL, else
+ * x*in_scale[b,ci] + in_shift[b,ci] followed by Swish when in_swish != 0 (the preceding AdaGN+Swish,
+ * folded). stats_part (optional, f32[p2pb_conv3d_k3_stats_floats()]) receives per-(b, slot, cout)
+ * {sum, sum of squares} of the output for the GroupNorm that follows. r in {4,8,16,32}. */
+size_t p2pb_conv3d_k3_stats_floats(int b, int cout, int r);
+int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+                           const float *bias, const float *in_scale, const float *in_shift, int in_swish,
+                           float *out, float *stats_part, void *stream);
+
+/* GroupNorm (+AdaGN style, models/modules.py:341-358) folded into a per-(sample, channel) affine:
+ * AdaGN(GN(x)) == x*scale + shift. part f32[b,nslots,c,2] partial {sum,sumsq}; gamma/beta f32[c] or
+ * NULL; style f32[b,2c] = (factor | bias) or NULL; chmean (optional) = per-channel mean of the
+ * transformed output (SE3d squeeze, models/modules.py:377-378). */
+int p2pb_gn_affine_params(int b, int c, int groups, int nslots, double count_per_channel, const float *part,
+                          const float *gamma, const float *beta, const float *style, float eps, float *scale,
+                          float *shift, float *chmean, void *stream);
+
+/* trilinear devoxelize of feat*aff_a[b,c] + aff_b[b,c] (AdaGN + SE gate folded), inference only */
+int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *coords, const float *feat,
+                                     const float *aff_a, const float *aff_b, float *outs, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused shared point MLPs (SharedMLP models/pvcnn.py:162-205 = k=1 Conv1d/Conv2d -> AdaGN|GroupNorm ->
+ * Swish, chained; set-abstraction neighbour max :414; Pnet2Stage max-pool :923,930). Inference only.
+ * ------------------------------------------------------------------------------------------- */
+size_t p2pb_pointwise_packed_floats(int cout, int cin);
+int p2pb_pointwise_pack_weights(int cout, int cin, const float *w /* [cout][cin] */, float *wp, void *stream);
+size_t p2pb_pointwise_stats_floats(int b, int cout, int npos);
+/* out[b,cout,npos] = bias[cout] (+ bias_b[b,cout]) + W * xf(in[b,cin,npos]); xf / stats_part as in
+ * p2pb_conv3d_k3_forward (stats_part f32[b, ceil(npos/256)*4, cout, 2]). bias, bias_b may be NULL. */
+int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const float *wp,
+                                const float *bias, const float *bias_b, const float *in_scale,
+                                const float *in_shift, int in_swish, float *out, float *stats_part, void *stream);
+/* y[b,c,p] = act(x*scale[b,c] + shift[b,c]) (+ residual[b,c,p]); act = Swish when swish != 0 */
+int p2pb_affine_act(int b, int c, int npos, const float *x, const float *scale, const float *shift, int swish,
+                    const float *residual, float *y, void *stream);
+/* y[b,c,m] = max_{k<u} act(x[b,c,m,k]*scale + shift), u a power of two <= 64; u == 0: y[b,c] = max over m */
+int p2pb_affine_act_max(int b, int c, int m, int u, const float *x, const float *scale, const float *shift,
+                        int swish, float *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

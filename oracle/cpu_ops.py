@@ -42,6 +42,10 @@ def lib():
     return _lib
 
 
+def set_threads(n: int):
+    lib().orc_set_threads(ctypes.c_int(int(n)))
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 

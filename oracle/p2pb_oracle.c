@@ -25,6 +25,15 @@
 
 #define ORC_API __attribute__((visibility("default")))
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+ORC_API void orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#endif
+}
+
 static inline float sqdist3(float dx, float dy, float dz) {
   /* nvcc contraction of dx*dx + dy*dy + dz*dz */
   return fmaf(dz, dz, fmaf(dy, dy, dx * dx));

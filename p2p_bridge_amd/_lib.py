@@ -19,7 +19,10 @@ SYMBOLS = [
     "p2pb_gather_features_forward", "p2pb_gather_features_backward", "p2pb_furthest_point_sampling",
     "p2pb_three_nn_interpolate_forward", "p2pb_three_nn_interpolate_backward", "p2pb_chamfer_forward",
     "p2pb_chamfer_backward", "p2pb_approxmatch_forward", "p2pb_matchcost_forward", "p2pb_matchcost_backward",
-    "p2pb_auction_forward", "p2pb_auction_backward",
+    "p2pb_auction_forward", "p2pb_auction_backward", "p2pb_conv3d_k3_packed_floats", "p2pb_conv3d_k3_pack_weights",
+    "p2pb_conv3d_k3_stats_floats", "p2pb_conv3d_k3_forward", "p2pb_gn_affine_params",
+    "p2pb_trilinear_devoxelize_affine", "p2pb_pointwise_packed_floats", "p2pb_pointwise_pack_weights",
+    "p2pb_pointwise_stats_floats", "p2pb_pointwise_conv_forward", "p2pb_affine_act", "p2pb_affine_act_max",
 ]
 
 _lib = None
@@ -39,6 +42,10 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.p2pb_target_arch.restype = ctypes.c_char_p
         _lib.p2pb_avg_voxelize_ws_bytes.restype = ctypes.c_size_t
+        _lib.p2pb_conv3d_k3_packed_floats.restype = ctypes.c_size_t
+        _lib.p2pb_conv3d_k3_stats_floats.restype = ctypes.c_size_t
+        _lib.p2pb_pointwise_packed_floats.restype = ctypes.c_size_t
+        _lib.p2pb_pointwise_stats_floats.restype = ctypes.c_size_t
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here = stale library
     return _lib

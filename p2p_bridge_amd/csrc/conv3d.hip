@@ -1,0 +1,329 @@
+// conv3d.hip -- 3x3x3 / stride 1 / pad 1 voxel convolution on the gfx950 matrix cores, exact fp32.
+//
+// This is the dominant kernel of the path: 72 % of the network's FLOPs (SURVEY.md 8a row a11,
+// models/pvcnn.py:265-284) and MFMA-bound. The reference calls cuDNN (TF32 on NVIDIA); CDNA4 has no
+// TF32 but has an exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TFLOP/s dense), which keeps the
+// build's 1e-4 parity budget: every product is rounded once and accumulated in fp32, like an fmaf chain.
+//
+// Formulation: implicit GEMM   out[co, p] = sum_{tap, ci} W[tap][ci][co] * in[ci, p + off(tap)]
+//   M = output channels (MFMA rows), N = voxels (MFMA columns), K = 27 * Cin.
+// N is the voxel index on purpose: an accumulator register then holds 32 consecutive w-voxels of one
+// output channel across lanes 0..31, so the NCDHW store is lane-consecutive (128-byte segments).
+//
+// Workgroup = 256 threads (4 waves) -> 256 voxels (8 N-tiles of 32) x NC output channels of one sample.
+// Per chunk of CK input channels the workgroup stages the zero-padded halo brick
+// [CK][TD+2][TH+2][TW+2] into LDS once (coalesced rows, optional per-channel affine + Swish applied on
+// the way in: that is how the preceding AdaGN + Swish is fused away), then every wave walks the 27
+// taps reading its B fragments from LDS at constant offsets; A fragments (packed weights
+// [27][CinPad][CoutPad]) come straight from L1/L2 -- all 4 waves of a workgroup and all workgroups of a
+// launch read the same few hundred KB.
+// Epilogue: + bias, store, and optionally per-(sample, channel) sum / sum-of-squares partials for the
+// GroupNorm that follows (one partial per workgroup, reduced deterministically by a second tiny kernel).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CONV_CK 8  // input channels per LDS stage
+
+template <int R>
+struct ConvGeom;  // brick = TD x TH x TW voxels = 8 N-tiles of 32; NT_* = N-tile shape (d,h,w)
+template <>
+struct ConvGeom<32> {
+  static constexpr int TD = 2, TH = 4, TW = 32, ND = 1, NH = 1;
+};
+template <>
+struct ConvGeom<16> {
+  static constexpr int TD = 2, TH = 8, TW = 16, ND = 1, NH = 2;
+};
+template <>
+struct ConvGeom<8> {
+  static constexpr int TD = 4, TH = 8, TW = 8, ND = 1, NH = 4;
+};
+template <>
+struct ConvGeom<4> {
+  static constexpr int TD = 4, TH = 4, TW = 4, ND = 2, NH = 4;
+};
+
+// MT = 32-row output-channel tiles per workgroup (NC = 32*MT), XF = apply affine(+swish) to the input
+template <int R, int MT, bool XF, bool STATS>
+__global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int cin_pad, int cout_pad,
+                                                        const float *__restrict__ in, const float *__restrict__ wt,
+                                                        const float *__restrict__ bias,
+                                                        const float *__restrict__ in_scale,
+                                                        const float *__restrict__ in_shift, int in_swish,
+                                                        float *__restrict__ out, float *__restrict__ stats_part) {
+  using G = ConvGeom<R>;
+  constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
+  constexpr int PLANE = HD * HH * HW;
+  constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;  // N-tiles in the brick (8, or 2 for R=4)
+  constexpr int BD = R / G::TD, BH = R / G::TH;          // bricks per sample along d, h
+  __shared__ float tile[CONV_CK * PLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int brick = blockIdx.x;  // over BD*BH
+  const int d0 = (brick / BH) * G::TD, h0 = (brick % BH) * G::TH;
+  const int co0 = blockIdx.y * (32 * MT);
+  const int b = blockIdx.z;
+
+  // this wave's two N-tiles: tile index t = 2*wave + s ; origin of an N-tile inside the brick
+  int nbase[2];
+  bool nact[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = 2 * wave + s;
+    nact[s] = t < NTILES;
+    // N-tiles enumerate (d-blocks of ND) x (h-blocks of NH)
+    constexpr int HB = G::TH / G::NH;
+    const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
+    // lane's voxel inside the N-tile
+    const int jw = l31 % G::TW, jr = l31 / G::TW;  // jr over NH*ND rows
+    const int jh = jr % G::NH, jd = jr / G::NH;
+    nbase[s] = ((td + jd) * HH + (th + jh)) * HW + jw;
+  }
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
+
+  const float *inb = in + (size_t)b * cin * R * R * R;
+  for (int ci0 = 0; ci0 < cin; ci0 += CONV_CK) {
+    __syncthreads();
+    // ---- stage the halo brick of CK channels (zero outside the grid / beyond cin)
+    for (int e = tid; e < CONV_CK * PLANE; e += 256) {
+      const int ci = e / PLANE, rem = e % PLANE;
+      const int dz = rem / (HH * HW), hy = (rem / HW) % HH, wx = rem % HW;
+      const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = wx - 1;
+      float v = 0.0f;
+      if (ci0 + ci < cin && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R) {
+        v = inb[((size_t)(ci0 + ci) * R + d) * R * R + h * R + w];
+        if (XF) {
+          v = v * in_scale[b * cin + ci0 + ci] + in_shift[b * cin + ci0 + ci];
+          if (in_swish) v = v * __fdiv_rn(1.0f, 1.0f + expf(-v));
+        }
+      }
+      tile[e] = v;
+    }
+    __syncthreads();
+    // ---- 27 taps x CK/2 k-pairs of MFMAs
+    const float *wchunk = wt + ((size_t)(ci0 + khalf)) * cout_pad + co0 + l31;
+#pragma unroll 1
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = (kd * 3 + kh) * 3 + kw;
+          const int toff = (kd * HH + kh) * HW + kw;
+          const float *wtap = wchunk + (size_t)tap * cin_pad * cout_pad;
+#pragma unroll
+          for (int kk = 0; kk < CONV_CK / 2; ++kk) {
+            float a[MT], bf[2];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = wtap[(size_t)(2 * kk) * cout_pad + m * 32];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bf[s] = tile[(2 * kk + khalf) * PLANE + nbase[s] + toff];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int s = 0; s < 2; ++s)
+                acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bf[s], acc[m][s], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias, store (lane-consecutive along w), optional GroupNorm partial statistics
+  float *outb = out + (size_t)b * cout * R * R * R;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const float bv = co < cout ? bias[co] : 0.0f;
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (!nact[s]) continue;
+        const int t = 2 * wave + s;
+        constexpr int HB = G::TH / G::NH;
+        const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
+        const int jw = l31 % G::TW, jr = l31 / G::TW;
+        const int d = d0 + td + jr / G::NH, h = h0 + th + jr % G::NH;
+        const float v = acc[m][s][r] + bv;
+        if (co < cout) outb[((size_t)co * R + d) * R * R + h * R + jw] = v;
+        if (STATS) {
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+      if (STATS) {
+        // sum over the 32 lanes of this half-wave (a channel row lives in exactly one half of the wave),
+        // one private slot per (sample, brick, wave, channel): plain stores, reduced later in fixed order
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off);
+          s2 += __shfl_xor(s2, off);
+        }
+        if (l31 == 0 && co < cout) {
+          float *p = stats_part + ((((size_t)b * gridDim.x + brick) * 4 + wave) * cout + co) * 2;
+          p[0] = s1;
+          p[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+// weights [cout][cin][3][3][3] -> packed [27][cin_pad][cout_pad] (zero padded)
+__global__ void conv3d_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, const float *__restrict__ w,
+                                   float *__restrict__ wt) {
+  const size_t total = (size_t)27 * cin_pad * cout_pad;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int co = (int)(e % cout_pad), ci = (int)((e / cout_pad) % cin_pad), tap = (int)(e / ((size_t)cout_pad * cin_pad));
+    wt[e] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 27 + tap] : 0.0f;
+  }
+}
+
+extern "C" int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, float *wt_packed, void *stream) {
+  if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
+  const int cin_pad = (cin + CONV_CK - 1) / CONV_CK * CONV_CK, cout_pad = (cout + 63) / 64 * 64;
+  const size_t total = (size_t)27 * cin_pad * cout_pad;
+  hipLaunchKernelGGL(conv3d_pack_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, cin_pad, cout_pad, w, wt_packed);
+  return p2pb_launch_status();
+}
+
+extern "C" size_t p2pb_conv3d_k3_packed_floats(int cout, int cin) {
+  const int cin_pad = (cin + CONV_CK - 1) / CONV_CK * CONV_CK, cout_pad = (cout + 63) / 64 * 64;
+  return (size_t)27 * cin_pad * cout_pad;
+}
+
+extern "C" size_t p2pb_conv3d_k3_stats_floats(int b, int cout, int r) {
+  int bricks = 1;
+  if (r == 32) bricks = (32 / 2) * (32 / 4);
+  else if (r == 16) bricks = (16 / 2) * (16 / 8);
+  else if (r == 8) bricks = (8 / 4) * (8 / 8);
+  return (size_t)b * bricks * 4 * cout * 2;
+}
+
+template <int R, int MT>
+static int conv_launch(int b, int cin, int cout, const float *in, const float *wt, const float *bias,
+                       const float *in_scale, const float *in_shift, int in_swish, float *out, float *stats_part,
+                       hipStream_t s) {
+  using G = ConvGeom<R>;
+  const int cin_pad = (cin + CONV_CK - 1) / CONV_CK * CONV_CK, cout_pad = (cout + 63) / 64 * 64;
+  dim3 grid((R / G::TD) * (R / G::TH), (cout + 32 * MT - 1) / (32 * MT), b);
+  const bool xf = in_scale != nullptr, st = stats_part != nullptr;
+#define LAUNCH(XF, ST)                                                                                         \
+  hipLaunchKernelGGL((conv3d_k3_kernel<R, MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, cin_pad, cout_pad, in, wt, \
+                     bias, in_scale, in_shift, in_swish, out, stats_part)
+  if (xf && st) LAUNCH(true, true);
+  else if (xf) LAUNCH(true, false);
+  else if (st) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  return p2pb_launch_status();
+}
+
+// out[b,cout,r,r,r] = conv3d(xf(in[b,cin,r,r,r]), W) + bias, where xf(x) = x (in_scale == NULL) or
+// swish?(x*in_scale[b,ci] + in_shift[b,ci]); stats_part (optional) receives per-(b, brick, cout)
+// {sum, sum of squares} of the output. r in {4, 8, 16, 32}.
+extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+                                      const float *bias, const float *in_scale, const float *in_shift, int in_swish,
+                                      float *out, float *stats_part, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const bool wide = cout > 32;
+#define GO(RR)                                                                                                      \
+  return wide ? conv_launch<RR, 2>(b, cin, cout, in, wt_packed, bias, in_scale, in_shift, in_swish, out, stats_part, s) \
+              : conv_launch<RR, 1>(b, cin, cout, in, wt_packed, bias, in_scale, in_shift, in_swish, out, stats_part, s)
+  switch (r) {
+    case 32: GO(32);
+    case 16: GO(16);
+    case 8: GO(8);
+    case 4: GO(4);
+    default: return P2PB_EINVAL;
+  }
+#undef GO
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(+AdaGN) folded to a per-(sample, channel) affine:  AdaGN(GN(x)) == x*scale + shift.
+//   GroupNorm (biased variance, eps) : y = (x - mean_g) * rstd_g * gamma_c + beta_c
+//   AdaGN (models/modules.py:341-358): z = y * factor_bc + bias_bc , (factor, bias) = chunk(style, 2)
+// Statistics come from the producing kernel's per-slot partial {sum, sum of squares}; they are
+// combined in double in a fixed order (deterministic). One thread per (sample, channel); the group
+// moments are recomputed by each of the group's channels (C/G <= 64 channels x nslots partials, tiny).
+// Also returns chmean[b,c] = mean over positions of the transformed output (SE3d's squeeze input).
+// ------------------------------------------------------------------------------------------------
+// one workgroup per (sample, group): the group's channels are reduced over the slots by the whole block
+// (fixed lane-strided partials + fixed LDS tree => deterministic), then thread k finalises channel k.
+__global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int nslots, double count_per_channel,
+                                                        const float *__restrict__ part, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, const float *__restrict__ style,
+                                                        float eps, float *__restrict__ scale, float *__restrict__ shift,
+                                                        float *__restrict__ chmean) {
+  __shared__ double red[2][256];
+  __shared__ double chs[256], chq[256];  // per-channel totals of this group (cg <= 256)
+  const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
+  const int cg = c / groups, g0 = g * cg;
+  for (int k = 0; k < cg; ++k) {
+    double s = 0.0, q = 0.0;
+    for (int sl = t; sl < nslots; sl += 256) {
+      const float *p = part + (((size_t)b * nslots + sl) * c + g0 + k) * 2;
+      s += (double)p[0];
+      q += (double)p[1];
+    }
+    red[0][t] = s;
+    red[1][t] = q;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if (t < w) {
+        red[0][t] += red[0][t + w];
+        red[1][t] += red[1][t + w];
+      }
+      __syncthreads();
+    }
+    if (t == 0) {
+      chs[k] = red[0][0];
+      chq[k] = red[1][0];
+    }
+    __syncthreads();
+  }
+  double gs = 0.0, gq = 0.0;
+  for (int k = 0; k < cg; ++k) {
+    gs += chs[k];
+    gq += chq[k];
+  }
+  if (t >= cg) return;
+  const int ch = g0 + t;
+  const double n = count_per_channel * cg;
+  const double mean = gs / n;
+  double var = gq / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double rstd = 1.0 / sqrt(var + (double)eps);
+  const double ga = gamma ? (double)gamma[ch] : 1.0, be = beta ? (double)beta[ch] : 0.0;
+  const double f = style ? (double)style[(size_t)b * 2 * c + ch] : 1.0;
+  const double bi = style ? (double)style[(size_t)b * 2 * c + c + ch] : 0.0;
+  const double sc = rstd * ga * f;
+  const double sh = (be - mean * rstd * ga) * f + bi;
+  scale[(size_t)b * c + ch] = (float)sc;
+  shift[(size_t)b * c + ch] = (float)sh;
+  if (chmean) chmean[(size_t)b * c + ch] = (float)(sc * (chs[t] / count_per_channel) + sh);
+}
+
+// part: f32[b, nslots, c, 2]; gamma/beta f32[c] or NULL; style f32[b, 2c] or NULL -> scale/shift/chmean f32[b,c]
+extern "C" int p2pb_gn_affine_params(int b, int c, int groups, int nslots, double count_per_channel,
+                                     const float *part, const float *gamma, const float *beta, const float *style,
+                                     float eps, float *scale, float *shift, float *chmean, void *stream) {
+  if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || nslots <= 0 || c / groups > 256) return P2PB_EINVAL;
+  hipLaunchKernelGGL(gn_affine_kernel, dim3(groups, b), dim3(256), 0, (hipStream_t)stream, c, groups, nslots,
+                     count_per_channel, part, gamma, beta, style, eps, scale, shift, chmean);
+  return p2pb_launch_status();
+}

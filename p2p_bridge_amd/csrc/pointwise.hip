@@ -1,0 +1,275 @@
+// pointwise.hip -- the shared point MLPs (1x1 convolutions + AdaGN/GroupNorm + Swish (+ neighbour max))
+// of models/pvcnn.py:162-205 (SharedMLP), :388-424 (set abstraction), :446-467 (feature propagation),
+// :905-932 (Pnet2Stage) as fused gfx950 kernels.
+//
+//   pw_conv      out[b,co,p] = bias[co] (+ bias_b[b,co]) + sum_ci W[co,ci] * xf(in[b,ci,p])
+//                xf = identity, or the PREVIOUS layer's norm+activation folded to a per-(b,ci) affine
+//                + Swish applied while the operand is staged into LDS; epilogue emits the {sum, sumsq}
+//                partials the NEXT GroupNorm needs. So a chain conv-norm-act-conv-norm-act touches
+//                each activation tensor exactly twice (one write, one read) instead of ~8 times.
+//   affine_act   y = swish(x*scale[b,c] + shift[b,c]) (+ residual)           (last layer of a chain)
+//   affine_act_max  y[b,c,m] = max_u swish(x[b,c,m,u]*scale + shift)         (set-abstraction pooling)
+//
+// The GEMM runs on the exact-fp32 MFMA (32x32x2): M = output channels, N = 32 consecutive positions
+// (so stores are lane-consecutive), K = input channels. Small-C layers are HBM-bound (8 FLOP/B at
+// C=32..64), the wide ones (Pnet2Stage 512->1024) MFMA-bound.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PW_CK 32  // input channels per LDS stage (4 sub-chunks of 8)
+
+__device__ __forceinline__ float swishf(float v) { return v * __fdiv_rn(1.0f, 1.0f + expf(-v)); }
+
+// packed weights: wp[cin_pad/8][2][cout_pad][4], element (chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf]
+template <int MT, bool XF, bool STATS>
+__global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cout_pad, int P,
+                                                      const float *__restrict__ in, const float *__restrict__ wp,
+                                                      const float *__restrict__ bias,
+                                                      const float *__restrict__ bias_b,
+                                                      const float *__restrict__ in_scale,
+                                                      const float *__restrict__ in_shift, int in_swish,
+                                                      float *__restrict__ out, float *__restrict__ stats_part) {
+  __shared__ float tile[PW_CK][256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int p0 = blockIdx.x * 256, co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
+  const bool pok = p0 + tid < P;
+  const float *inb = in + (size_t)b * cin * P + p0 + tid;
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
+
+  for (int ci0 = 0; ci0 < cin; ci0 += PW_CK) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PW_CK; ++k) {
+      const int ci = ci0 + k;
+      float v = 0.0f;
+      if (pok && ci < cin) {
+        v = inb[(size_t)ci * P];
+        if (XF) {
+          v = v * in_scale[b * cin + ci] + in_shift[b * cin + ci];
+          if (in_swish) v = swishf(v);
+        }
+      }
+      tile[k][tid] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < PW_CK / 8; ++sub) {
+      if (ci0 + sub * 8 >= cin) break;
+      const int chunk = (ci0 >> 3) + sub;
+      f32x4 a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        a[m] = *(const f32x4 *)(wp + (((size_t)chunk * 2 + khalf) * cout_pad + co0 + m * 32 + l31) * 4);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        float bf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bf[s] = tile[sub * 8 + 2 * kk + khalf][wave * 64 + s * 32 + l31];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][kk], bf[s], acc[m][s], 0, 0, 0);
+      }
+    }
+  }
+
+  float *outb = out + (size_t)b * cout * P;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      float bv = 0.0f;
+      if (co < cout) {
+        bv = bias ? bias[co] : 0.0f;
+        if (bias_b) bv += bias_b[(size_t)b * cout + co];
+      }
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int p = p0 + wave * 64 + s * 32 + l31;
+        const float v = acc[m][s][r] + bv;
+        if (co < cout && p < P) {
+          outb[(size_t)co * P + p] = v;
+          if (STATS) {
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (STATS) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off);
+          s2 += __shfl_xor(s2, off);
+        }
+        if (l31 == 0 && co < cout) {
+          float *q = stats_part + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * cout + co) * 2;
+          q[0] = s1;
+          q[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+__global__ void pw_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, const float *__restrict__ w,
+                               float *__restrict__ wp) {
+  const size_t total = (size_t)cin_pad * cout_pad;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kk = (int)(e & 3);
+    const int co = (int)((e >> 2) % cout_pad);
+    const int kh = (int)((e / ((size_t)4 * cout_pad)) & 1);
+    const int chunk = (int)(e / ((size_t)8 * cout_pad));
+    const int ci = chunk * 8 + 2 * kk + kh;
+    wp[e] = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
+  }
+}
+
+static inline int pw_cin_pad(int cin) { return (cin + 7) / 8 * 8; }
+static inline int pw_cout_pad(int cout) { return (cout + 63) / 64 * 64; }
+
+extern "C" size_t p2pb_pointwise_packed_floats(int cout, int cin) {
+  return (size_t)pw_cin_pad(cin) * pw_cout_pad(cout);
+}
+
+extern "C" int p2pb_pointwise_pack_weights(int cout, int cin, const float *w, float *wp, void *stream) {
+  if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
+  const size_t total = p2pb_pointwise_packed_floats(cout, cin);
+  hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256),
+                     0, (hipStream_t)stream, cout, cin, pw_cin_pad(cin), pw_cout_pad(cout), w, wp);
+  return p2pb_launch_status();
+}
+
+extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
+  return (size_t)b * ((npos + 255) / 256) * 4 * cout * 2;
+}
+
+template <int MT>
+static int pw_launch(int b, int cin, int cout, int P, const float *in, const float *wp, const float *bias,
+                     const float *bias_b, const float *in_scale, const float *in_shift, int in_swish, float *out,
+                     float *stats_part, hipStream_t s) {
+  dim3 grid((P + 255) / 256, (cout + 32 * MT - 1) / (32 * MT), b);
+  const bool xf = in_scale != nullptr, st = stats_part != nullptr;
+#define LAUNCH(XF, ST)                                                                                            \
+  hipLaunchKernelGGL((pw_conv_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, in, wp, bias, \
+                     bias_b, in_scale, in_shift, in_swish, out, stats_part)
+  if (xf && st) LAUNCH(true, true);
+  else if (xf) LAUNCH(true, false);
+  else if (st) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  return p2pb_launch_status();
+}
+
+extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const float *wp,
+                                           const float *bias, const float *bias_b, const float *in_scale,
+                                           const float *in_shift, int in_swish, float *out, float *stats_part,
+                                           void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, s)
+                   : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = act(x*scale[b,c] + shift[b,c]) (+ residual)   over [b, c, P]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_act_kernel(int c, int P, const float *__restrict__ x,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int swish,
+                                                         const float *__restrict__ residual, float *__restrict__ y) {
+  const int bc = blockIdx.y;  // b*c + ch
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * P;
+  const float *rr = residual ? residual + (size_t)bc * P : nullptr;
+  float *yr = y + (size_t)bc * P;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+    float v = xr[p] * sc + sh;
+    if (swish) v = swishf(v);
+    if (rr) v = rr[p] + v;
+    yr[p] = v;
+  }
+}
+
+extern "C" int p2pb_affine_act(int b, int c, int npos, const float *x, const float *scale, const float *shift,
+                               int swish, const float *residual, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || npos <= 0) return P2PB_EINVAL;
+  const unsigned gx = (unsigned)((npos + 255) / 256 > 64 ? 64 : (npos + 255) / 256);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(gx, b * c), dim3(256), 0, (hipStream_t)stream, c, npos, x, scale, shift,
+                     swish, residual, y);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[b,c,m] = max_{u < U} act(x[b,c,m,u]*scale + shift), U a power of two <= 64 (32 in every config):
+// lanes read the [m,u] plane contiguously, the max runs over aligned groups of U lanes.
+// U == 0 selects "max over the whole row" (Pnet2Stage's global max-pool): y[b,c] = max_p act(...).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_act_max_kernel(int M, int U, const float *__restrict__ x,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int swish,
+                                                             float *__restrict__ y) {
+  const int bc = blockIdx.y;
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * M * U;
+  float *yr = y + (size_t)bc * M;
+  const int total = M * U;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {  // total % 64 == 0 by construction
+    float v = xr[e] * sc + sh;
+    if (swish) v = swishf(v);
+    for (int off = U >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    if ((e & (U - 1)) == 0) yr[e / U] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_rowmax_kernel(int P, const float *__restrict__ x,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift, int swish,
+                                                                float *__restrict__ y) {
+  __shared__ float red[256];
+  const int bc = blockIdx.x;
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * P;
+  float mx = -INFINITY;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    float v = xr[p] * sc + sh;
+    if (swish) v = swishf(v);
+    mx = fmaxf(mx, v);
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) y[bc] = red[0];
+}
+
+extern "C" int p2pb_affine_act_max(int b, int c, int m, int u, const float *x, const float *scale, const float *shift,
+                                   int swish, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || m <= 0 || u < 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (u == 0) {
+    hipLaunchKernelGGL(affine_act_rowmax_kernel, dim3(b * c), dim3(256), 0, s, m, x, scale, shift, swish, y);
+    return p2pb_launch_status();
+  }
+  if ((u & (u - 1)) != 0 || u > 64 || ((long)m * u) % 64 != 0) return P2PB_EINVAL;
+  const long total = (long)m * u;
+  const unsigned gx = (unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256);
+  hipLaunchKernelGGL(affine_act_max_kernel, dim3(gx, b * c), dim3(256), 0, s, m, u, x, scale, shift, swish, y);
+  return p2pb_launch_status();
+}

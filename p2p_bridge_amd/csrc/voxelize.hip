@@ -261,9 +261,13 @@ __device__ __forceinline__ Corners devox_corners(float x, float y, float z, int 
   return k;
 }
 
-template <int CC>
+// AFF: the grid holds the RAW second-convolution output; the per-(sample, channel) affine that stands for
+// AdaGN + SE gating (feat*A + B) is applied to each corner value before interpolating, i.e. the same
+// "transform, then interpolate" order as the unfused graph, without a pass over the grid in between.
+template <int CC, bool AFF>
 __global__ __launch_bounds__(256) void devox_kernel(int c, int n, int r, int training,
                                                     const float *__restrict__ coords, const float *__restrict__ feat,
+                                                    const float *__restrict__ aff_a, const float *__restrict__ aff_b,
                                                     int *__restrict__ inds, float *__restrict__ wgts,
                                                     float *__restrict__ outs) {
   const int b = blockIdx.z;
@@ -284,9 +288,17 @@ __global__ __launch_bounds__(256) void devox_kernel(int c, int n, int r, int tra
   float *o = outs + (size_t)b * c * n + i;
   for (int j = c0; j < c1; ++j) {
     const float *fj = f + (size_t)j * r3;
-    float acc = k.w[0] * fj[k.idx[0]];
+    float fv[8];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) acc = __fmaf_rn(k.w[q], fj[k.idx[q]], acc);
+    for (int q = 0; q < 8; ++q) fv[q] = fj[k.idx[q]];
+    if (AFF) {
+      const float a = aff_a[(size_t)b * c + j], bb = aff_b[(size_t)b * c + j];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fv[q] = fv[q] * a + bb;
+    }
+    float acc = k.w[0] * fv[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) acc = __fmaf_rn(k.w[q], fv[q], acc);
     o[(size_t)j * n] = acc;
   }
 }
@@ -297,8 +309,19 @@ extern "C" int p2pb_trilinear_devoxelize_forward(int b, int c, int n, int r, int
   if (b <= 0 || c <= 0 || n <= 0 || r <= 0) return P2PB_EINVAL;
   if (is_training && (!inds || !wgts)) return P2PB_EINVAL;
   constexpr int CC = 16;
-  hipLaunchKernelGGL(devox_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c, n, r,
-                     is_training, coords, feat, inds, wgts, outs);
+  hipLaunchKernelGGL((devox_kernel<CC, false>), dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream,
+                     c, n, r, is_training, coords, feat, (const float *)nullptr, (const float *)nullptr, inds, wgts,
+                     outs);
+  return p2pb_launch_status();
+}
+
+// inference-only fused form: outs[b,c,i] = sum_k w_k * (feat[b,c,idx_k] * aff_a[b,c] + aff_b[b,c])
+extern "C" int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *coords, const float *feat,
+                                                const float *aff_a, const float *aff_b, float *outs, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || !aff_a || !aff_b) return P2PB_EINVAL;
+  constexpr int CC = 16;
+  hipLaunchKernelGGL((devox_kernel<CC, true>), dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream,
+                     c, n, r, 0, coords, feat, aff_a, aff_b, (int *)nullptr, (float *)nullptr, outs);
   return p2pb_launch_status();
 }
 

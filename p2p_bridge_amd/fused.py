@@ -1,0 +1,139 @@
+"""Inference-time fused voxel branch of PVConv on the gfx950 kernels (csrc/conv3d.hip, voxelize.hip).
+
+    voxel grid --conv3d+stats--> y1 --[GN+AdaGN -> affine]--> conv3d(affine+Swish on load)+stats --> y2
+               --[GN+AdaGN -> affine, SE gate from channel means]--> devoxelize(affine on load)
+
+Every normalisation / activation between the two convolutions and the devoxelisation is folded into
+per-(sample, channel) scale/shift vectors, so each grid tensor is written once and read once.
+Training keeps the unfused autograd graph (pvcnn_unet.PVConv.forward).
+"""
+import ctypes
+
+import torch
+
+from ._lib import call, check, lib, ptr, stream_ptr
+
+_i, _f, _d = ctypes.c_int, ctypes.c_float, ctypes.c_double
+F32 = torch.float32
+
+
+def pack_conv3d_weight(conv: torch.nn.Conv3d) -> torch.Tensor:
+    """packed [27][cin_pad][cout_pad] copy of a Conv3d weight, cached on the module and refreshed when the
+    parameter is modified in place (optimizer step / load_state_dict) or replaced"""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device)
+    cache = getattr(conv, "_p2pb_packed", None)
+    if cache is None or cache[0] != key:
+        co, ci = w.shape[:2]
+        assert tuple(w.shape[2:]) == (3, 3, 3) and conv.padding == (1, 1, 1) and conv.stride == (1, 1, 1)
+        wt = torch.empty(lib().p2pb_conv3d_k3_packed_floats(_i(co), _i(ci)), dtype=F32, device=w.device)
+        call("p2pb_conv3d_k3_pack_weights", _i(co), _i(ci), ptr(w.detach().contiguous()), ptr(wt), stream_ptr())
+        conv._p2pb_packed = (key, wt)
+        cache = conv._p2pb_packed
+    return cache[1]
+
+
+def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True):
+    """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None)"""
+    check(x, F32, "x")
+    b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+    co = conv.out_channels
+    wt = pack_conv3d_weight(conv)
+    y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
+    st = None
+    if stats:
+        nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
+        st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    call("p2pb_conv3d_k3_forward", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(in_scale),
+         ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), stream_ptr())
+    return y, st
+
+
+def gn_affine_params(part, count_per_channel, groups, gamma, beta, style=None, eps=1e-5, want_mean=False):
+    """partials f32[B,nslots,C,2] -> scale, shift (, chmean) f32[B,C]"""
+    b, nslots, c, _ = part.shape
+    scale = torch.empty(b, c, dtype=F32, device=part.device)
+    shift = torch.empty_like(scale)
+    chmean = torch.empty_like(scale) if want_mean else None
+    if style is not None:
+        style = style.contiguous()
+    call("p2pb_gn_affine_params", _i(b), _i(c), _i(groups), _i(nslots), _d(float(count_per_channel)), ptr(part),
+         ptr(gamma), ptr(beta), ptr(style), _f(eps), ptr(scale), ptr(shift), ptr(chmean), stream_ptr())
+    return scale, shift, chmean
+
+
+def devoxelize_affine(grid, vcoords, r, aff_a, aff_b):
+    """grid f32[B,C,r,r,r] (raw), vcoords f32[B,3,N] -> f32[B,C,N] of trilinear(grid*a + b)"""
+    check(grid, F32, "grid"), check(vcoords, F32, "coords")
+    b, c = grid.shape[:2]
+    n = vcoords.shape[2]
+    out = torch.empty(b, c, n, dtype=F32, device=grid.device)
+    call("p2pb_trilinear_devoxelize_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
+         ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(out), stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------ shared point MLPs (csrc/pointwise.hip)
+
+
+def enabled(module: torch.nn.Module, x: torch.Tensor) -> bool:
+    """the fused inference kernels are used when no autograd graph is being recorded"""
+    return x.is_cuda and not module.training and not torch.is_grad_enabled()
+
+
+def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None) -> torch.Tensor:
+    """packed copy of a k=1 Conv1d/Conv2d (or Linear) weight [co, ci(,1(,1))], optionally an input-channel
+    slice; cached on the module like pack_conv3d_weight"""
+    w = conv.weight
+    ci_hi = w.shape[1] if ci_hi is None else ci_hi
+    key = (w.data_ptr(), w._version, w.device, ci_lo, ci_hi)
+    cache = getattr(conv, "_p2pb_packed_pw", None)
+    if cache is None:
+        cache = conv._p2pb_packed_pw = {}
+    hit = cache.get((ci_lo, ci_hi))
+    if hit is None or hit[0] != key:
+        co = w.shape[0]
+        w2 = w.detach().reshape(co, -1)[:, ci_lo:ci_hi].contiguous()
+        wp = torch.empty(lib().p2pb_pointwise_packed_floats(_i(co), _i(ci_hi - ci_lo)), dtype=F32, device=w.device)
+        call("p2pb_pointwise_pack_weights", _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
+        hit = cache[(ci_lo, ci_hi)] = (key, wp)
+    return hit[1]
+
+
+def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
+            use_bias=True):
+    """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None)"""
+    check(x, F32, "x")
+    b, ci, p = x.shape
+    co = conv.weight.shape[0]
+    wp = pack_pointwise_weight(conv, ci_lo, ci_hi)
+    y = torch.empty(b, co, p, dtype=F32, device=x.device)
+    st = None
+    if stats:
+        nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
+        st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    bias = conv.bias if use_bias else None
+    call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), stream_ptr())
+    return y, st
+
+
+def affine_act(x, scale, shift, swish=True, residual=None):
+    """swish(x*scale[b,c]+shift[b,c]) (+ residual), x f32[B,C,P]"""
+    b, c, p = x.shape
+    y = torch.empty_like(x)
+    if residual is not None:
+        residual = residual.contiguous()
+    call("p2pb_affine_act", _i(b), _i(c), _i(p), ptr(x), ptr(scale), ptr(shift), _i(int(swish)), ptr(residual), ptr(y),
+         stream_ptr())
+    return y
+
+
+def affine_act_max(x, scale, shift, m, u, swish=True):
+    """max over the last (neighbour) axis of swish(x*scale+shift): x f32[B,C,m*u] -> f32[B,C,m];
+    u == 0: max over the whole row -> f32[B,C]"""
+    b, c = x.shape[:2]
+    y = torch.empty((b, c, m) if u else (b, c), dtype=F32, device=x.device)
+    call("p2pb_affine_act_max", _i(b), _i(c), _i(m), _i(u), ptr(x), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
+         stream_ptr())
+    return y

@@ -121,6 +121,25 @@ class LinearAttention(nn.Module):
         return self.to_out(out).squeeze(-1)
 
 
+def norm_affine(norm, part, count, cond, want_mean=False):
+    """AdaGN / GroupNorm / MyGroupNorm folded to per-(sample, channel) (scale, shift[, channel mean]) from the
+    producing kernel's {sum, sumsq} partials (fused.gn_affine_params)"""
+    from . import fused
+
+    style = None
+    if isinstance(norm, AdaGN):
+        gn = norm.norm
+        style = norm.emd(cond) if cond is not None else None
+        if cond is None:
+            raise RuntimeError("AdaGN needs the global embedding")
+    elif isinstance(norm, MyGroupNorm):
+        gn = norm.group_norm
+    else:
+        gn = norm
+    out = fused.gn_affine_params(part, count, gn.num_groups, gn.weight, gn.bias, style, gn.eps, want_mean)
+    return out if want_mean else out[:2]
+
+
 class SharedMLP(nn.Module):
     """(1x1 conv -> AdaGN|GroupNorm(8) -> Swish) repeated; parameters live in `layers` at indices
     3i / 3i+1 like the reference (models/pvcnn.py:162-205)."""
@@ -139,10 +158,38 @@ class SharedMLP(nn.Module):
             in_channels = oc
         self.layers = nn.ModuleList(mods)
 
-    def run(self, x, cond):
+    def run(self, x, cond, reduce_max=False, residual=None):
+        """the chain on x[B,C,...]; reduce_max: max over the last axis afterwards (set abstraction);
+        residual: tensor added to the result (PVConv's voxel branch)"""
+        from . import fused
+
+        if fused.enabled(self, x):
+            return self._run_fused(x, cond, reduce_max, residual)
         for m in self.layers:
             x = m(x, cond) if (isinstance(m, AdaGN) and cond is not None) else m(x)
-        return x
+        if reduce_max:
+            x = x.max(dim=-1).values
+        return x if residual is None else residual + x
+
+    def _run_fused(self, x, cond, reduce_max, residual):
+        """inference: every norm+Swish is folded into the next kernel's operand load (fused.py)"""
+        from . import fused
+
+        shape = x.shape
+        B, P = shape[0], int(np.prod(shape[2:]))
+        h = x.reshape(B, shape[1], P)
+        if not h.is_contiguous():
+            h = h.contiguous()
+        sc = sh = None
+        for i in range(0, len(self.layers), 3):
+            conv, norm = self.layers[i], self.layers[i + 1]
+            h, st = fused.pw_conv(h, conv, sc, sh, swish=sc is not None)
+            sc, sh = norm_affine(norm, st, P, cond)
+        C = h.shape[1]
+        if reduce_max:
+            return fused.affine_act_max(h, sc, sh, int(np.prod(shape[2:-1])), shape[-1]).view(B, C, *shape[2:-1])
+        res = None if residual is None else residual.reshape(B, C, P)
+        return fused.affine_act(h, sc, sh, True, res).view(B, C, *shape[2:])
 
     def forward(self, data: PVCData) -> PVCData:
         data.features = self.run(data.features, data.cond)
@@ -182,14 +229,34 @@ class PVConv(nn.Module):
         self.attn = None
         self.point_features = SharedMLP(in_channels, out_channels, gn_groups=gn_groups, cond_dim=cond_dim)
 
+    def _voxel_branch_fused(self, v, vcoords, cond):
+        """inference: conv -> [AdaGN,Swish folded] -> conv -> [AdaGN,SE folded] -> devoxelize, grid tensors
+        written once / read once (fused.py)"""
+        from . import fused
+
+        vl = self.voxel_layers
+        r3 = float(self.resolution ** 3)
+        y1, st1 = fused.conv3d_k3(v, vl[0])
+        sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
+        y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True)
+        se = vl[6] if len(vl) > 6 else None
+        sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
+        if se is not None:
+            gate = se.fc(mean2)
+            sc2, sh2 = sc2 * gate, sh2 * gate
+        return fused.devoxelize_affine(y2, vcoords, self.resolution, sc2, sh2)
+
     def forward(self, data: PVCData) -> PVCData:
         coords, features, cond = data.coords, data.features, data.cond
         assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2] and coords.shape[1] == 3
         v, vcoords = self.voxelization(features, coords)
-        for m in self.voxel_layers:
-            v = m(v, cond) if isinstance(m, AdaGN) else m(v)
-        fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
-        data.features = fused + self.point_features.run(features, cond)
+        if not self.training and not torch.is_grad_enabled() and self.resolution in (4, 8, 16, 32):
+            fused = self._voxel_branch_fused(v, vcoords, cond)
+        else:
+            for m in self.voxel_layers:
+                v = m(v, cond) if isinstance(m, AdaGN) else m(v)
+            fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
+        data.features = self.point_features.run(features, cond, residual=fused)
         return data
 
 
@@ -228,7 +295,7 @@ class PointNetSAModule(nn.Module):
         if data.time_emb is not None:
             data.time_emb = data.time_emb[:, :, : centers.shape[-1]]
         grouped = self.groupers[0](coords, centers, data.features)
-        data.features = self.mlps[0].run(grouped, data.cond).max(dim=-1).values
+        data.features = self.mlps[0].run(grouped, data.cond, reduce_max=True)
         data.coords = centers
         return data
 
@@ -302,10 +369,42 @@ class Pnet2Stage(nn.Module):
         self.mlp2 = ConditionedSharedMLPLayer([2 * mlp1[-1]] + mlp2)
 
     def forward(self, coords):
+        from . import fused
+
+        if fused.enabled(self, coords) and self._fusable():
+            return self._forward_fused(coords)
         f = self.mlp1(coords.unsqueeze(-1))
         g = f.amax(dim=2, keepdim=True).expand(-1, -1, f.size(2), -1)
         f = self.mlp2(torch.cat([f, g], dim=1))
         return f.amax(dim=2).squeeze(-1)
+
+    def _fusable(self):
+        ok = len(self.mlp1.last_mlp_layers) == 0 and len(self.mlp2.last_mlp_layers) == 0
+        for blk in (self.mlp1.shared_mlp_0, self.mlp1.shared_mlp_1, self.mlp2.shared_mlp_0, self.mlp2.shared_mlp_1):
+            ok = ok and blk.mlp[1].num_channels == blk.mlp[0].out_channels
+        return ok
+
+    def _forward_fused(self, coords):
+        """inference: 4 fused GEMMs + 2 fused max-pools. The concat with the broadcast max-pooled vector is
+        never materialised: W @ cat(f, g) = W[:, :C] @ f + (W[:, C:] @ g), the second term a per-sample bias."""
+        from . import fused
+
+        N = coords.shape[2]
+        a0, a1 = self.mlp1.shared_mlp_0.mlp, self.mlp1.shared_mlp_1.mlp
+        b0, b1 = self.mlp2.shared_mlp_0.mlp, self.mlp2.shared_mlp_1.mlp
+        h, st = fused.pw_conv(coords.contiguous(), a0[0])
+        sc, sh = norm_affine(a0[1], st, N, None)
+        h, st = fused.pw_conv(h, a1[0], sc, sh, swish=True)
+        sc, sh = norm_affine(a1[1], st, N, None)
+        g = fused.affine_act_max(h, sc, sh, N, 0)
+        c1 = h.shape[1]
+        w = b0[0].weight.reshape(b0[0].out_channels, -1)
+        bias_b = (g @ w[:, c1:].t()).contiguous()
+        h, st = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1)
+        sc, sh = norm_affine(b0[1], st, N, None)
+        h, st = fused.pw_conv(h, b1[0], sc, sh, swish=True)
+        sc, sh = norm_affine(b1[1], st, N, None)
+        return fused.affine_act_max(h, sc, sh, N, 0)
 
 
 # ------------------------------------------------------------------------------------ stage plan
@@ -441,8 +540,17 @@ class PVCNN2Unet(nn.Module):
             f"input dim: {C}, expected: {self.input_dim + self.extra_feature_channels}"
         coords = x[:, : self.input_dim].contiguous()
         feats = x[:, self.input_dim:].contiguous()
+        from . import fused
+
+        use_fused = fused.enabled(self, x)
         if self.embed_feats is not None:
-            feats = self.embed_feats(coords if self.extra_feature_channels == 0 else feats)
+            src = coords if self.extra_feature_channels == 0 else feats
+            if use_fused:
+                h, st = fused.pw_conv(src, self.embed_feats[0])
+                sc, sh = norm_affine(self.embed_feats[1], st, N, None)
+                feats, _ = fused.pw_conv(h, self.embed_feats[3], sc, sh, swish=True, stats=False)
+            else:
+                feats = self.embed_feats(src)
         cond = self.global_pnet(coords) if self.global_pnet is not None else None
         feats = torch.cat([coords, feats], dim=1)
         time_emb = None
@@ -468,5 +576,10 @@ class PVCNN2Unet(nn.Module):
             data = stage(PVCData(features=skips[-1 - j], coords=level_coords[-1 - j], lower_coords=data.coords,
                                  lower_features=lower, time_emb=data.time_emb, cond=data.cond))
 
+        if use_fused:  # classifier: SharedMLP(GroupNorm) -> Dropout(eval: identity) -> Conv1d, two fused GEMMs
+            c0 = self.classifier[0]
+            h, st = fused.pw_conv(data.features.contiguous(), c0.layers[0])
+            sc, sh = norm_affine(c0.layers[1], st, h.shape[2], None)
+            return fused.pw_conv(h, self.classifier[2], sc, sh, swish=True, stats=False)[0]
         h = self.classifier[0].run(data.features, None)
         return self.classifier[2](self.classifier[1](h))
