@@ -22,6 +22,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CONV_CK 8  // input channels per LDS stage
 
@@ -44,9 +45,17 @@ struct ConvGeom<4> {
   static constexpr int TD = 4, TH = 4, TW = 4, ND = 2, NH = 4;
 };
 
+// Swish with the hardware exp2 / reciprocal units: v * rcp(1 + exp2(-v*log2(e))). ~1e-6 relative error
+// (both units are 1 ulp), an order of magnitude below the fp32 summation-order noise of the dense layers
+// and two below the 1e-4 parity budget; 6 VALU ops instead of ~45 for expf + IEEE divide. It matters
+// because the activation is recomputed on every operand stage (once per output-channel block).
+__device__ __forceinline__ float fast_swish(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
+
 // MT = 32-row output-channel tiles per workgroup (NC = 32*MT), XF = apply affine(+swish) to the input
 template <int R, int MT, bool XF, bool STATS>
-__global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int cin_pad, int cout_pad,
+__global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                         const float *__restrict__ in, const float *__restrict__ wt,
                                                         const float *__restrict__ bias,
                                                         const float *__restrict__ in_scale,
@@ -56,12 +65,14 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int c
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
   constexpr int PLANE = HD * HH * HW;
   constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;  // N-tiles in the brick (8, or 2 for R=4)
-  constexpr int BD = R / G::TD, BH = R / G::TH;          // bricks per sample along d, h
+  constexpr int BH = R / G::TH;                          // bricks per sample along h
+  constexpr int NE = (CONV_CK * PLANE + 255) / 256;      // staged elements per thread per chunk
+  constexpr int R3 = R * R * R;
   __shared__ float tile[CONV_CK * PLANE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int brick = blockIdx.x;  // over BD*BH
+  const int brick = blockIdx.x;
   const int d0 = (brick / BH) * G::TD, h0 = (brick % BH) * G::TH;
   const int co0 = blockIdx.y * (32 * MT);
   const int b = blockIdx.z;
@@ -73,13 +84,25 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int c
   for (int s = 0; s < 2; ++s) {
     const int t = 2 * wave + s;
     nact[s] = t < NTILES;
-    // N-tiles enumerate (d-blocks of ND) x (h-blocks of NH)
     constexpr int HB = G::TH / G::NH;
     const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
-    // lane's voxel inside the N-tile
-    const int jw = l31 % G::TW, jr = l31 / G::TW;  // jr over NH*ND rows
+    const int jw = l31 % G::TW, jr = l31 / G::TW;  // lane's voxel inside the N-tile
     const int jh = jr % G::NH, jd = jr / G::NH;
     nbase[s] = ((td + jd) * HH + (th + jh)) * HW + jw;
+  }
+
+  // staging map, fixed for the whole kernel: element e = tid + k*256 of the [CK][HD][HH][HW] halo brick
+  // -> (channel-in-chunk << 16 | offset inside the channel's r^3 grid), or -1 outside the grid / brick
+  int gpk[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int e = tid + k * 256;
+    const int ci = e / PLANE, rem = e % PLANE;
+    const int dz = rem / (HH * HW), hy = (rem / HW) % HH, wx = rem % HW;
+    const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = wx - 1;
+    const bool ok = e < CONV_CK * PLANE && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R &&
+                    (unsigned)w < (unsigned)R;
+    gpk[k] = ok ? ((ci << 16) | ((d * R + h) * R + w)) : -1;
   }
 
   f32x16 acc[MT][2];
@@ -90,50 +113,68 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int c
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
 
-  const float *inb = in + (size_t)b * cin * R * R * R;
+  const float *inb = in + (size_t)b * cin * R3;
+  float stg[NE];
+  auto stage_load = [&](int ci0) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int g = gpk[k];
+      const int ci = ci0 + ((g >> 16) & 7);
+      stg[k] = (g >= 0 && ci < cin) ? inb[(size_t)ci * R3 + (g & 0xFFFF)] : 0.0f;
+    }
+  };
+  stage_load(0);
+
   for (int ci0 = 0; ci0 < cin; ci0 += CONV_CK) {
-    __syncthreads();
-    // ---- stage the halo brick of CK channels (zero outside the grid / beyond cin)
-    for (int e = tid; e < CONV_CK * PLANE; e += 256) {
-      const int ci = e / PLANE, rem = e % PLANE;
-      const int dz = rem / (HH * HW), hy = (rem / HW) % HH, wx = rem % HW;
-      const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = wx - 1;
-      float v = 0.0f;
-      if (ci0 + ci < cin && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R) {
-        v = inb[((size_t)(ci0 + ci) * R + d) * R * R + h * R + w];
-        if (XF) {
-          v = v * in_scale[b * cin + ci0 + ci] + in_shift[b * cin + ci0 + ci];
-          if (in_swish) v = v * __fdiv_rn(1.0f, 1.0f + expf(-v));
+    __syncthreads();  // everyone is done reading the previous chunk's tile
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+      const int e = tid + k * 256;
+      float v = stg[k];
+      if (XF) {
+        const int g = gpk[k];
+        const int ci = ci0 + ((g >> 16) & 7);
+        if (g >= 0 && ci < cin) {
+          v = v * in_scale[b * cin + ci] + in_shift[b * cin + ci];
+          if (in_swish) v = fast_swish(v);
         }
       }
-      tile[e] = v;
+      if (e < CONV_CK * PLANE) tile[e] = v;
     }
     __syncthreads();
-    // ---- 27 taps x CK/2 k-pairs of MFMAs
-    const float *wchunk = wt + ((size_t)(ci0 + khalf)) * cout_pad + co0 + l31;
-#pragma unroll 1
-    for (int kd = 0; kd < 3; ++kd) {
+    if (ci0 + CONV_CK < cin) stage_load(ci0 + CONV_CK);  // next chunk's loads fly during the MFMAs
+
+    // ---- 27 taps x CK/2 k-pairs of MFMAs; A fragments: one 16-byte load per (tap, M-tile), next tap
+    //      prefetched while the current one is multiplied
+    const float *wchunk = wt + ((((size_t)(ci0 / CONV_CK)) * 2 + khalf) * cout_pad + co0 + l31) * 4;
+    const size_t wtap_stride = (size_t)nchunk * 2 * cout_pad * 4;
+    f32x4 a_cur[MT];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
+    for (int m = 0; m < MT; ++m) a_cur[m] = *(const f32x4 *)(wchunk + (size_t)m * 32 * 4);
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int tap = (kd * 3 + kh) * 3 + kw;
-          const int toff = (kd * HH + kh) * HW + kw;
-          const float *wtap = wchunk + (size_t)tap * cin_pad * cout_pad;
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int toff = (kd * HH + kh) * HW + kw;
+      f32x4 a_nxt[MT];
+      if (tap + 1 < 27) {
 #pragma unroll
-          for (int kk = 0; kk < CONV_CK / 2; ++kk) {
-            float a[MT], bf[2];
+        for (int m = 0; m < MT; ++m)
+          a_nxt[m] = *(const f32x4 *)(wchunk + (size_t)(tap + 1) * wtap_stride + (size_t)m * 32 * 4);
+      }
 #pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = wtap[(size_t)(2 * kk) * cout_pad + m * 32];
+      for (int kk = 0; kk < CONV_CK / 2; ++kk) {
+        float bf[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) bf[s] = tile[(2 * kk + khalf) * PLANE + nbase[s] + toff];
+        for (int s = 0; s < 2; ++s) bf[s] = tile[(2 * kk + khalf) * PLANE + nbase[s] + toff];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-              for (int s = 0; s < 2; ++s)
-                acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bf[s], acc[m][s], 0, 0, 0);
-          }
-        }
+          for (int s = 0; s < 2; ++s)
+            acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][kk], bf[s], acc[m][s], 0, 0, 0);
+      }
+      if (tap + 1 < 27) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
       }
     }
   }
@@ -180,22 +221,30 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int c
   }
 }
 
-// weights [cout][cin][3][3][3] -> packed [27][cin_pad][cout_pad] (zero padded)
-__global__ void conv3d_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, const float *__restrict__ w,
+// weights [cout][cin][3][3][3] -> packed [27][cin_pad/8][2][cout_pad][4] (zero padded):
+// element (tap, chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf][tap], so that the four k-pair
+// values one lane needs for a tap are one aligned 16-byte load and lanes 0..31 read 512 contiguous bytes
+__global__ void conv3d_pack_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
                                    float *__restrict__ wt) {
-  const size_t total = (size_t)27 * cin_pad * cout_pad;
+  const size_t total = (size_t)27 * nchunk * 8 * cout_pad;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    const int co = (int)(e % cout_pad), ci = (int)((e / cout_pad) % cin_pad), tap = (int)(e / ((size_t)cout_pad * cin_pad));
+    const int kk = (int)(e & 3);
+    const int co = (int)((e >> 2) % cout_pad);
+    size_t q = (e >> 2) / cout_pad;
+    const int kh = (int)(q & 1);
+    q >>= 1;
+    const int chunk = (int)(q % nchunk), tap = (int)(q / nchunk);
+    const int ci = chunk * 8 + 2 * kk + kh;
     wt[e] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 27 + tap] : 0.0f;
   }
 }
 
 extern "C" int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, float *wt_packed, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
-  const int cin_pad = (cin + CONV_CK - 1) / CONV_CK * CONV_CK, cout_pad = (cout + 63) / 64 * 64;
-  const size_t total = (size_t)27 * cin_pad * cout_pad;
+  const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
+  const size_t total = (size_t)27 * nchunk * 8 * cout_pad;
   hipLaunchKernelGGL(conv3d_pack_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, cout, cin, cin_pad, cout_pad, w, wt_packed);
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, wt_packed);
   return p2pb_launch_status();
 }
 
@@ -217,11 +266,11 @@ static int conv_launch(int b, int cin, int cout, const float *in, const float *w
                        const float *in_scale, const float *in_shift, int in_swish, float *out, float *stats_part,
                        hipStream_t s) {
   using G = ConvGeom<R>;
-  const int cin_pad = (cin + CONV_CK - 1) / CONV_CK * CONV_CK, cout_pad = (cout + 63) / 64 * 64;
+  const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
   dim3 grid((R / G::TD) * (R / G::TH), (cout + 32 * MT - 1) / (32 * MT), b);
   const bool xf = in_scale != nullptr, st = stats_part != nullptr;
 #define LAUNCH(XF, ST)                                                                                         \
-  hipLaunchKernelGGL((conv3d_k3_kernel<R, MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, cin_pad, cout_pad, in, wt, \
+  hipLaunchKernelGGL((conv3d_k3_kernel<R, MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in, wt, \
                      bias, in_scale, in_shift, in_swish, out, stats_part)
   if (xf && st) LAUNCH(true, true);
   else if (xf) LAUNCH(true, false);
@@ -239,7 +288,12 @@ extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const flo
                                       float *out, float *stats_part, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = cout > 32;
+  // 64 output channels per workgroup unless that leaves fewer than 2 workgroups per CU (small grids)
+  int bricks = 1;
+  if (r == 32) bricks = 128;
+  else if (r == 16) bricks = 16;
+  else if (r == 8) bricks = 2;
+  const bool wide = cout > 32 && (long)bricks * ((cout + 63) / 64) * b >= 512;
 #define GO(RR)                                                                                                      \
   return wide ? conv_launch<RR, 2>(b, cin, cout, in, wt_packed, bias, in_scale, in_shift, in_swish, out, stats_part, s) \
               : conv_launch<RR, 1>(b, cin, cout, in, wt_packed, bias, in_scale, in_shift, in_swish, out, stats_part, s)
@@ -262,46 +316,46 @@ extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const flo
 // moments are recomputed by each of the group's channels (C/G <= 64 channels x nslots partials, tiny).
 // Also returns chmean[b,c] = mean over positions of the transformed output (SE3d's squeeze input).
 // ------------------------------------------------------------------------------------------------
-// one workgroup per (sample, group): the group's channels are reduced over the slots by the whole block
-// (fixed lane-strided partials + fixed LDS tree => deterministic), then thread k finalises channel k.
+// one workgroup per (sample, group). Thread t accumulates channel (t mod cg) over the slots
+// t/cg, t/cg + 256/cg, ... (adjacent threads read adjacent channels: coalesced), the 256/cg partial
+// accumulators per channel are then summed in ascending order -- a fixed order, so deterministic.
 __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int nslots, double count_per_channel,
                                                         const float *__restrict__ part, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, const float *__restrict__ style,
                                                         float eps, float *__restrict__ scale, float *__restrict__ shift,
                                                         float *__restrict__ chmean) {
-  __shared__ double red[2][256];
+  __shared__ double rs[256], rq[256];
   __shared__ double chs[256], chq[256];  // per-channel totals of this group (cg <= 256)
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
   const int cg = c / groups, g0 = g * cg;
-  for (int k = 0; k < cg; ++k) {
-    double s = 0.0, q = 0.0;
-    for (int sl = t; sl < nslots; sl += 256) {
+  const int nt = 256 / cg;  // partial accumulators per channel
+  const int k = t % cg, j = t / cg;
+  double s = 0.0, q = 0.0;
+  if (j < nt)
+    for (int sl = j; sl < nslots; sl += nt) {
       const float *p = part + (((size_t)b * nslots + sl) * c + g0 + k) * 2;
       s += (double)p[0];
       q += (double)p[1];
     }
-    red[0][t] = s;
-    red[1][t] = q;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-      if (t < w) {
-        red[0][t] += red[0][t + w];
-        red[1][t] += red[1][t + w];
-      }
-      __syncthreads();
+  rs[t] = s;
+  rq[t] = q;
+  __syncthreads();
+  if (t < cg) {
+    double ts = 0.0, tq = 0.0;
+    for (int jj = 0; jj < nt; ++jj) {
+      ts += rs[jj * cg + t];
+      tq += rq[jj * cg + t];
     }
-    if (t == 0) {
-      chs[k] = red[0][0];
-      chq[k] = red[1][0];
-    }
-    __syncthreads();
+    chs[t] = ts;
+    chq[t] = tq;
   }
-  double gs = 0.0, gq = 0.0;
-  for (int k = 0; k < cg; ++k) {
-    gs += chs[k];
-    gq += chq[k];
-  }
+  __syncthreads();
   if (t >= cg) return;
+  double gs = 0.0, gq = 0.0;
+  for (int kk = 0; kk < cg; ++kk) {
+    gs += chs[kk];
+    gq += chq[kk];
+  }
   const int ch = g0 + t;
   const double n = count_per_channel * cg;
   const double mean = gs / n;

@@ -20,7 +20,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PW_CK 32  // input channels per LDS stage (4 sub-chunks of 8)
 
-__device__ __forceinline__ float swishf(float v) { return v * __fdiv_rn(1.0f, 1.0f + expf(-v)); }
+// Swish on the hardware exp2 / reciprocal units (see conv3d.hip fast_swish for the error budget)
+__device__ __forceinline__ float swishf(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
 
 // packed weights: wp[cin_pad/8][2][cout_pad][4], element (chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf]
 template <int MT, bool XF, bool STATS>
@@ -138,7 +141,7 @@ __global__ void pw_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, con
 }
 
 static inline int pw_cin_pad(int cin) { return (cin + 7) / 8 * 8; }
-static inline int pw_cout_pad(int cout) { return (cout + 63) / 64 * 64; }
+static inline int pw_cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 
 extern "C" size_t p2pb_pointwise_packed_floats(int cout, int cin) {
   return (size_t)pw_cin_pad(cin) * pw_cout_pad(cout);
@@ -179,6 +182,11 @@ extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, c
                                            void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  // the operand tile (and its folded activation) is re-staged once per output-channel block: use 128-wide
+  // blocks for wide layers as long as the grid still covers the chip twice
+  const long wgs128 = (long)((npos + 255) / 256) * ((cout + 127) / 128) * b;
+  if (cout > 64 && wgs128 >= 512)
+    return pw_launch<4>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, s);
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
                                   stats_part, s)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
