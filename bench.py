@@ -39,28 +39,34 @@ CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample p
 
 
 def conv_roofline(model, B, reps=10):
-    """Dominant kernel = the 3x3x3 voxel convolution. Time the largest one (fp_layers.3.1 conv: C 64->64,
-    r=32, 29.0 GFLOP... per launch at this B) with HIP events on the stream it is launched on."""
+    """Dominant kernel = conv3d_k3_kernel (csrc/conv3d.hip), the 3x3x3 voxel convolution on the fp32 MFMA.
+    Timed live on its largest instance (fp_layers.3.1 second conv: C 64->64, r=32, with the folded
+    AdaGN+Swish operand transform and the GroupNorm statistics epilogue, exactly as the sampler runs it)
+    with HIP events on the stream the kernel is launched on (torch's current stream)."""
+    from p2p_bridge_amd import fused
+
     pv = model.model.fp_layers[3][1]
     conv = pv.voxel_layers[4]
     C, r = conv.in_channels, pv.resolution
     x = torch.randn(B, C, r, r, r, device="cuda")
-    flops = 2.0 * B * r ** 3 * 27 * conv.in_channels * conv.out_channels
+    sc, sh = torch.rand(B, C, device="cuda") + 0.5, torch.randn(B, C, device="cuda")
+    flops = 2.0 * B * r ** 3 * 27 * conv.in_channels * conv.out_channels  # algorithmic FLOPs of one launch
     with torch.no_grad():
         for _ in range(3):
-            conv(x)
+            fused.conv3d_k3(x, conv, sc, sh, swish=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            conv(x)
+            fused.conv3d_k3(x, conv, sc, sh, swish=True)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": f"conv3d 3x3x3 C{conv.in_channels}->{conv.out_channels} r{r} B{B} (fp_layers.3.1)",
+            "kernel": f"conv3d_k3_kernel<32,2,true,true> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
+                      f"(fp_layers.3.1.voxel_layers.4)",
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 

@@ -25,5 +25,21 @@ __device__ __forceinline__ int mbcnt(unsigned long long mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
+// sum over each 32-lane half of the wave with DPP row shifts (VALU-rate, no LDS traffic); the result is
+// valid in lanes 31 and 63 only. Summation order is fixed by the instruction sequence (deterministic).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add_step(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, o);
+}
+__device__ __forceinline__ float halfwave_sum_to_last(float v) {
+  v = dpp_add_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add_step<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each 16-lane row = row sum
+  v = dpp_add_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 = half-wave sums
+  return v;
+}
+
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);

@@ -206,12 +206,9 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
       if (STATS) {
         // sum over the 32 lanes of this half-wave (a channel row lives in exactly one half of the wave),
         // one private slot per (sample, brick, wave, channel): plain stores, reduced later in fixed order
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off);
-          s2 += __shfl_xor(s2, off);
-        }
-        if (l31 == 0 && co < cout) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && co < cout) {
           float *p = stats_part + ((((size_t)b * gridDim.x + brick) * 4 + wave) * cout + co) * 2;
           p[0] = s1;
           p[1] = s2;

@@ -14,6 +14,7 @@
 // (so stores are lane-consecutive), K = input channels. Small-C layers are HBM-bound (8 FLOP/B at
 // C=32..64), the wide ones (Pnet2Stage 512->1024) MFMA-bound.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -26,6 +27,13 @@ __device__ __forceinline__ float swishf(float v) {
 }
 
 // packed weights: wp[cin_pad/8][2][cout_pad][4], element (chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf]
+//
+// No LDS, no barriers: in a 1x1 convolution the B operand (activations) is not shared between waves --
+// each wave owns 64 distinct positions -- so every lane loads its own MFMA B fragments straight from HBM
+// (lanes 0..31 = 32 consecutive positions of channel 2kk, lanes 32..63 of channel 2kk+1: two 128-byte
+// segments per load instruction) and the four waves of a workgroup run fully decoupled. The loads of
+// chunk c+1 are issued before chunk c is multiplied; A fragments (weights) are 16-byte L1/L2 loads issued
+// first, so the in-order vmcnt wait in front of the MFMAs never covers the HBM prefetch.
 template <int MT, bool XF, bool STATS>
 __global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cout_pad, int P,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
@@ -34,12 +42,13 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cou
                                                       const float *__restrict__ in_scale,
                                                       const float *__restrict__ in_shift, int in_swish,
                                                       float *__restrict__ out, float *__restrict__ stats_part) {
-  __shared__ float tile[PW_CK][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int p0 = blockIdx.x * 256, co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
-  const bool pok = p0 + tid < P;
-  const float *inb = in + (size_t)b * cin * P + p0 + tid;
+  const int pl[2] = {p0 + wave * 64 + l31, p0 + wave * 64 + 32 + l31};
+  const bool pok[2] = {pl[0] < P, pl[1] < P};
+  const float *inb = in + (size_t)b * cin * P;
+  const int nchunk8 = (cin + 7) >> 3;
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -49,41 +58,61 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cou
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
 
-  for (int ci0 = 0; ci0 < cin; ci0 += PW_CK) {
-    __syncthreads();
+  float bcur[PW_CK / 2][2], bnxt[PW_CK / 2][2];
+  auto load_b = [&](int ci0, float(&dst)[PW_CK / 2][2]) {
 #pragma unroll
-    for (int k = 0; k < PW_CK; ++k) {
-      const int ci = ci0 + k;
-      float v = 0.0f;
-      if (pok && ci < cin) {
-        v = inb[(size_t)ci * P];
-        if (XF) {
-          v = v * in_scale[b * cin + ci] + in_shift[b * cin + ci];
-          if (in_swish) v = swishf(v);
-        }
-      }
-      tile[k][tid] = v;
+    for (int kk = 0; kk < PW_CK / 2; ++kk) {
+      const int ci = ci0 + 2 * kk + khalf;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) dst[kk][s] = (ci < cin && pok[s]) ? inb[(size_t)ci * P + pl[s]] : 0.0f;
     }
-    __syncthreads();
+  };
+  load_b(0, bcur);
+  const float *wbase = wp + ((size_t)khalf * cout_pad + co0 + l31) * 4;
+  const size_t wchunk_stride = (size_t)2 * cout_pad * 4;
+
+  for (int ci0 = 0; ci0 < cin; ci0 += PW_CK) {
+    const int chunk0 = ci0 >> 3;
+    f32x4 a_all[PW_CK / 8][MT];
 #pragma unroll
     for (int sub = 0; sub < PW_CK / 8; ++sub) {
-      if (ci0 + sub * 8 >= cin) break;
-      const int chunk = (ci0 >> 3) + sub;
-      f32x4 a[MT];
+      const int ch = chunk0 + sub < nchunk8 ? chunk0 + sub : nchunk8 - 1;  // clamp: stays inside the buffer
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
-        a[m] = *(const f32x4 *)(wp + (((size_t)chunk * 2 + khalf) * cout_pad + co0 + m * 32 + l31) * 4);
+      for (int m = 0; m < MT; ++m) a_all[sub][m] = *(const f32x4 *)(wbase + (size_t)ch * wchunk_stride + (size_t)m * 32 * 4);
+    }
+    if (ci0 + PW_CK < cin) load_b(ci0 + PW_CK, bnxt);
+    if (XF) {
+#pragma unroll
+      for (int kk = 0; kk < PW_CK / 2; ++kk) {
+        const int ci = ci0 + 2 * kk + khalf;
+        if (ci < cin) {
+          const float sc = in_scale[b * cin + ci], sh = in_shift[b * cin + ci];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            float v = bcur[kk][s] * sc + sh;
+            if (in_swish) v = swishf(v);
+            bcur[kk][s] = pok[s] ? v : 0.0f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < PW_CK / 8; ++sub) {
+      if (chunk0 + sub >= nchunk8) break;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        float bf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) bf[s] = tile[sub * 8 + 2 * kk + khalf][wave * 64 + s * 32 + l31];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
-            acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][kk], bf[s], acc[m][s], 0, 0, 0);
+            acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_all[sub][m][kk], bcur[sub * 4 + kk][s], acc[m][s], 0, 0, 0);
       }
+    }
+    if (ci0 + PW_CK < cin) {
+#pragma unroll
+      for (int kk = 0; kk < PW_CK / 2; ++kk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bcur[kk][s] = bnxt[kk][s];
     }
   }
 
@@ -101,9 +130,9 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cou
       float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int p = p0 + wave * 64 + s * 32 + l31;
+        const int p = pl[s];
         const float v = acc[m][s][r] + bv;
-        if (co < cout && p < P) {
+        if (co < cout && pok[s]) {
           outb[(size_t)co * P + p] = v;
           if (STATS) {
             s1 += v;
@@ -112,12 +141,9 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cou
         }
       }
       if (STATS) {
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off);
-          s2 += __shfl_xor(s2, off);
-        }
-        if (l31 == 0 && co < cout) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && co < cout) {
           float *q = stats_part + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * cout + co) * 2;
           q[0] = s1;
           q[1] = s2;
@@ -182,11 +208,8 @@ extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, c
                                            void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  // the operand tile (and its folded activation) is re-staged once per output-channel block: use 128-wide
-  // blocks for wide layers as long as the grid still covers the chip twice
   const long wgs128 = (long)((npos + 255) / 256) * ((cout + 127) / 128) * b;
-  if (cout > 64 && wgs128 >= 512)
-    return pw_launch<4>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, s);
+  (void)wgs128;  // 128-wide blocks measured slower (1 wave/SIMD at 377 registers): 64-wide is the default
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
                                   stats_part, s)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,

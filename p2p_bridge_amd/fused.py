@@ -106,6 +106,12 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
     check(x, F32, "x")
     b, ci, p = x.shape
     co = conv.weight.shape[0]
+    if in_scale is not None and (co + 63) // 64 >= 3:
+        # every 64-channel output block re-applies the folded norm+Swish to its operand: for wide layers one
+        # elementwise pre-pass (1 read + 1 write of the input) is cheaper than >= 3 recomputations
+        x = affine_act(x, in_scale, in_shift, swish)
+        in_scale = in_shift = None
+        swish = False
     wp = pack_pointwise_weight(conv, ci_lo, ci_hi)
     y = torch.empty(b, co, p, dtype=F32, device=x.device)
     st = None
