@@ -74,13 +74,17 @@ extern "C" int p2pb_voxel_coords(int b, int n, int r, int normalize, float eps, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// avg_voxelize forward, deterministic:
-//   1 count : ind[i] = x*r2 + y*r + z ; cnt[ind]++           (int atomics: order independent)
-//   2 scan  : cur[v] = exclusive prefix of cnt over the cloud  (one workgroup per cloud)
-//   3 fill  : list[cur[v]++] = i                              (order inside a voxel arbitrary ...)
-//   4 sort  : ... so every voxel's few point ids are sorted ascending
-//   5 gather: out[c,v] = sum_{i in voxel v, ascending} feat[c,i] * (1/cnt)  and zeros elsewhere
-// Step 5 writes the whole [C,r^3] grid with lane-consecutive stores (the dominant HBM traffic).
+// avg_voxelize forward, deterministic (each voxel sums its points in ascending point index):
+//   1 count  : ind[i] = x*r2 + y*r + z ; cnt[ind]++                    (int atomics: order independent)
+//   2 scan   : cur[v] = exclusive prefix of cnt; occ[] = compacted list of non-empty voxels, nocc
+//   3 fill   : list[cur[v]++] = i                                     (order inside a voxel arbitrary ...)
+//   4 sort   : ... one WAVE per non-empty voxel ranks its ids by counting and writes slist[] ascending
+//   5 zero   : the dense [C, r^3] grid is streamed out as zeros (16-byte stores; the dominant HBM traffic:
+//              a PU-Net patch occupies only ~2-3 % of a 32^3 grid)
+//   6 gather : one wave per non-empty voxel, lane = channel: acc += feat[c, p] * (1/cnt) over the voxel's
+//              points in ascending order, then out[c, v] = acc
+// The point cloud of a patch is a 2-manifold, so a voxel that is occupied holds ~10 points (8192 points
+// over ~800 voxels at r = 32): work is organised per occupied voxel, not per voxel.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void vox_count_kernel(int n, int r, const int *__restrict__ coords,
                                                         int *__restrict__ ind, int *__restrict__ cnt) {
@@ -93,29 +97,51 @@ __global__ __launch_bounds__(256) void vox_count_kernel(int n, int r, const int 
   atomicAdd(cnt + (size_t)b * r * r * r + v, 1);
 }
 
-__global__ __launch_bounds__(1024) void vox_scan_kernel(int r3, const int *__restrict__ cnt, int *__restrict__ cur) {
+// block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive prefix, total in *tot
+__device__ __forceinline__ int block_exscan_1024(int x, int *wsum, int *tot) {
+  const int t = threadIdx.x;
+  int inc = x;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(inc, d);
+    if ((t & 63) >= d) inc += y;
+  }
+  __syncthreads();  // wsum may still be read from a previous call
+  if ((t & 63) == 63) wsum[t >> 6] = inc;
+  __syncthreads();
+  int base = 0, all = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < (t >> 6)) base += wsum[w];
+    all += wsum[w];
+  }
+  *tot = all;
+  return base + inc - x;
+}
+
+__global__ __launch_bounds__(1024) void vox_scan_kernel(int n, int r3, const int *__restrict__ cnt,
+                                                        int *__restrict__ cur, int *__restrict__ occ,
+                                                        int *__restrict__ nocc) {
   __shared__ int wsum[16];
   const int t = threadIdx.x;
   const int *c = cnt + (size_t)blockIdx.x * r3;
   int *o = cur + (size_t)blockIdx.x * r3;
+  int *oc = occ + (size_t)blockIdx.x * n;
   const int per = (r3 + 1023) / 1024;
   const int beg = t * per, end = min(beg + per, r3);
-  int s = 0;
-  for (int k = beg; k < end; ++k) s += c[k];
-  // inclusive wave scan of s
-  int x = s;
-  for (int d = 1; d < 64; d <<= 1) {
-    int y = __shfl_up(x, d);
-    if ((t & 63) >= d) x += y;
+  int s = 0, k = 0;
+  for (int v = beg; v < end; ++v) {
+    const int x = c[v];
+    s += x;
+    k += x > 0;
   }
-  if ((t & 63) == 63) wsum[t >> 6] = x;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < (t >> 6); ++w) base += wsum[w];
-  int run = base + x - s;  // exclusive prefix of this thread's chunk
-  for (int k = beg; k < end; ++k) {
-    o[k] = run;
-    run += c[k];
+  int tot;
+  int run = block_exscan_1024(s, wsum, &tot);
+  int kpos = block_exscan_1024(k, wsum, &tot);
+  if (t == 0) nocc[blockIdx.x] = tot;
+  for (int v = beg; v < end; ++v) {
+    const int x = c[v];
+    o[v] = run;
+    run += x;
+    if (x > 0) oc[kpos++] = v;
   }
 }
 
@@ -129,57 +155,56 @@ __global__ __launch_bounds__(256) void vox_fill_kernel(int n, int r3, const int 
   list[(size_t)b * n + pos] = i;
 }
 
+// one wave per non-empty voxel: slist[start + rank(id)] = id, rank by counting (ids are distinct)
 __global__ __launch_bounds__(256) void vox_sort_kernel(int n, int r3, const int *__restrict__ cnt,
-                                                       const int *__restrict__ cur, int *__restrict__ list) {
+                                                       const int *__restrict__ cur, const int *__restrict__ occ,
+                                                       const int *__restrict__ nocc, const int *__restrict__ list,
+                                                       int *__restrict__ slist) {
   const int b = blockIdx.y;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= r3) return;
-  const int c = cnt[(size_t)b * r3 + v];
-  if (c < 2) return;
-  int *seg = list + (size_t)b * n + (cur[(size_t)b * r3 + v] - c);  // cur now points at the segment end
-  for (int a = 1; a < c; ++a) {
-    int key = seg[a], q = a - 1;
-    while (q >= 0 && seg[q] > key) {
-      seg[q + 1] = seg[q];
-      --q;
-    }
-    seg[q + 1] = key;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= nocc[b]) return;
+  const int lane = lane_id();
+  const int v = occ[(size_t)b * n + k];
+  const int cn = cnt[(size_t)b * r3 + v];
+  const int start = cur[(size_t)b * r3 + v] - cn;  // cur points at the segment end after the fill
+  const int *seg = list + (size_t)b * n + start;
+  int *dst = slist + (size_t)b * n + start;
+  for (int l0 = 0; l0 < cn; l0 += 64) {
+    const int l = l0 + lane;
+    const int mine = l < cn ? seg[l] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < cn; ++j) rank += seg[j] < mine;  // wave-uniform address: one broadcast load
+    if (l < cn) dst[rank] = mine;
   }
 }
 
-template <int CC>
 __global__ __launch_bounds__(256) void vox_gather_kernel(int c, int n, int r3, const int *__restrict__ cnt,
-                                                         const int *__restrict__ cur, const int *__restrict__ list,
+                                                         const int *__restrict__ cur, const int *__restrict__ occ,
+                                                         const int *__restrict__ nocc, const int *__restrict__ slist,
                                                          const float *__restrict__ feat, float *__restrict__ out) {
-  const int b = blockIdx.z;
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= r3) return;
-  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= nocc[b]) return;
+  const int lane = lane_id();
+  const int v = occ[(size_t)b * n + k];
+  const int cn = cnt[(size_t)b * r3 + v];
+  const int *seg = slist + (size_t)b * n + (cur[(size_t)b * r3 + v] - cn);
+  const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
   const float *f = feat + (size_t)b * c * n;
   float *o = out + (size_t)b * c * r3 + v;
-  const int cn = cnt[(size_t)b * r3 + v];
-  if (cn == 0) {
-    for (int j = c0; j < c1; ++j) o[(size_t)j * r3] = 0.0f;
-    return;
-  }
-  const int *seg = list + (size_t)b * n + (cur[(size_t)b * r3 + v] - cn);
-  const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
-  int ids[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) ids[q] = q < cn ? seg[q] : 0;
-  for (int j = c0; j < c1; ++j) {
-    const float *fj = f + (size_t)j * n;
-    float acc = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (q < cn) acc += fj[ids[q]] * div;
-    for (int q = 8; q < cn; ++q) acc += fj[seg[q]] * div;
-    o[(size_t)j * r3] = acc;
+  for (int c0 = 0; c0 < c; c0 += 64) {
+    const int ch = c0 + lane;
+    if (ch < c) {
+      const float *fj = f + (size_t)ch * n;
+      float acc = 0.0f;
+      for (int q = 0; q < cn; ++q) acc += fj[seg[q]] * div;
+      o[(size_t)ch * r3] = acc;
+    }
   }
 }
 
 extern "C" size_t p2pb_avg_voxelize_ws_bytes(int b, int n, int r) {
-  return sizeof(int) * ((size_t)b * r * r * r + (size_t)b * n);
+  return sizeof(int) * ((size_t)b * r * r * r + 3 * (size_t)b * n + (size_t)b);
 }
 
 extern "C" int p2pb_avg_voxelize_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind,
@@ -189,15 +214,21 @@ extern "C" int p2pb_avg_voxelize_forward(int b, int c, int n, int r, const int *
   const int r3 = r * r * r;
   int *cur = (int *)ws;
   int *list = cur + (size_t)b * r3;
+  int *slist = list + (size_t)b * n;
+  int *occ = slist + (size_t)b * n;
+  int *nocc = occ + (size_t)b * n;
   int e = p2pb_zero_async(cnt, sizeof(int) * (size_t)b * r3, s);
   if (e != 0) return e;
   hipLaunchKernelGGL(vox_count_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r, coords, ind, cnt);
-  hipLaunchKernelGGL(vox_scan_kernel, dim3(b), dim3(1024), 0, s, r3, cnt, cur);
+  hipLaunchKernelGGL(vox_scan_kernel, dim3(b), dim3(1024), 0, s, n, r3, cnt, cur, occ, nocc);
   hipLaunchKernelGGL(vox_fill_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r3, ind, cur, list);
-  hipLaunchKernelGGL(vox_sort_kernel, dim3(cdiv(r3, 256), b), dim3(256), 0, s, n, r3, cnt, cur, list);
-  constexpr int CC = 16;
-  hipLaunchKernelGGL(vox_gather_kernel<CC>, dim3(cdiv(r3, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n, r3, cnt, cur,
-                     list, feat, out);
+  const int maxocc = n < r3 ? n : r3;
+  hipLaunchKernelGGL(vox_sort_kernel, dim3(cdiv(maxocc, 4), b), dim3(256), 0, s, n, r3, cnt, cur, occ, nocc, list,
+                     slist);
+  e = p2pb_zero_async(out, sizeof(float) * (size_t)b * c * r3, s);
+  if (e != 0) return e;
+  hipLaunchKernelGGL(vox_gather_kernel, dim3(cdiv(maxocc, 4), b), dim3(256), 0, s, c, n, r3, cnt, cur, occ, nocc, slist,
+                     feat, out);
   return p2pb_launch_status();
 }
 
