@@ -98,6 +98,11 @@ int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float
  *   points f32[b,3,n], centers f32[b,3,m], cfeat f32[b,c,m] -> idx i32[b,3,n], w f32[b,3,n], out f32[b,c,n] */
 int p2pb_three_nn_interpolate_forward(int b, int c, int m, int n, const float *points, const float *centers,
                                       const float *cfeat, int *idx, float *w, float *out, void *stream);
+/* the same op in two launches (search: coordinates only; interpolation: features), for callers that
+ * overlap the geometry pipeline with the feature path */
+int p2pb_three_nn(int b, int m, int n, const float *points, const float *centers, int *idx, float *w, void *stream);
+int p2pb_three_interpolate(int b, int c, int m, int n, const float *cfeat, const int *idx, const float *w,
+                           float *out, void *stream);
 int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
                                        const float *w, float *grad_x, void *stream);
 

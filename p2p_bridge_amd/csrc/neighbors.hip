@@ -244,6 +244,25 @@ extern "C" int p2pb_three_nn_interpolate_forward(int b, int c, int m, int n, con
   return p2pb_launch_status();
 }
 
+// the two halves of the op as separate entry points: the search depends on coordinates only, so the
+// sampler runs it on a side stream (geometry pipeline) while the feature path is still busy
+extern "C" int p2pb_three_nn(int b, int m, int n, const float *points, const float *centers, int *idx, float *w,
+                             void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
+  hipLaunchKernelGGL(three_nn_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, m, points, centers,
+                     w, idx);
+  return p2pb_launch_status();
+}
+
+extern "C" int p2pb_three_interpolate(int b, int c, int m, int n, const float *cfeat, const int *idx, const float *w,
+                                      float *out, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
+  constexpr int CC = 16;
+  hipLaunchKernelGGL(three_interp_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c,
+                     m, n, cfeat, idx, w, out);
+  return p2pb_launch_status();
+}
+
 template <int CC>
 __global__ __launch_bounds__(256) void three_interp_grad_kernel(int c, int n, int m, const float *__restrict__ gy,
                                                                 const int *__restrict__ indices,

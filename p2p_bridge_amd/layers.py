@@ -13,6 +13,8 @@ __all__ = ["avg_voxelize", "trilinear_devoxelize", "ball_query", "pvcnn_grouping
            "furthest_point_sample_pvcnn", "nearest_neighbor_interpolate", "voxel_coords"]
 
 voxel_coords = _ext.voxel_coords
+three_nn = _ext.three_nn
+three_interpolate = _ext.three_interpolate
 
 
 class AvgVoxelization(Function):

@@ -178,3 +178,25 @@ def three_nearest_neighbors_interpolate_backward(grad_y, indices, weights, m):
     call("p2pb_three_nn_interpolate_backward", _i(b), _i(c), _i(n), _i(int(m)), ptr(grad_y), ptr(indices),
          ptr(weights), ptr(gx), stream_ptr())
     return gx
+
+
+def three_nn(points_coords, centers_coords):
+    """build addition: the search half of the op -> (idx i32[B,3,N], w f32[B,3,N])"""
+    check(points_coords, F32, "points_coords"), check(centers_coords, F32, "centers_coords")
+    b, _, n = points_coords.shape
+    m = centers_coords.shape[2]
+    idx = torch.empty(b, 3, n, dtype=I32, device=points_coords.device)
+    w = torch.empty(b, 3, n, dtype=F32, device=points_coords.device)
+    call("p2pb_three_nn", _i(b), _i(m), _i(n), ptr(points_coords), ptr(centers_coords), ptr(idx), ptr(w), stream_ptr())
+    return idx, w
+
+
+def three_interpolate(centers_features, idx, w):
+    """build addition: the interpolation half -> f32[B,C,N]"""
+    check(centers_features, F32, "centers_features"), check(idx, I32, "idx"), check(w, F32, "w")
+    b, c, m = centers_features.shape
+    n = idx.shape[2]
+    out = torch.empty(b, c, n, dtype=F32, device=centers_features.device)
+    call("p2pb_three_interpolate", _i(b), _i(c), _i(m), _i(n), ptr(centers_features), ptr(idx), ptr(w), ptr(out),
+         stream_ptr())
+    return out

@@ -48,6 +48,7 @@ class PVCData:
     lower_features: torch.Tensor = None
     time_emb: torch.Tensor = None
     cond: Any = None
+    geo: Any = None  # build addition: precomputed geometry (Geometry) of this evaluation, inference only
 
 
 # ------------------------------------------------------------------------------------ small modules
@@ -284,6 +285,7 @@ class PointNetSAModule(nn.Module):
     def __init__(self, num_centers, radius, num_neighbors, in_channels, out_channels, gn_groups=8, cond_dim=0):
         super().__init__()
         self.num_centers = num_centers
+        self.level = -1  # set by PVCNN2Unet: index of this stage in the geometry pipeline
         self.out_channels = out_channels[-1]
         self.groupers = nn.ModuleList([BallQuery(radius, num_neighbors, True)])
         self.mlps = nn.ModuleList([SharedMLP(in_channels + 3, out_channels, dim=2, gn_groups=gn_groups,
@@ -291,6 +293,15 @@ class PointNetSAModule(nn.Module):
 
     def forward(self, data: PVCData) -> PVCData:
         coords = data.coords[:, :3]
+        if data.geo is not None:  # inference: FPS + ball query were produced on the geometry stream
+            centers, nidx = data.geo.take_sa(self.level)
+            if data.time_emb is not None:
+                data.time_emb = data.time_emb[:, :, : centers.shape[-1]]
+            rel = L.pvcnn_grouping(coords.contiguous(), nidx) - centers.unsqueeze(-1)
+            grouped = torch.cat([rel, L.pvcnn_grouping(data.features, nidx)], dim=1)
+            data.features = self.mlps[0].run(grouped, data.cond, reduce_max=True)
+            data.coords = centers
+            return data
         centers = L.furthest_point_sample_pvcnn(coords, self.num_centers)
         if data.time_emb is not None:
             data.time_emb = data.time_emb[:, :, : centers.shape[-1]]
@@ -305,10 +316,15 @@ class PointNetFPModule(nn.Module):
 
     def __init__(self, in_channels, out_channels, gn_groups=8, cond_dim=0):
         super().__init__()
+        self.level = -1
         self.mlp = SharedMLP(in_channels, list(out_channels), dim=1, gn_groups=gn_groups, cond_dim=cond_dim)
 
     def forward(self, data: PVCData) -> PVCData:
-        x = L.nearest_neighbor_interpolate(data.coords, data.lower_coords, data.lower_features)
+        if data.geo is not None:
+            idx, w = data.geo.take_fp(self.level)
+            x = L.three_interpolate(data.lower_features.contiguous(), idx, w)
+        else:
+            x = L.nearest_neighbor_interpolate(data.coords, data.lower_coords, data.lower_features)
         if data.features is not None:
             x = torch.cat([x, data.features], dim=1)
         if data.time_emb is not None:
@@ -452,6 +468,59 @@ def stage_plan(npoints: int, channels: List[int], n_sa_blocks: List[int], n_fp_b
     return dict(sa=sa, fp=fp, bottleneck=sa[-1]["mlp_out"][-1], out=cin)
 
 
+class Geometry:
+    """Everything in one network evaluation that depends on coordinates only -- FPS centres, ball-query
+    neighbour lists, 3-NN indices/weights for every level -- computed on a SIDE stream while the main
+    stream runs the dense feature path (global embedding GEMMs, first PVConv). FPS is a latency-bound
+    chain that occupies one CU per cloud (32 of 256 CUs at B = 32); overlapping it removes it from the
+    critical path. Per-level events let the consumer wait for exactly what it needs; under hipGraph capture
+    the fork/join becomes two parallel branches of the graph."""
+
+    def __init__(self, plan, coords, side):
+        main = torch.cuda.current_stream()
+        self.main = main
+        side.wait_stream(main)
+        self.sa, self.fp = [], []
+        with torch.cuda.stream(side):
+            level_coords = []
+            c = coords.contiguous()
+            for st in plan["sa"]:
+                level_coords.append(c)
+                idx = L._ext.furthest_point_sampling_forward(c, st["centers"])
+                cen = L._ext.gather_features_forward(c, idx)
+                nidx = L._ext.ball_query(cen, c, st["radius"], st["neighbors"])
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self.sa.append((cen, nidx, ev))
+                c = cen
+            lower = c
+            for j in range(len(plan["fp"])):
+                pts = level_coords[-1 - j]
+                idx, w = L._ext.three_nn(pts, lower)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self.fp.append((idx, w, ev))
+                lower = pts
+        self.join = torch.cuda.Event()
+        self.join.record(side)
+
+    def _take(self, items, level):
+        *vals, ev = items[level]
+        self.main.wait_event(ev)
+        for v in vals:
+            v.record_stream(self.main)
+        return vals
+
+    def take_sa(self, level):
+        return self._take(self.sa, level)
+
+    def take_fp(self, level):
+        return self._take(self.fp, level)
+
+    def finish(self):
+        self.main.wait_event(self.join)
+
+
 class _Stage(nn.Sequential):
     """a stage with several blocks is indexable like the reference's nn.Sequential (`sa_layers.0.1...`)"""
 
@@ -504,6 +573,8 @@ class PVCNN2Unet(nn.Module):
                                            cond_dim=cd))
             sa_layers.append(blocks[0] if len(blocks) == 1 else _Stage(*blocks))
         self.sa_layers = nn.ModuleList(sa_layers)
+        for i, stage in enumerate(self.sa_layers):
+            (stage[-1] if isinstance(stage, _Stage) else stage).level = i
         attn_type = str(_get(pvd, "attention_type", "linear")).lower()
         if attn_type != "linear":
             raise NotImplementedError("only attention_type='linear' is on the hot path (SURVEY.md section 2 #4)")
@@ -513,6 +584,9 @@ class PVCNN2Unet(nn.Module):
             blocks = [PointNetFPModule(st["mlp_in"], st["mlp_out"], cond_dim=cd)] + [pv(s) for s in st["convs"]]
             fp_layers.append(blocks[0] if len(blocks) == 1 else _Stage(*blocks))
         self.fp_layers = nn.ModuleList(fp_layers)
+        for j, stage in enumerate(self.fp_layers):
+            (stage[0] if isinstance(stage, _Stage) else stage).level = j
+        self._side_streams = {}
         out_mlp = _get(pvd, "out_mlp", 128)
         self.classifier = nn.ModuleList([SharedMLP(plan["out"], out_mlp, cond_dim=0), nn.Dropout(dropout),
                                          nn.Conv1d(out_mlp, out_dim, 1)])
@@ -521,6 +595,7 @@ class PVCNN2Unet(nn.Module):
         # models/unet_pvc.py:162-163); same float64 -> float32 values
         freq = torch.from_numpy(np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))).float()
         self.register_buffer("_temb_freq", freq, persistent=False)
+        self.overlap_geometry = True  # inference: run FPS / ball query / 3-NN on a side stream (Geometry)
 
     def get_timestep_embedding(self, timesteps, device=None):
         if timesteps.dim() == 2 and timesteps.shape[1] == 1:
@@ -543,6 +618,13 @@ class PVCNN2Unet(nn.Module):
         from . import fused
 
         use_fused = fused.enabled(self, x)
+        geo = None
+        if use_fused and self.overlap_geometry:
+            # fork the coordinate-only pipeline FIRST, so it overlaps with everything enqueued below
+            dev = x.device
+            if dev not in self._side_streams:
+                self._side_streams[dev] = torch.cuda.Stream(device=dev)
+            geo = Geometry(self.plan, coords, self._side_streams[dev])
         if self.embed_feats is not None:
             src = coords if self.extra_feature_channels == 0 else feats
             if use_fused:
@@ -558,7 +640,7 @@ class PVCNN2Unet(nn.Module):
             if t.dim() == 0:
                 t = t.view(1).expand(B)
             time_emb = self.embedf(self.get_timestep_embedding(t))[:, :, None].expand(-1, -1, N)
-        data = PVCData(features=feats, coords=coords, time_emb=time_emb, cond=cond)
+        data = PVCData(features=feats, coords=coords, time_emb=time_emb, cond=cond, geo=geo)
 
         skips, level_coords = [feats], []
         for i, stage in enumerate(self.sa_layers):
@@ -574,7 +656,9 @@ class PVCNN2Unet(nn.Module):
         for j, stage in enumerate(self.fp_layers):
             lower = data.features if data.time_emb is None else torch.cat([data.features, data.time_emb], dim=1)
             data = stage(PVCData(features=skips[-1 - j], coords=level_coords[-1 - j], lower_coords=data.coords,
-                                 lower_features=lower, time_emb=data.time_emb, cond=data.cond))
+                                 lower_features=lower, time_emb=data.time_emb, cond=data.cond, geo=geo))
+        if geo is not None:
+            geo.finish()
 
         if use_fused:  # classifier: SharedMLP(GroupNorm) -> Dropout(eval: identity) -> Conv1d, two fused GEMMs
             c0 = self.classifier[0]
