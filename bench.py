@@ -53,19 +53,19 @@ def conv_roofline(model, B, reps=10):
     flops = 2.0 * B * r ** 3 * 27 * conv.in_channels * conv.out_channels  # algorithmic FLOPs of one launch
     with torch.no_grad():
         for _ in range(3):
-            fused.conv3d_k3(x, conv, sc, sh, swish=True)
+            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fused.conv3d_k3(x, conv, sc, sh, swish=True)
+            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": f"conv3d_k3_kernel<32,2,true,true> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
+            "kernel": f"conv3d_k3_kernel<32,compact,2,XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
                       f"(fp_layers.3.1.voxel_layers.4)",
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 

@@ -156,6 +156,19 @@ int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, con
                            const float *bias, const float *in_scale, const float *in_shift, int in_swish,
                            float *out, float *stats_part, void *stream);
 
+/* Sparse-aware form (exact): in_sub f32[b,cin] is subtracted from the transformed operand, out_class
+ * f32[b,27,cout] replaces bias per boundary class (low / interior / high along d,h,w) -- see conv3d.hip:
+ * conv(x) = conv(x - a) + conv(a). flags bit 0: skip all-zero operand tiles; bit 1: compact 4x8x8 bricks. */
+int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+                              const float *bias, const float *out_class, const float *in_scale,
+                              const float *in_shift, int in_swish, const float *in_sub, int flags, float *out,
+                              float *stats_part, void *stream);
+/* a[b,cin] = xf(prev_bias[cin]) (the operand's far-field constant) and k_out[b,27,cout] = conv(a) + bias per
+ * boundary class, for p2pb_conv3d_k3_forward_ex */
+int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
+                             const float *in_shift, int in_swish, const float *wt_packed, const float *bias,
+                             float *a, float *k_out, void *stream);
+
 /* GroupNorm (+AdaGN style, models/modules.py:341-358) folded into a per-(sample, channel) affine:
  * AdaGN(GN(x)) == x*scale + shift. part f32[b,nslots,c,2] partial {sum,sumsq}; gamma/beta f32[c] or
  * NULL; style f32[b,2c] = (factor | bias) or NULL; chmean (optional) = per-channel mean of the

@@ -7,18 +7,28 @@
 //
 // Formulation: implicit GEMM   out[co, p] = sum_{tap, ci} W[tap][ci][co] * in[ci, p + off(tap)]
 //   M = output channels (MFMA rows), N = voxels (MFMA columns), K = 27 * Cin.
-// N is the voxel index on purpose: an accumulator register then holds 32 consecutive w-voxels of one
-// output channel across lanes 0..31, so the NCDHW store is lane-consecutive (128-byte segments).
+// N is the voxel index on purpose: an accumulator register then holds consecutive w-voxels of one
+// output channel across lanes 0..31, so the NCDHW store is lane-consecutive.
 //
-// Workgroup = 256 threads (4 waves) -> 256 voxels (8 N-tiles of 32) x NC output channels of one sample.
-// Per chunk of CK input channels the workgroup stages the zero-padded halo brick
-// [CK][TD+2][TH+2][TW+2] into LDS once (coalesced rows, optional per-channel affine + Swish applied on
-// the way in: that is how the preceding AdaGN + Swish is fused away), then every wave walks the 27
-// taps reading its B fragments from LDS at constant offsets; A fragments (packed weights
-// [27][CinPad][CoutPad]) come straight from L1/L2 -- all 4 waves of a workgroup and all workgroups of a
-// launch read the same few hundred KB.
-// Epilogue: + bias, store, and optionally per-(sample, channel) sum / sum-of-squares partials for the
-// GroupNorm that follows (one partial per workgroup, reduced deterministically by a second tiny kernel).
+// Workgroup = 256 threads (4 waves) -> one brick of 256 voxels (8 N-tiles of 32) x NC output channels of
+// one sample. Per chunk of CK input channels the workgroup stages the zero-padded halo brick
+// [CK][TD+2][TH+2][TW+2] into LDS once (optional per-channel affine + Swish applied on the way in: that is
+// how the preceding AdaGN + Swish is fused away), then every wave walks the 27 taps reading its B
+// fragments from LDS at constant offsets; A fragments (packed weights) are 16-byte L1/L2 loads.
+// Epilogue: + bias, store, and per-(sample, brick, wave, channel) {sum, sum of squares} partials for the
+// GroupNorm that follows (reduced deterministically by gn_affine_kernel).
+//
+// Sparsity (exact, not approximate). A PU-Net patch is a 2-manifold: ~2.5 % of a 32^3 grid is occupied.
+//   * first convolution of a PVConv: the input is zero away from the surface -> a (brick, chunk) whose
+//     staged halo tile is all zero contributes exactly +0 and its 27x4 MFMA steps are skipped;
+//   * second convolution: its input swish(affine(conv0)) equals a per-channel constant a[b,ci] wherever
+//     conv0's input was zero (conv0 = bias there, exactly). By linearity
+//         conv(x) = conv(x - a) + conv(a),
+//     x - a is exactly zero in the far field (same skip applies) and conv(a) -- a constant field with
+//     zero padding -- depends only on which of the 27 boundary classes (low/interior/high per axis) the
+//     voxel is in: K[b, class, co] = bias + sum_{taps inside} sum_ci W*a, added in the epilogue.
+// Every output voxel and every statistic is still produced by this kernel; only all-zero MFMA work is
+// skipped. Compact 4x8x8 bricks (instead of full-row bricks) make the zero test fine-grained in 3-D.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,24 +36,33 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CONV_CK 8  // input channels per LDS stage
 
-template <int R>
-struct ConvGeom;  // brick = TD x TH x TW voxels = 8 N-tiles of 32; NT_* = N-tile shape (d,h,w)
+// brick = TD x TH x TW voxels = 8 N-tiles of 32 (2 for R = 4); an N-tile = ND x NH x TW voxels
+template <int R, bool COMPACT>
+struct ConvGeom;
 template <>
-struct ConvGeom<32> {
+struct ConvGeom<32, false> {
   static constexpr int TD = 2, TH = 4, TW = 32, ND = 1, NH = 1;
 };
 template <>
-struct ConvGeom<16> {
+struct ConvGeom<16, false> {
   static constexpr int TD = 2, TH = 8, TW = 16, ND = 1, NH = 2;
 };
 template <>
-struct ConvGeom<8> {
+struct ConvGeom<8, false> {
   static constexpr int TD = 4, TH = 8, TW = 8, ND = 1, NH = 4;
 };
 template <>
-struct ConvGeom<4> {
+struct ConvGeom<4, false> {
   static constexpr int TD = 4, TH = 4, TW = 4, ND = 2, NH = 4;
 };
+template <>
+struct ConvGeom<32, true> : ConvGeom<8, false> {};
+template <>
+struct ConvGeom<16, true> : ConvGeom<8, false> {};
+template <>
+struct ConvGeom<8, true> : ConvGeom<8, false> {};
+template <>
+struct ConvGeom<4, true> : ConvGeom<4, false> {};
 
 // Swish with the hardware exp2 / reciprocal units: v * rcp(1 + exp2(-v*log2(e))). ~1e-6 relative error
 // (both units are 1 ulp), an order of magnitude below the fp32 summation-order noise of the dense layers
@@ -53,27 +72,52 @@ __device__ __forceinline__ float fast_swish(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
 }
 
-// MT = 32-row output-channel tiles per workgroup (NC = 32*MT), XF = apply affine(+swish) to the input
-template <int R, int MT, bool XF, bool STATS>
+// the folded operand transform, ONE definition used by the staging code and by far_value_kernel so that
+// "x - a" is bit-exactly zero wherever x is the far-field constant
+__device__ __forceinline__ float xf_apply(float v, float sc, float sh, int swish) {
+  v = v * sc + sh;
+  return swish ? fast_swish(v) : v;
+}
+
+// MT = 32-row output-channel tiles per workgroup (NC = 32*MT), XF = apply affine(+swish)(-sub) to the input
+template <int R, bool COMPACT, int MT, bool XF>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                         const float *__restrict__ in, const float *__restrict__ wt,
                                                         const float *__restrict__ bias,
+                                                        const float *__restrict__ out_class,
                                                         const float *__restrict__ in_scale,
                                                         const float *__restrict__ in_shift, int in_swish,
+                                                        const float *__restrict__ in_sub, int skip_zero,
                                                         float *__restrict__ out, float *__restrict__ stats_part) {
-  using G = ConvGeom<R>;
+  using G = ConvGeom<R, COMPACT>;
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
   constexpr int PLANE = HD * HH * HW;
   constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;  // N-tiles in the brick (8, or 2 for R=4)
-  constexpr int BH = R / G::TH;                          // bricks per sample along h
+  constexpr int BH = R / G::TH, BW = R / G::TW;          // bricks per sample along h, w
   constexpr int NE = (CONV_CK * PLANE + 255) / 256;      // staged elements per thread per chunk
   constexpr int R3 = R * R * R;
   __shared__ float tile[CONV_CK * PLANE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
-  const int brick = blockIdx.x;
-  const int d0 = (brick / BH) * G::TD, h0 = (brick % BH) * G::TH;
+  // blockIdx.x -> brick. Workgroups are dealt to the 8 XCDs round-robin (id mod 8); with the zero-tile skip
+  // the active bricks hug the surface, and a linear map would park a whole (h,w) column of bricks -- i.e.
+  // all of the surface or none of it -- on one XCD. The compact geometry therefore uses a diagonal hash:
+  // d-index = (x mod BD) - (3*bh + 5*bw), so consecutive ids walk diagonally through the grid.
+  constexpr int BD = R / G::TD;
+  int bd, bh, bw;
+  if (COMPACT) {
+    const int hi = blockIdx.x / BD, lo = blockIdx.x % BD;
+    bh = hi / BW;
+    bw = hi % BW;
+    bd = (lo + 8 * BD - (3 * bh + 5 * bw)) % BD;
+  } else {
+    bd = blockIdx.x / (BH * BW);
+    bh = (blockIdx.x / BW) % BH;
+    bw = blockIdx.x % BW;
+  }
+  const int brick = (bd * BH + bh) * BW + bw;
+  const int d0 = bd * G::TD, h0 = bh * G::TH, w0 = bw * G::TW;
   const int co0 = blockIdx.y * (32 * MT);
   const int b = blockIdx.z;
 
@@ -99,7 +143,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
     const int e = tid + k * 256;
     const int ci = e / PLANE, rem = e % PLANE;
     const int dz = rem / (HH * HW), hy = (rem / HW) % HH, wx = rem % HW;
-    const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = wx - 1;
+    const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = w0 - 1 + wx;
     const bool ok = e < CONV_CK * PLANE && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R &&
                     (unsigned)w < (unsigned)R;
     gpk[k] = ok ? ((ci << 16) | ((d * R + h) * R + w)) : -1;
@@ -127,6 +171,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
 
   for (int ci0 = 0; ci0 < cin; ci0 += CONV_CK) {
     __syncthreads();  // everyone is done reading the previous chunk's tile
+    int nonzero = 0;
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
       const int e = tid + k * 256;
@@ -135,14 +180,17 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
         const int g = gpk[k];
         const int ci = ci0 + ((g >> 16) & 7);
         if (g >= 0 && ci < cin) {
-          v = v * in_scale[b * cin + ci] + in_shift[b * cin + ci];
-          if (in_swish) v = fast_swish(v);
+          v = xf_apply(v, in_scale[b * cin + ci], in_shift[b * cin + ci], in_swish);
+          if (in_sub) v -= in_sub[b * cin + ci];
         }
       }
+      nonzero |= (v != 0.0f);
       if (e < CONV_CK * PLANE) tile[e] = v;
     }
-    __syncthreads();
+    // barrier + "is any staged value non-zero" in one; an all-zero tile contributes exactly +0
+    const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
     if (ci0 + CONV_CK < cin) stage_load(ci0 + CONV_CK);  // next chunk's loads fly during the MFMAs
+    if (!any) continue;
 
     // ---- 27 taps x CK/2 k-pairs of MFMAs; A fragments: one 16-byte load per (tap, M-tile), next tap
     //      prefetched while the current one is multiplied
@@ -179,36 +227,45 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
     }
   }
 
-  // ---- epilogue: bias, store (lane-consecutive along w), optional GroupNorm partial statistics
-  float *outb = out + (size_t)b * cout * R * R * R;
+  // ---- epilogue: bias (or the boundary-class constant), store, GroupNorm partial statistics
+  float *outb = out + (size_t)b * cout * R3;
+  // voxel coordinates / boundary class of this lane's column in each of the wave's two N-tiles
+  int vox[2], cls[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = 2 * wave + s;
+    constexpr int HB = G::TH / G::NH;
+    const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
+    const int jw = l31 % G::TW, jr = l31 / G::TW;
+    const int d = d0 + td + jr / G::NH, h = h0 + th + jr % G::NH, w = w0 + jw;
+    vox[s] = (d * R + h) * R + w;
+    const int cd = d == 0 ? 0 : (d == R - 1 ? 2 : 1), ch = h == 0 ? 0 : (h == R - 1 ? 2 : 1),
+              cw = w == 0 ? 0 : (w == R - 1 ? 2 : 1);
+    cls[s] = (cd * 3 + ch) * 3 + cw;
+  }
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      const float bv = co < cout ? bias[co] : 0.0f;
+      const bool cok = co < cout;
+      const float bv = (cok && !out_class) ? bias[co] : 0.0f;
       float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (!nact[s]) continue;
-        const int t = 2 * wave + s;
-        constexpr int HB = G::TH / G::NH;
-        const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
-        const int jw = l31 % G::TW, jr = l31 / G::TW;
-        const int d = d0 + td + jr / G::NH, h = h0 + th + jr % G::NH;
-        const float v = acc[m][s][r] + bv;
-        if (co < cout) outb[((size_t)co * R + d) * R * R + h * R + jw] = v;
-        if (STATS) {
-          s1 += v;
-          s2 += v * v;
-        }
+        float v = acc[m][s][r] + bv;
+        if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
+        if (cok) outb[(size_t)co * R3 + vox[s]] = v;
+        s1 += v;
+        s2 += v * v;
       }
-      if (STATS) {
+      if (stats_part) {
         // sum over the 32 lanes of this half-wave (a channel row lives in exactly one half of the wave),
         // one private slot per (sample, brick, wave, channel): plain stores, reduced later in fixed order
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
-        if (l31 == 31 && co < cout) {
+        if (l31 == 31 && cok) {
           float *p = stats_part + ((((size_t)b * gridDim.x + brick) * 4 + wave) * cout + co) * 2;
           p[0] = s1;
           p[1] = s2;
@@ -250,55 +307,106 @@ extern "C" size_t p2pb_conv3d_k3_packed_floats(int cout, int cin) {
   return (size_t)27 * cin_pad * cout_pad;
 }
 
+static int conv_bricks(int r) { return r == 32 ? 128 : r == 16 ? 16 : r == 8 ? 2 : 1; }  // both geometries
+
 extern "C" size_t p2pb_conv3d_k3_stats_floats(int b, int cout, int r) {
-  int bricks = 1;
-  if (r == 32) bricks = (32 / 2) * (32 / 4);
-  else if (r == 16) bricks = (16 / 2) * (16 / 8);
-  else if (r == 8) bricks = (8 / 4) * (8 / 8);
-  return (size_t)b * bricks * 4 * cout * 2;
+  return (size_t)b * conv_bricks(r) * 4 * cout * 2;
 }
 
-template <int R, int MT>
-static int conv_launch(int b, int cin, int cout, const float *in, const float *wt, const float *bias,
-                       const float *in_scale, const float *in_shift, int in_swish, float *out, float *stats_part,
-                       hipStream_t s) {
-  using G = ConvGeom<R>;
+// far-field constants of a folded operand transform: a[b,c] = xf(base[c]) with the SAME device function the
+// staging code uses (bit-identical), i.e. the value of swish(affine(conv0 output)) where conv0 saw only zeros
+__global__ void far_value_kernel(int c, const float *__restrict__ base, const float *__restrict__ scale,
+                                 const float *__restrict__ shift, int swish, float *__restrict__ a) {
+  const int b = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch < c) a[(size_t)b * c + ch] = xf_apply(base[ch], scale[(size_t)b * c + ch], shift[(size_t)b * c + ch], swish);
+}
+
+// K[b, class, co] = bias[co] + sum over the taps that stay inside the grid for that boundary class of
+// sum_ci W[tap][ci][co] * a[b,ci]   (the convolution of the constant field a with zero padding)
+__global__ __launch_bounds__(256) void class_bias_kernel(int cin, int cout, int nchunk, int cout_pad,
+                                                         const float *__restrict__ wt, const float *__restrict__ bias,
+                                                         const float *__restrict__ a, float *__restrict__ k_out) {
+  const int cls = blockIdx.y, b = blockIdx.z;
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (co >= cout) return;
+  const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
+  float acc = 0.0f;
+  for (int tap = 0; tap < 27; ++tap) {
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    // class 0 = low face: the tap reading index -1 is outside; class 2 = high face: the tap reading R is outside
+    if ((cd == 0 && kd == 0) || (cd == 2 && kd == 2) || (ch == 0 && kh == 0) || (ch == 2 && kh == 2) ||
+        (cw == 0 && kw == 0) || (cw == 2 && kw == 2))
+      continue;
+    for (int ci = 0; ci < cin; ++ci) {
+      const size_t idx = ((((size_t)tap * nchunk + (ci >> 3)) * 2 + (ci & 1)) * cout_pad + co) * 4 + ((ci & 7) >> 1);
+      acc = __fmaf_rn(wt[idx], a[(size_t)b * cin + ci], acc);
+    }
+  }
+  k_out[((size_t)b * 27 + cls) * cout + co] = acc + bias[co];
+}
+
+// a f32[b,cin] = far-field operand constants, k_out f32[b,27,cout] = per-boundary-class output constants
+extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
+                                        const float *in_shift, int in_swish, const float *wt_packed,
+                                        const float *bias, float *a, float *k_out, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
-  dim3 grid((R / G::TD) * (R / G::TH), (cout + 32 * MT - 1) / (32 * MT), b);
-  const bool xf = in_scale != nullptr, st = stats_part != nullptr;
-#define LAUNCH(XF, ST)                                                                                         \
-  hipLaunchKernelGGL((conv3d_k3_kernel<R, MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in, wt, \
-                     bias, in_scale, in_shift, in_swish, out, stats_part)
-  if (xf && st) LAUNCH(true, true);
-  else if (xf) LAUNCH(true, false);
-  else if (st) LAUNCH(false, true);
-  else LAUNCH(false, false);
-#undef LAUNCH
+  hipLaunchKernelGGL(far_value_kernel, dim3(cdiv(cin, 256), b), dim3(256), 0, s, cin, prev_bias, in_scale, in_shift,
+                     in_swish, a);
+  hipLaunchKernelGGL(class_bias_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cin, cout, nchunk, cout_pad,
+                     wt_packed, bias, a, k_out);
+  return p2pb_launch_status();
+}
+
+template <int R, bool COMPACT, int MT>
+static int conv_launch(int b, int cin, int cout, const float *in, const float *wt, const float *bias,
+                       const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                       const float *in_sub, int skip_zero, float *out, float *stats_part, hipStream_t s) {
+  const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
+  dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
+  if (in_scale != nullptr)
+    hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, true>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
+                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, out, stats_part);
+  else
+    hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, false>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
+                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, out, stats_part);
   return p2pb_launch_status();
 }
 
 // out[b,cout,r,r,r] = conv3d(xf(in[b,cin,r,r,r]), W) + bias, where xf(x) = x (in_scale == NULL) or
-// swish?(x*in_scale[b,ci] + in_shift[b,ci]); stats_part (optional) receives per-(b, brick, cout)
-// {sum, sum of squares} of the output. r in {4, 8, 16, 32}.
+// swish?(x*in_scale[b,ci] + in_shift[b,ci]) - in_sub[b,ci]; out_class (optional, f32[b,27,cout]) replaces
+// bias per boundary class; stats_part (optional) receives per-(b, slot, cout) {sum, sum of squares} of the
+// output. flags: bit 0 = skip all-zero operand tiles (exact), bit 1 = compact 4x8x8 bricks. r in {4,8,16,32}.
 extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
                                       const float *bias, const float *in_scale, const float *in_shift, int in_swish,
                                       float *out, float *stats_part, void *stream) {
+  return p2pb_conv3d_k3_forward_ex(b, cin, cout, r, in, wt_packed, bias, nullptr, in_scale, in_shift, in_swish, nullptr,
+                                   0, out, stats_part, stream);
+}
+
+extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+                                         const float *bias, const float *out_class, const float *in_scale,
+                                         const float *in_shift, int in_swish, const float *in_sub, int flags,
+                                         float *out, float *stats_part, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const int skip = flags & 1;
+  const bool compact = (flags & 2) != 0;
   // 64 output channels per workgroup unless that leaves fewer than 2 workgroups per CU (small grids)
-  int bricks = 1;
-  if (r == 32) bricks = 128;
-  else if (r == 16) bricks = 16;
-  else if (r == 8) bricks = 2;
-  const bool wide = cout > 32 && (long)bricks * ((cout + 63) / 64) * b >= 512;
-#define GO(RR)                                                                                                      \
-  return wide ? conv_launch<RR, 2>(b, cin, cout, in, wt_packed, bias, in_scale, in_shift, in_swish, out, stats_part, s) \
-              : conv_launch<RR, 1>(b, cin, cout, in, wt_packed, bias, in_scale, in_shift, in_swish, out, stats_part, s)
+  const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 512;
+#define GO(RR, CP)                                                                                                    \
+  return wide ? conv_launch<RR, CP, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,    \
+                                       in_sub, skip, out, stats_part, s)                                              \
+              : conv_launch<RR, CP, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,    \
+                                       in_sub, skip, out, stats_part, s)
   switch (r) {
-    case 32: GO(32);
-    case 16: GO(16);
-    case 8: GO(8);
-    case 4: GO(4);
+    case 32:
+      if (compact) { GO(32, true); } else { GO(32, false); }
+    case 16:
+      if (compact) { GO(16, true); } else { GO(16, false); }
+    case 8: GO(8, false);
+    case 4: GO(4, false);
     default: return P2PB_EINVAL;
   }
 #undef GO

@@ -33,8 +33,10 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d) -> torch.Tensor:
     return cache[1]
 
 
-def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True):
-    """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None)"""
+def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
+              skip_zero=False, compact=False):
+    """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None).
+    in_sub / out_class / skip_zero / compact: the exact sparse form (csrc/conv3d.hip header)."""
     check(x, F32, "x")
     b, ci, r = x.shape[0], x.shape[1], x.shape[2]
     co = conv.out_channels
@@ -44,9 +46,24 @@ def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True):
     if stats:
         nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
-    call("p2pb_conv3d_k3_forward", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(in_scale),
-         ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), stream_ptr())
+    flags = (1 if skip_zero else 0) | (2 if compact else 0)
+    call("p2pb_conv3d_k3_forward_ex", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st), stream_ptr())
     return y, st
+
+
+def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
+    """far-field constants for the sparse form of `conv` applied to swish(affine(prev conv output)):
+    a f32[B,Cin] (operand value where the previous conv saw only zeros, i.e. where its output == prev_bias) and
+    K f32[B,27,Cout] (conv(a)+bias per boundary class)"""
+    b, ci = in_scale.shape
+    co = conv.out_channels
+    wt = pack_conv3d_weight(conv)
+    a = torch.empty(b, ci, dtype=F32, device=in_scale.device)
+    k = torch.empty(b, 27, co, dtype=F32, device=in_scale.device)
+    call("p2pb_conv3d_k3_far_field", _i(b), _i(ci), _i(co), ptr(prev_bias), ptr(in_scale), ptr(in_shift),
+         _i(int(swish)), ptr(wt), ptr(conv.bias), ptr(a), ptr(k), stream_ptr())
+    return a, k
 
 
 def gn_affine_params(part, count_per_channel, groups, gamma, beta, style=None, eps=1e-5, want_mean=False):

@@ -237,9 +237,10 @@ class PVConv(nn.Module):
 
         vl = self.voxel_layers
         r3 = float(self.resolution ** 3)
-        y1, st1 = fused.conv3d_k3(v, vl[0])
+        cp = self.resolution >= 16  # compact 4x8x8 bricks: smaller halo, measured 25-35 % faster than row bricks
+        y1, st1 = fused.conv3d_k3(v, vl[0], compact=cp)
         sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
-        y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True)
+        y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=cp)
         se = vl[6] if len(vl) > 6 else None
         sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
         if se is not None:
