@@ -163,6 +163,19 @@ int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, 
                               const float *bias, const float *out_class, const float *in_scale,
                               const float *in_shift, int in_swish, const float *in_sub, int flags, float *out,
                               float *stats_part, void *stream);
+/* List-driven sparse form. p2pb_conv3d_brick_lists derives, from the voxel occupancy cnt i32[b,r^3] of
+ * avg_voxelize, the compacted lists of (sample*NBRICK + brick) with / without MFMA work for the first
+ * (halo 1) and second (halo 2) convolution of a PVConv: lists i32[4][b*NBRICK] = {active0, inactive0,
+ * active1, inactive1}, counts i32[4]; flags_ws = b*NBRICK*2 bytes scratch; NBRICK = 128 (r=32) / 16 (r=16).
+ * p2pb_conv3d_k3_forward_sparse runs the MFMA kernel on the active pairs only and writes the (exactly
+ * known) constants + statistics of the inactive bricks. */
+int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned char *flags_ws, int *lists, int *counts,
+                            void *stream);
+int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+                                  const float *bias, const float *out_class, const float *in_scale,
+                                  const float *in_shift, int in_swish, const float *in_sub, const int *active_list,
+                                  const int *active_count, const int *inactive_list, const int *inactive_count,
+                                  float *out, float *stats_part, void *stream);
 /* a[b,cin] = xf(prev_bias[cin]) (the operand's far-field constant) and k_out[b,27,cout] = conv(a) + bias per
  * boundary class, for p2pb_conv3d_k3_forward_ex */
 int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,

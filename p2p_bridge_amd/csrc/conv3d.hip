@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
                                                         const float *__restrict__ in_scale,
                                                         const float *__restrict__ in_shift, int in_swish,
                                                         const float *__restrict__ in_sub, int skip_zero,
+                                                        const int *__restrict__ brick_list,
+                                                        const int *__restrict__ brick_count,
                                                         float *__restrict__ out, float *__restrict__ stats_part) {
   using G = ConvGeom<R, COMPACT>;
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
@@ -105,8 +107,17 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
   // all of the surface or none of it -- on one XCD. The compact geometry therefore uses a diagonal hash:
   // d-index = (x mod BD) - (3*bh + 5*bw), so consecutive ids walk diagonally through the grid.
   constexpr int BD = R / G::TD;
-  int bd, bh, bw;
-  if (COMPACT) {
+  constexpr int NBRICK = BD * BH * BW;
+  int bd, bh, bw, b = blockIdx.z;
+  if (brick_list) {  // compacted list of ACTIVE (sample, brick) pairs; the rest is written by conv3d_fill_kernel
+    if ((int)blockIdx.x >= *brick_count) return;
+    const int entry = brick_list[blockIdx.x];
+    b = entry / NBRICK;
+    const int bk = entry % NBRICK;
+    bd = bk / (BH * BW);
+    bh = (bk / BW) % BH;
+    bw = bk % BW;
+  } else if (COMPACT) {
     const int hi = blockIdx.x / BD, lo = blockIdx.x % BD;
     bh = hi / BW;
     bw = hi % BW;
@@ -119,7 +130,6 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
   const int brick = (bd * BH + bh) * BW + bw;
   const int d0 = bd * G::TD, h0 = bh * G::TH, w0 = bw * G::TW;
   const int co0 = blockIdx.y * (32 * MT);
-  const int b = blockIdx.z;
 
   // this wave's two N-tiles: tile index t = 2*wave + s ; origin of an N-tile inside the brick
   int nbase[2];
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
         if (l31 == 31 && cok) {
-          float *p = stats_part + ((((size_t)b * gridDim.x + brick) * 4 + wave) * cout + co) * 2;
+          float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wave) * cout + co) * 2;
           p[0] = s1;
           p[1] = s2;
         }
@@ -362,16 +372,159 @@ extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *p
 template <int R, bool COMPACT, int MT>
 static int conv_launch(int b, int cin, int cout, const float *in, const float *wt, const float *bias,
                        const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
-                       const float *in_sub, int skip_zero, float *out, float *stats_part, hipStream_t s) {
+                       const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
+                       float *stats_part, hipStream_t s) {
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
+  if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
   if (in_scale != nullptr)
     hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, true>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
-                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, out, stats_part);
+                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,
+                       out, stats_part);
   else
     hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, false>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
-                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, out, stats_part);
+                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,
+                       out, stats_part);
   return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Brick activity from the voxel occupancy (cnt of avg_voxelize), compact 4x8x8 bricks:
+//   first conv : a brick has non-zero input in its halo  <=> an occupied voxel within brick +- 1
+//   second conv: its operand differs from the far-field constant only inside dil(occupied, 1), so a brick
+//                has work <=> an occupied voxel within brick +- 2
+// Output: four compacted lists of (sample*NBRICK + brick): active/inactive for each conv, and their counts.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(256) void brick_flags_kernel(const int *__restrict__ cnt, unsigned char *__restrict__ flags) {
+  constexpr int TD = 4, TH = 8, TW = 8, BH = R / TH, BW = R / TW, NBRICK = (R / TD) * BH * BW;
+  __shared__ int f1, f2;
+  const int b = blockIdx.y, bk = blockIdx.x;
+  const int d0 = (bk / (BH * BW)) * TD, h0 = ((bk / BW) % BH) * TH, w0 = (bk % BW) * TW;
+  if (threadIdx.x == 0) f1 = f2 = 0;
+  __syncthreads();
+  constexpr int ED = TD + 4, EH = TH + 4, EW = TW + 4;
+  int a1 = 0, a2 = 0;
+  for (int e = threadIdx.x; e < ED * EH * EW; e += 256) {
+    const int dz = e / (EH * EW), hy = (e / EW) % EH, wx = e % EW;
+    const int d = d0 - 2 + dz, h = h0 - 2 + hy, w = w0 - 2 + wx;
+    if ((unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R) {
+      if (cnt[(size_t)b * R * R * R + (d * R + h) * R + w] > 0) {
+        a2 = 1;
+        if (dz >= 1 && dz <= TD + 2 && hy >= 1 && hy <= TH + 2 && wx >= 1 && wx <= TW + 2) a1 = 1;
+      }
+    }
+  }
+  if (a1) f1 = 1;  // benign race: every writer stores 1
+  if (a2) f2 = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    flags[((size_t)b * NBRICK + bk) * 2 + 0] = (unsigned char)f1;
+    flags[((size_t)b * NBRICK + bk) * 2 + 1] = (unsigned char)f2;
+  }
+}
+
+// single workgroup: compaction of up to 1024*PER entries into active/inactive lists for both convolutions
+__global__ __launch_bounds__(1024) void brick_compact_kernel(int total, const unsigned char *__restrict__ flags,
+                                                            int *__restrict__ lists, int *__restrict__ counts) {
+  __shared__ int wsum[16];
+  const int t = threadIdx.x;
+  const int per = (total + 1023) / 1024;
+  const int beg = t * per, end = min(beg + per, total);
+  for (int which = 0; which < 2; ++which) {
+    int k = 0;
+    for (int e = beg; e < end; ++e) k += flags[(size_t)e * 2 + which];
+    // inclusive wave scan + cross-wave offsets
+    int inc = k;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int y = __shfl_up(inc, d);
+      if ((t & 63) >= d) inc += y;
+    }
+    __syncthreads();
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    int base = 0, all = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < (t >> 6)) base += wsum[w];
+      all += wsum[w];
+    }
+    int apos = base + inc - k;      // active entries before this thread's range
+    int ipos = beg - apos;          // inactive entries before it
+    int *act = lists + (size_t)(2 * which) * total, *ina = lists + (size_t)(2 * which + 1) * total;
+    for (int e = beg; e < end; ++e) {
+      if (flags[(size_t)e * 2 + which]) act[apos++] = e;
+      else ina[ipos++] = e;
+    }
+    if (t == 0) {
+      counts[2 * which] = all;
+      counts[2 * which + 1] = total - all;
+    }
+  }
+}
+
+// lists i32[4][b*NBRICK] = {active conv0, inactive conv0, active conv1, inactive conv1}, counts i32[4];
+// flags_ws: b*NBRICK*2 bytes of scratch. r in {16, 32}.
+extern "C" int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned char *flags_ws, int *lists, int *counts,
+                                       void *stream) {
+  if (b <= 0 || (r != 16 && r != 32)) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = conv_bricks(r);
+  if (r == 32) hipLaunchKernelGGL(brick_flags_kernel<32>, dim3(nb, b), dim3(256), 0, s, cnt, flags_ws);
+  else hipLaunchKernelGGL(brick_flags_kernel<16>, dim3(nb, b), dim3(256), 0, s, cnt, flags_ws);
+  hipLaunchKernelGGL(brick_compact_kernel, dim3(1), dim3(1024), 0, s, nb * b, flags_ws, lists, counts);
+  return p2pb_launch_status();
+}
+
+// inactive bricks: the convolution's output there is a known constant per channel (bias, or the
+// boundary-class constant K): write it and the brick's exact {sum, sum of squares} partials
+template <int R>
+__global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float *__restrict__ bias,
+                                                          const float *__restrict__ out_class,
+                                                          const int *__restrict__ brick_list,
+                                                          const int *__restrict__ brick_count, float *__restrict__ out,
+                                                          float *__restrict__ stats_part) {
+  constexpr int TD = 4, TH = 8, TW = 8, BH = R / TH, BW = R / TW, NBRICK = (R / TD) * BH * BW, R3 = R * R * R;
+  __shared__ int ncls[27];
+  if ((int)blockIdx.x >= *brick_count) return;
+  const int entry = brick_list[blockIdx.x];
+  const int b = entry / NBRICK, bk = entry % NBRICK;
+  const int d0 = (bk / (BH * BW)) * TD, h0 = ((bk / BW) % BH) * TH, w0 = (bk % BW) * TW;
+  const int t = threadIdx.x;
+  const int d = d0 + t / (TH * TW), h = h0 + (t / TW) % TH, w = w0 + t % TW;
+  const int cd = d == 0 ? 0 : (d == R - 1 ? 2 : 1), ch = h == 0 ? 0 : (h == R - 1 ? 2 : 1),
+            cw = w == 0 ? 0 : (w == R - 1 ? 2 : 1);
+  const int cls = (cd * 3 + ch) * 3 + cw;
+  if (t < 27) ncls[t] = 0;
+  __syncthreads();
+  atomicAdd(&ncls[cls], 1);
+  __syncthreads();
+  float *ob = out + (size_t)b * cout * R3 + (d * R + h) * R + w;
+  const float *kb = out_class ? out_class + (size_t)b * 27 * cout : nullptr;
+  for (int co = 0; co < cout; ++co) ob[(size_t)co * R3] = kb ? kb[cls * cout + co] : bias[co];
+  if (stats_part) {
+    for (int co = t; co < cout; co += 256) {
+      float s1 = 0.0f, s2 = 0.0f;
+      if (kb) {
+        for (int c = 0; c < 27; ++c) {
+          const float v = kb[c * cout + co], n = (float)ncls[c];
+          s1 += n * v;
+          s2 += n * v * v;
+        }
+      } else {
+        const float v = bias[co];
+        s1 = 256.0f * v;
+        s2 = 256.0f * v * v;
+      }
+      float *p = stats_part + (((size_t)b * NBRICK + bk) * 4) * cout * 2;
+      p[(size_t)co * 2] = s1;
+      p[(size_t)co * 2 + 1] = s2;
+#pragma unroll
+      for (int wv = 1; wv < 4; ++wv) {
+        p[((size_t)wv * cout + co) * 2] = 0.0f;
+        p[((size_t)wv * cout + co) * 2 + 1] = 0.0f;
+      }
+    }
+  }
 }
 
 // out[b,cout,r,r,r] = conv3d(xf(in[b,cin,r,r,r]), W) + bias, where xf(x) = x (in_scale == NULL) or
@@ -397,9 +550,9 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
   const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 512;
 #define GO(RR, CP)                                                                                                    \
   return wide ? conv_launch<RR, CP, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,    \
-                                       in_sub, skip, out, stats_part, s)                                              \
+                                       in_sub, skip, nullptr, nullptr, out, stats_part, s)                            \
               : conv_launch<RR, CP, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,    \
-                                       in_sub, skip, out, stats_part, s)
+                                       in_sub, skip, nullptr, nullptr, out, stats_part, s)
   switch (r) {
     case 32:
       if (compact) { GO(32, true); } else { GO(32, false); }
@@ -409,6 +562,34 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
     case 4: GO(4, false);
     default: return P2PB_EINVAL;
   }
+#undef GO
+}
+
+// list-driven sparse form: MFMA workgroups only for the `active` (sample, brick) pairs, constants for the
+// `inactive` ones (lists from p2pb_conv3d_brick_lists). Compact geometry; r in {16, 32}.
+extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+                                             const float *bias, const float *out_class, const float *in_scale,
+                                             const float *in_shift, int in_swish, const float *in_sub,
+                                             const int *active_list, const int *active_count,
+                                             const int *inactive_list, const int *inactive_count, float *out,
+                                             float *stats_part, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || (r != 16 && r != 32) || !active_list || !inactive_list) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int total = conv_bricks(r) * b;
+  if (r == 32)
+    hipLaunchKernelGGL(conv3d_fill_kernel<32>, dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list,
+                       inactive_count, out, stats_part);
+  else
+    hipLaunchKernelGGL(conv3d_fill_kernel<16>, dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list,
+                       inactive_count, out, stats_part);
+  const bool wide = cout > 32;
+#define GO(RR)                                                                                                        \
+  return wide ? conv_launch<RR, true, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
+                                         in_sub, 1, active_list, active_count, out, stats_part, s)                    \
+              : conv_launch<RR, true, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
+                                         in_sub, 1, active_list, active_count, out, stats_part, s)
+  if (r == 32) { GO(32); }
+  GO(16);
 #undef GO
 }
 

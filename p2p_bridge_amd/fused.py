@@ -52,6 +52,35 @@ def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in
     return y, st
 
 
+def brick_lists(cnt, r):
+    """cnt i32[B, r^3] (voxel occupancy from avg_voxelize) -> (lists i32[4, B*NBRICK], counts i32[4]):
+    active / inactive compact bricks of the first (halo 1) and second (halo 2) convolution of a PVConv"""
+    b = cnt.shape[0]
+    nb = {32: 128, 16: 16}[r]
+    lists = torch.empty(4, b * nb, dtype=torch.int32, device=cnt.device)
+    counts = torch.empty(4, dtype=torch.int32, device=cnt.device)
+    flags = torch.empty(b * nb * 2, dtype=torch.uint8, device=cnt.device)
+    call("p2pb_conv3d_brick_lists", _i(b), _i(r), ptr(cnt), ptr(flags), ptr(lists), ptr(counts), stream_ptr())
+    return lists, counts
+
+
+def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
+                     out_class=None):
+    """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second"""
+    check(x, F32, "x")
+    b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+    co = conv.out_channels
+    wt = pack_conv3d_weight(conv)
+    y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
+    nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
+    st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    act, ina = lists[2 * which], lists[2 * which + 1]
+    call("p2pb_conv3d_k3_forward_sparse", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(act), ptr(counts[2 * which:]), ptr(ina),
+         ptr(counts[2 * which + 1:]), ptr(y), ptr(st), stream_ptr())
+    return y, st
+
+
 def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
     """far-field constants for the sparse form of `conv` applied to swish(affine(prev conv output)):
     a f32[B,Cin] (operand value where the previous conv saw only zeros, i.e. where its output == prev_bias) and

@@ -228,33 +228,47 @@ class PVConv(nn.Module):
             mods.append(SE3d(out_channels))
         self.voxel_layers = nn.ModuleList(mods)
         self.attn = None
+        self.sparse_conv = True  # inference: exact sparse convolution for r >= 16 (fused._voxel_branch_fused)
         self.point_features = SharedMLP(in_channels, out_channels, gn_groups=gn_groups, cond_dim=cond_dim)
 
-    def _voxel_branch_fused(self, v, vcoords, cond):
-        """inference: conv -> [AdaGN,Swish folded] -> conv -> [AdaGN,SE folded] -> devoxelize, grid tensors
-        written once / read once (fused.py)"""
+    def _voxel_branch_fused(self, features, coords, cond):
+        """inference: voxelize -> conv -> [AdaGN,Swish folded] -> conv -> [AdaGN,SE folded] -> devoxelize; grid
+        tensors written once / read once (fused.py). For r >= 16 the convolutions run in their exact sparse form:
+        MFMA work only on the bricks near the surface, analytic constants elsewhere (csrc/conv3d.hip)."""
         from . import fused
 
-        vl = self.voxel_layers
-        r3 = float(self.resolution ** 3)
-        cp = self.resolution >= 16  # compact 4x8x8 bricks: smaller halo, measured 25-35 % faster than row bricks
-        y1, st1 = fused.conv3d_k3(v, vl[0], compact=cp)
-        sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
-        y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=cp)
+        vl, r = self.voxel_layers, self.resolution
+        vcoords, vox = L.voxel_coords(coords.detach().contiguous(), r, self.voxelization.normalize,
+                                      self.voxelization.eps)
+        B, C = features.shape[:2]
+        v, _, cnt = L._ext.avg_voxelize_forward(features.contiguous(), vox, r)
+        v = v.view(B, C, r, r, r)
+        r3 = float(r ** 3)
+        if r >= 32 and self.sparse_conv:  # at r = 16 every 4x8x8 brick touches the surface: dense is faster
+            lists, counts = fused.brick_lists(cnt, r)
+            y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0)
+            sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
+            a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
+            y2, st2 = fused.conv3d_k3_sparse(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k)
+        else:
+            cp = r >= 16  # compact 4x8x8 bricks: smaller halo, measured 25-35 % faster than row bricks
+            y1, st1 = fused.conv3d_k3(v, vl[0], compact=cp)
+            sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
+            y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=cp)
         se = vl[6] if len(vl) > 6 else None
         sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
         if se is not None:
             gate = se.fc(mean2)
             sc2, sh2 = sc2 * gate, sh2 * gate
-        return fused.devoxelize_affine(y2, vcoords, self.resolution, sc2, sh2)
+        return fused.devoxelize_affine(y2, vcoords, r, sc2, sh2)
 
     def forward(self, data: PVCData) -> PVCData:
         coords, features, cond = data.coords, data.features, data.cond
         assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2] and coords.shape[1] == 3
-        v, vcoords = self.voxelization(features, coords)
         if not self.training and not torch.is_grad_enabled() and self.resolution in (4, 8, 16, 32):
-            fused = self._voxel_branch_fused(v, vcoords, cond)
+            fused = self._voxel_branch_fused(features, coords, cond)
         else:
+            v, vcoords = self.voxelization(features, coords)
             for m in self.voxel_layers:
                 v = m(v, cond) if isinstance(m, AdaGN) else m(v)
             fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)

@@ -47,3 +47,27 @@ for (B, ci, co, N, r) in [(2, 35, 32, 8192, 32), (2, 64, 64, 8192, 32), (2, 128,
             tf = bench(lambda: fused.conv3d_far_field(c0.bias, c1, sc, sh, True))
             msg += f" | ms conv0 dense {t0d:.3f} compact-dense {t0c:.3f} sparse {t0s:.3f}; conv1 dense {t1d:.3f} sparse {t1s:.3f} (+far {tf:.3f})"
         print(msg, flush=True)
+print("---- list-driven sparse")
+for (B, ci, co, N, r) in [(2, 35, 32, 8192, 32), (2, 128, 64, 2048, 16), (32, 64, 64, 8192, 32), (32, 35, 32, 8192, 32), (32, 128, 128, 2048, 16)]:
+    x = net_ref.synthetic_patches(B, N, seed=1)[0].cuda()
+    _, vox = ext.voxel_coords(x, r)
+    f = torch.randn(B, ci, N, device="cuda")
+    v, ind, cnt = ext.avg_voxelize_forward(f, vox, r)
+    v = v.view(B, ci, r, r, r)
+    c0 = torch.nn.Conv3d(ci, co, 3, padding=1).cuda(); c1 = torch.nn.Conv3d(co, co, 3, padding=1).cuda()
+    sc, sh = torch.rand(B, co, device="cuda") + 0.5, torch.randn(B, co, device="cuda") * 0.3
+    with torch.no_grad():
+        y0d, s0d = fused.conv3d_k3(v, c0, compact=True)
+        y1d, s1d = fused.conv3d_k3(y0d, c1, sc, sh, swish=True, compact=True)
+        lists, counts = fused.brick_lists(cnt, r)
+        y0s, s0s = fused.conv3d_k3_sparse(v, c0, lists, counts, 0)
+        a, k = fused.conv3d_far_field(c0.bias, c1, sc, sh, True)
+        y1s, s1s = fused.conv3d_k3_sparse(y0s, c1, lists, counts, 1, sc, sh, True, in_sub=a, out_class=k)
+        tot = lists.shape[1]
+        e0 = (y0s - y0d).abs().max().item(); e1 = (y1s - y1d).abs().max().item()
+        se0 = ((s0s.double().sum(1) - s0d.double().sum(1)).abs().max() / s0d.double().sum(1).abs().max()).item()
+        se1 = ((s1s.double().sum(1) - s1d.double().sum(1)).abs().max() / s1d.double().sum(1).abs().max()).item()
+        msg = f"B{B} {ci}->{co} r{r}: active {counts[0].item()/tot:.2f}/{counts[2].item()/tot:.2f} err0 {e0:.1e} err1 {e1:.1e} stats {se0:.1e} {se1:.1e}"
+        if B > 2:
+            msg += f" | ms conv0 dense {bench(lambda: fused.conv3d_k3(v, c0, compact=True)):.3f} sparse {bench(lambda: fused.conv3d_k3_sparse(v, c0, lists, counts, 0)):.3f}; conv1 dense {bench(lambda: fused.conv3d_k3(y0d, c1, sc, sh, swish=True, compact=True)):.3f} sparse {bench(lambda: fused.conv3d_k3_sparse(y0s, c1, lists, counts, 1, sc, sh, True, in_sub=a, out_class=k)):.3f} lists {bench(lambda: fused.brick_lists(cnt, r)):.3f}"
+        print(msg, flush=True)
