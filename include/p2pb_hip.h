@@ -78,6 +78,11 @@ int p2pb_grouping_forward(int b, int c, int n, int m, int u, const float *feat, 
 int p2pb_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *idx,
                            float *grad_x, void *stream);
 
+/* fused set-abstraction operand (BallQuery.forward, models/pvcnn.py:116-126, inference): out f32[b,3+c,m,u] =
+ * [coords[:, idx] - centers (3 ch) | feat[:, idx] (c ch)] in one pass */
+int p2pb_group_concat(int b, int c, int n, int m, int u, const float *coords, const float *centers,
+                      const float *feat, const int *idx, float *out, void *stream);
+
 /* gather: replaces gather_features() / _grad() PN2/pvcnn_sampling.cuh:4-7
  * (kernels PN2/pvcnn_sampling_gpu.cu:17,55).  feat f32[b,c,n], idx i32[b,m] -> out f32[b,c,m] */
 int p2pb_gather_features_forward(int b, int c, int n, int m, const float *feat, const int *idx, float *out,
@@ -180,7 +185,7 @@ int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *
  * boundary class, for p2pb_conv3d_k3_forward_ex */
 int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
                              const float *in_shift, int in_swish, const float *wt_packed, const float *bias,
-                             float *a, float *k_out, void *stream);
+                             float *a, float *k_out, float *tap_ws /* f32[b,27,cout] scratch */, void *stream);
 
 /* GroupNorm (+AdaGN style, models/modules.py:341-358) folded into a per-(sample, channel) affine:
  * AdaGN(GN(x)) == x*scale + shift. part f32[b,nslots,c,2] partial {sum,sumsq}; gamma/beta f32[c] or

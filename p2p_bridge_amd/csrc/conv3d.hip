@@ -331,11 +331,25 @@ __global__ void far_value_kernel(int c, const float *__restrict__ base, const fl
   if (ch < c) a[(size_t)b * c + ch] = xf_apply(base[ch], scale[(size_t)b * c + ch], shift[(size_t)b * c + ch], swish);
 }
 
-// K[b, class, co] = bias[co] + sum over the taps that stay inside the grid for that boundary class of
-// sum_ci W[tap][ci][co] * a[b,ci]   (the convolution of the constant field a with zero padding)
-__global__ __launch_bounds__(256) void class_bias_kernel(int cin, int cout, int nchunk, int cout_pad,
-                                                         const float *__restrict__ wt, const float *__restrict__ bias,
-                                                         const float *__restrict__ a, float *__restrict__ k_out) {
+// T[b, tap, co] = sum_ci W[tap][ci][co] * a[b,ci]  (one thread per output channel, weights read coalesced)
+__global__ __launch_bounds__(256) void tap_sum_kernel(int cin, int cout, int nchunk, int cout_pad,
+                                                      const float *__restrict__ wt, const float *__restrict__ a,
+                                                      float *__restrict__ tsum) {
+  const int tap = blockIdx.y, b = blockIdx.z;
+  const int co = blockIdx.x * 256 + threadIdx.x;
+  if (co >= cout) return;
+  float acc = 0.0f;
+  for (int ci = 0; ci < cin; ++ci) {
+    const size_t idx = ((((size_t)tap * nchunk + (ci >> 3)) * 2 + (ci & 1)) * cout_pad + co) * 4 + ((ci & 7) >> 1);
+    acc = __fmaf_rn(wt[idx], a[(size_t)b * cin + ci], acc);
+  }
+  tsum[((size_t)b * 27 + tap) * cout + co] = acc;
+}
+
+// K[b, class, co] = bias[co] + sum over the taps that stay inside the grid for that boundary class of T[b,tap,co]
+// (the convolution of the constant field a with zero padding)
+__global__ __launch_bounds__(256) void class_bias_kernel(int cout, const float *__restrict__ tsum,
+                                                         const float *__restrict__ bias, float *__restrict__ k_out) {
   const int cls = blockIdx.y, b = blockIdx.z;
   const int co = blockIdx.x * 256 + threadIdx.x;
   if (co >= cout) return;
@@ -347,25 +361,24 @@ __global__ __launch_bounds__(256) void class_bias_kernel(int cin, int cout, int 
     if ((cd == 0 && kd == 0) || (cd == 2 && kd == 2) || (ch == 0 && kh == 0) || (ch == 2 && kh == 2) ||
         (cw == 0 && kw == 0) || (cw == 2 && kw == 2))
       continue;
-    for (int ci = 0; ci < cin; ++ci) {
-      const size_t idx = ((((size_t)tap * nchunk + (ci >> 3)) * 2 + (ci & 1)) * cout_pad + co) * 4 + ((ci & 7) >> 1);
-      acc = __fmaf_rn(wt[idx], a[(size_t)b * cin + ci], acc);
-    }
+    acc += tsum[((size_t)b * 27 + tap) * cout + co];
   }
   k_out[((size_t)b * 27 + cls) * cout + co] = acc + bias[co];
 }
 
-// a f32[b,cin] = far-field operand constants, k_out f32[b,27,cout] = per-boundary-class output constants
+// a f32[b,cin] = far-field operand constants, k_out f32[b,27,cout] = per-boundary-class output constants,
+// tap_ws f32[b,27,cout] scratch
 extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
                                         const float *in_shift, int in_swish, const float *wt_packed,
-                                        const float *bias, float *a, float *k_out, void *stream) {
+                                        const float *bias, float *a, float *k_out, float *tap_ws, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
   hipLaunchKernelGGL(far_value_kernel, dim3(cdiv(cin, 256), b), dim3(256), 0, s, cin, prev_bias, in_scale, in_shift,
                      in_swish, a);
-  hipLaunchKernelGGL(class_bias_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cin, cout, nchunk, cout_pad,
-                     wt_packed, bias, a, k_out);
+  hipLaunchKernelGGL(tap_sum_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cin, cout, nchunk, cout_pad,
+                     wt_packed, a, tap_ws);
+  hipLaunchKernelGGL(class_bias_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cout, tap_ws, bias, k_out);
   return p2pb_launch_status();
 }
 

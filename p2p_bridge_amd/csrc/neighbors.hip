@@ -89,6 +89,40 @@ extern "C" int p2pb_grouping_forward(int b, int c, int n, int m, int u, const fl
   return p2pb_launch_status();
 }
 
+// set-abstraction operand in one pass: out[b, 0:3, j, k] = coords[b, :, idx] - centers[b, :, j] (relative
+// neighbour coordinates, models/pvcnn.py:117-118) and out[b, 3:, j, k] = feat[b, :, idx] (:124-126), i.e.
+// grouping x2 + subtract + concat of the unfused graph without the two intermediate tensors
+template <int CC>
+__global__ __launch_bounds__(256) void group_concat_kernel(int c, int n, int m, int u,
+                                                           const float *__restrict__ coords,
+                                                           const float *__restrict__ centers,
+                                                           const float *__restrict__ feat, const int *__restrict__ idx,
+                                                           float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int mu = m * u;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= mu) return;
+  const int id = idx[(size_t)b * mu + q];
+  const int j = q / u;
+  const int ct = 3 + c;
+  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, ct);
+  for (int l = c0; l < c1; ++l) {
+    float v;
+    if (l < 3) v = coords[((size_t)b * 3 + l) * n + id] - centers[((size_t)b * 3 + l) * m + j];
+    else v = feat[((size_t)b * c + (l - 3)) * n + id];
+    out[((size_t)b * ct + l) * mu + q] = v;
+  }
+}
+
+extern "C" int p2pb_group_concat(int b, int c, int n, int m, int u, const float *coords, const float *centers,
+                                 const float *feat, const int *idx, float *out, void *stream) {
+  if (b <= 0 || c < 0 || n <= 0 || m <= 0 || u <= 0) return P2PB_EINVAL;
+  constexpr int CC = 8;
+  hipLaunchKernelGGL(group_concat_kernel<CC>, dim3(cdiv((long)m * u, 256), cdiv(3 + c, CC), b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, m, u, coords, centers, feat, idx, out);
+  return p2pb_launch_status();
+}
+
 template <int CC>
 __global__ __launch_bounds__(256) void grouping_grad_kernel(int c, int n, int mu, const float *__restrict__ gy,
                                                             const int *__restrict__ idx, float *__restrict__ gx) {

@@ -19,7 +19,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define PW_CK 32  // input channels per LDS stage (4 sub-chunks of 8)
+#define PW_CK 16  // input channels per register stage (2 sub-chunks of 8): 3 waves/SIMD stay resident (32 -> 2)
 
 // Swish on the hardware exp2 / reciprocal units (see conv3d.hip fast_swish for the error budget)
 __device__ __forceinline__ float swishf(float v) {

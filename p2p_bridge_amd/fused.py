@@ -90,8 +90,9 @@ def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
     wt = pack_conv3d_weight(conv)
     a = torch.empty(b, ci, dtype=F32, device=in_scale.device)
     k = torch.empty(b, 27, co, dtype=F32, device=in_scale.device)
+    ws = torch.empty(b, 27, co, dtype=F32, device=in_scale.device)
     call("p2pb_conv3d_k3_far_field", _i(b), _i(ci), _i(co), ptr(prev_bias), ptr(in_scale), ptr(in_shift),
-         _i(int(swish)), ptr(wt), ptr(conv.bias), ptr(a), ptr(k), stream_ptr())
+         _i(int(swish)), ptr(wt), ptr(conv.bias), ptr(a), ptr(k), ptr(ws), stream_ptr())
     return a, k
 
 

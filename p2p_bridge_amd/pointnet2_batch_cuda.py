@@ -200,3 +200,15 @@ def three_interpolate(centers_features, idx, w):
     call("p2pb_three_interpolate", _i(b), _i(c), _i(m), _i(n), ptr(centers_features), ptr(idx), ptr(w), ptr(out),
          stream_ptr())
     return out
+
+
+def group_concat(points_coords, centers_coords, points_features, indices):
+    """build addition (inference): [coords[:, idx] - centers | features[:, idx]] -> f32[B, 3+C, M, U]"""
+    check(points_coords, F32, "points_coords"), check(centers_coords, F32, "centers_coords")
+    check(points_features, F32, "points_features"), check(indices, I32, "indices")
+    b, c, n = points_features.shape
+    _, m, u = indices.shape
+    out = torch.empty(b, 3 + c, m, u, dtype=F32, device=points_features.device)
+    call("p2pb_group_concat", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(points_coords), ptr(centers_coords),
+         ptr(points_features), ptr(indices), ptr(out), stream_ptr())
+    return out

@@ -82,8 +82,8 @@ class AdaGN(nn.Module):
             self.emd.bias[num_channels:] = 0
 
     def forward(self, x, cond):
-        style = self.emd(cond)
-        style = style.view(style.shape[0], -1, *([1] * (x.dim() - 2)))
+        style = cond.style(self) if isinstance(cond, _Styles) else self.emd(cond)
+        style = style.reshape(style.shape[0], -1, *([1] * (x.dim() - 2)))
         factor, bias = style.chunk(2, 1)
         return self.norm(x) * factor + bias
 
@@ -122,6 +122,47 @@ class LinearAttention(nn.Module):
         return self.to_out(out).squeeze(-1)
 
 
+class StyleBank:
+    """All AdaGN style vectors of one network evaluation from ONE GEMM: every AdaGN owns a
+    Linear(cond_dim -> 2C) on the same global embedding (models/modules.py:337,345), 42 (PVDS) / 57 (PVDL)
+    tiny GEMVs per evaluation in the reference. The weights are concatenated once (refreshed when any of
+    them changes) and `cond @ W_all^T + b_all` is sliced per layer."""
+
+    def __init__(self, net: nn.Module):
+        self.mods = [m for m in net.modules() if isinstance(m, AdaGN)]
+        self.key = None
+        self.weight = self.bias = None
+        self.slices = {}
+
+    def _refresh(self):
+        key = tuple((m.emd.weight.data_ptr(), m.emd.weight._version, m.emd.bias._version) for m in self.mods)
+        if key != self.key:
+            self.weight = torch.cat([m.emd.weight.detach() for m in self.mods], dim=0).contiguous()
+            self.bias = torch.cat([m.emd.bias.detach() for m in self.mods], dim=0).contiguous()
+            off = 0
+            self.slices = {}
+            for m in self.mods:
+                n2 = m.emd.weight.shape[0]
+                self.slices[id(m)] = (off, off + n2)
+                off += n2
+            self.key = key
+
+    def evaluate(self, cond):
+        self._refresh()
+        return _Styles(cond, F.linear(cond, self.weight, self.bias), self.slices)
+
+
+class _Styles:
+    """the global embedding of this evaluation + the precomputed style of every AdaGN"""
+
+    def __init__(self, vector, styles, slices):
+        self.vector, self.styles, self.slices = vector, styles, slices
+
+    def style(self, adagn):
+        lo, hi = self.slices[id(adagn)]
+        return self.styles[:, lo:hi]
+
+
 def norm_affine(norm, part, count, cond, want_mean=False):
     """AdaGN / GroupNorm / MyGroupNorm folded to per-(sample, channel) (scale, shift[, channel mean]) from the
     producing kernel's {sum, sumsq} partials (fused.gn_affine_params)"""
@@ -130,9 +171,9 @@ def norm_affine(norm, part, count, cond, want_mean=False):
     style = None
     if isinstance(norm, AdaGN):
         gn = norm.norm
-        style = norm.emd(cond) if cond is not None else None
         if cond is None:
             raise RuntimeError("AdaGN needs the global embedding")
+        style = cond.style(norm) if isinstance(cond, _Styles) else norm.emd(cond)
     elif isinstance(norm, MyGroupNorm):
         gn = norm.group_norm
     else:
@@ -312,8 +353,7 @@ class PointNetSAModule(nn.Module):
             centers, nidx = data.geo.take_sa(self.level)
             if data.time_emb is not None:
                 data.time_emb = data.time_emb[:, :, : centers.shape[-1]]
-            rel = L.pvcnn_grouping(coords.contiguous(), nidx) - centers.unsqueeze(-1)
-            grouped = torch.cat([rel, L.pvcnn_grouping(data.features, nidx)], dim=1)
+            grouped = L._ext.group_concat(coords.contiguous(), centers, data.features.contiguous(), nidx)
             data.features = self.mlps[0].run(grouped, data.cond, reduce_max=True)
             data.coords = centers
             return data
@@ -610,6 +650,7 @@ class PVCNN2Unet(nn.Module):
         # models/unet_pvc.py:162-163); same float64 -> float32 values
         freq = torch.from_numpy(np.exp(np.arange(0, half) * -(np.log(10000) / (half - 1)))).float()
         self.register_buffer("_temb_freq", freq, persistent=False)
+        self._style_bank = None
         self.overlap_geometry = True  # inference: run FPS / ball query / 3-NN on a side stream (Geometry)
 
     def get_timestep_embedding(self, timesteps, device=None):
@@ -649,6 +690,10 @@ class PVCNN2Unet(nn.Module):
             else:
                 feats = self.embed_feats(src)
         cond = self.global_pnet(coords) if self.global_pnet is not None else None
+        if use_fused and cond is not None:
+            if self._style_bank is None:
+                self._style_bank = StyleBank(self)
+            cond = self._style_bank.evaluate(cond)
         feats = torch.cat([coords, feats], dim=1)
         time_emb = None
         if t is not None:
