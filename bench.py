@@ -40,12 +40,13 @@ CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample p
 
 def conv_roofline(model, B, reps=10):
     """Dominant kernel = conv3d_k3_kernel (csrc/conv3d.hip), the 3x3x3 voxel convolution on the fp32 MFMA.
-    Timed live on its largest instance (fp_layers.3.1 second conv: C 64->64, r=32, with the folded
-    AdaGN+Swish operand transform and the GroupNorm statistics epilogue, exactly as the sampler runs it)
-    with HIP events on the stream the kernel is launched on (torch's current stream)."""
+    Timed live on the instance that costs the sampler most (fp_layers.2.{1,2} second conv: C 128->128,
+    r=16, compact bricks, folded AdaGN+Swish operand transform, GroupNorm statistics epilogue -- exactly as
+    the sampler launches it, 3x per network evaluation) with HIP events on the stream the kernel is
+    launched on (torch's current stream). (At r=32 the same kernel runs in its list-driven sparse form.)"""
     from p2p_bridge_amd import fused
 
-    pv = model.model.fp_layers[3][1]
+    pv = model.model.fp_layers[2][1]
     conv = pv.voxel_layers[4]
     C, r = conv.in_channels, pv.resolution
     x = torch.randn(B, C, r, r, r, device="cuda")
@@ -65,8 +66,8 @@ def conv_roofline(model, B, reps=10):
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": f"conv3d_k3_kernel<32,compact,2,XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
-                      f"(fp_layers.3.1.voxel_layers.4)",
+            "kernel": f"conv3d_k3_kernel<{r},compact,2,XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
+                      f"(fp_layers.2.1.voxel_layers.4)",
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 
