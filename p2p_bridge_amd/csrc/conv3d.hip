@@ -145,18 +145,18 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
     nbase[s] = ((td + jd) * HH + (th + jh)) * HW + jw;
   }
 
-  // staging map, fixed for the whole kernel: element e = tid + k*256 of the [CK][HD][HH][HW] halo brick
-  // -> (channel-in-chunk << 16 | offset inside the channel's r^3 grid), or -1 outside the grid / brick
-  int gpk[NE];
+  // staging map, fixed for the whole kernel: this thread stages halo positions tid, tid+256, ... of EVERY
+  // channel of a chunk (channel-outer order keeps the folded scale/shift wave-uniform, i.e. scalar loads,
+  // and needs only NP offsets instead of one per staged element)
+  constexpr int NP = (PLANE + 255) / 256;
+  int soff[NP];  // offset inside a channel's r^3 grid, or -1 outside the grid / beyond the halo
 #pragma unroll
-  for (int k = 0; k < NE; ++k) {
-    const int e = tid + k * 256;
-    const int ci = e / PLANE, rem = e % PLANE;
-    const int dz = rem / (HH * HW), hy = (rem / HW) % HH, wx = rem % HW;
+  for (int j = 0; j < NP; ++j) {
+    const int e = tid + j * 256;
+    const int dz = e / (HH * HW), hy = (e / HW) % HH, wx = e % HW;
     const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = w0 - 1 + wx;
-    const bool ok = e < CONV_CK * PLANE && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R &&
-                    (unsigned)w < (unsigned)R;
-    gpk[k] = ok ? ((ci << 16) | ((d * R + h) * R + w)) : -1;
+    const bool ok = e < PLANE && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
+    soff[j] = ok ? (d * R + h) * R + w : -1;
   }
 
   f32x16 acc[MT][2];
@@ -168,14 +168,13 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
       for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
 
   const float *inb = in + (size_t)b * cin * R3;
-  float stg[NE];
+  float stg[CONV_CK][NP];
   auto stage_load = [&](int ci0) {
 #pragma unroll
-    for (int k = 0; k < NE; ++k) {
-      const int g = gpk[k];
-      const int ci = ci0 + ((g >> 16) & 7);
-      stg[k] = (g >= 0 && ci < cin) ? inb[(size_t)ci * R3 + (g & 0xFFFF)] : 0.0f;
-    }
+    for (int c = 0; c < CONV_CK; ++c)
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        stg[c][j] = (soff[j] >= 0 && ci0 + c < cin) ? inb[(size_t)(ci0 + c) * R3 + soff[j]] : 0.0f;
   };
   stage_load(0);
 
@@ -183,19 +182,21 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
     __syncthreads();  // everyone is done reading the previous chunk's tile
     int nonzero = 0;
 #pragma unroll
-    for (int k = 0; k < NE; ++k) {
-      const int e = tid + k * 256;
-      float v = stg[k];
-      if (XF) {
-        const int g = gpk[k];
-        const int ci = ci0 + ((g >> 16) & 7);
-        if (g >= 0 && ci < cin) {
-          v = xf_apply(v, in_scale[b * cin + ci], in_shift[b * cin + ci], in_swish);
-          if (in_sub) v -= in_sub[b * cin + ci];
-        }
+    for (int c = 0; c < CONV_CK; ++c) {
+      float sc = 1.0f, sh = 0.0f, sub = 0.0f;
+      const bool cok = ci0 + c < cin;
+      if (XF && cok) {
+        sc = in_scale[b * cin + ci0 + c];
+        sh = in_shift[b * cin + ci0 + c];
+        if (in_sub) sub = in_sub[b * cin + ci0 + c];
       }
-      nonzero |= (v != 0.0f);
-      if (e < CONV_CK * PLANE) tile[e] = v;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        float v = stg[c][j];
+        if (XF && cok && soff[j] >= 0) v = xf_apply(v, sc, sh, in_swish) - sub;
+        nonzero |= (v != 0.0f);
+        if (tid + j * 256 < PLANE) tile[c * PLANE + tid + j * 256] = v;
+      }
     }
     // barrier + "is any staged value non-zero" in one; an all-zero tile contributes exactly +0
     const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
