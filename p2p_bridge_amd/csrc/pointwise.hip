@@ -35,7 +35,7 @@ __device__ __forceinline__ float swishf(float v) {
 // chunk c+1 are issued before chunk c is multiplied; A fragments (weights) are 16-byte L1/L2 loads issued
 // first, so the in-order vmcnt wait in front of the MFMAs never covers the HBM prefetch.
 template <int MT, bool XF, bool STATS>
-__global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cout_pad, int P,
+__global__ __launch_bounds__(256, 3) void pw_conv_kernel(int cin, int cout, int cout_pad, int P,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias,
                                                       const float *__restrict__ bias_b,
@@ -70,17 +70,24 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cou
   load_b(0, bcur);
   const float *wbase = wp + ((size_t)khalf * cout_pad + co0 + l31) * 4;
   const size_t wchunk_stride = (size_t)2 * cout_pad * 4;
-
-  for (int ci0 = 0; ci0 < cin; ci0 += PW_CK) {
-    const int chunk0 = ci0 >> 3;
-    f32x4 a_all[PW_CK / 8][MT];
+  f32x4 a_cur[PW_CK / 8][MT], a_nxt[PW_CK / 8][MT];
+  auto load_a = [&](int chunk0, f32x4(&dst)[PW_CK / 8][MT]) {
 #pragma unroll
     for (int sub = 0; sub < PW_CK / 8; ++sub) {
       const int ch = chunk0 + sub < nchunk8 ? chunk0 + sub : nchunk8 - 1;  // clamp: stays inside the buffer
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a_all[sub][m] = *(const f32x4 *)(wbase + (size_t)ch * wchunk_stride + (size_t)m * 32 * 4);
+      for (int m = 0; m < MT; ++m) dst[sub][m] = *(const f32x4 *)(wbase + (size_t)ch * wchunk_stride + (size_t)m * 32 * 4);
     }
-    if (ci0 + PW_CK < cin) load_b(ci0 + PW_CK, bnxt);
+  };
+  load_a(0, a_cur);
+
+  for (int ci0 = 0; ci0 < cin; ci0 += PW_CK) {
+    const int chunk0 = ci0 >> 3;
+    const bool more = ci0 + PW_CK < cin;
+    if (more) {  // both operands of the NEXT chunk are requested before this chunk is multiplied
+      load_a(chunk0 + PW_CK / 8, a_nxt);
+      load_b(ci0 + PW_CK, bnxt);
+    }
     if (XF) {
 #pragma unroll
       for (int kk = 0; kk < PW_CK / 2; ++kk) {
@@ -105,14 +112,18 @@ __global__ __launch_bounds__(256) void pw_conv_kernel(int cin, int cout, int cou
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
-            acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_all[sub][m][kk], bcur[sub * 4 + kk][s], acc[m][s], 0, 0, 0);
+            acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[sub][m][kk], bcur[sub * 4 + kk][s], acc[m][s], 0, 0, 0);
       }
     }
-    if (ci0 + PW_CK < cin) {
+    if (more) {
 #pragma unroll
       for (int kk = 0; kk < PW_CK / 2; ++kk)
 #pragma unroll
         for (int s = 0; s < 2; ++s) bcur[kk][s] = bnxt[kk][s];
+#pragma unroll
+      for (int sub = 0; sub < PW_CK / 8; ++sub)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[sub][m] = a_nxt[sub][m];
     }
   }
 
