@@ -1,0 +1,12 @@
+"""Launch the widest pointwise GEMM (Pnet2Stage 512->1024, P=8192, B=32) a few times for rocprofv3 --pmc runs."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from p2p_bridge_amd import fused
+B, ci, co, P = 32, 512, 1024, 8192
+x = torch.randn(B, ci, P, device="cuda")
+conv = torch.nn.Conv1d(ci, co, 1).cuda()
+with torch.no_grad():
+    for _ in range(4):
+        fused.pw_conv(x, conv)
+torch.cuda.synchronize()
