@@ -182,14 +182,36 @@ __global__ __launch_bounds__(256, 3) void pw_conv_kernel(int cin, int cout, int 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define PWW_CK 8
 
-template <int MT, bool XF, bool STATS>
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_perm(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false));
+}
+// min and max over aligned groups of g lanes. g = 2..16: every lane of the group ends with the result
+// (xor-1, xor-2 inside quads, then the half-row and row mirrors); g = 32: lanes 31 / 63 hold their half-wave's.
+__device__ __forceinline__ void group_minmax(float &mn, float &mx, int g) {
+  if (g > 1) { mn = fminf(mn, dpp_perm<0xB1, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0xB1, 0xf>(mx)); }    // quad_perm [1,0,3,2]
+  if (g > 2) { mn = fminf(mn, dpp_perm<0x4E, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x4E, 0xf>(mx)); }    // quad_perm [2,3,0,1]
+  if (g > 4) { mn = fminf(mn, dpp_perm<0x141, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x141, 0xf>(mx)); }  // row_half_mirror
+  if (g > 8) { mn = fminf(mn, dpp_perm<0x140, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x140, 0xf>(mx)); }  // row_mirror
+  if (g > 16) { mn = fminf(mn, dpp_perm<0x142, 0xa>(mn)); mx = fmaxf(mx, dpp_perm<0x142, 0xa>(mx)); } // row_bcast:15
+}
+
+// POOL: additionally emit {min, max} of the raw output over groups of pool_g lanes (= 4*pool_g consecutive
+// positions: a set-abstraction neighbourhood) or, pool_g == 32, over the wave's 128 positions (global max-pool
+// partials); `out` may then be NULL. Swish (like every activation the network uses) is quasi-convex, so
+//   max_p act(scale*x_p + shift) = max(act(scale*min_p x_p + shift), act(scale*max_p x_p + shift)),
+// and the pooled tensor is produced by p2pb_minmax_act from 2/U-th of the data without the layer's
+// output ever being written or re-read.
+template <int MT, bool XF, bool STATS, bool POOL>
 __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int cout_pad, int P, int nslots,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias,
                                                       const float *__restrict__ bias_b,
                                                       const float *__restrict__ in_scale,
                                                       const float *__restrict__ in_shift, int in_swish,
-                                                      float *__restrict__ out, float *__restrict__ stats_part) {
+                                                      float *__restrict__ out, float *__restrict__ stats_part,
+                                                      float *__restrict__ mm_out, int pool_g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
@@ -279,10 +301,29 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       const f32x4 v = {acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv};
       float s1 = 0.0f, s2 = 0.0f;
       if (co < cout && pok) {
-        *(f32x4 *)(outb + (size_t)co * P + p) = v;
+        if (!POOL || out) *(f32x4 *)(outb + (size_t)co * P + p) = v;
         if (STATS) {
           s1 = (v[0] + v[1]) + (v[2] + v[3]);
           s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+      }
+      if (POOL) {
+        float mn = pok ? fminf(fminf(v[0], v[1]), fminf(v[2], v[3])) : INFINITY;
+        float mx = pok ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
+        group_minmax(mn, mx, pool_g);
+        if (co < cout) {
+          if (pool_g == 32) {
+            if (l31 == 31) {
+              float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * cout + co) * 2;
+              q[0] = mn;
+              q[1] = mx;
+            }
+          } else if ((l31 & (pool_g - 1)) == 0 && pok) {
+            const int u = 4 * pool_g;
+            float *q = mm_out + (((size_t)b * cout + co) * (P / u) + p / u) * 2;
+            q[0] = mn;
+            q[1] = mx;
+          }
         }
       }
       if (STATS) {
@@ -337,26 +378,33 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
   return (size_t)b * ((npos + 255) / 256) * 4 * cout * 2;
 }
 
+static bool pw_wide_ok(int P, const float *in, const float *out) {
+  // 16-byte rows: every row of in/out starts on a 16-byte boundary and holds whole quads
+  return P % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+}
+
 template <int MT>
 static int pw_launch(int b, int cin, int cout, int P, const float *in, const float *wp, const float *bias,
                      const float *bias_b, const float *in_scale, const float *in_shift, int in_swish, float *out,
-                     float *stats_part, hipStream_t s) {
+                     float *stats_part, float *minmax, int pool_g, hipStream_t s) {
   const bool xf = in_scale != nullptr, st = stats_part != nullptr;
-  // 16-byte rows: every row of in/out starts on a 16-byte boundary and holds whole quads
-  const bool wide = P % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
-  if (wide) {
+  if (pw_wide_ok(P, in, out)) {
     dim3 grid((P + 511) / 512, (cout + 32 * MT - 1) / (32 * MT), b);
     const int nslots = (P + 255) / 256 * 4;
-#define LAUNCH(XF, ST)                                                                                              \
-  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, nslots, in, \
-                     wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part)
-    if (xf && st) LAUNCH(true, true);
-    else if (xf) LAUNCH(true, false);
-    else if (st) LAUNCH(false, true);
-    else LAUNCH(false, false);
+#define LAUNCH(XF, ST, PL)                                                                                         \
+  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, nslots, \
+                     in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g)
+    if (minmax) {
+      if (xf) LAUNCH(true, true, true);
+      else LAUNCH(false, true, true);
+    } else if (xf && st) LAUNCH(true, true, false);
+    else if (xf) LAUNCH(true, false, false);
+    else if (st) LAUNCH(false, true, false);
+    else LAUNCH(false, false, false);
 #undef LAUNCH
     return p2pb_launch_status();
   }
+  if (minmax) return P2PB_EINVAL;
   dim3 grid((P + 255) / 256, (cout + 32 * MT - 1) / (32 * MT), b);
 #define LAUNCH(XF, ST)                                                                                            \
   hipLaunchKernelGGL((pw_conv_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, in, wp, bias, \
@@ -373,13 +421,86 @@ extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, c
                                            const float *bias, const float *bias_b, const float *in_scale,
                                            const float *in_shift, int in_swish, float *out, float *stats_part,
                                            void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0) return P2PB_EINVAL;
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, s)
+                                  stats_part, nullptr, 0, s)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, s);
+                                  stats_part, nullptr, 0, s);
+}
+
+// pool_u = neighbourhood size (4, 8, 16, 32 or 64 consecutive positions) or 0 for the global pool
+static int pool_lanes(int pool_u) { return pool_u == 0 ? 32 : pool_u / 4; }
+
+extern "C" int p2pb_pointwise_pool_supported(int npos, int pool_u) {
+  const bool uok = pool_u == 0 || pool_u == 4 || pool_u == 8 || pool_u == 16 || pool_u == 32 || pool_u == 64;
+  return npos > 0 && npos % 4 == 0 && uok && (pool_u == 0 || npos % pool_u == 0);
+}
+
+extern "C" size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int pool_u) {
+  if (pool_u == 0) return (size_t)b * ((npos + 511) / 512) * 4 * cout * 2;
+  return (size_t)b * cout * (npos / pool_u) * 2;
+}
+
+extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in, const float *wp,
+                                                const float *bias, const float *bias_b, const float *in_scale,
+                                                const float *in_shift, int in_swish, float *out, float *stats_part,
+                                                int pool_u, float *minmax, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !stats_part || !minmax) return P2PB_EINVAL;
+  if (!p2pb_pointwise_pool_supported(npos, pool_u) || !pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = pool_lanes(pool_u);
+  return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, minmax, g, s)
+                   : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, minmax, g, s);
+}
+
+// y = max(act(scale*min + shift), act(scale*max + shift)):
+//   nslots == 0: minmax f32[b, c, m, 2] -> y f32[b, c, m]      (set-abstraction neighbour max)
+//   nslots  > 0: minmax f32[b, nslots, c, 2] -> y f32[b, c]    (global max-pool; partials reduced first)
+__global__ __launch_bounds__(256) void minmax_act_kernel(int c, int m, int nslots, const float *__restrict__ mm,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int swish,
+                                                         float *__restrict__ y, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    float mn, mx;
+    size_t bc;
+    if (nslots == 0) {
+      bc = e / m;
+      const float2 v = *(const float2 *)(mm + e * 2);
+      mn = v.x;
+      mx = v.y;
+    } else {
+      bc = e;
+      const size_t b = e / c, ch = e % c;
+      mn = INFINITY;
+      mx = -INFINITY;
+      for (int sl = 0; sl < nslots; ++sl) {
+        const float2 v = *(const float2 *)(mm + ((b * nslots + sl) * c + ch) * 2);
+        mn = fminf(mn, v.x);
+        mx = fmaxf(mx, v.y);
+      }
+    }
+    const float sc = scale[bc], sh = shift[bc];
+    float lo = mn * sc + sh, hi = mx * sc + sh;
+    if (swish) {
+      lo = swishf(lo);
+      hi = swishf(hi);
+    }
+    y[e] = fmaxf(lo, hi);
+  }
+}
+
+extern "C" int p2pb_minmax_act(int b, int c, int m, int nslots, const float *minmax, const float *scale,
+                               const float *shift, int swish, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || m <= 0 || nslots < 0) return P2PB_EINVAL;
+  const size_t total = nslots == 0 ? (size_t)b * c * m : (size_t)b * c;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(minmax_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, m, nslots, minmax, scale,
+                     shift, swish, y, total);
+  return p2pb_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------

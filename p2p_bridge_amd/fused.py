@@ -147,9 +147,16 @@ def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None) -> torch.Tensor:
     return hit[1]
 
 
+def pool_supported(npos: int, pool_u: int) -> bool:
+    """can pw_conv(..., pool_u=) prepare this max-pool in its epilogue? (16-byte rows, u in 4..64 or 0 = global)"""
+    return bool(lib().p2pb_pointwise_pool_supported(_i(npos), _i(pool_u)))
+
+
 def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
-            use_bias=True):
-    """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None)"""
+            use_bias=True, pool_u=None, store=True):
+    """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None).
+    pool_u (0 = all positions, or the neighbourhood size): also returns the {min, max} tensor minmax_act()
+    pools from -> (y | None, stats, minmax); store=False skips writing y altogether."""
     check(x, F32, "x")
     b, ci, p = x.shape
     co = conv.weight.shape[0]
@@ -160,15 +167,38 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         in_scale = in_shift = None
         swish = False
     wp = pack_pointwise_weight(conv, ci_lo, ci_hi)
-    y = torch.empty(b, co, p, dtype=F32, device=x.device)
+    y = torch.empty(b, co, p, dtype=F32, device=x.device) if (store or pool_u is None) else None
     st = None
-    if stats:
+    if stats or pool_u is not None:
         nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     bias = conv.bias if use_bias else None
-    call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), stream_ptr())
-    return y, st
+    if pool_u is None:
+        call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
+             ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), stream_ptr())
+        return y, st
+    nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(pool_u))
+    mm = torch.empty((b, nmm // (b * co * 2), co, 2) if pool_u == 0 else (b, co, p // pool_u, 2), dtype=F32,
+                     device=x.device)
+    call("p2pb_pointwise_conv_pool_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), _i(pool_u), ptr(mm), stream_ptr())
+    return y, st, mm
+
+
+def minmax_act(mm, scale, shift, swish=True, global_pool=False):
+    """max(act(scale*min+shift), act(scale*max+shift)): mm f32[B,C,M,2] -> f32[B,C,M], or (global_pool)
+    per-wave partials f32[B,nslots,C,2] -> f32[B,C]"""
+    if global_pool:
+        b, nslots, c, _ = mm.shape
+        y = torch.empty(b, c, dtype=F32, device=mm.device)
+        call("p2pb_minmax_act", _i(b), _i(c), _i(1), _i(nslots), ptr(mm), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
+             stream_ptr())
+    else:
+        b, c, m, _ = mm.shape
+        y = torch.empty(b, c, m, dtype=F32, device=mm.device)
+        call("p2pb_minmax_act", _i(b), _i(c), _i(m), _i(0), ptr(mm), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
+             stream_ptr())
+    return y
 
 
 def affine_act(x, scale, shift, swish=True, residual=None):

@@ -223,8 +223,16 @@ class SharedMLP(nn.Module):
         if not h.is_contiguous():
             h = h.contiguous()
         sc = sh = None
-        for i in range(0, len(self.layers), 3):
-            conv, norm = self.layers[i], self.layers[i + 1]
+        nl = len(self.layers) // 3
+        # set abstraction: the last layer's output is only ever max-pooled over the neighbour axis, so its
+        # GEMM emits per-neighbourhood {min, max} instead of the tensor (fused.pw_conv pool_u)
+        pool = reduce_max and fused.pool_supported(P, shape[-1])
+        for i in range(nl):
+            conv, norm = self.layers[3 * i], self.layers[3 * i + 1]
+            if pool and i == nl - 1:
+                _, st, mm = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, pool_u=shape[-1], store=False)
+                sc, sh = norm_affine(norm, st, P, cond)
+                return fused.minmax_act(mm, sc, sh).view(B, conv.weight.shape[0], *shape[2:-1])
             h, st = fused.pw_conv(h, conv, sc, sh, swish=sc is not None)
             sc, sh = norm_affine(norm, st, P, cond)
         C = h.shape[1]
@@ -465,14 +473,24 @@ class Pnet2Stage(nn.Module):
         b0, b1 = self.mlp2.shared_mlp_0.mlp, self.mlp2.shared_mlp_1.mlp
         h, st = fused.pw_conv(coords.contiguous(), a0[0])
         sc, sh = norm_affine(a0[1], st, N, None)
-        h, st = fused.pw_conv(h, a1[0], sc, sh, swish=True)
-        sc, sh = norm_affine(a1[1], st, N, None)
-        g = fused.affine_act_max(h, sc, sh, N, 0)
+        pool = fused.pool_supported(N, 0)  # the max-pools ride in the GEMM epilogues as {min, max} partials
+        if pool:
+            h, st, mm = fused.pw_conv(h, a1[0], sc, sh, swish=True, pool_u=0)
+            sc, sh = norm_affine(a1[1], st, N, None)
+            g = fused.minmax_act(mm, sc, sh, global_pool=True)
+        else:
+            h, st = fused.pw_conv(h, a1[0], sc, sh, swish=True)
+            sc, sh = norm_affine(a1[1], st, N, None)
+            g = fused.affine_act_max(h, sc, sh, N, 0)
         c1 = h.shape[1]
         w = b0[0].weight.reshape(b0[0].out_channels, -1)
         bias_b = (g @ w[:, c1:].t()).contiguous()
         h, st = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1)
         sc, sh = norm_affine(b0[1], st, N, None)
+        if pool:  # the 1024-channel output is never written: only its statistics and extrema are needed
+            _, st, mm = fused.pw_conv(h, b1[0], sc, sh, swish=True, pool_u=0, store=False)
+            sc, sh = norm_affine(b1[1], st, N, None)
+            return fused.minmax_act(mm, sc, sh, global_pool=True)
         h, st = fused.pw_conv(h, b1[0], sc, sh, swish=True)
         sc, sh = norm_affine(b1[1], st, N, None)
         return fused.affine_act_max(h, sc, sh, N, 0)

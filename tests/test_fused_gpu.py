@@ -1,0 +1,183 @@
+"""The fused inference kernels (csrc/pointwise.hip, csrc/conv3d.hip) against plain torch references of the
+same operator chains (models/pvcnn.py:162-205 SharedMLP, :414 neighbour max, :923,930 Pnet2Stage pools,
+:109-125 PVConv voxel convs). Floating point: tolerance 1e-4 relative to the tensor scale (north_star)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def fused():
+    from p2p_bridge_amd import fused as f
+    return f
+
+
+def rel_err(a, ref):
+    return ((a.double() - ref.double()).abs().max() / ref.double().abs().max().clamp_min(1e-30)).item()
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def stats_of(st):
+    s = st.double().sum(1)
+    return s[..., 0], s[..., 1]
+
+
+# (B, cin, cout, P): wide path (P % 4 == 0), ragged channel counts, partial 512-position blocks, and the
+# one-position-per-lane fallback (P % 4 != 0)
+PW_SHAPES = [(2, 3, 128, 1000), (2, 35, 32, 4096), (2, 512, 1024, 512), (2, 131, 128, 300), (2, 64, 200, 256),
+             (3, 1, 7, 4), (2, 67, 64, 333), (2, 16, 16, 1021), (1, 259, 128, 516)]
+
+
+@pytest.mark.parametrize("B,ci,co,P", PW_SHAPES)
+def test_pointwise_conv(fused, B, ci, co, P):
+    torch.manual_seed(B * 1000 + ci + co + P)
+    x = torch.randn(B, ci, P, device="cuda")
+    conv = torch.nn.Conv1d(ci, co, 1).cuda()
+    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
+    bias_b = torch.randn(B, co, device="cuda")
+    with torch.no_grad():
+        ref = torch.nn.functional.conv1d(x.double(), conv.weight.double(), conv.bias.double())
+        y, st = fused.pw_conv(x, conv)
+        assert rel_err(y, ref) < TOL
+        s1, s2 = stats_of(st)
+        assert rel_err(s1, ref.sum(2)) < TOL * 10 or (s1 - ref.sum(2)).abs().max() < 1e-3
+        assert rel_err(s2, (ref * ref).sum(2)) < TOL
+        y0, st0 = fused.pw_conv(x, conv, stats=False)
+        assert st0 is None and torch.equal(y0, y)
+        # folded norm + Swish on the operand, per-sample bias
+        xin = swish(x * sc[:, :, None] + sh[:, :, None])
+        ref2 = torch.nn.functional.conv1d(xin.double(), conv.weight.double(), conv.bias.double()) + bias_b[:, :, None]
+        y2, st2 = fused.pw_conv(x, conv, sc, sh, swish=True, bias_b=bias_b)
+        assert rel_err(y2, ref2) < TOL
+        assert rel_err(stats_of(st2)[1], (ref2 * ref2).sum(2)) < TOL
+        # affine only (no activation)
+        ref3 = torch.nn.functional.conv1d((x * sc[:, :, None] + sh[:, :, None]).double(), conv.weight.double(),
+                                          conv.bias.double())
+        assert rel_err(fused.pw_conv(x, conv, sc, sh, swish=False)[0], ref3) < TOL
+
+
+def test_pointwise_conv_channel_slice(fused):
+    """W[:, lo:hi] @ x without a bias: the split concat of Pnet2Stage (models/pvcnn.py:925-928)"""
+    torch.manual_seed(5)
+    x = torch.randn(2, 24, 512, device="cuda")
+    conv = torch.nn.Conv2d(40, 48, 1).cuda()
+    with torch.no_grad():
+        y, _ = fused.pw_conv(x, conv, ci_lo=0, ci_hi=24, use_bias=False)
+        ref = torch.einsum("oc,bcp->bop", conv.weight[:, :24, 0, 0].double(), x.double())
+        assert rel_err(y, ref) < TOL
+
+
+@pytest.mark.parametrize("B,ci,co,M,U", [(2, 35, 32, 64, 32), (2, 64, 128, 40, 32), (1, 16, 200, 24, 16), (2, 8, 64, 16, 64),
+                                         (2, 9, 16, 128, 4), (1, 32, 64, 50, 8)])
+@pytest.mark.parametrize("xf", [False, True])
+def test_pointwise_neighbour_pool(fused, B, ci, co, M, U, xf):
+    """GEMM -> norm -> Swish -> max over the U neighbours, through the {min, max} epilogue"""
+    torch.manual_seed(M * U + ci)
+    P = M * U
+    assert fused.pool_supported(P, U)
+    x = torch.randn(B, ci, P, device="cuda") * 2
+    conv = torch.nn.Conv2d(ci, co, 1).cuda()
+    isc = (torch.rand(B, ci, device="cuda") + 0.5) if xf else None
+    ish = torch.randn(B, ci, device="cuda") if xf else None
+    # output-side folded norm: both signs of the scale
+    sc, sh = torch.randn(B, co, device="cuda"), torch.randn(B, co, device="cuda")
+    with torch.no_grad():
+        yfull, st_full = fused.pw_conv(x, conv, isc, ish, swish=xf)
+        ref = swish(yfull.double() * sc[:, :, None].double() + sh[:, :, None].double()).view(B, co, M, U).amax(3)
+        # the two-pass form this replaces (it needs whole waves of neighbourhoods)
+        want = fused.affine_act_max(yfull, sc, sh, M, U) if (M * U) % 64 == 0 else ref
+        for store in (True, False):
+            y, st, mm = fused.pw_conv(x, conv, isc, ish, swish=xf, pool_u=U, store=store)
+            assert (y is None) == (not store)
+            if store:
+                assert torch.equal(y, yfull)
+            assert torch.equal(st, st_full)
+            got = fused.minmax_act(mm, sc, sh)
+            assert got.shape == (B, co, M)
+            assert rel_err(got, ref) < 1e-5
+            assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("B,ci,co,P", [(2, 64, 128, 1024), (3, 128, 1024, 520), (1, 16, 24, 4), (2, 32, 64, 8192)])
+def test_pointwise_global_pool(fused, B, ci, co, P):
+    torch.manual_seed(P + co)
+    x = torch.randn(B, ci, P, device="cuda")
+    conv = torch.nn.Conv2d(ci, co, 1).cuda()
+    sc, sh = torch.randn(B, co, device="cuda"), torch.randn(B, co, device="cuda")
+    with torch.no_grad():
+        yfull, st_full = fused.pw_conv(x, conv)
+        ref = swish(yfull.double() * sc[:, :, None].double() + sh[:, :, None].double()).amax(2)
+        want = fused.affine_act_max(yfull, sc, sh, P, 0)
+        y, st, mm = fused.pw_conv(x, conv, pool_u=0, store=False)
+        assert y is None and torch.equal(st, st_full)
+        got = fused.minmax_act(mm, sc, sh, global_pool=True)
+        assert got.shape == (B, co)
+        assert rel_err(got, ref) < 1e-5 and rel_err(got, want) < 1e-5
+
+
+def test_pool_unsupported_shapes(fused):
+    assert not fused.pool_supported(1001, 0)      # rows not 16-byte aligned
+    assert not fused.pool_supported(96 * 3, 96)   # neighbourhood size not a power of two in 4..64
+    assert not fused.pool_supported(128 * 128, 128)
+    assert fused.pool_supported(1024 * 32, 32) and fused.pool_supported(8192, 0)
+
+
+def test_affine_act_and_max(fused):
+    torch.manual_seed(3)
+    B, C, M, U = 2, 24, 48, 32
+    x = torch.randn(B, C, M * U, device="cuda")
+    sc, sh = torch.randn(B, C, device="cuda"), torch.randn(B, C, device="cuda")
+    res = torch.randn(B, C, M * U, device="cuda")
+    with torch.no_grad():
+        z = swish(x.double() * sc[:, :, None].double() + sh[:, :, None].double())
+        assert rel_err(fused.affine_act(x, sc, sh, True, res), z + res.double()) < 1e-5
+        assert rel_err(fused.affine_act(x, sc, sh, False), x.double() * sc[:, :, None] + sh[:, :, None]) < 1e-6
+        assert rel_err(fused.affine_act_max(x, sc, sh, M, U), z.view(B, C, M, U).amax(3)) < 1e-5
+        assert rel_err(fused.affine_act_max(x, sc, sh, M * U, 0), z.amax(2)) < 1e-5
+
+
+@pytest.mark.parametrize("groups,style", [(8, False), (8, True), (4, True)])
+def test_gn_affine_params(fused, groups, style):
+    """{sum, sumsq} partials -> the per-(sample, channel) affine equal to GroupNorm (+ AdaGN style)"""
+    torch.manual_seed(11)
+    B, C, P = 3, 64, 1000
+    x = torch.randn(B, C, P, device="cuda") * 3 + 1
+    conv = torch.nn.Conv1d(C, C, 1).cuda()
+    gn = torch.nn.GroupNorm(groups, C).cuda()
+    with torch.no_grad():
+        gn.weight.normal_()
+        gn.bias.normal_()
+        y, st = fused.pw_conv(x, conv)
+        sty = torch.randn(B, 2 * C, device="cuda") if style else None
+        sc, sh, _ = fused.gn_affine_params(st, P, groups, gn.weight, gn.bias, sty, gn.eps)
+        ref = gn(y)
+        if style:  # AdaGN (models/modules.py:319-358): factor, bias = style.chunk(2); out = norm * factor + bias
+            ref = ref * sty[:, :C, None] + sty[:, C:, None]
+        got = y * sc[:, :, None] + sh[:, :, None]
+        assert rel_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("B,ci,co,r,compact", [(2, 35, 32, 32, True), (2, 16, 64, 32, False), (2, 64, 64, 16, True),
+                                               (2, 128, 64, 16, False), (2, 24, 40, 8, False), (1, 8, 8, 4, False)])
+def test_conv3d_k3(fused, B, ci, co, r, compact):
+    torch.manual_seed(r + ci)
+    x = torch.randn(B, ci, r, r, r, device="cuda")
+    x[:, :, : r // 2] = 0  # an all-zero slab exercises the zero-tile skip
+    conv = torch.nn.Conv3d(ci, co, 3, padding=1).cuda()
+    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
+    with torch.no_grad():
+        ref = torch.nn.functional.conv3d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        for skip in (False, True):
+            y, st = fused.conv3d_k3(x, conv, skip_zero=skip, compact=compact)
+            assert rel_err(y, ref) < TOL
+            assert rel_err(stats_of(st)[1], (ref * ref).flatten(2).sum(2)) < TOL
+        xin = swish(x * sc[:, :, None, None, None] + sh[:, :, None, None, None])
+        ref2 = torch.nn.functional.conv3d(xin.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        y2, _ = fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=compact)
+        assert rel_err(y2, ref2) < TOL
