@@ -152,6 +152,11 @@ int p2pb_auction_backward(int b, int n, const float *xyz1, const float *xyz2, fl
  * Weights are pre-packed once: w f32[cout,cin,3,3,3] -> wt_packed f32[p2pb_conv3d_k3_packed_floats()]. */
 size_t p2pb_conv3d_k3_packed_floats(int cout, int cin);
 int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, float *wt_packed, void *stream);
+/* The split pack: every weight as three bf16 terms (w = w0 + w1 + w2) for the bf16x6 form of the same
+ * convolution -- six bf16 MFMA products per fp32 product, fp32 accumulate, dropped terms < 2^-26 |x*w|
+ * (conv3d.hip: fp32-faithful, 1.6x the fp32 matrix-core rate). Selected by flags bit 2 below. */
+size_t p2pb_conv3d_k3_split_packed_bytes(int cout, int cin);
+int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float *w, void *wt_split, void *stream);
 /* out[b,cout,r,r,r] = conv(xf(in[b,cin,r,r,r])) + bias;  xf(x) = x when in_scale == NULL, else
  * x*in_scale[b,ci] + in_shift[b,ci] followed by Swish when in_swish != 0 (the preceding AdaGN+Swish,
  * folded). stats_part (optional, f32[p2pb_conv3d_k3_stats_floats()]) receives per-(b, slot, cout)
@@ -163,8 +168,9 @@ int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, con
 
 /* Sparse-aware form (exact): in_sub f32[b,cin] is subtracted from the transformed operand, out_class
  * f32[b,27,cout] replaces bias per boundary class (low / interior / high along d,h,w) -- see conv3d.hip:
- * conv(x) = conv(x - a) + conv(a). flags bit 0: skip all-zero operand tiles; bit 1: compact 4x8x8 bricks. */
-int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+ * conv(x) = conv(x - a) + conv(a). flags bit 0: skip all-zero operand tiles; bit 1: compact 4x8x8 bricks;
+ * bit 2: wt_packed is the split pack (bf16x6 arithmetic), else the fp32 pack (exact-fp32 MFMA). */
+int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                               const float *bias, const float *out_class, const float *in_scale,
                               const float *in_shift, int in_swish, const float *in_sub, int flags, float *out,
                               float *stats_part, void *stream);
@@ -176,11 +182,11 @@ int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, 
  * known) constants + statistics of the inactive bricks. */
 int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned char *flags_ws, int *lists, int *counts,
                             void *stream);
-int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                   const float *bias, const float *out_class, const float *in_scale,
-                                  const float *in_shift, int in_swish, const float *in_sub, const int *active_list,
-                                  const int *active_count, const int *inactive_list, const int *inactive_count,
-                                  float *out, float *stats_part, void *stream);
+                                  const float *in_shift, int in_swish, const float *in_sub, int flags /* bit 2 */,
+                                  const int *active_list, const int *active_count, const int *inactive_list,
+                                  const int *inactive_count, float *out, float *stats_part, void *stream);
 /* a[b,cin] = xf(prev_bias[cin]) (the operand's far-field constant) and k_out[b,27,cout] = conv(a) + bias per
  * boundary class, for p2pb_conv3d_k3_forward_ex */
 int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,

@@ -21,6 +21,7 @@ SYMBOLS = [
     "p2pb_three_interpolate", "p2pb_chamfer_forward",
     "p2pb_chamfer_backward", "p2pb_approxmatch_forward", "p2pb_matchcost_forward", "p2pb_matchcost_backward",
     "p2pb_auction_forward", "p2pb_auction_backward", "p2pb_conv3d_k3_packed_floats", "p2pb_conv3d_k3_pack_weights",
+    "p2pb_conv3d_k3_split_packed_bytes", "p2pb_conv3d_k3_pack_weights_split",
     "p2pb_conv3d_k3_stats_floats", "p2pb_conv3d_k3_forward", "p2pb_conv3d_k3_forward_ex",
     "p2pb_conv3d_k3_far_field", "p2pb_conv3d_brick_lists", "p2pb_conv3d_k3_forward_sparse", "p2pb_gn_affine_params",
     "p2pb_trilinear_devoxelize_affine", "p2pb_pointwise_packed_floats", "p2pb_pointwise_pack_weights",
@@ -47,6 +48,7 @@ def lib():
         _lib.p2pb_target_arch.restype = ctypes.c_char_p
         _lib.p2pb_avg_voxelize_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_conv3d_k3_packed_floats.restype = ctypes.c_size_t
+        _lib.p2pb_conv3d_k3_split_packed_bytes.restype = ctypes.c_size_t
         _lib.p2pb_conv3d_k3_stats_floats.restype = ctypes.c_size_t
         _lib.p2pb_pointwise_packed_floats.restype = ctypes.c_size_t
         _lib.p2pb_pointwise_stats_floats.restype = ctypes.c_size_t

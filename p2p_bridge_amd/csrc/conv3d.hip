@@ -210,10 +210,14 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
     f32x4 a_cur[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a_cur[m] = *(const f32x4 *)(wchunk + (size_t)m * 32 * 4);
+    // B fragments are read one k-pair ahead, A fragments one tap ahead; the scheduling barriers pin both
+    // prefetches (left alone, the scheduler sinks every load to just before its first use, so each group of
+    // MFMAs would start with an exposed LDS / L2 round trip)
+    float bf[2], bf_nxt[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) bf[s] = tile[khalf * PLANE + nbase[s]];
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
-      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-      const int toff = (kd * HH + kh) * HW + kw;
       f32x4 a_nxt[MT];
       if (tap + 1 < 27) {
 #pragma unroll
@@ -222,14 +226,21 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
       }
 #pragma unroll
       for (int kk = 0; kk < CONV_CK / 2; ++kk) {
-        float bf[2];
+        const int step = tap * (CONV_CK / 2) + kk + 1;  // the (tap, k-pair) after this one
+        if (step < 27 * (CONV_CK / 2)) {
+          const int ntap = step / (CONV_CK / 2), nkk = step % (CONV_CK / 2);
+          const int ntoff = ((ntap / 9) * HH + (ntap / 3) % 3) * HW + ntap % 3;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) bf[s] = tile[(2 * kk + khalf) * PLANE + nbase[s] + toff];
+          for (int s = 0; s < 2; ++s) bf_nxt[s] = tile[(2 * nkk + khalf) * PLANE + nbase[s] + ntoff];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int s = 0; s < 2; ++s)
             acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][kk], bf[s], acc[m][s], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bf[s] = bf_nxt[s];
       }
       if (tap + 1 < 27) {
 #pragma unroll
@@ -286,6 +297,296 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
   }
 }
 
+// ================================================================================================
+// Split-operand form (the default): the same implicit GEMM on the bf16 matrix pipe, fp32-faithful.
+//
+// gfx950 multiplies fp32 on the matrix cores at 1/16 of the bf16 rate (v_mfma_f32_32x32x2_f32: 2048 MACs
+// per 64 cycles; v_mfma_f32_32x32x16_bf16: 16384 per 32), and has no TF32. Each fp32 operand is therefore
+// split into three bf16 terms, x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)
+// (round-to-nearest; the two residuals are exact in fp32), which carries 24+ significand bits, and a product
+// is evaluated as the six terms
+//        x*y ~= x2*y0 + x1*y1 + x0*y2 + x1*y0 + x0*y1 + x0*y0        (bf16 x bf16 is exact in fp32)
+// accumulated in the fp32 MFMA accumulator, small terms first. The three dropped terms are below
+// 2^-26 |x*y| (a quarter of an fp32 ulp), so the result differs from the exact-fp32 MFMA kernel above by
+// less than a change of summation order: measured against fp64 on the network's layer shapes the rms error
+// is 1.6e-7 for this kernel vs 1.9e-7 for the fp32 MFMA one (tests/test_fused_gpu.py pins this).
+// Six bf16 MFMAs (192 cycles) replace eight fp32 ones (512 cycles) per 32x32x16 block: 2.67x fewer matrix
+// cycles; measured 196 vs 120 TFLOP/s (fp32-equivalent) on the 128->128 r=16 layer.
+//
+// Layout: LDS tile[split][khalf][halo voxel] of 16-byte groups = 8 consecutive input channels as bf16, so a
+// lane's B fragment of one MFMA is one ds_read_b128; weights pre-split and packed
+// [tap][chunk16][split][khalf][cout_pad][8 bf16] so an A fragment is one 16-byte load. The operand
+// transform (folded norm + Swish, far-field subtraction), the zero-tile skip, the brick lists and the epilogue
+// are those of the fp32 kernel; the split happens once per staged element and is reused by 27 taps.
+// ================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define CONV_SCK 16  // input channels per LDS stage of the split kernel = K of one bf16 MFMA
+
+// (a, b) -> packed bf16 pairs of the three split terms
+__device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2) {
+  f32x2 v = {a, b};
+  const bf16x2 q0 = __builtin_convertvector(v, bf16x2);
+  v = v - __builtin_convertvector(q0, f32x2);
+  const bf16x2 q1 = __builtin_convertvector(v, bf16x2);
+  v = v - __builtin_convertvector(q1, f32x2);
+  const bf16x2 q2 = __builtin_convertvector(v, bf16x2);
+  p0 = __builtin_bit_cast(unsigned, q0);
+  p1 = __builtin_bit_cast(unsigned, q1);
+  p2 = __builtin_bit_cast(unsigned, q2);
+}
+
+// packed weights: wt[tap][chunk16][split 3][khalf 2][cout_pad][8 bf16]; element idx = channel chunk*16 + khalf*8 + idx
+__global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
+                                        unsigned short *__restrict__ wt) {
+  const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;  // one thread per (tap, chunk, khalf, co, idx)
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int idx = (int)(e & 7);
+    size_t q = e >> 3;
+    const int co = (int)(q % cout_pad);
+    q /= cout_pad;
+    const int kh = (int)(q & 1);
+    q >>= 1;
+    const int chunk = (int)(q % nchunk), tap = (int)(q / nchunk);
+    const int ci = chunk * CONV_SCK + kh * 8 + idx;
+    const float x = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 27 + tap] : 0.0f;
+    unsigned p0, p1, p2;
+    split3(x, 0.0f, p0, p1, p2);
+    const unsigned p[3] = {p0, p1, p2};
+    for (int s = 0; s < 3; ++s)
+      wt[((((size_t)(tap * nchunk + chunk) * 3 + s) * 2 + kh) * cout_pad + co) * 8 + idx] = (unsigned short)(p[s] & 0xffff);
+  }
+}
+
+template <int R, bool COMPACT, int MT, bool XF>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
+                                                             const float *__restrict__ in,
+                                                             const unsigned short *__restrict__ wt,
+                                                             const float *__restrict__ bias,
+                                                             const float *__restrict__ out_class,
+                                                             const float *__restrict__ in_scale,
+                                                             const float *__restrict__ in_shift, int in_swish,
+                                                             const float *__restrict__ in_sub, int skip_zero,
+                                                             const int *__restrict__ brick_list,
+                                                             const int *__restrict__ brick_count,
+                                                             float *__restrict__ out, float *__restrict__ stats_part) {
+  using G = ConvGeom<R, COMPACT>;
+  constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
+  constexpr int PLANE = HD * HH * HW;
+  constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;
+  constexpr int BH = R / G::TH, BW = R / G::TW;
+  constexpr int R3 = R * R * R;
+  // tile[split][khalf][voxel] : 8 bf16 (16 bytes) = channels khalf*8 .. khalf*8+7 of the staged chunk
+  __shared__ u32x4 tile[3 * 2 * PLANE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  constexpr int BD = R / G::TD;
+  constexpr int NBRICK = BD * BH * BW;
+  int bd, bh, bw, b = blockIdx.z;
+  if (brick_list) {
+    if ((int)blockIdx.x >= *brick_count) return;
+    const int entry = brick_list[blockIdx.x];
+    b = entry / NBRICK;
+    const int bk = entry % NBRICK;
+    bd = bk / (BH * BW);
+    bh = (bk / BW) % BH;
+    bw = bk % BW;
+  } else if (COMPACT) {
+    const int hi = blockIdx.x / BD, lo = blockIdx.x % BD;
+    bh = hi / BW;
+    bw = hi % BW;
+    bd = (lo + 8 * BD - (3 * bh + 5 * bw)) % BD;
+  } else {
+    bd = blockIdx.x / (BH * BW);
+    bh = (blockIdx.x / BW) % BH;
+    bw = blockIdx.x % BW;
+  }
+  const int brick = (bd * BH + bh) * BW + bw;
+  const int d0 = bd * G::TD, h0 = bh * G::TH, w0 = bw * G::TW;
+  const int co0 = blockIdx.y * (32 * MT);
+
+  int nbase[2];
+  bool nact[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = 2 * wave + s;
+    nact[s] = t < NTILES;
+    constexpr int HB = G::TH / G::NH;
+    const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
+    const int jw = l31 % G::TW, jr = l31 / G::TW;
+    const int jh = jr % G::NH, jd = jr / G::NH;
+    nbase[s] = ((td + jd) * HH + (th + jh)) * HW + jw;
+  }
+
+  constexpr int NP = (PLANE + 255) / 256;
+  int soff[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int e = tid + j * 256;
+    const int dz = e / (HH * HW), hy = (e / HW) % HH, wx = e % HW;
+    const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = w0 - 1 + wx;
+    const bool ok = e < PLANE && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
+    soff[j] = ok ? (d * R + h) * R + w : -1;
+  }
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
+
+  const float *inb = in + (size_t)b * cin * R3;
+  float stg[CONV_SCK][NP];
+  auto stage_load = [&](int ci0) {
+#pragma unroll
+    for (int c = 0; c < CONV_SCK; ++c)
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+        stg[c][j] = (soff[j] >= 0 && ci0 + c < cin) ? inb[(size_t)(ci0 + c) * R3 + soff[j]] : 0.0f;
+  };
+  stage_load(0);
+
+  for (int ci0 = 0; ci0 < cin; ci0 += CONV_SCK) {
+    __syncthreads();
+    int nonzero = 0;
+#pragma unroll
+    for (int c = 0; c < CONV_SCK; ++c) {
+      float sc = 1.0f, sh = 0.0f, sub = 0.0f;
+      const bool cok = ci0 + c < cin;
+      if (XF && cok) {
+        sc = in_scale[b * cin + ci0 + c];
+        sh = in_shift[b * cin + ci0 + c];
+        if (in_sub) sub = in_sub[b * cin + ci0 + c];
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        float v = stg[c][j];
+        if (XF && cok && soff[j] >= 0) v = xf_apply(v, sc, sh, in_swish) - sub;
+        nonzero |= (v != 0.0f);
+        stg[c][j] = v;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int e = tid + j * 256;
+      if (e < PLANE) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4 q[3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned p0, p1, p2;
+            split3(stg[h * 8 + 2 * i][j], stg[h * 8 + 2 * i + 1][j], p0, p1, p2);
+            q[0][i] = p0;
+            q[1][i] = p1;
+            q[2][i] = p2;
+          }
+#pragma unroll
+          for (int s = 0; s < 3; ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
+        }
+      }
+    }
+    const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
+    if (ci0 + CONV_SCK < cin) stage_load(ci0 + CONV_SCK);
+    if (!any) continue;
+
+    const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
+    const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
+    u32x4 a_cur[3][MT], bf[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_cur[s][m] = wchunk[s * wsplit_stride + m * 32];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n]];
+    }
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+      u32x4 a_nxt[3][MT], bf_nxt[3][2];
+      if (tap + 1 < 27) {  // both operands of the next tap are requested before this tap is multiplied
+        const int ntap = tap + 1;
+        const int toff = ((ntap / 9) * HH + (ntap / 3) % 3) * HW + ntap % 3;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a_nxt[s][m] = wchunk[(size_t)ntap * wtap_stride + s * wsplit_stride + m * 32];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) bf_nxt[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // small terms first
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[PA[t]][m]),
+                                                                __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
+      if (tap + 1 < 27) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a_cur[s][m] = a_nxt[s][m];
+#pragma unroll
+          for (int n = 0; n < 2; ++n) bf[s][n] = bf_nxt[s][n];
+        }
+      }
+    }
+  }
+
+  float *outb = out + (size_t)b * cout * R3;
+  int vox[2], cls[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int t = 2 * wave + s;
+    constexpr int HB = G::TH / G::NH;
+    const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
+    const int jw = l31 % G::TW, jr = l31 / G::TW;
+    const int d = d0 + td + jr / G::NH, h = h0 + th + jr % G::NH, w = w0 + jw;
+    vox[s] = (d * R + h) * R + w;
+    const int cd = d == 0 ? 0 : (d == R - 1 ? 2 : 1), ch = h == 0 ? 0 : (h == R - 1 ? 2 : 1),
+              cw = w == 0 ? 0 : (w == R - 1 ? 2 : 1);
+    cls[s] = (cd * 3 + ch) * 3 + cw;
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const bool cok = co < cout;
+      const float bv = (cok && !out_class) ? bias[co] : 0.0f;
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (!nact[s]) continue;
+        float v = acc[m][s][r] + bv;
+        if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
+        if (cok) outb[(size_t)co * R3 + vox[s]] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+      if (stats_part) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && cok) {
+          float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wave) * cout + co) * 2;
+          p[0] = s1;
+          p[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+
 // weights [cout][cin][3][3][3] -> packed [27][cin_pad/8][2][cout_pad][4] (zero padded):
 // element (tap, chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf][tap], so that the four k-pair
 // values one lane needs for a tap are one aligned 16-byte load and lanes 0..31 read 512 contiguous bytes
@@ -316,6 +617,20 @@ extern "C" int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, fl
 extern "C" size_t p2pb_conv3d_k3_packed_floats(int cout, int cin) {
   const int cin_pad = (cin + CONV_CK - 1) / CONV_CK * CONV_CK, cout_pad = (cout + 63) / 64 * 64;
   return (size_t)27 * cin_pad * cout_pad;
+}
+
+extern "C" size_t p2pb_conv3d_k3_split_packed_bytes(int cout, int cin) {
+  const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
+  return (size_t)27 * nchunk * 3 * 2 * cout_pad * 8 * sizeof(unsigned short);
+}
+
+extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float *w, void *wt_split, void *stream) {
+  if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
+  const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
+  const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;
+  hipLaunchKernelGGL(conv3d_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, (unsigned short *)wt_split);
+  return p2pb_launch_status();
 }
 
 static int conv_bricks(int r) { return r == 32 ? 128 : r == 16 ? 16 : r == 8 ? 2 : 1; }  // both geometries
@@ -399,6 +714,26 @@ static int conv_launch(int b, int cin, int cout, const float *in, const float *w
     hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, false>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
                        wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,
                        out, stats_part);
+  return p2pb_launch_status();
+}
+
+template <int R, int MT>
+static int conv_launch_split(int b, int cin, int cout, const float *in, const void *wt, const float *bias,
+                             const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                             const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count,
+                             float *out, float *stats_part, hipStream_t s) {
+  const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
+  dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
+  if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
+  const unsigned short *w = (const unsigned short *)wt;
+  if (in_scale != nullptr)
+    hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, true>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
+                       w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count, out,
+                       stats_part);
+  else
+    hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, false>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
+                       w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count, out,
+                       stats_part);
   return p2pb_launch_status();
 }
 
@@ -544,7 +879,8 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
 // out[b,cout,r,r,r] = conv3d(xf(in[b,cin,r,r,r]), W) + bias, where xf(x) = x (in_scale == NULL) or
 // swish?(x*in_scale[b,ci] + in_shift[b,ci]) - in_sub[b,ci]; out_class (optional, f32[b,27,cout]) replaces
 // bias per boundary class; stats_part (optional) receives per-(b, slot, cout) {sum, sum of squares} of the
-// output. flags: bit 0 = skip all-zero operand tiles (exact), bit 1 = compact 4x8x8 bricks. r in {4,8,16,32}.
+// output. flags: bit 0 = skip all-zero operand tiles (exact), bit 1 = compact 4x8x8 bricks, bit 2 = wt_packed is
+// the split pack (p2pb_conv3d_k3_pack_weights_split) -> bf16x6 kernel. r in {4,8,16,32}.
 extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
                                       const float *bias, const float *in_scale, const float *in_shift, int in_swish,
                                       float *out, float *stats_part, void *stream) {
@@ -552,7 +888,7 @@ extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const flo
                                    0, out, stats_part, stream);
 }
 
-extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                          const float *bias, const float *out_class, const float *in_scale,
                                          const float *in_shift, int in_swish, const float *in_sub, int flags,
                                          float *out, float *stats_part, void *stream) {
@@ -562,10 +898,26 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
   const bool compact = (flags & 2) != 0;
   // 64 output channels per workgroup unless that leaves fewer than 2 workgroups per CU (small grids)
   const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 512;
+  if (flags & 4) {  // wt_packed is the split (3 x bf16) pack; always the compact tiling (same results, same slots)
+#define GOS(RR)                                                                                                       \
+  return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, s)                          \
+              : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, s)
+    switch (r) {
+      case 32: GOS(32);
+      case 16: GOS(16);
+      case 8: GOS(8);
+      case 4: GOS(4);
+      default: return P2PB_EINVAL;
+    }
+#undef GOS
+  }
+  const float *wt32 = (const float *)wt_packed;
 #define GO(RR, CP)                                                                                                    \
-  return wide ? conv_launch<RR, CP, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,    \
+  return wide ? conv_launch<RR, CP, 2>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,         \
                                        in_sub, skip, nullptr, nullptr, out, stats_part, s)                            \
-              : conv_launch<RR, CP, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,    \
+              : conv_launch<RR, CP, 1>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,         \
                                        in_sub, skip, nullptr, nullptr, out, stats_part, s)
   switch (r) {
     case 32:
@@ -581,9 +933,9 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
 
 // list-driven sparse form: MFMA workgroups only for the `active` (sample, brick) pairs, constants for the
 // `inactive` ones (lists from p2pb_conv3d_brick_lists). Compact geometry; r in {16, 32}.
-extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
+extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                              const float *bias, const float *out_class, const float *in_scale,
-                                             const float *in_shift, int in_swish, const float *in_sub,
+                                             const float *in_shift, int in_swish, const float *in_sub, int flags,
                                              const int *active_list, const int *active_count,
                                              const int *inactive_list, const int *inactive_count, float *out,
                                              float *stats_part, void *stream) {
@@ -597,10 +949,21 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
     hipLaunchKernelGGL(conv3d_fill_kernel<16>, dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list,
                        inactive_count, out, stats_part);
   const bool wide = cout > 32;
-#define GO(RR)                                                                                                        \
-  return wide ? conv_launch<RR, true, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
+  if (flags & 4) {
+#define GOS(RR)                                                                                                       \
+  return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
                                          in_sub, 1, active_list, active_count, out, stats_part, s)                    \
-              : conv_launch<RR, true, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
+              : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
+                                         in_sub, 1, active_list, active_count, out, stats_part, s)
+    if (r == 32) { GOS(32); }
+    GOS(16);
+#undef GOS
+  }
+  const float *wt32 = (const float *)wt_packed;
+#define GO(RR)                                                                                                        \
+  return wide ? conv_launch<RR, true, 2>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,       \
+                                         in_sub, 1, active_list, active_count, out, stats_part, s)                    \
+              : conv_launch<RR, true, 1>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,       \
                                          in_sub, 1, active_list, active_count, out, stats_part, s)
   if (r == 32) { GO(32); }
   GO(16);

@@ -8,6 +8,7 @@ per-(sample, channel) scale/shift vectors, so each grid tensor is written once a
 Training keeps the unfused autograd graph (pvcnn_unet.PVConv.forward).
 """
 import ctypes
+import os
 
 import torch
 
@@ -17,36 +18,55 @@ _i, _f, _d = ctypes.c_int, ctypes.c_float, ctypes.c_double
 F32 = torch.float32
 
 
-def pack_conv3d_weight(conv: torch.nn.Conv3d) -> torch.Tensor:
-    """packed [27][cin_pad][cout_pad] copy of a Conv3d weight, cached on the module and refreshed when the
-    parameter is modified in place (optimizer step / load_state_dict) or replaced"""
+def conv_math() -> str:
+    """arithmetic of the voxel convolutions: "bf16x6" (default: fp32 operands as three bf16 terms, six bf16 MFMA
+    products per fp32 product, fp32 accumulate -- fp32-faithful, csrc/conv3d.hip) or "fp32" (exact-fp32 MFMA);
+    chosen with P2PB_CONV_MATH"""
+    m = os.environ.get("P2PB_CONV_MATH", "bf16x6")
+    if m not in ("bf16x6", "fp32"):
+        raise ValueError(f"P2PB_CONV_MATH must be bf16x6 or fp32, got {m!r}")
+    return m
+
+
+def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
+    """packed copy of a Conv3d weight (fp32 [27][cin_pad][cout_pad], or split=True the 3 x bf16 pack of the bf16x6
+    kernel), cached on the module and refreshed when the parameter is modified in place (optimizer step /
+    load_state_dict) or replaced"""
     w = conv.weight
     key = (w.data_ptr(), w._version, w.device)
     cache = getattr(conv, "_p2pb_packed", None)
     if cache is None or cache[0] != key:
+        cache = conv._p2pb_packed = (key, {})
+    packs = cache[1]
+    if split not in packs:
         co, ci = w.shape[:2]
         assert tuple(w.shape[2:]) == (3, 3, 3) and conv.padding == (1, 1, 1) and conv.stride == (1, 1, 1)
-        wt = torch.empty(lib().p2pb_conv3d_k3_packed_floats(_i(co), _i(ci)), dtype=F32, device=w.device)
-        call("p2pb_conv3d_k3_pack_weights", _i(co), _i(ci), ptr(w.detach().contiguous()), ptr(wt), stream_ptr())
-        conv._p2pb_packed = (key, wt)
-        cache = conv._p2pb_packed
-    return cache[1]
+        wc = w.detach().contiguous()
+        if split:
+            wt = torch.empty(lib().p2pb_conv3d_k3_split_packed_bytes(_i(co), _i(ci)), dtype=torch.uint8, device=w.device)
+            call("p2pb_conv3d_k3_pack_weights_split", _i(co), _i(ci), ptr(wc), ptr(wt), stream_ptr())
+        else:
+            wt = torch.empty(lib().p2pb_conv3d_k3_packed_floats(_i(co), _i(ci)), dtype=F32, device=w.device)
+            call("p2pb_conv3d_k3_pack_weights", _i(co), _i(ci), ptr(wc), ptr(wt), stream_ptr())
+        packs[split] = wt
+    return packs[split]
 
 
 def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
-              skip_zero=False, compact=False):
+              skip_zero=False, compact=False, math=None):
     """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None).
     in_sub / out_class / skip_zero / compact: the exact sparse form (csrc/conv3d.hip header)."""
     check(x, F32, "x")
     b, ci, r = x.shape[0], x.shape[1], x.shape[2]
     co = conv.out_channels
-    wt = pack_conv3d_weight(conv)
+    split = (math or conv_math()) == "bf16x6"
+    wt = pack_conv3d_weight(conv, split)
     y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
     st = None
     if stats:
         nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
-    flags = (1 if skip_zero else 0) | (2 if compact else 0)
+    flags = (1 if skip_zero else 0) | (2 if compact else 0) | (4 if split else 0)
     call("p2pb_conv3d_k3_forward_ex", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
          ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st), stream_ptr())
     return y, st
@@ -65,19 +85,20 @@ def brick_lists(cnt, r):
 
 
 def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                     out_class=None):
+                     out_class=None, math=None):
     """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second"""
     check(x, F32, "x")
     b, ci, r = x.shape[0], x.shape[1], x.shape[2]
     co = conv.out_channels
-    wt = pack_conv3d_weight(conv)
+    split = (math or conv_math()) == "bf16x6"
+    wt = pack_conv3d_weight(conv, split)
     y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
     nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
     st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     act, ina = lists[2 * which], lists[2 * which + 1]
     call("p2pb_conv3d_k3_forward_sparse", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(act), ptr(counts[2 * which:]), ptr(ina),
-         ptr(counts[2 * which + 1:]), ptr(y), ptr(st), stream_ptr())
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(4 if split else 0), ptr(act),
+         ptr(counts[2 * which:]), ptr(ina), ptr(counts[2 * which + 1:]), ptr(y), ptr(st), stream_ptr())
     return y, st
 
 

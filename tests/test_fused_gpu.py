@@ -163,9 +163,11 @@ def test_gn_affine_params(fused, groups, style):
         assert rel_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("math", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("B,ci,co,r,compact", [(2, 35, 32, 32, True), (2, 16, 64, 32, False), (2, 64, 64, 16, True),
-                                               (2, 128, 64, 16, False), (2, 24, 40, 8, False), (1, 8, 8, 4, False)])
-def test_conv3d_k3(fused, B, ci, co, r, compact):
+                                               (2, 128, 64, 16, False), (2, 24, 40, 8, False), (1, 8, 8, 4, False),
+                                               (3, 200, 72, 8, False)])
+def test_conv3d_k3(fused, B, ci, co, r, compact, math):
     torch.manual_seed(r + ci)
     x = torch.randn(B, ci, r, r, r, device="cuda")
     x[:, :, : r // 2] = 0  # an all-zero slab exercises the zero-tile skip
@@ -174,10 +176,55 @@ def test_conv3d_k3(fused, B, ci, co, r, compact):
     with torch.no_grad():
         ref = torch.nn.functional.conv3d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
         for skip in (False, True):
-            y, st = fused.conv3d_k3(x, conv, skip_zero=skip, compact=compact)
+            y, st = fused.conv3d_k3(x, conv, skip_zero=skip, compact=compact, math=math)
             assert rel_err(y, ref) < TOL
             assert rel_err(stats_of(st)[1], (ref * ref).flatten(2).sum(2)) < TOL
         xin = swish(x * sc[:, :, None, None, None] + sh[:, :, None, None, None])
         ref2 = torch.nn.functional.conv3d(xin.double(), conv.weight.double(), conv.bias.double(), padding=1)
-        y2, _ = fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=compact)
+        y2, _ = fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=compact, math=math)
         assert rel_err(y2, ref2) < TOL
+
+
+@pytest.mark.parametrize("B,ci,co,r", [(2, 128, 128, 16), (2, 64, 64, 32), (4, 256, 256, 8)])
+def test_conv3d_split_is_fp32_faithful(fused, B, ci, co, r):
+    """The bf16x6 form (three bf16 terms per operand, six MFMA products, fp32 accumulate) must be as close to
+    the fp64 result as the exact-fp32 MFMA kernel is: its error is summation-order noise, not bf16 noise."""
+    torch.manual_seed(ci + r)
+    # wide dynamic range: values across 8 binades, both signs
+    x = torch.randn(B, ci, r, r, r, device="cuda") * torch.exp2(torch.randint(-4, 4, (B, ci, 1, 1, 1), device="cuda").float())
+    conv = torch.nn.Conv3d(ci, co, 3, padding=1).cuda()
+    with torch.no_grad():
+        ref = torch.nn.functional.conv3d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        y6, _ = fused.conv3d_k3(x, conv, compact=True, math="bf16x6")
+        y32, _ = fused.conv3d_k3(x, conv, compact=True, math="fp32")
+        scale = ref.abs().max()
+        rms6 = ((y6 - ref).pow(2).mean().sqrt() / scale).item()
+        rms32 = ((y32 - ref).pow(2).mean().sqrt() / scale).item()
+        max6 = ((y6 - ref).abs().max() / scale).item()
+        max32 = ((y32 - ref).abs().max() / scale).item()
+        assert rms6 < 1.25 * rms32 + 1e-9, (rms6, rms32)
+        assert max6 < 1.5 * max32 + 1e-8, (max6, max32)
+        assert max6 < 1e-5  # two orders inside the 1e-4 budget; plain bf16 would sit at ~4e-3
+
+
+def test_conv3d_sparse_lists_match_dense(fused):
+    """list-driven sparse form == dense form on a surface-like occupancy, both arithmetic modes"""
+    from p2p_bridge_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(9)
+    B, C, r, N = 2, 32, 32, 2048
+    pts = torch.nn.functional.normalize(torch.randn(B, 3, N, device="cuda"), dim=1) * 0.8  # points on a sphere
+    _, vox = ext.voxel_coords(pts, r)
+    f = torch.randn(B, C, N, device="cuda")
+    grid, _, cnt = ext.avg_voxelize_forward(f, vox, r)
+    grid = grid.view(B, C, r, r, r)
+    conv = torch.nn.Conv3d(C, 48, 3, padding=1).cuda()
+    lists, counts = fused.brick_lists(cnt, r)
+    assert 0 < counts[0].item() < B * 128
+    with torch.no_grad():
+        ref = torch.nn.functional.conv3d(grid.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        for math in ("bf16x6", "fp32"):
+            ys, sts = fused.conv3d_k3_sparse(grid, conv, lists, counts, 0, math=math)
+            yd, std = fused.conv3d_k3(grid, conv, compact=True, math=math)
+            assert torch.equal(ys, yd)
+            assert rel_err(ys, ref) < TOL
+            assert rel_err(stats_of(sts)[1], stats_of(std)[1]) < 1e-6
