@@ -35,15 +35,20 @@ PVDS = dict(
                         n_fp_blocks=[1, 2, 1, 1], radius=[0.1, 0.2, 0.4, 0.8], out_mlp=128)))
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
+# the split kernel spends six bf16 MFMA products per fp32 product: its matrix-pipe ceiling in fp32-equivalent FLOP/s
+SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6
 CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample per network evaluation (PVDS)
 
 
 def conv_roofline(model, B, reps=10):
-    """Dominant kernel = conv3d_k3_kernel (csrc/conv3d.hip), the 3x3x3 voxel convolution on the fp32 MFMA.
-    Timed live on the instance that costs the sampler most (fp_layers.2.{1,2} second conv: C 128->128,
-    r=16, compact bricks, folded AdaGN+Swish operand transform, GroupNorm statistics epilogue -- exactly as
-    the sampler launches it, 3x per network evaluation) with HIP events on the stream the kernel is
-    launched on (torch's current stream). (At r=32 the same kernel runs in its list-driven sparse form.)"""
+    """Dominant kernel = the 3x3x3 voxel convolution (csrc/conv3d.hip), timed live on the instance that costs
+    the sampler most (fp_layers.2.{1,2} second conv: C 128->128, r=16, compact bricks, folded AdaGN+Swish
+    operand transform, GroupNorm statistics epilogue -- exactly as the sampler launches it, 3x per network
+    evaluation) with HIP events on the stream the kernel is launched on (torch's current stream).
+    `achieved` counts ALGORITHMIC fp32 FLOPs (2*27*Cin*Cout per voxel). Default arithmetic: bf16x6 split
+    operands on the bf16 matrix pipe (six MFMA products per fp32 product), so `peak` is the dense bf16 MFMA
+    peak / 6; with P2PB_CONV_MATH=fp32 it is the exact-fp32 MFMA kernel against the fp32 MFMA peak."""
     from p2p_bridge_amd import fused
 
     pv = model.model.fp_layers[2][1]
@@ -64,11 +69,24 @@ def conv_roofline(model, B, reps=10):
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": f"conv3d_k3_kernel<{r},compact,2,XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
+    split = fused.conv_math() == "bf16x6"
+    peak = SPLIT_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
+    kname = "conv3d_k3_split_kernel" if split else "conv3d_k3_kernel"
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None,
+            "kernel": f"{kname}<{r},compact,2,XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
                       f"(fp_layers.2.1.voxel_layers.4)",
+            "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
+                           "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def conv_math_note():
+    from p2p_bridge_amd import fused
+
+    return ("fp32 results; voxel-conv products as bf16x6 split operands (3 bf16 terms each, 6 MFMA products, fp32 "
+            "accumulate; error vs fp64 equal to the fp32 MFMA kernel's)" if fused.conv_math() == "bf16x6"
+            else "exact-fp32 MFMA")
 
 
 def cpu_baseline(sd, n_points, T, steps_sampled=2):
@@ -163,7 +181,8 @@ def main():
         "config": {"workload": f"PVDS_PUNet xyz-only, {args.points}-pt patches, T={args.T} bridge steps, batch "
                                f"{args.batch} per GPU (BASELINE configs[1])", "patches_per_gpu": args.batch,
                    "points_per_patch": args.points, "bridge_steps": args.T, "parallelism": f"patch-shard x{world}",
-                   "hipgraph": bool(args.graph), "weights": "seeded random init (26.44 M params)"},
+                   "hipgraph": bool(args.graph), "weights": "seeded random init (26.44 M params)",
+                   "conv_math": conv_math_note()},
     }
     if rank == 0:
         res["roofline"] = conv_roofline(model, args.batch)

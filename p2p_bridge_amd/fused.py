@@ -28,6 +28,12 @@ def conv_math() -> str:
     return m
 
 
+def use_split(cout: int, math=None) -> bool:
+    """the split kernel pays off with 64 output channels per workgroup (two M-tiles share every B fragment);
+    32-channel layers (the first PVConv) stay on the exact-fp32 MFMA kernel, which is faster there"""
+    return (math or conv_math()) == "bf16x6" and cout > 32
+
+
 def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
     """packed copy of a Conv3d weight (fp32 [27][cin_pad][cout_pad], or split=True the 3 x bf16 pack of the bf16x6
     kernel), cached on the module and refreshed when the parameter is modified in place (optimizer step /
@@ -53,13 +59,13 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
 
 
 def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
-              skip_zero=False, compact=False, math=None):
+              skip_zero=False, compact=False, math=None, force_split=False):
     """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None).
     in_sub / out_class / skip_zero / compact: the exact sparse form (csrc/conv3d.hip header)."""
     check(x, F32, "x")
     b, ci, r = x.shape[0], x.shape[1], x.shape[2]
     co = conv.out_channels
-    split = (math or conv_math()) == "bf16x6"
+    split = force_split or use_split(co, math)  # force_split: the split kernel's 32-channel variant (tests)
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
     st = None
@@ -90,7 +96,7 @@ def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None
     check(x, F32, "x")
     b, ci, r = x.shape[0], x.shape[1], x.shape[2]
     co = conv.out_channels
-    split = (math or conv_math()) == "bf16x6"
+    split = use_split(co, math)
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
     nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
