@@ -214,22 +214,28 @@ int p2pb_pointwise_pack_weights(int cout, int cin, const float *w /* [cout][cin]
 size_t p2pb_pointwise_stats_floats(int b, int cout, int npos);
 /* out[b,cout,npos] = bias[cout] (+ bias_b[b,cout]) + W * xf(in[b,cin,npos]); xf / stats_part as in
  * p2pb_conv3d_k3_forward (stats_part f32[b, ceil(npos/256)*4, cout, 2]). bias, bias_b may be NULL. */
-int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const float *wp,
+int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const void *wp,
                                 const float *bias, const float *bias_b, const float *in_scale,
-                                const float *in_shift, int in_swish, float *out, float *stats_part, void *stream);
+                                const float *in_shift, int in_swish, int flags, float *out, float *stats_part,
+                                void *stream);
+/* flags bit 2: wp is the split pack below and the GEMM runs in the bf16x6 form (three bf16 terms per fp32
+ * operand, six MFMA products, fp32 accumulate -- see the conv3d split pack); needs npos % 4 == 0 and
+ * 16-byte aligned in/out. Meant for the matrix-bound layers (wide channel counts). */
+size_t p2pb_pointwise_split_packed_bytes(int cout, int cin);
+int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w /* [cout][cin] */, void *wp, void *stream);
 /* The same GEMM with the max-pool that follows the layer (set abstraction: max over the pool_u = 4..64
  * neighbours, models/pvcnn.py:414; Pnet2Stage: pool_u = 0, max over all positions, :923,930) prepared in the
  * epilogue: minmax receives {min, max} of the raw output per pooling group (pool_u > 0: f32[b,cout,npos/pool_u,2];
- * pool_u == 0: per-wave partials f32[b, ceil(npos/512)*4, cout, 2]) and p2pb_minmax_act turns them into the
+ * pool_u == 0: per-wave partials f32[b, nslots, cout, 2], nslots from p2pb_pointwise_minmax_floats) and p2pb_minmax_act turns them into the
  * pooled activations once the norm parameters are known (the activations are quasi-convex, so the max sits at
  * the min or the max of the pre-activation). out may be NULL: the layer output is then never written.
  * Needs npos % 4 == 0 and 16-byte aligned in/out (p2pb_pointwise_pool_supported), else P2PB_EINVAL. */
 int p2pb_pointwise_pool_supported(int npos, int pool_u);
-size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int pool_u);
-int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in, const float *wp,
+size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int pool_u, int flags);
+int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in, const void *wp,
                                      const float *bias, const float *bias_b, const float *in_scale,
-                                     const float *in_shift, int in_swish, float *out, float *stats_part, int pool_u,
-                                     float *minmax, void *stream);
+                                     const float *in_shift, int in_swish, int flags, float *out, float *stats_part,
+                                     int pool_u, float *minmax, void *stream);
 /* y = max(act(scale*min+shift), act(scale*max+shift)); nslots == 0: minmax f32[b,c,m,2] -> y f32[b,c,m];
  * nslots > 0: minmax f32[b,nslots,c,2] (reduced over nslots first) -> y f32[b,c] */
 int p2pb_minmax_act(int b, int c, int m, int nslots, const float *minmax, const float *scale, const float *shift,

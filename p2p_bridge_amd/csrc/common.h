@@ -41,5 +41,26 @@ __device__ __forceinline__ float halfwave_sum_to_last(float v) {
   return v;
 }
 
+// ---- fp32 operands on the bf16 matrix pipe (conv3d.hip "split-operand form", pointwise.hip) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> the three bf16 terms of each, packed as pairs (a in the low half): x = x0 + x1 + x2 with
+// x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round-to-nearest-even (v_cvt_pk_bf16_f32); both
+// residuals are exact in fp32, so the three terms carry 24+ significand bits
+__device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2) {
+  f32x2 v = {a, b};
+  const bf16x2 q0 = __builtin_convertvector(v, bf16x2);
+  v = v - __builtin_convertvector(q0, f32x2);
+  const bf16x2 q1 = __builtin_convertvector(v, bf16x2);
+  v = v - __builtin_convertvector(q1, f32x2);
+  const bf16x2 q2 = __builtin_convertvector(v, bf16x2);
+  p0 = __builtin_bit_cast(unsigned, q0);
+  p1 = __builtin_bit_cast(unsigned, q1);
+  p2 = __builtin_bit_cast(unsigned, q2);
+}
+
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);

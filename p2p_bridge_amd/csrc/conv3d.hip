@@ -319,24 +319,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
 // transform (folded norm + Swish, far-field subtraction), the zero-tile skip, the brick lists and the epilogue
 // are those of the fp32 kernel; the split happens once per staged element and is reused by 27 taps.
 // ================================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define CONV_SCK 16  // input channels per LDS stage of the split kernel = K of one bf16 MFMA
-
-// (a, b) -> packed bf16 pairs of the three split terms
-__device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2) {
-  f32x2 v = {a, b};
-  const bf16x2 q0 = __builtin_convertvector(v, bf16x2);
-  v = v - __builtin_convertvector(q0, f32x2);
-  const bf16x2 q1 = __builtin_convertvector(v, bf16x2);
-  v = v - __builtin_convertvector(q1, f32x2);
-  const bf16x2 q2 = __builtin_convertvector(v, bf16x2);
-  p0 = __builtin_bit_cast(unsigned, q0);
-  p1 = __builtin_bit_cast(unsigned, q1);
-  p2 = __builtin_bit_cast(unsigned, q2);
-}
 
 // packed weights: wt[tap][chunk16][split 3][khalf 2][cout_pad][8 bf16]; element idx = channel chunk*16 + khalf*8 + idx
 __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,

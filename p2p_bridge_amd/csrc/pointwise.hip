@@ -378,6 +378,252 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
   return (size_t)b * ((npos + 255) / 256) * 4 * cout * 2;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-operand form of the same GEMM for the matrix-bound layers (wide channel counts): fp32 operands as
+// three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulate -- the arithmetic of
+// conv3d.hip's split kernel (fp32-faithful: dropped terms < 2^-26 |x*w|), 2.67x fewer matrix cycles.
+// At that rate the operands can no longer stream through per-lane global loads (the wide kernel above
+// would need ~50 B/clk/CU of L1 bandwidth), so this one is the classic LDS-tiled GEMM:
+//   workgroup = 4 waves as 2 (M) x 2 (N): 128 output channels x 128 positions, 32 input channels per stage;
+//   A: pre-split packed weights, one contiguous 24 KB tile per (stage, 128-channel block), copied to LDS;
+//   B: each wave loads 8 channels x 128 positions (8-byte coalesced loads through scalar row descriptors),
+//      applies the folded norm + Swish ONCE per element, splits, and writes 16-byte groups of 8 channels;
+//   LDS[kstep][split][khalf][128 rows] x 16 B for both, so every MFMA fragment is one conflict-free
+//   ds_read_b128 (positions are stored even/odd de-interleaved: lane j of N-tile n owns position 2j+n,
+//   which also makes the epilogue's stores 8 bytes per lane).
+// Global loads of the next stage fly during the MFMAs of the current one (register staged).
+// ------------------------------------------------------------------------------------------------
+#define PWS_CK 32
+
+template <bool XF, bool POOL>
+__global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int P, int nslots,
+                                                       const float *__restrict__ in, const u32x4 *__restrict__ wp,
+                                                       const float *__restrict__ bias,
+                                                       const float *__restrict__ bias_b,
+                                                       const float *__restrict__ in_scale,
+                                                       const float *__restrict__ in_shift, int in_swish,
+                                                       float *__restrict__ out, float *__restrict__ stats_part,
+                                                       float *__restrict__ mm_out, int pool_u) {
+  __shared__ u32x4 lds_a[2 * 3 * 2 * 128];
+  __shared__ u32x4 lds_b[2 * 3 * 2 * 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the scalar descriptors
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int pblk = blockIdx.x * 128, co0 = blockIdx.y * 128, b = blockIdx.z;
+  const int ncoblk = gridDim.y;
+  const float *inb = in + (size_t)b * cin * P;
+  const bool mact = co0 + wm * 64 < cout;  // this wave's 64 channels exist (wave-uniform)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  // B staging: wave w owns channel group w (8 channels) of the stage, lane l positions 2l, 2l+1
+  const int pl = pblk + 2 * lane;
+  const unsigned voff = (unsigned)(pl < P ? pl : P - 2) * 4u;  // clamped lanes stage garbage that is never stored
+  f32x2 braw[8];
+  auto load_b = [&](int ci0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(ci0 + 8 * wave + i, cin - 1);  // beyond cin: finite garbage x zero weights
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, P * 4, 0x00020000);
+      braw[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+    }
+  };
+  u32x4 araw[6];
+  auto load_a = [&](int chunk) {
+    const u32x4 *src = wp + ((size_t)chunk * ncoblk + blockIdx.y) * (2 * 3 * 2 * 128);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) araw[i] = src[tid + i * 256];
+  };
+  load_b(0);
+  load_a(0);
+
+  for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
+    __syncthreads();  // everyone is done reading the previous stage
+    // ---- stage: A copy, B transform + split
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lds_a[tid + i * 256] = araw[i];
+    {
+      if (XF) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = b * cin + min(ci0 + 8 * wave + i, cin - 1);
+          const float sc = in_scale[c], sh = in_shift[c];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float v = braw[i][e] * sc + sh;
+            if (in_swish) v = swishf(v);
+            braw[i][e] = v;
+          }
+        }
+      }
+      const int kstep = wave >> 1, kh = wave & 1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        u32x4 q[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned p0, p1, p2;
+          split3(braw[2 * i][e], braw[2 * i + 1][e], p0, p1, p2);
+          q[0][i] = p0;
+          q[1][i] = p1;
+          q[2][i] = p2;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * 128 + e * 64 + lane] = q[s];
+      }
+    }
+    __syncthreads();
+    if (ci0 + PWS_CK < cin) {  // next stage's global loads fly during the MFMAs
+      load_b(ci0 + PWS_CK);
+      load_a(ci0 / PWS_CK + 1);
+    }
+    if (!mact) continue;
+#pragma unroll
+    for (int kstep = 0; kstep < 2; ++kstep) {
+      u32x4 af[3][2], bf[3][2];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af[s][m] = lds_a[((kstep * 3 + s) * 2 + khalf) * 128 + wm * 64 + m * 32 + l31];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * 128 + n * 64 + wn * 32 + l31];
+      }
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[t]][m]),
+                                                                __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
+    }
+  }
+  if (!mact) return;
+
+  // ---- epilogue: bias, 8-byte stores, GroupNorm partials per 64-position slot, optional {min, max}
+  float *outb = out ? out + (size_t)b * cout * P : nullptr;
+  const int p = pblk + 2 * (wn * 32 + l31);
+  const bool pok = p < P;
+  const int slot = blockIdx.x * 2 + wn;
+  const int pool_g = pool_u ? pool_u / 2 : 32;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const bool cok = co < cout;
+      float bv = 0.0f;
+      if (cok) {
+        bv = bias ? bias[co] : 0.0f;
+        if (bias_b) bv += bias_b[(size_t)b * cout + co];
+      }
+      const f32x2 v = {acc[m][0][r] + bv, acc[m][1][r] + bv};
+      float s1 = 0.0f, s2 = 0.0f;
+      if (cok && pok) {
+        if (outb) *(f32x2 *)(outb + (size_t)co * P + p) = v;
+        s1 = v[0] + v[1];
+        s2 = v[0] * v[0] + v[1] * v[1];
+      }
+      if (POOL) {
+        float mn = pok ? fminf(v[0], v[1]) : INFINITY, mx = pok ? fmaxf(v[0], v[1]) : -INFINITY;
+        group_minmax(mn, mx, pool_g);
+        if (cok) {
+          if (pool_u == 0) {
+            if (l31 == 31) {
+              float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 2 + wn) * cout + co) * 2;
+              q[0] = mn;
+              q[1] = mx;
+            }
+          } else if (pok && (pool_g == 32 ? l31 == 31 : (l31 & (pool_g - 1)) == 0)) {
+            float *q = mm_out + (((size_t)b * cout + co) * (P / pool_u) + p / pool_u) * 2;
+            q[0] = mn;
+            q[1] = mx;
+          }
+        }
+      }
+      if (stats_part) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && cok) {
+          float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
+          q[0] = s1;
+          q[1] = s2;
+          if (blockIdx.x == gridDim.x - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
+            for (int sl = slot + 1; sl < nslots; ++sl) {
+              float *z = stats_part + (((size_t)b * nslots + sl) * cout + co) * 2;
+              z[0] = 0.0f;
+              z[1] = 0.0f;
+            }
+        }
+      }
+    }
+  }
+}
+
+// split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
+// channel = chunk*32 + kstep*16 + khalf*8 + idx
+__global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, const float *__restrict__ w,
+                                     unsigned short *__restrict__ wp) {
+  const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;  // (chunk, coblk, kstep, khalf, co, idx)
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int idx = (int)(e & 7);
+    size_t q = e >> 3;
+    const int col = (int)(q & 127);
+    q >>= 7;
+    const int kh = (int)(q & 1);
+    q >>= 1;
+    const int ks = (int)(q & 1);
+    q >>= 1;
+    const int cb = (int)(q % ncoblk), chunk = (int)(q / ncoblk);
+    const int co = cb * 128 + col, ci = chunk * PWS_CK + ks * 16 + kh * 8 + idx;
+    const float x = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
+    unsigned p0, p1, p2;
+    split3(x, 0.0f, p0, p1, p2);
+    const unsigned pp[3] = {p0, p1, p2};
+    for (int s = 0; s < 3; ++s)
+      wp[((((((size_t)chunk * ncoblk + cb) * 2 + ks) * 3 + s) * 2 + kh) * 128 + col) * 8 + idx] = (unsigned short)(pp[s] & 0xffff);
+  }
+}
+
+extern "C" size_t p2pb_pointwise_split_packed_bytes(int cout, int cin) {
+  const size_t nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
+  return nchunk * ncoblk * (2 * 3 * 2 * 128) * 16;
+}
+
+extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w, void *wp, void *stream) {
+  if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
+  const int nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
+  const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;
+  hipLaunchKernelGGL(pw_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp);
+  return p2pb_launch_status();
+}
+
+static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
+                           const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
+                           float *out, float *stats_part, float *minmax, int pool_u, hipStream_t s) {
+  dim3 grid((P + 127) / 128, (cout + 127) / 128, b);
+  const int nslots = (P + 255) / 256 * 4;
+  const u32x4 *w = (const u32x4 *)wp;
+#define LAUNCH(XF, PL)                                                                                               \
+  hipLaunchKernelGGL((pw_split_kernel<XF, PL>), grid, dim3(256), 0, s, cin, cout, P, nslots, in, w, bias, bias_b,      \
+                     in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u)
+  if (in_scale && minmax) LAUNCH(true, true);
+  else if (in_scale) LAUNCH(true, false);
+  else if (minmax) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  return p2pb_launch_status();
+}
+
 static bool pw_wide_ok(int P, const float *in, const float *out) {
   // 16-byte rows: every row of in/out starts on a 16-byte boundary and holds whole quads
   return P % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
@@ -417,12 +663,18 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
   return p2pb_launch_status();
 }
 
-extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const float *wp,
+extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const void *wp_any,
                                            const float *bias, const float *bias_b, const float *in_scale,
-                                           const float *in_shift, int in_swish, float *out, float *stats_part,
-                                           void *stream) {
+                                           const float *in_shift, int in_swish, int flags, float *out,
+                                           float *stats_part, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (flags & 4) {  // wp is the split pack
+    if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
+    return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
+                           nullptr, 0, s);
+  }
+  const float *wp = (const float *)wp_any;
   // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
                                   stats_part, nullptr, 0, s)
@@ -438,18 +690,23 @@ extern "C" int p2pb_pointwise_pool_supported(int npos, int pool_u) {
   return npos > 0 && npos % 4 == 0 && uok && (pool_u == 0 || npos % pool_u == 0);
 }
 
-extern "C" size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int pool_u) {
-  if (pool_u == 0) return (size_t)b * ((npos + 511) / 512) * 4 * cout * 2;
+extern "C" size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int pool_u, int flags) {
+  if (pool_u == 0) return (size_t)b * ((flags & 4) ? (npos + 127) / 128 * 2 : (npos + 511) / 512 * 4) * cout * 2;
   return (size_t)b * cout * (npos / pool_u) * 2;
 }
 
-extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in, const float *wp,
-                                                const float *bias, const float *bias_b, const float *in_scale,
-                                                const float *in_shift, int in_swish, float *out, float *stats_part,
-                                                int pool_u, float *minmax, void *stream) {
+extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in,
+                                                const void *wp_any, const float *bias, const float *bias_b,
+                                                const float *in_scale, const float *in_shift, int in_swish, int flags,
+                                                float *out, float *stats_part, int pool_u, float *minmax,
+                                                void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !stats_part || !minmax) return P2PB_EINVAL;
   if (!p2pb_pointwise_pool_supported(npos, pool_u) || !pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (flags & 4)
+    return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
+                           minmax, pool_u, s);
+  const float *wp = (const float *)wp_any;
   const int g = pool_lanes(pool_u);
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
                                   stats_part, minmax, g, s)

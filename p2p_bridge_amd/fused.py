@@ -155,23 +155,30 @@ def enabled(module: torch.nn.Module, x: torch.Tensor) -> bool:
     return x.is_cuda and not module.training and not torch.is_grad_enabled()
 
 
-def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None) -> torch.Tensor:
+def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None, split=False) -> torch.Tensor:
     """packed copy of a k=1 Conv1d/Conv2d (or Linear) weight [co, ci(,1(,1))], optionally an input-channel
-    slice; cached on the module like pack_conv3d_weight"""
+    slice; fp32 pack or (split) the 3 x bf16 pack of the bf16x6 kernel; cached on the module like
+    pack_conv3d_weight"""
     w = conv.weight
     ci_hi = w.shape[1] if ci_hi is None else ci_hi
-    key = (w.data_ptr(), w._version, w.device, ci_lo, ci_hi)
+    key = (w.data_ptr(), w._version, w.device)
     cache = getattr(conv, "_p2pb_packed_pw", None)
-    if cache is None:
-        cache = conv._p2pb_packed_pw = {}
-    hit = cache.get((ci_lo, ci_hi))
-    if hit is None or hit[0] != key:
+    if cache is None or cache[0] != key:
+        cache = conv._p2pb_packed_pw = (key, {})
+    packs = cache[1]
+    k = (ci_lo, ci_hi, split)
+    if k not in packs:
         co = w.shape[0]
         w2 = w.detach().reshape(co, -1)[:, ci_lo:ci_hi].contiguous()
-        wp = torch.empty(lib().p2pb_pointwise_packed_floats(_i(co), _i(ci_hi - ci_lo)), dtype=F32, device=w.device)
-        call("p2pb_pointwise_pack_weights", _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
-        hit = cache[(ci_lo, ci_hi)] = (key, wp)
-    return hit[1]
+        if split:
+            wp = torch.empty(lib().p2pb_pointwise_split_packed_bytes(_i(co), _i(ci_hi - ci_lo)), dtype=torch.uint8,
+                             device=w.device)
+            call("p2pb_pointwise_pack_weights_split", _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
+        else:
+            wp = torch.empty(lib().p2pb_pointwise_packed_floats(_i(co), _i(ci_hi - ci_lo)), dtype=F32, device=w.device)
+            call("p2pb_pointwise_pack_weights", _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
+        packs[k] = wp
+    return packs[k]
 
 
 def pool_supported(npos: int, pool_u: int) -> bool:
@@ -179,21 +186,33 @@ def pool_supported(npos: int, pool_u: int) -> bool:
     return bool(lib().p2pb_pointwise_pool_supported(_i(npos), _i(pool_u)))
 
 
+PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/test_pw.py)
+
+
+def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
+    """the bf16x6 GEMM (csrc/pointwise.hip pw_split_kernel) for the matrix-bound layers; narrow layers are
+    HBM-bound and stay on the streaming fp32 kernel"""
+    return ((math or conv_math()) == "bf16x6" and ci >= PW_SPLIT_MIN_CIN and co >= PW_SPLIT_MIN_COUT
+            and npos % 4 == 0)
+
+
 def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
-            use_bias=True, pool_u=None, store=True):
+            use_bias=True, pool_u=None, store=True, math=None):
     """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None).
     pool_u (0 = all positions, or the neighbourhood size): also returns the {min, max} tensor minmax_act()
     pools from -> (y | None, stats, minmax); store=False skips writing y altogether."""
     check(x, F32, "x")
     b, ci, p = x.shape
     co = conv.weight.shape[0]
-    if in_scale is not None and (co + 63) // 64 >= 3:
-        # every 64-channel output block re-applies the folded norm+Swish to its operand: for wide layers one
+    split = use_split_pw(ci, co, p, math)
+    if in_scale is not None and (co + (127 if split else 63)) // (128 if split else 64) >= 3:
+        # every output-channel block re-applies the folded norm+Swish to its operand: for wide layers one
         # elementwise pre-pass (1 read + 1 write of the input) is cheaper than >= 3 recomputations
         x = affine_act(x, in_scale, in_shift, swish)
         in_scale = in_shift = None
         swish = False
-    wp = pack_pointwise_weight(conv, ci_lo, ci_hi)
+    wp = pack_pointwise_weight(conv, ci_lo, ci_hi, split)
+    flags = _i(4 if split else 0)
     y = torch.empty(b, co, p, dtype=F32, device=x.device) if (store or pool_u is None) else None
     st = None
     if stats or pool_u is not None:
@@ -202,13 +221,13 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
     bias = conv.bias if use_bias else None
     if pool_u is None:
         call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
-             ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), stream_ptr())
+             ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), stream_ptr())
         return y, st
-    nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(pool_u))
+    nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(pool_u), flags)
     mm = torch.empty((b, nmm // (b * co * 2), co, 2) if pool_u == 0 else (b, co, p // pool_u, 2), dtype=F32,
                      device=x.device)
     call("p2pb_pointwise_conv_pool_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(y), ptr(st), _i(pool_u), ptr(mm), stream_ptr())
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), _i(pool_u), ptr(mm), stream_ptr())
     return y, st, mm
 
 

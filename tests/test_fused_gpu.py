@@ -34,8 +34,18 @@ PW_SHAPES = [(2, 3, 128, 1000), (2, 35, 32, 4096), (2, 512, 1024, 512), (2, 131,
              (3, 1, 7, 4), (2, 67, 64, 333), (2, 16, 16, 1021), (1, 259, 128, 516)]
 
 
+@pytest.fixture(params=["fp32", "bf16x6"])
+def pw_math(request, fused, monkeypatch):
+    """both GEMM kernels on every shape: the streaming fp32 one and (where rows are 16-byte aligned) the LDS-tiled
+    bf16x6 one, whatever the production crossover (fused.PW_SPLIT_MIN_*) would pick"""
+    monkeypatch.setattr(fused, "PW_SPLIT_MIN_CIN", 1)
+    monkeypatch.setattr(fused, "PW_SPLIT_MIN_COUT", 1)
+    return request.param
+
+
 @pytest.mark.parametrize("B,ci,co,P", PW_SHAPES)
-def test_pointwise_conv(fused, B, ci, co, P):
+def test_pointwise_conv(fused, pw_math, B, ci, co, P):
+    math = pw_math
     torch.manual_seed(B * 1000 + ci + co + P)
     x = torch.randn(B, ci, P, device="cuda")
     conv = torch.nn.Conv1d(ci, co, 1).cuda()
@@ -43,23 +53,39 @@ def test_pointwise_conv(fused, B, ci, co, P):
     bias_b = torch.randn(B, co, device="cuda")
     with torch.no_grad():
         ref = torch.nn.functional.conv1d(x.double(), conv.weight.double(), conv.bias.double())
-        y, st = fused.pw_conv(x, conv)
+        y, st = fused.pw_conv(x, conv, math=math)
         assert rel_err(y, ref) < TOL
         s1, s2 = stats_of(st)
         assert rel_err(s1, ref.sum(2)) < TOL * 10 or (s1 - ref.sum(2)).abs().max() < 1e-3
         assert rel_err(s2, (ref * ref).sum(2)) < TOL
-        y0, st0 = fused.pw_conv(x, conv, stats=False)
+        y0, st0 = fused.pw_conv(x, conv, stats=False, math=math)
         assert st0 is None and torch.equal(y0, y)
         # folded norm + Swish on the operand, per-sample bias
         xin = swish(x * sc[:, :, None] + sh[:, :, None])
         ref2 = torch.nn.functional.conv1d(xin.double(), conv.weight.double(), conv.bias.double()) + bias_b[:, :, None]
-        y2, st2 = fused.pw_conv(x, conv, sc, sh, swish=True, bias_b=bias_b)
+        y2, st2 = fused.pw_conv(x, conv, sc, sh, swish=True, bias_b=bias_b, math=math)
         assert rel_err(y2, ref2) < TOL
         assert rel_err(stats_of(st2)[1], (ref2 * ref2).sum(2)) < TOL
         # affine only (no activation)
         ref3 = torch.nn.functional.conv1d((x * sc[:, :, None] + sh[:, :, None]).double(), conv.weight.double(),
                                           conv.bias.double())
-        assert rel_err(fused.pw_conv(x, conv, sc, sh, swish=False)[0], ref3) < TOL
+        assert rel_err(fused.pw_conv(x, conv, sc, sh, swish=False, math=math)[0], ref3) < TOL
+
+
+def test_pointwise_split_is_fp32_faithful(fused):
+    """bf16x6 GEMM vs the fp32 kernel, both against fp64, operands spread over 8 binades"""
+    torch.manual_seed(21)
+    B, ci, co, P = 2, 512, 1024, 2048
+    x = torch.randn(B, ci, P, device="cuda") * torch.exp2(torch.randint(-4, 4, (B, ci, 1), device="cuda").float())
+    conv = torch.nn.Conv1d(ci, co, 1).cuda()
+    with torch.no_grad():
+        ref = torch.nn.functional.conv1d(x.double(), conv.weight.double(), conv.bias.double())
+        y6, y32 = fused.pw_conv(x, conv, math="bf16x6")[0], fused.pw_conv(x, conv, math="fp32")[0]
+        assert fused.use_split_pw(ci, co, P, "bf16x6") and not fused.use_split_pw(ci, co, P, "fp32")
+        scale = ref.abs().max()
+        rms6, rms32 = ((y6 - ref).pow(2).mean().sqrt() / scale).item(), ((y32 - ref).pow(2).mean().sqrt() / scale).item()
+        assert rms6 < 1.25 * rms32 + 1e-9, (rms6, rms32)
+        assert rel_err(y6, ref) < 1e-5
 
 
 def test_pointwise_conv_channel_slice(fused):
@@ -68,15 +94,16 @@ def test_pointwise_conv_channel_slice(fused):
     x = torch.randn(2, 24, 512, device="cuda")
     conv = torch.nn.Conv2d(40, 48, 1).cuda()
     with torch.no_grad():
-        y, _ = fused.pw_conv(x, conv, ci_lo=0, ci_hi=24, use_bias=False)
         ref = torch.einsum("oc,bcp->bop", conv.weight[:, :24, 0, 0].double(), x.double())
-        assert rel_err(y, ref) < TOL
+        for math in ("fp32", "bf16x6"):
+            y, _ = fused.pw_conv(x, conv, ci_lo=0, ci_hi=24, use_bias=False, math=math)
+            assert rel_err(y, ref) < TOL
 
 
 @pytest.mark.parametrize("B,ci,co,M,U", [(2, 35, 32, 64, 32), (2, 64, 128, 40, 32), (1, 16, 200, 24, 16), (2, 8, 64, 16, 64),
                                          (2, 9, 16, 128, 4), (1, 32, 64, 50, 8)])
 @pytest.mark.parametrize("xf", [False, True])
-def test_pointwise_neighbour_pool(fused, B, ci, co, M, U, xf):
+def test_pointwise_neighbour_pool(fused, pw_math, B, ci, co, M, U, xf):
     """GEMM -> norm -> Swish -> max over the U neighbours, through the {min, max} epilogue"""
     torch.manual_seed(M * U + ci)
     P = M * U
@@ -88,12 +115,12 @@ def test_pointwise_neighbour_pool(fused, B, ci, co, M, U, xf):
     # output-side folded norm: both signs of the scale
     sc, sh = torch.randn(B, co, device="cuda"), torch.randn(B, co, device="cuda")
     with torch.no_grad():
-        yfull, st_full = fused.pw_conv(x, conv, isc, ish, swish=xf)
+        yfull, st_full = fused.pw_conv(x, conv, isc, ish, swish=xf, math=pw_math)
         ref = swish(yfull.double() * sc[:, :, None].double() + sh[:, :, None].double()).view(B, co, M, U).amax(3)
         # the two-pass form this replaces (it needs whole waves of neighbourhoods)
         want = fused.affine_act_max(yfull, sc, sh, M, U) if (M * U) % 64 == 0 else ref
         for store in (True, False):
-            y, st, mm = fused.pw_conv(x, conv, isc, ish, swish=xf, pool_u=U, store=store)
+            y, st, mm = fused.pw_conv(x, conv, isc, ish, swish=xf, pool_u=U, store=store, math=pw_math)
             assert (y is None) == (not store)
             if store:
                 assert torch.equal(y, yfull)
@@ -105,16 +132,16 @@ def test_pointwise_neighbour_pool(fused, B, ci, co, M, U, xf):
 
 
 @pytest.mark.parametrize("B,ci,co,P", [(2, 64, 128, 1024), (3, 128, 1024, 520), (1, 16, 24, 4), (2, 32, 64, 8192)])
-def test_pointwise_global_pool(fused, B, ci, co, P):
+def test_pointwise_global_pool(fused, pw_math, B, ci, co, P):
     torch.manual_seed(P + co)
     x = torch.randn(B, ci, P, device="cuda")
     conv = torch.nn.Conv2d(ci, co, 1).cuda()
     sc, sh = torch.randn(B, co, device="cuda"), torch.randn(B, co, device="cuda")
     with torch.no_grad():
-        yfull, st_full = fused.pw_conv(x, conv)
+        yfull, st_full = fused.pw_conv(x, conv, math=pw_math)
         ref = swish(yfull.double() * sc[:, :, None].double() + sh[:, :, None].double()).amax(2)
         want = fused.affine_act_max(yfull, sc, sh, P, 0)
-        y, st, mm = fused.pw_conv(x, conv, pool_u=0, store=False)
+        y, st, mm = fused.pw_conv(x, conv, pool_u=0, store=False, math=pw_math)
         assert y is None and torch.equal(st, st_full)
         got = fused.minmax_act(mm, sc, sh, global_pool=True)
         assert got.shape == (B, co)
