@@ -169,12 +169,18 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
 
   const float *inb = in + (size_t)b * cin * R3;
   float stg[CONV_CK][NP];
+  // unpredicated: one scalar descriptor per channel row (rows past cin are clamped and zeroed at staging time),
+  // halo positions outside the grid carry an out-of-range offset and read the hardware's zero
+  unsigned voff[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) voff[j] = soff[j] >= 0 ? (unsigned)soff[j] * 4u : 0x80000000u;
   auto stage_load = [&](int ci0) {
 #pragma unroll
-    for (int c = 0; c < CONV_CK; ++c)
+    for (int c = 0; c < CONV_CK; ++c) {
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)min(ci0 + c, cin - 1) * R3), 0, R3 * 4, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < NP; ++j)
-        stg[c][j] = (soff[j] >= 0 && ci0 + c < cin) ? inb[(size_t)(ci0 + c) * R3 + soff[j]] : 0.0f;
+      for (int j = 0; j < NP; ++j) stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j], 0, 0));
+    }
   };
   stage_load(0);
 
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
       }
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        float v = stg[c][j];
+        float v = cok ? stg[c][j] : 0.0f;
         if (XF && cok && soff[j] >= 0) v = xf_apply(v, sc, sh, in_swish) - sub;
         nonzero |= (v != 0.0f);
         if (tid + j * 256 < PLANE) tile[c * PLANE + tid + j * 256] = v;
@@ -200,7 +206,11 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
     }
     // barrier + "is any staged value non-zero" in one; an all-zero tile contributes exactly +0
     const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
-    if (ci0 + CONV_CK < cin) stage_load(ci0 + CONV_CK);  // next chunk's loads fly during the MFMAs
+    if (ci0 + CONV_CK < cin) {  // next chunk's loads fly during the MFMAs
+      int nxt = ci0 + CONV_CK;
+      asm volatile("" : "+s"(nxt));  // opaque: unpredicated loads would otherwise be hoisted above the staging phase
+      stage_load(nxt);
+    }
     if (!any) continue;
 
     // ---- 27 taps x CK/2 k-pairs of MFMAs; A fragments: one 16-byte load per (tap, M-tile), next tap
@@ -425,12 +435,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 
   const float *inb = in + (size_t)b * cin * R3;
   float stg[CONV_SCK][NP];
+  // unpredicated: one scalar descriptor per channel row (rows past cin are clamped and zeroed at staging time),
+  // halo positions outside the grid carry an out-of-range offset and read the hardware's zero
+  unsigned voff[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) voff[j] = soff[j] >= 0 ? (unsigned)soff[j] * 4u : 0x80000000u;
   auto stage_load = [&](int ci0) {
 #pragma unroll
-    for (int c = 0; c < CONV_SCK; ++c)
+    for (int c = 0; c < CONV_SCK; ++c) {
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)min(ci0 + c, cin - 1) * R3), 0, R3 * 4, 0x00020000);
 #pragma unroll
-      for (int j = 0; j < NP; ++j)
-        stg[c][j] = (soff[j] >= 0 && ci0 + c < cin) ? inb[(size_t)(ci0 + c) * R3 + soff[j]] : 0.0f;
+      for (int j = 0; j < NP; ++j) stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j], 0, 0));
+    }
   };
   stage_load(0);
 
@@ -448,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
       }
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        float v = stg[c][j];
+        float v = cok ? stg[c][j] : 0.0f;
         if (XF && cok && soff[j] >= 0) v = xf_apply(v, sc, sh, in_swish) - sub;
         nonzero |= (v != 0.0f);
         stg[c][j] = v;
@@ -475,33 +491,36 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
       }
     }
     const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
-    if (ci0 + CONV_SCK < cin) stage_load(ci0 + CONV_SCK);
+    if (ci0 + CONV_SCK < cin) {  // next stage's loads fly during the MFMAs
+      int nxt = ci0 + CONV_SCK;
+      asm volatile("" : "+s"(nxt));  // opaque: unpredicated loads would otherwise be hoisted above the staging phase
+      stage_load(nxt);
+    }
     if (!any) continue;
 
     const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
     const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
-    u32x4 a_cur[3][MT], bf[3][2];
+    u32x4 a_cur[3][MT];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int m = 0; m < MT; ++m) a_cur[s][m] = wchunk[s * wsplit_stride + m * 32];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n]];
-    }
-#pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
-      u32x4 a_nxt[3][MT], bf_nxt[3][2];
-      if (tap + 1 < 27) {  // both operands of the next tap are requested before this tap is multiplied
-        const int ntap = tap + 1;
-        const int toff = ((ntap / 9) * HH + (ntap / 3) % 3) * HW + ntap % 3;
+      const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+      // A fragments one tap ahead (L2 latency), B fragments at the top of the tap (LDS latency is covered by
+      // the co-resident wave; a second B buffer costs 24 registers and spills); the barrier pins both
+      u32x4 a_nxt[3][MT], bf[3][2];
+      if (tap + 1 < 27) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < 3; ++s)
 #pragma unroll
-          for (int m = 0; m < MT; ++m) a_nxt[s][m] = wchunk[(size_t)ntap * wtap_stride + s * wsplit_stride + m * 32];
-#pragma unroll
-          for (int n = 0; n < 2; ++n) bf_nxt[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
-        }
+          for (int m = 0; m < MT; ++m) a_nxt[s][m] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride + m * 32];
       }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
       __builtin_amdgcn_sched_barrier(0);
       // small terms first
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
@@ -515,12 +534,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
                                                                 __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
       if (tap + 1 < 27) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < 3; ++s)
 #pragma unroll
           for (int m = 0; m < MT; ++m) a_cur[s][m] = a_nxt[s][m];
-#pragma unroll
-          for (int n = 0; n < 2; ++n) bf[s][n] = bf_nxt[s][n];
-        }
       }
     }
   }
