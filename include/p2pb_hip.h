@@ -195,11 +195,15 @@ int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, c
 
 /* GroupNorm (+AdaGN style, models/modules.py:341-358) folded into a per-(sample, channel) affine:
  * AdaGN(GN(x)) == x*scale + shift. part f32[b,nslots,c,2] partial {sum,sumsq}; gamma/beta f32[c] or
- * NULL; style f32[b,2c] = (factor | bias) or NULL; chmean (optional) = per-channel mean of the
- * transformed output (SE3d squeeze, models/modules.py:377-378). */
+ * NULL; style = b rows of (factor[c] | bias[c]) with a row pitch of style_stride floats, or NULL; chmean
+ * (optional) = per-channel mean of the transformed output (SE3d squeeze, models/modules.py:377-378). */
 int p2pb_gn_affine_params(int b, int c, int groups, int nslots, double count_per_channel, const float *part,
-                          const float *gamma, const float *beta, const float *style, float eps, float *scale,
-                          float *shift, float *chmean, void *stream);
+                          const float *gamma, const float *beta, const float *style, int style_stride, float eps,
+                          float *scale, float *shift, float *chmean, void *stream);
+/* SE3d gate (models/modules.py:362-378) folded into the devoxelisation affine: gate = sigmoid(w2 relu(w1 chmean)),
+ * aff_a = scale*gate, aff_b = shift*gate. w1 f32[hidden,c], w2 f32[c,hidden] (nn.Linear layouts, no bias). */
+int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,
+                        const float *scale, const float *shift, float *aff_a, float *aff_b, void *stream);
 
 /* trilinear devoxelize of feat*aff_a[b,c] + aff_b[b,c] (AdaGN + SE gate folded), inference only */
 int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *coords, const float *feat,

@@ -985,8 +985,8 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
 __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int nslots, double count_per_channel,
                                                         const float *__restrict__ part, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, const float *__restrict__ style,
-                                                        float eps, float *__restrict__ scale, float *__restrict__ shift,
-                                                        float *__restrict__ chmean) {
+                                                        int style_stride, float eps, float *__restrict__ scale,
+                                                        float *__restrict__ shift, float *__restrict__ chmean) {
   __shared__ double rs[256], rq[256];
   __shared__ double chs[256], chq[256];  // per-channel totals of this group (cg <= 256)
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
@@ -1026,8 +1026,8 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int n
   if (var < 0.0) var = 0.0;
   const double rstd = 1.0 / sqrt(var + (double)eps);
   const double ga = gamma ? (double)gamma[ch] : 1.0, be = beta ? (double)beta[ch] : 0.0;
-  const double f = style ? (double)style[(size_t)b * 2 * c + ch] : 1.0;
-  const double bi = style ? (double)style[(size_t)b * 2 * c + c + ch] : 0.0;
+  const double f = style ? (double)style[(size_t)b * style_stride + ch] : 1.0;
+  const double bi = style ? (double)style[(size_t)b * style_stride + c + ch] : 0.0;
   const double sc = rstd * ga * f;
   const double sh = (be - mean * rstd * ga) * f + bi;
   scale[(size_t)b * c + ch] = (float)sc;
@@ -1035,12 +1035,53 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int n
   if (chmean) chmean[(size_t)b * c + ch] = (float)(sc * (chs[t] / count_per_channel) + sh);
 }
 
-// part: f32[b, nslots, c, 2]; gamma/beta f32[c] or NULL; style f32[b, 2c] or NULL -> scale/shift/chmean f32[b,c]
+// part: f32[b, nslots, c, 2]; gamma/beta f32[c] or NULL; style = rows of (factor[c] | bias[c]) with a row pitch of
+// style_stride floats (a column slice of the one style GEMM of the evaluation), or NULL -> scale/shift/chmean f32[b,c]
 extern "C" int p2pb_gn_affine_params(int b, int c, int groups, int nslots, double count_per_channel,
                                      const float *part, const float *gamma, const float *beta, const float *style,
-                                     float eps, float *scale, float *shift, float *chmean, void *stream) {
+                                     int style_stride, float eps, float *scale, float *shift, float *chmean,
+                                     void *stream) {
   if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || nslots <= 0 || c / groups > 256) return P2PB_EINVAL;
+  if (style && style_stride < 2 * c) return P2PB_EINVAL;
   hipLaunchKernelGGL(gn_affine_kernel, dim3(groups, b), dim3(256), 0, (hipStream_t)stream, c, groups, nslots,
-                     count_per_channel, part, gamma, beta, style, eps, scale, shift, chmean);
+                     count_per_channel, part, gamma, beta, style, style_stride, eps, scale, shift, chmean);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Squeeze-excite gate (models/modules.py:362-378: Linear(c, c/8, no bias) -> ReLU -> Linear(c/8, c, no bias) ->
+// Sigmoid on the per-channel mean of the normalised grid) folded into the devoxelisation affine:
+//   gate = sigmoid(W2 relu(W1 chmean)),  aff_a = scale * gate,  aff_b = shift * gate.   One workgroup per sample.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_affine_kernel(int c, int hidden, const float *__restrict__ chmean,
+                                                             const float *__restrict__ w1, const float *__restrict__ w2,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, float *__restrict__ aff_a,
+                                                             float *__restrict__ aff_b) {
+  extern __shared__ float se_sm[];  // c means + hidden activations
+  float *mean = se_sm, *hid = se_sm + c;
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < c; i += 256) mean[i] = chmean[(size_t)b * c + i];
+  __syncthreads();
+  for (int h = t; h < hidden; h += 256) {
+    float acc = 0.0f;
+    for (int i = 0; i < c; ++i) acc = __fmaf_rn(w1[(size_t)h * c + i], mean[i], acc);
+    hid[h] = fmaxf(acc, 0.0f);
+  }
+  __syncthreads();
+  for (int i = t; i < c; i += 256) {
+    float acc = 0.0f;
+    for (int h = 0; h < hidden; ++h) acc = __fmaf_rn(w2[(size_t)i * hidden + h], hid[h], acc);
+    const float gate = 1.0f / (1.0f + expf(-acc));
+    aff_a[(size_t)b * c + i] = scale[(size_t)b * c + i] * gate;
+    aff_b[(size_t)b * c + i] = shift[(size_t)b * c + i] * gate;
+  }
+}
+
+extern "C" int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,
+                                   const float *scale, const float *shift, float *aff_a, float *aff_b, void *stream) {
+  if (b <= 0 || c <= 0 || hidden <= 0) return P2PB_EINVAL;
+  hipLaunchKernelGGL(se_gate_affine_kernel, dim3(b), dim3(256), (size_t)(c + hidden) * sizeof(float),
+                     (hipStream_t)stream, c, hidden, chmean, w1, w2, scale, shift, aff_a, aff_b);
   return p2pb_launch_status();
 }

@@ -124,16 +124,29 @@ def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
 
 
 def gn_affine_params(part, count_per_channel, groups, gamma, beta, style=None, eps=1e-5, want_mean=False):
-    """partials f32[B,nslots,C,2] -> scale, shift (, chmean) f32[B,C]"""
+    """partials f32[B,nslots,C,2] -> scale, shift (, chmean) f32[B,C]. style: f32[B,2C] rows (factor | bias), may
+    be a column slice of a wider matrix (row stride passed through, no copy)"""
     b, nslots, c, _ = part.shape
     scale = torch.empty(b, c, dtype=F32, device=part.device)
     shift = torch.empty_like(scale)
     chmean = torch.empty_like(scale) if want_mean else None
+    stride = 0
     if style is not None:
-        style = style.contiguous()
+        if style.stride(1) != 1 or style.shape[1] != 2 * c:
+            style = style.contiguous()
+        stride = style.stride(0)
     call("p2pb_gn_affine_params", _i(b), _i(c), _i(groups), _i(nslots), _d(float(count_per_channel)), ptr(part),
-         ptr(gamma), ptr(beta), ptr(style), _f(eps), ptr(scale), ptr(shift), ptr(chmean), stream_ptr())
+         ptr(gamma), ptr(beta), ptr(style), _i(stride), _f(eps), ptr(scale), ptr(shift), ptr(chmean), stream_ptr())
     return scale, shift, chmean
+
+
+def se_gate_affine(chmean, fc1_weight, fc2_weight, scale, shift):
+    """SE3d gate folded into the devoxelisation affine: (scale, shift) * sigmoid(W2 relu(W1 chmean))"""
+    b, c = chmean.shape
+    a, bb = torch.empty_like(scale), torch.empty_like(shift)
+    call("p2pb_se_gate_affine", _i(b), _i(c), _i(fc1_weight.shape[0]), ptr(chmean), ptr(fc1_weight), ptr(fc2_weight),
+         ptr(scale), ptr(shift), ptr(a), ptr(bb), stream_ptr())
+    return a, bb
 
 
 def devoxelize_affine(grid, vcoords, r, aff_a, aff_b):

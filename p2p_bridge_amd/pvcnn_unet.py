@@ -307,8 +307,7 @@ class PVConv(nn.Module):
         se = vl[6] if len(vl) > 6 else None
         sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
         if se is not None:
-            gate = se.fc(mean2)
-            sc2, sh2 = sc2 * gate, sh2 * gate
+            sc2, sh2 = fused.se_gate_affine(mean2, se.fc[0].weight, se.fc[2].weight, sc2, sh2)
         return fused.devoxelize_affine(y2, vcoords, r, sc2, sh2)
 
     def forward(self, data: PVCData) -> PVCData:

@@ -181,13 +181,28 @@ def test_gn_affine_params(fused, groups, style):
         gn.weight.normal_()
         gn.bias.normal_()
         y, st = fused.pw_conv(x, conv)
-        sty = torch.randn(B, 2 * C, device="cuda") if style else None
+        # the style rows are a column slice of the evaluation's one style matrix: passed by stride, not copied
+        bank = torch.randn(B, 2 * C + 40, device="cuda")
+        sty = bank[:, 24:24 + 2 * C] if style else None
         sc, sh, _ = fused.gn_affine_params(st, P, groups, gn.weight, gn.bias, sty, gn.eps)
         ref = gn(y)
         if style:  # AdaGN (models/modules.py:319-358): factor, bias = style.chunk(2); out = norm * factor + bias
             ref = ref * sty[:, :C, None] + sty[:, C:, None]
         got = y * sc[:, :, None] + sh[:, :, None]
         assert rel_err(got, ref) < TOL
+
+
+@pytest.mark.parametrize("B,C", [(3, 64), (2, 256), (1, 40)])
+def test_se_gate_affine(fused, B, C):
+    """SE3d (models/modules.py:362-378) folded into the devoxelisation affine"""
+    torch.manual_seed(C)
+    fc = torch.nn.Sequential(torch.nn.Linear(C, C // 8, bias=False), torch.nn.ReLU(), torch.nn.Linear(C // 8, C, bias=False),
+                             torch.nn.Sigmoid()).cuda()
+    mean, sc, sh = (torch.randn(B, C, device="cuda") for _ in range(3))
+    with torch.no_grad():
+        gate = fc(mean)
+        a, b = fused.se_gate_affine(mean, fc[0].weight, fc[2].weight, sc, sh)
+        assert rel_err(a, sc * gate) < 1e-5 and rel_err(b, sh * gate) < 1e-5
 
 
 @pytest.mark.parametrize("math", ["bf16x6", "fp32"])
