@@ -29,7 +29,7 @@
 //     voxel is in: K[b, class, co] = bias + sum_{taps inside} sum_ci W*a, added in the epilogue.
 // Every output voxel and every statistic is still produced by this kernel; only all-zero MFMA work is
 // skipped. Compact 4x8x8 bricks (instead of full-row bricks) make the zero test fine-grained in 3-D.
-#include "common.h"
+#include "../../p2p_bridge_amd/csrc/common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -353,24 +353,6 @@ __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout
   }
 }
 
-// Brick geometry of the split kernel: 4 x 8 x 8 bricks whose N-tiles are 4(d) x 1(h) x 8(w) columns. A B fragment is
-// a ds_read_b128, which the LDS serves in four groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...),
-// one cycle per group if the 16 lanes hit 16 different 16-byte bank groups. With the d-plane pitch of the halo
-// tile (100 slots = 4 mod 16) the four d-rows of an N-tile start 4 bank groups apart, and swapping the two w-halves
-// in rows 1 and 2 (lane_w below) gives every service group the residues {0..15} exactly once -- conflict-free for
-// every tap offset (a tap only adds a constant). The h-row shape of the fp32 kernel is 3-way conflicted (pitch 10).
-template <int R>
-struct SplitGeom {
-  static constexpr int TD = 4, TH = 8, TW = 8, ND = 4, NH = 1;
-};
-template <>
-struct SplitGeom<4> : ConvGeom<4, false> {};
-template <int TW>
-__device__ __forceinline__ int lane_w(int l31) {
-  const int jw = l31 % TW, jr = l31 / TW;
-  return (TW == 8 && (jr == 1 || jr == 2)) ? jw ^ 4 : jw;
-}
-
 template <int R, bool COMPACT, int MT, bool XF>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
@@ -383,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
                                                              const int *__restrict__ brick_list,
                                                              const int *__restrict__ brick_count,
                                                              float *__restrict__ out, float *__restrict__ stats_part) {
-  using G = SplitGeom<R>;
+  using G = ConvGeom<R, COMPACT>;
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
   constexpr int PLANE = HD * HH * HW;
   constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;
@@ -417,23 +399,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
   }
   const int brick = (bd * BH + bh) * BW + bw;
   const int d0 = bd * G::TD, h0 = bh * G::TH, w0 = bw * G::TW;
-  // waves as WM x WN: every wave owns ONE 32-channel M-tile and NT N-tiles of the brick. With 64 channels per
-  // workgroup (MT = 2) that is 2 x 2 waves of 4 N-tiles each: an A fragment (weights, a 16-byte L1/L2 load
-  // per lane) then feeds four N-tiles instead of two -- measured, the A stream through the L1 is what bounds
-  // this kernel (removing it: 179 -> 230 TFLOP/s), while B fragments come from LDS, which has room.
-  constexpr int WM = MT, WN = 4 / WM, NT = (NTILES / WN) > 0 ? NTILES / WN : 1;
-  const int wm = wave / WN, wn = wave % WN;
-  const int co0 = blockIdx.y * (32 * MT) + 32 * wm;
+  const int co0 = blockIdx.y * (32 * MT);
 
-  int nbase[NT];
-  bool nact[NT];
+  int nbase[2];
+  bool nact[2];
 #pragma unroll
-  for (int s = 0; s < NT; ++s) {
-    const int t = NT * wn + s;
+  for (int s = 0; s < 2; ++s) {
+    const int t = 2 * wave + s;
     nact[s] = t < NTILES;
     constexpr int HB = G::TH / G::NH;
     const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
-    const int jw = lane_w<G::TW>(l31), jr = l31 / G::TW;
+    const int jw = l31 % G::TW, jr = l31 / G::TW;
     const int jh = jr % G::NH, jd = jr / G::NH;
     nbase[s] = ((td + jd) * HH + (th + jh)) * HW + jw;
   }
@@ -449,11 +425,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
     soff[j] = ok ? (d * R + h) * R + w : -1;
   }
 
-  f32x16 acc[NT];
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int s = 0; s < NT; ++s)
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
 
   const float *inb = in + (size_t)b * cin * R3;
   float stg[CONV_SCK][NP];
@@ -474,7 +452,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 
   for (int ci0 = 0; ci0 < cin; ci0 += CONV_SCK) {
     __syncthreads();
-    int nonzero = 0;
+    int nonzero = 1;
+#if EXP_NOSTAGE
+    if (ci0 == 0) {
+#endif
+
 #pragma unroll
     for (int c = 0; c < CONV_SCK; ++c) {
       float sc = 1.0f, sh = 0.0f, sub = 0.0f;
@@ -512,6 +494,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
         }
       }
     }
+#if EXP_NOSTAGE
+    }
+#endif
     const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
     if (ci0 + CONV_SCK < cin) {  // next stage's loads fly during the MFMAs
       int nxt = ci0 + CONV_SCK;
@@ -522,47 +507,60 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 
     const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
     const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
-    u32x4 a_cur[3];
+    u32x4 a_cur[3][MT];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) a_cur[s] = wchunk[s * wsplit_stride];
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a_cur[s][m] = wchunk[s * wsplit_stride + m * 32];
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
       // A fragments one tap ahead (L2 latency), B fragments at the top of the tap (LDS latency is covered by
-      // the co-resident wave); the scheduling barrier pins both, else every load sinks to its first use
-      u32x4 a_nxt[3], bf[3][NT];
+      // the co-resident wave; a second B buffer costs 24 registers and spills); the barrier pins both
+      u32x4 a_nxt[3][MT], bf[3][2];
       if (tap + 1 < 27) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#if EXP_NOALOAD
+            a_nxt[s][m] = a_cur[s][m];
+#else
+            a_nxt[s][m] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride + m * 32];
+#endif
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+        for (int n = 0; n < 2; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
       __builtin_amdgcn_sched_barrier(0);
       // small terms first
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[PA[t]]),
-                                                           __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[n], 0, 0, 0);
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[PA[t]][m]),
+                                                                __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
       if (tap + 1 < 27) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a_cur[s] = a_nxt[s];
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a_cur[s][m] = a_nxt[s][m];
       }
     }
   }
 
   float *outb = out + (size_t)b * cout * R3;
-  int vox[NT], cls[NT];
+  int vox[2], cls[2];
 #pragma unroll
-  for (int s = 0; s < NT; ++s) {
-    const int t = NT * wn + s;
+  for (int s = 0; s < 2; ++s) {
+    const int t = 2 * wave + s;
     constexpr int HB = G::TH / G::NH;
     const int td = (t / HB) * G::ND, th = (t % HB) * G::NH;
-    const int jw = lane_w<G::TW>(l31), jr = l31 / G::TW;
+    const int jw = l31 % G::TW, jr = l31 / G::TW;
     const int d = d0 + td + jr / G::NH, h = h0 + th + jr % G::NH, w = w0 + jw;
     vox[s] = (d * R + h) * R + w;
     const int cd = d == 0 ? 0 : (d == R - 1 ? 2 : 1), ch = h == 0 ? 0 : (h == R - 1 ? 2 : 1),
@@ -570,38 +568,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
     cls[s] = (cd * 3 + ch) * 3 + cw;
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-    const bool cok = co < cout;
-    const float bv = (cok && !out_class) ? bias[co] : 0.0f;
-    float s1 = 0.0f, s2 = 0.0f;
+  for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int s = 0; s < NT; ++s) {
-      if (!nact[s]) continue;
-      float v = acc[s][r] + bv;
-      if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
-      if (cok) outb[(size_t)co * R3 + vox[s]] = v;
-      s1 += v;
-      s2 += v * v;
-    }
-    if (stats_part) {
-      // the brick's four statistics slots: wave column wn fills slot wn for its channels; with two wave rows
-      // only two columns exist and slots 2, 3 are zeroed
-      s1 = halfwave_sum_to_last(s1);
-      s2 = halfwave_sum_to_last(s2);
-      if (l31 == 31 && cok) {
-        float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wn) * cout + co) * 2;
-        p[0] = s1;
-        p[1] = s2;
-        if (WN < 4) {
-          float *z = stats_part + ((((size_t)b * NBRICK + brick) * 4 + WN + wn) * cout + co) * 2;
-          z[0] = 0.0f;
-          z[1] = 0.0f;
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const bool cok = co < cout;
+      const float bv = (cok && !out_class) ? bias[co] : 0.0f;
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (!nact[s]) continue;
+        float v = acc[m][s][r] + bv;
+        if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
+        if (cok) outb[(size_t)co * R3 + vox[s]] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+      if (stats_part) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && cok) {
+          float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wave) * cout + co) * 2;
+          p[0] = s1;
+          p[1] = s2;
         }
       }
     }
   }
 }
+
 
 // weights [cout][cin][3][3][3] -> packed [27][cin_pad/8][2][cout_pad][4] (zero padded):
 // element (tap, chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf][tap], so that the four k-pair
