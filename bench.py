@@ -54,17 +54,17 @@ def conv_roofline(model, B, reps=10):
     pv = model.model.fp_layers[2][1]
     conv = pv.voxel_layers[4]
     C, r = conv.in_channels, pv.resolution
-    x = torch.randn(B, C, r, r, r, device="cuda")
+    x = torch.randn(B, r, r, r, C, device="cuda")  # voxel-major grids, as in PVConv._voxel_branch_fused
     sc, sh = torch.rand(B, C, device="cuda") + 0.5, torch.randn(B, C, device="cuda")
     flops = 2.0 * B * r ** 3 * 27 * conv.in_channels * conv.out_channels  # algorithmic FLOPs of one launch
     with torch.no_grad():
         for _ in range(3):
-            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True)
+            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True, channels_last=True)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True)
+            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True, channels_last=True)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
@@ -74,7 +74,7 @@ def conv_roofline(model, B, reps=10):
     kname = "conv3d_k3_split_kernel" if split else "conv3d_k3_kernel"
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": None,
-            "kernel": f"{kname}<{r},compact,2,XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
+            "kernel": f"{kname}<{r},compact,2,XF,voxel-major> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
                       f"(fp_layers.2.1.voxel_layers.4)",
             "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
                            "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),

@@ -169,7 +169,9 @@ int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, con
 /* Sparse-aware form (exact): in_sub f32[b,cin] is subtracted from the transformed operand, out_class
  * f32[b,27,cout] replaces bias per boundary class (low / interior / high along d,h,w) -- see conv3d.hip:
  * conv(x) = conv(x - a) + conv(a). flags bit 0: skip all-zero operand tiles; bit 1: compact 4x8x8 bricks;
- * bit 2: wt_packed is the split pack (bf16x6 arithmetic), else the fp32 pack (exact-fp32 MFMA). */
+ * bit 2: wt_packed is the split pack (bf16x6 arithmetic), else the fp32 pack (exact-fp32 MFMA);
+ * bit 3: voxel-major grids, in f32[b,r,r,r,cin] / out f32[b,r,r,r,cout] (the fused voxel branch's layout: a
+ * voxel's channels are contiguous for the staging loads, the stores, voxelize and devoxelize). */
 int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                               const float *bias, const float *out_class, const float *in_scale,
                               const float *in_shift, int in_swish, const float *in_sub, int flags, float *out,
@@ -184,7 +186,7 @@ int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned char *flags_w
                             void *stream);
 int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                   const float *bias, const float *out_class, const float *in_scale,
-                                  const float *in_shift, int in_swish, const float *in_sub, int flags /* bit 2 */,
+                                  const float *in_shift, int in_swish, const float *in_sub, int flags /* bits 2, 3 */,
                                   const int *active_list, const int *active_count, const int *inactive_list,
                                   const int *inactive_count, float *out, float *stats_part, void *stream);
 /* a[b,cin] = xf(prev_bias[cin]) (the operand's far-field constant) and k_out[b,27,cout] = conv(a) + bias per
@@ -205,6 +207,13 @@ int p2pb_gn_affine_params(int b, int c, int groups, int nslots, double count_per
 int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,
                         const float *scale, const float *shift, float *aff_a, float *aff_b, void *stream);
 
+/* Voxel-major forms for the fused branch (grid f32[b,r,r,r,c]; conv flags bit 3): same values as
+ * p2pb_avg_voxelize_forward / p2pb_trilinear_devoxelize_affine, coalesced on both sides (voxelize.hip).
+ * feat_t: f32[b,n,c] scratch (the point-major copy of feat); aff_a/aff_b may both be NULL. */
+int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind, int *cnt,
+                                 float *out, float *feat_t, void *ws, void *stream);
+int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float *coords, const float *grid,
+                                        const float *aff_a, const float *aff_b, float *outs, void *stream);
 /* trilinear devoxelize of feat*aff_a[b,c] + aff_b[b,c] (AdaGN + SE gate folded), inference only */
 int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *coords, const float *feat,
                                      const float *aff_a, const float *aff_b, float *outs, void *stream);

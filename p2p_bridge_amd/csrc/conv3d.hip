@@ -80,7 +80,7 @@ __device__ __forceinline__ float xf_apply(float v, float sc, float sh, int swish
 }
 
 // MT = 32-row output-channel tiles per workgroup (NC = 32*MT), XF = apply affine(+swish)(-sub) to the input
-template <int R, bool COMPACT, int MT, bool XF>
+template <int R, bool COMPACT, int MT, bool XF, bool CL>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                         const float *__restrict__ in, const float *__restrict__ wt,
                                                         const float *__restrict__ bias,
@@ -169,17 +169,40 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
 
   const float *inb = in + (size_t)b * cin * R3;
   float stg[CONV_CK][NP];
-  // unpredicated: one scalar descriptor per channel row (rows past cin are clamped and zeroed at staging time),
-  // halo positions outside the grid carry an out-of-range offset and read the hardware's zero
+  // unpredicated loads through scalar descriptors; halo positions outside the grid carry an out-of-range offset
+  // and read the hardware's zero. Channel-major (reference) layout: one descriptor per channel row (rows past cin
+  // are clamped and zeroed at staging time). Voxel-major layout (CL): a staged voxel's channels are contiguous,
+  // 32 bytes per stage = 16-byte loads when cin % 4 == 0 (quads past cin are zeroed at staging time).
   unsigned voff[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) voff[j] = soff[j] >= 0 ? (unsigned)soff[j] * 4u : 0x80000000u;
+  for (int j = 0; j < NP; ++j)
+    voff[j] = soff[j] >= 0 ? (unsigned)soff[j] * (CL ? (unsigned)cin * 4u : 4u) : 0x80000000u;
   auto stage_load = [&](int ci0) {
+    if (CL) {
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)inb, 0, R3 * cin * 4, 0x00020000);
+      if ((cin & 3) == 0) {
 #pragma unroll
-    for (int c = 0; c < CONV_CK; ++c) {
-      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)min(ci0 + c, cin - 1) * R3), 0, R3 * 4, 0x00020000);
+        for (int j = 0; j < NP; ++j)
 #pragma unroll
-      for (int j = 0; j < NP; ++j) stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j], 0, 0));
+          for (int q = 0; q < CONV_CK / 4; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j] + (unsigned)(ci0 + 4 * q) * 4u, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stg[4 * q + i][j] = v[i];
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+          for (int c = 0; c < CONV_CK; ++c)
+            stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j] + (unsigned)(ci0 + c) * 4u, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CONV_CK; ++c) {
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)min(ci0 + c, cin - 1) * R3), 0, R3 * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j], 0, 0));
+      }
     }
   };
   stage_load(0);
@@ -278,29 +301,47 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      const bool cok = co < cout;
-      const float bv = (cok && !out_class) ? bias[co] : 0.0f;
-      float s1 = 0.0f, s2 = 0.0f;
+    for (int g = 0; g < 4; ++g) {
+      float vv[2][4];  // voxel-major stores: the four consecutive channels of register group g, per N-tile
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (!nact[s]) continue;
-        float v = acc[m][s][r] + bv;
-        if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
-        if (cok) outb[(size_t)co * R3 + vox[s]] = v;
-        s1 += v;
-        s2 += v * v;
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const int co = co0 + m * 32 + i + 8 * g + 4 * khalf;
+        const bool cok = co < cout;
+        const float bv = (cok && !out_class) ? bias[co] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (!nact[s]) continue;
+          float v = acc[m][s][r] + bv;
+          if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
+          if (CL) vv[s][i] = v;
+          else if (cok) outb[(size_t)co * R3 + vox[s]] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+        if (stats_part) {
+          // sum over the 32 lanes of this half-wave (a channel row lives in exactly one half of the wave),
+          // one private slot per (sample, brick, wave, channel): plain stores, reduced later in fixed order
+          s1 = halfwave_sum_to_last(s1);
+          s2 = halfwave_sum_to_last(s2);
+          if (l31 == 31 && cok) {
+            float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wave) * cout + co) * 2;
+            p[0] = s1;
+            p[1] = s2;
+          }
+        }
       }
-      if (stats_part) {
-        // sum over the 32 lanes of this half-wave (a channel row lives in exactly one half of the wave),
-        // one private slot per (sample, brick, wave, channel): plain stores, reduced later in fixed order
-        s1 = halfwave_sum_to_last(s1);
-        s2 = halfwave_sum_to_last(s2);
-        if (l31 == 31 && cok) {
-          float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wave) * cout + co) * 2;
-          p[0] = s1;
-          p[1] = s2;
+      if (CL) {
+        const int cq = co0 + m * 32 + 8 * g + 4 * khalf;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (!nact[s]) continue;
+          float *q = outb + (size_t)vox[s] * cout + cq;
+          if (cq + 3 < cout && (cout & 3) == 0) *(f32x4 *)q = f32x4{vv[s][0], vv[s][1], vv[s][2], vv[s][3]};
+          else
+            for (int i = 0; i < 4; ++i)
+              if (cq + i < cout) q[i] = vv[s][i];
         }
       }
     }
@@ -371,7 +412,7 @@ __device__ __forceinline__ int lane_w(int l31) {
   return (TW == 8 && (jr == 1 || jr == 2)) ? jw ^ 4 : jw;
 }
 
-template <int R, bool COMPACT, int MT, bool XF>
+template <int R, bool COMPACT, int MT, bool XF, bool CL>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
@@ -457,17 +498,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 
   const float *inb = in + (size_t)b * cin * R3;
   float stg[CONV_SCK][NP];
-  // unpredicated: one scalar descriptor per channel row (rows past cin are clamped and zeroed at staging time),
-  // halo positions outside the grid carry an out-of-range offset and read the hardware's zero
+  // unpredicated loads through scalar descriptors; halo positions outside the grid carry an out-of-range offset
+  // and read the hardware's zero. Channel-major (reference) layout: one descriptor per channel row (rows past cin
+  // are clamped and zeroed at staging time). Voxel-major layout (CL): a staged voxel's channels are contiguous,
+  // 64 bytes per stage = 16-byte loads when cin % 4 == 0 (quads past cin are zeroed at staging time).
   unsigned voff[NP];
 #pragma unroll
-  for (int j = 0; j < NP; ++j) voff[j] = soff[j] >= 0 ? (unsigned)soff[j] * 4u : 0x80000000u;
+  for (int j = 0; j < NP; ++j)
+    voff[j] = soff[j] >= 0 ? (unsigned)soff[j] * (CL ? (unsigned)cin * 4u : 4u) : 0x80000000u;
   auto stage_load = [&](int ci0) {
+    if (CL) {
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)inb, 0, R3 * cin * 4, 0x00020000);
+      if ((cin & 3) == 0) {
 #pragma unroll
-    for (int c = 0; c < CONV_SCK; ++c) {
-      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)min(ci0 + c, cin - 1) * R3), 0, R3 * 4, 0x00020000);
+        for (int j = 0; j < NP; ++j)
 #pragma unroll
-      for (int j = 0; j < NP; ++j) stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j], 0, 0));
+          for (int q = 0; q < CONV_SCK / 4; ++q) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j] + (unsigned)(ci0 + 4 * q) * 4u, 0, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stg[4 * q + i][j] = v[i];
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+          for (int c = 0; c < CONV_SCK; ++c)
+            stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j] + (unsigned)(ci0 + c) * 4u, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CONV_SCK; ++c) {
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)min(ci0 + c, cin - 1) * R3), 0, R3 * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j], 0, 0));
+      }
     }
   };
   stage_load(0);
@@ -570,34 +634,52 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
     cls[s] = (cd * 3 + ch) * 3 + cw;
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-    const bool cok = co < cout;
-    const float bv = (cok && !out_class) ? bias[co] : 0.0f;
-    float s1 = 0.0f, s2 = 0.0f;
+  for (int g = 0; g < 4; ++g) {
+    float vv[NT][4];  // voxel-major stores: the four consecutive channels of register group g, per N-tile
 #pragma unroll
-    for (int s = 0; s < NT; ++s) {
-      if (!nact[s]) continue;
-      float v = acc[s][r] + bv;
-      if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
-      if (cok) outb[(size_t)co * R3 + vox[s]] = v;
-      s1 += v;
-      s2 += v * v;
-    }
-    if (stats_part) {
-      // the brick's four statistics slots: wave column wn fills slot wn for its channels; with two wave rows
-      // only two columns exist and slots 2, 3 are zeroed
-      s1 = halfwave_sum_to_last(s1);
-      s2 = halfwave_sum_to_last(s2);
-      if (l31 == 31 && cok) {
-        float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wn) * cout + co) * 2;
-        p[0] = s1;
-        p[1] = s2;
-        if (WN < 4) {
-          float *z = stats_part + ((((size_t)b * NBRICK + brick) * 4 + WN + wn) * cout + co) * 2;
-          z[0] = 0.0f;
-          z[1] = 0.0f;
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * g + i;
+      const int co = co0 + i + 8 * g + 4 * khalf;
+      const bool cok = co < cout;
+      const float bv = (cok && !out_class) ? bias[co] : 0.0f;
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NT; ++s) {
+        if (!nact[s]) continue;
+        float v = acc[s][r] + bv;
+        if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
+        if (CL) vv[s][i] = v;
+        else if (cok) outb[(size_t)co * R3 + vox[s]] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+      if (stats_part) {
+        // the brick's four statistics slots: wave column wn fills slot wn for its channels; with two wave rows
+        // only two columns exist and slots 2, 3 are zeroed
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && cok) {
+          float *p = stats_part + ((((size_t)b * NBRICK + brick) * 4 + wn) * cout + co) * 2;
+          p[0] = s1;
+          p[1] = s2;
+          if (WN < 4) {
+            float *z = stats_part + ((((size_t)b * NBRICK + brick) * 4 + WN + wn) * cout + co) * 2;
+            z[0] = 0.0f;
+            z[1] = 0.0f;
+          }
         }
+      }
+    }
+    if (CL) {
+      const int cq = co0 + 8 * g + 4 * khalf;
+#pragma unroll
+      for (int s = 0; s < NT; ++s) {
+        if (!nact[s]) continue;
+        float *q = outb + (size_t)vox[s] * cout + cq;
+        if (cq + 3 < cout && (cout & 3) == 0) *(f32x4 *)q = f32x4{vv[s][0], vv[s][1], vv[s][2], vv[s][3]};
+        else
+          for (int i = 0; i < 4; ++i)
+            if (cq + i < cout) q[i] = vv[s][i];
       }
     }
   }
@@ -718,18 +800,22 @@ template <int R, bool COMPACT, int MT>
 static int conv_launch(int b, int cin, int cout, const float *in, const float *wt, const float *bias,
                        const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                        const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
-                       float *stats_part, hipStream_t s) {
+                       float *stats_part, bool cl, hipStream_t s) {
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
   if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
-  if (in_scale != nullptr)
-    hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, true>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
-                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,
-                       out, stats_part);
-  else
-    hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, false>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
-                       wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,
-                       out, stats_part);
+#define LAUNCH(XF, CL)                                                                                               \
+  hipLaunchKernelGGL((conv3d_k3_kernel<R, COMPACT, MT, XF, CL>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
+                     in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list,            \
+                     brick_count, out, stats_part)
+  if (in_scale != nullptr) {
+    if (cl) LAUNCH(true, true);
+    else LAUNCH(true, false);
+  } else {
+    if (cl) LAUNCH(false, true);
+    else LAUNCH(false, false);
+  }
+#undef LAUNCH
   return p2pb_launch_status();
 }
 
@@ -737,19 +823,23 @@ template <int R, int MT>
 static int conv_launch_split(int b, int cin, int cout, const float *in, const void *wt, const float *bias,
                              const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                              const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count,
-                             float *out, float *stats_part, hipStream_t s) {
+                             float *out, float *stats_part, bool cl, hipStream_t s) {
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
   if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
   const unsigned short *w = (const unsigned short *)wt;
-  if (in_scale != nullptr)
-    hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, true>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
-                       w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count, out,
-                       stats_part);
-  else
-    hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, false>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in,
-                       w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count, out,
-                       stats_part);
+#define LAUNCH(XF, CL)                                                                                                \
+  hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
+                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,  \
+                     out, stats_part)
+  if (in_scale != nullptr) {
+    if (cl) LAUNCH(true, true);
+    else LAUNCH(true, false);
+  } else {
+    if (cl) LAUNCH(false, true);
+    else LAUNCH(false, false);
+  }
+#undef LAUNCH
   return p2pb_launch_status();
 }
 
@@ -842,7 +932,7 @@ extern "C" int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned ch
 
 // inactive bricks: the convolution's output there is a known constant per channel (bias, or the
 // boundary-class constant K): write it and the brick's exact {sum, sum of squares} partials
-template <int R>
+template <int R, bool CL>
 __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float *__restrict__ bias,
                                                           const float *__restrict__ out_class,
                                                           const int *__restrict__ brick_list,
@@ -863,9 +953,21 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
   __syncthreads();
   atomicAdd(&ncls[cls], 1);
   __syncthreads();
-  float *ob = out + (size_t)b * cout * R3 + (d * R + h) * R + w;
   const float *kb = out_class ? out_class + (size_t)b * 27 * cout : nullptr;
-  for (int co = 0; co < cout; ++co) ob[(size_t)co * R3] = kb ? kb[cls * cout + co] : bias[co];
+  if (CL) {  // voxel-major: the brick's voxels x channels, channels fastest (coalesced)
+    __shared__ unsigned char vcls[256];
+    vcls[t] = (unsigned char)cls;
+    __syncthreads();
+    float *ob = out + (size_t)b * cout * R3;
+    for (int e = t; e < 256 * cout; e += 256) {
+      const int vl = e / cout, co = e - vl * cout;
+      const int dd = d0 + vl / (TH * TW), hh = h0 + (vl / TW) % TH, ww = w0 + vl % TW;
+      ob[(size_t)((dd * R + hh) * R + ww) * cout + co] = kb ? kb[vcls[vl] * cout + co] : bias[co];
+    }
+  } else {
+    float *ob = out + (size_t)b * cout * R3 + (d * R + h) * R + w;
+    for (int co = 0; co < cout; ++co) ob[(size_t)co * R3] = kb ? kb[cls * cout + co] : bias[co];
+  }
   if (stats_part) {
     for (int co = t; co < cout; co += 256) {
       float s1 = 0.0f, s2 = 0.0f;
@@ -912,15 +1014,16 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
   hipStream_t s = (hipStream_t)stream;
   const int skip = flags & 1;
   const bool compact = (flags & 2) != 0;
+  const bool cl = (flags & 8) != 0;  // voxel-major tensors in[b,r,r,r,cin], out[b,r,r,r,cout]
   // 64 output channels per workgroup unless that leaves fewer than 2 workgroups per CU (small grids)
   const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 512;
   if (flags & 4) {  // wt_packed is the split (3 x bf16) pack; always the compact tiling (same results, same slots)
     const bool wide = cout > 32;
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, s)                          \
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s)                          \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, s)
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s)
     switch (r) {
       case 32: GOS(32);
       case 16: GOS(16);
@@ -933,9 +1036,9 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
   const float *wt32 = (const float *)wt_packed;
 #define GO(RR, CP)                                                                                                    \
   return wide ? conv_launch<RR, CP, 2>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,         \
-                                       in_sub, skip, nullptr, nullptr, out, stats_part, s)                            \
+                                       in_sub, skip, nullptr, nullptr, out, stats_part, cl, s)                            \
               : conv_launch<RR, CP, 1>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,         \
-                                       in_sub, skip, nullptr, nullptr, out, stats_part, s)
+                                       in_sub, skip, nullptr, nullptr, out, stats_part, cl, s)
   switch (r) {
     case 32:
       if (compact) { GO(32, true); } else { GO(32, false); }
@@ -959,19 +1062,25 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
   if (b <= 0 || cin <= 0 || cout <= 0 || (r != 16 && r != 32) || !active_list || !inactive_list) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int total = conv_bricks(r) * b;
-  if (r == 32)
-    hipLaunchKernelGGL(conv3d_fill_kernel<32>, dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list,
-                       inactive_count, out, stats_part);
-  else
-    hipLaunchKernelGGL(conv3d_fill_kernel<16>, dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list,
-                       inactive_count, out, stats_part);
+  const bool cl = (flags & 8) != 0;
+#define FILL(RR, CL)                                                                                          \
+  hipLaunchKernelGGL((conv3d_fill_kernel<RR, CL>), dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list, \
+                     inactive_count, out, stats_part)
+  if (r == 32) {
+    if (cl) FILL(32, true);
+    else FILL(32, false);
+  } else {
+    if (cl) FILL(16, true);
+    else FILL(16, false);
+  }
+#undef FILL
   const bool wide = cout > 32;
   if (flags & 4) {
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, s)                    \
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s)                    \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, s)
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s)
     if (r == 32) { GOS(32); }
     GOS(16);
 #undef GOS
@@ -979,9 +1088,9 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
   const float *wt32 = (const float *)wt_packed;
 #define GO(RR)                                                                                                        \
   return wide ? conv_launch<RR, true, 2>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,       \
-                                         in_sub, 1, active_list, active_count, out, stats_part, s)                    \
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s)                    \
               : conv_launch<RR, true, 1>(b, cin, cout, in, wt32, bias, out_class, in_scale, in_shift, in_swish,       \
-                                         in_sub, 1, active_list, active_count, out, stats_part, s)
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s)
   if (r == 32) { GO(32); }
   GO(16);
 #undef GO

@@ -232,6 +232,87 @@ extern "C" int p2pb_avg_voxelize_forward(int b, int c, int n, int r, const int *
   return p2pb_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Voxel-major variants for the fused inference branch (grid f32[b, r^3, c], a voxel's channels contiguous):
+// the convolutions stage and store contiguous channel runs, and both ends of the branch become coalesced:
+//   voxelize : features are first transposed to point-major [b, n, c] (LDS tile transpose), then one wave per
+//              occupied voxel reads whole 4c-byte point rows (lane = channel) and writes one contiguous row --
+//              the channel-major form reads and writes 4 bytes per 32-byte sector on both sides;
+//   devoxelize: lane = channel reads the 8 corner rows, results go through an LDS transpose so the
+//              channel-major output [b, c, n] is written in 256-byte runs.
+// Same arithmetic, same summation order as the reference-layout kernels (bit-identical values).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const float *__restrict__ in,
+                                                           float *__restrict__ out) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float *src = in + (size_t)b * c * n;
+  float *dst = out + (size_t)b * c * n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = c0 + ty + 8 * k, nn = n0 + tx;
+    t[ty + 8 * k][tx] = (cc < c && nn < n) ? src[(size_t)cc * n + nn] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int nn = n0 + ty + 8 * k, cc = c0 + tx;
+    if (cc < c && nn < n) dst[(size_t)nn * c + cc] = t[tx][ty + 8 * k];
+  }
+}
+
+__global__ __launch_bounds__(256) void vox_gather_cl_kernel(int c, int n, int r3, const int *__restrict__ cnt,
+                                                            const int *__restrict__ cur, const int *__restrict__ occ,
+                                                            const int *__restrict__ nocc, const int *__restrict__ slist,
+                                                            const float *__restrict__ feat_t, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (k >= nocc[b]) return;
+  const int lane = lane_id();
+  const int v = occ[(size_t)b * n + k];
+  const int cn = cnt[(size_t)b * r3 + v];
+  const int *seg = slist + (size_t)b * n + (cur[(size_t)b * r3 + v] - cn);
+  const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
+  const float *f = feat_t + (size_t)b * n * c;
+  float *o = out + ((size_t)b * r3 + v) * c;
+  for (int c0 = 0; c0 < c; c0 += 64) {
+    const int ch = c0 + lane;
+    if (ch < c) {
+      float acc = 0.0f;
+      for (int q = 0; q < cn; ++q) acc += f[(size_t)seg[q] * c + ch] * div;  // ascending point index, like the oracle
+      o[ch] = acc;
+    }
+  }
+}
+
+// out f32[b, r^3, c] (voxel-major); feat_t f32[b, n, c] scratch; everything else as p2pb_avg_voxelize_forward
+extern "C" int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind,
+                                            int *cnt, float *out, float *feat_t, void *ws, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || !ws || !feat_t) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int r3 = r * r * r;
+  int *cur = (int *)ws;
+  int *list = cur + (size_t)b * r3;
+  int *slist = list + (size_t)b * n;
+  int *occ = slist + (size_t)b * n;
+  int *nocc = occ + (size_t)b * n;
+  int e = p2pb_zero_async(cnt, sizeof(int) * (size_t)b * r3, s);
+  if (e != 0) return e;
+  hipLaunchKernelGGL(vox_count_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r, coords, ind, cnt);
+  hipLaunchKernelGGL(vox_scan_kernel, dim3(b), dim3(1024), 0, s, n, r3, cnt, cur, occ, nocc);
+  hipLaunchKernelGGL(vox_fill_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, r3, ind, cur, list);
+  const int maxocc = n < r3 ? n : r3;
+  hipLaunchKernelGGL(vox_sort_kernel, dim3(cdiv(maxocc, 4), b), dim3(256), 0, s, n, r3, cnt, cur, occ, nocc, list,
+                     slist);
+  hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, feat, feat_t);
+  e = p2pb_zero_async(out, sizeof(float) * (size_t)b * c * r3, s);
+  if (e != 0) return e;
+  hipLaunchKernelGGL(vox_gather_cl_kernel, dim3(cdiv(maxocc, 4), b), dim3(256), 0, s, c, n, r3, cnt, cur, occ, nocc,
+                     slist, feat_t, out);
+  return p2pb_launch_status();
+}
+
 template <int CC>
 __global__ __launch_bounds__(256) void vox_grad_kernel(int c, int n, int r3, const int *__restrict__ ind,
                                                        const int *__restrict__ cnt, const float *__restrict__ gy,
@@ -353,6 +434,67 @@ extern "C" int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, cons
   constexpr int CC = 16;
   hipLaunchKernelGGL((devox_kernel<CC, true>), dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream,
                      c, n, r, 0, coords, feat, aff_a, aff_b, (int *)nullptr, (float *)nullptr, outs);
+  return p2pb_launch_status();
+}
+
+// voxel-major grid f32[b, r^3, c] -> outs f32[b, c, n] = sum_k w_k * (grid[idx_k]*aff_a + aff_b)
+__global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, const float *__restrict__ coords,
+                                                       const float *__restrict__ grid, const float *__restrict__ aff_a,
+                                                       const float *__restrict__ aff_b, float *__restrict__ outs) {
+  __shared__ float tile[64][65];  // [channel][point]
+  __shared__ int sidx[64][8];
+  __shared__ float sw[64][8];
+  const int b = blockIdx.z, p0 = blockIdx.x * 64, t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int r3 = r * r * r;
+  if (t < 64) {
+    const int i = min(p0 + t, n - 1);
+    const float *co = coords + (size_t)b * 3 * n;
+    const Corners k = devox_corners(co[i], co[i + n], co[i + 2 * n], r);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      sidx[t][q] = k.idx[q];
+      sw[t][q] = k.w[q];
+    }
+  }
+  __syncthreads();
+  const float *g = grid + (size_t)b * r3 * c;
+  for (int c0 = 0; c0 < c; c0 += 64) {
+    const int ch = c0 + lane;
+    if (ch < c) {
+      const float a = aff_a ? aff_a[(size_t)b * c + ch] : 1.0f, bb = aff_b ? aff_b[(size_t)b * c + ch] : 0.0f;
+      for (int pl = wave * 16; pl < wave * 16 + 16; ++pl) {
+        float fv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fv[q] = g[(size_t)sidx[pl][q] * c + ch];
+        if (aff_a) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) fv[q] = fv[q] * a + bb;
+        }
+        float acc = sw[pl][0] * fv[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) acc = __fmaf_rn(sw[pl][q], fv[q], acc);
+        tile[lane][pl] = acc;
+      }
+    }
+    __syncthreads();
+    const int pt = t & 63;
+    if (p0 + pt < n) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int cr = (t >> 6) + 4 * k;
+        if (c0 + cr < c) outs[((size_t)b * c + c0 + cr) * n + p0 + pt] = tile[cr][pt];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float *coords, const float *grid,
+                                                   const float *aff_a, const float *aff_b, float *outs, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || ((aff_a == nullptr) != (aff_b == nullptr))) return P2PB_EINVAL;
+  hipLaunchKernelGGL(devox_cl_kernel, dim3(cdiv(n, 64), 1, b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
+                     aff_a, aff_b, outs);
   return p2pb_launch_status();
 }
 

@@ -59,20 +59,22 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
 
 
 def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
-              skip_zero=False, compact=False, math=None, force_split=False):
-    """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None).
+              skip_zero=False, compact=False, math=None, force_split=False, channels_last=False):
+    """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None); with
+    channels_last the grids are voxel-major, x f32[B,r,r,r,Cin] -> y f32[B,r,r,r,Cout] (the layout of the fused
+    voxel branch: contiguous channels for the staging loads, the stores, voxelize and devoxelize).
     in_sub / out_class / skip_zero / compact: the exact sparse form (csrc/conv3d.hip header)."""
     check(x, F32, "x")
-    b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+    b, ci, r = (x.shape[0], x.shape[4], x.shape[1]) if channels_last else (x.shape[0], x.shape[1], x.shape[2])
     co = conv.out_channels
     split = force_split or use_split(co, math)  # force_split: the split kernel's 32-channel variant (tests)
     wt = pack_conv3d_weight(conv, split)
-    y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
+    y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
     st = None
     if stats:
         nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
-    flags = (1 if skip_zero else 0) | (2 if compact else 0) | (4 if split else 0)
+    flags = (1 if skip_zero else 0) | (2 if compact else 0) | (4 if split else 0) | (8 if channels_last else 0)
     call("p2pb_conv3d_k3_forward_ex", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
          ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st), stream_ptr())
     return y, st
@@ -91,19 +93,20 @@ def brick_lists(cnt, r):
 
 
 def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                     out_class=None, math=None):
+                     out_class=None, math=None, channels_last=False):
     """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second"""
     check(x, F32, "x")
-    b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+    b, ci, r = (x.shape[0], x.shape[4], x.shape[1]) if channels_last else (x.shape[0], x.shape[1], x.shape[2])
     co = conv.out_channels
     split = use_split(co, math)
     wt = pack_conv3d_weight(conv, split)
-    y = torch.empty(b, co, r, r, r, dtype=F32, device=x.device)
+    y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
     nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
     st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     act, ina = lists[2 * which], lists[2 * which + 1]
+    flags = (4 if split else 0) | (8 if channels_last else 0)
     call("p2pb_conv3d_k3_forward_sparse", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(4 if split else 0), ptr(act),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(act),
          ptr(counts[2 * which:]), ptr(ina), ptr(counts[2 * which + 1:]), ptr(y), ptr(st), stream_ptr())
     return y, st
 
@@ -149,15 +152,34 @@ def se_gate_affine(chmean, fc1_weight, fc2_weight, scale, shift):
     return a, bb
 
 
-def devoxelize_affine(grid, vcoords, r, aff_a, aff_b):
-    """grid f32[B,C,r,r,r] (raw), vcoords f32[B,3,N] -> f32[B,C,N] of trilinear(grid*a + b)"""
+def devoxelize_affine(grid, vcoords, r, aff_a, aff_b, channels_last=False):
+    """grid f32[B,C,r,r,r] (raw; or voxel-major f32[B,r,r,r,C]), vcoords f32[B,3,N] -> f32[B,C,N] of
+    trilinear(grid*a + b)"""
     check(grid, F32, "grid"), check(vcoords, F32, "coords")
-    b, c = grid.shape[:2]
+    b, c = (grid.shape[0], grid.shape[4]) if channels_last else grid.shape[:2]
     n = vcoords.shape[2]
     out = torch.empty(b, c, n, dtype=F32, device=grid.device)
-    call("p2pb_trilinear_devoxelize_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
-         ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(out), stream_ptr())
+    call("p2pb_trilinear_devoxelize_cl_affine" if channels_last else "p2pb_trilinear_devoxelize_affine", _i(b), _i(c),
+         _i(n), _i(int(r)), ptr(vcoords), ptr(grid), ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(out),
+         stream_ptr())
     return out
+
+
+def voxelize_cl(features, vox, r):
+    """avg_voxelize into a voxel-major grid: features f32[B,C,N], vox i32[B,3,N] -> (grid f32[B,r,r,r,C],
+    cnt i32[B,r^3]); values identical to pointnet2_batch_cuda.avg_voxelize_forward"""
+    check(features, F32, "features")
+    b, c, n = features.shape
+    r = int(r)
+    dev = features.device
+    out = torch.empty(b, r, r, r, c, dtype=F32, device=dev)
+    ind = torch.empty(b, n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(b, r * r * r, dtype=torch.int32, device=dev)
+    feat_t = torch.empty(b, n, c, dtype=F32, device=dev)
+    ws = torch.empty(lib().p2pb_avg_voxelize_ws_bytes(_i(b), _i(n), _i(r)), dtype=torch.uint8, device=dev)
+    call("p2pb_avg_voxelize_cl_forward", _i(b), _i(c), _i(n), _i(r), ptr(vox), ptr(features), ptr(ind), ptr(cnt),
+         ptr(out), ptr(feat_t), ptr(ws), stream_ptr())
+    return out, cnt
 
 
 # ------------------------------------------------------------------ shared point MLPs (csrc/pointwise.hip)

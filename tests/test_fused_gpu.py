@@ -192,6 +192,30 @@ def test_gn_affine_params(fused, groups, style):
         assert rel_err(got, ref) < TOL
 
 
+@pytest.mark.parametrize("B,C,N,r", [(2, 64, 2048, 32), (2, 35, 1000, 16), (3, 200, 300, 8), (1, 16, 64, 4)])
+def test_voxel_major_voxelize_devoxelize(fused, B, C, N, r):
+    """the voxel-major forms produce exactly the values of the reference-layout ops (same arithmetic and order)"""
+    from p2p_bridge_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(N + C)
+    pts = torch.randn(B, 3, N, device="cuda")
+    vcoords, vox = ext.voxel_coords(pts, r)
+    f = torch.randn(B, C, N, device="cuda")
+    grid_ref, _, cnt_ref = ext.avg_voxelize_forward(f, vox, r)
+    grid, cnt = fused.voxelize_cl(f, vox, r)
+    assert grid.shape == (B, r, r, r, C)
+    assert torch.equal(cnt, cnt_ref)
+    assert torch.equal(grid.permute(0, 4, 1, 2, 3).reshape(B, C, -1), grid_ref)
+    a, b = torch.randn(B, C, device="cuda"), torch.randn(B, C, device="cuda")
+    dense = torch.randn(B, C, r, r, r, device="cuda")
+    want = fused.devoxelize_affine(dense, vcoords, r, a, b)
+    got = fused.devoxelize_affine(dense.permute(0, 2, 3, 4, 1).contiguous(), vcoords, r, a, b, channels_last=True)
+    assert torch.equal(got, want)
+    plain = ext.trilinear_devoxelize_forward(r, False, vcoords, dense.view(B, C, -1))[0]
+    ones, zeros = torch.ones(B, C, device="cuda"), torch.zeros(B, C, device="cuda")
+    assert torch.equal(fused.devoxelize_affine(dense.permute(0, 2, 3, 4, 1).contiguous(), vcoords, r, ones, zeros,
+                                               channels_last=True), plain)
+
+
 @pytest.mark.parametrize("B,C", [(3, 64), (2, 256), (1, 40)])
 def test_se_gate_affine(fused, B, C):
     """SE3d (models/modules.py:362-378) folded into the devoxelisation affine"""
@@ -205,26 +229,31 @@ def test_se_gate_affine(fused, B, C):
         assert rel_err(a, sc * gate) < 1e-5 and rel_err(b, sh * gate) < 1e-5
 
 
+@pytest.mark.parametrize("cl", [False, True])
 @pytest.mark.parametrize("math", ["bf16x6", "fp32"])
 @pytest.mark.parametrize("B,ci,co,r,compact", [(2, 35, 32, 32, True), (2, 16, 64, 32, False), (2, 64, 64, 16, True),
                                                (2, 128, 64, 16, False), (2, 24, 40, 8, False), (1, 8, 8, 4, False),
-                                               (3, 200, 72, 8, False)])
-def test_conv3d_k3(fused, B, ci, co, r, compact, math):
+                                               (3, 200, 72, 8, False), (2, 19, 50, 16, True)])
+def test_conv3d_k3(fused, B, ci, co, r, compact, math, cl):
+    """cl: voxel-major grids [B,r,r,r,C] (the fused voxel branch's layout) vs the reference's [B,C,r,r,r]"""
     torch.manual_seed(r + ci)
     x = torch.randn(B, ci, r, r, r, device="cuda")
     x[:, :, : r // 2] = 0  # an all-zero slab exercises the zero-tile skip
     conv = torch.nn.Conv3d(ci, co, 3, padding=1).cuda()
     sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
+    xi = x.permute(0, 2, 3, 4, 1).contiguous() if cl else x
+    back = (lambda t: t.permute(0, 4, 1, 2, 3)) if cl else (lambda t: t)
+    kw = dict(compact=compact, math=math, force_split=math == "bf16x6", channels_last=cl)
     with torch.no_grad():
         ref = torch.nn.functional.conv3d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
         for skip in (False, True):
-            y, st = fused.conv3d_k3(x, conv, skip_zero=skip, compact=compact, math=math, force_split=math == "bf16x6")
-            assert rel_err(y, ref) < TOL
+            y, st = fused.conv3d_k3(xi, conv, skip_zero=skip, **kw)
+            assert rel_err(back(y), ref) < TOL
             assert rel_err(stats_of(st)[1], (ref * ref).flatten(2).sum(2)) < TOL
         xin = swish(x * sc[:, :, None, None, None] + sh[:, :, None, None, None])
         ref2 = torch.nn.functional.conv3d(xin.double(), conv.weight.double(), conv.bias.double(), padding=1)
-        y2, _ = fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=compact, math=math, force_split=math == "bf16x6")
-        assert rel_err(y2, ref2) < TOL
+        y2, _ = fused.conv3d_k3(xi, conv, sc, sh, swish=True, **kw)
+        assert rel_err(back(y2), ref2) < TOL
 
 
 @pytest.mark.parametrize("B,ci,co,r", [(2, 128, 128, 16), (2, 64, 64, 32), (4, 256, 256, 8)])
@@ -264,9 +293,12 @@ def test_conv3d_sparse_lists_match_dense(fused):
     assert 0 < counts[0].item() < B * 128
     with torch.no_grad():
         ref = torch.nn.functional.conv3d(grid.double(), conv.weight.double(), conv.bias.double(), padding=1)
+        gcl = grid.permute(0, 2, 3, 4, 1).contiguous()
         for math in ("bf16x6", "fp32"):
             ys, sts = fused.conv3d_k3_sparse(grid, conv, lists, counts, 0, math=math)
             yd, std = fused.conv3d_k3(grid, conv, compact=True, math=math)
             assert torch.equal(ys, yd)
             assert rel_err(ys, ref) < TOL
             assert rel_err(stats_of(sts)[1], stats_of(std)[1]) < 1e-6
+            yc, stc = fused.conv3d_k3_sparse(gcl, conv, lists, counts, 0, math=math, channels_last=True)
+            assert torch.equal(yc.permute(0, 4, 1, 2, 3), ys) and torch.equal(stc, sts)

@@ -1,0 +1,869 @@
+// pointwise.hip -- the shared point MLPs (1x1 convolutions + AdaGN/GroupNorm + Swish (+ neighbour max))
+// of models/pvcnn.py:162-205 (SharedMLP), :388-424 (set abstraction), :446-467 (feature propagation),
+// :905-932 (Pnet2Stage) as fused gfx950 kernels.
+//
+//   pw_conv      out[b,co,p] = bias[co] (+ bias_b[b,co]) + sum_ci W[co,ci] * xf(in[b,ci,p])
+//                xf = identity, or the PREVIOUS layer's norm+activation folded to a per-(b,ci) affine
+//                + Swish applied while the operand is staged into LDS; epilogue emits the {sum, sumsq}
+//                partials the NEXT GroupNorm needs. So a chain conv-norm-act-conv-norm-act touches
+//                each activation tensor exactly twice (one write, one read) instead of ~8 times.
+//   affine_act   y = swish(x*scale[b,c] + shift[b,c]) (+ residual)           (last layer of a chain)
+//   affine_act_max  y[b,c,m] = max_u swish(x[b,c,m,u]*scale + shift)         (set-abstraction pooling)
+//
+// The GEMM runs on the exact-fp32 MFMA (32x32x2): M = output channels, N = 32 consecutive positions
+// (so stores are lane-consecutive), K = input channels. Small-C layers are HBM-bound (8 FLOP/B at
+// C=32..64), the wide ones (Pnet2Stage 512->1024) MFMA-bound.
+#include "../../p2p_bridge_amd/csrc/common.h"
+#include <stdint.h>
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PW_CK 16  // input channels per register stage (2 sub-chunks of 8): 3 waves/SIMD stay resident (32 -> 2)
+
+// Swish on the hardware exp2 / reciprocal units (see conv3d.hip fast_swish for the error budget)
+__device__ __forceinline__ float swishf(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
+
+// packed weights: wp[cin_pad/8][2][cout_pad][4], element (chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf]
+//
+// No LDS, no barriers: in a 1x1 convolution the B operand (activations) is not shared between waves --
+// each wave owns 64 distinct positions -- so every lane loads its own MFMA B fragments straight from HBM
+// (lanes 0..31 = 32 consecutive positions of channel 2kk, lanes 32..63 of channel 2kk+1: two 128-byte
+// segments per load instruction) and the four waves of a workgroup run fully decoupled. The loads of
+// chunk c+1 are issued before chunk c is multiplied; A fragments (weights) are 16-byte L1/L2 loads issued
+// first, so the in-order vmcnt wait in front of the MFMAs never covers the HBM prefetch.
+template <int MT, bool XF, bool STATS>
+__global__ __launch_bounds__(256, 3) void pw_conv_kernel(int cin, int cout, int cout_pad, int P,
+                                                      const float *__restrict__ in, const float *__restrict__ wp,
+                                                      const float *__restrict__ bias,
+                                                      const float *__restrict__ bias_b,
+                                                      const float *__restrict__ in_scale,
+                                                      const float *__restrict__ in_shift, int in_swish,
+                                                      float *__restrict__ out, float *__restrict__ stats_part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int p0 = blockIdx.x * 256, co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
+  const int pl[2] = {p0 + wave * 64 + l31, p0 + wave * 64 + 32 + l31};
+  const bool pok[2] = {pl[0] < P, pl[1] < P};
+  const float *inb = in + (size_t)b * cin * P;
+  const int nchunk8 = (cin + 7) >> 3;
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
+
+  float bcur[PW_CK / 2][2], bnxt[PW_CK / 2][2];
+  auto load_b = [&](int ci0, float(&dst)[PW_CK / 2][2]) {
+#pragma unroll
+    for (int kk = 0; kk < PW_CK / 2; ++kk) {
+      const int ci = ci0 + 2 * kk + khalf;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) dst[kk][s] = (ci < cin && pok[s]) ? inb[(size_t)ci * P + pl[s]] : 0.0f;
+    }
+  };
+  load_b(0, bcur);
+  const float *wbase = wp + ((size_t)khalf * cout_pad + co0 + l31) * 4;
+  const size_t wchunk_stride = (size_t)2 * cout_pad * 4;
+  f32x4 a_cur[PW_CK / 8][MT], a_nxt[PW_CK / 8][MT];
+  auto load_a = [&](int chunk0, f32x4(&dst)[PW_CK / 8][MT]) {
+#pragma unroll
+    for (int sub = 0; sub < PW_CK / 8; ++sub) {
+      const int ch = chunk0 + sub < nchunk8 ? chunk0 + sub : nchunk8 - 1;  // clamp: stays inside the buffer
+#pragma unroll
+      for (int m = 0; m < MT; ++m) dst[sub][m] = *(const f32x4 *)(wbase + (size_t)ch * wchunk_stride + (size_t)m * 32 * 4);
+    }
+  };
+  load_a(0, a_cur);
+
+  for (int ci0 = 0; ci0 < cin; ci0 += PW_CK) {
+    const int chunk0 = ci0 >> 3;
+    const bool more = ci0 + PW_CK < cin;
+    if (more) {  // both operands of the NEXT chunk are requested before this chunk is multiplied
+      load_a(chunk0 + PW_CK / 8, a_nxt);
+      load_b(ci0 + PW_CK, bnxt);
+    }
+    if (XF) {
+#pragma unroll
+      for (int kk = 0; kk < PW_CK / 2; ++kk) {
+        const int ci = ci0 + 2 * kk + khalf;
+        if (ci < cin) {
+          const float sc = in_scale[b * cin + ci], sh = in_shift[b * cin + ci];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            float v = bcur[kk][s] * sc + sh;
+            if (in_swish) v = swishf(v);
+            bcur[kk][s] = pok[s] ? v : 0.0f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < PW_CK / 8; ++sub) {
+      if (chunk0 + sub >= nchunk8) break;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[sub][m][kk], bcur[sub * 4 + kk][s], acc[m][s], 0, 0, 0);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int kk = 0; kk < PW_CK / 2; ++kk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bcur[kk][s] = bnxt[kk][s];
+#pragma unroll
+      for (int sub = 0; sub < PW_CK / 8; ++sub)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[sub][m] = a_nxt[sub][m];
+    }
+  }
+
+  float *outb = out + (size_t)b * cout * P;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      float bv = 0.0f;
+      if (co < cout) {
+        bv = bias ? bias[co] : 0.0f;
+        if (bias_b) bv += bias_b[(size_t)b * cout + co];
+      }
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int p = pl[s];
+        const float v = acc[m][s][r] + bv;
+        if (co < cout && pok[s]) {
+          outb[(size_t)co * P + p] = v;
+          if (STATS) {
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (STATS) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && co < cout) {
+          float *q = stats_part + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * cout + co) * 2;
+          q[0] = s1;
+          q[1] = s2;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wide tile (the default whenever rows are 16-byte aligned: npos % 4 == 0): a wave owns 32*MT output
+// channels x 128 positions. Lane j of a half-wave holds positions 4j..4j+3 of one input channel in ONE
+// 16-byte buffer load; MFMA column tile s is the position set {4j+s}, so the four tiles of a lane are the
+// four components of that load and the epilogue stores 16 bytes per lane as well: 4x fewer memory
+// instructions per MFMA than the one-position-per-lane kernel above, and the channel rows are addressed
+// through scalar descriptors (no per-lane 64-bit address arithmetic). Chunks of 8 input channels are
+// double-buffered in registers: 184 VGPRs, 2 waves/SIMD. Measured on 512->1024 x 262144 positions:
+// 133 TFLOP/s without / 125 with the statistics epilogue (the MFMA-only loop of the same shape: 133),
+// vs 86 for the narrow kernel.
+// Ragged channel counts need no predicates: a row pair starting at ci >= cin is clamped to the last row
+// (the packed weights are zero there, so the finite garbage contributes exactly 0), and the descriptor's
+// num_records ends at the sample's last row, so the odd half of a half-valid pair reads hardware zeros.
+// ------------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define PWW_CK 8
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_perm(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, ROW_MASK, 0xf, false));
+}
+// min and max over aligned groups of g lanes. g = 2..16: every lane of the group ends with the result
+// (xor-1, xor-2 inside quads, then the half-row and row mirrors); g = 32: lanes 31 / 63 hold their half-wave's.
+__device__ __forceinline__ void group_minmax(float &mn, float &mx, int g) {
+  if (g > 1) { mn = fminf(mn, dpp_perm<0xB1, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0xB1, 0xf>(mx)); }    // quad_perm [1,0,3,2]
+  if (g > 2) { mn = fminf(mn, dpp_perm<0x4E, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x4E, 0xf>(mx)); }    // quad_perm [2,3,0,1]
+  if (g > 4) { mn = fminf(mn, dpp_perm<0x141, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x141, 0xf>(mx)); }  // row_half_mirror
+  if (g > 8) { mn = fminf(mn, dpp_perm<0x140, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x140, 0xf>(mx)); }  // row_mirror
+  if (g > 16) { mn = fminf(mn, dpp_perm<0x142, 0xa>(mn)); mx = fmaxf(mx, dpp_perm<0x142, 0xa>(mx)); } // row_bcast:15
+}
+
+// POOL: additionally emit {min, max} of the raw output over groups of pool_g lanes (= 4*pool_g consecutive
+// positions: a set-abstraction neighbourhood) or, pool_g == 32, over the wave's 128 positions (global max-pool
+// partials); `out` may then be NULL. Swish (like every activation the network uses) is quasi-convex, so
+//   max_p act(scale*x_p + shift) = max(act(scale*min_p x_p + shift), act(scale*max_p x_p + shift)),
+// and the pooled tensor is produced by p2pb_minmax_act from 2/U-th of the data without the layer's
+// output ever being written or re-read.
+template <int MT, bool XF, bool STATS, bool POOL>
+__global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int cout_pad, int P, int nslots,
+                                                      const float *__restrict__ in, const float *__restrict__ wp,
+                                                      const float *__restrict__ bias,
+                                                      const float *__restrict__ bias_b,
+                                                      const float *__restrict__ in_scale,
+                                                      const float *__restrict__ in_shift, int in_swish,
+                                                      float *__restrict__ out, float *__restrict__ stats_part,
+                                                      float *__restrict__ mm_out, int pool_g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
+  const int p = blockIdx.x * 512 + wave * 128 + l31 * 4;
+  const bool pok = p < P;
+  const int pc = pok ? p : P - 4;  // clamped lanes multiply garbage that is never stored
+  const float *inb = in + (size_t)b * cin * P;
+
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
+
+  const unsigned voff = (unsigned)(khalf * P + pc) * 4u;
+  const unsigned rowbytes = (unsigned)P * 4u;
+  f32x4 bcur[PWW_CK / 2], bnxt[PWW_CK / 2];
+  auto load_b = [&](int ci0, f32x4(&dst)[PWW_CK / 2]) {
+#pragma unroll
+    for (int kk = 0; kk < PWW_CK / 2; ++kk) {
+      const int row0 = min(ci0 + 2 * kk, cin - 1);
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row0 * P), 0,
+                                                  (int)(min(cin - row0, 2) * rowbytes), 0x00020000);
+      dst[kk] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+    }
+  };
+  const float *wbase = wp + ((size_t)khalf * cout_pad + co0 + l31) * 4;
+  const size_t wchunk_stride = (size_t)2 * cout_pad * 4;
+  f32x4 a_cur[MT], a_nxt[MT];
+  auto load_a = [&](int chunk, f32x4(&dst)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) dst[m] = *(const f32x4 *)(wbase + (size_t)chunk * wchunk_stride + (size_t)m * 32 * 4);
+  };
+  load_b(0, bnxt);
+  load_a(0, a_nxt);
+
+  for (int ci0 = 0; ci0 < cin; ci0 += PWW_CK) {
+    // rotate (the vmcnt wait lands here), request the next chunk, then multiply the current one
+#pragma unroll
+    for (int kk = 0; kk < PWW_CK / 2; ++kk) bcur[kk] = bnxt[kk];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    if (ci0 + PWW_CK < cin) {
+      load_a((ci0 >> 3) + 1, a_nxt);
+      load_b(ci0 + PWW_CK, bnxt);
+    }
+    if (XF) {
+#pragma unroll
+      for (int kk = 0; kk < PWW_CK / 2; ++kk) {
+        // wave-uniform indices: the folded norm parameters travel through the scalar cache
+        const int ca = b * cin + min(ci0 + 2 * kk, cin - 1), cb = b * cin + min(ci0 + 2 * kk + 1, cin - 1);
+        const float sca = in_scale[ca], scb = in_scale[cb], sha = in_shift[ca], shb = in_shift[cb];
+        const float sc = khalf ? scb : sca, sh = khalf ? shb : sha;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          float v = bcur[kk][s] * sc + sh;
+          if (in_swish) v = swishf(v);
+          bcur[kk][s] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][kk], bcur[kk][s], acc[m][s], 0, 0, 0);
+  }
+
+  float *outb = out + (size_t)b * cout * P;
+  // statistics slots keep the 64-position granularity of the narrow kernel: this wave fills slot `slot`
+  // with its 128-position sums and zeroes slot + 1
+  const int slot = (blockIdx.x * 4 + wave) * 2;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      float bv = 0.0f;
+      if (co < cout) {
+        bv = bias ? bias[co] : 0.0f;
+        if (bias_b) bv += bias_b[(size_t)b * cout + co];
+      }
+      const f32x4 v = {acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv};
+      float s1 = 0.0f, s2 = 0.0f;
+      if (co < cout && pok) {
+        if (!POOL || out) *(f32x4 *)(outb + (size_t)co * P + p) = v;
+        if (STATS) {
+          s1 = (v[0] + v[1]) + (v[2] + v[3]);
+          s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+      }
+      if (POOL) {
+        float mn = pok ? fminf(fminf(v[0], v[1]), fminf(v[2], v[3])) : INFINITY;
+        float mx = pok ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
+        group_minmax(mn, mx, pool_g);
+        if (co < cout) {
+          if (pool_g == 32) {
+            if (l31 == 31) {
+              float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * cout + co) * 2;
+              q[0] = mn;
+              q[1] = mx;
+            }
+          } else if ((l31 & (pool_g - 1)) == 0 && pok) {
+            const int u = 4 * pool_g;
+            float *q = mm_out + (((size_t)b * cout + co) * (P / u) + p / u) * 2;
+            q[0] = mn;
+            q[1] = mx;
+          }
+        }
+      }
+      if (STATS) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && co < cout) {
+          if (slot < nslots) {
+            float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
+            q[0] = s1;
+            q[1] = s2;
+          }
+          if (slot + 1 < nslots) {
+            float *q = stats_part + (((size_t)b * nslots + slot + 1) * cout + co) * 2;
+            q[0] = 0.0f;
+            q[1] = 0.0f;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void pw_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, const float *__restrict__ w,
+                               float *__restrict__ wp) {
+  const size_t total = (size_t)cin_pad * cout_pad;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int kk = (int)(e & 3);
+    const int co = (int)((e >> 2) % cout_pad);
+    const int kh = (int)((e / ((size_t)4 * cout_pad)) & 1);
+    const int chunk = (int)(e / ((size_t)8 * cout_pad));
+    const int ci = chunk * 8 + 2 * kk + kh;
+    wp[e] = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
+  }
+}
+
+static inline int pw_cin_pad(int cin) { return (cin + 7) / 8 * 8; }
+static inline int pw_cout_pad(int cout) { return (cout + 127) / 128 * 128; }
+
+extern "C" size_t p2pb_pointwise_packed_floats(int cout, int cin) {
+  return (size_t)pw_cin_pad(cin) * pw_cout_pad(cout);
+}
+
+extern "C" int p2pb_pointwise_pack_weights(int cout, int cin, const float *w, float *wp, void *stream) {
+  if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
+  const size_t total = p2pb_pointwise_packed_floats(cout, cin);
+  hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256),
+                     0, (hipStream_t)stream, cout, cin, pw_cin_pad(cin), pw_cout_pad(cout), w, wp);
+  return p2pb_launch_status();
+}
+
+extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
+  return (size_t)b * ((npos + 255) / 256) * 4 * cout * 2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-operand form of the same GEMM for the matrix-bound layers (wide channel counts): fp32 operands as
+// three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulate -- the arithmetic of
+// conv3d.hip's split kernel (fp32-faithful: dropped terms < 2^-26 |x*w|), 2.67x fewer matrix cycles.
+// At that rate the operands can no longer stream through per-lane global loads (the wide kernel above
+// would need ~50 B/clk/CU of L1 bandwidth), so this one is the classic LDS-tiled GEMM:
+//   workgroup = 4 waves as 2 (M) x 2 (N): 128 output channels x 128 positions, 32 input channels per stage;
+//   A: pre-split packed weights, one contiguous 24 KB tile per (stage, 128-channel block), copied to LDS;
+//   B: each wave loads 8 channels x 128 positions (8-byte coalesced loads through scalar row descriptors),
+//      applies the folded norm + Swish ONCE per element, splits, and writes 16-byte groups of 8 channels;
+//   LDS[kstep][split][khalf][128 rows] x 16 B for both, so every MFMA fragment is one conflict-free
+//   ds_read_b128 (positions are stored even/odd de-interleaved: lane j of N-tile n owns position 2j+n,
+//   which also makes the epilogue's stores 8 bytes per lane).
+// Global loads of the next stage fly during the MFMAs of the current one (register staged).
+// ------------------------------------------------------------------------------------------------
+#define PWS_CK 32
+
+template <bool XF, bool POOL>
+__global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int P, int nslots,
+                                                       const float *__restrict__ in, const u32x4 *__restrict__ wp,
+                                                       const float *__restrict__ bias,
+                                                       const float *__restrict__ bias_b,
+                                                       const float *__restrict__ in_scale,
+                                                       const float *__restrict__ in_shift, int in_swish,
+                                                       float *__restrict__ out, float *__restrict__ stats_part,
+                                                       float *__restrict__ mm_out, int pool_u) {
+  __shared__ u32x4 lds_a[2 * 3 * 2 * 128];
+  __shared__ u32x4 lds_b[2 * 3 * 2 * 128];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the scalar descriptors
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int pblk = blockIdx.x * 128, co0 = blockIdx.y * 128, b = blockIdx.z;
+  const int ncoblk = gridDim.y;
+  const float *inb = in + (size_t)b * cin * P;
+  const bool mact = co0 + wm * 64 < cout;  // this wave's 64 channels exist (wave-uniform)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  // B staging: wave w owns channel group w (8 channels) of the stage, lane l positions 2l, 2l+1
+  const int pl = pblk + 2 * lane;
+  const unsigned voff = (unsigned)(pl < P ? pl : P - 2) * 4u;  // clamped lanes stage garbage that is never stored
+  f32x2 braw[8];
+  auto load_b = [&](int ci0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(ci0 + 8 * wave + i, cin - 1);  // beyond cin: finite garbage x zero weights
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, P * 4, 0x00020000);
+      braw[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+    }
+  };
+  u32x4 araw[6];
+  auto load_a = [&](int chunk) {
+    const u32x4 *src = wp + ((size_t)chunk * ncoblk + blockIdx.y) * (2 * 3 * 2 * 128);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) araw[i] = src[tid + i * 256];
+  };
+  load_b(0);
+  load_a(0);
+
+  u32x4 afk[2][3][2], bfk[2][3][2];
+  for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
+    __syncthreads();  // everyone is done reading the previous stage
+#if EXP_NOSTAGE
+    if (ci0 == 0) {
+#endif
+    // ---- stage: A copy, B transform + split
+#if EXP_NOA
+    if (ci0 == 0)
+#endif
+#pragma unroll
+    for (int i = 0; i < 6; ++i) lds_a[tid + i * 256] = araw[i];
+    {
+      if (XF) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = b * cin + min(ci0 + 8 * wave + i, cin - 1);
+          const float sc = in_scale[c], sh = in_shift[c];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float v = braw[i][e] * sc + sh;
+            if (in_swish) v = swishf(v);
+            braw[i][e] = v;
+          }
+        }
+      }
+      const int kstep = wave >> 1, kh = wave & 1;
+#if EXP_NOB
+      if (ci0 == 0)
+#endif
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        u32x4 q[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned p0, p1, p2;
+          split3(braw[2 * i][e], braw[2 * i + 1][e], p0, p1, p2);
+          q[0][i] = p0;
+          q[1][i] = p1;
+          q[2][i] = p2;
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * 128 + e * 64 + lane] = q[s];
+      }
+    }
+#if EXP_NOSTAGE
+    }
+#endif
+    __syncthreads();
+#if !EXP_NOLOAD
+    if (ci0 + PWS_CK < cin) {  // next stage's global loads fly during the MFMAs
+      load_b(ci0 + PWS_CK);
+      load_a(ci0 / PWS_CK + 1);
+    }
+#endif
+    if (!mact) continue;
+#pragma unroll
+    for (int kstep = 0; kstep < 2; ++kstep) {
+#define af afk[kstep]
+#define bf bfk[kstep]
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#if EXP_NOLDSREAD
+        if (ci0 > 0) continue;
+#endif
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af[s][m] = lds_a[((kstep * 3 + s) * 2 + khalf) * 128 + wm * 64 + m * 32 + l31];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * 128 + n * 64 + wn * 32 + l31];
+      }
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[t]][m]),
+                                                                __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
+    }
+  }
+  if (!mact) return;
+
+  // ---- epilogue: bias, 8-byte stores, GroupNorm partials per 64-position slot, optional {min, max}
+  float *outb = out ? out + (size_t)b * cout * P : nullptr;
+  const int p = pblk + 2 * (wn * 32 + l31);
+  const bool pok = p < P;
+  const int slot = blockIdx.x * 2 + wn;
+  const int pool_g = pool_u ? pool_u / 2 : 32;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      const bool cok = co < cout;
+      float bv = 0.0f;
+      if (cok) {
+        bv = bias ? bias[co] : 0.0f;
+        if (bias_b) bv += bias_b[(size_t)b * cout + co];
+      }
+      const f32x2 v = {acc[m][0][r] + bv, acc[m][1][r] + bv};
+      float s1 = 0.0f, s2 = 0.0f;
+      if (cok && pok) {
+        if (outb) *(f32x2 *)(outb + (size_t)co * P + p) = v;
+        s1 = v[0] + v[1];
+        s2 = v[0] * v[0] + v[1] * v[1];
+      }
+      if (POOL) {
+        float mn = pok ? fminf(v[0], v[1]) : INFINITY, mx = pok ? fmaxf(v[0], v[1]) : -INFINITY;
+        group_minmax(mn, mx, pool_g);
+        if (cok) {
+          if (pool_u == 0) {
+            if (l31 == 31) {
+              float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 2 + wn) * cout + co) * 2;
+              q[0] = mn;
+              q[1] = mx;
+            }
+          } else if (pok && (pool_g == 32 ? l31 == 31 : (l31 & (pool_g - 1)) == 0)) {
+            float *q = mm_out + (((size_t)b * cout + co) * (P / pool_u) + p / pool_u) * 2;
+            q[0] = mn;
+            q[1] = mx;
+          }
+        }
+      }
+      if (stats_part) {
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && cok) {
+          float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
+          q[0] = s1;
+          q[1] = s2;
+          if (blockIdx.x == gridDim.x - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
+            for (int sl = slot + 1; sl < nslots; ++sl) {
+              float *z = stats_part + (((size_t)b * nslots + sl) * cout + co) * 2;
+              z[0] = 0.0f;
+              z[1] = 0.0f;
+            }
+        }
+      }
+    }
+  }
+}
+
+// split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
+// channel = chunk*32 + kstep*16 + khalf*8 + idx
+__global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, const float *__restrict__ w,
+                                     unsigned short *__restrict__ wp) {
+  const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;  // (chunk, coblk, kstep, khalf, co, idx)
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int idx = (int)(e & 7);
+    size_t q = e >> 3;
+    const int col = (int)(q & 127);
+    q >>= 7;
+    const int kh = (int)(q & 1);
+    q >>= 1;
+    const int ks = (int)(q & 1);
+    q >>= 1;
+    const int cb = (int)(q % ncoblk), chunk = (int)(q / ncoblk);
+    const int co = cb * 128 + col, ci = chunk * PWS_CK + ks * 16 + kh * 8 + idx;
+    const float x = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
+    unsigned p0, p1, p2;
+    split3(x, 0.0f, p0, p1, p2);
+    const unsigned pp[3] = {p0, p1, p2};
+    for (int s = 0; s < 3; ++s)
+      wp[((((((size_t)chunk * ncoblk + cb) * 2 + ks) * 3 + s) * 2 + kh) * 128 + col) * 8 + idx] = (unsigned short)(pp[s] & 0xffff);
+  }
+}
+
+extern "C" size_t p2pb_pointwise_split_packed_bytes(int cout, int cin) {
+  const size_t nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
+  return nchunk * ncoblk * (2 * 3 * 2 * 128) * 16;
+}
+
+extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w, void *wp, void *stream) {
+  if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
+  const int nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
+  const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;
+  hipLaunchKernelGGL(pw_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp);
+  return p2pb_launch_status();
+}
+
+static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
+                           const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
+                           float *out, float *stats_part, float *minmax, int pool_u, hipStream_t s) {
+  dim3 grid((P + 127) / 128, (cout + 127) / 128, b);
+  const int nslots = (P + 255) / 256 * 4;
+  const u32x4 *w = (const u32x4 *)wp;
+#define LAUNCH(XF, PL)                                                                                               \
+  hipLaunchKernelGGL((pw_split_kernel<XF, PL>), grid, dim3(256), 0, s, cin, cout, P, nslots, in, w, bias, bias_b,      \
+                     in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u)
+  if (in_scale && minmax) LAUNCH(true, true);
+  else if (in_scale) LAUNCH(true, false);
+  else if (minmax) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  return p2pb_launch_status();
+}
+
+static bool pw_wide_ok(int P, const float *in, const float *out) {
+  // 16-byte rows: every row of in/out starts on a 16-byte boundary and holds whole quads
+  return P % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+}
+
+template <int MT>
+static int pw_launch(int b, int cin, int cout, int P, const float *in, const float *wp, const float *bias,
+                     const float *bias_b, const float *in_scale, const float *in_shift, int in_swish, float *out,
+                     float *stats_part, float *minmax, int pool_g, hipStream_t s) {
+  const bool xf = in_scale != nullptr, st = stats_part != nullptr;
+  if (pw_wide_ok(P, in, out)) {
+    dim3 grid((P + 511) / 512, (cout + 32 * MT - 1) / (32 * MT), b);
+    const int nslots = (P + 255) / 256 * 4;
+#define LAUNCH(XF, ST, PL)                                                                                         \
+  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, nslots, \
+                     in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g)
+    if (minmax) {
+      if (xf) LAUNCH(true, true, true);
+      else LAUNCH(false, true, true);
+    } else if (xf && st) LAUNCH(true, true, false);
+    else if (xf) LAUNCH(true, false, false);
+    else if (st) LAUNCH(false, true, false);
+    else LAUNCH(false, false, false);
+#undef LAUNCH
+    return p2pb_launch_status();
+  }
+  if (minmax) return P2PB_EINVAL;
+  dim3 grid((P + 255) / 256, (cout + 32 * MT - 1) / (32 * MT), b);
+#define LAUNCH(XF, ST)                                                                                            \
+  hipLaunchKernelGGL((pw_conv_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, in, wp, bias, \
+                     bias_b, in_scale, in_shift, in_swish, out, stats_part)
+  if (xf && st) LAUNCH(true, true);
+  else if (xf) LAUNCH(true, false);
+  else if (st) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  return p2pb_launch_status();
+}
+
+extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const void *wp_any,
+                                           const float *bias, const float *bias_b, const float *in_scale,
+                                           const float *in_shift, int in_swish, int flags, float *out,
+                                           float *stats_part, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & 4) {  // wp is the split pack
+    if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
+    return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
+                           nullptr, 0, s);
+  }
+  const float *wp = (const float *)wp_any;
+  // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
+  return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, nullptr, 0, s)
+                   : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, nullptr, 0, s);
+}
+
+// pool_u = neighbourhood size (4, 8, 16, 32 or 64 consecutive positions) or 0 for the global pool
+static int pool_lanes(int pool_u) { return pool_u == 0 ? 32 : pool_u / 4; }
+
+extern "C" int p2pb_pointwise_pool_supported(int npos, int pool_u) {
+  const bool uok = pool_u == 0 || pool_u == 4 || pool_u == 8 || pool_u == 16 || pool_u == 32 || pool_u == 64;
+  return npos > 0 && npos % 4 == 0 && uok && (pool_u == 0 || npos % pool_u == 0);
+}
+
+extern "C" size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int pool_u, int flags) {
+  if (pool_u == 0) return (size_t)b * ((flags & 4) ? (npos + 127) / 128 * 2 : (npos + 511) / 512 * 4) * cout * 2;
+  return (size_t)b * cout * (npos / pool_u) * 2;
+}
+
+extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in,
+                                                const void *wp_any, const float *bias, const float *bias_b,
+                                                const float *in_scale, const float *in_shift, int in_swish, int flags,
+                                                float *out, float *stats_part, int pool_u, float *minmax,
+                                                void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !stats_part || !minmax) return P2PB_EINVAL;
+  if (!p2pb_pointwise_pool_supported(npos, pool_u) || !pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (flags & 4)
+    return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
+                           minmax, pool_u, s);
+  const float *wp = (const float *)wp_any;
+  const int g = pool_lanes(pool_u);
+  return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, minmax, g, s)
+                   : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                  stats_part, minmax, g, s);
+}
+
+// y = max(act(scale*min + shift), act(scale*max + shift)):
+//   nslots == 0: minmax f32[b, c, m, 2] -> y f32[b, c, m]      (set-abstraction neighbour max)
+//   nslots  > 0: minmax f32[b, nslots, c, 2] -> y f32[b, c]    (global max-pool; partials reduced first)
+__global__ __launch_bounds__(256) void minmax_act_kernel(int c, int m, int nslots, const float *__restrict__ mm,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int swish,
+                                                         float *__restrict__ y, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    float mn, mx;
+    size_t bc;
+    if (nslots == 0) {
+      bc = e / m;
+      const float2 v = *(const float2 *)(mm + e * 2);
+      mn = v.x;
+      mx = v.y;
+    } else {
+      bc = e;
+      const size_t b = e / c, ch = e % c;
+      mn = INFINITY;
+      mx = -INFINITY;
+      for (int sl = 0; sl < nslots; ++sl) {
+        const float2 v = *(const float2 *)(mm + ((b * nslots + sl) * c + ch) * 2);
+        mn = fminf(mn, v.x);
+        mx = fmaxf(mx, v.y);
+      }
+    }
+    const float sc = scale[bc], sh = shift[bc];
+    float lo = mn * sc + sh, hi = mx * sc + sh;
+    if (swish) {
+      lo = swishf(lo);
+      hi = swishf(hi);
+    }
+    y[e] = fmaxf(lo, hi);
+  }
+}
+
+extern "C" int p2pb_minmax_act(int b, int c, int m, int nslots, const float *minmax, const float *scale,
+                               const float *shift, int swish, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || m <= 0 || nslots < 0) return P2PB_EINVAL;
+  const size_t total = nslots == 0 ? (size_t)b * c * m : (size_t)b * c;
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(minmax_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, m, nslots, minmax, scale,
+                     shift, swish, y, total);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = act(x*scale[b,c] + shift[b,c]) (+ residual)   over [b, c, P]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_act_kernel(int c, int P, const float *__restrict__ x,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int swish,
+                                                         const float *__restrict__ residual, float *__restrict__ y) {
+  const int bc = blockIdx.y;  // b*c + ch
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * P;
+  const float *rr = residual ? residual + (size_t)bc * P : nullptr;
+  float *yr = y + (size_t)bc * P;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+    float v = xr[p] * sc + sh;
+    if (swish) v = swishf(v);
+    if (rr) v = rr[p] + v;
+    yr[p] = v;
+  }
+}
+
+extern "C" int p2pb_affine_act(int b, int c, int npos, const float *x, const float *scale, const float *shift,
+                               int swish, const float *residual, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || npos <= 0) return P2PB_EINVAL;
+  const unsigned gx = (unsigned)((npos + 255) / 256 > 64 ? 64 : (npos + 255) / 256);
+  hipLaunchKernelGGL(affine_act_kernel, dim3(gx, b * c), dim3(256), 0, (hipStream_t)stream, c, npos, x, scale, shift,
+                     swish, residual, y);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// y[b,c,m] = max_{u < U} act(x[b,c,m,u]*scale + shift), U a power of two <= 64 (32 in every config):
+// lanes read the [m,u] plane contiguously, the max runs over aligned groups of U lanes.
+// U == 0 selects "max over the whole row" (Pnet2Stage's global max-pool): y[b,c] = max_p act(...).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void affine_act_max_kernel(int M, int U, const float *__restrict__ x,
+                                                             const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int swish,
+                                                             float *__restrict__ y) {
+  const int bc = blockIdx.y;
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * M * U;
+  float *yr = y + (size_t)bc * M;
+  const int total = M * U;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {  // total % 64 == 0 by construction
+    float v = xr[e] * sc + sh;
+    if (swish) v = swishf(v);
+    for (int off = U >> 1; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    if ((e & (U - 1)) == 0) yr[e / U] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_act_rowmax_kernel(int P, const float *__restrict__ x,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift, int swish,
+                                                                float *__restrict__ y) {
+  __shared__ float red[256];
+  const int bc = blockIdx.x;
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * P;
+  float mx = -INFINITY;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    float v = xr[p] * sc + sh;
+    if (swish) v = swishf(v);
+    mx = fmaxf(mx, v);
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) y[bc] = red[0];
+}
+
+extern "C" int p2pb_affine_act_max(int b, int c, int m, int u, const float *x, const float *scale, const float *shift,
+                                   int swish, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || m <= 0 || u < 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (u == 0) {
+    hipLaunchKernelGGL(affine_act_rowmax_kernel, dim3(b * c), dim3(256), 0, s, m, x, scale, shift, swish, y);
+    return p2pb_launch_status();
+  }
+  if ((u & (u - 1)) != 0 || u > 64 || ((long)m * u) % 64 != 0) return P2PB_EINVAL;
+  const long total = (long)m * u;
+  const unsigned gx = (unsigned)((total + 255) / 256 > 64 ? 64 : (total + 255) / 256);
+  hipLaunchKernelGGL(affine_act_max_kernel, dim3(gx, b * c), dim3(256), 0, s, m, u, x, scale, shift, swish, y);
+  return p2pb_launch_status();
+}

@@ -26,3 +26,13 @@ for (r, ci, co) in shapes:
             ms = bench(lambda: fused.conv3d_k3(x, conv, compact=True, math=math))
             msx = bench(lambda: fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True, math=math))
             print(f"r{r} {ci}->{co} {math:7s}: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s | xf {msx:.3f} ms {fl / msx / 1e9:.0f} TF/s", flush=True)
+print("---- voxel-major (channels_last) grids")
+for (r, ci, co) in shapes:
+    x = torch.randn(B, r, r, r, ci, device="cuda")
+    conv = torch.nn.Conv3d(ci, co, 3, padding=1).cuda()
+    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
+    fl = 27 * 2.0 * ci * co * r ** 3 * B
+    with torch.no_grad():
+        ms = bench(lambda: fused.conv3d_k3(x, conv, compact=True, channels_last=True))
+        msx = bench(lambda: fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True, channels_last=True))
+        print(f"r{r} {ci}->{co} CL default-math: {ms:.3f} ms {fl / ms / 1e9:.0f} TF/s | xf {msx:.3f} ms {fl / msx / 1e9:.0f} TF/s", flush=True)
