@@ -385,7 +385,9 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
 // At that rate the operands can no longer stream through per-lane global loads (the wide kernel above
 // would need ~50 B/clk/CU of L1 bandwidth), so this one is the classic LDS-tiled GEMM:
 //   workgroup = 4 waves as 2 (M) x 2 (N): 128 output channels x 128 positions, 32 input channels per stage;
-//   A: pre-split packed weights, one contiguous 24 KB tile per (stage, 128-channel block), copied to LDS;
+//   A: pre-split packed weights, one contiguous 24 KB tile per (stage, 128-channel block), brought into a
+//      double-buffered LDS tile by the LDS-DMA path (global_load_lds_dwordx4: no registers, no ds_write --
+//      measured, the VGPR->LDS store path is what bounds this kernel: staging off = 141 -> 206 TFLOP/s);
 //   B: each wave loads 8 channels x 128 positions (8-byte coalesced loads through scalar row descriptors),
 //      applies the folded norm + Swish ONCE per element, splits, and writes 16-byte groups of 8 channels;
 //   LDS[kstep][split][khalf][128 rows] x 16 B for both, so every MFMA fragment is one conflict-free
@@ -394,6 +396,9 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
 // Global loads of the next stage fly during the MFMAs of the current one (register staged).
 // ------------------------------------------------------------------------------------------------
 #define PWS_CK 32
+
+#define PWS_TILE (2 * 3 * 2 * 128)                     // 16-byte groups per operand tile (24 KB)
+#define PWS_LDS_BYTES (2 * PWS_TILE * 16)               // A + B
 
 template <bool XF, bool POOL>
 __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int P, int nslots,
@@ -404,8 +409,9 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
                                                        const float *__restrict__ in_shift, int in_swish,
                                                        float *__restrict__ out, float *__restrict__ stats_part,
                                                        float *__restrict__ mm_out, int pool_u) {
-  __shared__ u32x4 lds_a[2 * 3 * 2 * 128];
-  __shared__ u32x4 lds_b[2 * 3 * 2 * 128];
+  extern __shared__ u32x4 pws_lds[];  // [A][B]
+  u32x4 *lds_b = pws_lds + PWS_TILE;
+  const u32x4 *lds_a = pws_lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the scalar descriptors
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -435,20 +441,21 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
       braw[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
     }
   };
-  u32x4 araw[6];
-  auto load_a = [&](int chunk) {
-    const u32x4 *src = wp + ((size_t)chunk * ncoblk + blockIdx.y) * (2 * 3 * 2 * 128);
+  // A tile of stage `chunk` -> LDS, asynchronously: lane i of a wave lands at base + 16*i
+  auto dma_a = [&](int chunk) {
+    const u32x4 *src = wp + ((size_t)chunk * ncoblk + blockIdx.y) * PWS_TILE;
+    u32x4 *dst = pws_lds;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) araw[i] = src[tid + i * 256];
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256 + tid),
+                                       (__attribute__((address_space(3))) void *)(dst + i * 256 + wave * 64), 16, 0, 0);
   };
   load_b(0);
-  load_a(0);
 
   for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
     __syncthreads();  // everyone is done reading the previous stage
-    // ---- stage: A copy, B transform + split
-#pragma unroll
-    for (int i = 0; i < 6; ++i) lds_a[tid + i * 256] = araw[i];
+    dma_a(ci0 / PWS_CK);  // lands while B is transformed and split below
+    // ---- stage B: transform + split
     {
       if (XF) {
 #pragma unroll
@@ -479,11 +486,9 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
         for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * 128 + e * 64 + lane] = q[s];
       }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this stage's A tile has landed
     __syncthreads();
-    if (ci0 + PWS_CK < cin) {  // next stage's global loads fly during the MFMAs
-      load_b(ci0 + PWS_CK);
-      load_a(ci0 / PWS_CK + 1);
-    }
+    if (ci0 + PWS_CK < cin) load_b(ci0 + PWS_CK);  // next stage's B loads fly during the MFMAs
     if (!mact) continue;
 #pragma unroll
     for (int kstep = 0; kstep < 2; ++kstep) {
@@ -613,9 +618,18 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   dim3 grid((P + 127) / 128, (cout + 127) / 128, b);
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
+  // 72 KB of dynamic LDS (above the 64 KB default): opt in once per instantiation
 #define LAUNCH(XF, PL)                                                                                               \
-  hipLaunchKernelGGL((pw_split_kernel<XF, PL>), grid, dim3(256), 0, s, cin, cout, P, nslots, in, w, bias, bias_b,      \
-                     in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u)
+  do {                                                                                                               \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
+                          PWS_LDS_BYTES);                                                                            \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((pw_split_kernel<XF, PL>), grid, dim3(256), PWS_LDS_BYTES, s, cin, cout, P, nslots, in, w, bias, \
+                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                        \
+  } while (0)
   if (in_scale && minmax) LAUNCH(true, true);
   else if (in_scale) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
