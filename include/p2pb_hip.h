@@ -209,11 +209,13 @@ int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const flo
 
 /* Voxel-major forms for the fused branch (grid f32[b,r,r,r,c]; conv flags bit 3): same values as
  * p2pb_avg_voxelize_forward / p2pb_trilinear_devoxelize_affine, coalesced on both sides (voxelize.hip).
- * feat_t: f32[b,n,c] scratch (the point-major copy of feat); aff_a/aff_b may both be NULL. */
+ * feat_t: f32[b,n,c] scratch (the point-major copy of feat); aff_a/aff_b may both be NULL. With add:
+ * outs += swish(add*add_scale[b,c] + add_shift[b,c]), PVConv's point branch (models/pvcnn.py:286,325). */
 int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind, int *cnt,
                                  float *out, float *feat_t, void *ws, void *stream);
 int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float *coords, const float *grid,
-                                        const float *aff_a, const float *aff_b, float *outs, void *stream);
+                                        const float *aff_a, const float *aff_b, const float *add /* f32[b,c,n] or NULL */,
+                                        const float *add_scale, const float *add_shift, float *outs, void *stream);
 /* trilinear devoxelize of feat*aff_a[b,c] + aff_b[b,c] (AdaGN + SE gate folded), inference only */
 int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *coords, const float *feat,
                                      const float *aff_a, const float *aff_b, float *outs, void *stream);

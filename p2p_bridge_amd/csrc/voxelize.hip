@@ -438,9 +438,13 @@ extern "C" int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, cons
 }
 
 // voxel-major grid f32[b, r^3, c] -> outs f32[b, c, n] = sum_k w_k * (grid[idx_k]*aff_a + aff_b)
+// add (optional, f32[b,c,n]) with add_scale/add_shift f32[b,c]: outs += swish(add*add_scale + add_shift) -- PVConv's
+// point branch (conv -> norm -> Swish, models/pvcnn.py:286,325) joined to the voxel branch in the same pass
 __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, const float *__restrict__ coords,
                                                        const float *__restrict__ grid, const float *__restrict__ aff_a,
-                                                       const float *__restrict__ aff_b, float *__restrict__ outs) {
+                                                       const float *__restrict__ aff_b, const float *__restrict__ add,
+                                                       const float *__restrict__ add_scale,
+                                                       const float *__restrict__ add_shift, float *__restrict__ outs) {
   __shared__ float tile[64][65];  // [channel][point]
   __shared__ int sidx[64][8];
   __shared__ float sw[64][8];
@@ -483,7 +487,15 @@ __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, cons
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         const int cr = (t >> 6) + 4 * k;
-        if (c0 + cr < c) outs[((size_t)b * c + c0 + cr) * n + p0 + pt] = tile[cr][pt];
+        if (c0 + cr < c) {
+          const size_t o = ((size_t)b * c + c0 + cr) * n + p0 + pt;
+          float v = tile[cr][pt];
+          if (add) {
+            const float z = add[o] * add_scale[(size_t)b * c + c0 + cr] + add_shift[(size_t)b * c + c0 + cr];
+            v = z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f)) + v;
+          }
+          outs[o] = v;
+        }
       }
     }
     __syncthreads();
@@ -491,10 +503,13 @@ __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, cons
 }
 
 extern "C" int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float *coords, const float *grid,
-                                                   const float *aff_a, const float *aff_b, float *outs, void *stream) {
+                                                   const float *aff_a, const float *aff_b, const float *add,
+                                                   const float *add_scale, const float *add_shift, float *outs,
+                                                   void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || ((aff_a == nullptr) != (aff_b == nullptr))) return P2PB_EINVAL;
+  if (add && (!add_scale || !add_shift)) return P2PB_EINVAL;
   hipLaunchKernelGGL(devox_cl_kernel, dim3(cdiv(n, 64), 1, b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
-                     aff_a, aff_b, outs);
+                     aff_a, aff_b, add, add_scale, add_shift, outs);
   return p2pb_launch_status();
 }
 

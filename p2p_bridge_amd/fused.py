@@ -152,16 +152,21 @@ def se_gate_affine(chmean, fc1_weight, fc2_weight, scale, shift):
     return a, bb
 
 
-def devoxelize_affine(grid, vcoords, r, aff_a, aff_b, channels_last=False):
+def devoxelize_affine(grid, vcoords, r, aff_a, aff_b, channels_last=False, add=None):
     """grid f32[B,C,r,r,r] (raw; or voxel-major f32[B,r,r,r,C]), vcoords f32[B,3,N] -> f32[B,C,N] of
-    trilinear(grid*a + b)"""
+    trilinear(grid*a + b); add = (h f32[B,C,N], scale, shift f32[B,C]) (voxel-major form only): + swish(h*scale+shift)"""
     check(grid, F32, "grid"), check(vcoords, F32, "coords")
     b, c = (grid.shape[0], grid.shape[4]) if channels_last else grid.shape[:2]
     n = vcoords.shape[2]
     out = torch.empty(b, c, n, dtype=F32, device=grid.device)
-    call("p2pb_trilinear_devoxelize_cl_affine" if channels_last else "p2pb_trilinear_devoxelize_affine", _i(b), _i(c),
-         _i(n), _i(int(r)), ptr(vcoords), ptr(grid), ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(out),
-         stream_ptr())
+    if channels_last:
+        h, hs, hb = add if add is not None else (None, None, None)
+        call("p2pb_trilinear_devoxelize_cl_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
+             ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(h), ptr(hs), ptr(hb), ptr(out), stream_ptr())
+    else:
+        assert add is None
+        call("p2pb_trilinear_devoxelize_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
+             ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(out), stream_ptr())
     return out
 
 

@@ -280,7 +280,7 @@ class PVConv(nn.Module):
         self.sparse_conv = True  # inference: exact sparse convolution for r >= 16 (fused._voxel_branch_fused)
         self.point_features = SharedMLP(in_channels, out_channels, gn_groups=gn_groups, cond_dim=cond_dim)
 
-    def _voxel_branch_fused(self, features, coords, cond):
+    def _voxel_branch_fused(self, features, coords, cond, point=None):
         """inference: voxelize -> conv -> [AdaGN,Swish folded] -> conv -> [AdaGN,SE folded] -> devoxelize; grid
         tensors written once / read once (fused.py). For r >= 16 the convolutions run in their exact sparse form:
         MFMA work only on the bricks near the surface, analytic constants elsewhere (csrc/conv3d.hip)."""
@@ -308,12 +308,23 @@ class PVConv(nn.Module):
         sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
         if se is not None:
             sc2, sh2 = fused.se_gate_affine(mean2, se.fc[0].weight, se.fc[2].weight, sc2, sh2)
-        return fused.devoxelize_affine(y2, vcoords, r, sc2, sh2, channels_last=True)
+        # point = (h, scale, shift): the point branch's raw conv output and folded norm; its Swish and the sum of
+        # the two branches happen in the devoxelisation pass
+        return fused.devoxelize_affine(y2, vcoords, r, sc2, sh2, channels_last=True, add=point)
 
     def forward(self, data: PVCData) -> PVCData:
         coords, features, cond = data.coords, data.features, data.cond
         assert features.shape[0] == coords.shape[0] and features.shape[2] == coords.shape[2] and coords.shape[1] == 3
         if not self.training and not torch.is_grad_enabled() and self.resolution in (4, 8, 16, 32):
+            pf = self.point_features.layers
+            if len(pf) == 3 and features.is_cuda:  # one conv -> norm -> Swish: joined to the voxel branch in one pass
+                from . import fused as F_
+
+                feats = features.contiguous()
+                h, st = F_.pw_conv(feats, pf[0])
+                scp, shp = norm_affine(pf[1], st, feats.shape[2], cond)
+                data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, scp, shp))
+                return data
             fused = self._voxel_branch_fused(features, coords, cond)
         else:
             v, vcoords = self.voxelization(features, coords)

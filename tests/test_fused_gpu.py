@@ -210,6 +210,10 @@ def test_voxel_major_voxelize_devoxelize(fused, B, C, N, r):
     want = fused.devoxelize_affine(dense, vcoords, r, a, b)
     got = fused.devoxelize_affine(dense.permute(0, 2, 3, 4, 1).contiguous(), vcoords, r, a, b, channels_last=True)
     assert torch.equal(got, want)
+    h, hs, hb = torch.randn(B, C, N, device="cuda"), torch.randn(B, C, device="cuda"), torch.randn(B, C, device="cuda")
+    joined = fused.devoxelize_affine(dense.permute(0, 2, 3, 4, 1).contiguous(), vcoords, r, a, b, channels_last=True,
+                                     add=(h, hs, hb))
+    assert rel_err(joined, want.double() + swish(h.double() * hs[:, :, None] + hb[:, :, None])) < 1e-5
     plain = ext.trilinear_devoxelize_forward(r, False, vcoords, dense.view(B, C, -1))[0]
     ones, zeros = torch.ones(B, C, device="cuda"), torch.zeros(B, C, device="cuda")
     assert torch.equal(fused.devoxelize_affine(dense.permute(0, 2, 3, 4, 1).contiguous(), vcoords, r, ones, zeros,
