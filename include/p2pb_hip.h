@@ -220,6 +220,14 @@ int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float 
 int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *coords, const float *feat,
                                      const float *aff_a, const float *aff_b, float *outs, void *stream);
 
+/* Set abstraction with the first 1x1 convolution applied before the grouping (linear: W[xyz[idx]-centre; f[idx]]
+ * = Z[:,idx] - Cx[:,centre], Z = W[xyz;f]+bias on the n points, Cx = W_xyz centre): out[b,c,j,k] = z[b,c,idx[b,j,k]]
+ * - cx[b,c,j] (cx may be NULL), plus the {sum, sumsq} partials f32[p2pb_group_sub_stats_floats()] = [b,nslots,c,2] of
+ * the GroupNorm that follows. Replaces grouping + concat + the (3+C)-channel GEMM of models/pvcnn.py:117-126,408. */
+size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u);
+int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx, float *out,
+                   float *stats_part, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused shared point MLPs (SharedMLP models/pvcnn.py:162-205 = k=1 Conv1d/Conv2d -> AdaGN|GroupNorm ->
  * Swish, chained; set-abstraction neighbour max :414; Pnet2Stage max-pool :923,930). Inference only.

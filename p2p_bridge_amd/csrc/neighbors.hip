@@ -123,6 +123,60 @@ extern "C" int p2pb_group_concat(int b, int c, int n, int m, int u, const float 
   return p2pb_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// First layer of a set-abstraction MLP applied BEFORE the grouping (inference): a 1x1 convolution is linear, so
+//   W [xyz[idx] - centre ; f[idx]] + bias  =  Z[:, idx] - Cx[:, centre],   Z = W [xyz ; f] + bias (N points),
+//                                                                          Cx = W_xyz centre (M centres),
+// i.e. the GEMM runs on the N points instead of the M*U grouped positions (4x .. 32x fewer) and the
+// (3+C)-channel grouped tensor of models/pvcnn.py:117-126 is never built. This kernel gathers the C1-channel
+// result, subtracts the centre term and emits the {sum, sum of squares} partials of the GroupNorm that follows
+// (one slot per half-wave = 32 positions; reduced in fixed order by gn_affine_kernel).
+//   z f32[b,c,n], cx f32[b,c,m] (or NULL), idx i32[b,m,u] -> out f32[b,c,m*u], stats f32[b, nslots, c, 2]
+// ------------------------------------------------------------------------------------------------
+template <int CC>
+__global__ __launch_bounds__(256) void group_sub_kernel(int c, int n, int m, int u, int nslots,
+                                                        const float *__restrict__ z, const float *__restrict__ cx,
+                                                        const int *__restrict__ idx, float *__restrict__ out,
+                                                        float *__restrict__ stats) {
+  const int b = blockIdx.z;
+  const int mu = m * u;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = q < mu;
+  const int id = ok ? idx[(size_t)b * mu + q] : 0;
+  const int j = ok ? q / u : 0;
+  const int lane = threadIdx.x & 63, l31 = lane & 31;
+  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
+  for (int l = c0; l < c1; ++l) {
+    float v = 0.0f;
+    if (ok) {
+      v = z[((size_t)b * c + l) * n + id];
+      if (cx) v -= cx[((size_t)b * c + l) * m + j];
+      out[((size_t)b * c + l) * mu + q] = v;
+    }
+    const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
+    if (l31 == 31) {
+      float *p = stats + (((size_t)b * nslots + slot) * c + l) * 2;
+      p[0] = s1;
+      p[1] = s2;
+    }
+  }
+}
+
+extern "C" size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u) {
+  return (size_t)b * (((size_t)m * u + 255) / 256 * 8) * c * 2;
+}
+
+extern "C" int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx,
+                              float *out, float *stats_part, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !stats_part) return P2PB_EINVAL;
+  constexpr int CC = 8;
+  const int nblk = (int)(((long)m * u + 255) / 256);
+  hipLaunchKernelGGL(group_sub_kernel<CC>, dim3(nblk, cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c, n, m, u,
+                     nblk * 8, z, cx, idx, out, stats_part);
+  return p2pb_launch_status();
+}
+
 template <int CC>
 __global__ __launch_bounds__(256) void grouping_grad_kernel(int c, int n, int mu, const float *__restrict__ gy,
                                                             const int *__restrict__ idx, float *__restrict__ gx) {

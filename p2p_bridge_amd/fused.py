@@ -287,6 +287,20 @@ def minmax_act(mm, scale, shift, swish=True, global_pool=False):
     return y
 
 
+def group_sub(z, cx, idx):
+    """z f32[B,C,N], cx f32[B,C,M] | None, idx i32[B,M,U] -> (y f32[B,C,M*U] = z[:, :, idx] - cx[:, :, :, None],
+    GroupNorm partials f32[B,nslots,C,2]): the grouped output of a set abstraction's first layer when that layer
+    was applied to the ungrouped points (csrc/neighbors.hip group_sub_kernel)"""
+    check(z, F32, "z")
+    b, c, n = z.shape
+    m, u = idx.shape[1], idx.shape[2]
+    y = torch.empty(b, c, m * u, dtype=F32, device=z.device)
+    nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
+    st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
+    call("p2pb_group_sub", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st), stream_ptr())
+    return y, st
+
+
 def affine_act(x, scale, shift, swish=True, residual=None):
     """swish(x*scale[b,c]+shift[b,c]) (+ residual), x f32[B,C,P]"""
     b, c, p = x.shape

@@ -213,8 +213,10 @@ class SharedMLP(nn.Module):
             x = x.max(dim=-1).values
         return x if residual is None else residual + x
 
-    def _run_fused(self, x, cond, reduce_max, residual):
-        """inference: every norm+Swish is folded into the next kernel's operand load (fused.py)"""
+    def _run_fused(self, x, cond, reduce_max, residual, first=None):
+        """inference: every norm+Swish is folded into the next kernel's operand load (fused.py).
+        first = (statistics partials) when x already is the raw output of layer 0's convolution (set abstraction
+        with the first layer applied before the grouping)"""
         from . import fused
 
         shape = x.shape
@@ -224,10 +226,17 @@ class SharedMLP(nn.Module):
             h = h.contiguous()
         sc = sh = None
         nl = len(self.layers) // 3
+        if first is not None:
+            sc, sh = norm_affine(self.layers[1], first, P, cond)
+            if nl == 1:
+                C = h.shape[1]
+                if reduce_max:
+                    return fused.affine_act_max(h, sc, sh, int(np.prod(shape[2:-1])), shape[-1]).view(B, C, *shape[2:-1])
+                return fused.affine_act(h, sc, sh, True, None).view(B, C, *shape[2:])
         # set abstraction: the last layer's output is only ever max-pooled over the neighbour axis, so its
         # GEMM emits per-neighbourhood {min, max} instead of the tensor (fused.pw_conv pool_u)
         pool = reduce_max and fused.pool_supported(P, shape[-1])
-        for i in range(nl):
+        for i in range(1 if first is not None else 0, nl):
             conv, norm = self.layers[3 * i], self.layers[3 * i + 1]
             if pool and i == nl - 1:
                 _, st, mm = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, pool_u=shape[-1], store=False)
@@ -371,8 +380,21 @@ class PointNetSAModule(nn.Module):
             centers, nidx = data.geo.take_sa(self.level)
             if data.time_emb is not None:
                 data.time_emb = data.time_emb[:, :, : centers.shape[-1]]
-            grouped = L._ext.group_concat(coords.contiguous(), centers, data.features.contiguous(), nidx)
-            data.features = self.mlps[0].run(grouped, data.cond, reduce_max=True)
+            mlp = self.mlps[0]
+            from . import fused
+
+            if fused.enabled(mlp, coords) and data.features is not None:
+                # the first 1x1 convolution commutes with the grouping (linear): run it on the N points, then gather
+                # its C1-channel output and subtract the centre term (csrc/neighbors.hip group_sub_kernel)
+                conv0 = mlp.layers[0]
+                z, _ = fused.pw_conv(torch.cat([coords, data.features], dim=1), conv0, stats=False)
+                cx, _ = fused.pw_conv(centers.contiguous(), conv0, stats=False, ci_lo=0, ci_hi=3, use_bias=False)
+                y, st = fused.group_sub(z, cx, nidx)
+                M, U = nidx.shape[1], nidx.shape[2]
+                data.features = mlp._run_fused(y.view(y.shape[0], y.shape[1], M, U), data.cond, True, None, first=st)
+            else:
+                grouped = L._ext.group_concat(coords.contiguous(), centers, data.features.contiguous(), nidx)
+                data.features = mlp.run(grouped, data.cond, reduce_max=True)
             data.coords = centers
             return data
         centers = L.furthest_point_sample_pvcnn(coords, self.num_centers)

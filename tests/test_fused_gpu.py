@@ -148,6 +148,32 @@ def test_pointwise_global_pool(fused, pw_math, B, ci, co, P):
         assert rel_err(got, ref) < 1e-5 and rel_err(got, want) < 1e-5
 
 
+@pytest.mark.parametrize("B,C,C1,N,M,U", [(2, 32, 32, 2048, 256, 32), (2, 64, 64, 500, 100, 16), (1, 5, 40, 300, 37, 8)])
+def test_first_layer_before_grouping(fused, B, C, C1, N, M, U):
+    """W [xyz[idx] - centre ; f[idx]] + bias == (W [xyz ; f] + bias)[idx] - W_xyz centre (models/pvcnn.py:117-126,408)"""
+    from p2p_bridge_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(N + C)
+    xyz = torch.randn(B, 3, N, device="cuda")
+    f = torch.randn(B, C, N, device="cuda")
+    cidx = torch.stack([torch.randperm(N, device="cuda")[:M] for _ in range(B)]).int()
+    centers = ext.gather_features_forward(xyz, cidx)
+    idx = torch.randint(0, N, (B, M, U), device="cuda", dtype=torch.int32)
+    conv = torch.nn.Conv2d(3 + C, C1, 1).cuda()
+    with torch.no_grad():
+        grouped = ext.group_concat(xyz, centers, f, idx)              # the (3+C)-channel grouped tensor
+        want, st_want = fused.pw_conv(grouped.view(B, 3 + C, M * U), conv, math="fp32")
+        z, _ = fused.pw_conv(torch.cat([xyz, f], 1), conv, stats=False)
+        cx, _ = fused.pw_conv(centers, conv, stats=False, ci_lo=0, ci_hi=3, use_bias=False)
+        got, st = fused.group_sub(z, cx, idx)
+        assert got.shape == (B, C1, M * U)
+        assert rel_err(got, want) < 1e-5
+        s1w, s2w = stats_of(st_want)
+        s1, s2 = stats_of(st)
+        assert rel_err(s2, s2w) < 1e-5 and (s1 - s1w).abs().max() < 1e-3 * max(1.0, s1w.abs().max().item())
+        ref = torch.nn.functional.conv2d(grouped.double(), conv.weight.double(), conv.bias.double()).view(B, C1, -1)
+        assert rel_err(got, ref) < 1e-5
+
+
 def test_pool_unsupported_shapes(fused):
     assert not fused.pool_supported(1001, 0)      # rows not 16-byte aligned
     assert not fused.pool_supported(96 * 3, 96)   # neighbourhood size not a power of two in 4..64
