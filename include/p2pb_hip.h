@@ -224,6 +224,12 @@ int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *co
  * = Z[:,idx] - Cx[:,centre], Z = W[xyz;f]+bias on the n points, Cx = W_xyz centre): out[b,c,j,k] = z[b,c,idx[b,j,k]]
  * - cx[b,c,j] (cx may be NULL), plus the {sum, sumsq} partials f32[p2pb_group_sub_stats_floats()] = [b,nslots,c,2] of
  * the GroupNorm that follows. Replaces grouping + concat + the (3+C)-channel GEMM of models/pvcnn.py:117-126,408. */
+/* Feature propagation likewise (interpolation is linear too): out[b,c,j] = sum_k w_k cz[b,c,idx[b,k,j]] + add[b,c,j]
+ * (+ bias[c]), cz = W_g g on the m coarse points, add = W_s skip + bias on the n fine ones (either may be NULL);
+ * stats_part f32[p2pb_group_sub_stats_floats(b,c,n,1)]. Replaces interpolate + concat + the first GEMM of
+ * models/pvcnn.py:457-461. */
+int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
+                               const float *add, const float *bias, float *out, float *stats_part, void *stream);
 size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u);
 int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx, float *out,
                    float *stats_part, void *stream);

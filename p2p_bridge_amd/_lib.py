@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libp2pb_hip.so")
 SYMBOLS = [
     "p2pb_version", "p2pb_target_arch", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
     "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_trilinear_devoxelize_forward",
-    "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_group_sub_stats_floats",
+    "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats",
     "p2pb_gather_features_forward", "p2pb_gather_features_backward", "p2pb_furthest_point_sampling",
     "p2pb_three_nn_interpolate_forward", "p2pb_three_nn_interpolate_backward", "p2pb_three_nn",
     "p2pb_three_interpolate", "p2pb_chamfer_forward",

@@ -351,6 +351,60 @@ extern "C" int p2pb_three_interpolate(int b, int c, int m, int n, const float *c
   return p2pb_launch_status();
 }
 
+// Feature propagation with the first 1x1 convolution applied before the interpolation (inference): interpolation and
+// convolution are both linear, so W [interp(g) ; skip] + bias = interp(W_g g) + (W_s skip + bias): the GEMM on the
+// interpolated channels runs on the m coarse points instead of the n fine ones and the concatenated tensor of
+// models/pvcnn.py:457-461 is never built.  out[b,c,j] = sum_k w_k * cz[b,c,idx_k] + add[b,c,j] (+ bias[c]), plus the
+// {sum, sum of squares} partials of the GroupNorm that follows (one slot per half-wave, as group_sub_kernel).
+template <int CC>
+__global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int n, int nslots,
+                                                               const float *__restrict__ cz,
+                                                               const int *__restrict__ indices,
+                                                               const float *__restrict__ weights,
+                                                               const float *__restrict__ add,
+                                                               const float *__restrict__ bias, float *__restrict__ out,
+                                                               float *__restrict__ stats) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = j < n;
+  const int jj = ok ? j : 0;
+  const int *id = indices + (size_t)b * 3 * n;
+  const float *w = weights + (size_t)b * 3 * n;
+  const int a0 = id[jj], a1 = id[jj + n], a2 = id[jj + 2 * n];
+  const float w0 = w[jj], w1 = w[jj + n], w2 = w[jj + 2 * n];
+  const int lane = threadIdx.x & 63, l31 = lane & 31;
+  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
+  for (int l = c0; l < c1; ++l) {
+    const float *f = cz + ((size_t)b * c + l) * m;
+    float v = 0.0f;
+    if (ok) {
+      v = __fmaf_rn(f[a2], w2, __fmaf_rn(f[a1], w1, f[a0] * w0));
+      if (add) v += add[((size_t)b * c + l) * n + j];
+      if (bias) v += bias[l];
+      out[((size_t)b * c + l) * n + j] = v;
+    }
+    const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
+    if (l31 == 31) {
+      float *p = stats + (((size_t)b * nslots + slot) * c + l) * 2;
+      p[0] = s1;
+      p[1] = s2;
+    }
+  }
+}
+
+// stats_part: f32[p2pb_group_sub_stats_floats(b, c, n, 1)]
+extern "C" int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
+                                          const float *add, const float *bias, float *out, float *stats_part,
+                                          void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || !stats_part) return P2PB_EINVAL;
+  constexpr int CC = 16;
+  const int nblk = (n + 255) / 256;
+  hipLaunchKernelGGL(three_interp_add_kernel<CC>, dim3(nblk, cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c, m, n,
+                     nblk * 8, cz, idx, w, add, bias, out, stats_part);
+  return p2pb_launch_status();
+}
+
 template <int CC>
 __global__ __launch_bounds__(256) void three_interp_grad_kernel(int c, int n, int m, const float *__restrict__ gy,
                                                                 const int *__restrict__ indices,

@@ -301,6 +301,20 @@ def group_sub(z, cx, idx):
     return y, st
 
 
+def interp_add(cz, idx, w, add=None, bias=None):
+    """cz f32[B,C,M], idx i32[B,3,N], w f32[B,3,N], add f32[B,C,N] | None, bias f32[C] | None ->
+    (y f32[B,C,N] = sum_k w_k cz[:, :, idx_k] + add (+ bias), GroupNorm partials f32[B,nslots,C,2])"""
+    check(cz, F32, "cz")
+    b, c, m = cz.shape
+    n = idx.shape[2]
+    y = torch.empty(b, c, n, dtype=F32, device=cz.device)
+    nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(n), _i(1))
+    st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=cz.device)
+    call("p2pb_three_interpolate_add", _i(b), _i(c), _i(m), _i(n), ptr(cz), ptr(idx), ptr(w), ptr(add), ptr(bias),
+         ptr(y), ptr(st), stream_ptr())
+    return y, st
+
+
 def affine_act(x, scale, shift, swish=True, residual=None):
     """swish(x*scale[b,c]+shift[b,c]) (+ residual), x f32[B,C,P]"""
     b, c, p = x.shape

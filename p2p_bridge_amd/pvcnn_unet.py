@@ -417,6 +417,25 @@ class PointNetFPModule(nn.Module):
     def forward(self, data: PVCData) -> PVCData:
         if data.geo is not None:
             idx, w = data.geo.take_fp(self.level)
+            from . import fused
+
+            if fused.enabled(self.mlp, data.lower_features):
+                # interpolation and the first 1x1 convolution are both linear: W [interp(g) ; skip] + bias =
+                # interp(W_g g) + (W_s skip + bias); the concat is never built (csrc/neighbors.hip)
+                conv0 = self.mlp.layers[0]
+                g = data.lower_features.contiguous()
+                cg = g.shape[1]
+                cz, _ = fused.pw_conv(g, conv0, stats=False, ci_lo=0, ci_hi=cg, use_bias=False)
+                skip = data.features
+                if skip is not None:
+                    ys, _ = fused.pw_conv(skip.contiguous(), conv0, stats=False, ci_lo=cg, ci_hi=cg + skip.shape[1])
+                    y, st = fused.interp_add(cz, idx, w, add=ys)
+                else:
+                    y, st = fused.interp_add(cz, idx, w, bias=conv0.bias)
+                if data.time_emb is not None:
+                    data.time_emb = data.time_emb[:, :, 0:1].expand(-1, -1, data.coords.shape[-1])
+                data.features = self.mlp._run_fused(y, data.cond, False, None, first=st)
+                return data
             x = L.three_interpolate(data.lower_features.contiguous(), idx, w)
         else:
             x = L.nearest_neighbor_interpolate(data.coords, data.lower_coords, data.lower_features)

@@ -174,6 +174,33 @@ def test_first_layer_before_grouping(fused, B, C, C1, N, M, U):
         assert rel_err(got, ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,Cg,Cs,C1,M,N", [(2, 128, 64, 128, 256, 2048), (2, 40, 0, 24, 50, 333), (1, 256, 128, 256, 64, 500)])
+def test_first_layer_before_interpolation(fused, B, Cg, Cs, C1, M, N):
+    """W [interp(g) ; skip] + bias == interp(W_g g) + W_s skip + bias (models/pvcnn.py:457-461)"""
+    from p2p_bridge_amd import layers as L
+    torch.manual_seed(N + Cg)
+    g = torch.randn(B, Cg, M, device="cuda")
+    skip = torch.randn(B, Cs, N, device="cuda") if Cs else None
+    idx = torch.randint(0, M, (B, 3, N), device="cuda", dtype=torch.int32)
+    w = torch.rand(B, 3, N, device="cuda")
+    w = w / w.sum(1, keepdim=True)
+    conv = torch.nn.Conv1d(Cg + Cs, C1, 1).cuda()
+    with torch.no_grad():
+        x = L.three_interpolate(g, idx, w)
+        if skip is not None:
+            x = torch.cat([x, skip], 1)
+        ref = torch.nn.functional.conv1d(x.double(), conv.weight.double(), conv.bias.double())
+        cz, _ = fused.pw_conv(g, conv, stats=False, ci_lo=0, ci_hi=Cg, use_bias=False)
+        if skip is not None:
+            ys, _ = fused.pw_conv(skip, conv, stats=False, ci_lo=Cg, ci_hi=Cg + Cs)
+            y, st = fused.interp_add(cz, idx, w, add=ys)
+        else:
+            y, st = fused.interp_add(cz, idx, w, bias=conv.bias)
+        assert rel_err(y, ref) < 1e-5
+        s1, s2 = stats_of(st)
+        assert rel_err(s2, (ref * ref).sum(2)) < 1e-5
+
+
 def test_pool_unsupported_shapes(fused):
     assert not fused.pool_supported(1001, 0)      # rows not 16-byte aligned
     assert not fused.pool_supported(96 * 3, 96)   # neighbourhood size not a power of two in 4..64
