@@ -229,10 +229,11 @@ int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *co
  * stats_part f32[p2pb_group_sub_stats_floats(b,c,n,1)]. Replaces interpolate + concat + the first GEMM of
  * models/pvcnn.py:457-461. */
 int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
-                               const float *add, const float *bias, float *out, float *stats_part, void *stream);
+                               const float *add, const float *bias, float *out, float *stats_part,
+                               float *ws /* f32[b*m*c] */, void *stream);
 size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u);
 int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx, float *out,
-                   float *stats_part, void *stream);
+                   float *stats_part, float *ws /* f32[b*(n+m)*c] */, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused shared point MLPs (SharedMLP models/pvcnn.py:162-205 = k=1 Conv1d/Conv2d -> AdaGN|GroupNorm ->

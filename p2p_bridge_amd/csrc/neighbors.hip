@@ -133,47 +133,94 @@ extern "C" int p2pb_group_concat(int b, int c, int n, int m, int u, const float 
 // (one slot per half-wave = 32 positions; reduced in fixed order by gn_affine_kernel).
 //   z f32[b,c,n], cx f32[b,c,m] (or NULL), idx i32[b,m,u] -> out f32[b,c,m*u], stats f32[b, nslots, c, 2]
 // ------------------------------------------------------------------------------------------------
-template <int CC>
+// [b, c, n] -> [b, n, c] (32 x 32 LDS tiles)
+__global__ __launch_bounds__(256) void nb_transpose_kernel(int c, int n, const float *__restrict__ in,
+                                                           float *__restrict__ out) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float *src = in + (size_t)b * c * n;
+  float *dst = out + (size_t)b * c * n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = c0 + ty + 8 * k, nn = n0 + tx;
+    t[ty + 8 * k][tx] = (cc < c && nn < n) ? src[(size_t)cc * n + nn] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int nn = n0 + ty + 8 * k, cc = c0 + tx;
+    if (cc < c && nn < n) dst[(size_t)nn * c + cc] = t[tx][ty + 8 * k];
+  }
+}
+
+// Gathers run on POINT-MAJOR copies (zt f32[b,n,c], cxt f32[b,m,c]): lane = channel reads one contiguous row per
+// neighbour (a channel-major gather touches 4 bytes per 64-byte line), 64 positions per workgroup go through an LDS
+// transpose so the channel-major output is written in 256-byte runs; a wave then owns whole channel rows of the
+// tile, and the statistics are two half-wave sums per row (slot = 32 positions).
 __global__ __launch_bounds__(256) void group_sub_kernel(int c, int n, int m, int u, int nslots,
-                                                        const float *__restrict__ z, const float *__restrict__ cx,
+                                                        const float *__restrict__ zt, const float *__restrict__ cxt,
                                                         const int *__restrict__ idx, float *__restrict__ out,
                                                         float *__restrict__ stats) {
-  const int b = blockIdx.z;
+  __shared__ float tile[64][65];  // [channel][position]
+  const int b = blockIdx.z, p0 = blockIdx.x * 64, t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
   const int mu = m * u;
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = q < mu;
-  const int id = ok ? idx[(size_t)b * mu + q] : 0;
-  const int j = ok ? q / u : 0;
-  const int lane = threadIdx.x & 63, l31 = lane & 31;
-  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
-  for (int l = c0; l < c1; ++l) {
-    float v = 0.0f;
-    if (ok) {
-      v = z[((size_t)b * c + l) * n + id];
-      if (cx) v -= cx[((size_t)b * c + l) * m + j];
-      out[((size_t)b * c + l) * mu + q] = v;
+  // the wave's 16 neighbour indices (and centre rows) are fetched once, by lanes 0..15
+  const int qmine = p0 + wave * 16 + (lane & 15);
+  const int id_mine = qmine < mu ? idx[(size_t)b * mu + qmine] : -1;
+  // narrow layers (c <= 32) gather two positions per step, one per half-wave
+  const int cpl = c <= 32 ? 32 : 64, pps = 64 / cpl;
+  const int sub = lane / cpl, chl = lane % cpl;
+  {
+    const int c0 = blockIdx.y * cpl;  // one channel chunk per workgroup (more workgroups on the small levels)
+    const int ch = c0 + chl;
+#pragma unroll 4
+    for (int it = 0; it < 16 / pps; ++it) {
+      const int pl = wave * 16 + it * pps + sub;
+      const int id = __shfl(id_mine, it * pps + sub);
+      float v = 0.0f;
+      if (id >= 0 && ch < c) {
+        v = zt[((size_t)b * n + id) * c + ch];
+        if (cxt) v -= cxt[((size_t)b * m + (p0 + pl) / u) * c + ch];
+      }
+      tile[chl][pl] = v;
     }
-    const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
-    if (l31 == 31) {
-      float *p = stats + (((size_t)b * nslots + slot) * c + l) * 2;
-      p[0] = s1;
-      p[1] = s2;
+    __syncthreads();
+    const int pt = lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int cr = wave + 4 * k;
+      const float v = tile[cr][pt];  // zero outside the tensor: statistics unaffected
+      if (cr < cpl && c0 + cr < c) {
+        if (p0 + pt < mu) out[((size_t)b * c + c0 + cr) * mu + p0 + pt] = v;
+        const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
+        if ((lane & 31) == 31) {
+          float *p = stats + (((size_t)b * nslots + blockIdx.x * 2 + (lane >> 5)) * c + c0 + cr) * 2;
+          p[0] = s1;
+          p[1] = s2;
+        }
+      }
     }
+    __syncthreads();
   }
 }
 
 extern "C" size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u) {
-  return (size_t)b * (((size_t)m * u + 255) / 256 * 8) * c * 2;
+  return (size_t)b * (((size_t)m * u + 63) / 64 * 2) * c * 2;
 }
 
+// ws: f32[b*(n+m)*c] scratch for the point-major copies
 extern "C" int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx,
-                              float *out, float *stats_part, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !stats_part) return P2PB_EINVAL;
-  constexpr int CC = 8;
-  const int nblk = (int)(((long)m * u + 255) / 256);
-  hipLaunchKernelGGL(group_sub_kernel<CC>, dim3(nblk, cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c, n, m, u,
-                     nblk * 8, z, cx, idx, out, stats_part);
+                              float *out, float *stats_part, float *ws, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !stats_part || !ws) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float *zt = ws, *cxt = cx ? ws + (size_t)b * n * c : nullptr;
+  hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, z, zt);
+  if (cx) hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(m, 32), cdiv(c, 32), b), dim3(256), 0, s, c, m, cx, cxt);
+  const int nblk = (int)(((long)m * u + 63) / 64);
+  hipLaunchKernelGGL(group_sub_kernel, dim3(nblk, cdiv(c, c <= 32 ? 32 : 64), b), dim3(256), 0, s, c, n, m, u, nblk * 2,
+                     zt, cxt, idx, out, stats_part);
   return p2pb_launch_status();
 }
 
@@ -356,52 +403,74 @@ extern "C" int p2pb_three_interpolate(int b, int c, int m, int n, const float *c
 // interpolated channels runs on the m coarse points instead of the n fine ones and the concatenated tensor of
 // models/pvcnn.py:457-461 is never built.  out[b,c,j] = sum_k w_k * cz[b,c,idx_k] + add[b,c,j] (+ bias[c]), plus the
 // {sum, sum of squares} partials of the GroupNorm that follows (one slot per half-wave, as group_sub_kernel).
-template <int CC>
 __global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int n, int nslots,
-                                                               const float *__restrict__ cz,
+                                                               const float *__restrict__ czt,
                                                                const int *__restrict__ indices,
                                                                const float *__restrict__ weights,
                                                                const float *__restrict__ add,
                                                                const float *__restrict__ bias, float *__restrict__ out,
                                                                float *__restrict__ stats) {
-  const int b = blockIdx.z;
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  const bool ok = j < n;
-  const int jj = ok ? j : 0;
-  const int *id = indices + (size_t)b * 3 * n;
-  const float *w = weights + (size_t)b * 3 * n;
-  const int a0 = id[jj], a1 = id[jj + n], a2 = id[jj + 2 * n];
-  const float w0 = w[jj], w1 = w[jj + n], w2 = w[jj + 2 * n];
-  const int lane = threadIdx.x & 63, l31 = lane & 31;
-  const int slot = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
-  const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
-  for (int l = c0; l < c1; ++l) {
-    const float *f = cz + ((size_t)b * c + l) * m;
-    float v = 0.0f;
-    if (ok) {
-      v = __fmaf_rn(f[a2], w2, __fmaf_rn(f[a1], w1, f[a0] * w0));
-      if (add) v += add[((size_t)b * c + l) * n + j];
-      if (bias) v += bias[l];
-      out[((size_t)b * c + l) * n + j] = v;
+  __shared__ float tile[64][65];  // [channel][position]
+  __shared__ int sid[64][3];
+  __shared__ float sw[64][3];
+  const int b = blockIdx.z, p0 = blockIdx.x * 64, t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  if (t < 64) {
+    const int j = min(p0 + t, n - 1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      sid[t][k] = indices[((size_t)b * 3 + k) * n + j];
+      sw[t][k] = weights[((size_t)b * 3 + k) * n + j];
     }
-    const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
-    if (l31 == 31) {
-      float *p = stats + (((size_t)b * nslots + slot) * c + l) * 2;
-      p[0] = s1;
-      p[1] = s2;
+  }
+  __syncthreads();
+  {
+    const int c0 = blockIdx.y * 64;  // one 64-channel chunk per workgroup
+    const int ch = c0 + lane;
+    if (ch < c) {
+      const float *f = czt + (size_t)b * m * c + ch;  // point-major coarse features: one contiguous row per neighbour
+#pragma unroll 4
+      for (int pl = wave * 16; pl < wave * 16 + 16; ++pl)
+        tile[lane][pl] = __fmaf_rn(f[(size_t)sid[pl][2] * c], sw[pl][2],
+                                   __fmaf_rn(f[(size_t)sid[pl][1] * c], sw[pl][1], f[(size_t)sid[pl][0] * c] * sw[pl][0]));
     }
+    __syncthreads();
+    const int pt = lane;
+    const bool pok = p0 + pt < n;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int cr = wave + 4 * k;
+      if (c0 + cr < c) {
+        float v = 0.0f;
+        if (pok) {
+          const size_t o = ((size_t)b * c + c0 + cr) * n + p0 + pt;
+          v = tile[cr][pt];
+          if (add) v += add[o];
+          if (bias) v += bias[c0 + cr];
+          out[o] = v;
+        }
+        const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
+        if ((lane & 31) == 31) {
+          float *p = stats + (((size_t)b * nslots + blockIdx.x * 2 + (lane >> 5)) * c + c0 + cr) * 2;
+          p[0] = s1;
+          p[1] = s2;
+        }
+      }
+    }
+    __syncthreads();
   }
 }
 
-// stats_part: f32[p2pb_group_sub_stats_floats(b, c, n, 1)]
+// stats_part: f32[p2pb_group_sub_stats_floats(b, c, n, 1)]; ws: f32[b*m*c] scratch (point-major copy of cz)
 extern "C" int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
                                           const float *add, const float *bias, float *out, float *stats_part,
-                                          void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || !stats_part) return P2PB_EINVAL;
-  constexpr int CC = 16;
-  const int nblk = (n + 255) / 256;
-  hipLaunchKernelGGL(three_interp_add_kernel<CC>, dim3(nblk, cdiv(c, CC), b), dim3(256), 0, (hipStream_t)stream, c, m, n,
-                     nblk * 8, cz, idx, w, add, bias, out, stats_part);
+                                          float *ws, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || !stats_part || !ws) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(m, 32), cdiv(c, 32), b), dim3(256), 0, s, c, m, cz, ws);
+  const int nblk = (n + 63) / 64;
+  hipLaunchKernelGGL(three_interp_add_kernel, dim3(nblk, cdiv(c, 64), b), dim3(256), 0, s, c, m, n, nblk * 2, ws, idx, w,
+                     add, bias, out, stats_part);
   return p2pb_launch_status();
 }
 

@@ -794,9 +794,39 @@ __global__ __launch_bounds__(256) void affine_act_kernel(int c, int P, const flo
   }
 }
 
+// 16-byte form (rows of whole, aligned quads): a pure streaming pass, HBM-bound
+__global__ __launch_bounds__(256) void affine_act4_kernel(int c, int P4, const f32x4 *__restrict__ x,
+                                                          const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int swish,
+                                                          const f32x4 *__restrict__ residual, f32x4 *__restrict__ y) {
+  const int bc = blockIdx.y;
+  const float sc = scale[bc], sh = shift[bc];
+  const f32x4 *xr = x + (size_t)bc * P4;
+  const f32x4 *rr = residual ? residual + (size_t)bc * P4 : nullptr;
+  f32x4 *yr = y + (size_t)bc * P4;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < P4; p += gridDim.x * 256) {
+    f32x4 v = xr[p];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = v[i] * sc + sh;
+      if (swish) t = swishf(t);
+      v[i] = t;
+    }
+    if (rr) v += rr[p];
+    yr[p] = v;
+  }
+}
+
 extern "C" int p2pb_affine_act(int b, int c, int npos, const float *x, const float *scale, const float *shift,
                                int swish, const float *residual, float *y, void *stream) {
   if (b <= 0 || c <= 0 || npos <= 0) return P2PB_EINVAL;
+  if (npos % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) {
+    const int p4 = npos / 4;
+    const unsigned gx = (unsigned)((p4 + 255) / 256 > 64 ? 64 : (p4 + 255) / 256);
+    hipLaunchKernelGGL(affine_act4_kernel, dim3(gx, b * c), dim3(256), 0, (hipStream_t)stream, c, p4, (const f32x4 *)x,
+                       scale, shift, swish, (const f32x4 *)residual, (f32x4 *)y);
+    return p2pb_launch_status();
+  }
   const unsigned gx = (unsigned)((npos + 255) / 256 > 64 ? 64 : (npos + 255) / 256);
   hipLaunchKernelGGL(affine_act_kernel, dim3(gx, b * c), dim3(256), 0, (hipStream_t)stream, c, npos, x, scale, shift,
                      swish, residual, y);

@@ -463,10 +463,12 @@ __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, cons
   }
   __syncthreads();
   const float *g = grid + (size_t)b * r3 * c;
-  for (int c0 = 0; c0 < c; c0 += 64) {
+  {
+    const int c0 = blockIdx.y * 64;  // one 64-channel chunk per workgroup
     const int ch = c0 + lane;
     if (ch < c) {
       const float a = aff_a ? aff_a[(size_t)b * c + ch] : 1.0f, bb = aff_b ? aff_b[(size_t)b * c + ch] : 0.0f;
+#pragma unroll 2
       for (int pl = wave * 16; pl < wave * 16 + 16; ++pl) {
         float fv[8];
 #pragma unroll
@@ -508,7 +510,7 @@ extern "C" int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, c
                                                    void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || ((aff_a == nullptr) != (aff_b == nullptr))) return P2PB_EINVAL;
   if (add && (!add_scale || !add_shift)) return P2PB_EINVAL;
-  hipLaunchKernelGGL(devox_cl_kernel, dim3(cdiv(n, 64), 1, b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
+  hipLaunchKernelGGL(devox_cl_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
                      aff_a, aff_b, add, add_scale, add_shift, outs);
   return p2pb_launch_status();
 }

@@ -297,7 +297,9 @@ def group_sub(z, cx, idx):
     y = torch.empty(b, c, m * u, dtype=F32, device=z.device)
     nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
     st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
-    call("p2pb_group_sub", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st), stream_ptr())
+    ws = torch.empty(b * (n + m) * c, dtype=F32, device=z.device)  # point-major copies of z and cx
+    call("p2pb_group_sub", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st), ptr(ws),
+         stream_ptr())
     return y, st
 
 
@@ -310,8 +312,9 @@ def interp_add(cz, idx, w, add=None, bias=None):
     y = torch.empty(b, c, n, dtype=F32, device=cz.device)
     nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(n), _i(1))
     st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=cz.device)
+    ws = torch.empty(b * m * c, dtype=F32, device=cz.device)  # point-major copy of cz
     call("p2pb_three_interpolate_add", _i(b), _i(c), _i(m), _i(n), ptr(cz), ptr(idx), ptr(w), ptr(add), ptr(bias),
-         ptr(y), ptr(st), stream_ptr())
+         ptr(y), ptr(st), ptr(ws), stream_ptr())
     return y, st
 
 
