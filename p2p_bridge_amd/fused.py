@@ -29,9 +29,8 @@ def conv_math() -> str:
 
 
 def use_split(cout: int, math=None) -> bool:
-    """the split kernel pays off with 64 output channels per workgroup (two M-tiles share every B fragment);
-    32-channel layers (the first PVConv) stay on the exact-fp32 MFMA kernel, which is faster there"""
-    return (math or conv_math()) == "bf16x6" and cout > 32
+    """bf16x6 split-operand kernel unless P2PB_CONV_MATH=fp32 (or math="fp32") asks for the exact-fp32 MFMA one"""
+    return (math or conv_math()) == "bf16x6"
 
 
 def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
@@ -67,7 +66,7 @@ def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in
     check(x, F32, "x")
     b, ci, r = (x.shape[0], x.shape[4], x.shape[1]) if channels_last else (x.shape[0], x.shape[1], x.shape[2])
     co = conv.out_channels
-    split = force_split or use_split(co, math)  # force_split: the split kernel's 32-channel variant (tests)
+    split = force_split or use_split(co, math)
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
     st = None

@@ -335,7 +335,8 @@ def test_conv3d_split_is_fp32_faithful(fused, B, ci, co, r):
         assert max6 < 1e-5  # two orders inside the 1e-4 budget; plain bf16 would sit at ~4e-3
 
 
-def test_conv3d_sparse_lists_match_dense(fused):
+@pytest.mark.parametrize("cout", [48, 32])
+def test_conv3d_sparse_lists_match_dense(fused, cout):
     """list-driven sparse form == dense form on a surface-like occupancy, both arithmetic modes"""
     from p2p_bridge_amd import pointnet2_batch_cuda as ext
     torch.manual_seed(9)
@@ -345,7 +346,7 @@ def test_conv3d_sparse_lists_match_dense(fused):
     f = torch.randn(B, C, N, device="cuda")
     grid, _, cnt = ext.avg_voxelize_forward(f, vox, r)
     grid = grid.view(B, C, r, r, r)
-    conv = torch.nn.Conv3d(C, 48, 3, padding=1).cuda()
+    conv = torch.nn.Conv3d(C, cout, 3, padding=1).cuda()
     lists, counts = fused.brick_lists(cnt, r)
     assert 0 < counts[0].item() < B * 128
     with torch.no_grad():
