@@ -62,5 +62,57 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned 
   p2 = __builtin_bit_cast(unsigned, q2);
 }
 
+// ---- 32 rows x 32 lanes -> one row total per lane ("reduce-scatter" over the half-wave) ----
+// A GEMM epilogue holds, per lane, one value of each of 32 output-channel rows and needs every row's reduction
+// over the 32 lanes of its half-wave. Reducing the rows one by one costs 5 DPP steps per row (160 per statistic);
+// this network halves the register count at every level instead -- v_permlane16_swap_b32 pairs lanes L, L^16 and
+// merges two registers in 2 instructions, the four in-row levels (row_ror:8, half mirror, quad perms) take 3 --
+// 77 instructions per statistic, and lane l ends with the total of row (l & 31). Fixed order: deterministic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_full(float v) {
+  const int i = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ void permlane16_swap(float &a, float &b) {
+  // inline asm: the builtin's second result is mis-assigned by this compiler (both results alias one register)
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+struct RowAdd {
+  __device__ static float f(float a, float b) { return a + b; }
+};
+struct RowMin {
+  __device__ static float f(float a, float b) { return fminf(a, b); }
+};
+struct RowMax {
+  __device__ static float f(float a, float b) { return fmaxf(a, b); }
+};
+template <class Op>
+__device__ __forceinline__ float rowreduce32(float (&v)[32]) {
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {  // lanes L, L^16: the odd 16-lane rows keep v[i + 16]
+    float a = v[i], b = v[i + 16];
+    permlane16_swap(a, b);
+    v[i] = Op::f(a, b);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // L, L^8 (row_ror:8)
+    const float x = Op::f(v[i], dpp_full<0x128>(v[i])), y = Op::f(v[i + 8], dpp_full<0x128>(v[i + 8]));
+    v[i] = (lane & 8) ? y : x;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // L, 7-L inside each group of 8 (row_half_mirror)
+    const float x = Op::f(v[i], dpp_full<0x141>(v[i])), y = Op::f(v[i + 4], dpp_full<0x141>(v[i + 4]));
+    v[i] = (lane & 4) ? y : x;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // L, L^2 (quad_perm [2,3,0,1])
+    const float x = Op::f(v[i], dpp_full<0x4E>(v[i])), y = Op::f(v[i + 2], dpp_full<0x4E>(v[i + 2]));
+    v[i] = (lane & 2) ? y : x;
+  }
+  const float x = Op::f(v[0], dpp_full<0xB1>(v[0])), y = Op::f(v[1], dpp_full<0xB1>(v[1]));  // L, L^1
+  return (lane & 1) ? y : x;
+}
+
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);

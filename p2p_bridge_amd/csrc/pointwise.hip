@@ -513,12 +513,14 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
   }
   if (!mact) return;
 
-  // ---- epilogue: bias, 8-byte stores, GroupNorm partials per 64-position slot, optional {min, max}
+  // ---- epilogue: bias, 8-byte stores, GroupNorm partials per 64-position slot, optional {min, max}.
+  // Row index of the reductions: idx = m*16 + r; rowreduce32 leaves row (l31) in lane l31.
   float *outb = out ? out + (size_t)b * cout * P : nullptr;
   const int p = pblk + 2 * (wn * 32 + l31);
   const bool pok = p < P;
   const int slot = blockIdx.x * 2 + wn;
   const int pool_g = pool_u ? pool_u / 2 : 32;
+  float s1v[32], s2v[32], mnv[32], mxv[32];
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -531,44 +533,49 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
         if (bias_b) bv += bias_b[(size_t)b * cout + co];
       }
       const f32x2 v = {acc[m][0][r] + bv, acc[m][1][r] + bv};
-      float s1 = 0.0f, s2 = 0.0f;
-      if (cok && pok) {
-        if (outb) *(f32x2 *)(outb + (size_t)co * P + p) = v;
-        s1 = v[0] + v[1];
-        s2 = v[0] * v[0] + v[1] * v[1];
-      }
+      const bool ok = cok && pok;
+      if (ok && outb) *(f32x2 *)(outb + (size_t)co * P + p) = v;
+      s1v[m * 16 + r] = ok ? v[0] + v[1] : 0.0f;
+      s2v[m * 16 + r] = ok ? v[0] * v[0] + v[1] * v[1] : 0.0f;
       if (POOL) {
         float mn = pok ? fminf(v[0], v[1]) : INFINITY, mx = pok ? fmaxf(v[0], v[1]) : -INFINITY;
-        group_minmax(mn, mx, pool_g);
-        if (cok) {
-          if (pool_u == 0) {
-            if (l31 == 31) {
-              float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 2 + wn) * cout + co) * 2;
-              q[0] = mn;
-              q[1] = mx;
-            }
-          } else if (pok && (pool_g == 32 ? l31 == 31 : (l31 & (pool_g - 1)) == 0)) {
+        if (pool_u == 0) {
+          mnv[m * 16 + r] = mn;
+          mxv[m * 16 + r] = mx;
+        } else {
+          group_minmax(mn, mx, pool_g);
+          if (cok && pok && (pool_g == 32 ? l31 == 31 : (l31 & (pool_g - 1)) == 0)) {
             float *q = mm_out + (((size_t)b * cout + co) * (P / pool_u) + p / pool_u) * 2;
             q[0] = mn;
             q[1] = mx;
           }
         }
       }
-      if (stats_part) {
-        s1 = halfwave_sum_to_last(s1);
-        s2 = halfwave_sum_to_last(s2);
-        if (l31 == 31 && cok) {
-          float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
-          q[0] = s1;
-          q[1] = s2;
-          if (blockIdx.x == gridDim.x - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
-            for (int sl = slot + 1; sl < nslots; ++sl) {
-              float *z = stats_part + (((size_t)b * nslots + sl) * cout + co) * 2;
-              z[0] = 0.0f;
-              z[1] = 0.0f;
-            }
+    }
+  }
+  // this lane's row after the reductions
+  const int rm = l31 >> 4, rr = l31 & 15;
+  const int rco = co0 + wm * 64 + rm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * khalf;
+  if (stats_part) {
+    const float s1 = rowreduce32<RowAdd>(s1v), s2 = rowreduce32<RowAdd>(s2v);
+    if (rco < cout) {
+      float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
+      q[0] = s1;
+      q[1] = s2;
+      if (blockIdx.x == gridDim.x - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
+        for (int sl = slot + 1; sl < nslots; ++sl) {
+          float *z = stats_part + (((size_t)b * nslots + sl) * cout + rco) * 2;
+          z[0] = 0.0f;
+          z[1] = 0.0f;
         }
-      }
+    }
+  }
+  if (POOL && pool_u == 0) {
+    const float mn = rowreduce32<RowMin>(mnv), mx = rowreduce32<RowMax>(mxv);
+    if (rco < cout) {
+      float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 2 + wn) * cout + rco) * 2;
+      q[0] = mn;
+      q[1] = mx;
     }
   }
 }
