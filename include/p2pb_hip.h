@@ -213,6 +213,11 @@ int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const flo
  * outs += swish(add*add_scale[b,c] + add_shift[b,c]), PVConv's point branch (models/pvcnn.py:286,325). */
 int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind, int *cnt,
                                  float *out, float *feat_t, void *ws, void *stream);
+/* the same in two halves: the coordinate-only sort (run once per (level, resolution), on the geometry stream) and
+ * the feature gather that consumes its cnt / ws */
+int p2pb_voxel_sort(int b, int n, int r, const int *coords, int *ind, int *cnt, void *ws, void *stream);
+int p2pb_avg_voxelize_cl_gather(int b, int c, int n, int r, const float *feat, const int *cnt, const void *ws,
+                                float *out, float *feat_t, void *stream);
 int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float *coords, const float *grid,
                                         const float *aff_a, const float *aff_b, const float *add /* f32[b,c,n] or NULL */,
                                         const float *add_scale, const float *add_shift, float *outs, void *stream);

@@ -286,10 +286,11 @@ __global__ __launch_bounds__(256) void vox_gather_cl_kernel(int c, int n, int r3
   }
 }
 
-// out f32[b, r^3, c] (voxel-major); feat_t f32[b, n, c] scratch; everything else as p2pb_avg_voxelize_forward
-extern "C" int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind,
-                                            int *cnt, float *out, float *feat_t, void *ws, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || !ws || !feat_t) return P2PB_EINVAL;
+// The coordinate-only half of the voxelisation (occupancy counts + per-voxel sorted point lists): it depends on
+// the voxel coordinates alone, so the sampler runs it once per (level, resolution) on the geometry stream and every
+// PVConv of that level reuses it. ws: p2pb_avg_voxelize_ws_bytes(b,n,r) bytes, consumed by ..._cl_gather.
+extern "C" int p2pb_voxel_sort(int b, int n, int r, const int *coords, int *ind, int *cnt, void *ws, void *stream) {
+  if (b <= 0 || n <= 0 || r <= 0 || !ws) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int r3 = r * r * r;
   int *cur = (int *)ws;
@@ -305,12 +306,35 @@ extern "C" int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const in
   const int maxocc = n < r3 ? n : r3;
   hipLaunchKernelGGL(vox_sort_kernel, dim3(cdiv(maxocc, 4), b), dim3(256), 0, s, n, r3, cnt, cur, occ, nocc, list,
                      slist);
+  return p2pb_launch_status();
+}
+
+// The feature half: out f32[b, r^3, c] (voxel-major) from feat f32[b,c,n] and the sort of p2pb_voxel_sort
+// (cnt, ws); feat_t f32[b, n, c] scratch
+extern "C" int p2pb_avg_voxelize_cl_gather(int b, int c, int n, int r, const float *feat, const int *cnt, const void *ws,
+                                           float *out, float *feat_t, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || !ws || !feat_t) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int r3 = r * r * r;
+  const int *cur = (const int *)ws;
+  const int *slist = cur + (size_t)b * r3 + (size_t)b * n;
+  const int *occ = slist + (size_t)b * n;
+  const int *nocc = occ + (size_t)b * n;
+  const int maxocc = n < r3 ? n : r3;
   hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, feat, feat_t);
-  e = p2pb_zero_async(out, sizeof(float) * (size_t)b * c * r3, s);
+  int e = p2pb_zero_async(out, sizeof(float) * (size_t)b * c * r3, s);
   if (e != 0) return e;
   hipLaunchKernelGGL(vox_gather_cl_kernel, dim3(cdiv(maxocc, 4), b), dim3(256), 0, s, c, n, r3, cnt, cur, occ, nocc,
                      slist, feat_t, out);
   return p2pb_launch_status();
+}
+
+// both halves: out f32[b, r^3, c] (voxel-major); feat_t f32[b, n, c] scratch; everything else as p2pb_avg_voxelize_forward
+extern "C" int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const int *coords, const float *feat, int *ind,
+                                            int *cnt, float *out, float *feat_t, void *ws, void *stream) {
+  const int e = p2pb_voxel_sort(b, n, r, coords, ind, cnt, ws, stream);
+  if (e != 0) return e;
+  return p2pb_avg_voxelize_cl_gather(b, c, n, r, feat, cnt, ws, out, feat_t, stream);
 }
 
 template <int CC>

@@ -169,6 +169,30 @@ def devoxelize_affine(grid, vcoords, r, aff_a, aff_b, channels_last=False, add=N
     return out
 
 
+def voxel_sort(vox, r):
+    """coordinate-only half of voxelize_cl: vox i32[B,3,N] -> (cnt i32[B,r^3], ws) for voxelize_cl_gather"""
+    b, _, n = vox.shape
+    r = int(r)
+    dev = vox.device
+    ind = torch.empty(b, n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(b, r * r * r, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib().p2pb_avg_voxelize_ws_bytes(_i(b), _i(n), _i(r)), dtype=torch.uint8, device=dev)
+    call("p2pb_voxel_sort", _i(b), _i(n), _i(r), ptr(vox), ptr(ind), ptr(cnt), ptr(ws), stream_ptr())
+    return cnt, ws
+
+
+def voxelize_cl_gather(features, cnt, ws, r):
+    """feature half of voxelize_cl: features f32[B,C,N] + (cnt, ws) of voxel_sort -> grid f32[B,r,r,r,C]"""
+    check(features, F32, "features")
+    b, c, n = features.shape
+    r = int(r)
+    out = torch.empty(b, r, r, r, c, dtype=F32, device=features.device)
+    feat_t = torch.empty(b, n, c, dtype=F32, device=features.device)
+    call("p2pb_avg_voxelize_cl_gather", _i(b), _i(c), _i(n), _i(r), ptr(features), ptr(cnt), ptr(ws), ptr(out),
+         ptr(feat_t), stream_ptr())
+    return out
+
+
 def voxelize_cl(features, vox, r):
     """avg_voxelize into a voxel-major grid: features f32[B,C,N], vox i32[B,3,N] -> (grid f32[B,r,r,r,C],
     cnt i32[B,r^3]); values identical to pointnet2_batch_cuda.avg_voxelize_forward"""

@@ -287,23 +287,31 @@ class PVConv(nn.Module):
         self.voxel_layers = nn.ModuleList(mods)
         self.attn = None
         self.sparse_conv = True  # inference: exact sparse convolution for r >= 16 (fused._voxel_branch_fused)
+        self.level = -1  # set by PVCNN2Unet: index of the coordinate level this block works on (Geometry.take_voxel)
         self.point_features = SharedMLP(in_channels, out_channels, gn_groups=gn_groups, cond_dim=cond_dim)
 
-    def _voxel_branch_fused(self, features, coords, cond, point=None):
+    def _voxel_branch_fused(self, features, coords, cond, point=None, geo=None):
         """inference: voxelize -> conv -> [AdaGN,Swish folded] -> conv -> [AdaGN,SE folded] -> devoxelize; grid
         tensors written once / read once (fused.py). For r >= 16 the convolutions run in their exact sparse form:
         MFMA work only on the bricks near the surface, analytic constants elsewhere (csrc/conv3d.hip)."""
         from . import fused
 
         vl, r = self.voxel_layers, self.resolution
-        vcoords, vox = L.voxel_coords(coords.detach().contiguous(), r, self.voxelization.normalize,
-                                      self.voxelization.eps)
+        geo_v = geo.take_voxel(self.level, r) if (geo is not None and self.level >= 0) else None
+        lists = counts = None
         # the grids of this branch are voxel-major [B,r,r,r,C]: contiguous channels for the convolutions' staging
         # loads and stores, and coalesced voxelize / devoxelize (csrc/voxelize.hip)
-        v, cnt = fused.voxelize_cl(features.contiguous(), vox, r)
+        if geo_v is not None:  # coordinate-only half (voxel coordinates, sort, brick lists) came from the geometry stream
+            vcoords, cnt, ws, lists, counts = geo_v
+            v = fused.voxelize_cl_gather(features.contiguous(), cnt, ws, r)
+        else:
+            vcoords, vox = L.voxel_coords(coords.detach().contiguous(), r, self.voxelization.normalize,
+                                          self.voxelization.eps)
+            v, cnt = fused.voxelize_cl(features.contiguous(), vox, r)
         r3 = float(r ** 3)
         if r >= 32 and self.sparse_conv:  # at r = 16 every 4x8x8 brick touches the surface: dense is faster
-            lists, counts = fused.brick_lists(cnt, r)
+            if lists is None:
+                lists, counts = fused.brick_lists(cnt, r)
             y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0, channels_last=True)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
             a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
@@ -332,9 +340,9 @@ class PVConv(nn.Module):
                 feats = features.contiguous()
                 h, st = F_.pw_conv(feats, pf[0])
                 scp, shp = norm_affine(pf[1], st, feats.shape[2], cond)
-                data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, scp, shp))
+                data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, scp, shp), geo=data.geo)
                 return data
-            fused = self._voxel_branch_fused(features, coords, cond)
+            fused = self._voxel_branch_fused(features, coords, cond, geo=data.geo)
         else:
             v, vcoords = self.voxelization(features, coords)
             for m in self.voxel_layers:
@@ -605,11 +613,29 @@ class Geometry:
         self.main = main
         side.wait_stream(main)
         self.sa, self.fp = [], []
+        from . import fused
+
+        self.voxel = {}
+        vox_plan = {}
+        for (lev, r, normalize, eps) in plan.get("voxel", ()):
+            vox_plan.setdefault(lev, []).append((r, normalize, eps))
         with torch.cuda.stream(side):
             level_coords = []
             c = coords.contiguous()
-            for st in plan["sa"]:
+            for i, st in enumerate(plan["sa"]):
                 level_coords.append(c)
+                # per (level, resolution): voxel coordinates, occupancy + sorted point lists, brick lists of the
+                # sparse convolutions -- coordinate-only, shared by every PVConv of the level; issued before this
+                # level's FPS so that the first consumer (the level's own PVConv) never waits for it
+                for (r, normalize, eps) in vox_plan.get(i, ()):
+                    vcoords, vox = L.voxel_coords(c, r, normalize, eps)
+                    cnt, ws = fused.voxel_sort(vox, r)
+                    lists = counts = None
+                    if r >= 32:
+                        lists, counts = fused.brick_lists(cnt, r)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self.voxel[(i, r)] = (vcoords, cnt, ws, lists, counts, ev)
                 idx = L._ext.furthest_point_sampling_forward(c, st["centers"])
                 cen = L._ext.gather_features_forward(c, idx)
                 nidx = L._ext.ball_query(cen, c, st["radius"], st["neighbors"])
@@ -633,6 +659,17 @@ class Geometry:
         self.main.wait_event(ev)
         for v in vals:
             v.record_stream(self.main)
+        return vals
+
+    def take_voxel(self, level, r):
+        item = self.voxel.get((level, r))
+        if item is None:
+            return None
+        *vals, ev = item
+        self.main.wait_event(ev)
+        for v in vals:
+            if v is not None:
+                v.record_stream(self.main)
         return vals
 
     def take_sa(self, level):
@@ -697,8 +734,12 @@ class PVCNN2Unet(nn.Module):
                                            cond_dim=cd))
             sa_layers.append(blocks[0] if len(blocks) == 1 else _Stage(*blocks))
         self.sa_layers = nn.ModuleList(sa_layers)
+        nlev = len(plan["sa"])
         for i, stage in enumerate(self.sa_layers):
             (stage[-1] if isinstance(stage, _Stage) else stage).level = i
+            for blk in (stage if isinstance(stage, _Stage) else [stage]):
+                if isinstance(blk, PVConv):
+                    blk.level = i  # works on the stage's input coordinates
         attn_type = str(_get(pvd, "attention_type", "linear")).lower()
         if attn_type != "linear":
             raise NotImplementedError("only attention_type='linear' is on the hot path (SURVEY.md section 2 #4)")
@@ -710,6 +751,12 @@ class PVCNN2Unet(nn.Module):
         self.fp_layers = nn.ModuleList(fp_layers)
         for j, stage in enumerate(self.fp_layers):
             (stage[0] if isinstance(stage, _Stage) else stage).level = j
+            for blk in (stage if isinstance(stage, _Stage) else [stage]):
+                if isinstance(blk, PVConv):
+                    blk.level = nlev - 1 - j  # works on the coordinates of the level it up-samples to
+        # unique (coordinate level, resolution) pairs of all PVConvs: their voxel sorts run on the geometry stream
+        self.plan["voxel"] = sorted({(m.level, m.resolution, bool(m.voxelization.normalize), float(m.voxelization.eps))
+                                     for m in self.modules() if isinstance(m, PVConv)})
         self._side_streams = {}
         out_mlp = _get(pvd, "out_mlp", 128)
         self.classifier = nn.ModuleList([SharedMLP(plan["out"], out_mlp, cond_dim=0), nn.Dropout(dropout),
