@@ -116,6 +116,40 @@ def test_stock_pvds_config1():
     check_sampler(model, orc, PVDS, x, 5)
 
 
+def test_pvdl_like_topology(tiny):
+    """A PVDL-shaped network (extra input features, two PVConvs in SA stage 0, 2/2/3/2 feature-propagation blocks:
+    models/pvcnn.py:615-618,78-95), tiny channel widths, seeded weights shared by both sides: the fused inference path
+    (first-layer-before-grouping / -interpolation, shared voxel sorts per level, ...) vs the oracle network."""
+    import copy
+
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
+
+    cfg = copy.deepcopy(tiny[0])
+    cfg["model"]["extra_feature_channels"] = 3
+    cfg["model"]["PVD"]["n_sa_blocks"] = [2, 1, 1, 1]
+    cfg["model"]["PVD"]["n_fp_blocks"] = [2, 2, 3, 2]
+    cfg["gpu"] = "cpu"
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in PVCNN2Unet(cfg).state_dict().items()}
+    torch.manual_seed(1)
+    xyz, _ = net_ref.synthetic_patches(2, 1024, seed=3)
+    x = torch.cat([xyz, torch.rand(2, 3, 1024)], dim=1)  # xyz + RGB-like features
+    t = torch.tensor([10.0, 500.0])
+    model = product.build_model(cfg, sd, device="cuda")
+    model.eval()
+    orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    with torch.no_grad():
+        out = model.model(x.cuda(), t.cuda()).cpu()
+        ref = orc(x, t)
+    assert out.shape == ref.shape == (2, 3, 1024)
+    assert (out - ref).abs().max().item() < TOL
+    # the unfused (training-mode layers, autograd ops) path of the same module agrees as well
+    model.model.train()
+    out_train = model.model(x.cuda(), t.cuda()).detach().cpu()
+    assert (out_train - ref).abs().max().item() < TOL
+
+
 def test_training_step_grads(tiny):
     """forward+backward of the bridge loss on the GPU (HIP grad kernels) vs the golden loss/gradients
     the reference produced on CPU for the same fixed steps."""
