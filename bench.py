@@ -76,7 +76,7 @@ def conv_roofline(model, B, reps=10):
             "frac": round(achieved / peak, 4), "traffic": pmc_traffic(split),
             "traffic_basis": "profiles/r01_pmc_*.csv: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch; algorithmic "
                              f"input + output = {4 * B * r ** 3 * (conv.in_channels + conv.out_channels)} B, the 6x10x10 "
-                             "halo of a 4x8x8 brick re-reads the input 2.34x",
+                             "halo of a 4x8x8 brick re-reads the input 2.34x, about half of it absorbed by the per-XCD L2 (XCD-aware order)",
             "kernel": f"{kname}<{r},compact,2,XF,voxel-major> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
                       f"(fp_layers.2.1.voxel_layers.4)",
             "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "

@@ -437,24 +437,40 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
   const int l31 = lane & 31, khalf = lane >> 5;
   constexpr int BD = R / G::TD;
   constexpr int NBRICK = BD * BH * BW;
-  int bd, bh, bw, b = blockIdx.z;
-  if (brick_list) {
-    if ((int)blockIdx.x >= *brick_count) return;
-    const int entry = brick_list[blockIdx.x];
+  // Workgroup -> (sample, brick, channel block). The hardware deals workgroups to the 8 XCDs round-robin in launch
+  // order (id mod 8), and every XCD has its own 4 MB L2. The launch id is therefore re-read as (xcd, j) and XCD x is
+  // given the x-th CONTIGUOUS eighth of the work list, ordered (sample, brick, channel block): the bricks of a
+  // sample -- whose 6x10x10 halos overlap 2.34x -- and both channel blocks of a brick then share one L2.
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+  const int ncoblk = (cout + 32 * MT - 1) / (32 * MT);
+  int bd, bh, bw, b, coblk;
+  if (brick_list) {  // compacted list of ACTIVE (sample, brick) pairs; the rest is written by conv3d_fill_kernel
+    const unsigned total = (unsigned)(*brick_count) * ncoblk;
+    unsigned v = lin;
+    if (nblk % 8 == 0) {
+      const unsigned per = (total + 7) / 8;
+      if (lin / 8 >= per) return;
+      v = (lin % 8) * per + lin / 8;
+    }
+    if (v >= total) return;
+    const int entry = brick_list[v / ncoblk];
+    coblk = v % ncoblk;
     b = entry / NBRICK;
     const int bk = entry % NBRICK;
     bd = bk / (BH * BW);
     bh = (bk / BW) % BH;
     bw = bk % BW;
-  } else if (COMPACT) {
-    const int hi = blockIdx.x / BD, lo = blockIdx.x % BD;
-    bh = hi / BW;
-    bw = hi % BW;
-    bd = (lo + 8 * BD - (3 * bh + 5 * bw)) % BD;
   } else {
-    bd = blockIdx.x / (BH * BW);
-    bh = (blockIdx.x / BW) % BH;
-    bw = blockIdx.x % BW;
+    const unsigned v = nblk % 8 == 0 ? (lin % 8) * (nblk / 8) + lin / 8 : lin;
+    const unsigned per_sample = NBRICK * ncoblk;
+    b = v / per_sample;
+    const unsigned rem = v % per_sample;
+    const int bk = rem / ncoblk;
+    coblk = rem % ncoblk;
+    bd = bk / (BH * BW);
+    bh = (bk / BW) % BH;
+    bw = bk % BW;
   }
   const int brick = (bd * BH + bh) * BW + bw;
   const int d0 = bd * G::TD, h0 = bh * G::TH, w0 = bw * G::TW;
@@ -464,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
   // this kernel (removing it: 179 -> 230 TFLOP/s), while B fragments come from LDS, which has room.
   constexpr int WM = MT, WN = 4 / WM, NT = (NTILES / WN) > 0 ? NTILES / WN : 1;
   const int wm = wave / WN, wn = wave % WN;
-  const int co0 = blockIdx.y * (32 * MT) + 32 * wm;
+  const int co0 = coblk * (32 * MT) + 32 * wm;
 
   int nbase[NT];
   bool nact[NT];
