@@ -235,10 +235,10 @@ int p2pb_trilinear_devoxelize_affine(int b, int c, int n, int r, const float *co
  * models/pvcnn.py:457-461. */
 int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
                                const float *add, const float *bias, float *out, float *stats_part,
-                               float *ws /* f32[b*m*c] */, void *stream);
+                               float *ws /* f32[b*m*c], or NULL if cz is point-major f32[b,m,c] */, void *stream);
 size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u);
 int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx, float *out,
-                   float *stats_part, float *ws /* f32[b*(n+m)*c] */, void *stream);
+                   float *stats_part, float *ws /* f32[b*(n+m)*c], or NULL if z, cx are point-major */, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused shared point MLPs (SharedMLP models/pvcnn.py:162-205 = k=1 Conv1d/Conv2d -> AdaGN|GroupNorm ->
@@ -253,7 +253,9 @@ int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float 
                                 const float *bias, const float *bias_b, const float *in_scale,
                                 const float *in_shift, int in_swish, int flags, float *out, float *stats_part,
                                 void *stream);
-/* flags bit 2: wp is the split pack below and the GEMM runs in the bf16x6 form (three bf16 terms per fp32
+/* flags bit 5: point-major output, out f32[b,npos,cout] (what p2pb_group_sub / p2pb_three_interpolate_add gather
+ * whole rows from); stats_part must be NULL.
+ * flags bit 2: wp is the split pack below and the GEMM runs in the bf16x6 form (three bf16 terms per fp32
  * operand, six MFMA products, fp32 accumulate -- see the conv3d split pack); needs npos % 4 == 0 and
  * 16-byte aligned in/out. Meant for the matrix-bound layers (wide channel counts). */
 size_t p2pb_pointwise_split_packed_bytes(int cout, int cin);

@@ -213,11 +213,16 @@ extern "C" size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u) {
 // ws: f32[b*(n+m)*c] scratch for the point-major copies
 extern "C" int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx,
                               float *out, float *stats_part, float *ws, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !stats_part || !ws) return P2PB_EINVAL;
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !stats_part) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  float *zt = ws, *cxt = cx ? ws + (size_t)b * n * c : nullptr;
-  hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, z, zt);
-  if (cx) hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(m, 32), cdiv(c, 32), b), dim3(256), 0, s, c, m, cx, cxt);
+  const float *zt = z, *cxt = cx;  // ws == NULL: z f32[b,n,c] and cx f32[b,m,c] are point-major already
+  if (ws) {
+    float *zw = ws, *cw = ws + (size_t)b * n * c;
+    hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, z, zw);
+    if (cx) hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(m, 32), cdiv(c, 32), b), dim3(256), 0, s, c, m, cx, cw);
+    zt = zw;
+    cxt = cx ? cw : nullptr;
+  }
   const int nblk = (int)(((long)m * u + 63) / 64);
   hipLaunchKernelGGL(group_sub_kernel, dim3(nblk, cdiv(c, c <= 32 ? 32 : 64), b), dim3(256), 0, s, c, n, m, u, nblk * 2,
                      zt, cxt, idx, out, stats_part);
@@ -465,11 +470,15 @@ __global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int
 extern "C" int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
                                           const float *add, const float *bias, float *out, float *stats_part,
                                           float *ws, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || !stats_part || !ws) return P2PB_EINVAL;
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || !stats_part) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(m, 32), cdiv(c, 32), b), dim3(256), 0, s, c, m, cz, ws);
+  const float *czt = cz;  // ws == NULL: cz f32[b,m,c] is point-major already
+  if (ws) {
+    hipLaunchKernelGGL(nb_transpose_kernel, dim3(cdiv(m, 32), cdiv(c, 32), b), dim3(256), 0, s, c, m, cz, ws);
+    czt = ws;
+  }
   const int nblk = (n + 63) / 64;
-  hipLaunchKernelGGL(three_interp_add_kernel, dim3(nblk, cdiv(c, 64), b), dim3(256), 0, s, c, m, n, nblk * 2, ws, idx, w,
+  hipLaunchKernelGGL(three_interp_add_kernel, dim3(nblk, cdiv(c, 64), b), dim3(256), 0, s, c, m, n, nblk * 2, czt, idx, w,
                      add, bias, out, stats_part);
   return p2pb_launch_status();
 }

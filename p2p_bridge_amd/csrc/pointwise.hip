@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
                                                       const float *__restrict__ in_scale,
                                                       const float *__restrict__ in_shift, int in_swish,
                                                       float *__restrict__ out, float *__restrict__ stats_part,
-                                                      float *__restrict__ mm_out, int pool_g) {
+                                                      float *__restrict__ mm_out, int pool_g, int out_pm) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
@@ -284,6 +284,37 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
           acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][kk], bcur[kk][s], acc[m][s], 0, 0, 0);
   }
 
+  if (out_pm) {  // point-major output f32[b, P, cout] (the consumer gathers whole rows); no statistics in this form
+    float *ob = out + (size_t)b * P * cout;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cq = co0 + m * 32 + 8 * g + 4 * khalf;
+        float bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bv[i] = 0.0f;
+          if (cq + i < cout) {
+            bv[i] = bias ? bias[cq + i] : 0.0f;
+            if (bias_b) bv[i] += bias_b[(size_t)b * cout + cq + i];
+          }
+        }
+        if (pok && cq < cout) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            float *q = ob + (size_t)(p + s) * cout + cq;
+            const f32x4 v = {acc[m][s][4 * g] + bv[0], acc[m][s][4 * g + 1] + bv[1], acc[m][s][4 * g + 2] + bv[2],
+                             acc[m][s][4 * g + 3] + bv[3]};
+            if (cq + 3 < cout && (cout & 3) == 0) *(f32x4 *)q = v;
+            else
+              for (int i = 0; i < 4; ++i)
+                if (cq + i < cout) q[i] = v[i];
+          }
+        }
+      }
+    return;
+  }
   float *outb = out + (size_t)b * cout * P;
   // statistics slots keep the 64-position granularity of the narrow kernel: this wave fills slot `slot`
   // with its 128-position sums and zeroes slot + 1
@@ -408,7 +439,7 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
                                                        const float *__restrict__ in_scale,
                                                        const float *__restrict__ in_shift, int in_swish,
                                                        float *__restrict__ out, float *__restrict__ stats_part,
-                                                       float *__restrict__ mm_out, int pool_u) {
+                                                       float *__restrict__ mm_out, int pool_u, int out_pm) {
   extern __shared__ u32x4 pws_lds[];  // [A][B]
   u32x4 *lds_b = pws_lds + PWS_TILE;
   const u32x4 *lds_a = pws_lds;
@@ -513,11 +544,42 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
   }
   if (!mact) return;
 
+  const int p = pblk + 2 * (wn * 32 + l31);
+  const bool pok = p < P;
+  if (out_pm) {  // point-major output f32[b, P, cout]; no statistics in this form
+    float *ob = out + (size_t)b * P * cout;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cq = co0 + wm * 64 + m * 32 + 8 * g + 4 * khalf;
+        float bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bv[i] = 0.0f;
+          if (cq + i < cout) {
+            bv[i] = bias ? bias[cq + i] : 0.0f;
+            if (bias_b) bv[i] += bias_b[(size_t)b * cout + cq + i];
+          }
+        }
+        if (pok && cq < cout) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            float *q = ob + (size_t)(p + n) * cout + cq;
+            const f32x4 v = {acc[m][n][4 * g] + bv[0], acc[m][n][4 * g + 1] + bv[1], acc[m][n][4 * g + 2] + bv[2],
+                             acc[m][n][4 * g + 3] + bv[3]};
+            if (cq + 3 < cout && (cout & 3) == 0) *(f32x4 *)q = v;
+            else
+              for (int i = 0; i < 4; ++i)
+                if (cq + i < cout) q[i] = v[i];
+          }
+        }
+      }
+    return;
+  }
   // ---- epilogue: bias, 8-byte stores, GroupNorm partials per 64-position slot, optional {min, max}.
   // Row index of the reductions: idx = m*16 + r; rowreduce32 leaves row (l31) in lane l31.
   float *outb = out ? out + (size_t)b * cout * P : nullptr;
-  const int p = pblk + 2 * (wn * 32 + l31);
-  const bool pok = p < P;
   const int slot = blockIdx.x * 2 + wn;
   const int pool_g = pool_u ? pool_u / 2 : 32;
   float s1v[32], s2v[32], mnv[32], mxv[32];
@@ -621,7 +683,7 @@ extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float 
 
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
-                           float *out, float *stats_part, float *minmax, int pool_u, hipStream_t s) {
+                           float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
   dim3 grid((P + 127) / 128, (cout + 127) / 128, b);
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
@@ -635,7 +697,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
       once = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL((pw_split_kernel<XF, PL>), grid, dim3(256), PWS_LDS_BYTES, s, cin, cout, P, nslots, in, w, bias, \
-                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                        \
+                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm);                \
   } while (0)
   if (in_scale && minmax) LAUNCH(true, true);
   else if (in_scale) LAUNCH(true, false);
@@ -653,14 +715,14 @@ static bool pw_wide_ok(int P, const float *in, const float *out) {
 template <int MT>
 static int pw_launch(int b, int cin, int cout, int P, const float *in, const float *wp, const float *bias,
                      const float *bias_b, const float *in_scale, const float *in_shift, int in_swish, float *out,
-                     float *stats_part, float *minmax, int pool_g, hipStream_t s) {
+                     float *stats_part, float *minmax, int pool_g, int out_pm, hipStream_t s) {
   const bool xf = in_scale != nullptr, st = stats_part != nullptr;
   if (pw_wide_ok(P, in, out)) {
     dim3 grid((P + 511) / 512, (cout + 32 * MT - 1) / (32 * MT), b);
     const int nslots = (P + 255) / 256 * 4;
 #define LAUNCH(XF, ST, PL)                                                                                         \
   hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, nslots, \
-                     in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g)
+                     in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm)
     if (minmax) {
       if (xf) LAUNCH(true, true, true);
       else LAUNCH(false, true, true);
@@ -671,7 +733,7 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
 #undef LAUNCH
     return p2pb_launch_status();
   }
-  if (minmax) return P2PB_EINVAL;
+  if (minmax || out_pm) return P2PB_EINVAL;
   dim3 grid((P + 255) / 256, (cout + 32 * MT - 1) / (32 * MT), b);
 #define LAUNCH(XF, ST)                                                                                            \
   hipLaunchKernelGGL((pw_conv_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, in, wp, bias, \
@@ -690,17 +752,19 @@ extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, c
                                            float *stats_part, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const int out_pm = (flags & 32) != 0;  // point-major output f32[b, npos, cout]
+  if (out_pm && stats_part) return P2PB_EINVAL;
   if (flags & 4) {  // wp is the split pack
     if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           nullptr, 0, s);
+                           nullptr, 0, out_pm, s);
   }
   const float *wp = (const float *)wp_any;
   // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, nullptr, 0, s)
+                                  stats_part, nullptr, 0, out_pm, s)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, nullptr, 0, s);
+                                  stats_part, nullptr, 0, out_pm, s);
 }
 
 // pool_u = neighbourhood size (4, 8, 16, 32 or 64 consecutive positions) or 0 for the global pool
@@ -726,13 +790,13 @@ extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int np
   hipStream_t s = (hipStream_t)stream;
   if (flags & 4)
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           minmax, pool_u, s);
+                           minmax, pool_u, 0, s);
   const float *wp = (const float *)wp_any;
   const int g = pool_lanes(pool_u);
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, minmax, g, s)
+                                  stats_part, minmax, g, 0, s)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, minmax, g, s);
+                                  stats_part, minmax, g, 0, s);
 }
 
 // y = max(act(scale*min + shift), act(scale*max + shift)):

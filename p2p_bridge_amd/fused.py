@@ -260,10 +260,11 @@ def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
 
 
 def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
-            use_bias=True, pool_u=None, store=True, math=None):
+            use_bias=True, pool_u=None, store=True, math=None, point_major=False):
     """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None).
     pool_u (0 = all positions, or the neighbourhood size): also returns the {min, max} tensor minmax_act()
-    pools from -> (y | None, stats, minmax); store=False skips writing y altogether."""
+    pools from -> (y | None, stats, minmax); store=False skips writing y altogether.
+    point_major (no statistics, rows 16-byte aligned): y f32[B,P,Cout], the layout group_sub / interp_add gather from."""
     check(x, F32, "x")
     b, ci, p = x.shape
     co = conv.weight.shape[0]
@@ -275,8 +276,12 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         in_scale = in_shift = None
         swish = False
     wp = pack_pointwise_weight(conv, ci_lo, ci_hi, split)
-    flags = _i(4 if split else 0)
-    y = torch.empty(b, co, p, dtype=F32, device=x.device) if (store or pool_u is None) else None
+    point_major = point_major and not stats and pool_u is None and p % 4 == 0
+    flags = _i((4 if split else 0) | (32 if point_major else 0))
+    if point_major:
+        y = torch.empty(b, p, co, dtype=F32, device=x.device)
+    else:
+        y = torch.empty(b, co, p, dtype=F32, device=x.device) if (store or pool_u is None) else None
     st = None
     if stats or pool_u is not None:
         nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
@@ -310,32 +315,39 @@ def minmax_act(mm, scale, shift, swish=True, global_pool=False):
     return y
 
 
-def group_sub(z, cx, idx):
+def group_sub(z, cx, idx, point_major=False):
     """z f32[B,C,N], cx f32[B,C,M] | None, idx i32[B,M,U] -> (y f32[B,C,M*U] = z[:, :, idx] - cx[:, :, :, None],
     GroupNorm partials f32[B,nslots,C,2]): the grouped output of a set abstraction's first layer when that layer
-    was applied to the ungrouped points (csrc/neighbors.hip group_sub_kernel)"""
+    was applied to the ungrouped points (csrc/neighbors.hip group_sub_kernel). point_major: z f32[B,N,C] and
+    cx f32[B,M,C] already are in the layout the gather wants (pw_conv(point_major=True))"""
     check(z, F32, "z")
-    b, c, n = z.shape
+    if point_major:
+        b, n, c = z.shape
+    else:
+        b, c, n = z.shape
     m, u = idx.shape[1], idx.shape[2]
     y = torch.empty(b, c, m * u, dtype=F32, device=z.device)
     nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
     st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
-    ws = torch.empty(b * (n + m) * c, dtype=F32, device=z.device)  # point-major copies of z and cx
+    ws = None if point_major else torch.empty(b * (n + m) * c, dtype=F32, device=z.device)
     call("p2pb_group_sub", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st), ptr(ws),
          stream_ptr())
     return y, st
 
 
-def interp_add(cz, idx, w, add=None, bias=None):
-    """cz f32[B,C,M], idx i32[B,3,N], w f32[B,3,N], add f32[B,C,N] | None, bias f32[C] | None ->
-    (y f32[B,C,N] = sum_k w_k cz[:, :, idx_k] + add (+ bias), GroupNorm partials f32[B,nslots,C,2])"""
+def interp_add(cz, idx, w, add=None, bias=None, point_major=False):
+    """cz f32[B,C,M] (point_major: f32[B,M,C]), idx i32[B,3,N], w f32[B,3,N], add f32[B,C,N] | None, bias f32[C] | None
+    -> (y f32[B,C,N] = sum_k w_k cz[:, :, idx_k] + add (+ bias), GroupNorm partials f32[B,nslots,C,2])"""
     check(cz, F32, "cz")
-    b, c, m = cz.shape
+    if point_major:
+        b, m, c = cz.shape
+    else:
+        b, c, m = cz.shape
     n = idx.shape[2]
     y = torch.empty(b, c, n, dtype=F32, device=cz.device)
     nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(n), _i(1))
     st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=cz.device)
-    ws = torch.empty(b * m * c, dtype=F32, device=cz.device)  # point-major copy of cz
+    ws = None if point_major else torch.empty(b * m * c, dtype=F32, device=cz.device)
     call("p2pb_three_interpolate_add", _i(b), _i(c), _i(m), _i(n), ptr(cz), ptr(idx), ptr(w), ptr(add), ptr(bias),
          ptr(y), ptr(st), ptr(ws), stream_ptr())
     return y, st

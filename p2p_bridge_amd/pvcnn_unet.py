@@ -395,9 +395,12 @@ class PointNetSAModule(nn.Module):
                 # the first 1x1 convolution commutes with the grouping (linear): run it on the N points, then gather
                 # its C1-channel output and subtract the centre term (csrc/neighbors.hip group_sub_kernel)
                 conv0 = mlp.layers[0]
-                z, _ = fused.pw_conv(torch.cat([coords, data.features], dim=1), conv0, stats=False)
-                cx, _ = fused.pw_conv(centers.contiguous(), conv0, stats=False, ci_lo=0, ci_hi=3, use_bias=False)
-                y, st = fused.group_sub(z, cx, nidx)
+                xin = torch.cat([coords, data.features], dim=1)
+                cen = centers.contiguous()
+                pm = xin.shape[2] % 4 == 0 and cen.shape[2] % 4 == 0  # both GEMMs can write point-major rows
+                z, _ = fused.pw_conv(xin, conv0, stats=False, point_major=pm)
+                cx, _ = fused.pw_conv(cen, conv0, stats=False, ci_lo=0, ci_hi=3, use_bias=False, point_major=pm)
+                y, st = fused.group_sub(z, cx, nidx, point_major=pm)
                 M, U = nidx.shape[1], nidx.shape[2]
                 data.features = mlp._run_fused(y.view(y.shape[0], y.shape[1], M, U), data.cond, True, None, first=st)
             else:
@@ -433,13 +436,14 @@ class PointNetFPModule(nn.Module):
                 conv0 = self.mlp.layers[0]
                 g = data.lower_features.contiguous()
                 cg = g.shape[1]
-                cz, _ = fused.pw_conv(g, conv0, stats=False, ci_lo=0, ci_hi=cg, use_bias=False)
+                pm = g.shape[2] % 4 == 0  # the coarse-level GEMM writes the point-major rows the blend gathers
+                cz, _ = fused.pw_conv(g, conv0, stats=False, ci_lo=0, ci_hi=cg, use_bias=False, point_major=pm)
                 skip = data.features
                 if skip is not None:
                     ys, _ = fused.pw_conv(skip.contiguous(), conv0, stats=False, ci_lo=cg, ci_hi=cg + skip.shape[1])
-                    y, st = fused.interp_add(cz, idx, w, add=ys)
+                    y, st = fused.interp_add(cz, idx, w, add=ys, point_major=pm)
                 else:
-                    y, st = fused.interp_add(cz, idx, w, bias=conv0.bias)
+                    y, st = fused.interp_add(cz, idx, w, bias=conv0.bias, point_major=pm)
                 if data.time_emb is not None:
                     data.time_emb = data.time_emb[:, :, 0:1].expand(-1, -1, data.coords.shape[-1])
                 data.features = self.mlp._run_fused(y, data.cond, False, None, first=st)

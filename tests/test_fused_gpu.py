@@ -166,6 +166,12 @@ def test_first_layer_before_grouping(fused, B, C, C1, N, M, U):
         cx, _ = fused.pw_conv(centers, conv, stats=False, ci_lo=0, ci_hi=3, use_bias=False)
         got, st = fused.group_sub(z, cx, idx)
         assert got.shape == (B, C1, M * U)
+        if N % 4 == 0 and M % 4 == 0:  # the GEMMs write point-major rows directly: same values, no transposes
+            zt, _ = fused.pw_conv(torch.cat([xyz, f], 1), conv, stats=False, point_major=True)
+            cxt, _ = fused.pw_conv(centers, conv, stats=False, ci_lo=0, ci_hi=3, use_bias=False, point_major=True)
+            assert zt.shape == (B, N, C1) and torch.equal(zt.transpose(1, 2), z) and torch.equal(cxt.transpose(1, 2), cx)
+            got_pm, st_pm = fused.group_sub(zt, cxt, idx, point_major=True)
+            assert torch.equal(got_pm, got) and torch.equal(st_pm, st)
         assert rel_err(got, want) < 1e-5
         s1w, s2w = stats_of(st_want)
         s1, s2 = stats_of(st)
@@ -199,6 +205,15 @@ def test_first_layer_before_interpolation(fused, B, Cg, Cs, C1, M, N):
         assert rel_err(y, ref) < 1e-5
         s1, s2 = stats_of(st)
         assert rel_err(s2, (ref * ref).sum(2)) < 1e-5
+        if M % 4 == 0:
+            for math in ("fp32", "bf16x6"):
+                czt, _ = fused.pw_conv(g, conv, stats=False, ci_lo=0, ci_hi=Cg, use_bias=False, point_major=True, math=math)
+                czm, _ = fused.pw_conv(g, conv, stats=False, ci_lo=0, ci_hi=Cg, use_bias=False, math=math)
+                assert czt.shape == (B, M, C1) and torch.equal(czt.transpose(1, 2), czm)
+            czt, _ = fused.pw_conv(g, conv, stats=False, ci_lo=0, ci_hi=Cg, use_bias=False, point_major=True)
+            y_pm, st_pm = (fused.interp_add(czt, idx, w, add=ys, point_major=True) if skip is not None
+                           else fused.interp_add(czt, idx, w, bias=conv.bias, point_major=True))
+            assert torch.equal(y_pm, y) and torch.equal(st_pm, st)
 
 
 def test_pool_unsupported_shapes(fused):
