@@ -102,3 +102,32 @@ def test_product_sampler_requires_gpu_ops():
     x, _ = net_ref.synthetic_patches(1, 1024)
     with pytest.raises(RuntimeError):
         m.sample(x_start=x, steps=2, verbose=False)
+
+
+def test_voxel_plan_and_levels():
+    """every PVConv knows the coordinate level it works on, and the unique (level, resolution) pairs -- the voxel
+    sorts the geometry stream computes once per evaluation -- are exactly the four of PVDS (SA and FP stages share them)"""
+    from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet, PVConv
+
+    net = PVCNN2Unet(PVDS)
+    pairs = [(lev, r) for (lev, r, _, _) in net.plan["voxel"]]
+    assert pairs == [(0, 32), (1, 16), (2, 8), (3, 8)]
+    got = sorted((name, m.level, m.resolution) for name, m in net.named_modules() if isinstance(m, PVConv))
+    assert got == [("fp_layers.0.1", 3, 8), ("fp_layers.1.1", 2, 8), ("fp_layers.2.1", 1, 16), ("fp_layers.2.2", 1, 16),
+                   ("fp_layers.3.1", 0, 32), ("sa_layers.0.0", 0, 32), ("sa_layers.1.0", 1, 16), ("sa_layers.2.0", 2, 8)]
+
+
+def test_conv_math_switch(monkeypatch):
+    from p2p_bridge_amd import fused
+
+    monkeypatch.delenv("P2PB_CONV_MATH", raising=False)
+    assert fused.conv_math() == "bf16x6" and fused.use_split(32) and fused.use_split(256)
+    assert fused.use_split_pw(512, 1024, 8192) and not fused.use_split_pw(64, 128, 8192)
+    assert not fused.use_split_pw(512, 1024, 8190)  # rows must be 16-byte aligned
+    monkeypatch.setenv("P2PB_CONV_MATH", "fp32")
+    assert fused.conv_math() == "fp32" and not fused.use_split(256) and not fused.use_split_pw(512, 1024, 8192)
+    assert fused.use_split(256, math="bf16x6")
+    monkeypatch.setenv("P2PB_CONV_MATH", "bf16")
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        fused.conv_math()
