@@ -150,6 +150,28 @@ def test_pvdl_like_topology(tiny):
     assert (out_train - ref).abs().max().item() < TOL
 
 
+def test_odd_point_counts(tiny):
+    """N = 1000 (centres 250 / 62 / 15 / 3): rows that are not 16-byte multiples take the fallback paths of the fused
+    kernels (one-position-per-lane GEMM, two-pass pooling, channel-major gathers) -- same contract."""
+    import copy
+
+    from p2p_bridge_amd import p2pb as product
+
+    cfg, sd, _ = tiny
+    cfg = copy.deepcopy(cfg)
+    cfg["data"]["npoints"] = 1000
+    x, _ = net_ref.synthetic_patches(2, 1000, seed=5)
+    t = torch.tensor([3.0, 700.0])
+    model = product.build_model(cfg, sd, device="cuda")
+    model.eval()
+    orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    with torch.no_grad():
+        out = model.model(x.cuda(), t.cuda()).cpu()
+        ref = orc(x, t)
+    assert out.shape == ref.shape == (2, 3, 1000)
+    assert (out - ref).abs().max().item() < TOL
+
+
 def test_training_step_grads(tiny):
     """forward+backward of the bridge loss on the GPU (HIP grad kernels) vs the golden loss/gradients
     the reference produced on CPU for the same fixed steps."""
