@@ -172,6 +172,28 @@ def test_odd_point_counts(tiny):
     assert (out - ref).abs().max().item() < TOL
 
 
+def test_large_cloud(tiny):
+    """one 20000-point cloud (BASELINE configs 4/5 feed 50000-point room patches): the global-memory FPS variant
+    (n > 16384), long rows in every kernel, stock radii -- network output vs the oracle"""
+    import copy
+
+    from p2p_bridge_amd import p2pb as product
+
+    cfg, sd, _ = tiny
+    cfg = copy.deepcopy(cfg)
+    cfg["data"]["npoints"] = 20000
+    x, _ = net_ref.synthetic_patches(1, 20000, seed=7)
+    t = torch.tensor([250.0])
+    model = product.build_model(cfg, sd, device="cuda")
+    model.eval()
+    orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    with torch.no_grad():
+        out = model.model(x.cuda(), t.cuda()).cpu()
+        ref = orc(x, t)
+    assert out.shape == ref.shape == (1, 3, 20000)
+    assert (out - ref).abs().max().item() < TOL
+
+
 def test_training_step_grads(tiny):
     """forward+backward of the bridge loss on the GPU (HIP grad kernels) vs the golden loss/gradients
     the reference produced on CPU for the same fixed steps."""
