@@ -10,8 +10,8 @@ def main(path, out=None, top=60):
     tot = sum(r[2] for r in rows)
     lines = ["pct,calls,avg_us,total_ms,kernel"]
     for name, calls, dur, avg, pct in rows[:top]:
-        lines.append(f"{dur / tot * 100:.2f},{calls},{avg / 1e3:.1f},{dur / 1e6:.2f},\"{name[:160]}\"")
-    lines.append(f"# total kernel time {tot / 1e6:.1f} ms over {sum(r[1] for r in rows)} dispatches, {len(rows)} distinct kernels")
+        lines.append(f"{dur / tot * 100:.2f},{calls},{avg:.1f},{dur / 1e3:.2f},\"{name[:160]}\"")  # view is in microseconds
+    lines.append(f"# total kernel time {tot / 1e3:.1f} ms over {sum(r[1] for r in rows)} dispatches, {len(rows)} distinct kernels")
     txt = "\n".join(lines)
     print(txt)
     if out:
