@@ -189,6 +189,18 @@ int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *
                                   const float *in_shift, int in_swish, const float *in_sub, int flags /* bits 2, 3 */,
                                   const int *active_list, const int *active_count, const int *inactive_list,
                                   const int *inactive_count, float *out, float *stats_part, void *stream);
+/* Compact form (voxel-level sparsity inside the bricks; conv3d.hip). p2pb_conv3d_active_lists derives, from the voxel
+ * occupancy cnt i32[b,r^3], per (sample, 4x8x8 brick) the sorted local ids of the voxels in D1 = dilate(occupied,1)
+ * (set 0) and D2 = dilate(D1,1) (set 1), followed by the ids outside the set: lists u8[2][b][NBRICK][256], counts
+ * i32[2][b][NBRICK]; r in {8,16,32}. p2pb_conv3d_k3_forward_compact computes only the listed outputs of every brick
+ * (a first convolution with set 0; a second one in far-field form -- in_sub / out_class -- with set 1) and writes the
+ * known constants (+ their exact statistics) elsewhere. Voxel-major tensors, split weight pack. */
+int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned char *lists, int *counts, void *stream);
+int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split,
+                                   const float *bias, const float *out_class, const float *in_scale,
+                                   const float *in_shift, int in_swish, const float *in_sub,
+                                   const unsigned char *alist, const int *acount, float *out, float *stats_part,
+                                   void *stream);
 /* a[b,cin] = xf(prev_bias[cin]) (the operand's far-field constant) and k_out[b,27,cout] = conv(a) + bias per
  * boundary class, for p2pb_conv3d_k3_forward_ex */
 int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,

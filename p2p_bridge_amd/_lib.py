@@ -23,7 +23,7 @@ SYMBOLS = [
     "p2pb_auction_forward", "p2pb_auction_backward", "p2pb_conv3d_k3_packed_floats", "p2pb_conv3d_k3_pack_weights",
     "p2pb_conv3d_k3_split_packed_bytes", "p2pb_conv3d_k3_pack_weights_split",
     "p2pb_conv3d_k3_stats_floats", "p2pb_conv3d_k3_forward", "p2pb_conv3d_k3_forward_ex",
-    "p2pb_conv3d_k3_far_field", "p2pb_conv3d_brick_lists", "p2pb_conv3d_k3_forward_sparse", "p2pb_gn_affine_params", "p2pb_se_gate_affine",
+    "p2pb_conv3d_k3_far_field", "p2pb_conv3d_active_lists", "p2pb_conv3d_k3_forward_compact", "p2pb_conv3d_brick_lists", "p2pb_conv3d_k3_forward_sparse", "p2pb_gn_affine_params", "p2pb_se_gate_affine",
     "p2pb_trilinear_devoxelize_affine", "p2pb_avg_voxelize_cl_forward", "p2pb_voxel_sort", "p2pb_avg_voxelize_cl_gather", "p2pb_trilinear_devoxelize_cl_affine", "p2pb_pointwise_packed_floats", "p2pb_pointwise_pack_weights",
     "p2pb_pointwise_stats_floats", "p2pb_pointwise_conv_forward", "p2pb_affine_act", "p2pb_affine_act_max",
     "p2pb_pointwise_split_packed_bytes", "p2pb_pointwise_pack_weights_split", "p2pb_pointwise_pool_supported", "p2pb_pointwise_minmax_floats", "p2pb_pointwise_conv_pool_forward",

@@ -602,32 +602,49 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 
     const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
     const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
-    u32x4 a_cur[3];
+    u32x4 a_cur[3], bf[3][NT];
 #pragma unroll
     for (int s = 0; s < 3; ++s) a_cur[s] = wchunk[s * wsplit_stride];
+    auto load_b = [&](int s, int toff) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+    };
+    auto mfma_term = [&](int pa, int pb) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[pa]),
+                                                         __builtin_bit_cast(bf16x8, bf[pb][n]), acc[n], 0, 0, 0);
+    };
+    // Six products per (tap, tile), the small ones first: x0y2, x1y1, x2y0 | x1y0, x0y1 | x0y0. The B fragments roll
+    // through ONE register set: y2 of the next tap is read as soon as this tap's x0y2 products have issued, y1 after
+    // x0y1, y0 at the top of the tap (it is first needed by the third product) -- every LDS read has >= 8 MFMAs
+    // (256+ cycles) in front of its first use without a second fragment buffer; A fragments one tap ahead (L2
+    // latency). The scheduling barriers pin this order, else every load sinks to its first use.
+    load_b(2, 0);
+    load_b(1, 0);
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
       const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
-      // A fragments one tap ahead (L2 latency), B fragments at the top of the tap (LDS latency is covered by
-      // the co-resident wave); the scheduling barrier pins both, else every load sinks to its first use
-      u32x4 a_nxt[3], bf[3][NT];
+      const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
+      u32x4 a_nxt[3];
       if (tap + 1 < 27) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
       }
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+      load_b(0, toff);
       __builtin_amdgcn_sched_barrier(0);
-      // small terms first
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[PA[t]]),
-                                                           __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[n], 0, 0, 0);
+      mfma_term(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 27) load_b(2, toff_n);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_term(1, 1);
+      mfma_term(2, 0);
+      mfma_term(1, 0);
+      mfma_term(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < 27) load_b(1, toff_n);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_term(0, 0);
       if (tap + 1 < 27) {
 #pragma unroll
         for (int s = 0; s < 3; ++s) a_cur[s] = a_nxt[s];
@@ -1110,6 +1127,460 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
   if (r == 32) { GO(32); }
   GO(16);
 #undef GO
+}
+
+// ================================================================================================
+// Compact form of the split kernel: voxel-level sparsity inside the bricks.
+//
+// The first convolution of a PVConv is non-constant only on D1 = dilate(occupied, 1) (elsewhere every input in
+// the 3x3x3 window is zero and the output is the bias), the second -- in its far-field form, operand x - a --
+// only on D2 = dilate(D1, 1) (elsewhere the output is the boundary-class constant K). D1 / D2 are 15 % / 26 % of a
+// 32^3 grid, 30 % / 50 % at 16^3, 57 % / 87 % at 8^3, while a brick (4x8x8) is "active" as soon as it holds one
+// such voxel. So a workgroup computes only the ACTIVE outputs of its brick: their local ids come from a per-brick
+// list (coordinate-only: built once per (level, resolution) on the geometry stream), they are packed 32 to an
+// MFMA column tile, and the B fragment of (tile, tap) is still "halo slot of my voxel + constant tap offset" --
+// the main loop is the split kernel's, with 1..8 gathered tiles instead of 8 fixed ones. The remaining voxels of the
+// brick get their constant (and its exact contribution to the GroupNorm statistics) from the same workgroup.
+// Waves: WM = 4 -> four M-tiles (128 channels per workgroup), every wave walks all tiles, four at a time (a brick
+// with more than four active tiles takes a second pass over the input stages); WM = 2 -> 64 channels, the tiles
+// are dealt to two wave columns. Values are bit-identical to the dense split kernel on the computed outputs.
+// ================================================================================================
+
+// per (sample, brick): local ids (ld*8 + lh)*8 + lw of the voxels in D1 (which = 0) / D2 (which = 1), in an
+// LDS-conflict-avoiding order (below), followed by the ids NOT in the set; counts[which][b][brick] = size of the set.
+template <int R>
+__global__ __launch_bounds__(256) void active_lists_kernel(const int *__restrict__ cnt, unsigned char *__restrict__ lists,
+                                                           int *__restrict__ counts, int nb) {
+  constexpr int TD = 4, TH = 8, TW = 8, BH = R / TH, BW = R / TW, NBRICK = (R / TD) * BH * BW;
+  constexpr int ED = TD + 4, EH = TH + 4, EW = TW + 4;  // occupancy, brick +- 2
+  constexpr int FD = TD + 2, FH = TH + 2, FW = TW + 2;  // D1, brick +- 1
+  __shared__ unsigned char occ[ED * EH * EW], d1[FD * FH * FW];
+  __shared__ int wcount[2][4], wbc[2][4][16];
+  const int b = blockIdx.y, bk = blockIdx.x, t = threadIdx.x;
+  const int d0 = (bk / (BH * BW)) * TD, h0 = ((bk / BW) % BH) * TH, w0 = (bk % BW) * TW;
+  for (int e = t; e < ED * EH * EW; e += 256) {
+    const int d = d0 - 2 + e / (EH * EW), h = h0 - 2 + (e / EW) % EH, w = w0 - 2 + e % EW;
+    const bool in = (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
+    occ[e] = in && cnt[(size_t)b * R * R * R + (d * R + h) * R + w] > 0;
+  }
+  __syncthreads();
+  for (int e = t; e < FD * FH * FW; e += 256) {
+    const int z = e / (FH * FW), y = (e / FW) % FH, x = e % FW;  // voxel (d0-1+z, ...): occ index offset by +1
+    int any = 0;
+    for (int k = 0; k < 27; ++k) any |= occ[((z + k / 9) * EH + (y + (k / 3) % 3)) * EW + x + k % 3];
+    // a voxel outside the grid is never an input: its D1 flag must not leak into D2 of its neighbours
+    const int d = d0 - 1 + z, h = h0 - 1 + y, w = w0 - 1 + x;
+    const bool in = (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
+    d1[e] = in ? any : 0;
+  }
+  __syncthreads();
+  const int ld = t / 64, lh = (t / 8) % 8, lw = t % 8;
+  int f[2];
+  f[0] = d1[((ld + 1) * FH + lh + 1) * FW + lw + 1];
+  f[1] = 0;
+  for (int k = 0; k < 27; ++k) f[1] |= d1[((ld + k / 9) * FH + lh + (k / 3) % 3) * FW + lw + k % 3];
+  const int lane = t & 63, wave = t >> 6;
+  // Order of the active ids: the convolution reads the B fragment of a column tile with one ds_read_b128 per lane at
+  // "halo slot of my voxel + tap offset", served in groups of 16 lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31} of a
+  // half-wave), one cycle per group when the 16 slots differ mod 16. Sorting the ids by (rank inside their residue
+  // class, residue) makes any 16 consecutive ones (nearly) distinct mod 16; full tiles then deal the first / second
+  // 16 of their 32 ids to the lanes of the first / second service group. Ascending ids would be 2-3-way conflicted.
+  const int rho = ((ld * (TH + 2) + lh) * (TW + 2) + lw) & 15;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    int rk = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const unsigned long long m = __ballot(f[w] && rho == q);
+      if (rho == q) rk = mbcnt(m);
+      if (lane == 0) wbc[w][wave][q] = __popcll(m);
+    }
+    f[w] |= rk << 1;  // bit 0: active, the rest: rank among the wave's active ids of the same residue
+  }
+  __syncthreads();
+  constexpr int POS[32] = {0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27,
+                           4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31};
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const int act = f[w] & 1;
+    int rk = f[w] >> 1, total = 0, below = 0, inact_before = 0;
+    for (int q = 0; q < wave; ++q) rk += wbc[w][q][rho];
+    for (int q = 0; q < 16; ++q) {
+      int c = 0;
+      for (int v = 0; v < 4; ++v) c += wbc[w][v][q];
+      total += c;
+      below += min(c, rk) + (q < rho && c > rk);  // ids sorted before (rk, rho)
+    }
+    // inactive ids keep their ascending order behind the active ones
+    const unsigned long long ia = __ballot(!act);
+    if (lane == 0) wcount[w][wave] = __popcll(ia);
+    __syncthreads();
+    for (int q = 0; q < wave; ++q) inact_before += wcount[w][q];
+    int slot;
+    if (act) slot = below < (total & ~31) ? (below & ~31) + POS[below & 31] : below;
+    else slot = total + inact_before + mbcnt(ia);
+    unsigned char *dst = lists + (((size_t)w * nb + b) * NBRICK + bk) * 256;
+    dst[slot] = (unsigned char)t;
+    if (t == 0) counts[((size_t)w * nb + b) * NBRICK + bk] = total;
+  }
+}
+
+// lists u8[2][b][NBRICK][256], counts i32[2][b][NBRICK]; r in {8, 16, 32}
+extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned char *lists, int *counts, void *stream) {
+  if (b <= 0 || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nbrick = conv_bricks(r);
+  if (r == 32) hipLaunchKernelGGL(active_lists_kernel<32>, dim3(nbrick, b), dim3(256), 0, s, cnt, lists, counts, b);
+  else if (r == 16) hipLaunchKernelGGL(active_lists_kernel<16>, dim3(nbrick, b), dim3(256), 0, s, cnt, lists, counts, b);
+  else hipLaunchKernelGGL(active_lists_kernel<8>, dim3(nbrick, b), dim3(256), 0, s, cnt, lists, counts, b);
+  return p2pb_launch_status();
+}
+
+// the 27-tap MFMA loop of one input stage for nt (1..4, wave-uniform) gathered tiles. Tile-major inside a tap: the
+// six products of a tile run back to back on its accumulator (the co-resident wave covers the dependency gaps),
+// which keeps one code path for every tile count and only one tile's B fragments live at a time.
+template <int HH, int HW, int PLANE>
+__device__ __forceinline__ void compact_taps(f32x16 (&acc)[4], int nt, const u32x4 *__restrict__ tile,
+                                             const u32x4 *wchunk, size_t wsplit_stride, size_t wtap_stride,
+                                             const int (&nbase)[4], int khalf) {
+  // the A fragments are prefetched one (kd, kh) row = three taps ahead: with one or two tiles per wave a single tap
+  // (192 MFMA cycles per tile) is shorter than the L2 latency of the weight loads
+  u32x4 a_cur[3][3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) a_cur[q][s] = wchunk[(size_t)q * wtap_stride + s * wsplit_stride];
+#pragma unroll
+  for (int row = 0; row < 9; ++row) {
+    u32x4 a_nxt[3][3];
+    if (row + 1 < 9) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a_nxt[q][s] = wchunk[(size_t)(3 * row + 3 + q) * wtap_stride + s * wsplit_stride];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // pins the prefetch
+    constexpr int PA[6] = {0, 1, 2, 1, 0, 0}, PB[6] = {2, 1, 0, 0, 1, 0};  // small terms first, as the split kernel
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int toff = ((row / 3) * HH + row % 3) * HW + q;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n < nt) {
+          u32x4 bf[3];
+#pragma unroll
+          for (int s = 0; s < 3; ++s) bf[s] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+#pragma unroll
+          for (int t = 0; t < 6; ++t)
+            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[q][PA[t]]),
+                                                             __builtin_bit_cast(bf16x8, bf[PB[t]]), acc[n], 0, 0, 0);
+        }
+      }
+    }
+    if (row + 1 < 9) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a_cur[q][s] = a_nxt[q][s];
+    }
+  }
+}
+
+template <int R, int WM, bool XF>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
+                                                                const float *__restrict__ in,
+                                                                const unsigned short *__restrict__ wt,
+                                                                const float *__restrict__ bias,
+                                                                const float *__restrict__ out_class,
+                                                                const float *__restrict__ in_scale,
+                                                                const float *__restrict__ in_shift, int in_swish,
+                                                                const float *__restrict__ in_sub, int skip_zero,
+                                                                const unsigned char *__restrict__ alist,
+                                                                const int *__restrict__ acount,
+                                                                float *__restrict__ out, float *__restrict__ stats_part) {
+  using G = SplitGeom<R>;
+  constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
+  constexpr int PLANE = HD * HH * HW;
+  constexpr int BH = R / G::TH, BW = R / G::TW, BD = R / G::TD, NBRICK = BD * BH * BW;
+  constexpr int R3 = R * R * R;
+  constexpr int WN = 4 / WM;
+  __shared__ u32x4 tile[3 * 2 * PLANE];
+  __shared__ unsigned char lst[256];
+  __shared__ int ncls[27];
+  __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, khalf = lane >> 5;
+  // XCD-aware order (see the split kernel): XCD x gets the x-th contiguous eighth of (sample, brick, channel block)
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+  const int ncoblk = (cout + 32 * WM - 1) / (32 * WM);
+  const unsigned v = nblk % 8 == 0 ? (lin % 8) * (nblk / 8) + lin / 8 : lin;
+  const unsigned per_sample = NBRICK * ncoblk;
+  const int b = v / per_sample;
+  const int brick = (v % per_sample) / ncoblk, coblk = (v % per_sample) % ncoblk;
+  const int bd = brick / (BH * BW), bh = (brick / BW) % BH, bw = brick % BW;
+  const int d0 = bd * G::TD, h0 = bh * G::TH, w0 = bw * G::TW;
+  const int wm = wave / WN, wn = wave % WN;
+  const int cob = coblk * (32 * WM);  // first channel of the workgroup
+  const int co0 = cob + 32 * wm;      // first channel of this wave's M-tile
+
+  const int count = acount[(size_t)b * NBRICK + brick];
+  lst[tid] = alist[((size_t)b * NBRICK + brick) * 256 + tid];
+  if (tid < 27) ncls[tid] = 0;
+  __syncthreads();
+  const int ntiles = (count + 31) >> 5;
+  auto vox_of = [&](int l, int &cls) {
+    const int d = d0 + (l >> 6), h = h0 + ((l >> 3) & 7), w = w0 + (l & 7);
+    const int cd = d == 0 ? 0 : (d == R - 1 ? 2 : 1), ch = h == 0 ? 0 : (h == R - 1 ? 2 : 1),
+              cw = w == 0 ? 0 : (w == R - 1 ? 2 : 1);
+    cls = (cd * 3 + ch) * 3 + cw;
+    return (d * R + h) * R + w;
+  };
+
+  constexpr int NP = (PLANE + 255) / 256;
+  int soff[NP];
+  unsigned voff[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int e = tid + j * 256;
+    const int dz = e / (HH * HW), hy = (e / HW) % HH, wx = e % HW;
+    const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = w0 - 1 + wx;
+    const bool ok = e < PLANE && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
+    soff[j] = ok ? (d * R + h) * R + w : -1;
+    voff[j] = ok ? (unsigned)soff[j] * (unsigned)cin * 4u : 0x80000000u;
+  }
+  const float *inb = in + (size_t)b * cin * R3;
+  float *outb = out + (size_t)b * cout * R3;
+  float stg[CONV_SCK][NP];
+  auto stage_load = [&](int ci0) {
+    auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)inb, 0, R3 * cin * 4, 0x00020000);
+    if ((cin & 3) == 0) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int q = 0; q < CONV_SCK / 4; ++q) {
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[j] + (unsigned)(ci0 + 4 * q) * 4u, 0, 0));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) stg[4 * q + i][j] = x[i];
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int c = 0; c < CONV_SCK; ++c)
+          stg[c][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[j] + (unsigned)(ci0 + c) * 4u, 0, 0));
+    }
+  };
+
+  if (l31 == 31) {  // this wave's statistics accumulate in LDS across the passes (touched by lanes 31 / 63 only)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wstat[wave][khalf][r][0] = wstat[wave][khalf][r][1] = 0.0f;
+  }
+
+  // WM = 4: the wave takes tiles 4p .. 4p+3 in pass p; WM = 2: wave column wn takes tiles wn, wn+2, wn+4, wn+6
+  const int npass = WM == 4 ? (ntiles + 3) / 4 : (ntiles > 0 ? 1 : 0);
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+    int nt = 0, nbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tl = (4 * pass + i) * WN + wn;
+      if (tl < ntiles) nt = i + 1;
+      const int o = tl * 32 + l31;
+      const int l = lst[o < count ? o : 0];
+      nbase[i] = ((l >> 6) * HH + ((l >> 3) & 7)) * HW + (l & 7);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    stage_load(0);
+    for (int ci0 = 0; ci0 < cin; ci0 += CONV_SCK) {
+      __syncthreads();
+      int nonzero = 0;
+#pragma unroll
+      for (int c = 0; c < CONV_SCK; ++c) {
+        float sc = 1.0f, sh = 0.0f, sub = 0.0f;
+        const bool cok = ci0 + c < cin;
+        if (XF && cok) {
+          sc = in_scale[b * cin + ci0 + c];
+          sh = in_shift[b * cin + ci0 + c];
+          if (in_sub) sub = in_sub[b * cin + ci0 + c];
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          float x = cok ? stg[c][j] : 0.0f;
+          if (XF && cok && soff[j] >= 0) x = xf_apply(x, sc, sh, in_swish) - sub;
+          nonzero |= (x != 0.0f);
+          stg[c][j] = x;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int e = tid + j * 256;
+        if (e < PLANE) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            u32x4 q[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              unsigned p0, p1, p2;
+              split3(stg[h * 8 + 2 * i][j], stg[h * 8 + 2 * i + 1][j], p0, p1, p2);
+              q[0][i] = p0;
+              q[1][i] = p1;
+              q[2][i] = p2;
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
+          }
+        }
+      }
+      const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
+      if (ci0 + CONV_SCK < cin) {
+        int nxt = ci0 + CONV_SCK;
+        asm volatile("" : "+s"(nxt));
+        stage_load(nxt);
+      }
+      if (!any || nt == 0) continue;
+      const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
+      const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
+      compact_taps<HH, HW, PLANE>(acc, nt, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
+    }
+    __syncthreads();  // the tile is re-staged by the next pass
+
+    // ---- the pass's active outputs: bias / class constant, 16-byte voxel-major stores, statistics
+    int ovox[4], ocls[4];
+    bool oact[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = ((4 * pass + i) * WN + wn) * 32 + l31;
+      oact[i] = i < nt && o < count;
+      ovox[i] = vox_of(lst[oact[i] ? o : 0], ocls[i]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float vv[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g + i;
+        const int co = co0 + i + 8 * g + 4 * khalf;
+        const bool cok = co < cout;
+        const float bv = (cok && !out_class) ? bias[co] : 0.0f;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          float x = acc[n][r] + bv;
+          if (out_class && cok) x += out_class[((size_t)b * 27 + ocls[n]) * cout + co];
+          vv[n][i] = x;
+          if (oact[n]) {
+            s1 += x;
+            s2 += x * x;
+          }
+        }
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31) {
+          wstat[wave][khalf][r][0] += s1;
+          wstat[wave][khalf][r][1] += s2;
+        }
+      }
+      const int cq = co0 + 8 * g + 4 * khalf;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (!oact[n]) continue;
+        float *q = outb + (size_t)ovox[n] * cout + cq;
+        if (cq + 3 < cout && (cout & 3) == 0) *(f32x4 *)q = f32x4{vv[n][0], vv[n][1], vv[n][2], vv[n][3]};
+        else
+          for (int i = 0; i < 4; ++i)
+            if (cq + i < cout) q[i] = vv[n][i];
+      }
+    }
+  }
+
+  // ---- the brick's other voxels: their constant, and its exact share of the statistics
+  const int ninact = 256 - count;
+  for (int e = tid; e < ninact; e += 256) {
+    int cls;
+    (void)vox_of(lst[count + e], cls);
+    atomicAdd(&ncls[cls], 1);
+  }
+  __syncthreads();
+  const int cw = min(32 * WM, cout - cob);  // channels of this workgroup
+  const float *kb = out_class ? out_class + (size_t)b * 27 * cout : nullptr;
+  for (int e = tid; e < ninact * cw; e += 256) {
+    const int vi = e / cw, c = e - vi * cw;
+    int cls;
+    const int vx = vox_of(lst[count + vi], cls);
+    outb[(size_t)vx * cout + cob + c] = kb ? kb[cls * cout + cob + c] : bias[cob + c];
+  }
+  if (stats_part) {
+    // slots of the brick: [0, WN) = the wave columns' active sums, WN = the constants' sums, the rest zero
+    float *sp = stats_part + (((size_t)b * NBRICK + brick) * 4) * cout * 2;
+    if (l31 == 31) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (co < cout) {
+          sp[((size_t)wn * cout + co) * 2] = wstat[wave][khalf][r][0];
+          sp[((size_t)wn * cout + co) * 2 + 1] = wstat[wave][khalf][r][1];
+        }
+      }
+    }
+    if (tid < cw) {
+      const int co = cob + tid;
+      float s1 = 0.0f, s2 = 0.0f;
+      if (kb) {
+        for (int c = 0; c < 27; ++c) {
+          const float x = kb[c * cout + co], n = (float)ncls[c];
+          s1 += n * x;
+          s2 += n * x * x;
+        }
+      } else {
+        const float x = bias[co];
+        s1 = (float)ninact * x;
+        s2 = (float)ninact * x * x;
+      }
+      sp[((size_t)WN * cout + co) * 2] = s1;
+      sp[((size_t)WN * cout + co) * 2 + 1] = s2;
+      for (int sl = WN + 1; sl < 4; ++sl) {
+        sp[((size_t)sl * cout + co) * 2] = 0.0f;
+        sp[((size_t)sl * cout + co) * 2 + 1] = 0.0f;
+      }
+    }
+  }
+}
+
+// in f32[b,r,r,r,cin] -> out f32[b,r,r,r,cout] (voxel-major), wt = split pack; alist/acount = ONE set of
+// p2pb_conv3d_active_lists (D1 for a first convolution, D2 for a second one in far-field form). r in {8,16,32}.
+extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split,
+                                              const float *bias, const float *out_class, const float *in_scale,
+                                              const float *in_shift, int in_swish, const float *in_sub,
+                                              const unsigned char *alist, const int *acount, float *out,
+                                              float *stats_part, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !alist || !acount || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
+  const unsigned short *w = (const unsigned short *)wt_split;
+  const bool wm4 = false;  // cout > 64: 128 channels per workgroup -- needs two passes above 4 tiles, slower
+  dim3 grid(conv_bricks(r), (cout + (wm4 ? 127 : 63)) / (wm4 ? 128 : 64), b);
+#define LAUNCH(RR, WMV, XF)                                                                                          \
+  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in, w, \
+                     bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part)
+#define GO(RR)                                                   \
+  if (wm4) {                                                     \
+    if (in_scale) LAUNCH(RR, 4, true);                           \
+    else LAUNCH(RR, 4, false);                                   \
+  } else {                                                       \
+    if (in_scale) LAUNCH(RR, 2, true);                           \
+    else LAUNCH(RR, 2, false);                                   \
+  }
+  if (r == 32) { GO(32) } else if (r == 16) { GO(16) } else { GO(8) }
+#undef GO
+#undef LAUNCH
+  return p2pb_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------

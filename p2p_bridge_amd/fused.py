@@ -110,6 +110,36 @@ def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None
     return y, st
 
 
+def active_lists(cnt, r):
+    """cnt i32[B, r^3] (voxel occupancy) -> (lists u8[2,B,NBRICK,256], counts i32[2,B,NBRICK]): per 4x8x8 brick the
+    local ids of the voxels in D1 = dilate(occupied, 1) (index 0: outputs of a first convolution that are not the
+    bias) and D2 = dilate(D1, 1) (index 1: outputs of a far-field second convolution that are not the class constant)"""
+    b = cnt.shape[0]
+    nb = {32: 128, 16: 16, 8: 2}[int(r)]
+    lists = torch.empty(2, b, nb, 256, dtype=torch.uint8, device=cnt.device)
+    counts = torch.empty(2, b, nb, dtype=torch.int32, device=cnt.device)
+    call("p2pb_conv3d_active_lists", _i(b), _i(int(r)), ptr(cnt), ptr(lists), ptr(counts), stream_ptr())
+    return lists, counts
+
+
+def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
+                      out_class=None):
+    """compact sparse conv on voxel-major grids (csrc/conv3d.hip): only the listed outputs of every brick are computed,
+    the others get their constant. which = 0: first convolution of a PVConv (set D1); which = 1: second one in
+    far-field form (set D2; in_sub / out_class from conv3d_far_field). x f32[B,r,r,r,Cin] -> (y f32[B,r,r,r,Cout], stats)"""
+    check(x, F32, "x")
+    b, r, ci = x.shape[0], x.shape[1], x.shape[4]
+    co = conv.out_channels
+    wt = pack_conv3d_weight(conv, True)
+    y = torch.empty(b, r, r, r, co, dtype=F32, device=x.device)
+    nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
+    st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    call("p2pb_conv3d_k3_forward_compact", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(lists[which]), ptr(counts[which]), ptr(y), ptr(st),
+         stream_ptr())
+    return y, st
+
+
 def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
     """far-field constants for the sparse form of `conv` applied to swish(affine(prev conv output)):
     a f32[B,Cin] (operand value where the previous conv saw only zeros, i.e. where its output == prev_bias) and

@@ -309,7 +309,23 @@ class PVConv(nn.Module):
                                           self.voxelization.eps)
             v, cnt = fused.voxelize_cl(features.contiguous(), vox, r)
         r3 = float(r ** 3)
-        if r >= 32 and self.sparse_conv:  # at r = 16 every 4x8x8 brick touches the surface: dense is faster
+        c1, c2 = compact_plan()
+        if self.sparse_conv and (r in c1 or r in c2):
+            # voxel-level sparsity: only the outputs within one (first conv) / two (second conv, far-field form) voxels
+            # of an occupied voxel are computed, packed densely into the MFMA column tiles
+            if lists is None:
+                lists, counts = fused.active_lists(cnt, r)
+            if r in c1:
+                y1, st1 = fused.conv3d_k3_compact(v, vl[0], lists, counts, 0)
+            else:
+                y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True)
+            sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
+            if r in c2:
+                a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
+                y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k)
+            else:
+                y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True)
+        elif r >= 32 and self.sparse_conv:  # at r = 16 every 4x8x8 brick touches the surface: dense is faster
             if lists is None:
                 lists, counts = fused.brick_lists(cnt, r)
             y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0, channels_last=True)
@@ -350,6 +366,16 @@ class PVConv(nn.Module):
             fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
         data.features = self.point_features.run(features, cond, residual=fused)
         return data
+
+
+def compact_plan():
+    """resolutions whose first / second PVConv convolution run in compact (voxel-level sparse) form;
+    P2PB_COMPACT="32,16,8:32,16" overrides (empty = the brick-level kernels)"""
+    import os
+
+    spec = os.environ.get("P2PB_COMPACT", "32,16,8:32,16")
+    parts = (spec.split(":") + [""])[:2]
+    return tuple({int(t) for t in p.split(",") if t.strip()} for p in parts)
 
 
 class BallQuery(nn.Module):
@@ -635,7 +661,10 @@ class Geometry:
                     vcoords, vox = L.voxel_coords(c, r, normalize, eps)
                     cnt, ws = fused.voxel_sort(vox, r)
                     lists = counts = None
-                    if r >= 32:
+                    c1, c2 = compact_plan()
+                    if r in c1 or r in c2:
+                        lists, counts = fused.active_lists(cnt, r)
+                    elif r >= 32:
                         lists, counts = fused.brick_lists(cnt, r)
                     ev = torch.cuda.Event()
                     ev.record(side)

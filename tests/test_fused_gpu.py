@@ -375,3 +375,49 @@ def test_conv3d_sparse_lists_match_dense(fused, cout):
             assert rel_err(stats_of(sts)[1], stats_of(std)[1]) < 1e-6
             yc, stc = fused.conv3d_k3_sparse(gcl, conv, lists, counts, 0, math=math, channels_last=True)
             assert torch.equal(yc.permute(0, 4, 1, 2, 3), ys) and torch.equal(stc, sts)
+
+
+@pytest.mark.parametrize("r,C,C1,C2,N", [(32, 32, 48, 64, 2048), (16, 64, 128, 128, 1024), (8, 24, 160, 40, 300), (16, 19, 64, 200, 600)])
+def test_conv3d_compact_matches_dense(fused, r, C, C1, C2, N):
+    """a PVConv's two convolutions in compact form (only the outputs in D1 / D2 computed, constants elsewhere) vs the
+    dense split kernel: identical values on every voxel, same statistics; the active sets are supersets of the
+    non-constant outputs by construction, checked here against the dense results"""
+    from p2p_bridge_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(r + C)
+    B = 3
+    pts = torch.nn.functional.normalize(torch.randn(B, 3, N, device="cuda"), dim=1) * 0.8 + 0.05 * torch.randn(B, 3, N, device="cuda")
+    _, vox = ext.voxel_coords(pts, r)
+    f = torch.randn(B, C, N, device="cuda")
+    grid, cnt = fused.voxelize_cl(f, vox, r)
+    conv1, conv2 = torch.nn.Conv3d(C, C1, 3, padding=1).cuda(), torch.nn.Conv3d(C1, C2, 3, padding=1).cuda()
+    lists, counts = fused.active_lists(cnt, r)
+    nb = lists.shape[2]
+    assert 0 < counts[0].sum().item() < B * nb * 256 and (counts[1] >= counts[0]).all()
+    # every list is a permutation of the brick's 256 local ids whose first `count` entries are exactly D1 / D2
+    assert torch.equal(lists.long().sort(dim=-1).values, torch.arange(256, device="cuda").expand_as(lists))
+    occ = (cnt.view(B, 1, r, r, r) > 0).float()
+    d1 = torch.nn.functional.max_pool3d(occ, 3, 1, 1)
+    d2 = torch.nn.functional.max_pool3d(d1, 3, 1, 1)
+    for which, dset in enumerate((d1, d2)):
+        # [B,1,r,r,r] -> bricks of 4x8x8 in (bd, bh, bw) order, local id (ld*8 + lh)*8 + lw
+        bricks = dset.view(B, r // 4, 4, r // 8, 8, r // 8, 8).permute(0, 1, 3, 5, 2, 4, 6).reshape(B, nb, 256)
+        assert torch.equal(bricks.sum(-1).int(), counts[which])
+        pos = torch.arange(256, device="cuda").expand(B, nb, 256)
+        listed = torch.zeros(B, nb, 256, device="cuda").scatter_(2, lists[which].long(), (pos < counts[which][..., None]).float())
+        assert torch.equal(listed, bricks)
+    with torch.no_grad():
+        y1d, st1d = fused.conv3d_k3(grid, conv1, compact=True, channels_last=True, math="bf16x6")
+        y1c, st1c = fused.conv3d_k3_compact(grid, conv1, lists, counts, 0)
+        assert torch.equal(y1c, y1d)
+        assert rel_err(stats_of(st1c)[1], stats_of(st1d)[1]) < 1e-5
+        sc, sh = torch.rand(B, C1, device="cuda") + 0.5, torch.randn(B, C1, device="cuda")
+        a, k = fused.conv3d_far_field(conv1.bias, conv2, sc, sh, True)
+        y2d, st2d = fused.conv3d_k3(y1d, conv2, sc, sh, swish=True, compact=True, channels_last=True, math="bf16x6",
+                                    in_sub=a, out_class=k)
+        y2c, st2c = fused.conv3d_k3_compact(y1c, conv2, lists, counts, 1, sc, sh, True, in_sub=a, out_class=k)
+        assert torch.equal(y2c, y2d)
+        assert rel_err(stats_of(st2c)[1], stats_of(st2d)[1]) < 1e-5
+        # and the far-field form itself equals the plain convolution of the transformed operand
+        xin = swish(y1d.double() * sc[:, None, None, None, :] + sh[:, None, None, None, :]).permute(0, 4, 1, 2, 3)
+        ref = torch.nn.functional.conv3d(xin, conv2.weight.double(), conv2.bias.double(), padding=1)
+        assert rel_err(y2c.permute(0, 4, 1, 2, 3), ref) < TOL
