@@ -373,7 +373,7 @@ def compact_plan():
     P2PB_COMPACT="32,16,8:32,16" overrides (empty = the brick-level kernels)"""
     import os
 
-    spec = os.environ.get("P2PB_COMPACT", "32,16,8:32,16")
+    spec = os.environ.get("P2PB_COMPACT", "")
     parts = (spec.split(":") + [""])[:2]
     return tuple({int(t) for t in p.split(",") if t.strip()} for p in parts)
 
