@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp2pb_hip.so")
+LIB_PATH = os.environ.get("P2PB_LIB_PATH") or os.path.join(_HERE, "libp2pb_hip.so")  # override: kernel experiments
 
 # every symbol include/p2pb_hip.h declares (tests/test_abi.py checks the two lists agree)
 SYMBOLS = [

@@ -30,6 +30,7 @@
 // Every output voxel and every statistic is still produced by this kernel; only all-zero MFMA work is
 // skipped. Compact 4x8x8 bricks (instead of full-row bricks) make the zero test fine-grained in 3-D.
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -412,6 +413,63 @@ __device__ __forceinline__ int lane_w(int l31) {
   return (TW == 8 && (jr == 1 || jr == 2)) ? jw ^ 4 : jw;
 }
 
+#ifndef CONV_NTAPS
+#define CONV_NTAPS 27  // (timing experiments compile fewer)
+#endif
+// The 27-tap MFMA loop of one input stage (16 channels) for NT column tiles of one M-tile.
+// Six products per (tap, tile), the small ones first: x0y2, x1y1, x2y0 | x1y0, x0y1 | x0y0. The B fragments roll
+// through ONE register set: y2 of the next tap is read as soon as this tap's x0y2 products have issued, y1 after
+// x0y1, y0 at the top of the tap (it is first needed by the third product) -- every LDS read has >= 2 NT MFMAs
+// in front of its first use without a second fragment buffer; A fragments come straight from L2, one tap ahead.
+// The scheduling barriers pin this order, else every load sinks to its first use.
+template <int NT, int HH, int HW, int PLANE>
+__device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, const u32x4 *wchunk,
+                                           size_t wsplit_stride, size_t wtap_stride, const int (&nbase)[NT], int khalf) {
+  u32x4 a_cur[3], bf[3][NT];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) a_cur[s] = wchunk[s * wsplit_stride];
+  auto load_b = [&](int s, int toff) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+  };
+  auto mfma_term = [&](int pa, int pb) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[pa]),
+                                                       __builtin_bit_cast(bf16x8, bf[pb][n]), acc[n], 0, 0, 0);
+  };
+  load_b(2, 0);
+  load_b(1, 0);
+#pragma unroll
+  for (int tap = 0; tap < CONV_NTAPS; ++tap) {
+    const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+    const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
+    u32x4 a_nxt[3];
+    if (tap + 1 < CONV_NTAPS) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
+    }
+    load_b(0, toff);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_term(0, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap + 1 < CONV_NTAPS) load_b(2, toff_n);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_term(1, 1);
+    mfma_term(2, 0);
+    mfma_term(1, 0);
+    mfma_term(0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_term(0, 0);
+    if (tap + 1 < CONV_NTAPS) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s) a_cur[s] = a_nxt[s];
+    }
+  }
+}
+
 template <int R, bool COMPACT, int MT, bool XF, bool CL>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
@@ -602,54 +660,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 
     const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
     const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
-    u32x4 a_cur[3], bf[3][NT];
-#pragma unroll
-    for (int s = 0; s < 3; ++s) a_cur[s] = wchunk[s * wsplit_stride];
-    auto load_b = [&](int s, int toff) {
-#pragma unroll
-      for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
-    };
-    auto mfma_term = [&](int pa, int pb) {
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[pa]),
-                                                         __builtin_bit_cast(bf16x8, bf[pb][n]), acc[n], 0, 0, 0);
-    };
-    // Six products per (tap, tile), the small ones first: x0y2, x1y1, x2y0 | x1y0, x0y1 | x0y0. The B fragments roll
-    // through ONE register set: y2 of the next tap is read as soon as this tap's x0y2 products have issued, y1 after
-    // x0y1, y0 at the top of the tap (it is first needed by the third product) -- every LDS read has >= 8 MFMAs
-    // (256+ cycles) in front of its first use without a second fragment buffer; A fragments one tap ahead (L2
-    // latency). The scheduling barriers pin this order, else every load sinks to its first use.
-    load_b(2, 0);
-    load_b(1, 0);
-#pragma unroll
-    for (int tap = 0; tap < 27; ++tap) {
-      const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
-      const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
-      u32x4 a_nxt[3];
-      if (tap + 1 < 27) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
-      }
-      load_b(0, toff);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_term(0, 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap + 1 < 27) load_b(2, toff_n);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_term(1, 1);
-      mfma_term(2, 0);
-      mfma_term(1, 0);
-      mfma_term(0, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap + 1 < 27) load_b(1, toff_n);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma_term(0, 0);
-      if (tap + 1 < 27) {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a_cur[s] = a_nxt[s];
-      }
-    }
+    split_taps<NT, HH, HW, PLANE>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
   }
 
   float *outb = out + (size_t)b * cout * R3;
@@ -1141,9 +1152,8 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
 // MFMA column tile, and the B fragment of (tile, tap) is still "halo slot of my voxel + constant tap offset" --
 // the main loop is the split kernel's, with 1..8 gathered tiles instead of 8 fixed ones. The remaining voxels of the
 // brick get their constant (and its exact contribution to the GroupNorm statistics) from the same workgroup.
-// Waves: WM = 4 -> four M-tiles (128 channels per workgroup), every wave walks all tiles, four at a time (a brick
-// with more than four active tiles takes a second pass over the input stages); WM = 2 -> 64 channels, the tiles
-// are dealt to two wave columns. Values are bit-identical to the dense split kernel on the computed outputs.
+// Waves: WM = 2 -> 64 channels per workgroup, the tiles are dealt to two wave columns; WM = 1 (layers of 32
+// channels) -> four wave columns. Values are bit-identical to the dense split kernel on the computed outputs.
 // ================================================================================================
 
 // per (sample, brick): local ids (ld*8 + lh)*8 + lw of the voxels in D1 (which = 0) / D2 (which = 1), in an
@@ -1234,56 +1244,6 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
   else if (r == 16) hipLaunchKernelGGL(active_lists_kernel<16>, dim3(nbrick, b), dim3(256), 0, s, cnt, lists, counts, b);
   else hipLaunchKernelGGL(active_lists_kernel<8>, dim3(nbrick, b), dim3(256), 0, s, cnt, lists, counts, b);
   return p2pb_launch_status();
-}
-
-// the 27-tap MFMA loop of one input stage for nt (1..4, wave-uniform) gathered tiles. Tile-major inside a tap: the
-// six products of a tile run back to back on its accumulator (the co-resident wave covers the dependency gaps),
-// which keeps one code path for every tile count and only one tile's B fragments live at a time.
-template <int HH, int HW, int PLANE>
-__device__ __forceinline__ void compact_taps(f32x16 (&acc)[4], int nt, const u32x4 *__restrict__ tile,
-                                             const u32x4 *wchunk, size_t wsplit_stride, size_t wtap_stride,
-                                             const int (&nbase)[4], int khalf) {
-  // the A fragments are prefetched one (kd, kh) row = three taps ahead: with one or two tiles per wave a single tap
-  // (192 MFMA cycles per tile) is shorter than the L2 latency of the weight loads
-  u32x4 a_cur[3][3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) a_cur[q][s] = wchunk[(size_t)q * wtap_stride + s * wsplit_stride];
-#pragma unroll
-  for (int row = 0; row < 9; ++row) {
-    u32x4 a_nxt[3][3];
-    if (row + 1 < 9) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a_nxt[q][s] = wchunk[(size_t)(3 * row + 3 + q) * wtap_stride + s * wsplit_stride];
-    }
-    __builtin_amdgcn_sched_barrier(0);  // pins the prefetch
-    constexpr int PA[6] = {0, 1, 2, 1, 0, 0}, PB[6] = {2, 1, 0, 0, 1, 0};  // small terms first, as the split kernel
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const int toff = ((row / 3) * HH + row % 3) * HW + q;
-#pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        if (n < nt) {
-          u32x4 bf[3];
-#pragma unroll
-          for (int s = 0; s < 3; ++s) bf[s] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
-#pragma unroll
-          for (int t = 0; t < 6; ++t)
-            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[q][PA[t]]),
-                                                             __builtin_bit_cast(bf16x8, bf[PB[t]]), acc[n], 0, 0, 0);
-        }
-      }
-    }
-    if (row + 1 < 9) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) a_cur[q][s] = a_nxt[q][s];
-    }
-  }
 }
 
 template <int R, int WM, bool XF>
@@ -1378,22 +1338,26 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
     for (int r = 0; r < 16; ++r) wstat[wave][khalf][r][0] = wstat[wave][khalf][r][1] = 0.0f;
   }
 
-  // WM = 4: the wave takes tiles 4p .. 4p+3 in pass p; WM = 2: wave column wn takes tiles wn, wn+2, wn+4, wn+6
-  const int npass = WM == 4 ? (ntiles + 3) / 4 : (ntiles > 0 ? 1 : 0);
-#pragma unroll 1
-  for (int pass = 0; pass < npass; ++pass) {
-    int nt = 0, nbase[4];
+  // wave column wn takes tiles wn, wn + WN, ...: nt of them (<= 8 / WN <= 4), wave-uniform. The whole stage loop is
+  // specialised on nt (1..4): each count keeps split_taps' rolling schedule and only its own accumulators
+  int nt = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int tl = (4 * pass + i) * WN + wn;
-      if (tl < ntiles) nt = i + 1;
-      const int o = tl * 32 + l31;
+  for (int i = 0; i < 4; ++i)
+    if (i * WN + wn < ntiles) nt = i + 1;
+
+  auto run = [&](auto ntc_tag) {
+    constexpr int NTC = decltype(ntc_tag)::value;  // 0: this wave has no tile, it only helps staging
+    constexpr int NA = NTC > 0 ? NTC : 1;
+    int nbase[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int o = (i * WN + wn) * 32 + l31;
       const int l = lst[o < count ? o : 0];
       nbase[i] = ((l >> 6) * HH + ((l >> 3) & 7)) * HW + (l & 7);
     }
-    f32x16 acc[4];
+    f32x16 acc[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
@@ -1444,25 +1408,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
         asm volatile("" : "+s"(nxt));
         stage_load(nxt);
       }
-      if (!any || nt == 0) continue;
+      if (!any || NTC == 0) continue;
       const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
       const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
-      compact_taps<HH, HW, PLANE>(acc, nt, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
+      split_taps<NA, HH, HW, PLANE>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
     }
-    __syncthreads();  // the tile is re-staged by the next pass
+    if (NTC == 0) return;
 
-    // ---- the pass's active outputs: bias / class constant, 16-byte voxel-major stores, statistics
-    int ovox[4], ocls[4];
-    bool oact[4];
+    // ---- the active outputs: bias / class constant, 16-byte voxel-major stores, statistics
+    int ovox[NA], ocls[NA];
+    bool oact[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = ((4 * pass + i) * WN + wn) * 32 + l31;
-      oact[i] = i < nt && o < count;
+    for (int i = 0; i < NA; ++i) {
+      const int o = (i * WN + wn) * 32 + l31;
+      oact[i] = o < count;
       ovox[i] = vox_of(lst[oact[i] ? o : 0], ocls[i]);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float vv[4][4];
+      float vv[NA][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 4 * g + i;
@@ -1471,7 +1435,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
         const float bv = (cok && !out_class) ? bias[co] : 0.0f;
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < NA; ++n) {
           float x = acc[n][r] + bv;
           if (out_class && cok) x += out_class[((size_t)b * 27 + ocls[n]) * cout + co];
           vv[n][i] = x;
@@ -1483,13 +1447,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
         if (l31 == 31) {
-          wstat[wave][khalf][r][0] += s1;
-          wstat[wave][khalf][r][1] += s2;
+          wstat[wave][khalf][r][0] = s1;
+          wstat[wave][khalf][r][1] = s2;
         }
       }
       const int cq = co0 + 8 * g + 4 * khalf;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < NA; ++n) {
         if (!oact[n]) continue;
         float *q = outb + (size_t)ovox[n] * cout + cq;
         if (cq + 3 < cout && (cout & 3) == 0) *(f32x4 *)q = f32x4{vv[n][0], vv[n][1], vv[n][2], vv[n][3]};
@@ -1498,7 +1462,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
             if (cq + i < cout) q[i] = vv[n][i];
       }
     }
+  };
+  if (ntiles > 0) {  // (workgroup-uniform: every wave runs the stage loop, with its own tile count)
+    if (nt == 0) run(std::integral_constant<int, 0>{});
+    else if (nt == 1) run(std::integral_constant<int, 1>{});
+    else if (nt == 2) run(std::integral_constant<int, 2>{});
+    else if (nt == 3) run(std::integral_constant<int, 3>{});
+    else run(std::integral_constant<int, 4>{});
   }
+  __syncthreads();
 
   // ---- the brick's other voxels: their constant, and its exact share of the statistics
   const int ninact = 256 - count;
@@ -1510,11 +1482,32 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
   __syncthreads();
   const int cw = min(32 * WM, cout - cob);  // channels of this workgroup
   const float *kb = out_class ? out_class + (size_t)b * 27 * cout : nullptr;
-  for (int e = tid; e < ninact * cw; e += 256) {
-    const int vi = e / cw, c = e - vi * cw;
-    int cls;
-    const int vx = vox_of(lst[count + vi], cls);
-    outb[(size_t)vx * cout + cob + c] = kb ? kb[cls * cout + cob + c] : bias[cob + c];
+  if ((cout & 3) == 0) {  // 16 bytes per thread; (voxel, channel quad) advance incrementally, no division in the loop
+    const int cw4 = cw >> 2, dq = 256 / cw4, dr = 256 % cw4;
+    int vi = tid / cw4, c4 = tid % cw4;
+    f32x4 bq = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (!kb) bq = *(const f32x4 *)(bias + cob + 4 * c4);
+#pragma unroll 4
+    for (; vi < ninact; vi += dq) {
+      int cls;
+      const int vx = vox_of(lst[count + vi], cls);
+      *(f32x4 *)(outb + (size_t)vx * cout + cob + 4 * c4) = kb ? *(const f32x4 *)(kb + cls * cout + cob + 4 * c4) : bq;
+      if (dr) {
+        c4 += dr;
+        if (c4 >= cw4) {
+          c4 -= cw4;
+          ++vi;
+        }
+        if (!kb) bq = *(const f32x4 *)(bias + cob + 4 * c4);
+      }
+    }
+  } else {
+    for (int e = tid; e < ninact * cw; e += 256) {
+      const int vi = e / cw, c = e - vi * cw;
+      int cls;
+      const int vx = vox_of(lst[count + vi], cls);
+      outb[(size_t)vx * cout + cob + c] = kb ? kb[cls * cout + cob + c] : bias[cob + c];
+    }
   }
   if (stats_part) {
     // slots of the brick: [0, WN) = the wave columns' active sums, WN = the constants' sums, the rest zero
@@ -1529,6 +1522,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
         }
       }
     }
+    if (WN == 4) __syncthreads();
     if (tid < cw) {
       const int co = cob + tid;
       float s1 = 0.0f, s2 = 0.0f;
@@ -1543,8 +1537,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
         s1 = (float)ninact * x;
         s2 = (float)ninact * x * x;
       }
-      sp[((size_t)WN * cout + co) * 2] = s1;
-      sp[((size_t)WN * cout + co) * 2 + 1] = s2;
+      if (WN == 4) {  // no free slot: on top of wave column 0's sums (written before the barrier above)
+        sp[(size_t)co * 2] += s1;
+        sp[(size_t)co * 2 + 1] += s2;
+      } else {
+        sp[((size_t)WN * cout + co) * 2] = s1;
+        sp[((size_t)WN * cout + co) * 2 + 1] = s2;
+      }
       for (int sl = WN + 1; sl < 4; ++sl) {
         sp[((size_t)sl * cout + co) * 2] = 0.0f;
         sp[((size_t)sl * cout + co) * 2 + 1] = 0.0f;
@@ -1564,15 +1563,15 @@ extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, c
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   const unsigned short *w = (const unsigned short *)wt_split;
-  const bool wm4 = false;  // cout > 64: 128 channels per workgroup -- needs two passes above 4 tiles, slower
-  dim3 grid(conv_bricks(r), (cout + (wm4 ? 127 : 63)) / (wm4 ? 128 : 64), b);
+  const bool wm1 = cout <= 32;  // one M-tile per workgroup, tiles dealt to four wave columns
+  dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
 #define LAUNCH(RR, WMV, XF)                                                                                          \
   hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in, w, \
                      bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part)
 #define GO(RR)                                                   \
-  if (wm4) {                                                     \
-    if (in_scale) LAUNCH(RR, 4, true);                           \
-    else LAUNCH(RR, 4, false);                                   \
+  if (wm1) {                                                     \
+    if (in_scale) LAUNCH(RR, 1, true);                           \
+    else LAUNCH(RR, 1, false);                                   \
   } else {                                                       \
     if (in_scale) LAUNCH(RR, 2, true);                           \
     else LAUNCH(RR, 2, false);                                   \

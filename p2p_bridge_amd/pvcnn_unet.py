@@ -370,10 +370,10 @@ class PVConv(nn.Module):
 
 def compact_plan():
     """resolutions whose first / second PVConv convolution run in compact (voxel-level sparse) form;
-    P2PB_COMPACT="32,16,8:32,16" overrides (empty = the brick-level kernels)"""
+    default: r = 16 (measured: +2.5 %; at r = 32 the brick-level lists win, at r = 8 the dense kernel); P2PB_COMPACT="32,16:16" overrides, empty = off"""
     import os
 
-    spec = os.environ.get("P2PB_COMPACT", "")
+    spec = os.environ.get("P2PB_COMPACT", "16:16")
     parts = (spec.split(":") + [""])[:2]
     return tuple({int(t) for t in p.split(",") if t.strip()} for p in parts)
 
