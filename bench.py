@@ -42,10 +42,11 @@ CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample p
 
 
 def conv_roofline(model, B, reps=10):
-    """Dominant kernel = the 3x3x3 voxel convolution (csrc/conv3d.hip), timed live on the instance that costs
-    the sampler most (fp_layers.2.{1,2} second conv: C 128->128, r=16, compact bricks, folded AdaGN+Swish
-    operand transform, GroupNorm statistics epilogue -- exactly as the sampler launches it, 3x per network
-    evaluation) with HIP events on the stream the kernel is launched on (torch's current stream).
+    """Second kernel = the 3x3x3 voxel convolution (csrc/conv3d.hip) in its dense split form, timed on the widest
+    instance (fp_layers.2.{1,2} second conv: C 128->128, r=16, folded AdaGN+Swish operand transform, GroupNorm
+    statistics epilogue; the sampler runs this layer through the voxel-level compact variant of the same kernel, whose
+    work depends on the occupancy, so the dense form is the one with a well-defined FLOP count) with HIP events on the
+    stream the kernel is launched on (torch's current stream).
     `achieved` counts ALGORITHMIC fp32 FLOPs (2*27*Cin*Cout per voxel). Default arithmetic: bf16x6 split
     operands on the bf16 matrix pipe (six MFMA products per fp32 product), so `peak` is the dense bf16 MFMA
     peak / 6; with P2PB_CONV_MATH=fp32 it is the exact-fp32 MFMA kernel against the fp32 MFMA peak."""
@@ -79,6 +80,56 @@ def conv_roofline(model, B, reps=10):
                              "halo of a 4x8x8 brick re-reads the input 2.34x, about half of it absorbed by the per-XCD L2 (XCD-aware order)",
             "kernel": f"{kname}<{r},compact,2,XF,voxel-major> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
                       f"(fp_layers.2.1.voxel_layers.4)",
+            "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
+                           "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def gemm_roofline(model, B, P, reps=10):
+    """Dominant kernel of the sampler (largest share of the critical stream in profiles/r01*_per_eval.csv):
+    pw_split_kernel<XF=false, POOL=true> on the global embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels
+    over all P points of every patch; models/pvcnn.py:905-932): split-operand (bf16x6) GEMM whose epilogue emits the
+    GroupNorm statistics and the per-channel {min, max} the max-pool is formed from -- the 1024-channel output is
+    never written. Timed live with HIP events on torch's current stream, launched exactly as the sampler launches it
+    (the folded norm+Swish of its operand runs in a separate pre-pass there, as here it is simply absent).
+    `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
+    from p2p_bridge_amd import fused
+
+    conv = model.model.global_pnet.mlp2.shared_mlp_1.mlp[0]
+    ci, co = conv.in_channels, conv.out_channels
+    x = torch.randn(B, ci, P, device="cuda")
+    flops = 2.0 * B * P * ci * co
+    with torch.no_grad():
+        for _ in range(3):
+            fused.pw_conv(x, conv, pool_u=0, store=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fused.pw_conv(x, conv, pool_u=0, store=False)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = flops / (ms * 1e-3) / 1e12
+    split = fused.use_split_pw(ci, co, P, None)
+    peak = SPLIT_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
+    traffic = None
+    try:
+        vals = {}
+        for line in open(os.path.join(ROOT, "profiles", "r01_pmc_pw_split_512_1024_pool.csv")):
+            k, v = line.split(",")[:2]
+            if k in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[k] = float(v)
+        traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0) if split else None
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_basis": "profiles/r01_pmc_pw_split_512_1024_pool.csv: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch "
+                             "(FETCH_SIZE counts half of 8- and 16-byte-per-lane streaming reads on gfx950: calibrated on a "
+                             f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 6 * ci * co} B: "
+                             "the activations are staged by 8 output-channel blocks, the per-XCD L2 absorbs 3/4 of that",
+            "kernel": f"pw_split_kernel<XF=false,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)",
             "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
                            "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
@@ -205,7 +256,8 @@ def main():
                    "conv_math": conv_math_note()},
     }
     if rank == 0:
-        res["roofline"] = conv_roofline(model, args.batch)
+        res["roofline"] = gemm_roofline(model, args.batch, args.points)
+        res["roofline"]["second_kernel"] = conv_roofline(model, args.batch)  # the voxel convolution, same protocol
         evals = args.T
         res["roofline"]["sampler_dense_tflops"] = round(
             61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval

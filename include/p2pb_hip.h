@@ -98,6 +98,22 @@ int p2pb_gather_features_backward(int b, int c, int n, int m, const float *grad_
 int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float *dist_ws, int *idx,
                                  void *stream);
 
+/* the same sampling for ONE large cloud (object merge, denoise_object.py:112: 3N patch points -> N): 64 workgroups
+ * share a cloud, points and running distances stay in registers, one global all-gather per round. Same indices as
+ * p2pb_furthest_point_sampling. 16384 < n <= 524288, b <= 2 (b*64 workgroups must be resident together);
+ * ws: p2pb_fps_coop_ws_bytes(b) bytes, its last int is an error flag (1 = a workgroup never arrived). */
+size_t p2pb_fps_coop_ws_bytes(int b);
+int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx, void *stream);
+
+/* exact K nearest neighbours with patch-sized K: replaces pytorch3d.ops.knn_points(seeds, cloud, K, return_nn=True)
+ * as called by denoise_object.py:91 (pytorch3d: pip dependency, not vendored; contract = the K smallest squared
+ * distances per query, ascending, with indices). Ties: ascending point index.
+ *   query f32[b,s,3], points f32[b,n,3] (point-major) -> dist2 f32[b,s,k], idx i32[b,s,k], nn f32[b,s,k,3]
+ *   (any output may be NULL); 1 <= k <= min(n, 4096); ws: p2pb_knn_points_ws_bytes(b,s,n) bytes of scratch. */
+size_t p2pb_knn_points_ws_bytes(int b, int s, int n);
+int p2pb_knn_points(int b, int s, int n, int k, const float *query, const float *points, float *dist2, int *idx,
+                    float *nn, void *ws, void *stream);
+
 /* 3-NN inverse-squared-distance interpolation: replaces three_nearest_neighbors_interpolate() /
  * _grad() PN2/pvcnn_neighbor_interpolate.cuh:4-14 (kernels PN2/pvcnn_neighbor_interpolate_gpu.cu:20,96,154).
  *   points f32[b,3,n], centers f32[b,3,m], cfeat f32[b,c,m] -> idx i32[b,3,n], w f32[b,3,n], out f32[b,c,n] */

@@ -287,3 +287,44 @@ def auction_backward(xyz1, xyz2, gradxyz, graddist, idx):
 
 
 emd_assignment = types.SimpleNamespace(forward=auction_forward, backward=auction_backward)
+
+
+# ---- object patch pipeline: restatements of the reference's host code on the oracle ops
+def knn_points(p1, p2, K):
+    """pytorch3d.ops.knn_points contract (denoise_object.py:91): -> (dists f32[B,S,K] ascending, idx i64[B,S,K],
+    knn f32[B,S,K,3]); full sort by (distance, index) in orc_knn_points"""
+    _chk(p1, F32), _chk(p2, F32)
+    b, s, _ = p1.shape
+    n = p2.shape[1]
+    d = torch.empty(b, s, K, dtype=F32)
+    idx = torch.empty(b, s, K, dtype=I32)
+    lib().orc_knn_points(_i(b), _i(s), _i(n), _i(K), _p(p1), _p(p2), _p(d), _p(idx))
+    nn = torch.gather(p2[:, None].expand(b, s, n, 3), 2, idx.long()[..., None].expand(b, s, K, 3))
+    return d, idx.long(), nn
+
+
+def farthest_point_sampling(pcls, num_pnts):
+    """models/evaluation.py:297-311: torch_cluster.fps(x, ratio=0.01+num/N, random_start=False)[:num] = the first
+    `num` rounds of FPS from index 0 (published torch_cluster contract; squared distances, first maximum)"""
+    idx = furthest_point_sampling_forward(pcls.transpose(1, 2).contiguous(), int(num_pnts)).long()
+    b = pcls.shape[0]
+    return torch.gather(pcls, 1, idx[..., None].expand(b, int(num_pnts), 3)), [idx[i] for i in range(b)]
+
+
+def patch_based_denoise(sample_fn, pcl_noisy, patch_size, seed_k=3, trace=None):
+    """denoise_object.py:87-113 with `sample_fn(x_start [S,3,K]) -> x_pred [S,3,K]` standing for model.sample"""
+    N, d = pcl_noisy.shape
+    pcl = pcl_noisy.unsqueeze(0).contiguous()
+    seeds, seed_idx = farthest_point_sampling(pcl, int(seed_k * N / patch_size))
+    _, patch_idx, nn = knn_points(seeds, pcl, patch_size)
+    patches = nn[0]
+    centers = patches.mean(dim=1, keepdim=True)
+    patches = patches - centers
+    scale = torch.max(torch.norm(patches, dim=-1))
+    patches = patches / scale
+    den = sample_fn(patches.transpose(1, 2).contiguous()).transpose(1, 2)
+    den = den * scale + centers
+    out, fps_idx = farthest_point_sampling(den.reshape(1, -1, d).contiguous(), N)
+    if trace is not None:
+        trace.update(seed_idx=seed_idx[0], patch_idx=patch_idx[0], patches_denoised=den, fps_idx=fps_idx[0])
+    return out[0]

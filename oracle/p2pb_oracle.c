@@ -702,3 +702,40 @@ ORC_API void orc_auction_bwd(int b, int n, const float *xyz1, const float *xyz2,
             g * (xyz1[((size_t)i * n + j) * 3 + a] - xyz2[((size_t)i * n + j2) * 3 + a]);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * K nearest neighbours, patch-sized K (object patch extraction, denoise_object.py:91).
+ * pytorch3d.ops.knn_points is a pip dependency of the reference (not under /root/reference): its contract is
+ * "the K smallest squared distances per query point, ascending, and their indices"; the CUDA build accumulates
+ * diff*diff per dimension (contracted to fma, like every distance above). Restated as a full sort by
+ * (distance, index) -- ties by ascending index. Parity for this function is pinned to that published contract
+ * and to tests/test_denoise_* (brute force), not to a golden vector of the reference ("parity unpinned").
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { float d; int j; } orc_knn_pair;
+static int orc_knn_cmp(const void *a, const void *b) {
+  const orc_knn_pair *x = (const orc_knn_pair *)a, *y = (const orc_knn_pair *)b;
+  if (x->d < y->d) return -1;
+  if (x->d > y->d) return 1;
+  return (x->j > y->j) - (x->j < y->j);
+}
+/* query f32[b,s,3], points f32[b,n,3] -> dist2 f32[b,s,k], idx i32[b,s,k] */
+ORC_API void orc_knn_points(int b, int s, int n, int k, const float *query, const float *points, float *dist2,
+                            int *idx) {
+#pragma omp parallel for schedule(dynamic) collapse(2)
+  for (int bi = 0; bi < b; ++bi)
+    for (int q = 0; q < s; ++q) {
+      const float *p = points + (size_t)bi * n * 3;
+      const float *qp = query + ((size_t)bi * s + q) * 3;
+      orc_knn_pair *pr = (orc_knn_pair *)malloc(sizeof(orc_knn_pair) * (size_t)n);
+      for (int j = 0; j < n; ++j) {
+        pr[j].d = sqdist3(p[3 * j] - qp[0], p[3 * j + 1] - qp[1], p[3 * j + 2] - qp[2]);
+        pr[j].j = j;
+      }
+      qsort(pr, (size_t)n, sizeof(orc_knn_pair), orc_knn_cmp);
+      for (int i = 0; i < k; ++i) {
+        dist2[((size_t)bi * s + q) * k + i] = pr[i].d;
+        idx[((size_t)bi * s + q) * k + i] = pr[i].j;
+      }
+      free(pr);
+    }
+}

@@ -447,8 +447,17 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the scalar descriptors
   const int l31 = lane & 31, khalf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int pblk = blockIdx.x * 128, co0 = blockIdx.y * 128, b = blockIdx.z;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so XCD x takes the x-th
+  // contiguous eighth of (sample, position block, channel block) with the channel block fastest: the 2..8 workgroups
+  // that stage the SAME activation tile run side by side on one XCD and share it in its L2 (the dispatch order
+  // x + gx*(y + gy*z) put them 64 workgroups apart: 2.6x the algorithmic bytes from HBM).
   const int ncoblk = gridDim.y;
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned vid = nblk % 8 == 0 ? (lin % 8) * (nblk / 8) + lin / 8 : lin;
+  const int bx = (vid / ncoblk) % gridDim.x, by = vid % ncoblk;
+  const int b = vid / (ncoblk * gridDim.x);
+  const int pblk = bx * 128, co0 = by * 128;
   const float *inb = in + (size_t)b * cin * P;
   const bool mact = co0 + wm * 64 < cout;  // this wave's 64 channels exist (wave-uniform)
 
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
   };
   // A tile of stage `chunk` -> LDS, asynchronously: lane i of a wave lands at base + 16*i
   auto dma_a = [&](int chunk) {
-    const u32x4 *src = wp + ((size_t)chunk * ncoblk + blockIdx.y) * PWS_TILE;
+    const u32x4 *src = wp + ((size_t)chunk * ncoblk + by) * PWS_TILE;
     u32x4 *dst = pws_lds;
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -580,7 +589,7 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
   // ---- epilogue: bias, 8-byte stores, GroupNorm partials per 64-position slot, optional {min, max}.
   // Row index of the reductions: idx = m*16 + r; rowreduce32 leaves row (l31) in lane l31.
   float *outb = out ? out + (size_t)b * cout * P : nullptr;
-  const int slot = blockIdx.x * 2 + wn;
+  const int slot = bx * 2 + wn;
   const int pool_g = pool_u ? pool_u / 2 : 32;
   float s1v[32], s2v[32], mnv[32], mxv[32];
 #pragma unroll
@@ -624,7 +633,7 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
       q[0] = s1;
       q[1] = s2;
-      if (blockIdx.x == gridDim.x - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
+      if (bx == (int)gridDim.x - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
         for (int sl = slot + 1; sl < nslots; ++sl) {
           float *z = stats_part + (((size_t)b * nslots + sl) * cout + rco) * 2;
           z[0] = 0.0f;
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
   if (POOL && pool_u == 0) {
     const float mn = rowreduce32<RowMin>(mnv), mx = rowreduce32<RowMax>(mxv);
     if (rco < cout) {
-      float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 2 + wn) * cout + rco) * 2;
+      float *q = mm_out + ((((size_t)b * gridDim.x + bx) * 2 + wn) * cout + rco) * 2;
       q[0] = mn;
       q[1] = mx;
     }

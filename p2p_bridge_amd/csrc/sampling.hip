@@ -179,6 +179,88 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(int n, int m, const float
   }
 }
 
+// n > 16384, the object-merge case (denoise_object.py:112: 3N patch points -> N, N = 10^4 .. 10^5): one workgroup
+// would stream the whole cloud from L2 every round (28 us per round at 150 k points). Here FPS_G workgroups share
+// one cloud: every thread keeps its PPT points and their running distances in registers, a round is a local
+// (wave + LDS) argmax, one 8-byte slot per workgroup published to global memory with a round tag, and an
+// all-gather by polling: lane i of wave 0 spins on slot i, reduces, and broadcasts the winner through LDS. Slots
+// are double-buffered by round parity (a workgroup can only be one round ahead of the slowest reader). All
+// FPS_G workgroups must be resident together: 64 x 1024 threads is a quarter of the chip. A bounded spin turns a
+// lost peer into an error code instead of a hang.
+#define FPS_G 64
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, const float *__restrict__ coords,
+                                                        u64 *__restrict__ keys, unsigned *__restrict__ tags,
+                                                        int *__restrict__ indices, int *__restrict__ err) {
+  __shared__ u64 slots[2][16];
+  __shared__ int winner[2];
+  const int t = threadIdx.x, g = blockIdx.x, bi = blockIdx.y;
+  const float *c = coords + (size_t)bi * 3 * n;
+  int *out = indices + (size_t)bi * m;
+  u64 *kslot = keys + (size_t)bi * 2 * FPS_G;
+  unsigned *tslot = tags + (size_t)bi * 2 * FPS_G;
+
+  float x[PPT], y[PPT], z[PPT], dist[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = g * 1024 + t + i * (FPS_G * 1024);
+    const bool ok = k < n;
+    x[i] = ok ? c[k] : 0.0f;
+    y[i] = ok ? c[k + n] : 0.0f;
+    z[i] = ok ? c[k + 2 * n] : 0.0f;
+    dist[i] = ok ? 1e38f : -1.0f;
+  }
+  if (t < 32) slots[t >> 4][t & 15] = 0;
+  if (g == 0 && t == 0) out[0] = 0;
+  __syncthreads();
+
+  int old = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = c[old], y1 = c[old + n], z1 = c[old + 2 * n];
+    float best = -1.0f;
+    int bk = 0;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const float d = sqdist3(x[i] - x1, y[i] - y1, z[i] - z1);
+      const float d2 = fminf(d, dist[i]);
+      dist[i] = d2;
+      if (d2 > best) {
+        best = d2;
+        bk = g * 1024 + t + i * (FPS_G * 1024);
+      }
+    }
+    u64 key = wave_max_u64(fps_key(best, bk));
+    if ((t & 63) == 0) slots[j & 1][t >> 6] = key;
+    __syncthreads();
+    if (t < 64) {  // wave 0: the workgroup's maximum -> its global slot, then gather everybody's
+      u64 v = row_max_u64(slots[j & 1][t & 15]);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 15);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
+      const int par = (j & 1) * FPS_G;
+      if (t == 0) {
+        __hip_atomic_store(&kslot[par + g], ((u64)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&tslot[par + g], (unsigned)j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      int spins = 0;
+      while (__hip_atomic_load(&tslot[par + t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)j) {
+        if (++spins > (1 << 22)) {  // a peer never arrived (not co-resident?): give up loudly
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          spins = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const u64 all = wave_max_u64(__hip_atomic_load(&kslot[par + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const bool lost = __ballot(spins < 0) != 0;
+      if (t == 0) winner[j & 1] = lost ? -1 : fps_key_index(all);
+    }
+    __syncthreads();
+    old = winner[j & 1];
+    if (old < 0) return;  // (the peers run into their own spin bound)
+    if (g == 0 && t == 0) out[j] = old;
+  }
+}
+
 template <int THREADS, int PPT>
 static void fps_launch(int b, int n, int m, const float *coords, int *idx, hipStream_t s) {
   const size_t base = 2 * 16 * sizeof(u64);
@@ -216,5 +298,30 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
     if (!dist_ws) return P2PB_EINVAL;
     hipLaunchKernelGGL(fps_big_kernel, dim3(b), dim3(1024), 0, s, n, m, coords, dist_ws, idx);
   }
+  return p2pb_launch_status();
+}
+
+extern "C" size_t p2pb_fps_coop_ws_bytes(int b) { return (size_t)b * 2 * FPS_G * (sizeof(u64) + sizeof(unsigned)) + 16; }
+
+// Large single clouds (16384 < n <= 524288; b * 64 workgroups must be resident together, so b is small): same result
+// as p2pb_furthest_point_sampling. ws: p2pb_fps_coop_ws_bytes(b) bytes, zeroed by the callee. Returns P2PB_EINVAL
+// outside that range (callers fall back to p2pb_furthest_point_sampling).
+extern "C" int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx,
+                                                 void *stream) {
+  if (b <= 0 || b > 2 || n <= 16384 || n > FPS_G * 1024 * 8 || m < 0 || !ws) return P2PB_EINVAL;
+  if (m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t nbytes = p2pb_fps_coop_ws_bytes(b);
+  int e = p2pb_zero_async(ws, nbytes, s);
+  if (e != 0) return e;
+  u64 *keys = (u64 *)ws;
+  unsigned *tags = (unsigned *)(keys + (size_t)b * 2 * FPS_G);
+  int *err = (int *)(tags + (size_t)b * 2 * FPS_G);
+  const int ppt = (n + FPS_G * 1024 - 1) / (FPS_G * 1024);
+  dim3 grid(FPS_G, b);
+  if (ppt <= 1) hipLaunchKernelGGL(fps_coop_kernel<1>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
+  else if (ppt <= 2) hipLaunchKernelGGL(fps_coop_kernel<2>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
+  else if (ppt <= 4) hipLaunchKernelGGL(fps_coop_kernel<4>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
+  else hipLaunchKernelGGL(fps_coop_kernel<8>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
   return p2pb_launch_status();
 }

@@ -1,0 +1,150 @@
+"""Object patch pipeline (denoise_object.py:65-122): HIP ops vs the oracle's restatements of the
+pytorch3d / torch_cluster contracts. Indices bit-exact, distances bit-exact (same fma chain)."""
+import pytest
+import torch
+
+from oracle import cpu_ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dn():
+    from p2p_bridge_amd import denoise
+
+    return denoise
+
+
+def surface(n, seed=0, noise=0.01):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    u[:, 0] *= 0.6  # an ellipsoid shell
+    return (u + noise * torch.randn(n, 3, generator=g)).contiguous()
+
+
+@pytest.mark.parametrize("B,S,N,K", [(1, 5, 3000, 1024), (2, 3, 700, 1), (1, 2, 700, 700), (2, 4, 5000, 2048),
+                                     (1, 3, 9000, 4096), (1, 1, 100, 37), (1, 2, 1500, 1000)])
+def test_knn_points_matches_oracle(dn, B, S, N, K):
+    pts = torch.stack([surface(N, seed=10 * B + i) for i in range(B)])
+    q = pts[:, torch.arange(S) * (N // S)].contiguous()
+    d_ref, i_ref, nn_ref = cpu_ops.knn_points(q, pts, K)
+    out = dn.knn_points(q.cuda(), pts.cuda(), K=K, return_nn=True)
+    assert out.idx.dtype == torch.int64 and out.dists.shape == (B, S, K) and out.knn.shape == (B, S, K, 3)
+    assert torch.equal(out.idx.cpu(), i_ref)
+    assert torch.equal(out.dists.cpu(), d_ref)
+    assert torch.equal(out.knn.cpu(), nn_ref)
+    assert (out.dists[..., 1:] >= out.dists[..., :-1]).all()
+    assert dn.knn_points(q.cuda(), pts.cuda(), K=K).knn is None
+
+
+def test_knn_points_ties_and_duplicates(dn):
+    """duplicated points and lattice coordinates: many exactly equal distances, the K-th key is shared --
+    ties resolve by ascending index, like the oracle's (distance, index) sort"""
+    g = torch.Generator().manual_seed(3)
+    lattice = torch.randint(0, 4, (1, 2000, 3), generator=g).float() * 0.25
+    pts = torch.cat([lattice, lattice[:, :500]], 1).contiguous()
+    q = pts[:, :6].contiguous()
+    for K in (1, 17, 512, 1300):
+        d_ref, i_ref, _ = cpu_ops.knn_points(q, pts, K)
+        out = dn.knn_points(q.cuda(), pts.cuda(), K=K)
+        assert torch.equal(out.idx.cpu(), i_ref), K
+        assert torch.equal(out.dists.cpu(), d_ref), K
+
+
+def test_knn_points_rejects_bad_arguments(dn):
+    p = torch.randn(1, 10, 3, device="cuda")
+    with pytest.raises(ValueError):
+        dn.knn_points(p, p, K=11)
+    with pytest.raises(ValueError):
+        dn.knn_points(p, p, K=0)
+    with pytest.raises(ValueError):
+        dn.knn_points(p[0], p, K=1)
+    with pytest.raises((RuntimeError, TypeError, ValueError)):
+        dn.knn_points(p.cpu(), p.cpu(), K=1)
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 3000, 17), (1, 20000, 300), (3, 500, 500), (2, 70000, 257), (1, 140000, 64)])
+def test_farthest_point_sampling_matches_oracle(dn, B, N, M):
+    pts = torch.stack([surface(N, seed=5 + i) for i in range(B)])
+    s_ref, i_ref = cpu_ops.farthest_point_sampling(pts, M)
+    s, i = dn.farthest_point_sampling(pts.cuda(), M)
+    assert len(i) == B and i[0].dtype == torch.int64 and i[0][0].item() == 0
+    assert torch.equal(torch.stack(i).cpu(), torch.stack(i_ref))
+    assert torch.equal(s.cpu(), s_ref)
+    with pytest.raises(ValueError):
+        dn.farthest_point_sampling(pts.cuda(), N + 1)
+
+
+class _Shrink:
+    """stands for P2PB: a deterministic 'denoiser' with sample()'s signature and dict"""
+
+    def eval(self):
+        return self
+
+    def sample(self, x_start=None, use_ema=False, steps=None, log_count=None, verbose=False, graph=False):
+        xs = torch.stack([x_start * (0.9 + 0.01 * t) for t in range(steps)], 1)
+        return {"x_pred": xs[:, 0], "x_chain": xs, "x_start": x_start}
+
+
+def test_patch_based_denoise_matches_oracle_pipeline(dn):
+    N, K = 6000, 1024
+    pcl = surface(N, seed=42, noise=0.02)
+    tr_ref, tr = {}, {}
+    cpu_ops.patch_based_denoise(lambda x: x * 0.9, pcl, K, trace=tr_ref)
+    out, steps = dn.patch_based_denoise(_Shrink(), pcl.cuda(), K, seed_k=3, cfg={"steps": 3, "use_ema": False},
+                                        save_intermediate=True, trace=tr)
+    assert out.shape == (N, 3) and steps.shape == (3, N, 3)
+    # index-exact stages: FPS seeds and the K-NN patches
+    assert torch.equal(tr["seed_idx"].cpu(), tr_ref["seed_idx"])
+    assert torch.equal(tr["patch_idx"].cpu(), tr_ref["patch_idx"])
+    # the float steps in between (mean, norm, scale) are torch elementwise ops on both sides
+    assert (tr["patches_denoised"].cpu() - tr_ref["patches_denoised"]).abs().max().item() < 1e-6
+    # the merge is FPS again: index-exact on identical input (FPS is chaotic in near-ties, so it is checked on the
+    # product's own de-normalised patches rather than through the last-bit differences of the stage above)
+    merged = tr["patches_denoised"].reshape(1, -1, 3).contiguous()
+    _, idx_ref = cpu_ops.farthest_point_sampling(merged.cpu(), N)
+    assert torch.equal(tr["fps_idx"].cpu(), idx_ref[0])
+    assert torch.equal(out, merged[0, tr["fps_idx"]])
+    # chunked sampler calls give the same cloud
+    out2, _ = dn.patch_based_denoise(_Shrink(), pcl.cuda(), K, cfg={"steps": 3}, max_batch=4)
+    assert torch.equal(out2, out)
+
+
+def test_patch_based_denoise_with_the_network(dn):
+    """the real sampler inside the pipeline (tiny configuration): shapes, finiteness, and that every output point
+    is one of the de-normalised patch outputs"""
+    import json
+    import os
+
+    import numpy as np
+
+    from oracle import net_ref
+    from p2p_bridge_amd.p2pb import build_model
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cfg = json.load(open(os.path.join(golden, "tiny_cfg.json")))
+    w = np.load(os.path.join(golden, "tiny_weights.npz"))
+    sd = {k: torch.from_numpy(w[k]).float() for k in w.files}
+    model = build_model(cfg, sd, device="cuda")
+    K = int(cfg["data"]["npoints"])
+    pcl = surface(3 * K, seed=7, noise=0.02)
+    tr, tr_ref = {}, {}
+    out, _ = dn.patch_based_denoise(model, pcl.cuda(), K, cfg={"steps": 3, "use_ema": False}, trace=tr)
+    assert out.shape == (3 * K, 3) and torch.isfinite(out).all()
+    # same pipeline on the oracle: CPU network + CPU ops
+    orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    cpu_ops.patch_based_denoise(lambda x: net_ref.sample(orc, cfg, x, steps=3, log_count=3)["x_pred"], pcl, K, trace=tr_ref)
+    assert torch.equal(tr["patch_idx"].cpu(), tr_ref["patch_idx"])
+    # the network holds discrete decisions (FPS, ball query, voxel rounding): a last-bit difference can flip one and
+    # move a handful of points, so -- like tests/test_net_parity_gpu.py's sampler checks -- the patch outputs are
+    # compared through the Chamfer-L2 of north_star (<= 1e-4) and the typical pointwise difference
+    a, b = tr["patches_denoised"].cpu().contiguous(), tr_ref["patches_denoised"].contiguous()
+    S, n = a.shape[0], a.shape[1]
+    d1, d2 = torch.zeros(S, n), torch.zeros(S, n)
+    i1, i2 = torch.zeros(S, n, dtype=torch.int32), torch.zeros(S, n, dtype=torch.int32)
+    cpu_ops.chamfer_forward(a, b, d1, d2, i1, i2)
+    assert (d1.mean(1) + d2.mean(1)).max().item() < 1e-4
+    assert (a - b).abs().median().item() < 1e-5
+    merged = tr["patches_denoised"].reshape(1, -1, 3).contiguous()
+    _, idx_ref = cpu_ops.farthest_point_sampling(merged.cpu(), 3 * K)
+    assert torch.equal(tr["fps_idx"].cpu(), idx_ref[0])

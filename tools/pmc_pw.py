@@ -1,4 +1,5 @@
-"""Launch the widest pointwise GEMM (Pnet2Stage 512->1024, P=8192, B=32) a few times for rocprofv3 --pmc runs."""
+"""Launch the widest pointwise GEMM (Pnet2Stage 512->1024, P=8192, B=32) as the sampler does -- global {min,max}
+pooling epilogue, GroupNorm statistics, output not stored -- a few times for rocprofv3 --pmc runs."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,5 +9,5 @@ x = torch.randn(B, ci, P, device="cuda")
 conv = torch.nn.Conv1d(ci, co, 1).cuda()
 with torch.no_grad():
     for _ in range(4):
-        fused.pw_conv(x, conv)
+        fused.pw_conv(x, conv, pool_u=0, store=False)
 torch.cuda.synchronize()
