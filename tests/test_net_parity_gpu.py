@@ -98,7 +98,8 @@ def test_tiny_sampler(tiny, graph):
     if graph:  # replay determinism
         pred = out["x_pred"].cpu()
         again = model.sample(x_start=x.cuda(), steps=5, log_count=5, verbose=False, graph=True)["x_pred"].cpu()
-        assert torch.equal(again, pred)
+        assert torch.equal(again, pred), f"replay differs: max {(again - pred).abs().max().item():.3e}, " \
+                                         f"{(again != pred).sum().item()} of {pred.numel()} values"
 
 
 def test_stock_pvds_config1():
