@@ -105,6 +105,16 @@ int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float
 size_t p2pb_fps_coop_ws_bytes(int b);
 int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx, void *stream);
 
+/* point <-> triangle-mesh squared distances (P2M metric): replace pytorch3d._C.point_face_dist_forward /
+ * face_point_dist_forward as called by metrics/p2m.py:66,131 for one (mesh, cloud) pair. points f32[np,3],
+ * tris f32[nt,3,3] (faces as vertex triples); triangles of area < min_triangle_area count as their edges.
+ *   p2pb_point_face_dist -> dist f32[np], idx i32[np] (closest triangle of every point, first minimum)
+ *   p2pb_face_point_dist -> dist f32[nt], idx i32[nt] (closest point of every triangle) */
+int p2pb_point_face_dist(int np, int nt, const float *points, const float *tris, float min_triangle_area, float *dist,
+                         int *idx, void *stream);
+int p2pb_face_point_dist(int np, int nt, const float *points, const float *tris, float min_triangle_area, float *dist,
+                         int *idx, void *stream);
+
 /* exact K nearest neighbours with patch-sized K: replaces pytorch3d.ops.knn_points(seeds, cloud, K, return_nn=True)
  * as called by denoise_object.py:91 (pytorch3d: pip dependency, not vendored; contract = the K smallest squared
  * distances per query, ascending, with indices). Ties: ascending point index.

@@ -328,3 +328,15 @@ def patch_based_denoise(sample_fn, pcl_noisy, patch_size, seed_k=3, trace=None):
     if trace is not None:
         trace.update(seed_idx=seed_idx[0], patch_idx=patch_idx[0], patches_denoised=den, fps_idx=fps_idx[0])
     return out[0]
+
+
+def point_face_dist(points, tris, min_triangle_area=5e-3, which=0):
+    """pytorch3d._C.point_face_dist_forward (which=0) / face_point_dist_forward (which=1) for ONE object:
+    points f32[P,3], tris f32[T,3,3] -> (dist f32, idx i64)"""
+    _chk(points, F32), _chk(tris, F32)
+    n_out = points.shape[0] if which == 0 else tris.shape[0]
+    d = torch.empty(n_out, dtype=F32)
+    idx = torch.empty(n_out, dtype=I32)
+    lib().orc_point_face(_i(which), _i(points.shape[0]), _i(tris.shape[0]), _p(points), _p(tris),
+                         ctypes.c_float(min_triangle_area), _p(d), _p(idx))
+    return d, idx.long()

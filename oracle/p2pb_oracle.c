@@ -739,3 +739,65 @@ ORC_API void orc_knn_points(int b, int s, int n, int k, const float *query, cons
       free(pr);
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Point <-> triangle squared distances (P2M metric: metrics/p2m.py:66,131 -> pytorch3d._C.point_face_dist_forward /
+ * face_point_dist_forward). pytorch3d is a pip dependency (absent from /root/reference): restated from its published
+ * geometry_utils.cuh (PointTriangle3DistanceForward, IsInsideTriangle, BarycentricCoords3Forward,
+ * PointLine3DistanceForward, kEpsilon 1e-8). "Parity unpinned" against pytorch3d itself; pinned to closed-form
+ * cases in tests/test_metrics_unit_sphere_*.py. Plain fp32, no contraction (file is built with -ffp-contract=off).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { float x, y, z; } orc_v3;
+static inline orc_v3 orc_sub(orc_v3 a, orc_v3 b) { orc_v3 r = {a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+static inline float orc_dot(orc_v3 a, orc_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline orc_v3 orc_cross(orc_v3 a, orc_v3 b) {
+  orc_v3 r = {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+  return r;
+}
+static float orc_point_segment(orc_v3 p, orc_v3 v0, orc_v3 v1) {
+  orc_v3 d = orc_sub(v1, v0);
+  float l2 = orc_dot(d, d);
+  if (l2 <= 1e-8f) { orc_v3 q = orc_sub(p, v1); return orc_dot(q, q); }
+  float t = orc_dot(d, orc_sub(p, v0)) / l2;
+  t = fminf(fmaxf(t, 0.0f), 1.0f);
+  orc_v3 q = {p.x - (v0.x + t * d.x), p.y - (v0.y + t * d.y), p.z - (v0.z + t * d.z)};
+  return orc_dot(q, q);
+}
+static float orc_point_triangle(orc_v3 p, orc_v3 v0, orc_v3 v1, orc_v3 v2, float min_area) {
+  orc_v3 n = orc_cross(orc_sub(v2, v0), orc_sub(v1, v0));
+  float nn = sqrtf(orc_dot(n, n));
+  float inv = 1.0f / (nn + 1e-8f);
+  n.x *= inv; n.y *= inv; n.z *= inv;
+  float t = orc_dot(orc_sub(v0, p), n);
+  orc_v3 p0 = {p.x + t * n.x, p.y + t * n.y, p.z + t * n.z};
+  int inside = 0;
+  if (0.5f * nn >= min_area) {
+    orc_v3 e0 = orc_sub(v1, v0), e1 = orc_sub(v2, v0), e2 = orc_sub(p0, v0);
+    float d00 = orc_dot(e0, e0), d01 = orc_dot(e0, e1), d11 = orc_dot(e1, e1), d20 = orc_dot(e2, e0),
+          d21 = orc_dot(e2, e1);
+    float denom = d00 * d11 - d01 * d01 + 1e-8f;
+    float w1 = (d11 * d20 - d01 * d21) / denom, w2 = (d00 * d21 - d01 * d20) / denom;
+    float w0 = 1.0f - w1 - w2;
+    inside = (0.0f <= w0 && w0 <= 1.0f) && (0.0f <= w1 && w1 <= 1.0f) && (0.0f <= w2 && w2 <= 1.0f);
+  }
+  if (inside) return t * t;
+  return fminf(fminf(orc_point_segment(p, v0, v1), orc_point_segment(p, v0, v2)), orc_point_segment(p, v1, v2));
+}
+/* which = 0: per point the closest triangle; which = 1: per triangle the closest point */
+ORC_API void orc_point_face(int which, int np, int nt, const float *pts, const float *tris, float min_area,
+                            float *dist, int *idx) {
+  const int no = which == 0 ? np : nt, ni = which == 0 ? nt : np;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < no; ++i) {
+    float best = 3.4e38f;
+    int bi = 0;
+    for (int k = 0; k < ni; ++k) {
+      const float *pp = pts + 3 * (which == 0 ? i : k), *q = tris + 9 * (size_t)(which == 0 ? k : i);
+      orc_v3 p = {pp[0], pp[1], pp[2]}, v0 = {q[0], q[1], q[2]}, v1 = {q[3], q[4], q[5]}, v2 = {q[6], q[7], q[8]};
+      float d = orc_point_triangle(p, v0, v1, v2, min_area);
+      if (d < best) { best = d; bi = k; }
+    }
+    dist[i] = best;
+    idx[i] = bi;
+  }
+}

@@ -147,3 +147,113 @@ def calculate_emd_cuda(pred, gt, batch_size=4):
     for s in range(0, pred.shape[0], batch_size):
         out.append(earth_mover_distance_nograd(pred[s:s + batch_size], gt[s:s + batch_size], transpose=False))
     return torch.cat(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Evaluation metrics on the unit sphere: metrics/metrics.py:139-226, models/evaluation.py:314-353.
+# chamfer_dist_nograd is this package's HIP Chamfer; the point-to-mesh distances replace pytorch3d._C.point_face_dist_*
+# (csrc/p2m.hip). pytorch3d is a pip dependency of the reference: its published definitions are restated in oracle/.
+# ------------------------------------------------------------------------------------------------------------------
+def normalize_sphere(pc, radius=1.0):
+    """pc [B,N,3] -> (pc centred on the bounding-box centre and scaled to `radius`, center [B,1,3], scale [B,1,1])
+    (metrics/metrics.py:139-157)"""
+    p_max = pc.max(dim=-2, keepdim=True)[0]
+    p_min = pc.min(dim=-2, keepdim=True)[0]
+    center = (p_max + p_min) / 2
+    pc = pc - center
+    scale = (pc ** 2).sum(dim=-1, keepdim=True).sqrt().max(dim=-2, keepdim=True)[0] / radius
+    return pc / scale, center, scale
+
+
+def normalize_pcl(pc, center, scale):
+    return (pc - center) / scale
+
+
+def denormalize_pcl(pc, center, scale):
+    return pc * scale + center
+
+
+@torch.no_grad()
+def cd_unit_sphere(gen, ref, normalize=True):
+    """(mean_i min_j, mean_j min_i) squared distances, gen/ref [B,N,3] (metrics/metrics.py:177-195)"""
+    if normalize:
+        ref, center, scale = normalize_sphere(ref)
+        gen = normalize_pcl(gen, center, scale)
+    cd1, cd2 = chamfer_dist_nograd(gen.contiguous(), ref.contiguous())
+    return cd1.mean().item(), cd2.mean().item()
+
+
+def chamfer_distance_unit_sphere(gen, ref, batch_reduction="mean", point_reduction="mean"):
+    """pytorch3d.loss.chamfer_distance(gen, ref) after normalising both with ref's sphere (models/evaluation.py:291-294):
+    -> (loss, None); mean / sum reductions over points and batch, None batch reduction -> [B]"""
+    ref, center, scale = normalize_sphere(ref)
+    gen = normalize_pcl(gen, center, scale)
+    d1, d2, _, _ = chamfer_3DDist()(gen.contiguous(), ref.contiguous())
+    red = (lambda d: d.mean(dim=1)) if point_reduction == "mean" else (lambda d: d.sum(dim=1))
+    if point_reduction not in ("mean", "sum"):
+        raise ValueError("point_reduction must be 'mean' or 'sum'")
+    loss = red(d1) + red(d2)
+    if batch_reduction == "mean":
+        loss = loss.mean()
+    elif batch_reduction == "sum":
+        loss = loss.sum()
+    elif batch_reduction is not None:
+        raise ValueError("batch_reduction must be 'mean', 'sum' or None")
+    return loss, None
+
+
+_DEFAULT_MIN_TRIANGLE_AREA = 5e-3  # pytorch3d.loss.point_mesh_distance
+
+
+def _p2m(fn, points, tris, n_out, min_triangle_area):
+    from ._lib import call, check, ptr, stream_ptr
+    import ctypes
+
+    check(points, torch.float32, "points"), check(tris, torch.float32, "tris")
+    d = torch.empty(n_out, dtype=torch.float32, device=points.device)
+    idx = torch.empty(n_out, dtype=torch.int32, device=points.device)
+    call(fn, ctypes.c_int(points.shape[0]), ctypes.c_int(tris.shape[0]), ptr(points), ptr(tris),
+         ctypes.c_float(min_triangle_area), ptr(d), ptr(idx), stream_ptr())
+    return d, idx.long()
+
+
+def point_face_distance(points, tris, min_triangle_area=_DEFAULT_MIN_TRIANGLE_AREA):
+    """points f32[P,3], tris f32[T,3,3] -> (squared distance of every point to its closest triangle [P], its index)"""
+    return _p2m("p2pb_point_face_dist", points.contiguous(), tris.contiguous(), points.shape[0], min_triangle_area)
+
+
+def face_point_distance(points, tris, min_triangle_area=_DEFAULT_MIN_TRIANGLE_AREA):
+    """-> (squared distance of every triangle to its closest point [T], its index)"""
+    return _p2m("p2pb_face_point_dist", points.contiguous(), tris.contiguous(), tris.shape[0], min_triangle_area)
+
+
+@torch.no_grad()
+def point_mesh_face_distance(pcl, verts, faces, min_triangle_area=_DEFAULT_MIN_TRIANGLE_AREA):
+    """(point_dist, face_dist) of metrics/p2m.py:307-375 for one (mesh, cloud) pair: mean squared distance of the
+    points to the mesh and of the faces to the cloud"""
+    tris = verts[faces.long()].contiguous()
+    return (point_face_distance(pcl, tris, min_triangle_area)[0].mean(),
+            face_point_distance(pcl, tris, min_triangle_area)[0].mean())
+
+
+@torch.no_grad()
+def point_face_dist(pcl, verts, faces, normalize=True):
+    """metrics/metrics.py:198-226 -> (point_dist, face_dist) floats; pcl [N,3], verts [M,3], faces i64[T,3]"""
+    assert pcl.dim() == 2 and verts.dim() == 2 and faces.dim() == 2, "Batch is not supported."
+    if normalize:
+        verts, center, scale = normalize_sphere(verts.unsqueeze(0))
+        verts = verts[0]
+        pcl = normalize_pcl(pcl.unsqueeze(0), center=center, scale=scale)[0]
+    pd, fd = point_mesh_face_distance(pcl.cuda(), verts.cuda(), faces.cuda())
+    return pd.item(), fd.item()
+
+
+@torch.no_grad()
+def point_mesh_bidir_distance_single_unit_sphere(pcl, verts, faces):
+    """models/evaluation.py:329-353: pytorch3d.loss.point_mesh_face_distance(min_triangle_area=0.0) on the mesh's
+    unit sphere = point_dist + face_dist"""
+    assert pcl.dim() == 2 and verts.dim() == 2 and faces.dim() == 2, "Batch is not supported."
+    verts, center, scale = normalize_sphere(verts.unsqueeze(0))
+    pcl = normalize_pcl(pcl.unsqueeze(0), center=center, scale=scale)[0]
+    pd, fd = point_mesh_face_distance(pcl, verts[0], faces, min_triangle_area=0.0)
+    return pd + fd
