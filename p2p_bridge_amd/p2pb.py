@@ -92,22 +92,66 @@ def get_loss(kind: str):
 
 
 class EMA(nn.Module):
-    """minimal exponential-moving-average shadow (the reference uses ema_pytorch.EMA(model, beta=0.999),
-    models/p2pb.py:91; checkpoint keys `ema.ema_model.*`)"""
+    """Exponential-moving-average shadow of the network with ema_pytorch.EMA's interface and schedule (the reference
+    builds `EMA(model, beta=0.999)`, models/p2pb.py:91, and calls `.update()` once per optimiser step, train.py:139-140;
+    ema_pytorch is a pip dependency, restated from its published defaults): every `update_every` = 10 calls; a plain
+    copy of the online weights up to `update_after_step` = 100; afterwards `ema.lerp_(online, 1 - decay)` with
+    decay = clamp(1 - (1 + (step - update_after_step - 1) / inv_gamma) ** -power, min_value, beta), inv_gamma = 1,
+    power = 2/3. Checkpoint keys: `ema.ema_model.*`, `ema.initted`, `ema.step` (`ema.online_model.*` duplicates the
+    network and is ignored on load, see load_checkpoint)."""
 
-    def __init__(self, model: nn.Module, beta: float = 0.999):
+    def __init__(self, model: nn.Module, beta: float = 0.9999, update_after_step: int = 100, update_every: int = 10,
+                 inv_gamma: float = 1.0, power: float = 2.0 / 3.0, min_value: float = 0.0):
         super().__init__()
         import copy
 
-        self.beta = beta
+        self.beta, self.update_after_step, self.update_every = beta, update_after_step, update_every
+        self.inv_gamma, self.power, self.min_value = inv_gamma, power, min_value
+        self._online = [model]  # (not registered: the online network is saved under its own keys)
         self.ema_model = copy.deepcopy(model).requires_grad_(False)
+        self.register_buffer("initted", torch.tensor(False))
+        self.register_buffer("step", torch.tensor(0))
+
+    @property
+    def online_model(self):
+        return self._online[0]
 
     @torch.no_grad()
-    def update(self, model: nn.Module):
-        for pe, p in zip(self.ema_model.parameters(), model.parameters()):
-            pe.lerp_(p.detach(), 1.0 - self.beta)
-        for be, b_ in zip(self.ema_model.buffers(), model.buffers()):
+    def copy_params_from_model_to_ema(self):
+        for pe, p in zip(self.ema_model.parameters(), self.online_model.parameters()):
+            pe.copy_(p.detach())
+        for be, b_ in zip(self.ema_model.buffers(), self.online_model.buffers()):
             be.copy_(b_)
+
+    def get_current_decay(self) -> float:
+        epoch = max(int(self.step.item()) - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        value = 1.0 - (1.0 + epoch / self.inv_gamma) ** (-self.power)
+        return min(max(value, self.min_value), self.beta)
+
+    @torch.no_grad()
+    def update(self, model: Optional[nn.Module] = None):
+        if model is not None:
+            self._online[0] = model
+        step = int(self.step.item())
+        self.step += 1
+        if step % self.update_every != 0:
+            return
+        if step <= self.update_after_step:
+            self.copy_params_from_model_to_ema()
+            return
+        if not bool(self.initted.item()):
+            self.copy_params_from_model_to_ema()
+            self.initted.fill_(True)
+        decay = self.get_current_decay()
+        for pe, p in zip(self.ema_model.parameters(), self.online_model.parameters()):
+            pe.lerp_(p.detach(), 1.0 - decay)
+        for be, b_ in zip(self.ema_model.buffers(), self.online_model.buffers()):
+            if be.is_floating_point():
+                be.lerp_(b_, 1.0 - decay)
+            else:
+                be.copy_(b_)
 
     def forward(self, *a, **k):
         return self.ema_model(*a, **k)
@@ -308,6 +352,40 @@ class P2PB(nn.Module):
                                    sampling_steps=self.sampling_timesteps if steps is None else steps,
                                    verbose=verbose, use_ema=use_ema, log_count=log_count, graph=graph)
         return {"x_chain": xs, "x_pred": xs[:, 0, ...], "x_start": x_start}
+
+
+def extract_from_state_dict(state_dict, pattern):
+    """models/model_loader.py:167-179"""
+    return {k.replace(pattern, ""): v for k, v in state_dict.items() if k.startswith(pattern)}
+
+
+def load_checkpoint(model: "P2PB", ckpt, use_ema: bool = True, restart: bool = False) -> int:
+    """The weight-loading half of load_diffusion (models/model_loader.py:114-165) for a reference checkpoint
+    (`torch.load(step_*.pth)` dict or its path): `model_state` keys `model.*` (DataParallel / DDP runs:
+    `model.module.*`) -> the network, `ema.ema_model.*` (+ `ema.initted`, `ema.step`) -> the EMA shadow when
+    `use_ema` and the model has one. restart=True loads the network only (fresh EMA, start step 0).
+    Returns the step to resume from (`ckpt["step"] + 1`, or 0)."""
+    if isinstance(ckpt, (str, bytes)) or hasattr(ckpt, "__fspath__"):
+        ckpt = torch.load(ckpt, map_location="cpu")
+    state = ckpt["model_state"] if "model_state" in ckpt else ckpt
+    model_dict = extract_from_state_dict(state, "model.module.") or extract_from_state_dict(state, "model.")
+    if not model_dict:  # a bare network state_dict
+        model_dict = {k: v for k, v in state.items() if not k.startswith("ema.")}
+    model.model.load_state_dict(model_dict, strict=True)
+    if restart:
+        if model.ema is not None:
+            model.ema.copy_params_from_model_to_ema()
+        return 0
+    if use_ema and model.ema is not None:
+        ema_dict = extract_from_state_dict(state, "ema.")
+        shadow = extract_from_state_dict(ema_dict, "ema_model.")
+        shadow = extract_from_state_dict(shadow, "module.") or shadow
+        if shadow:
+            model.ema.ema_model.load_state_dict(shadow, strict=True)
+            for name in ("initted", "step"):
+                if name in ema_dict:
+                    getattr(model.ema, name).copy_(ema_dict[name].reshape(()))
+    return int(ckpt["step"]) + 1 if "step" in ckpt else 0
 
 
 def build_model(cfg, state_dict=None, device="cuda") -> P2PB:

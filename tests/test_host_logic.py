@@ -131,3 +131,57 @@ def test_conv_math_switch(monkeypatch):
     import pytest as _pt
     with _pt.raises(ValueError):
         fused.conv_math()
+
+
+def test_ema_schedule_and_reference_checkpoint_roundtrip(tmp_path):
+    """ema_pytorch's published schedule (copy up to step 100, every 10th call, decay 1-(1+k)^(-2/3) capped at beta) and
+    loading a reference-format checkpoint (models/model_loader.py:114-165): DDP-style `model.module.*` keys, the EMA
+    shadow under `ema.ema_model.*` next to `ema.online_model.*` / `ema.initted` / `ema.step`"""
+    import copy
+
+    import torch
+    from p2p_bridge_amd.p2pb import EMA, build_model, load_checkpoint
+
+    net = torch.nn.Linear(4, 3)
+    ema = EMA(net, beta=0.999)
+    w0 = net.weight.detach().clone()
+    for step in range(130):
+        with torch.no_grad():
+            net.weight.add_(0.01)
+        before = ema.ema_model.weight.clone()
+        ema.update()
+        if step % 10 != 0:
+            assert torch.equal(ema.ema_model.weight, before)  # only every 10th call touches the shadow
+        elif step <= 110:
+            # warm-up: plain copy; the first averaged update (step 110) starts from a fresh copy too (`initted`)
+            assert torch.equal(ema.ema_model.weight, net.weight)
+        else:
+            k = step + 1 - 100 - 1  # ema.step was incremented before the decay is read
+            decay = min(max(1 - (1 + k) ** (-2 / 3), 0.0), 0.999)
+            assert torch.allclose(ema.ema_model.weight, before + (net.weight - before) * (1 - decay), atol=1e-7)
+    assert int(ema.step) == 130 and bool(ema.initted) and not torch.equal(ema.ema_model.weight, w0)
+
+    cfg = json.load(open(os.path.join(GOLDEN, "tiny_cfg.json")))
+    cfg["model"]["ema"] = True
+    src = build_model(cfg, device="cpu")
+    with torch.no_grad():
+        for p in src.ema.ema_model.parameters():
+            p.mul_(0.5)
+    state = {"model.module." + k: v for k, v in src.model.state_dict().items()}
+    state.update({"ema.ema_model." + k: v for k, v in src.ema.ema_model.state_dict().items()})
+    state.update({"ema.online_model." + k: v for k, v in src.model.state_dict().items()})
+    state["ema.initted"], state["ema.step"] = torch.tensor([True]), torch.tensor([4321])
+    path = tmp_path / "step_4999.pth"
+    torch.save({"step": 4999, "model_state": state}, path)
+    dst = build_model(cfg, device="cpu")
+    assert load_checkpoint(dst, str(path), use_ema=True) == 5000
+    for (k, a), b in zip(src.model.state_dict().items(), dst.model.state_dict().values()):
+        assert torch.equal(a, b), k
+    for a, b in zip(src.ema.ema_model.state_dict().values(), dst.ema.ema_model.state_dict().values()):
+        assert torch.equal(a, b)
+    assert int(dst.ema.step) == 4321 and bool(dst.ema.initted)
+    # restart: network only, fresh shadow, step 0
+    dst2 = build_model(cfg, device="cpu")
+    assert load_checkpoint(dst2, torch.load(path), restart=True) == 0
+    for a, b in zip(dst2.model.state_dict().values(), dst2.ema.ema_model.state_dict().values()):
+        assert torch.equal(a, b)
