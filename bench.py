@@ -87,26 +87,27 @@ def conv_roofline(model, B, reps=10):
 
 def gemm_roofline(model, B, P, reps=10):
     """Dominant kernel of the sampler (largest share of the critical stream in profiles/r01*_per_eval.csv):
-    pw_split_kernel<XF=false, POOL=true> on the global embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels
-    over all P points of every patch; models/pvcnn.py:905-932): split-operand (bf16x6) GEMM whose epilogue emits the
-    GroupNorm statistics and the per-channel {min, max} the max-pool is formed from -- the 1024-channel output is
-    never written. Timed live with HIP events on torch's current stream, launched exactly as the sampler launches it
-    (the folded norm+Swish of its operand runs in a separate pre-pass there, as here it is simply absent).
+    pw_split_kernel<XF=true, POOL=true> on the global embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels
+    over all P points of every patch; models/pvcnn.py:905-932): split-operand (bf16x6) GEMM that applies the previous
+    layer's folded GroupNorm + Swish to its operand on load and whose epilogue emits the GroupNorm statistics and
+    the per-channel {min, max} the max-pool is formed from -- the 1024-channel output is never written. Timed live
+    with HIP events on torch's current stream, launched exactly as the sampler launches it.
     `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
     from p2p_bridge_amd import fused
 
     conv = model.model.global_pnet.mlp2.shared_mlp_1.mlp[0]
     ci, co = conv.in_channels, conv.out_channels
     x = torch.randn(B, ci, P, device="cuda")
+    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
     flops = 2.0 * B * P * ci * co
     with torch.no_grad():
         for _ in range(3):
-            fused.pw_conv(x, conv, pool_u=0, store=False)
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fused.pw_conv(x, conv, pool_u=0, store=False)
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
@@ -129,7 +130,7 @@ def gemm_roofline(model, B, P, reps=10):
                              "(FETCH_SIZE counts half of 8- and 16-byte-per-lane streaming reads on gfx950: calibrated on a "
                              f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 6 * ci * co} B: "
                              "the activations are staged by 8 output-channel blocks, the per-XCD L2 absorbs 3/4 of that",
-            "kernel": f"pw_split_kernel<XF=false,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)",
+            "kernel": f"pw_split_kernel<XF=true,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)",
             "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
                            "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}

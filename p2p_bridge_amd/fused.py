@@ -299,9 +299,11 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
     b, ci, p = x.shape
     co = conv.weight.shape[0]
     split = use_split_pw(ci, co, p, math)
-    if in_scale is not None and (co + (127 if split else 63)) // (128 if split else 64) >= 3:
-        # every output-channel block re-applies the folded norm+Swish to its operand: for wide layers one
-        # elementwise pre-pass (1 read + 1 write of the input) is cheaper than >= 3 recomputations
+    if in_scale is not None and (co + (127 if split else 63)) // (128 if split else 64) >= int(os.environ.get("P2PB_PREPASS_BLOCKS", "9")):
+        # every output-channel block re-applies the folded norm+Swish to its operand: for very wide layers one
+        # elementwise pre-pass (1 read + 1 write of the input) is cheaper than the recomputations. With the
+        # XCD-aware workgroup order the blocks of one activation tile run side by side and up to 8 recomputations
+        # measure faster than the extra pass (+0.9 % end to end), so the pass starts at 9 blocks (> 1024 channels)
         x = affine_act(x, in_scale, in_shift, swish)
         in_scale = in_shift = None
         swish = False

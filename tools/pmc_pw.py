@@ -7,7 +7,8 @@ from p2p_bridge_amd import fused
 B, ci, co, P = 32, 512, 1024, 8192
 x = torch.randn(B, ci, P, device="cuda")
 conv = torch.nn.Conv1d(ci, co, 1).cuda()
+sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
 with torch.no_grad():
     for _ in range(4):
-        fused.pw_conv(x, conv, pool_u=0, store=False)
+        fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
 torch.cuda.synchronize()
