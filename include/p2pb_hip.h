@@ -134,6 +134,11 @@ int p2pb_three_nn_interpolate_forward(int b, int c, int m, int n, const float *p
 int p2pb_three_nn(int b, int m, int n, const float *points, const float *centers, int *idx, float *w, void *stream);
 int p2pb_three_interpolate(int b, int c, int m, int n, const float *cfeat, const int *idx, const float *w,
                            float *out, void *stream);
+/* p2pb_three_nn through a uniform 16^3 grid over the centres (exact: same idx / w, ties by ascending index);
+ * 3 <= m <= 8192, ws: p2pb_three_nn_cells_ws_bytes(b, m) bytes of scratch (16-byte aligned) */
+size_t p2pb_three_nn_cells_ws_bytes(int b, int m);
+int p2pb_three_nn_cells(int b, int m, int n, const float *points, const float *centers, int *idx, float *w, void *ws,
+                        void *stream);
 int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
                                        const float *w, float *grad_x, void *stream);
 

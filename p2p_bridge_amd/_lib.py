@@ -17,7 +17,7 @@ SYMBOLS = [
     "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_trilinear_devoxelize_forward",
     "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats",
     "p2pb_gather_features_forward", "p2pb_gather_features_backward", "p2pb_furthest_point_sampling",
-    "p2pb_fps_coop_ws_bytes", "p2pb_furthest_point_sampling_coop", "p2pb_point_face_dist", "p2pb_face_point_dist", "p2pb_knn_points_ws_bytes", "p2pb_knn_points", "p2pb_three_nn_interpolate_forward", "p2pb_three_nn_interpolate_backward", "p2pb_three_nn",
+    "p2pb_fps_coop_ws_bytes", "p2pb_furthest_point_sampling_coop", "p2pb_point_face_dist", "p2pb_face_point_dist", "p2pb_knn_points_ws_bytes", "p2pb_knn_points", "p2pb_three_nn_interpolate_forward", "p2pb_three_nn_interpolate_backward", "p2pb_three_nn", "p2pb_three_nn_cells", "p2pb_three_nn_cells_ws_bytes",
     "p2pb_three_interpolate", "p2pb_chamfer_forward",
     "p2pb_chamfer_backward", "p2pb_approxmatch_forward", "p2pb_matchcost_forward", "p2pb_matchcost_backward",
     "p2pb_auction_forward", "p2pb_auction_backward", "p2pb_conv3d_k3_packed_floats", "p2pb_conv3d_k3_pack_weights",
@@ -48,6 +48,7 @@ def lib():
         _lib.p2pb_target_arch.restype = ctypes.c_char_p
         _lib.p2pb_avg_voxelize_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_knn_points_ws_bytes.restype = ctypes.c_size_t
+        _lib.p2pb_three_nn_cells_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_fps_coop_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_conv3d_k3_packed_floats.restype = ctypes.c_size_t
         _lib.p2pb_conv3d_k3_split_packed_bytes.restype = ctypes.c_size_t

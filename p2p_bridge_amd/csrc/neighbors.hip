@@ -421,6 +421,251 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
   id[j + 2 * n] = i2;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same search through a uniform grid over the centres (exact): brute force evaluates n x m pairs (537 M per call
+// at the first level; ~190 us of pure instruction issue, more beside the main stream), the grid ~50 per point.
+//   nn_cells_build : one workgroup per cloud. Cubic cells of edge h = (largest bounding-box extent of the centres) /
+//                    NNC_G; count (LDS atomics) -> exclusive scan -> fill -> every cell's short id list sorted
+//                    ascending. cell_start i32[b][G^3 + 1], cell_ids i32[b][m], box f32[b][4] = (min x, y, z, h).
+//   three_nn_cells : one thread per point, the cloud's records + cell table in LDS: visit the cells within Chebyshev
+//                    radius rho of the point's (clamped) cell, rho = 1 (the 3x3x3 block), 2, ... (one more shell
+//                    each); every centre outside is farther than rho * h, so the search stops as
+//                    soon as three are held and the third distance is <= (rho h)^2. Candidates arrive out of index
+//                    order, so ties are broken explicitly (smaller index first) -- what "first strict minimum in
+//                    ascending index" gives the brute-force kernel. Same distances (sqdist3), same weights.
+// ------------------------------------------------------------------------------------------------
+#define NNC_G 16
+#define NNC_CELLS (NNC_G * NNC_G * NNC_G)
+
+__global__ __launch_bounds__(1024) void nn_cells_build_kernel(int m, const float *__restrict__ centers,
+                                                              int *__restrict__ cell_start, int *__restrict__ cell_ids,
+                                                              float4 *__restrict__ cell_rec, float *__restrict__ box) {
+  __shared__ int cnt[NNC_CELLS];
+  __shared__ int part[1024];
+  __shared__ float red[6][16];
+  __shared__ float sbox[4];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float *ce = centers + (size_t)b * 3 * m;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = t; k < m; k += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = ce[k + a * m];
+      lo[a] = fminf(lo[a], v);
+      hi[a] = fmaxf(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+    }
+    if (lane == 0) {
+      red[a][wave] = lo[a];
+      red[3 + a][wave] = hi[a];
+    }
+  }
+  for (int i = t; i < NNC_CELLS; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  if (t == 0) {
+    float mn[3], ext = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+      float l = INFINITY, h = -INFINITY;
+      for (int w = 0; w < 16; ++w) {
+        l = fminf(l, red[a][w]);
+        h = fmaxf(h, red[3 + a][w]);
+      }
+      mn[a] = l;
+      ext = fmaxf(ext, h - l);
+    }
+    const float hcell = fmaxf(ext, 1e-12f) / NNC_G;
+    for (int a = 0; a < 3; ++a) {
+      sbox[a] = mn[a];
+      box[(size_t)b * 4 + a] = mn[a];
+    }
+    sbox[3] = hcell;
+    box[(size_t)b * 4 + 3] = hcell;
+  }
+  __syncthreads();
+  const float inv = 1.0f / sbox[3];
+  auto cell_of = [&](int k) {
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = min(max((int)floorf((ce[k + a * m] - sbox[a]) * inv), 0), NNC_G - 1);
+    return (c[2] * NNC_G + c[1]) * NNC_G + c[0];
+  };
+  for (int k = t; k < m; k += 1024) atomicAdd(&cnt[cell_of(k)], 1);
+  __syncthreads();
+  // exclusive scan of the 4096 counts: thread t owns cells 4t .. 4t+3
+  int c4[4], tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c4[i] = cnt[4 * t + i];
+    tot += c4[i];
+  }
+  part[t] = tot;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - tot;
+  int *cs = cell_start + (size_t)b * (NNC_CELLS + 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cs[4 * t + i] = run;
+    cnt[4 * t + i] = run;  // becomes the fill cursor
+    run += c4[i];
+  }
+  if (t == 1023) cs[NNC_CELLS] = run;
+  __syncthreads();
+  int *ids = cell_ids + (size_t)b * m;
+  for (int k = t; k < m; k += 1024) ids[atomicAdd(&cnt[cell_of(k)], 1)] = k;
+  __syncthreads();
+  // ascending ids inside every cell (insertion sort of a short list by the cell's owner thread)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s0 = cs[4 * t + i], s1 = s0 + c4[i];
+    for (int x = s0 + 1; x < s1; ++x) {
+      const int v = ids[x];
+      int y = x - 1;
+      while (y >= s0 && ids[y] > v) {
+        ids[y + 1] = ids[y];
+        --y;
+      }
+      ids[y + 1] = v;
+    }
+    // the cell's centres as (x, y, z, id) records, contiguous: what the search streams through LDS
+    float4 *rec = cell_rec + (size_t)b * m;
+    for (int x = s0; x < s1; ++x) {
+      const int k = ids[x];
+      rec[x] = make_float4(ce[k], ce[k + m], ce[k + 2 * m], __int_as_float(k));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void three_nn_cells_kernel(int n, int m, const float *__restrict__ points,
+                                                             const int *__restrict__ cell_start,
+                                                             const float4 *__restrict__ cell_rec,
+                                                             const float *__restrict__ box, float *__restrict__ weights,
+                                                             int *__restrict__ indices) {
+  // the cloud's cell table and sorted centre records, shared by the workgroup's 256 points (all of one cloud):
+  // every candidate is then one 16-byte LDS read at an address known up front (no dependent global loads)
+  extern __shared__ float4 nnc_lds[];
+  float4 *rec = nnc_lds;
+  int *cs = (int *)(nnc_lds + m);
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < m; i += 256) rec[i] = cell_rec[(size_t)b * m + i];
+  for (int i = threadIdx.x; i <= NNC_CELLS; i += 256) cs[i] = cell_start[(size_t)b * (NNC_CELLS + 1) + i];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float *p = points + (size_t)b * 3 * n;
+  const float ux = p[j], uy = p[j + n], uz = p[j + 2 * n];
+  const float h = box[(size_t)b * 4 + 3], inv = 1.0f / h;
+  const int cx = min(max((int)floorf((ux - box[(size_t)b * 4]) * inv), 0), NNC_G - 1);
+  const int cy = min(max((int)floorf((uy - box[(size_t)b * 4 + 1]) * inv), 0), NNC_G - 1);
+  const int cz = min(max((int)floorf((uz - box[(size_t)b * 4 + 2]) * inv), 0), NNC_G - 1);
+  float best0 = INFINITY, best1 = INFINITY, best2 = INFINITY;
+  int i0 = 0, i1 = 0, i2 = 0;
+  // (distance, index) lexicographic: what ascending-index brute force with strict '<' selects
+  auto before = [](float d, int k, float bd, int bi) { return d < bd || (d == bd && k < bi); };
+  // (always_inline: as an out-of-line call the by-reference captures -- the three bests -- would live in scratch)
+  auto consider = [&](const float4 r) __attribute__((always_inline)) {
+    const int k = __float_as_int(r.w);
+    const float d = sqdist3(ux - r.x, uy - r.y, uz - r.z);
+    if (d <= best2) {  // (one compare rejects almost every candidate)
+      // sorted insertion as selects: written with nested ifs + shifts the compiler turned the three bests into a
+      // dynamically indexed scratch array (8x slower)
+      const bool c2 = before(d, k, best2, i2), c1 = before(d, k, best1, i1), c0 = before(d, k, best0, i0);
+      const float n2 = c1 ? best1 : (c2 ? d : best2), n1 = c0 ? best0 : (c1 ? d : best1), n0 = c0 ? d : best0;
+      const int m2 = c1 ? i1 : (c2 ? k : i2), m1 = c0 ? i0 : (c1 ? k : i1), m0 = c0 ? k : i0;
+      best2 = n2;
+      best1 = n1;
+      best0 = n0;
+      i2 = m2;
+      i1 = m1;
+      i0 = m0;
+    }
+  };
+  auto visit_run = [&](int q0, int q1) __attribute__((always_inline)) {  // consecutive cells = consecutive records
+    for (int q = q0; q < q1; q += 4) {  // four independent LDS reads in flight, candidates taken in order
+      float4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = rec[min(q + u, q1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q + u < q1) consider(r[u]);
+    }
+  };
+  for (int rho = 1; rho < NNC_G; ++rho) {
+    const int z0 = max(cz - rho, 0), z1 = min(cz + rho, NNC_G - 1);
+    const int y0 = max(cy - rho, 0), y1 = min(cy + rho, NNC_G - 1);
+    const int x0 = max(cx - rho, 0), x1 = min(cx + rho, NNC_G - 1);
+    for (int z = z0; z <= z1; ++z)
+      for (int y = y0; y <= y1; ++y) {
+        const int row = (z * NNC_G + y) * NNC_G;  // the cells of one x-row are consecutive
+        // rho = 1: the whole 3x3x3 block (ring 0 alone can never end the search); later: the shell of Chebyshev
+        // radius rho -- full rows on its z / y faces, the two end cells on the interior rows
+        const bool face = rho == 1 || z == cz - rho || z == cz + rho || y == cy - rho || y == cy + rho;
+        if (face) {
+          visit_run(cs[row + x0], cs[row + x1 + 1]);
+        } else {
+          if (cx - rho >= 0) visit_run(cs[row + cx - rho], cs[row + cx - rho + 1]);
+          if (cx + rho <= NNC_G - 1) visit_run(cs[row + cx + rho], cs[row + cx + rho + 1]);
+        }
+      }
+    // everything not visited yet is farther than rho * h (in at least one axis the cell index differs by > rho)
+    const float bound = (float)rho * h;
+    if (best2 <= bound * bound * 0.9999f && best2 < INFINITY) break;  // (margin: cell assignment rounds)
+    if (x0 == 0 && y0 == 0 && z0 == 0 && x1 == NNC_G - 1 && y1 == NNC_G - 1 && z1 == NNC_G - 1) break;  // all cells seen
+  }
+  best0 = fmaxf(fminf(1e10f, best0), 1e-10f);
+  best1 = fmaxf(fminf(1e10f, best1), 1e-10f);
+  best2 = fmaxf(fminf(1e10f, best2), 1e-10f);
+  const float d0d1 = best0 * best1, d0d2 = best0 * best2, d1d2 = best1 * best2;
+  const float invw = __fdiv_rn(1.0f, d0d1 + d0d2 + d1d2);
+  float *w = weights + (size_t)b * 3 * n;
+  int *id = indices + (size_t)b * 3 * n;
+  w[j] = d1d2 * invw;
+  id[j] = i0;
+  w[j + n] = d0d2 * invw;
+  id[j + n] = i1;
+  w[j + 2 * n] = d0d1 * invw;
+  id[j + 2 * n] = i2;
+}
+
+#define NNC_MAX_M 8192  // records + cell table in LDS: 16 m + 16.4 KB <= 148 KB
+
+extern "C" size_t p2pb_three_nn_cells_ws_bytes(int b, int m) {
+  return (size_t)b * m * 16 + ((size_t)b * (NNC_CELLS + 1) + (size_t)b * m) * sizeof(int) + (size_t)b * 4 * sizeof(float);
+}
+
+// p2pb_three_nn through a uniform grid over the centres: same idx / w. 3 <= m <= 8192;
+// ws: p2pb_three_nn_cells_ws_bytes(b, m) bytes, 16-byte aligned
+extern "C" int p2pb_three_nn_cells(int b, int m, int n, const float *points, const float *centers, int *idx, float *w,
+                                   void *ws, void *stream) {
+  if (b <= 0 || n <= 0 || m < 3 || m > NNC_MAX_M || !ws || ((uintptr_t)ws & 15)) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float4 *cell_rec = (float4 *)ws;
+  int *cell_start = (int *)(cell_rec + (size_t)b * m);
+  int *cell_ids = cell_start + (size_t)b * (NNC_CELLS + 1);
+  float *box = (float *)(cell_ids + (size_t)b * m);
+  const size_t lds = (size_t)m * 16 + (NNC_CELLS + 1) * sizeof(int);
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void *)three_nn_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  hipLaunchKernelGGL(nn_cells_build_kernel, dim3(b), dim3(1024), 0, s, m, centers, cell_start, cell_ids, cell_rec, box);
+  hipLaunchKernelGGL(three_nn_cells_kernel, dim3(cdiv(n, 256), b), dim3(256), lds, s, n, m, points, cell_start, cell_rec,
+                     box, w, idx);
+  return p2pb_launch_status();
+}
+
 template <int CC>
 __global__ __launch_bounds__(256) void three_interp_kernel(int c, int m, int n, const float *__restrict__ cfeat,
                                                            const int *__restrict__ indices,

@@ -231,3 +231,34 @@ def test_auction(met):
     g0 = torch.zeros(B, N, 3)
     cpu_ops.auction_backward(x1, x2, g0, gd, a1)
     assert torch.allclose(gx.cpu(), g0, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,M,kind", [(3, 8192, 2048, "patch"), (2, 2048, 512, "patch"), (2, 1000, 300, "plane"),
+                                         (2, 777, 256, "dups"), (1, 5000, 1024, "outside"), (2, 600, 257, "line")])
+def test_three_nn_grid_search_matches_brute_force(ext, B, N, M, kind, monkeypatch):
+    """the uniform-grid 3-NN (csrc/neighbors.hip three_nn_cells) is exact: same indices (ties by ascending index) and
+    weights as the brute-force kernel, which is bit-exact against the oracle above"""
+    g = torch.Generator().manual_seed(N + M)
+    if kind == "patch":
+        pts = cloud(B, N, seed=3)
+    elif kind == "plane":
+        pts = torch.rand(B, 3, N, generator=g) * 2 - 1
+        pts[:, 2] = 0.25
+    elif kind == "line":
+        pts = torch.zeros(B, 3, N)
+        pts[:, 0] = torch.rand(B, N, generator=g)
+    else:
+        pts = torch.randn(B, 3, N, generator=g) * 0.4
+    pts = pts.contiguous()
+    cen = pts[:, :, torch.randperm(N, generator=g)[:M]].contiguous()
+    if kind == "dups":  # duplicated centres: exactly equal distances, ties must resolve by index
+        cen[:, :, M // 2:] = cen[:, :, :M - M // 2]
+        pts[:, :, :50] = cen[:, :, :50]  # zero distances too
+    if kind == "outside":  # query points far outside the centres' bounding box
+        pts[:, :, :500] = pts[:, :, :500] * 6 + 3
+    monkeypatch.setenv("P2PB_NN_CELLS", "0")
+    i_ref, w_ref = ext.three_nn(dev(pts), dev(cen))
+    monkeypatch.setenv("P2PB_NN_CELLS", "1")
+    i_got, w_got = ext.three_nn(dev(pts), dev(cen))
+    eq(i_got, i_ref, "idx")
+    eq(w_got, w_ref, "weights")
