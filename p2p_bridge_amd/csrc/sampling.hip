@@ -14,6 +14,7 @@
 // net order is (d desc, k mod 512 asc, k asc); it is encoded in the low word of the key so any
 // thread layout reproduces it.
 #include "common.h"
+#include <cstdlib>
 
 typedef unsigned long long u64;
 
@@ -283,6 +284,7 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
     (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)fps_kernel<512, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     attr_set = true;
   }
   if (n <= 64) fps_launch<64, 1>(b, n, m, coords, idx, s);
@@ -292,7 +294,7 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
   else if (n <= 1024) fps_launch<256, 4>(b, n, m, coords, idx, s);
   else if (n <= 2048) fps_launch<256, 8>(b, n, m, coords, idx, s);
   else if (n <= 4096) fps_launch<1024, 4>(b, n, m, coords, idx, s);
-  else if (n <= 8192) fps_launch<1024, 8>(b, n, m, coords, idx, s);
+  else if (n <= 8192) fps_launch<512, 16>(b, n, m, coords, idx, s);  // 8 waves: 1.71 ms vs 2.10 with 16 x 8 points
   else if (n <= 16384) fps_launch<1024, 16>(b, n, m, coords, idx, s);
   else {
     if (!dist_ws) return P2PB_EINVAL;
