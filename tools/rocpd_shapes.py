@@ -6,7 +6,7 @@ import sys
 
 def main(path, pat):
     cur = sqlite3.connect(path).cursor()
-    fps = [r for r in cur.execute("select start,end from kernels where name like '%fps_kernel<1024, 8%' order by start")]
+    fps = [r for r in cur.execute("select start,end from kernels where name like '%fps_kernel<512, 16%' order by start")]
     n = len(fps) // 2
     t0, t1 = fps[n][0], fps[-1][0] + (fps[-1][0] - fps[-2][0])
     ev = len(fps) - n
