@@ -1003,10 +1003,27 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
     vcls[t] = (unsigned char)cls;
     __syncthreads();
     float *ob = out + (size_t)b * cout * R3;
-    for (int e = t; e < 256 * cout; e += 256) {
-      const int vl = e / cout, co = e - vl * cout;
-      const int dd = d0 + vl / (TH * TW), hh = h0 + (vl / TW) % TH, ww = w0 + vl % TW;
-      ob[(size_t)((dd * R + hh) * R + ww) * cout + co] = kb ? kb[vcls[vl] * cout + co] : bias[co];
+    if ((cout & 3) == 0) {  // 16 bytes per thread, (voxel, channel quad) advanced without a division per element
+      const int c4n = cout >> 2, dq = 256 / c4n, dr = 256 % c4n;
+      int vl = t / c4n, c4 = t % c4n;
+      for (; vl < 256; vl += dq) {
+        const int dd = d0 + vl / (TH * TW), hh = h0 + (vl / TW) % TH, ww = w0 + vl % TW;
+        const float *src = kb ? kb + vcls[vl] * cout : bias;
+        *(f32x4 *)(ob + (size_t)((dd * R + hh) * R + ww) * cout + 4 * c4) = *(const f32x4 *)(src + 4 * c4);
+        if (dr) {
+          c4 += dr;
+          if (c4 >= c4n) {
+            c4 -= c4n;
+            ++vl;
+          }
+        }
+      }
+    } else {
+      for (int e = t; e < 256 * cout; e += 256) {
+        const int vl = e / cout, co = e - vl * cout;
+        const int dd = d0 + vl / (TH * TW), hh = h0 + (vl / TW) % TH, ww = w0 + vl % TW;
+        ob[(size_t)((dd * R + hh) * R + ww) * cout + co] = kb ? kb[vcls[vl] * cout + co] : bias[co];
+      }
     }
   } else {
     float *ob = out + (size_t)b * cout * R3 + (d * R + h) * R + w;

@@ -265,38 +265,46 @@ __global__ __launch_bounds__(256) void transpose_cn_kernel(int c, int n, const f
 // the whole grid in one pass: a thread owns V consecutive channels of one voxel -- zeros for an empty voxel, the
 // ascending-order mean (same arithmetic as above) otherwise; replaces zero-fill + gather over the occupied list
 typedef float vox_f32x4 __attribute__((ext_vector_type(4)));
-template <int V>
+// ALIGNED: c % 4 == 0, 16-byte loads / stores; else (e.g. the 3 + 32 channels of the first PVConv) a thread still owns
+// four consecutive channels -- one occupancy lookup per quad -- but moves them as scalars and clips the last quad
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void vox_gather_cl_all_kernel(int c, int n, int r3, const int *__restrict__ cnt,
                                                                 const int *__restrict__ cur,
                                                                 const int *__restrict__ slist,
                                                                 const float *__restrict__ feat_t,
                                                                 float *__restrict__ out) {
-  const int b = blockIdx.y, cv = c / V;
+  const int b = blockIdx.y, cv = (c + 3) / 4;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (size_t)r3 * cv) return;
-  const int v = (int)(e / cv), ch = (int)(e % cv) * V;
+  const int v = (int)(e / cv), ch = (int)(e % cv) * 4;
+  const int nch = min(4, c - ch);
   const int cn = cnt[(size_t)b * r3 + v];
-  float acc[V];
-#pragma unroll
-  for (int i = 0; i < V; ++i) acc[i] = 0.0f;
+  float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if (cn > 0) {
     const int *seg = slist + (size_t)b * n + (cur[(size_t)b * r3 + v] - cn);
     const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
     const float *f = feat_t + (size_t)b * n * c + ch;
     for (int q = 0; q < cn; ++q) {
       const float *fq = f + (size_t)seg[q] * c;
-      if (V == 4) {
+      if (ALIGNED) {
         const vox_f32x4 x = *(const vox_f32x4 *)fq;
 #pragma unroll
-        for (int i = 0; i < V; ++i) acc[i] += x[i] * div;
+        for (int i = 0; i < 4; ++i) acc[i] += x[i] * div;
       } else {
-        acc[0] += fq[0] * div;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < nch) acc[i] += fq[i] * div;
       }
     }
   }
   float *o = out + ((size_t)b * r3 + v) * c + ch;
-  if (V == 4) *(vox_f32x4 *)o = vox_f32x4{acc[0], acc[1], acc[2], acc[V - 1]};
-  else o[0] = acc[0];
+  if (ALIGNED) {
+    *(vox_f32x4 *)o = vox_f32x4{acc[0], acc[1], acc[2], acc[3]};
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < nch) o[i] = acc[i];
+  }
 }
 
 // The coordinate-only half of the voxelisation (occupancy counts + per-voxel sorted point lists): it depends on
@@ -335,12 +343,11 @@ extern "C" int p2pb_avg_voxelize_cl_gather(int b, int c, int n, int r, const flo
   const int *nocc = occ + (size_t)b * n;
   const int maxocc = n < r3 ? n : r3;
   hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, feat, feat_t);
+  const dim3 grid((unsigned)cdiv((size_t)r3 * ((c + 3) / 4), 256), b);
   if ((c & 3) == 0)
-    hipLaunchKernelGGL(vox_gather_cl_all_kernel<4>, dim3((unsigned)cdiv((size_t)r3 * (c / 4), 256), b), dim3(256), 0, s, c, n,
-                       r3, cnt, cur, slist, feat_t, out);
+    hipLaunchKernelGGL(vox_gather_cl_all_kernel<true>, grid, dim3(256), 0, s, c, n, r3, cnt, cur, slist, feat_t, out);
   else
-    hipLaunchKernelGGL(vox_gather_cl_all_kernel<1>, dim3((unsigned)cdiv((size_t)r3 * c, 256), b), dim3(256), 0, s, c, n, r3,
-                       cnt, cur, slist, feat_t, out);
+    hipLaunchKernelGGL(vox_gather_cl_all_kernel<false>, grid, dim3(256), 0, s, c, n, r3, cnt, cur, slist, feat_t, out);
   (void)occ;
   (void)nocc;
   (void)maxocc;
