@@ -208,7 +208,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from oracle import net_ref  # synthetic input generator only (bench leg of the oracle rules)
+    from p2p_bridge_amd.synthetic import synthetic_patches
     from p2p_bridge_amd import p2pb as product
     from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
 
@@ -219,7 +219,7 @@ def main():
     torch.manual_seed(0)
     sd = {k: v.clone() for k, v in PVCNN2Unet(cfg).state_dict().items()}
     model = product.build_model(cfg, sd, device=f"cuda:{local_rank}")
-    x_start, _ = net_ref.synthetic_patches(args.batch, args.points, seed=rank)
+    x_start, _ = synthetic_patches(args.batch, args.points, seed=rank)
     x_start = x_start.cuda()
 
     def one():

@@ -185,3 +185,16 @@ def test_ema_schedule_and_reference_checkpoint_roundtrip(tmp_path):
     assert load_checkpoint(dst2, torch.load(path), restart=True) == 0
     for a, b in zip(dst2.model.state_dict().values(), dst2.ema.ema_model.state_dict().values()):
         assert torch.equal(a, b)
+
+
+def test_bench_workload_generator_matches_oracle_copy():
+    """bench.py draws its patches from the product package (no oracle code on the measured path); the oracle keeps an
+    identical generator for its own use"""
+    import torch
+    from oracle import net_ref
+    from p2p_bridge_amd.synthetic import synthetic_patches
+
+    a, ac = synthetic_patches(3, 257, seed=5)
+    b, bc = net_ref.synthetic_patches(3, 257, seed=5)
+    assert torch.equal(a, b) and torch.equal(ac, bc)
+    assert a.shape == (3, 3, 257) and abs(a.norm(dim=1).max().item() - 1.0) < 1e-6
