@@ -373,6 +373,10 @@ def compact_plan():
     default: r = 16 (measured: +2.5 %; at r = 32 the brick-level lists win, at r = 8 the dense kernel); P2PB_COMPACT="32,16:16" overrides, empty = off"""
     import os
 
+    from . import fused
+
+    if fused.conv_math() != "bf16x6":  # the compact kernel exists in the split-operand arithmetic only
+        return set(), set()
     spec = os.environ.get("P2PB_COMPACT", "16:16")
     parts = (spec.split(":") + [""])[:2]
     return tuple({int(t) for t in p.split(",") if t.strip()} for p in parts)

@@ -198,3 +198,13 @@ def test_bench_workload_generator_matches_oracle_copy():
     b, bc = net_ref.synthetic_patches(3, 257, seed=5)
     assert torch.equal(a, b) and torch.equal(ac, bc)
     assert a.shape == (3, 3, 257) and abs(a.norm(dim=1).max().item() - 1.0) < 1e-6
+
+
+def test_exact_fp32_mode_disables_the_split_only_paths(monkeypatch):
+    from p2p_bridge_amd import pvcnn_unet
+
+    monkeypatch.delenv("P2PB_COMPACT", raising=False)
+    monkeypatch.setenv("P2PB_CONV_MATH", "bf16x6")
+    assert pvcnn_unet.compact_plan() == ({16}, {16})
+    monkeypatch.setenv("P2PB_CONV_MATH", "fp32")
+    assert pvcnn_unet.compact_plan() == (set(), set())
