@@ -220,3 +220,29 @@ def test_training_step_grads(tiny):
     for k in ("classifier.2.weight", "embedf.0.weight"):
         g, exp = params[k].grad.cpu().numpy(), run["grad_" + k]
         assert np.abs(g - exp).max() <= 1e-3 * max(1.0, np.abs(exp).max()), k
+
+
+def test_full_size_pvdl_fused_vs_unfused():
+    """PVDL at its real size (channels 64..1024, 13 PVConvs, 384 extra feature channels, 118.7 M parameters; BASELINE
+    configs 4-5): the fused inference path (compact / sparse convolutions, split-operand GEMMs, folded norms) against
+    the unfused autograd path of the same module on the same HIP ops -- one evaluation, B=2, N=4096"""
+    import copy
+
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.synthetic import synthetic_patches
+    from test_host_logic import pvdl_cfg
+
+    cfg = copy.deepcopy(pvdl_cfg())
+    torch.manual_seed(0)
+    model = product.build_model(cfg, device="cuda")
+    assert abs(sum(p.numel() for p in model.model.parameters()) / 1e6 - 118.67) < 0.01
+    x, _ = synthetic_patches(2, 4096, seed=1)
+    xin = torch.cat([x, torch.randn(2, 384, 4096)], 1).cuda()
+    t = torch.tensor([500.0, 20.0], device="cuda")
+    model.model.eval()
+    with torch.no_grad():
+        y_fused = model.model(xin, t)
+    with torch.enable_grad():
+        y_ref = model.model(xin, t).detach()
+    assert torch.isfinite(y_fused).all()
+    assert (y_fused - y_ref).abs().max().item() < TOL
