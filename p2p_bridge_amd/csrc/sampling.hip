@@ -238,12 +238,16 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, const floa
       const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 15);
       const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
       const int par = (j & 1) * FPS_G;
+      // Both words are device-scope write-through stores and L2-bypassing loads; ordering comes from waiting for
+      // the key's acknowledgement before the tag goes out (and the key being read after the tag was seen) -- a
+      // release / acquire pair here would write back / invalidate the XCD's whole L2 every round
       if (t == 0) {
         __hip_atomic_store(&kslot[par + g], ((u64)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&tslot[par + g], (unsigned)j, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (s_waitcnt: the key store has been acknowledged)
+        __hip_atomic_store(&tslot[par + g], (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       int spins = 0;
-      while (__hip_atomic_load(&tslot[par + t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)j) {
+      while (__hip_atomic_load(&tslot[par + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)j) {
         if (++spins > (1 << 22)) {  // a peer never arrived (not co-resident?): give up loudly
           __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           spins = -1;
