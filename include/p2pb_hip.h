@@ -100,7 +100,7 @@ int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float
 
 /* the same sampling for ONE large cloud (object merge, denoise_object.py:112: 3N patch points -> N): 64 workgroups
  * share a cloud, points and running distances stay in registers, one global all-gather per round. Same indices as
- * p2pb_furthest_point_sampling. 16384 < n <= 524288, b <= 2 (b*64 workgroups must be resident together);
+ * p2pb_furthest_point_sampling. 16384 < n <= 524288, b <= 4 (b*64 workgroups must be resident together);
  * ws: p2pb_fps_coop_ws_bytes(b) bytes, its last int is an error flag (1 = a workgroup never arrived). */
 size_t p2pb_fps_coop_ws_bytes(int b);
 int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx, void *stream);

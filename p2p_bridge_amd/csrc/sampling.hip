@@ -309,12 +309,12 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
 
 extern "C" size_t p2pb_fps_coop_ws_bytes(int b) { return (size_t)b * 2 * FPS_G * (sizeof(u64) + sizeof(unsigned)) + 16; }
 
-// Large single clouds (16384 < n <= 524288; b * 64 workgroups must be resident together, so b is small): same result
+// Large clouds (16384 < n <= 524288; b * 64 workgroups of 16 waves must be resident together: b <= 4): same result
 // as p2pb_furthest_point_sampling. ws: p2pb_fps_coop_ws_bytes(b) bytes, zeroed by the callee. Returns P2PB_EINVAL
 // outside that range (callers fall back to p2pb_furthest_point_sampling).
 extern "C" int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx,
                                                  void *stream) {
-  if (b <= 0 || b > 2 || n <= 16384 || n > FPS_G * 1024 * 8 || m < 0 || !ws) return P2PB_EINVAL;
+  if (b <= 0 || b > 4 || n <= 16384 || n > FPS_G * 1024 * 8 || m < 0 || !ws) return P2PB_EINVAL;
   if (m == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const size_t nbytes = p2pb_fps_coop_ws_bytes(b);

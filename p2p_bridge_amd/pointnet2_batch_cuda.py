@@ -149,11 +149,11 @@ def furthest_point_sampling_forward(coords, num_samples):
     m = int(num_samples)
     idx = torch.empty(b, m, dtype=I32, device=coords.device)
     if 16384 < n <= 524288 and m > 1 and os.environ.get("P2PB_FPS_COOP", "1") != "0":
-        # large clouds (BASELINE configs 4-5: 50000 points): 64 workgroups per cloud, two clouds per launch; same
+        # large clouds (BASELINE configs 4-5: 50000 points): 64 workgroups per cloud, up to four clouds per launch; same
         # indices as the single-workgroup kernel, 2.2x faster
         flags = []
-        for b0 in range(0, b, 2):
-            nb = min(2, b - b0)
+        for b0 in range(0, b, 4):
+            nb = min(4, b - b0)
             ws = torch.empty(int(lib().p2pb_fps_coop_ws_bytes(_i(nb))), dtype=torch.uint8, device=coords.device)
             call("p2pb_furthest_point_sampling_coop", _i(nb), _i(n), _i(m), ptr(coords[b0:]), ptr(ws), ptr(idx[b0:]),
                  stream_ptr())
