@@ -102,7 +102,7 @@ def test_ball_query_and_grouping(ext, B, N, M, radius):
 
 @pytest.mark.parametrize("B,N,M", [(4, 8192, 2048), (3, 2048, 512), (2, 512, 128), (2, 128, 32), (2, 1000, 999),
                                    (1, 5000, 700), (2, 100, 100), (1, 64, 8), (1, 16384, 300), (1, 20000, 200),
-                                   (2, 33, 1)])
+                                   (2, 33, 1), (2, 8192, 8192), (3, 6000, 63), (2, 7777, 1500)])
 def test_fps_and_gather(ext, B, N, M):
     c = cloud(B, N, seed=N + M)
     i0 = cpu_ops.furthest_point_sampling_forward(c, M)
@@ -113,7 +113,7 @@ def test_fps_and_gather(ext, B, N, M):
     eq(ext.gather_features_backward(dev(gy), i1, N), cpu_ops.gather_features_backward(gy, i0, N), "gather grad")
 
 
-@pytest.mark.parametrize("N,M", [(4096, 600), (1024, 256), (3000, 500)])
+@pytest.mark.parametrize("N,M", [(4096, 600), (1024, 256), (3000, 500), (8192, 900), (5000, 4999), (4097, 64)])
 def test_fps_tie_break(ext, N, M):
     """lattice points: many exactly equal distances, so the (d, k mod 512, k) order decides."""
     g = torch.Generator().manual_seed(N)
@@ -262,3 +262,23 @@ def test_three_nn_grid_search_matches_brute_force(ext, B, N, M, kind, monkeypatc
     i_got, w_got = ext.three_nn(dev(pts), dev(cen))
     eq(i_got, i_ref, "idx")
     eq(w_got, w_ref, "weights")
+
+
+@pytest.mark.parametrize("kind", ["line", "plane", "clusters", "dups"])
+def test_fps_degenerate_clouds(ext, kind):
+    """first-level FPS on degenerate clouds: collinear / planar points, tight far-apart clusters, exact duplicates"""
+    g = torch.Generator().manual_seed(7)
+    N, M = 8000, 1200
+    c = torch.zeros(2, 3, N)
+    if kind == "line":
+        c[:, 0] = torch.rand(2, N, generator=g)
+    elif kind == "plane":
+        c[:, :2] = torch.rand(2, 2, N, generator=g)
+    elif kind == "clusters":
+        centres = torch.randn(2, 3, 8, generator=g) * 3
+        c = centres[:, :, torch.randint(0, 8, (N,), generator=g)] + 1e-3 * torch.randn(2, 3, N, generator=g)
+    else:
+        c = torch.randn(2, 3, N, generator=g)
+        c[:, :, N // 2:] = c[:, :, :N - N // 2]
+    c = c.contiguous()
+    eq(ext.furthest_point_sampling_forward(dev(c), M), cpu_ops.furthest_point_sampling_forward(c, M), kind)
