@@ -161,6 +161,16 @@ def conv_math_note():
             else "exact-fp32 MFMA")
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sd, n_points, T, patches=2, budget_s=20.0):
     """The CPU oracle (C ops + torch CPU dense layers, all host threads) on a bounded sample of the same workload:
     `patches` patches through the FULL T-step sampler when that fits the time budget (it does on the GPU box's host:
@@ -170,7 +180,8 @@ def cpu_baseline(sd, n_points, T, patches=2, budget_s=20.0):
 
     x, _ = net_ref.synthetic_patches(patches, n_points, seed=0)
     net = net_ref.RefNet(PVDS, sd, vox_mode="tree")
-    cores = min(os.cpu_count() or 1, 32)  # beyond ~32 threads these small per-patch ops only contend
+    host = os.cpu_count() or 1
+    cores = min(host, 32)  # threads actually used: beyond ~32 these small per-patch ops only contend
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     from oracle import cpu_ops
@@ -183,7 +194,8 @@ def cpu_baseline(sd, n_points, T, patches=2, budget_s=20.0):
     t0 = time.perf_counter()
     net_ref.sample(net, PVDS, x, steps=steps, log_count=1)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(patches * n_points / (dt * T), 2), "unit": "points/s", "cores": cores, "kind": "port",
+    return {"value": round(patches * n_points / (dt * T), 2), "unit": "points/s", "cores": cores, "host_cores": host,
+            "host_cpu": cpu_model(), "kind": "port",
             "sample": f"{patches} patches x {n_points} pts, {steps} of T={T} bridge steps timed after 1 warm-up step "
                       f"({dt:.2f} s/step, {dt * steps:.1f} s of CPU work)"
                       + ("" if steps == T else f", extrapolated to T={T}")}
@@ -199,20 +211,30 @@ def main():
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL over xGMI); gloo only with --dry-run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / timing protocol only, no GPU work (CPU self-test of the N-rank path)")
     args = ap.parse_args()
+    from p2p_bridge_amd import sharding
 
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if not torch.cuda.is_available():
+    if args.backend != "nccl" and not args.dry_run:
+        raise SystemExit("--backend other than nccl is for --dry-run only: the product has no CPU path")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    mode, world = sharding.launch_plan(args.gpus, os.environ, ndev if args.backend == "nccl" else args.gpus, args.backend)
+    if mode == "spawn":  # `python bench.py --gpus N`: become N ranks, one per GPU (reference: train.py:20-46,229)
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], world))
+    if not args.dry_run and ndev == 0:
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    rank = local_rank = 0
     dist = None
-    if world > 1:
+    if mode == "rank":
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        rank, local_rank, world = sharding.init_rank(args.backend)
+    elif ndev:
+        torch.cuda.set_device(0)
+    if args.dry_run:
+        return dry_run(args, dist, rank, world)
 
     from p2p_bridge_amd.synthetic import synthetic_patches
     from p2p_bridge_amd import p2pb as product
@@ -225,7 +247,7 @@ def main():
     torch.manual_seed(0)
     sd = {k: v.clone() for k, v in PVCNN2Unet(cfg).state_dict().items()}
     model = product.build_model(cfg, sd, device=f"cuda:{local_rank}")
-    x_start, _ = synthetic_patches(args.batch, args.points, seed=rank)
+    x_start, _ = synthetic_patches(args.batch, args.points, seed=rank)  # every rank denoises its OWN patches
     x_start = x_start.cuda()
 
     def one():
@@ -245,23 +267,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt = sharding.max_over_ranks(dt, device="cuda")
     assert torch.isfinite(out["x_pred"]).all()
 
-    pts = world * args.batch * args.points * args.steps
-    res = {
-        "metric": "denoised points/sec (8192-pt patches, T=30)", "value": round(pts / dt, 1), "unit": "points/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"PVDS_PUNet xyz-only, {args.points}-pt patches, T={args.T} bridge steps, batch "
-                               f"{args.batch} per GPU (BASELINE configs[1])", "patches_per_gpu": args.batch,
-                   "points_per_patch": args.points, "bridge_steps": args.T, "parallelism": f"patch-shard x{world}",
-                   "hipgraph": bool(args.graph), "weights": "seeded random init (26.44 M params)",
-                   "conv_math": conv_math_note()},
-    }
+    res = result_line(args, world, dt, dist)
+    res["config"]["conv_math"] = conv_math_note()
     if rank == 0:
         res["roofline"] = gemm_roofline(model, args.batch, args.points)
         res["roofline"]["second_kernel"] = conv_roofline(model, args.batch)  # the voxel convolution, same protocol
@@ -270,6 +280,44 @@ def main():
             61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, args.points, args.T)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def result_line(args, world, dt, dist):
+    pts = world * args.batch * args.points * args.steps
+    return {
+        "metric": "denoised points/sec (8192-pt patches, T=30)", "value": round(pts / dt, 1), "unit": "points/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"PVDS_PUNet xyz-only, {args.points}-pt patches, T={args.T} bridge steps, batch "
+                               f"{args.batch} per GPU (BASELINE configs[1])", "patches_per_gpu": args.batch,
+                   "points_per_patch": args.points, "bridge_steps": args.T, "parallelism": f"patch-shard x{world}",
+                   "process_group_world_size": dist.get_world_size() if dist is not None else 1,
+                   "process_group_backend": (dist.get_backend() if dist is not None else None),
+                   "hipgraph": bool(args.graph), "weights": "seeded random init (26.44 M params)"},
+    }
+
+
+def dry_run(args, dist, rank, world):
+    """the N-rank protocol without a GPU (tests/test_bench_launch.py): same barrier / max-over-ranks bracket around a
+    stand-in step whose duration depends on the rank, same JSON line; `value` is meaningless and flagged as such"""
+    from p2p_bridge_amd import sharding
+
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))
+    if dist is not None:
+        dist.barrier()
+    dt = sharding.max_over_ranks(time.perf_counter() - t0)
+    res = result_line(args, world, dt, dist)
+    res["dry_run"] = True
+    res["data"] = "none (dry run: launch / rendezvous / timing protocol only)"
+    if rank == 0:
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

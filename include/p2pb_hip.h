@@ -98,11 +98,13 @@ int p2pb_gather_features_backward(int b, int c, int n, int m, const float *grad_
 int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float *dist_ws, int *idx,
                                  void *stream);
 
-/* the same sampling for ONE large cloud (object merge, denoise_object.py:112: 3N patch points -> N): 64 workgroups
- * share a cloud, points and running distances stay in registers, one global all-gather per round. Same indices as
- * p2pb_furthest_point_sampling. 16384 < n <= 524288, b <= 4 (b*64 workgroups must be resident together);
- * ws: p2pb_fps_coop_ws_bytes(b) bytes, its last int is an error flag (1 = a workgroup never arrived). */
-size_t p2pb_fps_coop_ws_bytes(int b);
+/* the same sampling for LARGE clouds (object merge, denoise_object.py:112: 3N patch points -> N; the 50000-point
+ * room patches of BASELINE configs 4-5): 64 workgroups share a cloud, points and running distances stay in registers,
+ * one global all-gather per round. Same indices as p2pb_furthest_point_sampling. 16384 < n <= 524288, any b (launched
+ * four clouds at a time). ws: p2pb_fps_coop_ws_bytes(b, n) bytes; after the call the b ints at ws + b*1024 are
+ * per-cloud flags (1 = the cooperative kernel lost a peer; the single-workgroup kernel then recomputed that cloud on
+ * the device, so idx is valid either way). P2PB_EINVAL when the device cannot hold 64 workgroups at once. */
+size_t p2pb_fps_coop_ws_bytes(int b, int n);
 int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx, void *stream);
 
 /* point <-> triangle-mesh squared distances (P2M metric): replace pytorch3d._C.point_face_dist_forward /
@@ -326,6 +328,17 @@ int p2pb_affine_act(int b, int c, int npos, const float *x, const float *scale, 
 /* y[b,c,m] = max_{k<u} act(x[b,c,m,k]*scale + shift), u a power of two <= 64; u == 0: y[b,c] = max over m */
 int p2pb_affine_act_max(int b, int c, int m, int u, const float *x, const float *scale, const float *shift,
                         int swish, float *y, void *stream);
+
+/* ---- LinearAttention core (models/modules.py:165-194: `global_att`, models/unet_pvc.py:124-125,234-244) ----
+ * replaces k.softmax(-1) + the two torch.einsum calls (:186-188) between the to_qkv and to_out 1x1 convolutions
+ * (which run on p2pb_pointwise_conv_forward). qkv f32[b, 3*heads*dim_head, n] in the reference's channel order
+ * (q | k | v) x heads x dim_head; out f32[b, heads*dim_head, n]; dim_head must be 32 (the reference's only value).
+ * ctx (optional, f32[b, heads, 32, 32]) receives softmax(k) v^T for the backward pass.
+ * backward: grad_out f32[b, heads*32, n] -> grad_qkv f32[b, 3*heads*32, n]. */
+int p2pb_linear_attention_forward(int b, int heads, int dim_head, int n, const float *qkv, float *out, float *ctx,
+                                  void *stream);
+int p2pb_linear_attention_backward(int b, int heads, int dim_head, int n, const float *qkv, const float *ctx,
+                                   const float *grad_out, float *grad_qkv, void *stream);
 
 #ifdef __cplusplus
 }

@@ -232,7 +232,10 @@ class RefNet:
         vf = _Devox.apply(v, vc, r, self.training)
         self._log("devox", [r, vc, v], [vf])
         pf = self._shared_mlp(features, cond, prefix + ".point_features", 1)
-        return vf + pf
+        out = vf + pf
+        if prefix + ".attn.to_qkv.weight" in sd:  # models/pvcnn.py:327-328 (cfg attentions[i] on an SA stage)
+            out = self._linear_attention(out, prefix + ".attn")
+        return out
 
     def _sa_module(self, features, coords, time_emb, cond, st):
         """models/pvcnn.py:388-424 + BallQuery.forward :111-127"""
@@ -289,19 +292,19 @@ class RefNet:
         f = self._pnet_mlp(torch.cat([f, g], dim=1), "global_pnet.mlp2")
         return F.max_pool2d(f, kernel_size=[f.size(2), 1]).squeeze(-1).squeeze(-1)
 
-    def _linear_attention(self, x):
+    def _linear_attention(self, x, prefix="global_att"):
         """models/modules.py:177-194"""
         h = self.heads
         x = x.unsqueeze(-1)
         b, c, n, _ = x.shape
-        qkv = F.conv2d(x, self.sd["global_att.to_qkv.weight"])
+        qkv = F.conv2d(x, self.sd[prefix + ".to_qkv.weight"])
         qkv = qkv.view(b, 3, h, -1, n)
         q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
         k = k.softmax(dim=-1)
         context = torch.einsum("bhdn,bhen->bhde", k, v)
         out = torch.einsum("bhde,bhdn->bhen", context, q)
         out = out.reshape(b, -1, n, 1)
-        out = F.conv2d(out, self.sd["global_att.to_out.weight"], self.sd["global_att.to_out.bias"])
+        out = F.conv2d(out, self.sd[prefix + ".to_out.weight"], self.sd[prefix + ".to_out.bias"])
         return out.squeeze(-1)
 
     # -- the network --------------------------------------------------------------------------
@@ -385,11 +388,12 @@ def make_schedule(diff):
 
 
 @torch.no_grad()
-def sample(net, cfg, x_start, x_cond=None, steps=None, log_count=10, clip=False):
-    """P2PB.sample -> ddpm_sampling -> sample_ddpm, ot_ode=True path (models/p2pb.py:338-363, :265-335,
-    :215-262, p_posterior :190-213). Returns the reference's dict keys."""
+def sample(net, cfg, x_start, x_cond=None, steps=None, log_count=10, clip=False, randn_like=torch.randn_like):
+    """P2PB.sample -> ddpm_sampling -> sample_ddpm (models/p2pb.py:338-363, :265-335, :215-262, p_posterior
+    :190-213, incl. the stochastic branch `if not ot_ode and nprev > 0` :207-208 with `randn_like` as the noise
+    source). Returns the reference's dict keys."""
     diff = cfg["diffusion"]
-    assert diff.get("ot_ode", True), "oracle sampler covers the deterministic (ot_ode) path"
+    ot_ode = diff.get("ot_ode", True)
     sch = make_schedule(diff)
     T = diff["timesteps"]
     nsteps = steps or diff.get("sampling_timesteps") or T - 1
@@ -411,6 +415,9 @@ def sample(net, cfg, x_start, x_cond=None, steps=None, log_count=10, clip=False)
         std_d = (std_n ** 2 - std_p ** 2).sqrt()
         den = std_p ** 2 + std_d ** 2
         xt = (std_d ** 2 / den) * x0 + (std_p ** 2 / den) * xt
+        if not ot_ode and prev > 0:
+            var = (std_p ** 2 * std_d ** 2) / den
+            xt = xt + var.sqrt() * randn_like(xt)
         if prev in log_steps:
             xs.append(xt.detach())
     chain = torch.flip(torch.stack(xs, dim=1), dims=(1,))

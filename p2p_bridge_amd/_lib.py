@@ -27,7 +27,7 @@ SYMBOLS = [
     "p2pb_trilinear_devoxelize_affine", "p2pb_avg_voxelize_cl_forward", "p2pb_voxel_sort", "p2pb_avg_voxelize_cl_gather", "p2pb_trilinear_devoxelize_cl_affine", "p2pb_pointwise_packed_floats", "p2pb_pointwise_pack_weights",
     "p2pb_pointwise_stats_floats", "p2pb_pointwise_conv_forward", "p2pb_affine_act", "p2pb_affine_act_max",
     "p2pb_pointwise_split_packed_bytes", "p2pb_pointwise_pack_weights_split", "p2pb_pointwise_pool_supported", "p2pb_pointwise_minmax_floats", "p2pb_pointwise_conv_pool_forward",
-    "p2pb_minmax_act",
+    "p2pb_minmax_act", "p2pb_linear_attention_forward", "p2pb_linear_attention_backward",
 ]
 
 _lib = None

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void auction_bid_kernel(int n, const float *__
   for (int k = lane; k < n; k += 64) {
     const float *q = xyz2 + ((size_t)b * n + k) * 3;
     // emd_cuda.cu:146 : `3.0 - sqrtf(..) - price` is evaluated in double (3.0 is a double literal)
-    const float d = (float)((3.0 - (double)__fsqrt_rn(sqdist3(q[0] - x1, q[1] - y1, q[2] - z1))) -
+    const float d = (float)((3.0 - (double)sqrtf(sqdist3(q[0] - x1, q[1] - y1, q[2] - z1))) -
                             (double)price[(size_t)b * n + k]);
     if (d > best) {
       better = best;

@@ -144,10 +144,13 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float 
 }
 
 // n > 16384: running distances in global scratch, coordinates streamed from L2 each round.
+// only_if != nullptr: the kernel is the on-device fallback of fps_coop_kernel and runs only when that flag was raised.
 __global__ __launch_bounds__(1024) void fps_big_kernel(int n, int m, const float *__restrict__ coords,
-                                                       float *__restrict__ dist_ws, int *__restrict__ indices) {
+                                                       float *__restrict__ dist_ws, int *__restrict__ indices,
+                                                       const int *__restrict__ only_if) {
   __shared__ u64 slots[2][16];
   const int t = threadIdx.x;
+  if (only_if && __hip_atomic_load(only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
   const float *c = coords + (size_t)blockIdx.x * 3 * n;
   float *dist = dist_ws + (size_t)blockIdx.x * n;
   int *out = indices + (size_t)blockIdx.x * m;
@@ -180,26 +183,40 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(int n, int m, const float
   }
 }
 
-// n > 16384, the object-merge case (denoise_object.py:112: 3N patch points -> N, N = 10^4 .. 10^5): one workgroup
-// would stream the whole cloud from L2 every round (28 us per round at 150 k points). Here FPS_G workgroups share
-// one cloud: every thread keeps its PPT points and their running distances in registers, a round is a local
-// (wave + LDS) argmax, one 8-byte slot per workgroup published to global memory with a round tag, and an
-// all-gather by polling: lane i of wave 0 spins on slot i, reduces, and broadcasts the winner through LDS. Slots
-// are double-buffered by round parity (a workgroup can only be one round ahead of the slowest reader). All
-// FPS_G workgroups must be resident together: 64 x 1024 threads is a quarter of the chip. A bounded spin turns a
-// lost peer into an error code instead of a hang.
+// n > 16384, the object-merge case (denoise_object.py:112: 3N patch points -> N, N = 10^4 .. 10^5) and the
+// 50000-point room patches of BASELINE configs 4-5: one workgroup would stream the whole cloud from L2 every round
+// (28 us per round at 150 k points). Here FPS_G workgroups share one cloud: every thread keeps its PPT points and
+// their running distances in registers, a round is a local (wave + LDS) argmax, ONE 8-byte word per workgroup
+// published to global memory, and an all-gather by polling: lane i of wave 0 spins on word i, reduces, and
+// broadcasts the winner through LDS. The word carries the round number (mod 8) in the three spare bits of the
+// tie-key (n <= 2^19 leaves them free; they are equal in all words of a round, so the maximum is unaffected): a
+// reader recognises a fresh word from the word itself, a 64-bit store is single-copy atomic, and no ordering
+// between different locations is needed -- hence no release / acquire fences (which would write back / invalidate
+// the XCD's whole L2 every round). Words are double-buffered by round parity (a workgroup can only be one round
+// ahead of the slowest reader; a slot is rewritten every second round, so a stale word's tag differs by 2 mod 8).
+// All FPS_G workgroups must be resident together: 64 x 1024 threads is a quarter of the chip; the host checks the
+// occupancy, and a bounded spin turns a lost peer into an error flag (never a hang) that triggers the
+// single-workgroup kernel as an on-device fallback (fps_big_kernel(only_if = flag)) -- the indices are always valid.
 #define FPS_G 64
+__device__ __forceinline__ u64 fps_tagged(u64 key, int j) {  // key's low word is ~sec, sec < 2^29
+  return key ^ ((u64)(unsigned)(j & 7) << 29);
+}
+__device__ __forceinline__ bool fps_tag_is(u64 word, int j) {
+  return ((~(unsigned)word) >> 29) == (unsigned)(j & 7);
+}
+__device__ __forceinline__ u64 fps_untag(u64 word) { return word | ((u64)7u << 29); }
+
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, const float *__restrict__ coords,
-                                                        u64 *__restrict__ keys, unsigned *__restrict__ tags,
-                                                        int *__restrict__ indices, int *__restrict__ err) {
+                                                        u64 *__restrict__ keys, int *__restrict__ indices,
+                                                        int *__restrict__ err) {
   __shared__ u64 slots[2][16];
   __shared__ int winner[2];
   const int t = threadIdx.x, g = blockIdx.x, bi = blockIdx.y;
   const float *c = coords + (size_t)bi * 3 * n;
   int *out = indices + (size_t)bi * m;
   u64 *kslot = keys + (size_t)bi * 2 * FPS_G;
-  unsigned *tslot = tags + (size_t)bi * 2 * FPS_G;
+  int *flag = err + bi;
 
   float x[PPT], y[PPT], z[PPT], dist[PPT];
 #pragma unroll
@@ -233,29 +250,26 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, const floa
     u64 key = wave_max_u64(fps_key(best, bk));
     if ((t & 63) == 0) slots[j & 1][t >> 6] = key;
     __syncthreads();
-    if (t < 64) {  // wave 0: the workgroup's maximum -> its global slot, then gather everybody's
+    if (t < 64) {  // wave 0: the workgroup's maximum -> its global word, then gather everybody's
       u64 v = row_max_u64(slots[j & 1][t & 15]);
       const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 15);
       const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
       const int par = (j & 1) * FPS_G;
-      // Both words are device-scope write-through stores and L2-bypassing loads; ordering comes from waiting for
-      // the key's acknowledgement before the tag goes out (and the key being read after the tag was seen) -- a
-      // release / acquire pair here would write back / invalidate the XCD's whole L2 every round
-      if (t == 0) {
-        __hip_atomic_store(&kslot[par + g], ((u64)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (s_waitcnt: the key store has been acknowledged)
-        __hip_atomic_store(&tslot[par + g], (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      // device-scope write-through store / L2-bypassing loads of ONE self-describing word (see above)
+      if (t == 0)
+        __hip_atomic_store(&kslot[par + g], fps_tagged(((u64)hi << 32) | lo, j), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
-      while (__hip_atomic_load(&tslot[par + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)j) {
-        if (++spins > (1 << 22)) {  // a peer never arrived (not co-resident?): give up loudly
-          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      u64 w;
+      while (!fps_tag_is(w = __hip_atomic_load(&kslot[par + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), j)) {
+        if (++spins > (1 << 22)) {  // a peer never arrived (not co-resident?): raise the flag, the fallback kernel runs
+          __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           spins = -1;
           break;
         }
         __builtin_amdgcn_s_sleep(1);
       }
-      const u64 all = wave_max_u64(__hip_atomic_load(&kslot[par + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      const u64 all = wave_max_u64(fps_untag(w));
       const bool lost = __ballot(spins < 0) != 0;
       if (t == 0) winner[j & 1] = lost ? -1 : fps_key_index(all);
     }
@@ -302,32 +316,60 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
   else if (n <= 16384) fps_launch<1024, 16>(b, n, m, coords, idx, s);
   else {
     if (!dist_ws) return P2PB_EINVAL;
-    hipLaunchKernelGGL(fps_big_kernel, dim3(b), dim3(1024), 0, s, n, m, coords, dist_ws, idx);
+    hipLaunchKernelGGL(fps_big_kernel, dim3(b), dim3(1024), 0, s, n, m, coords, dist_ws, idx, (const int *)nullptr);
   }
   return p2pb_launch_status();
 }
 
-extern "C" size_t p2pb_fps_coop_ws_bytes(int b) { return (size_t)b * 2 * FPS_G * (sizeof(u64) + sizeof(unsigned)) + 16; }
+// ws = [b][2][FPS_G] tagged words | [b] error flags (+ pad) | [b][n] fallback distances
+static size_t fps_coop_head_bytes(int b) { return ((size_t)b * 2 * FPS_G * sizeof(u64) + (size_t)b * sizeof(int) + 15) & ~(size_t)15; }
+extern "C" size_t p2pb_fps_coop_ws_bytes(int b, int n) {
+  return fps_coop_head_bytes(b) + (size_t)b * (size_t)n * sizeof(float);
+}
 
-// Large clouds (16384 < n <= 524288; b * 64 workgroups of 16 waves must be resident together: b <= 4): same result
-// as p2pb_furthest_point_sampling. ws: p2pb_fps_coop_ws_bytes(b) bytes, zeroed by the callee. Returns P2PB_EINVAL
-// outside that range (callers fall back to p2pb_furthest_point_sampling).
+// Large clouds (16384 < n <= 524288), any b (launched four clouds at a time: b * 64 workgroups of 16 waves must be
+// resident together): same result as p2pb_furthest_point_sampling. ws: p2pb_fps_coop_ws_bytes(b, n) bytes, head zeroed
+// by the callee; after the call the ints at ws + 2*FPS_G*8*b are per-cloud flags (1 = the cooperative kernel lost a
+// peer and the single-workgroup fallback produced that cloud's indices: slower, same result). Returns P2PB_EINVAL
+// outside the range or when the device cannot hold one launch's workgroups at once (callers use
+// p2pb_furthest_point_sampling then).
 extern "C" int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx,
                                                  void *stream) {
-  if (b <= 0 || b > 4 || n <= 16384 || n > FPS_G * 1024 * 8 || m < 0 || !ws) return P2PB_EINVAL;
+  if (b <= 0 || n <= 16384 || n > FPS_G * 1024 * 8 || m < 0 || !ws) return P2PB_EINVAL;
   if (m == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const size_t nbytes = p2pb_fps_coop_ws_bytes(b);
-  int e = p2pb_zero_async(ws, nbytes, s);
+  const int ppt = (n + FPS_G * 1024 - 1) / (FPS_G * 1024);
+  static int resident = -1;  // workgroups of the widest variant the device holds at once
+  if (resident < 0) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_coop_kernel<8>, 1024, 0) != hipSuccess)
+      return P2PB_EINVAL;
+    resident = cus * per_cu;
+  }
+  if (resident < FPS_G) return P2PB_EINVAL;
+  const int per_launch = resident / FPS_G < 4 ? resident / FPS_G : 4;
+  const size_t head = fps_coop_head_bytes(b);
+  int e = p2pb_zero_async(ws, head, s);
   if (e != 0) return e;
   u64 *keys = (u64 *)ws;
-  unsigned *tags = (unsigned *)(keys + (size_t)b * 2 * FPS_G);
-  int *err = (int *)(tags + (size_t)b * 2 * FPS_G);
-  const int ppt = (n + FPS_G * 1024 - 1) / (FPS_G * 1024);
-  dim3 grid(FPS_G, b);
-  if (ppt <= 1) hipLaunchKernelGGL(fps_coop_kernel<1>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
-  else if (ppt <= 2) hipLaunchKernelGGL(fps_coop_kernel<2>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
-  else if (ppt <= 4) hipLaunchKernelGGL(fps_coop_kernel<4>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
-  else hipLaunchKernelGGL(fps_coop_kernel<8>, grid, dim3(1024), 0, s, n, m, coords, keys, tags, idx, err);
+  int *err = (int *)(keys + (size_t)b * 2 * FPS_G);
+  float *dist = (float *)((char *)ws + head);
+  for (int b0 = 0; b0 < b; b0 += per_launch) {
+    const int nb = b - b0 < per_launch ? b - b0 : per_launch;
+    dim3 grid(FPS_G, nb);
+    const float *c0 = coords + (size_t)b0 * 3 * n;
+    u64 *k0 = keys + (size_t)b0 * 2 * FPS_G;
+    int *i0 = idx + (size_t)b0 * m, *e0 = err + b0;
+    if (ppt <= 1) hipLaunchKernelGGL(fps_coop_kernel<1>, grid, dim3(1024), 0, s, n, m, c0, k0, i0, e0);
+    else if (ppt <= 2) hipLaunchKernelGGL(fps_coop_kernel<2>, grid, dim3(1024), 0, s, n, m, c0, k0, i0, e0);
+    else if (ppt <= 4) hipLaunchKernelGGL(fps_coop_kernel<4>, grid, dim3(1024), 0, s, n, m, c0, k0, i0, e0);
+    else hipLaunchKernelGGL(fps_coop_kernel<8>, grid, dim3(1024), 0, s, n, m, c0, k0, i0, e0);
+  }
+  // on-device fallback, one workgroup per cloud, returns at once unless that cloud's flag was raised
+  for (int bi = 0; bi < b; ++bi)
+    hipLaunchKernelGGL(fps_big_kernel, dim3(1), dim3(1024), 0, s, n, m, coords + (size_t)bi * 3 * n,
+                       dist + (size_t)bi * n, idx + (size_t)bi * m, (const int *)(err + bi));
   return p2pb_launch_status();
 }

@@ -55,19 +55,8 @@ def farthest_point_sampling(pcls, num_pnts):
     if num > n:
         raise ValueError(f"farthest_point_sampling: num_pnts={num} > N={n}")
     coords = pcls.transpose(1, 2).contiguous()
-    if 16384 < n <= 524288 and num > 1:
-        # large clouds (the merge of all patch outputs): cooperative multi-workgroup kernel, one cloud at a time
-        idx = torch.empty(b, num, dtype=I32, device=pcls.device)
-        nws = int(lib().p2pb_fps_coop_ws_bytes(ctypes.c_int(1)))
-        for i in range(b):
-            ws = torch.empty(nws, dtype=torch.uint8, device=pcls.device)
-            call("p2pb_furthest_point_sampling_coop", ctypes.c_int(1), ctypes.c_int(n), ctypes.c_int(num),
-                 ptr(coords[i]), ptr(ws), ptr(idx[i]), stream_ptr())
-            if int(ws[-16:].view(torch.int32)[0].item()) != 0:
-                raise RuntimeError("p2pb_furthest_point_sampling_coop: a workgroup never arrived (GPU oversubscribed?)")
-        idx = idx.long()
-    else:
-        idx = _ext.furthest_point_sampling_forward(coords, num).long()  # [B,num]
+    # (large clouds -- the merge of all patch outputs -- take the cooperative multi-workgroup kernel inside)
+    idx = _ext.furthest_point_sampling_forward(coords, num).long()  # [B,num]
     sampled = torch.gather(pcls, 1, idx[..., None].expand(b, num, 3))
     return sampled, [idx[i] for i in range(b)]
 

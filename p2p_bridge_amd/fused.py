@@ -279,7 +279,7 @@ def pool_supported(npos: int, pool_u: int) -> bool:
     return bool(lib().p2pb_pointwise_pool_supported(_i(npos), _i(pool_u)))
 
 
-PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/test_pw.py)
+PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/exp_pw.py)
 
 
 def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:

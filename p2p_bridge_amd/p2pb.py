@@ -245,8 +245,10 @@ class P2PB(nn.Module):
 
     # ---- sampler ----------------------------------------------------------------------------------
     def step_tables(self, sampling_steps: int):
-        """(steps ascending, device table [T,4] = noise_level, std_fwd, mu_x0, mu_xn per reverse step).
-        The posterior coefficients follow p_posterior's fp32 arithmetic exactly (models/p2pb.py:203-209)."""
+        """(steps ascending, device table [T,5] = noise_level, std_fwd, mu_x0, mu_xn, posterior std per reverse step).
+        The posterior coefficients follow p_posterior's fp32 arithmetic exactly (models/p2pb.py:203-209); the last
+        column is sqrt(var) of the Gaussian product, 0 for the final step (prev == 0 adds no noise, :207) and for
+        ot_ode samplers."""
         assert 0 < sampling_steps < self.timesteps
         steps = space_indices(self.timesteps, sampling_steps + 1)
         sf = self.std_fwd.cpu()
@@ -258,10 +260,14 @@ class P2PB(nn.Module):
             std_n, std_p = sf[step], sf[prev]
             std_d = (std_n ** 2 - std_p ** 2).sqrt()
             den = std_p ** 2 + std_d ** 2
-            rows.append(torch.stack([nl[step], sf[step], std_d ** 2 / den, std_p ** 2 / den]))
+            var = (std_p ** 2 * std_d ** 2) / den
+            noise = var.sqrt() if (not self.ot_ode and prev > 0) else torch.zeros(())
+            rows.append(torch.stack([nl[step], sf[step], std_d ** 2 / den, std_p ** 2 / den, noise]))
         return steps, torch.stack(rows).to(self.device)
 
-    def _one_step(self, net, xt, coef, x1, x_cond, clip):
+    def _one_step(self, net, xt, coef, x1, x_cond, clip, noise=None):
+        """one reverse step: pred_x0_fn + p_posterior (models/p2pb.py:304-320, :190-213). noise: the standard-normal
+        draw of the stochastic posterior (ot_ode=false), scaled by the table's posterior std (0 on the last step)"""
         B = xt.shape[0]
         t = coef[0].expand(B)
         if self.cond_x1:
@@ -273,7 +279,10 @@ class P2PB(nn.Module):
                 x0 = x0.clamp(-3.0, 3.0)
         else:
             x0 = out
-        return coef[2] * x0 + coef[3] * xt, x0
+        xt_prev = coef[2] * x0 + coef[3] * xt
+        if noise is not None:
+            xt_prev = xt_prev + coef[4] * noise
+        return xt_prev, x0
 
     @torch.no_grad()
     def ddpm_sampling(self, x1, x_cond=None, clip_denoise=False, sampling_steps=None, log_count=10, verbose=True,
@@ -283,65 +292,101 @@ class P2PB(nn.Module):
         log_count = min(len(steps) - 1, log_count)
         log_steps = [steps[i] for i in space_indices(len(steps) - 1, log_count)]
         assert log_steps[0] == 0
-        if not self.ot_ode:
-            raise NotImplementedError("stochastic posterior sampling (ot_ode=false) is not used by any shipped config")
         self.model.eval()
         net = self.ema if (use_ema and self.ema is not None) else self.model
+        # The reference evaluates ema_pytorch's deep copy in whatever mode it was copied in (train: Dropout active,
+        # models/p2pb.py:91,312-313). Deliberate deviation: the shadow samples in eval mode like the online network
+        # (deterministic, fused inference path, graph-capturable) and gets its mode back afterwards.
+        ema_was_training = net is self.ema and self.ema.ema_model.training
+        if ema_was_training:
+            self.ema.ema_model.eval()
         if self.add_x1_noise:
             x1 = x1 + torch.randn_like(x1)
         xt = x1.detach().to(self.device)
         xs, x0s = [], []
         rev = steps[::-1]
         runner = self._graph_runner(net, xt, x_cond, clip_denoise) if graph else None
-        for i, prev in enumerate(rev[1:]):
-            if runner is not None:
-                xt, x0 = runner(xt, table[i])
-            else:
-                xt, x0 = self._one_step(net, xt, table[i], x1, x_cond, clip_denoise)
-            if prev in log_steps:
-                xs.append(xt.clone() if runner is not None else xt)
-                x0s.append(x0.clone() if runner is not None else x0)
-        self.model.train()
+        try:
+            for i, prev in enumerate(rev[1:]):
+                # stochastic posterior (ot_ode=false, models/p2pb.py:207-208): one standard-normal draw per step that adds
+                # noise (prev > 0), from torch's generator in the reference's order -- outside the captured graph
+                noise = torch.randn_like(xt) if (not self.ot_ode and prev > 0) else None
+                if runner is not None:
+                    xt, x0 = runner(xt, table[i], noise)
+                else:
+                    xt, x0 = self._one_step(net, xt, table[i], x1, x_cond, clip_denoise, noise)
+                if prev in log_steps:
+                    xs.append(xt.clone() if runner is not None else xt)
+                    x0s.append(x0.clone() if runner is not None else x0)
+        finally:
+            if ema_was_training:
+                self.ema.ema_model.train()
+            self.model.train()
         flip = lambda z: torch.flip(torch.stack(z, dim=1), dims=(1,))
         return flip(xs), flip(x0s)
 
+    @staticmethod
+    def _weights_fingerprint(net):
+        """identity + in-place version of every parameter and buffer: an optimiser step, load_state_dict, an EMA update
+        or a replaced parameter all change it"""
+        return tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
+
     def _graph_runner(self, net, xt, x_cond, clip):
         """capture ONE sampler step (network evaluation + posterior update) into a hipGraph with static
-        input/coef buffers; replays are keyed by (shape, cond shape, clip, network identity)."""
+        input / coefficient / noise buffers. Replays are keyed by (shape, cond shape, clip, network identity); a captured
+        graph bakes in the addresses of the weights AND of their derived packed copies (fused.pack_*, StyleBank), so
+        each entry also stores the weight fingerprint it was captured under and is re-captured when that changes
+        (optimiser step, load_checkpoint, EMA update). The packed tensors of a live graph stay referenced by the
+        modules' caches for exactly as long as the fingerprint is unchanged."""
         if self.cond_x1:
             raise NotImplementedError("graph capture with cond_x1")
         key = (tuple(xt.shape), None if x_cond is None else tuple(x_cond.shape), bool(clip), id(net))
-        if key not in self._graphs:
+        fp = self._weights_fingerprint(net)
+        entry = self._graphs.get(key)
+        if entry is not None and entry[0] != fp:
+            del self._graphs[key]  # stale: captured over weights that have changed since
+            entry = None
+        if entry is None:
             s_x = xt.clone()
-            s_c = torch.zeros(4, device=xt.device)
+            s_c = torch.zeros(5, device=xt.device)
+            s_n = None if self.ot_ode else torch.zeros_like(xt)
             s_cond = None if x_cond is None else x_cond.clone()
-            # lazy one-time initialisation (MIOpen solver selection, BLAS handles, kernel attributes) must
-            # not happen inside the capture: one eager step on the current stream, then two on a side
-            # stream (the documented torch.cuda.graph warm-up), then capture.
-            self._one_step(net, s_x, s_c, None, s_cond, clip)
+            # lazy one-time initialisation (BLAS handles, kernel attributes, weight packs) must not happen inside the
+            # capture: one eager step on the current stream, then two on a side stream (the documented
+            # torch.cuda.graph warm-up), then capture.
+            self._one_step(net, s_x, s_c, None, s_cond, clip, s_n)
             torch.cuda.synchronize()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._one_step(net, s_x, s_c, None, s_cond, clip)
+                    self._one_step(net, s_x, s_c, None, s_cond, clip, s_n)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                o_x, o_0 = self._one_step(net, s_x, s_c, None, s_cond, clip)
-            self._graphs[key] = (g, s_x, s_c, s_cond, o_x, o_0)
-        g, s_x, s_c, s_cond, o_x, o_0 = self._graphs[key]
+                o_x, o_0 = self._one_step(net, s_x, s_c, None, s_cond, clip, s_n)
+            entry = self._graphs[key] = (fp, g, s_x, s_c, s_n, s_cond, o_x, o_0)
+        _, g, s_x, s_c, s_n, s_cond, o_x, o_0 = entry
         if s_cond is not None:
             s_cond.copy_(x_cond)
 
-        def run(x, coef):
+        def run(x, coef, noise=None):
             s_x.copy_(x)
             s_c.copy_(coef)
+            if s_n is not None:
+                if noise is None:
+                    s_n.zero_()
+                else:
+                    s_n.copy_(noise)
             g.replay()
             return o_x, o_0
 
         return run
+
+    def clear_graphs(self):
+        """drop every captured sampler graph (they are also re-captured automatically when the weights change)"""
+        self._graphs.clear()
 
     @torch.no_grad()
     def sample(self, x_cond=None, x_start=None, clip=False, use_ema=False, verbose=True, log_count=10, steps=None,

@@ -102,8 +102,45 @@ class SE3d(nn.Module):
         return x * self.fc(s).view(x.shape[0], x.shape[1], 1, 1, 1)
 
 
+class _LinearAttentionCore(torch.autograd.Function):
+    """softmax(k) over tokens, ctx = ks v^T, out = ctx^T q -- csrc/attention.hip, one workgroup per (sample, head);
+    replaces the softmax + two einsums of models/modules.py:186-188 in both directions"""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        from ._lib import call, ptr, stream_ptr
+        import ctypes
+
+        qkv = qkv.contiguous()
+        b, c3, n = qkv.shape
+        dh = c3 // (3 * heads)
+        out = torch.empty(b, heads * dh, n, dtype=qkv.dtype, device=qkv.device)
+        need = ctx.needs_input_grad[0]
+        ctxm = torch.empty(b, heads, dh, dh, dtype=qkv.dtype, device=qkv.device) if need else None
+        call("p2pb_linear_attention_forward", ctypes.c_int(b), ctypes.c_int(heads), ctypes.c_int(dh), ctypes.c_int(n),
+             ptr(qkv), ptr(out), ptr(ctxm), stream_ptr())
+        if need:
+            ctx.save_for_backward(qkv, ctxm)
+            ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._lib import call, ptr, stream_ptr
+        import ctypes
+
+        qkv, ctxm = ctx.saved_tensors
+        b, c3, n = qkv.shape
+        heads = ctx.heads
+        dq = torch.empty_like(qkv)
+        call("p2pb_linear_attention_backward", ctypes.c_int(b), ctypes.c_int(heads), ctypes.c_int(c3 // (3 * heads)),
+             ctypes.c_int(n), ptr(qkv), ptr(ctxm), ptr(g.contiguous()), ptr(dq), stream_ptr())
+        return dq, None
+
+
 class LinearAttention(nn.Module):
-    """O(N) attention at the bottleneck: softmax over keys only (models/modules.py:165-194)"""
+    """O(N) attention: softmax over keys only (models/modules.py:165-194). to_qkv / to_out are 1x1 convolutions on
+    the pointwise GEMM kernels, the core between them is csrc/attention.hip (forward and backward)."""
 
     def __init__(self, dim, heads=4, dim_head=32):
         super().__init__()
@@ -113,13 +150,16 @@ class LinearAttention(nn.Module):
         self.to_out = nn.Conv2d(hidden, dim, 1)
 
     def forward(self, x):
+        from . import fused
+
         b, c, n = x.shape
-        qkv = self.to_qkv(x.unsqueeze(-1)).view(b, 3, self.heads, -1, n)
-        q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
-        k = k.softmax(dim=-1)
-        context = torch.einsum("bhdn,bhen->bhde", k, v)
-        out = torch.einsum("bhde,bhdn->bhen", context, q).reshape(b, -1, n, 1)
-        return self.to_out(out).squeeze(-1)
+        if fused.enabled(self, x):
+            qkv, _ = fused.pw_conv(x.contiguous(), self.to_qkv, stats=False, use_bias=False)
+            out = _LinearAttentionCore.apply(qkv, self.heads)
+            return fused.pw_conv(out, self.to_out, stats=False)[0]
+        qkv = self.to_qkv(x.unsqueeze(-1)).view(b, -1, n)
+        out = _LinearAttentionCore.apply(qkv, self.heads)
+        return self.to_out(out.unsqueeze(-1)).squeeze(-1)
 
 
 class StyleBank:
@@ -275,7 +315,7 @@ class PVConv(nn.Module):
     devoxelize) + point branch (SharedMLP), summed (models/pvcnn.py:237-334)."""
 
     def __init__(self, in_channels, out_channels, resolution, with_se=True, dropout=0.1, gn_groups=8, cond_dim=0,
-                 normalize=True, eps=0.0):
+                 normalize=True, eps=0.0, attention=None):
         super().__init__()
         self.resolution = int(resolution)
         self.voxelization = Voxelization(resolution, normalize, eps)
@@ -285,7 +325,8 @@ class PVConv(nn.Module):
         if with_se:
             mods.append(SE3d(out_channels))
         self.voxel_layers = nn.ModuleList(mods)
-        self.attn = None
+        # attention: a LinearAttention factory when the config's `attentions` flags this block (models/pvcnn.py:293-296)
+        self.attn = attention(out_channels) if attention is not None else None
         self.sparse_conv = True  # inference: exact sparse convolution for r >= 16 (fused._voxel_branch_fused)
         self.level = -1  # set by PVCNN2Unet: index of the coordinate level this block works on (Geometry.take_voxel)
         self.point_features = SharedMLP(in_channels, out_channels, gn_groups=gn_groups, cond_dim=cond_dim)
@@ -357,6 +398,8 @@ class PVConv(nn.Module):
                 h, st = F_.pw_conv(feats, pf[0])
                 scp, shp = norm_affine(pf[1], st, feats.shape[2], cond)
                 data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, scp, shp), geo=data.geo)
+                if self.attn is not None:
+                    data.features = self.attn(data.features)
                 return data
             fused = self._voxel_branch_fused(features, coords, cond, geo=data.geo)
         else:
@@ -365,6 +408,8 @@ class PVConv(nn.Module):
                 v = m(v, cond) if isinstance(m, AdaGN) else m(v)
             fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
         data.features = self.point_features.run(features, cond, residual=fused)
+        if self.attn is not None:  # models/pvcnn.py:327-328
+            data.features = self.attn(data.features)
         return data
 
 
@@ -594,7 +639,7 @@ class Pnet2Stage(nn.Module):
 
 def stage_plan(npoints: int, channels: List[int], n_sa_blocks: List[int], n_fp_blocks: List[int],
                radius: List[float], voxel_resolutions: List[int], feat_dim: int, input_dim: int = 3,
-               embed_dim: int = 64, centers: Optional[List[int]] = None):
+               embed_dim: int = 64, centers: Optional[List[int]] = None, attentions: Optional[List[int]] = None):
     """The network's shape as plain data (what create_pvc_layer_params + create_sa_components +
     create_fp_components compute, models/pvcnn.py:34-96,528-741), including the reference's quirks:
     only SA stage 0 honours n_sa_blocks>1 (:615-618), the last SA stage has no PVConv (:64-75), FP
@@ -609,8 +654,12 @@ def stage_plan(npoints: int, channels: List[int], n_sa_blocks: List[int], n_fp_b
         last = i == nlev - 1
         if not last:
             for p in range(n_sa_blocks[i] if i == 0 else min(1, n_sa_blocks[i])):
+                # `attentions[i]` puts a LinearAttention behind the FIRST PVConv of set-abstraction stage i
+                # (models/pvcnn.py:583-587,604); the feature-propagation side never gets one: its test
+                # `c < len(fp_blocks) - 1` reads the shadowed local list (:692,709) and is false whenever p == 0
                 convs.append(dict(cin=cin + (embed_dim if (i > 0 and p == 0) else 0), cout=channels[i],
-                                  r=int(voxel_resolutions[i])))
+                                  r=int(voxel_resolutions[i]),
+                                  attn=bool(attentions[i]) and p == 0 if attentions is not None else False))
                 cin = channels[i]
         mlp_in = cin + (embed_dim if (i > 0 and not convs) else 0)
         mlp_out = [channels[i], channels[i], channels[i + 1]] if last else [channels[i], channels[i + 1]]
@@ -760,10 +809,16 @@ class PVCNN2Unet(nn.Module):
         plan = stage_plan(_get(_get(cfg, "data"), "npoints"), list(_get(pvd, "channels")), list(_get(pvd, "n_sa_blocks")),
                           list(_get(pvd, "n_fp_blocks")), list(_get(pvd, "radius")),
                           list(_get(pvd, "voxel_resolutions")), self.f_embed_dim, self.input_dim, E,
-                          _get(pvd, "centers", None))
+                          _get(pvd, "centers", None), _get(pvd, "attentions", None))
         self.plan = plan
         cd = self.cond_emb_dim
-        pv = lambda s: PVConv(s["cin"], s["cout"], s["r"], with_se=with_se, dropout=dropout, cond_dim=cd)
+        attn_type = str(_get(pvd, "attention_type", "linear")).lower()
+        if attn_type != "linear":
+            raise NotImplementedError(f"attention_type={attn_type!r}: only 'linear' (LinearAttention, every shipped "
+                                      "config) is built; 'flash' (models/modules.py Attention) is off the hot path")
+        attn_fn = lambda dim: LinearAttention(dim, heads=heads)
+        pv = lambda s: PVConv(s["cin"], s["cout"], s["r"], with_se=with_se, dropout=dropout, cond_dim=cd,
+                              attention=attn_fn if s.get("attn") else None)
         sa_layers = []
         for st in plan["sa"]:
             blocks = [pv(s) for s in st["convs"]]
@@ -777,10 +832,7 @@ class PVCNN2Unet(nn.Module):
             for blk in (stage if isinstance(stage, _Stage) else [stage]):
                 if isinstance(blk, PVConv):
                     blk.level = i  # works on the stage's input coordinates
-        attn_type = str(_get(pvd, "attention_type", "linear")).lower()
-        if attn_type != "linear":
-            raise NotImplementedError("only attention_type='linear' is on the hot path (SURVEY.md section 2 #4)")
-        self.global_att = LinearAttention(plan["bottleneck"], heads=heads)
+        self.global_att = attn_fn(plan["bottleneck"])
         fp_layers = []
         for st in plan["fp"]:
             blocks = [PointNetFPModule(st["mlp_in"], st["mlp_out"], cond_dim=cd)] + [pv(s) for s in st["convs"]]

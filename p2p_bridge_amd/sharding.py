@@ -3,7 +3,10 @@ batch with blockIdx and never reads across it), so the N patches o
 contiguously over the ranks -- one process per GPU -- and NO collective is needed on the data path.
 A gather of the denoised patches to rank 0 (host side of `patch_based_denoise`, denoise_object.py:101-113)
 and the max-over-ranks timing reduction are the only communication."""
-from typing import Tuple
+import os
+import socket
+import sys
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -39,3 +42,66 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device or "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.item()
+
+
+# ---------------------------------------------------------------------------- one process per GPU: launching
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_plan(gpus: int, env, device_count: int, backend: str = "nccl") -> Tuple[str, int]:
+    """What a `--gpus N` entry point has to do, from the requested N, the process environment and the number of
+    visible devices (the reference spawns one process per GPU itself, train.py:229 `mp.spawn(..., nprocs=world_size)`,
+    and joins them with `init_process_group("nccl")`, :20-46):
+
+      ("run", 1)      single process, no process group
+      ("rank", N)     already one of N ranks started by torch.distributed.run (WORLD_SIZE == N): join the group
+      ("spawn", N)    N > 1 asked for from a plain `python script.py --gpus N`: re-exec N ranks (spawn_ranks)
+
+    Anything inconsistent is an error, never a silent 1-rank run: WORLD_SIZE != --gpus, or fewer devices than ranks
+    (one rank per GPU; RCCL cannot place two ranks on one device)."""
+    if gpus < 1:
+        raise SystemExit(f"--gpus {gpus}: need at least one")
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        ws = int(ws)
+        if ws != gpus:
+            raise SystemExit(f"--gpus {gpus} but the launcher started WORLD_SIZE={ws} ranks: refusing to report a "
+                             f"{gpus}-GPU number from {ws} ranks")
+        mode = "rank" if ws > 1 else "run"
+    else:
+        mode = "spawn" if gpus > 1 else "run"
+    if backend == "nccl" and device_count < gpus:
+        raise SystemExit(f"--gpus {gpus}: only {device_count} HIP device(s) visible; one rank per GPU is required "
+                         "(no oversubscription, no CPU fallback)")
+    return mode, gpus
+
+
+def spawn_ranks(script: str, argv: List[str], gpus: int, port: Optional[int] = None) -> int:
+    """re-exec `script argv` as `gpus` ranks of one node under torch.distributed.run (the launcher the driver uses),
+    rendezvous on 127.0.0.1; returns the launcher's exit code"""
+    import subprocess
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port or free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's only working mode on this driver
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_rank(backend: str = "nccl") -> Tuple[int, int, int]:
+    """join the process group torch.distributed.run prepared -> (rank, local_rank, world). backend "nccl" is RCCL
+    on ROCm; the device is selected BEFORE the group is created so that RCCL binds this rank to its own GPU."""
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    assert dist.get_world_size() == world
+    return rank, local_rank, world

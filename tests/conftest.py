@@ -2,6 +2,10 @@ import os
 import sys
 import warnings
 
+# two OpenMP runtimes live in the test process (torch's and the C oracle's): spinning waiters of one starve the other
+# on a many-core host (the GPU box), so both wait passively -- must be set before either runtime starts
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -66,7 +66,8 @@ def test_schedule_and_step_tables_match_golden():
     for T in (5, 10, 30):
         steps, table = m.step_tables(T)
         assert steps == g[f"space_indices.{T}"].tolist()
-        assert table.shape == (T, 4)
+        assert table.shape == (T, 5)
+        assert (table[:, 4] == 0).all()  # ot_ode: no posterior noise
         # same fp32 arithmetic as the oracle sampler / p_posterior
         sch = net_ref.make_schedule(cfg["diffusion"])
         rev = steps[::-1]
@@ -75,7 +76,21 @@ def test_schedule_and_step_tables_match_golden():
             sd_ = (sn ** 2 - sp ** 2).sqrt()
             den = sp ** 2 + sd_ ** 2
             exp = torch.stack([sch["noise_levels"][step], sn, sd_ ** 2 / den, sp ** 2 / den])
-            assert torch.equal(table[i], exp)
+            assert torch.equal(table[i, :4], exp)
+    # stochastic posterior (ot_ode=false): sqrt(var) of the Gaussian product on every step but the last (p2pb.py:207)
+    import copy
+
+    cfg2 = copy.deepcopy(cfg)
+    cfg2["diffusion"]["ot_ode"] = False
+    m2 = product.build_model(cfg2, None, device="cpu")
+    steps, table = m2.step_tables(5)
+    rev = steps[::-1]
+    sch = net_ref.make_schedule(cfg["diffusion"])
+    for i, (prev, step) in enumerate(zip(rev[1:], rev[:-1])):
+        sn, sp = sch["std_fwd"][step], sch["std_fwd"][prev]
+        sd_ = (sn ** 2 - sp ** 2).sqrt()
+        var = (sp ** 2 * sd_ ** 2) / (sp ** 2 + sd_ ** 2)
+        assert torch.equal(table[i, 4], var.sqrt() if prev > 0 else torch.zeros(()))
 
 
 def test_timestep_embedding_matches_golden():
