@@ -225,9 +225,12 @@ class P2PB(nn.Module):
             return ((xt - x0) / self._bc(self.std_fwd[step], x0)).detach()
         return x0.detach()
 
-    def forward(self, x0, x1, x_cond=None):
-        """training loss (models/p2pb.py:373-413)"""
-        steps = torch.randint(0, self.timesteps, (x0.shape[0],)).to(self.device)
+    def forward(self, x0, x1, x_cond=None, steps=None):
+        """training loss (models/p2pb.py:373-413). steps (build addition, tests): the per-sample bridge steps instead
+        of the random draw"""
+        if steps is None:
+            steps = torch.randint(0, self.timesteps, (x0.shape[0],))
+        steps = steps.to(self.device)
         if self.add_x1_noise:
             x1 = x1 + torch.randn_like(x1)
         xt = self.q_sample(steps, x0, x1)

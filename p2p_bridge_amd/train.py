@@ -1,0 +1,299 @@
+"""Training runner for the bridge denoiser: auction alignment -> P2PB.forward -> backward -> clip -> AdamW -> EMA ->
+loss all-reduce, one process per GPU with DDP over RCCL (BASELINE config 3).
+
+Host-side mirror of the reference's train.py:48-213 (the step loop), :20-46,229 (one process per GPU,
+`init_process_group("nccl")`), models/model_loader.py:13-61 (`load_optim_sched`), :99-104 (the DDP wrap of
+`model.model`), models/train_utils.py:140-185 (`get_data_batch`) and dataloaders/punet.py:310-318
+(`get_alignment_clean`): same order of operations, same config keys, same checkpoint dictionary
+(`step / model_state / optimizer_state`, keys `model.*` / `model.module.*` + `ema.*`).
+
+What is different (MI355X-first): ranks are started by torch.distributed.run (or by `--gpus N` self-spawn,
+sharding.spawn_ranks) instead of mp.spawn inside the script; the device is bound before the process group is created
+(RCCL binds a rank to its GPU at init); the gradient all-reduce is DDP's bucketed one over xGMI (25 MB buckets:
+105.8 MB of fp32 gradients = 5 ring all-reduces that overlap with the backward kernels); auction alignment, every
+point/voxel op and every dense layer of forward and backward are HIP kernels of this package. wandb / loguru are not
+reproduced (a `log` callable receives the same numbers).
+
+    python -m p2p_bridge_amd.train --gpus 8 --steps 100            # synthetic PU-Net-shaped data, config 3 shape
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+from typing import Callable, Dict, Iterator, Optional
+
+import torch
+import torch.distributed as dist
+from torch import optim
+
+from .pvcnn_unet import _get
+
+
+# ----------------------------------------------------------------------------------------- configuration defaults
+
+PVDS_PUNET_TRAIN = dict(  # configs/PVDS_PUNet.yaml (network + diffusion + training blocks)
+    data=dict(dataset="PUNet", npoints=2048, use_rgb_features=False, unconditional=False),
+    diffusion=dict(timesteps=1000, sampling_timesteps=10, objective="pred_noise", schedule="linear",
+                   sampling_strategy="DDPM", loss_type="mse", beta_start=1e-4, beta_end=0.02, t0=1e-4, T=1.0,
+                   ot_ode=True),
+    model=dict(type="PVD", ema=True, in_dim=3, extra_feature_channels=0, out_dim=3, time_embed_dim=64, dropout=0.15,
+               PVD=dict(use_global_embedding=True, global_embedding_dim=1024, feat_embed_dim=32,
+                        attention_type="linear", attention_heads=4, attentions=[0, 0, 0, 1],
+                        channels=[32, 64, 128, 256, 512], voxel_resolutions=[32, 16, 8, 8], n_sa_blocks=[1, 2, 1, 1],
+                        n_fp_blocks=[1, 2, 1, 1], radius=[0.1, 0.2, 0.4, 0.8], out_mlp=128)),
+    training=dict(optimizer=dict(type="AdamW", lr=3e-4, beta1=0.9, beta2=0.999, weight_decay=1e-5),
+                  scheduler=dict(type="constant", lr_gamma=0.999), grad_clip=dict(enabled=True, value=1.0), bs=32,
+                  amp=True, steps=450_000, accumulation_steps=1, log_interval=10, save_interval=10000,
+                  viz_interval=10000, seed=42),
+)
+
+
+# ----------------------------------------------------------------------------------------- optimiser / scheduler
+
+
+def load_optim_sched(cfg, model, ckpt: Optional[Dict] = None, restart: bool = False):
+    """models/model_loader.py:13-61"""
+    tr = _get(cfg, "training")
+    oc = _get(tr, "optimizer")
+    kind = _get(oc, "type")
+    kw = dict(lr=_get(oc, "lr"), weight_decay=_get(oc, "weight_decay"), betas=(_get(oc, "beta1"), _get(oc, "beta2")))
+    if kind == "Adam":
+        optimizer = optim.Adam(model.parameters(), **kw)
+    elif kind == "AdamW":
+        optimizer = optim.AdamW(model.parameters(), **kw)
+    else:
+        raise NotImplementedError(kind)
+    sc = _get(tr, "scheduler")
+    skind = _get(sc, "type")
+    if skind == "ExponentialLR":
+        sched = optim.lr_scheduler.ExponentialLR(optimizer, _get(sc, "lr_gamma"))
+    elif skind == "StepLR":
+        sched = optim.lr_scheduler.StepLR(optimizer, step_size=10_000, gamma=0.9)
+    else:
+        sched = optim.lr_scheduler.ConstantLR(optimizer, factor=1.0)
+    if ckpt is not None and not restart and "optimizer_state" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer_state"])
+    return optimizer, sched
+
+
+# ----------------------------------------------------------------------------------------- data side of a step
+
+
+def make_align_fn(eps: float = 0.01, iters: int = 100) -> Callable:
+    """train.py:69-82 + dataloaders/punet.py:310-318: the clean patch is permuted so that clean[:, :, i] is the auction
+    assignment (metrics/emd_assignment, eps 0.01, 100 rounds) of noisy[:, :, i] -- csrc/emd.hip. [B,3,N] -> [B,3,N]"""
+    from .metrics import emdModule
+
+    aligner = emdModule()
+
+    @torch.no_grad()
+    def align_fn(noisy, clean):
+        _, alignment = aligner(noisy.transpose(1, 2).contiguous(), clean.transpose(1, 2).contiguous(), eps, iters)
+        idx = alignment.detach().long().unsqueeze(1).expand(-1, 3, -1)
+        return torch.gather(clean, -1, idx)
+
+    return align_fn
+
+
+def ensure_size(x):
+    """B D N (models/train_utils.py:117-137)"""
+    if x.dim() == 2:
+        x = x.unsqueeze(1)
+    assert x.dim() == 3
+    return x.transpose(1, 2) if x.size(1) > x.size(2) else x
+
+
+def get_data_batch(batch: Dict, cfg, align_fn=None) -> Dict[str, torch.Tensor]:
+    """models/train_utils.py:140-185 -> {"x_gt", "x_start", "x_cond"} in B D N"""
+    data = _get(cfg, "data")
+    if _get(data, "dataset") == "PUNet":
+        clean, noisy = batch["clean_points"].squeeze(), batch["noisy_points"].squeeze()
+        clean_feat = lr_feat = None
+    else:
+        clean = batch["clean_points"].transpose(1, 2)
+        if not _get(data, "unconditional", False):
+            lr_feat, noisy, clean_feat = batch.get("noisy_features"), batch.get("noisy_points"), batch.get("clean_features")
+        else:
+            lr_feat = noisy = clean_feat = None
+    clean = ensure_size(clean)
+    lr_feat = ensure_size(lr_feat) if lr_feat is not None else None
+    noisy = ensure_size(noisy) if noisy is not None else None
+    noisy_colors = ensure_size(batch["noisy_colors"]) if "noisy_colors" in batch else None
+    if _get(data, "dataset") == "PUNet" and align_fn is not None:
+        clean = align_fn(noisy, clean)
+    if noisy_colors is not None and noisy_colors.shape[-1] > 0 and _get(data, "use_rgb_features", False):
+        lr_feat = torch.cat([noisy_colors, lr_feat], dim=1) if lr_feat is not None else noisy_colors
+    return {"x_gt": clean, "x_start": noisy, "x_cond": lr_feat}
+
+
+def synthetic_punet_batches(bs: int, npoints: int, seed: int, device) -> Iterator[Dict]:
+    """endless PU-Net-shaped batches: {clean_points, noisy_points} f32[bs, npoints, 3], the clean patch in
+    a random point ORDER like the dataset's independent clean / noisy K-NN patches (that is what the alignment undoes)"""
+    from .synthetic import synthetic_patches
+
+    k = 0
+    while True:
+        noisy, clean = synthetic_patches(bs, npoints, seed=seed + k)
+        g = torch.Generator().manual_seed(seed + k)
+        perm = torch.stack([torch.randperm(npoints, generator=g) for _ in range(bs)])
+        clean = torch.gather(clean, 2, perm.unsqueeze(1).expand(-1, 3, -1))
+        yield {"clean_points": clean.transpose(1, 2).contiguous().to(device),
+               "noisy_points": noisy.transpose(1, 2).contiguous().to(device)}
+        k += 1
+
+
+# ----------------------------------------------------------------------------------------- the step
+
+
+def ddp_wrap(model, device_index: Optional[int]):
+    """models/model_loader.py:99-104: wrap the NETWORK (model.model) in DistributedDataParallel. device_index None =
+    CPU tensors (gloo tests)."""
+    from torch.nn.parallel import DistributedDataParallel
+
+    def f(m):
+        if device_index is None:
+            return DistributedDataParallel(m)
+        return DistributedDataParallel(m, device_ids=[device_index], output_device=device_index)
+
+    model.multi_gpu_wrapper(f)
+    return model
+
+
+def get_grad_norm(net):
+    """models/train_utils.py getGradNorm: (parameter norm, gradient norm)"""
+    with torch.no_grad():
+        p2 = sum((p.detach() ** 2).sum() for p in net.parameters())
+        g2 = sum((p.grad.detach() ** 2).sum() for p in net.parameters() if p.grad is not None)
+    return float(p2) ** 0.5, float(g2) ** 0.5
+
+
+def train_step(model, optimizer, lr_scheduler, batches: Iterator[Dict], cfg, align_fn=None, scaler=None,
+               distributed: bool = False) -> torch.Tensor:
+    """ONE optimiser step, in the reference's order (train.py:107-143): zero_grad; per accumulation slice
+    get_data_batch(align) -> loss = model(x_gt, x1=x_start, x_cond) / accumulation_steps -> scaled backward (DDP
+    all-reduces the gradients over RCCL during it); unscale; clip_grad_norm_; optimizer step; scaler update; scheduler
+    step; EMA update; all-reduce (SUM) of the detached loss. Returns the summed loss tensor (caller divides by the world
+    size when logging, :146)."""
+    tr = _get(cfg, "training")
+    accum = int(_get(tr, "accumulation_steps", 1))
+    optimizer.zero_grad()
+    loss_accum = torch.zeros((), dtype=torch.float32, device=model.device)
+    for _ in range(accum):
+        data = get_data_batch(next(batches), cfg, align_fn)
+        loss = model(data["x_gt"], data["x_start"], data["x_cond"]) / accum
+        loss_accum += loss.detach()
+        (scaler.scale(loss) if scaler is not None else loss).backward()
+    if scaler is not None:
+        scaler.unscale_(optimizer)
+    clip = _get(tr, "grad_clip")
+    if _get(clip, "enabled", False):
+        torch.nn.utils.clip_grad_norm_(model.parameters(), _get(clip, "value"))
+    if scaler is not None:
+        scaler.step(optimizer)
+        scaler.update()
+    else:
+        optimizer.step()
+    lr_scheduler.step()
+    if model.ema is not None:
+        model.ema.update()
+    if distributed:
+        dist.all_reduce(loss_accum)
+    return loss_accum
+
+
+def save_checkpoint(path, step, model, optimizer):
+    """train.py:168-175"""
+    torch.save({"step": step, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict()}, path)
+
+
+def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, distributed: bool = False,
+          rank: int = 0, world: int = 1, output_dir: Optional[str] = None, log: Optional[Callable] = None,
+          align: bool = True, evaluate: Optional[Callable] = None):
+    """the reference's loop (train.py:107-211) over `steps` optimiser steps. Returns the list of logged mean losses."""
+    tr = _get(cfg, "training")
+    optimizer, sched = load_optim_sched(cfg, model)
+    align_fn = make_align_fn() if (align and _get(_get(cfg, "data"), "dataset") == "PUNet") else None
+    on_gpu = model.device.type == "cuda"
+    scaler = torch.amp.GradScaler("cuda", enabled=bool(_get(tr, "amp", False))) if on_gpu else None
+    model.train()
+    history = []
+    for step in range(start_step, start_step + steps):
+        loss_accum = train_step(model, optimizer, sched, batches, cfg, align_fn, scaler, distributed)
+        if step % int(_get(tr, "log_interval", 10)) == 0:
+            mean_loss = loss_accum.item() / world
+            history.append(mean_loss)
+            if rank == 0 and log is not None:
+                net = model.model.module if hasattr(model.model, "module") else model.model
+                pn, gn = get_grad_norm(net)
+                log({"step": step, "loss": mean_loss, "netpNorm": pn, "netgradNorm": gn})
+        if output_dir is not None and (step + 1) % int(_get(tr, "save_interval", 10000)) == 0:
+            path = os.path.join(output_dir, f"step_{step + 1}.pth")
+            if rank == 0:
+                save_checkpoint(path, step + 1, model, optimizer)
+            if distributed:  # every rank reloads rank 0's weights (train.py:177-185)
+                dist.barrier()
+                model.load_state_dict(torch.load(path, map_location=model.device)["model_state"])
+        if evaluate is not None and (step + 1) % int(_get(tr, "viz_interval", 10000)) == 0:
+            if distributed:
+                dist.barrier()
+            model.eval()
+            if rank == 0:
+                evaluate(model, step + 1)
+            model.train()
+    return history
+
+
+# ----------------------------------------------------------------------------------------- entry point
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--bs", type=int, default=64, help="GLOBAL batch (divided over the GPUs like train.py:226)")
+    ap.add_argument("--npoints", type=int, default=2048)
+    ap.add_argument("--no-align", action="store_true")
+    ap.add_argument("--output-dir", default=None)
+    args = ap.parse_args(argv)
+    from . import p2pb as product
+    from . import sharding
+    from .pvcnn_unet import PVCNN2Unet
+
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    mode, world = sharding.launch_plan(args.gpus, os.environ, ndev)
+    if mode == "spawn":
+        raise SystemExit(sharding.spawn_ranks("-m", ["p2p_bridge_amd.train"] + list(argv or sys.argv[1:]), world))
+    if ndev == 0:
+        raise SystemExit("p2p_bridge_amd.train needs a HIP device (the product has no CPU path)")
+    rank = local_rank = 0
+    if mode == "rank":
+        rank, local_rank, world = sharding.init_rank("nccl")
+    torch.cuda.set_device(local_rank)
+    cfg = copy.deepcopy(PVDS_PUNET_TRAIN)
+    cfg["data"]["npoints"] = args.npoints
+    cfg["training"]["bs"] = args.bs // world
+    cfg["training"]["log_interval"] = 1
+    cfg["gpu"] = f"cuda:{local_rank}"
+    torch.manual_seed(int(cfg["training"]["seed"]))  # identical initial weights on every rank (DDP broadcasts rank 0's anyway)
+    model = product.P2PB(cfg, PVCNN2Unet(cfg))
+    if mode == "rank":
+        ddp_wrap(model, local_rank)
+    batches = synthetic_punet_batches(cfg["training"]["bs"], args.npoints, seed=1000 * rank, device=model.device)
+    t0 = time.perf_counter()
+    hist = train(cfg, model, batches, args.steps, distributed=mode == "rank", rank=rank, world=world,
+                 output_dir=args.output_dir, align=not args.no_align,
+                 log=lambda d: print(json.dumps(d), flush=True))
+    torch.cuda.synchronize()
+    if rank == 0:
+        dt = time.perf_counter() - t0
+        print(json.dumps({"steps": args.steps, "world": world, "global_batch": cfg["training"]["bs"] * world,
+                          "s_per_step": dt / args.steps, "final_loss": hist[-1] if hist else None}), flush=True)
+    if mode == "rank":
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

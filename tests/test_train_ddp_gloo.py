@@ -1,0 +1,148 @@
+"""The training runner (p2p_bridge_amd/train.py, mirror of the reference's train.py:48-213 + model_loader.py:13-61,
+99-104) on CPU: world_size-2 `gloo` DDP over the runner's own wrap / step functions with a stand-in network (the
+product network has no CPU path; tests/test_train_gpu.py runs the same checks on the real network on the GPU)."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class StandInNet(nn.Module):
+    """same call signature as PVCNN2Unet.forward(x[B,3,N], t[B], x_cond) -> [B,3,N]"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Conv1d(3, 16, 1)
+        self.t = nn.Linear(1, 16)
+        self.b = nn.Conv1d(16, 3, 1)
+
+    def forward(self, x, t, x_cond=None):
+        h = self.a(x) + self.t(t[:, None] / 1000.0)[:, :, None]
+        return self.b(torch.tanh(h))
+
+
+def make(cfg_over=None):
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd import train as T
+
+    cfg = copy.deepcopy(T.PVDS_PUNET_TRAIN)
+    cfg["gpu"] = "cpu"
+    cfg["training"]["amp"] = False
+    cfg["training"]["log_interval"] = 1
+    for k, v in (cfg_over or {}).items():
+        cfg["training"][k] = v
+    torch.manual_seed(0)
+    return cfg, product.P2PB(cfg, StandInNet())
+
+
+def batch(bs, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    clean = torch.randn(bs, n, 3, generator=g)
+    return {"clean_points": clean, "noisy_points": clean + 0.05 * torch.randn(bs, n, 3, generator=g)}
+
+
+def _ddp_worker(rank, world, port, out):
+    from p2p_bridge_amd import train as T
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, model = make()
+    T.ddp_wrap(model, None)
+    assert isinstance(model.model, nn.parallel.DistributedDataParallel)  # model_loader.py:99-104 wraps the NETWORK
+    full = batch(8, 64, seed=3)
+    steps = torch.arange(8) * 100 + 7
+    lo, hi = rank * 4, rank * 4 + 4
+    data = T.get_data_batch({k: v[lo:hi] for k, v in full.items()}, cfg)
+    loss = model(data["x_gt"], data["x_start"], data["x_cond"], steps=steps[lo:hi])
+    loss.backward()  # DDP averages the gradients over the ranks during this call
+    grads = {k: p.grad.clone() for k, p in model.model.module.named_parameters()}
+    # one full runner step on fresh per-rank data: loss all-reduce is a SUM over ranks (train.py:143)
+    optimizer, sched = T.load_optim_sched(cfg, model)
+    it = iter([{k: v[lo:hi] for k, v in batch(8, 64, seed=9).items()}])
+    before = [p.detach().clone() for p in model.model.parameters()]
+    summed = T.train_step(model, optimizer, sched, it, cfg, None, None, distributed=True)
+    after = [p.detach().clone() for p in model.model.parameters()]
+    # every rank holds identical weights after the step
+    flat = torch.cat([a.flatten() for a in after])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert all(torch.equal(o, flat) for o in other)
+    assert any(not torch.equal(a, b) for a, b in zip(after, before))
+    if rank == 0:
+        torch.save({"grads": grads, "summed_loss": summed}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_world2_grads_equal_single_rank(tmp_path):
+    """2-rank DDP-averaged gradients == 1-rank gradients on the concatenated batch (the loss is a mean over the
+    batch and both ranks hold equal shares)"""
+    from p2p_bridge_amd import train as T
+    from p2p_bridge_amd.sharding import free_port
+
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_ddp_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    cfg, model = make()
+    full = batch(8, 64, seed=3)
+    data = T.get_data_batch(full, cfg)
+    loss = model(data["x_gt"], data["x_start"], data["x_cond"], steps=torch.arange(8) * 100 + 7)
+    loss.backward()
+    for k, p in model.model.named_parameters():
+        assert torch.allclose(got["grads"][k], p.grad, rtol=1e-5, atol=1e-7), k
+    assert got["summed_loss"].item() > 0
+
+
+def test_train_step_order_and_checkpoint(tmp_path):
+    """clip -> AdamW -> scheduler -> EMA update per step; reference-format checkpoint round trip"""
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd import train as T
+
+    cfg, model = make({"save_interval": 2, "grad_clip": {"enabled": True, "value": 1e-3}})
+    assert model.ema is not None
+    it = (batch(4, 64, seed=s) for s in range(100))
+    hist = T.train(cfg, model, it, steps=4, output_dir=str(tmp_path), log=None, align=False)
+    assert len(hist) == 4 and all(h == h and h > 0 for h in hist)
+    assert int(model.ema.step.item()) == 4  # one EMA update per optimiser step (train.py:139-140)
+    ck = torch.load(os.path.join(tmp_path, "step_4.pth"))
+    assert sorted(ck) == ["model_state", "optimizer_state", "step"] and ck["step"] == 4
+    assert any(k.startswith("model.") for k in ck["model_state"]) and any(k.startswith("ema.ema_model.") for k in ck["model_state"])
+    cfg2, fresh = make()
+    assert product.load_checkpoint(fresh, ck) == 5
+    for a, b in zip(fresh.model.parameters(), model.model.parameters()):
+        assert torch.equal(a, b)
+    # gradient clipping really bounded the update: with clip 1e-3 and lr 3e-4 AdamW's first steps are tiny but non-zero
+    opt, _ = T.load_optim_sched(cfg, model, ck)
+    assert isinstance(opt, torch.optim.AdamW) and opt.param_groups[0]["lr"] == 3e-4
+    assert opt.state_dict()["state"], "optimizer state restored from the checkpoint"
+
+
+def test_get_data_batch_and_align_hook():
+    from p2p_bridge_amd import train as T
+
+    cfg, _ = make()
+    b = batch(2, 64, seed=1)
+    seen = {}
+
+    def align(noisy, clean):
+        seen["shapes"] = (tuple(noisy.shape), tuple(clean.shape))
+        return clean.flip(-1)
+
+    d = T.get_data_batch(b, cfg, align)
+    assert seen["shapes"] == ((2, 3, 64), (2, 3, 64))  # B D N on both (ensure_size)
+    assert d["x_cond"] is None and torch.equal(d["x_start"], b["noisy_points"].transpose(1, 2))
+    assert torch.equal(d["x_gt"], b["clean_points"].transpose(1, 2).flip(-1))
+    cfg["data"].update(dataset="ARKit", use_rgb_features=True)
+    b2 = {"clean_points": torch.rand(2, 64, 3), "noisy_points": torch.rand(2, 3, 64),
+          "noisy_features": torch.rand(2, 5, 64), "noisy_colors": torch.rand(2, 64, 3)}
+    d2 = T.get_data_batch(b2, cfg)
+    assert d2["x_cond"].shape == (2, 8, 64) and d2["x_gt"].shape == (2, 3, 64)
