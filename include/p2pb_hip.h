@@ -340,6 +340,23 @@ int p2pb_linear_attention_forward(int b, int heads, int dim_head, int n, const f
 int p2pb_linear_attention_backward(int b, int heads, int dim_head, int n, const float *qkv, const float *ctx,
                                    const float *grad_out, float *grad_qkv, void *stream);
 
+/* ---- training: weight gradients of the dense layers (csrc/wgrad.hip) --------------------------------------
+ * What cuDNN / cuBLAS compute in the reference's backward pass for nn.Conv3d(k 3, pad 1) (models/pvcnn.py:265-282)
+ * and the k = 1 Conv1d / Conv2d layers (models/pvcnn.py:162-205, 803-823): exact-fp32 MFMA GEMMs over the voxel /
+ * position index, split over K with a deterministic reduction (ws = scratch for the partials).
+ *   x f32[b,cin,r,r,r], dy f32[b,cout,r,r,r]  ->  dw f32[cout,cin,3,3,3], db f32[cout] (db may be NULL); r in {4,8,16,32}
+ *   x f32[b,cin,npos],  dy f32[b,cout,npos]   ->  dw f32[cout,cin],       db f32[cout] (db may be NULL)
+ * (data gradients: p2pb_conv3d_k3_forward_ex on dy with the point-reflected, channel-swapped weight;
+ *  p2pb_pointwise_conv_forward with the transposed weight)
+ * math: 0 = bf16x3 split operands (default: torch's "high" float32 matmul precision, which the reference selects in
+ * train.py:221; 16 significand bits, the class of its TF32 kernels), 1 = bf16x6 (fp32-faithful), 2 = exact-fp32 MFMA. */
+size_t p2pb_conv3d_k3_wgrad_ws_floats(int b, int cin, int cout, int r, int math);
+int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float *x, const float *dy, float *dw, float *db,
+                         float *ws, int math, void *stream);
+size_t p2pb_pointwise_wgrad_ws_floats(int b, int cin, int cout, int npos, int math);
+int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const float *x, const float *dy, float *dw, float *db,
+                         float *ws, int math, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

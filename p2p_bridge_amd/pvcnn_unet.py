@@ -157,9 +157,11 @@ class LinearAttention(nn.Module):
             qkv, _ = fused.pw_conv(x.contiguous(), self.to_qkv, stats=False, use_bias=False)
             out = _LinearAttentionCore.apply(qkv, self.heads)
             return fused.pw_conv(out, self.to_out, stats=False)[0]
-        qkv = self.to_qkv(x.unsqueeze(-1)).view(b, -1, n)
+        from . import dense
+
+        qkv = dense.pointwise(x.unsqueeze(-1), self.to_qkv).view(b, -1, n)
         out = _LinearAttentionCore.apply(qkv, self.heads)
-        return self.to_out(out.unsqueeze(-1)).squeeze(-1)
+        return dense.pointwise(out.unsqueeze(-1), self.to_out).squeeze(-1)
 
 
 class StyleBank:
@@ -247,8 +249,13 @@ class SharedMLP(nn.Module):
 
         if fused.enabled(self, x):
             return self._run_fused(x, cond, reduce_max, residual)
+        from . import dense
+
         for m in self.layers:
-            x = m(x, cond) if (isinstance(m, AdaGN) and cond is not None) else m(x)
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+                x = dense.pointwise(x, m)  # training: HIP forward + backward (dense.py)
+            else:
+                x = m(x, cond) if (isinstance(m, AdaGN) and cond is not None) else m(x)
         if reduce_max:
             x = x.max(dim=-1).values
         return x if residual is None else residual + x
@@ -403,9 +410,14 @@ class PVConv(nn.Module):
                 return data
             fused = self._voxel_branch_fused(features, coords, cond, geo=data.geo)
         else:
+            from . import dense
+
             v, vcoords = self.voxelization(features, coords)
             for m in self.voxel_layers:
-                v = m(v, cond) if isinstance(m, AdaGN) else m(v)
+                if isinstance(m, nn.Conv3d):
+                    v = dense.conv3d_k3(v, m)  # training: HIP forward + backward (dense.py)
+                else:
+                    v = m(v, cond) if isinstance(m, AdaGN) else m(v)
             fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
         data.features = self.point_features.run(features, cond, residual=fused)
         if self.attn is not None:  # models/pvcnn.py:327-328
@@ -556,7 +568,9 @@ class _PnetMLP(nn.Module):
         self.mlp = nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=True), MyGroupNorm(32, cout), Swish())
 
     def forward(self, x):
-        return self.mlp(x)
+        from . import dense
+
+        return self.mlp[2](self.mlp[1](dense.pointwise(x, self.mlp[0])))
 
 
 class ConditionedSharedMLPLayer(nn.Module):
@@ -893,7 +907,10 @@ class PVCNN2Unet(nn.Module):
                 sc, sh = norm_affine(self.embed_feats[1], st, N, None)
                 feats, _ = fused.pw_conv(h, self.embed_feats[3], sc, sh, swish=True, stats=False)
             else:
-                feats = self.embed_feats(src)
+                from . import dense
+
+                e = self.embed_feats
+                feats = dense.pointwise(e[2](e[1](dense.pointwise(src, e[0]))), e[3])
         cond = self.global_pnet(coords) if self.global_pnet is not None else None
         if use_fused and cond is not None:
             if self._style_bank is None:
@@ -930,5 +947,7 @@ class PVCNN2Unet(nn.Module):
             h, st = fused.pw_conv(data.features.contiguous(), c0.layers[0])
             sc, sh = norm_affine(c0.layers[1], st, h.shape[2], None)
             return fused.pw_conv(h, self.classifier[2], sc, sh, swish=True, stats=False)[0]
+        from . import dense
+
         h = self.classifier[0].run(data.features, None)
-        return self.classifier[2](self.classifier[1](h))
+        return dense.pointwise(self.classifier[1](h), self.classifier[2])

@@ -9,6 +9,8 @@ from p2p_bridge_amd.synthetic import synthetic_patches
 cfg = copy.deepcopy(bench.PVDS)
 cfg["data"]["npoints"] = 2048
 torch.backends.cudnn.benchmark = os.environ.get("BENCHMARK", "0") == "1"
+from p2p_bridge_amd import dense
+dense.USE_HIP = os.environ.get("DENSE", "hip") == "hip"  # DENSE=torch: the dense layers on torch / MIOpen (round-1 path)
 torch.manual_seed(0)
 model = p2pb.build_model(cfg, device="cuda")
 model.train()
@@ -27,4 +29,4 @@ for _ in range(5): l = step()
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): l = step()
 torch.cuda.synchronize(); dt = (time.time() - t0) / 10
-print(f"train step (B=8, N=2048): {dt * 1e3:.1f} ms -> {8 / dt:.1f} patches/s, {8 * 2048 / dt / 1e3:.1f} k points/s; loss {float(l):.4f}")
+print(f"[dense={'hip' if dense.USE_HIP else 'torch'} benchmark={torch.backends.cudnn.benchmark}] train step (B=8, N=2048): {dt * 1e3:.1f} ms -> {8 / dt:.1f} patches/s, {8 * 2048 / dt / 1e3:.1f} k points/s; loss {float(l):.4f}")
