@@ -247,6 +247,19 @@ int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, c
 int p2pb_gn_affine_params(int b, int c, int groups, int nslots, double count_per_channel, const float *part,
                           const float *gamma, const float *beta, const float *style, int style_stride, float eps,
                           float *scale, float *shift, float *chmean, void *stream);
+/* the same, additionally returning the group moments mean_rstd f32[b,groups,2] = {mean, 1/sqrt(var+eps)} (may be NULL)
+ * for the training backward pass (p2pb_norm_act_backward) */
+int p2pb_gn_affine_params_ex(int b, int c, int groups, int nslots, double count_per_channel, const float *part,
+                             const float *gamma, const float *beta, const float *style, int style_stride, float eps,
+                             float *scale, float *shift, float *chmean, float *mean_rstd, void *stream);
+/* Training backward of y = act(GroupNorm(x) * gamma + beta [* factor + bias]) (torch.nn.GroupNorm + AdaGN,
+ * models/modules.py:341-358, + Swish :14-19) given the folded affine (scale, shift) and mean_rstd of the forward pass:
+ * x, gy f32[b,c,npos] -> dx f32[b,c,npos], dgamma / dbeta f32[c] (NULL to skip), dstyle f32[b,2c] = (d factor | d bias)
+ * (required iff style != NULL). ws: 2*b*c + 2*b*groups floats. Deterministic. */
+int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, const float *gy, const float *scale,
+                           const float *shift, const float *mean_rstd, const float *gamma, const float *beta,
+                           const float *style, int style_stride, int swish, float *dx, float *dgamma, float *dbeta,
+                           float *dstyle, float *ws, void *stream);
 /* SE3d gate (models/modules.py:362-378) folded into the devoxelisation affine: gate = sigmoid(w2 relu(w1 chmean)),
  * aff_a = scale*gate, aff_b = shift*gate. w1 f32[hidden,c], w2 f32[c,hidden] (nn.Linear layouts, no bias). */
 int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,

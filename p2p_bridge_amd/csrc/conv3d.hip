@@ -1615,7 +1615,8 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int n
                                                         const float *__restrict__ part, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, const float *__restrict__ style,
                                                         int style_stride, float eps, float *__restrict__ scale,
-                                                        float *__restrict__ shift, float *__restrict__ chmean) {
+                                                        float *__restrict__ shift, float *__restrict__ chmean,
+                                                        float *__restrict__ mean_rstd) {
   __shared__ double rs[256], rq[256];
   __shared__ double chs[256], chq[256];  // per-channel totals of this group (cg <= 256)
   const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
@@ -1662,19 +1663,31 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int n
   scale[(size_t)b * c + ch] = (float)sc;
   shift[(size_t)b * c + ch] = (float)sh;
   if (chmean) chmean[(size_t)b * c + ch] = (float)(sc * (chs[t] / count_per_channel) + sh);
+  if (mean_rstd && t == 0) {  // training: the backward pass of the norm needs the group moments (normact.hip)
+    mean_rstd[((size_t)b * groups + g) * 2] = (float)mean;
+    mean_rstd[((size_t)b * groups + g) * 2 + 1] = (float)rstd;
+  }
 }
 
 // part: f32[b, nslots, c, 2]; gamma/beta f32[c] or NULL; style = rows of (factor[c] | bias[c]) with a row pitch of
 // style_stride floats (a column slice of the one style GEMM of the evaluation), or NULL -> scale/shift/chmean f32[b,c]
+extern "C" int p2pb_gn_affine_params_ex(int b, int c, int groups, int nslots, double count_per_channel,
+                                        const float *part, const float *gamma, const float *beta, const float *style,
+                                        int style_stride, float eps, float *scale, float *shift, float *chmean,
+                                        float *mean_rstd, void *stream) {
+  if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || nslots <= 0 || c / groups > 256) return P2PB_EINVAL;
+  if (style && style_stride < 2 * c) return P2PB_EINVAL;
+  hipLaunchKernelGGL(gn_affine_kernel, dim3(groups, b), dim3(256), 0, (hipStream_t)stream, c, groups, nslots,
+                     count_per_channel, part, gamma, beta, style, style_stride, eps, scale, shift, chmean, mean_rstd);
+  return p2pb_launch_status();
+}
+
 extern "C" int p2pb_gn_affine_params(int b, int c, int groups, int nslots, double count_per_channel,
                                      const float *part, const float *gamma, const float *beta, const float *style,
                                      int style_stride, float eps, float *scale, float *shift, float *chmean,
                                      void *stream) {
-  if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || nslots <= 0 || c / groups > 256) return P2PB_EINVAL;
-  if (style && style_stride < 2 * c) return P2PB_EINVAL;
-  hipLaunchKernelGGL(gn_affine_kernel, dim3(groups, b), dim3(256), 0, (hipStream_t)stream, c, groups, nslots,
-                     count_per_channel, part, gamma, beta, style, style_stride, eps, scale, shift, chmean);
-  return p2pb_launch_status();
+  return p2pb_gn_affine_params_ex(b, c, groups, nslots, count_per_channel, part, gamma, beta, style, style_stride, eps,
+                                  scale, shift, chmean, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

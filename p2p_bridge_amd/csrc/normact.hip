@@ -1,0 +1,173 @@
+// normact.hip -- GroupNorm (+ AdaGN style) (+ Swish) for TRAINING: the backward pass of
+//     y = act( GN_groups(x) * gamma_c + beta_c ) * factor_bc + bias_bc )           act = Swish or identity
+// (models/modules.py:341-358 AdaGN.forward, torch.nn.GroupNorm, Swish :14-19; SharedMLP's conv -> norm -> Swish triple,
+// models/pvcnn.py:162-205) in three launches instead of the ~20 elementwise / reduction kernels the eager autograd graph
+// runs per layer. The forward pass is the inference machinery: the producing convolution emits {sum, sum of squares}
+// partials, gn_affine_kernel folds the norm to a per-(sample, channel) affine  u = A x + B  (p2pb_gn_affine_params_ex
+// additionally returns the group mean / rstd this file needs), p2pb_affine_act applies it.
+//
+// Backward, with n = (x - mu_g) rstd_g the normalised value and gu = gy * act'(u):
+//     per row (b,c):   S1 = sum_p gu ,  S2 = sum_p gu x      -> T1 = S1 , T2 = sum_p gu n = rstd (S2 - mu S1)
+//     d bias_bc = T1 ,  d factor_bc = gamma_c T2 + beta_c T1 ,  d gamma_c = sum_b factor T2 ,  d beta_c = sum_b factor T1
+//     m1_bg = sum_{c in g} gamma factor T1 / (cg P) ,  m2_bg = sum_{c in g} gamma factor T2 / (cg P)
+//     dx = rstd (gu gamma factor - m1 - n m2)  =  gu A + x c2_bg + c3_bg ,  c2 = -rstd^2 m2 ,  c3 = -rstd m1 + mu rstd^2 m2
+// All reductions run in a fixed order (deterministic), row sums in fp32 per thread + fp64 across threads.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// gu = gy * d act(u) / du
+__device__ __forceinline__ float act_grad(float u, float gy, int swish) {
+  if (!swish) return gy;
+  const float s = sigmoid_exact(u);
+  return gy * (s * (1.0f + u * (1.0f - s)));
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *sm) {
+  const int t = threadIdx.x;
+  sm[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) sm[t] += sm[t + s];
+    __syncthreads();
+  }
+  const double r = sm[0];
+  __syncthreads();
+  return r;
+}
+
+// one workgroup per row (b,c): rows[bc] = {S1, S2}
+__global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *__restrict__ x,
+                                                            const float *__restrict__ gy,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, int swish,
+                                                            float *__restrict__ rows) {
+  __shared__ double sm[256];
+  const int bc = blockIdx.x, t = threadIdx.x;
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
+  float s1 = 0.0f, s2 = 0.0f;
+  if ((P & 3) == 0) {
+    const f32x4 *x4 = (const f32x4 *)xr, *g4 = (const f32x4 *)gr;
+    for (int p = t; p < P / 4; p += 256) {
+      const f32x4 xv = x4[p], gv = g4[p];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gu = act_grad(xv[i] * sc + sh, gv[i], swish);
+        s1 += gu;
+        s2 += gu * xv[i];
+      }
+    }
+  } else {
+    for (int p = t; p < P; p += 256) {
+      const float xv = xr[p];
+      const float gu = act_grad(xv * sc + sh, gr[p], swish);
+      s1 += gu;
+      s2 += gu * xv;
+    }
+  }
+  const double a = block_sum_256((double)s1, sm), b2 = block_sum_256((double)s2, sm);
+  if (t == 0) {
+    rows[(size_t)bc * 2] = (float)a;
+    rows[(size_t)bc * 2 + 1] = (float)b2;
+  }
+}
+
+// one workgroup per GROUP, looping over the samples: parameter gradients (summed over b in ascending order) and the
+// per-(sample, group) coefficients of the dx pass
+__global__ __launch_bounds__(256) void na_bwd_params_kernel(int nb, int c, int groups, double count_per_channel,
+                                                            const float *__restrict__ rows,
+                                                            const float *__restrict__ mean_rstd,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
+                                                            const float *__restrict__ style, int style_stride,
+                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                            float *__restrict__ dstyle, float *__restrict__ coef) {
+  __shared__ double sm[256];
+  const int g = blockIdx.x, t = threadIdx.x;
+  const int cg = c / groups, ch = g * cg + t;
+  const bool on = t < cg;
+  const double ga = (on && gamma) ? (double)gamma[ch] : 1.0, be = (on && beta) ? (double)beta[ch] : 0.0;
+  double dga = 0.0, dbe = 0.0;
+  const double n = count_per_channel * cg;
+  for (int b = 0; b < nb; ++b) {
+    const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
+    double t1 = 0.0, t2 = 0.0, f = 1.0;
+    if (on) {
+      const double s1 = (double)rows[((size_t)b * c + ch) * 2], s2 = (double)rows[((size_t)b * c + ch) * 2 + 1];
+      t1 = s1;
+      t2 = rstd * (s2 - mu * s1);
+      if (style) {
+        f = (double)style[(size_t)b * style_stride + ch];
+        dstyle[(size_t)b * 2 * c + ch] = (float)(ga * t2 + be * t1);  // d factor
+        dstyle[(size_t)b * 2 * c + c + ch] = (float)t1;               // d bias
+      }
+      dga += f * t2;
+      dbe += f * t1;
+    }
+    const double m1 = block_sum_256(on ? ga * f * t1 : 0.0, sm) / n;
+    const double m2 = block_sum_256(on ? ga * f * t2 : 0.0, sm) / n;
+    if (t == 0) {
+      coef[((size_t)b * groups + g) * 2] = (float)(-rstd * rstd * m2);
+      coef[((size_t)b * groups + g) * 2 + 1] = (float)(-rstd * m1 + mu * rstd * rstd * m2);
+    }
+  }
+  if (on) {
+    if (dgamma) dgamma[ch] = (float)dga;
+    if (dbeta) dbeta[ch] = (float)dbe;
+  }
+}
+
+// dx = gu * A + x * c2 + c3
+__global__ __launch_bounds__(256) void na_bwd_apply_kernel(int c, int groups, int P, const float *__restrict__ x,
+                                                           const float *__restrict__ gy,
+                                                           const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, int swish,
+                                                           const float *__restrict__ coef, float *__restrict__ dx) {
+  const int bc = blockIdx.y, b = bc / c, ch = bc % c, g = ch / (c / groups);
+  const float sc = scale[bc], sh = shift[bc];
+  const float c2 = coef[((size_t)b * groups + g) * 2], c3 = coef[((size_t)b * groups + g) * 2 + 1];
+  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
+  float *dr = dx + (size_t)bc * P;
+  if ((P & 3) == 0) {
+    const f32x4 *x4 = (const f32x4 *)xr, *g4 = (const f32x4 *)gr;
+    f32x4 *d4 = (f32x4 *)dr;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P / 4; p += gridDim.x * 256) {
+      const f32x4 xv = x4[p], gv = g4[p];
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = act_grad(xv[i] * sc + sh, gv[i], swish) * sc + xv[i] * c2 + c3;
+      d4[p] = o;
+    }
+  } else {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+      const float xv = xr[p];
+      dr[p] = act_grad(xv * sc + sh, gr[p], swish) * sc + xv * c2 + c3;
+    }
+  }
+}
+
+// x, gy f32[b,c,npos]; scale, shift f32[b,c] and mean_rstd f32[b,groups,2] from p2pb_gn_affine_params_ex; gamma, beta
+// f32[c] or NULL; style rows (factor[c] | bias[c]) with pitch style_stride, or NULL. Outputs: dx f32[b,c,npos],
+// dgamma / dbeta f32[c] (may be NULL), dstyle f32[b,2c] (required iff style). ws: 2*b*c + 2*b*groups floats.
+extern "C" int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, const float *gy,
+                                      const float *scale, const float *shift, const float *mean_rstd,
+                                      const float *gamma, const float *beta, const float *style, int style_stride,
+                                      int swish, float *dx, float *dgamma, float *dbeta, float *dstyle, float *ws,
+                                      void *stream) {
+  if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || c / groups > 256 || npos <= 0 || !x || !gy || !scale ||
+      !shift || !mean_rstd || !dx || !ws || (style && (!dstyle || style_stride < 2 * c)))
+    return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float *rows = ws, *coef = ws + (size_t)2 * b * c;
+  hipLaunchKernelGGL(na_bwd_reduce_kernel, dim3(b * c), dim3(256), 0, s, npos, x, gy, scale, shift, swish, rows);
+  hipLaunchKernelGGL(na_bwd_params_kernel, dim3(groups), dim3(256), 0, s, b, c, groups, (double)npos, rows, mean_rstd,
+                     gamma, beta, style, style_stride, dgamma, dbeta, dstyle, coef);
+  const int per = (npos & 3) == 0 ? npos / 4 : npos;
+  const unsigned gx = (unsigned)((per + 255) / 256 > 32 ? 32 : (per + 255) / 256);
+  hipLaunchKernelGGL(na_bwd_apply_kernel, dim3(gx, b * c), dim3(256), 0, s, c, groups, npos, x, gy, scale, shift, swish,
+                     coef, dx);
+  return p2pb_launch_status();
+}

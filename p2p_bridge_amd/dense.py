@@ -61,17 +61,25 @@ def _dgrad_holder(conv, kind):
     return cache[1]
 
 
+def _empty(x):
+    return torch.empty(0, dtype=F32, device=x.device)
+
+
 class _Conv3dK3(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, conv):
-        x = x.contiguous()
-        y, _ = fused.conv3d_k3(x, conv, stats=False, compact=True)
-        ctx.save_for_backward(x)
-        ctx.conv = conv
-        return y
+    """-> (y, GroupNorm partials of y [B,nslots,Cout,2] or an empty tensor)"""
 
     @staticmethod
-    def backward(ctx, gy):
+    def forward(ctx, x, weight, bias, conv, want_stats=False):
+        x = x.contiguous()
+        y, st = fused.conv3d_k3(x, conv, stats=want_stats, compact=True)
+        ctx.save_for_backward(x)
+        ctx.conv = conv
+        st = st if st is not None else _empty(x)
+        ctx.mark_non_differentiable(st)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, gy, _gst=None):
         (x,) = ctx.saved_tensors
         conv = ctx.conv
         gy = gy.contiguous()
@@ -89,20 +97,24 @@ class _Conv3dK3(torch.autograd.Function):
                              device=x.device)
             call("p2pb_conv3d_k3_wgrad", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
                  math, stream_ptr())
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
 class _Pointwise(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, weight, bias, conv):
-        x = x.contiguous()
-        y, _ = fused.pw_conv(x, conv, stats=False, use_bias=bias is not None)
-        ctx.save_for_backward(x)
-        ctx.conv = conv
-        return y
+    """-> (y, GroupNorm partials of y or an empty tensor)"""
 
     @staticmethod
-    def backward(ctx, gy):
+    def forward(ctx, x, weight, bias, conv, want_stats=False):
+        x = x.contiguous()
+        y, st = fused.pw_conv(x, conv, stats=want_stats, use_bias=bias is not None)
+        ctx.save_for_backward(x)
+        ctx.conv = conv
+        st = st if st is not None else _empty(x)
+        ctx.mark_non_differentiable(st)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, gy, _gst=None):
         (x,) = ctx.saved_tensors
         conv = ctx.conv
         gy = gy.contiguous()
@@ -121,20 +133,94 @@ class _Pointwise(torch.autograd.Function):
             call("p2pb_pointwise_wgrad", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
                  math, stream_ptr())
             gw = gw.view(conv.weight.shape)
-        return gx, gw, gb, None
+        return gx, gw, gb, None, None
 
 
-def conv3d_k3(x, conv: torch.nn.Conv3d):
+class _NormAct(torch.autograd.Function):
+    """y = act(GroupNorm(x) * gamma + beta [* factor + bias]) with the statistics the producing convolution emitted:
+    forward = gn_affine (fold to a per-(sample, channel) affine) + affine_act, backward = csrc/normact.hip (3 launches)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, style, stats, groups, eps, swish):
+        b, c = x.shape[:2]
+        p = x.numel() // (b * c)
+        x3 = x.reshape(b, c, p)
+        if style is not None and (style.stride(1) != 1 or style.shape[1] != 2 * c):
+            style = style.contiguous()
+        scale = torch.empty(b, c, dtype=F32, device=x.device)
+        shift = torch.empty_like(scale)
+        mr = torch.empty(b, groups, 2, dtype=F32, device=x.device)
+        call("p2pb_gn_affine_params_ex", _i(b), _i(c), _i(groups), _i(stats.shape[1]), ctypes.c_double(float(p)),
+             ptr(stats), ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0),
+             ctypes.c_float(eps), ptr(scale), ptr(shift), ptr(None), ptr(mr), stream_ptr())
+        y = fused.affine_act(x3, scale, shift, bool(swish), None)
+        ctx.save_for_backward(x3, scale, shift, mr, gamma, beta, style)
+        ctx.groups, ctx.swish = groups, bool(swish)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, scale, shift, mr, gamma, beta, style = ctx.saved_tensors
+        b, c, p = x3.shape
+        groups = ctx.groups
+        gy = gy.contiguous()
+        dx = torch.empty_like(x3)
+        dgamma = torch.empty_like(gamma) if gamma is not None else None
+        dbeta = torch.empty_like(beta) if beta is not None else None
+        dstyle = torch.empty(b, 2 * c, dtype=F32, device=x3.device) if style is not None else None
+        ws = torch.empty(2 * b * c + 2 * b * groups, dtype=F32, device=x3.device)
+        call("p2pb_norm_act_backward", _i(b), _i(c), _i(groups), _i(p), ptr(x3), ptr(gy), ptr(scale), ptr(shift), ptr(mr),
+             ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0), _i(int(ctx.swish)),
+             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dstyle), ptr(ws), stream_ptr())
+        return dx.view(gy.shape), dgamma, dbeta, dstyle, None, None, None, None
+
+
+def conv3d_k3(x, conv: torch.nn.Conv3d, want_stats=False):
     """nn.Conv3d(kernel 3, stride 1, padding 1) applied to x f32[B,Cin,r,r,r], r in {4, 8, 16, 32}"""
     if not enabled(x) or x.shape[2] not in (4, 8, 16, 32):
-        return conv(x)
-    return _Conv3dK3.apply(x, conv.weight, conv.bias, conv)
+        return (conv(x), None) if want_stats else conv(x)
+    y, st = _Conv3dK3.apply(x, conv.weight, conv.bias, conv, want_stats)
+    return (y, st) if want_stats else y
 
 
-def pointwise(x, conv):
+def pointwise(x, conv, want_stats=False):
     """a k=1 nn.Conv1d / nn.Conv2d applied to x f32[B,Cin,...]"""
     if not enabled(x):
-        return conv(x)
+        return (conv(x), None) if want_stats else conv(x)
     shape = x.shape
-    y = _Pointwise.apply(x.reshape(shape[0], shape[1], -1), conv.weight, conv.bias, conv)
-    return y.view(shape[0], y.shape[1], *shape[2:])
+    y, st = _Pointwise.apply(x.reshape(shape[0], shape[1], -1), conv.weight, conv.bias, conv, want_stats)
+    y = y.view(shape[0], y.shape[1], *shape[2:])
+    return (y, st) if want_stats else y
+
+
+def _group_norm_of(norm):
+    """(nn.GroupNorm, emd Linear | None) of AdaGN / MyGroupNorm / GroupNorm, or None when the module is not foldable"""
+    gn = getattr(norm, "norm", None)
+    if gn is not None and hasattr(norm, "emd"):
+        return gn, norm.emd
+    gn = getattr(norm, "group_norm", None)
+    if gn is not None:
+        return gn, None
+    return (norm, None) if isinstance(norm, torch.nn.GroupNorm) else None
+
+
+def conv_norm_act(x, conv, norm, cond=None, swish=True):
+    """the reference's conv -> GroupNorm | AdaGN(cond) -> [Swish] triple (models/pvcnn.py:162-205, 265-283) for training:
+    HIP convolution (emitting the norm's statistics) + folded norm / activation with a 3-launch backward.
+    cond: the global embedding [B, ctx_dim] for AdaGN (its Linear `emd` stays a torch op: a plain [B, ctx] GEMM)."""
+    gn_emd = _group_norm_of(norm)
+    is3d = isinstance(conv, torch.nn.Conv3d)
+    ok = (enabled(x) and gn_emd is not None and gn_emd[0].num_channels == conv.out_channels
+          and gn_emd[0].num_channels // gn_emd[0].num_groups <= 256 and (not is3d or x.shape[2] in (4, 8, 16, 32)))
+    if not ok:
+        y = conv3d_k3(x, conv) if is3d else pointwise(x, conv)
+        y = norm(y, cond) if (gn_emd is not None and gn_emd[1] is not None and cond is not None) else norm(y)
+        return y * torch.sigmoid(y) if swish else y
+    gn, emd = gn_emd
+    y, st = conv3d_k3(x, conv, True) if is3d else pointwise(x, conv, True)
+    style = None
+    if emd is not None:
+        if cond is None:
+            raise RuntimeError("AdaGN needs the global embedding")
+        style = cond.style(norm) if hasattr(cond, "style") else emd(cond)
+    return _NormAct.apply(y, gn.weight, gn.bias, style, st, gn.num_groups, gn.eps, swish)

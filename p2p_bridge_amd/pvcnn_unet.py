@@ -251,11 +251,8 @@ class SharedMLP(nn.Module):
             return self._run_fused(x, cond, reduce_max, residual)
         from . import dense
 
-        for m in self.layers:
-            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
-                x = dense.pointwise(x, m)  # training: HIP forward + backward (dense.py)
-            else:
-                x = m(x, cond) if (isinstance(m, AdaGN) and cond is not None) else m(x)
+        for i in range(len(self.layers) // 3):  # training: HIP conv + folded norm / Swish, forward and backward
+            x = dense.conv_norm_act(x, self.layers[3 * i], self.layers[3 * i + 1], cond, swish=True)
         if reduce_max:
             x = x.max(dim=-1).values
         return x if residual is None else residual + x
@@ -413,11 +410,11 @@ class PVConv(nn.Module):
             from . import dense
 
             v, vcoords = self.voxelization(features, coords)
-            for m in self.voxel_layers:
-                if isinstance(m, nn.Conv3d):
-                    v = dense.conv3d_k3(v, m)  # training: HIP forward + backward (dense.py)
-                else:
-                    v = m(v, cond) if isinstance(m, AdaGN) else m(v)
+            vl = self.voxel_layers  # conv, norm, Swish, Dropout, conv, norm[, SE3d]: HIP forward + backward (dense.py)
+            v = vl[3](dense.conv_norm_act(v, vl[0], vl[1], cond, swish=True))
+            v = dense.conv_norm_act(v, vl[4], vl[5], cond, swish=False)
+            if len(vl) > 6:
+                v = vl[6](v)
             fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
         data.features = self.point_features.run(features, cond, residual=fused)
         if self.attn is not None:  # models/pvcnn.py:327-328
@@ -570,7 +567,7 @@ class _PnetMLP(nn.Module):
     def forward(self, x):
         from . import dense
 
-        return self.mlp[2](self.mlp[1](dense.pointwise(x, self.mlp[0])))
+        return dense.conv_norm_act(x, self.mlp[0], self.mlp[1], None, swish=True)
 
 
 class ConditionedSharedMLPLayer(nn.Module):
@@ -910,7 +907,7 @@ class PVCNN2Unet(nn.Module):
                 from . import dense
 
                 e = self.embed_feats
-                feats = dense.pointwise(e[2](e[1](dense.pointwise(src, e[0]))), e[3])
+                feats = dense.pointwise(dense.conv_norm_act(src, e[0], e[1], None, swish=True), e[3])
         cond = self.global_pnet(coords) if self.global_pnet is not None else None
         if use_fused and cond is not None:
             if self._style_bank is None:

@@ -126,3 +126,59 @@ def test_training_path_uses_no_miopen_convolutions():
         for cls, f in fsaved.items():
             cls.forward = f
     assert abs(loss.item() - float(run["loss"])) <= 1e-4 * abs(float(run["loss"]))
+
+
+@pytest.mark.parametrize("kind,b,ci,co,shape,swish", [
+    ("adagn3d", 2, 16, 64, (8, 8, 8), True), ("adagn3d", 3, 8, 32, (16, 16, 16), False),
+    ("adagn1d", 2, 67, 64, (1000,), True), ("adagn2d", 2, 35, 128, (64, 32), True), ("gn1d", 4, 64, 128, (2048,), True),
+    ("mygn2d", 2, 3, 128, (512, 1), True), ("adagn3d", 2, 8, 16, (4, 4, 4), True), ("gn1d", 2, 3, 24, (333,), False)])
+def test_conv_norm_act_forward_backward(kind, b, ci, co, shape, swish):
+    """conv -> GroupNorm | AdaGN | MyGroupNorm -> [Swish] through dense.conv_norm_act (HIP conv emitting the statistics,
+    folded norm, csrc/normact.hip backward) vs the same chain in torch fp64 autograd: output, dx, and every parameter
+    gradient (conv weight / bias, norm gamma / beta, AdaGN's style Linear, the conditioning vector)"""
+    from p2p_bridge_amd import dense
+    from p2p_bridge_amd.pvcnn_unet import AdaGN, MyGroupNorm
+
+    torch.manual_seed(len(kind) * 100 + co)
+    conv = {"3d": nn.Conv3d(ci, co, 3, padding=1), "1d": nn.Conv1d(ci, co, 1), "2d": nn.Conv2d(ci, co, 1)}[kind[-2:]].cuda()
+    if kind.startswith("adagn"):
+        norm = AdaGN(co, 48, len(shape), 8).cuda()
+        cond = torch.randn(b, 48, device="cuda", requires_grad=True)
+    elif kind.startswith("mygn"):
+        norm, cond = MyGroupNorm(32, co).cuda(), None
+    else:
+        norm, cond = nn.GroupNorm(8, co).cuda(), None
+    gn = norm.norm if isinstance(norm, AdaGN) else (norm.group_norm if isinstance(norm, MyGroupNorm) else norm)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.normal_()
+    x = torch.randn(b, ci, *shape, device="cuda", requires_grad=True)
+    y = dense.conv_norm_act(x, conv, norm, cond, swish)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = {"x": x.grad, "w": conv.weight.grad, "cb": conv.bias.grad, "gamma": gn.weight.grad, "beta": gn.bias.grad}
+    if cond is not None:
+        got.update(cond=cond.grad, ew=norm.emd.weight.grad, eb=norm.emd.bias.grad)
+    # fp64 reference on the CPU
+    d = lambda t: t.detach().double().cpu().requires_grad_(True)
+    x64, w64, cb64, ga64, be64 = d(x), d(conv.weight), d(conv.bias), d(gn.weight), d(gn.bias)
+    f = {"3d": lambda: F.conv3d(x64, w64, cb64, padding=1), "1d": lambda: F.conv1d(x64, w64, cb64),
+         "2d": lambda: F.conv2d(x64, w64, cb64)}[kind[-2:]]
+    h = F.group_norm(f(), gn.num_groups, ga64, be64, gn.eps)
+    ref = {"x": x64, "w": w64, "cb": cb64, "gamma": ga64, "beta": be64}
+    if cond is not None:
+        c64, ew64, eb64 = d(cond), d(norm.emd.weight), d(norm.emd.bias)
+        style = F.linear(c64, ew64, eb64).reshape(b, 2 * co, *([1] * len(shape)))
+        fac, bia = style.chunk(2, 1)
+        h = h * fac + bia
+        ref.update(cond=c64, ew=ew64, eb=eb64)
+    y64 = h * torch.sigmoid(h) if swish else h
+    y64.backward(gy.double().cpu())
+    assert _rel(y.detach(), y64.detach()) < 1e-5
+    for k, v in ref.items():
+        tol = 2e-4 if k in ("w",) else 5e-5  # (conv weight gradient: bf16x3 operands by default)
+        if k == "cb":  # sums of dx over a channel: heavy cancellation (they add up to zero over every group)
+            err = (got[k].double().cpu() - v.grad).abs().max().item()
+            assert err < 1e-5 * max(1.0, got["x"].abs().max().item() * x[0, 0].numel() ** 0.5), (k, err)
+            continue
+        assert _rel(got[k], v.grad) < tol, (k, _rel(got[k], v.grad))
