@@ -1079,7 +1079,9 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
   // 64 output channels per workgroup unless that leaves fewer than 2 workgroups per CU (small grids)
   const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 512;
   if (flags & 4) {  // wt_packed is the split (3 x bf16) pack; always the compact tiling (same results, same slots)
-    const bool wide = cout > 32;
+    // 64 output channels per workgroup, unless that leaves under one workgroup per CU (small grids x small batches:
+    // the 8^3 grids of a training batch of 8): 32 channels then double the workgroup count
+    const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 256;
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
                                          in_sub, skip, nullptr, nullptr, out, stats_part, cl, s)                          \

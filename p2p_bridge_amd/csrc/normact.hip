@@ -75,8 +75,10 @@ __global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *
   }
 }
 
-// one workgroup per GROUP, looping over the samples: parameter gradients (summed over b in ascending order) and the
-// per-(sample, group) coefficients of the dx pass
+// one workgroup per GROUP: thread t < cg owns channel g*cg + t and walks the samples (parameter gradients summed over b
+// in ascending order); the per-(sample, group) sums behind the dx coefficients are formed from an LDS table by thread
+// j = sample, serially over the cg channels -- fixed order, two barriers per 16 samples
+#define NA_BCH 16
 __global__ __launch_bounds__(256) void na_bwd_params_kernel(int nb, int c, int groups, double count_per_channel,
                                                             const float *__restrict__ rows,
                                                             const float *__restrict__ mean_rstd,
@@ -85,34 +87,47 @@ __global__ __launch_bounds__(256) void na_bwd_params_kernel(int nb, int c, int g
                                                             const float *__restrict__ style, int style_stride,
                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                             float *__restrict__ dstyle, float *__restrict__ coef) {
-  __shared__ double sm[256];
+  __shared__ double w1[NA_BCH][256], w2[NA_BCH][256];
   const int g = blockIdx.x, t = threadIdx.x;
   const int cg = c / groups, ch = g * cg + t;
   const bool on = t < cg;
   const double ga = (on && gamma) ? (double)gamma[ch] : 1.0, be = (on && beta) ? (double)beta[ch] : 0.0;
   double dga = 0.0, dbe = 0.0;
   const double n = count_per_channel * cg;
-  for (int b = 0; b < nb; ++b) {
-    const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
-    double t1 = 0.0, t2 = 0.0, f = 1.0;
-    if (on) {
-      const double s1 = (double)rows[((size_t)b * c + ch) * 2], s2 = (double)rows[((size_t)b * c + ch) * 2 + 1];
-      t1 = s1;
-      t2 = rstd * (s2 - mu * s1);
-      if (style) {
-        f = (double)style[(size_t)b * style_stride + ch];
-        dstyle[(size_t)b * 2 * c + ch] = (float)(ga * t2 + be * t1);  // d factor
-        dstyle[(size_t)b * 2 * c + c + ch] = (float)t1;               // d bias
+  for (int b0 = 0; b0 < nb; b0 += NA_BCH) {
+    const int nbb = min(NA_BCH, nb - b0);
+    if (on)
+      for (int j = 0; j < nbb; ++j) {
+        const int b = b0 + j;
+        const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
+        const double s1 = (double)rows[((size_t)b * c + ch) * 2], s2 = (double)rows[((size_t)b * c + ch) * 2 + 1];
+        const double t1 = s1, t2 = rstd * (s2 - mu * s1);
+        double f = 1.0;
+        if (style) {
+          f = (double)style[(size_t)b * style_stride + ch];
+          dstyle[(size_t)b * 2 * c + ch] = (float)(ga * t2 + be * t1);  // d factor
+          dstyle[(size_t)b * 2 * c + c + ch] = (float)t1;               // d bias
+        }
+        dga += f * t2;
+        dbe += f * t1;
+        w1[j][t] = ga * f * t1;
+        w2[j][t] = ga * f * t2;
       }
-      dga += f * t2;
-      dbe += f * t1;
-    }
-    const double m1 = block_sum_256(on ? ga * f * t1 : 0.0, sm) / n;
-    const double m2 = block_sum_256(on ? ga * f * t2 : 0.0, sm) / n;
-    if (t == 0) {
+    __syncthreads();
+    if (t < nbb) {
+      const int b = b0 + t;
+      double m1 = 0.0, m2 = 0.0;
+      for (int k = 0; k < cg; ++k) {
+        m1 += w1[t][k];
+        m2 += w2[t][k];
+      }
+      m1 /= n;
+      m2 /= n;
+      const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
       coef[((size_t)b * groups + g) * 2] = (float)(-rstd * rstd * m2);
       coef[((size_t)b * groups + g) * 2 + 1] = (float)(-rstd * m1 + mu * rstd * rstd * m2);
     }
+    __syncthreads();
   }
   if (on) {
     if (dgamma) dgamma[ch] = (float)dga;

@@ -431,129 +431,17 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
 #define PWS_TILE (2 * 3 * 2 * 128)                     // 16-byte groups per operand tile (24 KB)
 #define PWS_LDS_BYTES (2 * PWS_TILE * 16)               // A + B
 
-template <bool XF, bool POOL>
-__global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int P, int nslots,
-                                                       const float *__restrict__ in, const u32x4 *__restrict__ wp,
-                                                       const float *__restrict__ bias,
-                                                       const float *__restrict__ bias_b,
-                                                       const float *__restrict__ in_scale,
-                                                       const float *__restrict__ in_shift, int in_swish,
-                                                       float *__restrict__ out, float *__restrict__ stats_part,
-                                                       float *__restrict__ mm_out, int pool_u, int out_pm) {
-  extern __shared__ u32x4 pws_lds[];  // [A][B]
-  u32x4 *lds_b = pws_lds + PWS_TILE;
-  const u32x4 *lds_a = pws_lds;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the scalar descriptors
-  const int l31 = lane & 31, khalf = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so XCD x takes the x-th
-  // contiguous eighth of (sample, position block, channel block) with the channel block fastest: the 2..8 workgroups
-  // that stage the SAME activation tile run side by side on one XCD and share it in its L2 (the dispatch order
-  // x + gx*(y + gy*z) put them 64 workgroups apart: 2.6x the algorithmic bytes from HBM).
-  const int ncoblk = gridDim.y;
-  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
-  const unsigned vid = nblk % 8 == 0 ? (lin % 8) * (nblk / 8) + lin / 8 : lin;
-  const int bx = (vid / ncoblk) % gridDim.x, by = vid % ncoblk;
-  const int b = vid / (ncoblk * gridDim.x);
-  const int pblk = bx * 128, co0 = by * 128;
-  const float *inb = in + (size_t)b * cin * P;
-  const bool mact = co0 + wm * 64 < cout;  // this wave's 64 channels exist (wave-uniform)
-
-  f32x16 acc[2][2];
+// Epilogue of the split-operand GEMM kernels for one wave's 64 channels x NB x 64 positions: bias, stores (channel- or
+// point-major), GroupNorm partials per 64-position slot, optional {min, max} for the pooling that follows.
+template <bool POOL, int WM, int NB>
+__device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, int bx, int gx, int pblk, int co0,
+                                             int wm, int wn, int l31, int khalf, int cout, int P, int nslots,
+                                             const float *__restrict__ bias, const float *__restrict__ bias_b,
+                                             float *__restrict__ out, float *__restrict__ stats_part,
+                                             float *__restrict__ mm_out, int pool_u, int out_pm) {
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-  // B staging: wave w owns channel group w (8 channels) of the stage, lane l positions 2l, 2l+1
-  const int pl = pblk + 2 * lane;
-  const unsigned voff = (unsigned)(pl < P ? pl : P - 2) * 4u;  // clamped lanes stage garbage that is never stored
-  f32x2 braw[8];
-  auto load_b = [&](int ci0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = min(ci0 + 8 * wave + i, cin - 1);  // beyond cin: finite garbage x zero weights
-      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, P * 4, 0x00020000);
-      braw[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
-    }
-  };
-  // A tile of stage `chunk` -> LDS, asynchronously: lane i of a wave lands at base + 16*i
-  auto dma_a = [&](int chunk) {
-    const u32x4 *src = wp + ((size_t)chunk * ncoblk + by) * PWS_TILE;
-    u32x4 *dst = pws_lds;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256 + tid),
-                                       (__attribute__((address_space(3))) void *)(dst + i * 256 + wave * 64), 16, 0, 0);
-  };
-  load_b(0);
-
-  for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
-    __syncthreads();  // everyone is done reading the previous stage
-    dma_a(ci0 / PWS_CK);  // lands while B is transformed and split below
-    // ---- stage B: transform + split
-    {
-      if (XF) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c = b * cin + min(ci0 + 8 * wave + i, cin - 1);
-          const float sc = in_scale[c], sh = in_shift[c];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            float v = braw[i][e] * sc + sh;
-            if (in_swish) v = swishf(v);
-            braw[i][e] = v;
-          }
-        }
-      }
-      const int kstep = wave >> 1, kh = wave & 1;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        u32x4 q[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned p0, p1, p2;
-          split3(braw[2 * i][e], braw[2 * i + 1][e], p0, p1, p2);
-          q[0][i] = p0;
-          q[1][i] = p1;
-          q[2][i] = p2;
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * 128 + e * 64 + lane] = q[s];
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this stage's A tile has landed
-    __syncthreads();
-    if (ci0 + PWS_CK < cin) load_b(ci0 + PWS_CK);  // next stage's B loads fly during the MFMAs
-    if (!mact) continue;
-#pragma unroll
-    for (int kstep = 0; kstep < 2; ++kstep) {
-      u32x4 af[3][2], bf[3][2];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-#pragma unroll
-        for (int m = 0; m < 2; ++m) af[s][m] = lds_a[((kstep * 3 + s) * 2 + khalf) * 128 + wm * 64 + m * 32 + l31];
-#pragma unroll
-        for (int n = 0; n < 2; ++n) bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * 128 + n * 64 + wn * 32 + l31];
-      }
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[t]][m]),
-                                                                __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
-    }
-  }
-  if (!mact) return;
-
-  const int p = pblk + 2 * (wn * 32 + l31);
+  for (int pb = 0; pb < NB; ++pb) {  // the wave's NB blocks of 64 positions (even / odd tiles 2 pb, 2 pb + 1)
+  const int p = pblk + 128 * pb + 2 * (wn * 32 + l31);
   const bool pok = p < P;
   if (out_pm) {  // point-major output f32[b, P, cout]; no statistics in this form
     float *ob = out + (size_t)b * P * cout;
@@ -575,8 +463,8 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
             float *q = ob + (size_t)(p + n) * cout + cq;
-            const f32x4 v = {acc[m][n][4 * g] + bv[0], acc[m][n][4 * g + 1] + bv[1], acc[m][n][4 * g + 2] + bv[2],
-                             acc[m][n][4 * g + 3] + bv[3]};
+            const f32x4 v = {acc[m][2 * pb + n][4 * g] + bv[0], acc[m][2 * pb + n][4 * g + 1] + bv[1],
+                             acc[m][2 * pb + n][4 * g + 2] + bv[2], acc[m][2 * pb + n][4 * g + 3] + bv[3]};
             if (cq + 3 < cout && (cout & 3) == 0) *(f32x4 *)q = v;
             else
               for (int i = 0; i < 4; ++i)
@@ -584,14 +472,14 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
           }
         }
       }
-    return;
+    continue;
   }
   // ---- epilogue: bias, 8-byte stores, GroupNorm partials per 64-position slot, optional {min, max}.
   // Row index of the reductions: idx = m*16 + r; rowreduce32 leaves row (l31) in lane l31.
   float *outb = out ? out + (size_t)b * cout * P : nullptr;
-  const int slot = bx * 2 + wn;
+  const int slot = (bx * NB + pb) * 2 + wn;
   const int pool_g = pool_u ? pool_u / 2 : 32;
-  float s1v[32], s2v[32], mnv[32], mxv[32];
+  // pass 1: bias (in place), stores, neighbourhood {min, max}
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -603,37 +491,50 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
         bv = bias ? bias[co] : 0.0f;
         if (bias_b) bv += bias_b[(size_t)b * cout + co];
       }
-      const f32x2 v = {acc[m][0][r] + bv, acc[m][1][r] + bv};
-      const bool ok = cok && pok;
-      if (ok && outb) *(f32x2 *)(outb + (size_t)co * P + p) = v;
-      s1v[m * 16 + r] = ok ? v[0] + v[1] : 0.0f;
-      s2v[m * 16 + r] = ok ? v[0] * v[0] + v[1] * v[1] : 0.0f;
-      if (POOL) {
+      acc[m][2 * pb][r] += bv;
+      acc[m][2 * pb + 1][r] += bv;
+      const f32x2 v = {acc[m][2 * pb][r], acc[m][2 * pb + 1][r]};
+      if (cok && pok && outb) *(f32x2 *)(outb + (size_t)co * P + p) = v;
+      if (POOL && pool_u != 0) {
         float mn = pok ? fminf(v[0], v[1]) : INFINITY, mx = pok ? fmaxf(v[0], v[1]) : -INFINITY;
-        if (pool_u == 0) {
-          mnv[m * 16 + r] = mn;
-          mxv[m * 16 + r] = mx;
-        } else {
-          group_minmax(mn, mx, pool_g);
-          if (cok && pok && (pool_g == 32 ? l31 == 31 : (l31 & (pool_g - 1)) == 0)) {
-            float *q = mm_out + (((size_t)b * cout + co) * (P / pool_u) + p / pool_u) * 2;
-            q[0] = mn;
-            q[1] = mx;
-          }
+        group_minmax(mn, mx, pool_g);
+        if (cok && pok && (pool_g == 32 ? l31 == 31 : (l31 & (pool_g - 1)) == 0)) {
+          float *q = mm_out + (((size_t)b * cout + co) * (P / pool_u) + p / pool_u) * 2;
+          q[0] = mn;
+          q[1] = mx;
         }
       }
     }
   }
-  // this lane's row after the reductions
+  // this lane's row after the reductions; one 32-value array live at a time (register pressure: the other position
+  // block's accumulators are still waiting)
   const int rm = l31 >> 4, rr = l31 & 15;
   const int rco = co0 + wm * 64 + rm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * khalf;
+  auto rowvals = [&](int kind, float (&v)[32]) {  // 0: sum, 1: sum of squares, 2: min, 3: max over the lane's pair
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        const float v0 = acc[m][2 * pb][r], v1 = acc[m][2 * pb + 1][r];
+        const bool ok = co < cout && pok;
+        v[m * 16 + r] = kind == 0 ? (ok ? v0 + v1 : 0.0f)
+                        : kind == 1 ? (ok ? v0 * v0 + v1 * v1 : 0.0f)
+                        : kind == 2 ? (pok ? fminf(v0, v1) : INFINITY)
+                                    : (pok ? fmaxf(v0, v1) : -INFINITY);
+      }
+  };
   if (stats_part) {
-    const float s1 = rowreduce32<RowAdd>(s1v), s2 = rowreduce32<RowAdd>(s2v);
+    float tv[32];
+    rowvals(0, tv);
+    const float s1 = rowreduce32<RowAdd>(tv);
+    rowvals(1, tv);
+    const float s2 = rowreduce32<RowAdd>(tv);
     if (rco < cout) {
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
       q[0] = s1;
       q[1] = s2;
-      if (bx == (int)gridDim.x - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
+      if (bx == gx - 1 && pb == NB - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
         for (int sl = slot + 1; sl < nslots; ++sl) {
           float *z = stats_part + (((size_t)b * nslots + sl) * cout + rco) * 2;
           z[0] = 0.0f;
@@ -642,13 +543,217 @@ __global__ __launch_bounds__(256, 3) void pw_split_kernel(int cin, int cout, int
     }
   }
   if (POOL && pool_u == 0) {
-    const float mn = rowreduce32<RowMin>(mnv), mx = rowreduce32<RowMax>(mxv);
+    float tv[32];
+    rowvals(2, tv);
+    const float mn = rowreduce32<RowMin>(tv);
+    rowvals(3, tv);
+    const float mx = rowreduce32<RowMax>(tv);
     if (rco < cout) {
-      float *q = mm_out + ((((size_t)b * gridDim.x + bx) * 2 + wn) * cout + rco) * 2;
+      float *q = mm_out + ((((size_t)b * gx * NB + bx * NB + pb) * 2 + wn) * cout + rco) * 2;
       q[0] = mn;
       q[1] = mx;
     }
   }
+  }  // pb
+}
+
+// WM = waves along M: 2 -> 128 output channels per workgroup (4 waves, 48 KB of LDS, three workgroups per CU);
+// 4 -> 256 channels (8 waves, 72 KB, two per CU): the activation tile is transformed / split / staged once per 256
+// instead of once per 128 channels -- half the VALU + LDS-write work per MFMA -- for the layers whose grid still fills
+// the chip (the global embedding's 512 -> 1024 GEMM). A wave's tile, fragments and epilogue are the same in both.
+// NB = 128-position blocks per workgroup (1 or 2): with 2 a wave owns 64 channels x 128 positions (2 x 4 accumulator
+// tiles), every A fragment feeds four MFMAs instead of two and the weight tile is streamed from L2 once per 256
+// positions -- the 128 x 128 tiling moves 10.7 GB through L2 for the 512 -> 1024 x 262144 GEMM (6.4 GB of it the
+// pre-split weights, re-read by 2048 position blocks), 256 x 256 moves 5.3 GB.
+template <bool XF, bool POOL, int WM, int NB>
+__global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : 4)) void pw_split_kernel(int cin, int cout, int P, int nslots,
+                                                       const float *__restrict__ in, const u32x4 *__restrict__ wp,
+                                                       const float *__restrict__ bias,
+                                                       const float *__restrict__ bias_b,
+                                                       const float *__restrict__ in_scale,
+                                                       const float *__restrict__ in_shift, int in_swish,
+                                                       float *__restrict__ out, float *__restrict__ stats_part,
+                                                       float *__restrict__ mm_out, int pool_u, int out_pm) {
+  extern __shared__ u32x4 pws_lds[];  // [A: WM/2 blocks of 128 channels][B: NB blocks of 128 positions]
+  constexpr int NT = 128 * WM;
+  constexpr int BS = 128 * NB;  // 16-byte groups per (kstep, split, khalf) row of the B tile
+  u32x4 *lds_b = pws_lds + (WM / 2) * PWS_TILE;
+  const u32x4 *lds_a = pws_lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform for the scalar descriptors
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware order: workgroup ids go round-robin over the 8 XCDs (each with its own L2), so XCD x takes the x-th
+  // contiguous eighth of (sample, position block, channel block) with the channel block fastest: the 2..8 workgroups
+  // that stage the SAME activation tile run side by side on one XCD and share it in its L2 (the dispatch order
+  // x + gx*(y + gy*z) put them 64 workgroups apart: 2.6x the algorithmic bytes from HBM).
+  const int ncoblk = gridDim.y;
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned vid = nblk % 8 == 0 ? (lin % 8) * (nblk / 8) + lin / 8 : lin;
+  const int bx = (vid / ncoblk) % gridDim.x, by = vid % ncoblk;
+  const int b = vid / (ncoblk * gridDim.x);
+  const int pblk = bx * (128 * NB), co0 = by * (64 * WM);
+  const float *inb = in + (size_t)b * cin * P;
+  const bool mact = co0 + wm * 64 < cout;  // this wave's 64 channels exist (wave-uniform)
+
+  f32x16 acc[2][2 * NB];  // [M-tile][position block * 2 + even/odd tile]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2 * NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+  // B staging: the stage's 4 channel groups (8 channels each) x NB position blocks are dealt to the 2*WM waves.
+  //   WM == 2: wave w owns channel group w for ALL position blocks; lane l positions 2l, 2l+1 of each block;
+  //   WM == 4, NB == 2: wave w owns channel group w >> 1 of position block w & 1; lane l positions 2l, 2l+1;
+  //   WM == 4, NB == 1: wave w owns channel group w >> 1 for the position half w & 1; lane l position 64 (w & 1) + l.
+  constexpr bool ONE = WM == 4 && NB == 1;      // one position per lane (4-byte loads)
+  constexpr int NBW = WM == 2 ? NB : 1;         // position blocks staged by one wave
+  const int bgrp = WM == 2 ? wave : wave >> 1, bsel = WM == 2 ? 0 : (wave & 1);
+  unsigned voff[NBW];
+#pragma unroll
+  for (int q = 0; q < NBW; ++q) {
+    const int pl = ONE ? pblk + 64 * bsel + lane : pblk + 128 * (WM == 2 ? q : bsel) + 2 * lane;
+    voff[q] = (unsigned)(pl < P ? pl : P - (ONE ? 1 : 2)) * 4u;  // clamped lanes stage garbage that is never stored
+  }
+  f32x2 braw[NBW][8];
+  auto load_b = [&](int ci0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = min(ci0 + 8 * bgrp + i, cin - 1);  // beyond cin: finite garbage x zero weights
+      auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, P * 4, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < NBW; ++q) {
+        if (!ONE) braw[q][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q], 0, 0));
+        else braw[q][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[q], 0, 0));
+      }
+    }
+  };
+  // A tile of stage `chunk` -> LDS, asynchronously: lane i of a wave lands at base + 16*i
+  auto dma_a = [&](int chunk) {
+    // (the pack is in 128-channel blocks; a 256-channel workgroup takes two consecutive ones)
+    const int nblk128 = WM == 2 ? ncoblk : (cout + 127) / 128;
+    const u32x4 *src = wp + ((size_t)chunk * nblk128 + by * (WM / 2)) * PWS_TILE;
+    u32x4 *dst = pws_lds;
+    const bool second_ok = WM == 2 || by * 2 + 1 < nblk128;  // odd block count: the last workgroup has one block only
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      if (second_ok || i * NT + tid < PWS_TILE)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * NT + tid),
+                                         (__attribute__((address_space(3))) void *)(dst + i * NT + wave * 64), 16, 0, 0);
+  };
+  load_b(0);
+
+  for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
+    __syncthreads();  // everyone is done reading the previous stage
+#ifdef PWS_A_DIRECT
+    // experiment: A fragments straight from L1 / L2 into registers (issued here, consumed after the staging phase)
+    u32x4 areg[2][3][2];
+    {
+      const int nblk128 = WM == 2 ? ncoblk : (cout + 127) / 128;
+      const u32x4 *src = wp + ((size_t)(ci0 / PWS_CK) * nblk128 + by * (WM / 2) + (wm >> 1)) * PWS_TILE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            areg[ks][s][m] = src[((ks * 3 + s) * 2 + khalf) * 128 + (wm & 1) * 64 + m * 32 + l31];
+    }
+#elif !defined(PWS_EXP_NODMA)
+    dma_a(ci0 / PWS_CK);  // lands while B is transformed and split below
+#endif
+    // ---- stage B: transform + split
+    {
+      constexpr int NE = ONE ? 1 : 2;
+#ifndef PWS_EXP_NOXF
+      if (XF) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = b * cin + min(ci0 + 8 * bgrp + i, cin - 1);
+          const float sc = in_scale[c], sh = in_shift[c];
+#pragma unroll
+          for (int q = 0; q < NBW; ++q)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+              float v = braw[q][i][e] * sc + sh;
+              if (in_swish) v = swishf(v);
+              braw[q][i][e] = v;
+            }
+        }
+      }
+#endif
+      const int kstep = bgrp >> 1, kh = bgrp & 1;
+#pragma unroll
+      for (int q = 0; q < NBW; ++q)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          u32x4 qq[3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned p0, p1, p2;
+#ifndef PWS_EXP_NOSPLIT
+            split3(braw[q][2 * i][e], braw[q][2 * i + 1][e], p0, p1, p2);
+#else
+            p0 = __builtin_bit_cast(unsigned, braw[q][2 * i][e]), p1 = __builtin_bit_cast(unsigned, braw[q][2 * i + 1][e]), p2 = p0 ^ p1;
+#endif
+            qq[0][i] = p0;
+            qq[1][i] = p1;
+            qq[2][i] = p2;
+          }
+          // slot of position p of a 128-block: (p & 1) * 64 + (p >> 1)   (even / odd de-interleaved)
+          const int blk = WM == 2 ? q : (NB == 2 ? bsel : 0);
+          const int slot = blk * 128 + (ONE ? (lane & 1) * 64 + 32 * bsel + (lane >> 1) : e * 64 + lane);
+#pragma unroll
+          for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * BS + slot] = qq[s];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this stage's A tile has landed
+    __syncthreads();
+    if (ci0 + PWS_CK < cin) load_b(ci0 + PWS_CK);  // next stage's B loads fly during the MFMAs
+    if (!mact) continue;
+#ifdef PWS_EXP_NOMFMA
+    continue;
+#endif
+#pragma unroll
+    for (int kstep = 0; kstep < 2; ++kstep) {
+      u32x4 af[3][2];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#ifdef PWS_A_DIRECT
+          af[s][m] = areg[kstep][s][m];
+#else
+          af[s][m] = lds_a[(wm >> 1) * PWS_TILE + ((kstep * 3 + s) * 2 + khalf) * 128 + (wm & 1) * 64 + m * 32 + l31];
+#endif
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
+      // the B fragments of one position block (2 tiles x 3 terms) at a time: 24 registers live instead of 24 NB
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        u32x4 bf[3][2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * BS + nb * 128 + n * 64 + wn * 32 + l31];
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              acc[m][2 * nb + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[t]][m]),
+                                                                           __builtin_bit_cast(bf16x8, bf[PB[t]][n]),
+                                                                           acc[m][2 * nb + n], 0, 0, 0);
+      }
+    }
+  }
+  if (!mact) return;
+  pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
+                             stats_part, mm_out, pool_u, out_pm);
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
@@ -693,26 +798,38 @@ extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float 
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
-  dim3 grid((P + 127) / 128, (cout + 127) / 128, b);
+  // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
+  static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
+  const bool wm4 = wm_env ? wm_env == 4 : (cout >= 512 && (long)((P + 127) / 128) * ((cout + 255) / 256) * b >= 1024);
+  // (NB = 2, 256 positions per workgroup, halves the weight traffic through L2 -- 10.7 -> 5.3 GB for the 512 -> 1024
+  // launch -- but costs a wave per SIMD: measured 4 % / 7 % SLOWER with 256 / 128 channels; only NB = 1 is instantiated)
+  dim3 grid((P + 127) / 128, wm4 ? (cout + 255) / 256 : (cout + 127) / 128, b);
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
   // 72 KB of dynamic LDS (above the 64 KB default): opt in once per instantiation
-#define LAUNCH(XF, PL)                                                                                               \
+#define LAUNCHW(XF, PL, WM, NB)                                                                                     \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
+    const int lds = (WM / 2 + NB) * PWS_TILE * 16;                                                                    \
     if (!once) {                                                                                                     \
-      hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL>, hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                          PWS_LDS_BYTES);                                                                            \
+      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB>,                                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                    \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((pw_split_kernel<XF, PL>), grid, dim3(256), PWS_LDS_BYTES, s, cin, cout, P, nslots, in, w, bias, \
-                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm);                \
+    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, w,   \
+                       bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm);          \
+  } while (0)
+#define LAUNCH(XF, PL)                    \
+  do {                                    \
+    if (wm4) LAUNCHW(XF, PL, 4, 1);        \
+    else LAUNCHW(XF, PL, 2, 1);            \
   } while (0)
   if (in_scale && minmax) LAUNCH(true, true);
   else if (in_scale) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
+#undef LAUNCHW
   return p2pb_launch_status();
 }
 
