@@ -370,6 +370,22 @@ size_t p2pb_pointwise_wgrad_ws_floats(int b, int cin, int cout, int npos, int ma
 int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const float *x, const float *dy, float *dw, float *db,
                          float *ws, int math, void *stream);
 
+/* ---- room pipeline (denoise_room.py) ---------------------------------------------------------
+ * exact radius query = sklearn.neighbors.KDTree.query_radius as used at denoise_room.py:459-464: for every patch
+ * centre the indices of ALL points with |p - c|^2 <= r^2 (fp32, fma(dz,dz,fma(dy,dy,dx*dx))), ascending. Ragged, so two
+ * passes: p2pb_radius_count -> counts i32[s]; the caller prefix-sums them into offsets i64[s] (exclusive) and calls
+ * p2pb_radius_fill -> out i32[total]. centers f32[s,3], points f32[n,3] (point-major). */
+int p2pb_radius_count(int s, int n, const float *centers, const float *points, float radius, int *counts, void *stream);
+int p2pb_radius_fill(int s, int n, const float *centers, const float *points, float radius, const long long *offsets,
+                     int *out, void *stream);
+/* running-mean merge of overlapping patch predictions (update_prediction_noisy_batches, denoise_room.py:263-289):
+ * pred f32[npatch,k,3], idx i32[npatch,k] (room point of each patch point), cuts i32[npatch] (only the first cuts[p]
+ * entries of patch p count). sums f64[n,3] / counts i32[n] are accumulators zeroed by the caller once per room; any
+ * number of batches add into them; p2pb_merge_finish writes sums / counts (or `original` where counts == 0). */
+int p2pb_merge_accumulate(int npatch, int k, const float *pred, const int *idx, const int *cuts, double *sums,
+                          int *counts, void *stream);
+int p2pb_merge_finish(int n, const double *sums, const int *counts, const float *original, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -340,3 +340,85 @@ def point_face_dist(points, tris, min_triangle_area=5e-3, which=0):
     lib().orc_point_face(_i(which), _i(points.shape[0]), _i(tris.shape[0]), _p(points), _p(tris),
                          ctypes.c_float(min_triangle_area), _p(d), _p(idx))
     return d, idx.long()
+
+
+# ---- room pipeline: restatement of denoise_room.py's host code on the oracle ops
+def radius_query(centers, points, radius):
+    """sklearn KDTree.query_radius contract (denoise_room.py:464): -> (flat idx i32[total] ascending per centre,
+    offsets i64[S+1])"""
+    _chk(centers, F32), _chk(points, F32)
+    s, n = centers.shape[0], points.shape[0]
+    counts = torch.empty(s, dtype=I32)
+    lib().orc_radius_query(_i(s), _i(n), _p(centers), _p(points), ctypes.c_float(radius), _p(counts), None, None)
+    offsets = torch.zeros(s + 1, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(counts.long(), 0)
+    out = torch.empty(int(offsets[-1]), dtype=I32)
+    lib().orc_radius_query(_i(s), _i(n), _p(centers), _p(points), ctypes.c_float(radius), None, _p(offsets), _p(out))
+    return out, offsets
+
+
+def room_create_patches(points, idx_flat, offsets, patch_size, generator):
+    """create_patches (denoise_room.py:352-421) with every random draw taken from `generator` (torch CPU) in a fixed
+    order: small radius patches are padded with randomly chosen duplicates + Gaussian jitter (noise level = 1 % of the
+    bounding-box diagonal); large ones give `len // patch_size + 1` FPS subsets, each from a random start point
+    (fpsample's bucket FPS = exact FPS; its random start restated as a draw from `generator`).
+    -> (xyz f32[P,k,3], idx i64[P,k], cuts i64[P])"""
+    xyz, idxs, cuts = [], [], []
+    for c in range(offsets.numel() - 1):
+        m = idx_flat[offsets[c]:offsets[c + 1]].long()
+        L = m.numel()
+        if L == 0:
+            continue
+        p = points[m]
+        if L < patch_size:
+            diff = patch_size - L
+            r = torch.randint(0, L, (diff,), generator=generator)
+            level = float((p.max(0).values - p.min(0).values).double().norm().item()) * 1e-2
+            extra = p[r] + level * torch.randn(diff, 3, generator=generator)
+            xyz.append(torch.cat([p, extra], 0))
+            idxs.append(torch.cat([m, m[r]]))
+            cuts.append(L)
+        else:
+            for _ in range(L // patch_size + 1):
+                start = int(torch.randint(0, L, (1,), generator=generator))
+                q = p.clone()
+                q[[0, start]] = q[[start, 0]]  # FPS from `start`: swap it to the front, map the indices back
+                f = furthest_point_sampling_forward(q.t().contiguous()[None], patch_size)[0].long()
+                f = torch.where(f == 0, torch.full_like(f, start), torch.where(f == start, torch.zeros_like(f), f))
+                xyz.append(p[f])
+                idxs.append(m[f])
+                cuts.append(patch_size)
+    return torch.stack(xyz), torch.stack(idxs), torch.tensor(cuts, dtype=torch.int64)
+
+
+def room_merge(points, preds, idxs, cuts):
+    """update_prediction_noisy_batches (denoise_room.py:263-289), literally: sequential running mean in float64"""
+    den = points.double().clone()
+    num = torch.zeros(points.shape[0], dtype=torch.float64)
+    for p in range(preds.shape[0]):
+        c = int(cuts[p])
+        ii, x = idxs[p, :c], preds[p, :c].double()
+        num[ii] += 1
+        first = (num[ii] == 1)[:, None]
+        den[ii] = torch.where(first, x, (den[ii] * (num[ii] - 1)[:, None] + x) / num[ii][:, None])
+    return den, num
+
+
+def denoise_room(sample_fn, points, patch_size, k, radius, generator):
+    """denoise_room.py:main (average_predictions) with `sample_fn(x_start [B,3,K]) -> x_pred [B,3,K]` for model.sample:
+    FPS centres -> radius patches -> per-patch centre / scale -> sampler -> running-mean merge"""
+    n = points.shape[0]
+    n_centres = int(-(-n // patch_size) * k)
+    cidx = furthest_point_sampling_forward(points.t().contiguous()[None], n_centres)[0].long()
+    idx_flat, offsets = radius_query(points[cidx].contiguous(), points, radius)
+    xyz, idxs, cuts = room_create_patches(points, idx_flat, offsets, patch_size, generator)
+    centre = xyz.mean(1, keepdim=True)
+    x = xyz - centre
+    scale = x.norm(dim=2, keepdim=True).max(dim=1, keepdim=True).values
+    pred = sample_fn((x / scale).transpose(1, 2).contiguous()).transpose(1, 2) * scale + centre
+    den, num = room_merge(points, pred, idxs, cuts)
+    den = den.float()
+    missed = (num == 0).nonzero()[:, 0]
+    if missed.numel() > 0:  # points no patch reached take the value of a random point (:548-553)
+        den[missed] = den[torch.randint(0, n, (missed.numel(),), generator=generator)]
+    return den, num, dict(centres=cidx, xyz=xyz, idxs=idxs, cuts=cuts, offsets=offsets, idx_flat=idx_flat)

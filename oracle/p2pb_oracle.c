@@ -801,3 +801,29 @@ ORC_API void orc_point_face(int which, int np, int nt, const float *pts, const f
     idx[i] = bi;
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Room pipeline: exact radius query standing for sklearn.neighbors.KDTree.query_radius
+ * (denoise_room.py:459-464). The KD-tree returns the SET { i : |p_i - c| <= r } in tree order; the contract
+ * restated here fixes the order (ascending index) and the arithmetic (fp32 squared distance in the build's
+ * fma sequence, compared with r*r) -- third-party code absent from /root/reference: parity unpinned.
+ * Two calls: out == NULL counts, else fills out[offsets[s] ...].
+ * ------------------------------------------------------------------------------------------ */
+ORC_API void orc_radius_query(int s, int n, const float *centers, const float *points, float radius, int *counts,
+                              const long long *offsets, int *out) {
+  const float r2 = radius * radius;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int c = 0; c < s; ++c) {
+    const float cx = centers[c * 3], cy = centers[c * 3 + 1], cz = centers[c * 3 + 2];
+    long long pos = out ? offsets[c] : 0;
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+      const float d = sqdist3(points[(size_t)i * 3] - cx, points[(size_t)i * 3 + 1] - cy, points[(size_t)i * 3 + 2] - cz);
+      if (d <= r2) {
+        if (out) out[pos + cnt] = i;
+        ++cnt;
+      }
+    }
+    if (counts) counts[c] = cnt;
+  }
+}

@@ -188,14 +188,15 @@ def devoxelize_affine(grid, vcoords, r, aff_a, aff_b, channels_last=False, add=N
     b, c = (grid.shape[0], grid.shape[4]) if channels_last else grid.shape[:2]
     n = vcoords.shape[2]
     out = torch.empty(b, c, n, dtype=F32, device=grid.device)
-    if channels_last:
+    aff_a, aff_b = aff_a.contiguous(), aff_b.contiguous()  # (named: temporaries inside the argument list could be freed
+    if channels_last:                                      #  and their blocks reused before the launch)
         h, hs, hb = add if add is not None else (None, None, None)
         call("p2pb_trilinear_devoxelize_cl_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
-             ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(h), ptr(hs), ptr(hb), ptr(out), stream_ptr())
+             ptr(aff_a), ptr(aff_b), ptr(h), ptr(hs), ptr(hb), ptr(out), stream_ptr())
     else:
         assert add is None
         call("p2pb_trilinear_devoxelize_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
-             ptr(aff_a.contiguous()), ptr(aff_b.contiguous()), ptr(out), stream_ptr())
+             ptr(aff_a), ptr(aff_b), ptr(out), stream_ptr())
     return out
 
 

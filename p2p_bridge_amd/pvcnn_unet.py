@@ -133,8 +133,9 @@ class _LinearAttentionCore(torch.autograd.Function):
         b, c3, n = qkv.shape
         heads = ctx.heads
         dq = torch.empty_like(qkv)
+        g = g.contiguous()
         call("p2pb_linear_attention_backward", ctypes.c_int(b), ctypes.c_int(heads), ctypes.c_int(c3 // (3 * heads)),
-             ctypes.c_int(n), ptr(qkv), ptr(ctxm), ptr(g.contiguous()), ptr(dq), stream_ptr())
+             ctypes.c_int(n), ptr(qkv), ptr(ctxm), ptr(g), ptr(dq), stream_ptr())
         return dq, None
 
 

@@ -1,0 +1,49 @@
+"""The oracle's room-pipeline restatement (oracle/cpu_ops.py, denoise_room.py:352-421,263-289) on CPU: the radius
+lists against a float64 brute force, the literal sequential running mean against the plain mean, patch construction
+invariants. (sklearn / fpsample / numpy-RNG are not under /root/reference: parity unpinned there, see DESIGN.md.)"""
+import torch
+
+from oracle import cpu_ops
+
+
+def test_radius_query_matches_bruteforce():
+    g = torch.Generator().manual_seed(0)
+    pts = torch.rand(3000, 3, generator=g) * 3
+    cen = pts[torch.randperm(3000, generator=g)[:11]].contiguous()
+    for r in (0.0, 0.25, 0.7, 9.0):
+        idx, off = cpu_ops.radius_query(cen, pts, r)
+        d2 = (pts.double()[None] - cen.double()[:, None]).pow(2).sum(-1)
+        for c in range(11):
+            got = idx[off[c]:off[c + 1]].long()
+            assert torch.equal(got, torch.sort(got).values)  # ascending
+            exp = (d2[c] <= r * r).nonzero()[:, 0]
+            # identical away from the boundary (fp32 vs fp64 may disagree within 1e-6 of r^2)
+            sure = ((d2[c] - r * r).abs() > 1e-6)
+            assert torch.equal(got[sure[got]], exp[sure[exp]])
+
+
+def test_running_mean_is_the_mean_and_patches_are_consistent():
+    g = torch.Generator().manual_seed(1)
+    pts = torch.rand(8000, 3, generator=g) * torch.tensor([4.0, 3.0, 0.2])
+    cidx = cpu_ops.furthest_point_sampling_forward(pts.t().contiguous()[None], 12)[0].long()
+    idx_flat, off = cpu_ops.radius_query(pts[cidx].contiguous(), pts, 0.5)
+    xyz, idx, cuts = cpu_ops.room_create_patches(pts, idx_flat, off, 256, torch.Generator().manual_seed(2))
+    assert xyz.shape[1:] == (256, 3) and idx.shape == xyz.shape[:2]
+    for p in range(xyz.shape[0]):
+        c = int(cuts[p])
+        assert torch.equal(xyz[p, :c], pts[idx[p, :c]])            # real points up to the cut
+        assert idx[p, :c].unique().numel() == c                     # no duplicates before the cut
+        if c < 256:                                                 # padded: jittered copies of the patch's own points
+            assert (xyz[p, c:] - pts[idx[p, c:]]).abs().max() < 0.2
+    pred = xyz + 0.01
+    den, num = cpu_ops.room_merge(pts, pred, idx, cuts)
+    sums = torch.zeros(8000, 3, dtype=torch.float64)
+    cnt = torch.zeros(8000, dtype=torch.float64)
+    for p in range(xyz.shape[0]):
+        c = int(cuts[p])
+        sums.index_add_(0, idx[p, :c], pred[p, :c].double())
+        cnt.index_add_(0, idx[p, :c], torch.ones(c, dtype=torch.float64))
+    assert torch.equal(cnt, num)
+    hit = cnt > 0
+    assert (den[hit] - sums[hit] / cnt[hit, None]).abs().max().item() < 1e-12
+    assert torch.equal(den[~hit], pts[~hit].double())
