@@ -14,7 +14,7 @@ Parity: the radius query's SET of points, the normalisation and the merge (a mea
 against the oracle. sklearn's list order (tree order), numpy's global RNG and fpsample's bucket FPS (its start point
 is random and comes from its own Rust RNG) are third-party behaviour with no definition in /root/reference: the contract
 restated here -- ascending index lists, every random draw from ONE caller-supplied torch CPU generator in a fixed order,
-exact FPS from a drawn start index -- is "parity unpinned" against the reference and pinned to oracle/cpu_ops.py.
+exact FPS from a drawn start index -- is "parity unpinned" against the reference and pinned to the test oracle's restatement of the same contract.
 """
 import ctypes
 from typing import Optional
