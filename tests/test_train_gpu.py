@@ -135,3 +135,37 @@ def test_ddp_world2_real_network(tmp_path):
     print(f"\nworld-2 DDP vs 1-rank gradients on the real network: worst per-tensor max-abs error {worst:.2e}, "
           f"global relative L2 error {(num / den) ** 0.5:.2e}")
     assert worst < 2e-3 and (num / den) ** 0.5 < 1e-4  # (fp32 atomic scatters make every backward run order-dependent)
+
+
+def test_punet_paired_patches_on_device(tmp_path):
+    """PairedPatchDataset / make_patches_for_pcl_pair (dataloaders/punet.py:321-421) with the clouds on the GPU: the
+    patches are the exact K nearest neighbours of the seed (checked against a brute-force sort), centred / scaled like the
+    reference, and feed the training runner's get_data_batch + alignment"""
+    from p2p_bridge_amd import punet_data as D
+    from p2p_bridge_amd import train as T
+
+    for r in ("10000_poisson", "30000_poisson", "50000_poisson"):
+        d = tmp_path / "PUNet" / "pointclouds" / "train" / r
+        d.mkdir(parents=True)
+        g = torch.Generator().manual_seed(len(r))
+        v = torch.randn(6000, 3, generator=g)
+        np.savetxt(d / "sphere.xyz", (v / v.norm(dim=1, keepdim=True)).numpy())
+    ds = D.get_dataset(str(tmp_path), "train", patch_size=1024, device="cuda")
+    items = [ds[i] for i in range(4)]
+    for it in items:
+        assert it["noisy_points"].shape == (1024, 3) and it["clean_points"].shape == (1024, 3) and it["noisy_points"].is_cuda
+        assert abs(it["noisy_points"].norm(dim=1).max().item() - 1.0) < 1e-5
+        assert it["clean_points"].mean(0).abs().max().item() < 1e-5
+    # exact K-NN: patch == the K closest points of the cloud to the seed (brute force)
+    cloud = torch.randn(5000, 3, generator=torch.Generator().manual_seed(0)).cuda()
+    torch.manual_seed(4)
+    pa, pb = D.make_patches_for_pcl_pair(cloud, cloud * 1.0, patch_size=256, num_patches=3, ratio=1.0)
+    torch.manual_seed(4)
+    seeds = cloud[torch.randperm(5000)[:3].cuda()]
+    d2 = (cloud[None] - seeds[:, None]).pow(2).sum(-1)
+    ref = cloud[d2.argsort(dim=1, stable=True)[:, :256]]
+    assert torch.equal(pa, ref) and torch.equal(pb, ref)
+    batch = {"clean_points": torch.stack([it["clean_points"] for it in items]),
+             "noisy_points": torch.stack([it["noisy_points"] for it in items])}
+    out = T.get_data_batch(batch, T.PVDS_PUNET_TRAIN, T.make_align_fn())
+    assert out["x_gt"].shape == (4, 3, 1024) and out["x_start"].shape == (4, 3, 1024)

@@ -84,5 +84,71 @@ def main():
                                                               "manifest_tiny_attn.json")})
 
 
+def punet_transforms():
+    """tests/golden/punet_transforms.npz: the reference's OWN dataloaders/punet.py transform classes (pytorch3d and
+    torchvision stubbed: neither is used by the transforms) run on a seeded cloud with seeded RNGs -> inputs, every output"""
+    import importlib
+    import random
+    import types
+
+    ref_import.install()
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.transforms = ts
+
+        def __call__(self, d):
+            for t in self.transforms:
+                d = t(d)
+            return d
+
+    tvt.Compose = Compose
+    tv.transforms = tvt
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvt)
+    p3 = types.ModuleType("pytorch3d")
+    p3.ops = types.ModuleType("pytorch3d.ops")
+    sys.modules.setdefault("pytorch3d", p3)
+    sys.modules.setdefault("pytorch3d.ops", p3.ops)
+    pn = importlib.import_module("dataloaders.punet")
+    g = torch.Generator().manual_seed(5)
+    pcl = torch.rand(3000, 3, generator=g) * torch.tensor([2.0, 1.0, 0.5]) + 3.0
+    out = {"pcl": pcl.numpy()}
+
+    def seed():
+        random.seed(11)
+        np.random.seed(12)
+        torch.manual_seed(13)
+
+    seed()
+    d = pn.standard_train_transforms(0.01, 0.02)({"pcl_clean": pcl.clone()})
+    out.update(std_clean=d["pcl_clean"].numpy(), std_noisy=d["pcl_noisy"].numpy(), std_center=d["center"].numpy(),
+               std_scale=d["scale"].numpy(), std_noise_std=np.array(d["noise_std"]))
+    seed()
+    d = pn.standard_train_transforms_clean()({"pcl_clean": pcl.clone()})
+    out.update(clean_only=d["pcl_clean"].numpy())
+    unit = pn.NormalizeUnitSphere.normalize(pcl.clone())[0]
+    for name, t in (("laplace", pn.AddLaplacianNoise(0.01, 0.02)), ("ball", pn.AddUniformBallNoise(0.02)),
+                    ("cov", pn.AddCovNoise([[1e-4, 0, 0], [0, 4e-4, 0], [0, 0, 1e-4]], 1.5)),
+                    ("discrete", pn.AddDiscreteNoise(0.01))):
+        seed()
+        out[name] = t({"pcl_clean": unit.clone()})["pcl_noisy"].numpy()
+    # per-patch normalisation at the end of PairedPatchDataset.__getitem__ (:403-421), restated on fixed patches
+    noisy, clean = unit[:512] + 0.01, unit[:512].clone()
+    center = clean.mean(dim=0)
+    n2, c2 = noisy - center, clean - center
+    scale = torch.max(torch.norm(n2, dim=1))
+    out.update(pair_noisy_in=noisy.numpy(), pair_clean_in=clean.numpy(), pair_noisy=(n2 / scale).numpy(),
+               pair_clean=(c2 / scale).numpy(), pair_center=center.numpy(), pair_scale=scale.numpy())
+    np.savez_compressed(os.path.join(OUT, "punet_transforms.npz"), **out)
+    print("punet_transforms.npz", os.path.getsize(os.path.join(OUT, "punet_transforms.npz")))
+
+
 if __name__ == "__main__":
-    main()
+    if "--punet" in sys.argv:
+        punet_transforms()
+    else:
+        main()
+        punet_transforms()
