@@ -145,52 +145,68 @@ def test_c2_t30_free_running_chamfer(out_scale):
 
 def test_c3_training_step_stock_width():
     """(e) BASELINE config 3's per-GPU step: stock PVDS (npoints 2048), 8 patches x 2048 points, MSE bridge loss,
-    dropout off on both sides (it is the only stochastic layer): loss and all per-parameter gradient norms of the HIP
-    training path (autograd over the HIP ops and the hand-written dense backward kernels) vs the oracle's autograd."""
+    dropout off on both sides (it is the only stochastic layer): loss and EVERY parameter's gradient tensor of the HIP
+    training path (autograd over the HIP ops, the hand-written dense forward / backward kernels and the folded norms)
+    vs the oracle's autograd.
+
+    Tolerance: the loss agrees to 1e-6. The gradients of the deep encoder stages (sa_layers.2 / 3: sums over 32..128
+    points with heavy cancellation) are ill-conditioned -- the ORACLE ITSELF moves by up to 6e-3 (relative L2) there
+    when only its thread count changes (oneDNN's conv1d blocking changes the forward by 2e-6), while well-conditioned
+    tensors move by 1e-6. So the floor is measured, not assumed: the oracle runs twice (all threads / one thread) and
+    every HIP gradient must be within max(1e-3, 4 x that tensor's own oracle-vs-oracle distance) of the oracle's."""
     _threads()
     cfg = copy.deepcopy(PVDS)
     cfg["model"]["dropout"] = 0.0
     model, sd = seeded_model(cfg)
     x1, x0 = net_ref.synthetic_patches(8, 2048, seed=11)
     steps = torch.tensor([3, 120, 250, 400, 555, 700, 850, 998])
-    # oracle (same arithmetic as tests/test_oracle_golden.py::test_training_loss_and_grads, which is pinned to the
-    # reference's own loss / gradients on the tiny config)
-    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    orc = net_ref.RefNet(cfg, {}, vox_mode="tree")
-    orc.sd = osd
-    orc.training = True
-    sch = net_ref.make_schedule(cfg["diffusion"])
-    e = lambda a: a[steps].view(-1, 1, 1)
-    xt = e(sch["mu_x0"]) * x0 + e(sch["mu_x1"]) * x1
-    gt = (xt - x0) / e(sch["std_fwd"])
-    ref_loss = ((orc(xt, sch["noise_levels"][steps]) - gt) ** 2).mean(dim=(1, 2)).mean()
-    ref_loss.backward()
-    # product
+
+    def oracle_grads(nthreads):
+        # (same arithmetic as tests/test_oracle_golden.py::test_training_loss_and_grads, which is pinned to the
+        # reference's own loss / gradients on the tiny config)
+        torch.set_num_threads(nthreads)
+        cpu_ops.set_threads(nthreads)
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        orc = net_ref.RefNet(cfg, {}, vox_mode="tree")
+        orc.sd = osd
+        orc.training = True
+        sch = net_ref.make_schedule(cfg["diffusion"])
+        e = lambda a: a[steps].view(-1, 1, 1)
+        xt = e(sch["mu_x0"]) * x0 + e(sch["mu_x1"]) * x1
+        gt = (xt - x0) / e(sch["std_fwd"])
+        loss = ((orc(xt, sch["noise_levels"][steps]) - gt) ** 2).mean(dim=(1, 2)).mean()
+        loss.backward()
+        return loss.item(), {k: v.grad for k, v in osd.items()}
+
+    ref_loss, ga = oracle_grads(min(os.cpu_count() or 1, 32))
+    _, gb = oracle_grads(1)
+    _threads()
     model.train()
-    _randint = torch.randint
-    torch.randint = lambda *a, **k: steps.clone()
-    try:
-        loss = model(x0.cuda(), x1.cuda())
-    finally:
-        torch.randint = _randint
+    loss = model(x0.cuda(), x1.cuda(), steps=steps)
     loss.backward()
-    rel = abs(loss.item() - ref_loss.item()) / abs(ref_loss.item())
+    rel = abs(loss.item() - ref_loss) / abs(ref_loss)
     params = dict(model.model.named_parameters())
-    worst, worst_k = 0.0, None
+    rl2 = lambda u, v: (u - v).norm().item() / max(v.norm().item(), 1e-12)
+    rows, num, den, fnum = [], 0.0, 0.0, 0.0
     for k, p in params.items():
-        gr = osd[k].grad
-        assert (p.grad is None) == (gr is None), k
-        if gr is None:
+        assert (p.grad is None) == (ga[k] is None), k
+        if ga[k] is None:
             continue
-        r = abs(p.grad.norm().item() - gr.norm().item()) / max(gr.norm().item(), 1e-3)
-        if r > worst:
-            worst, worst_k = r, k
-    g, gr = params["classifier.2.weight"].grad.cpu(), osd["classifier.2.weight"].grad
-    print(f"\nC3 step (8 x 2048, stock PVDS): loss {loss.item():.6f} vs {ref_loss.item():.6f} (rel {rel:.2e}); worst "
-          f"grad-norm rel err {worst:.2e} at {worst_k}; classifier.2.weight max|dg| = {(g - gr).abs().max().item():.2e}")
-    assert rel <= 1e-4
-    assert worst <= 3e-3, worst_k
-    assert (g - gr).abs().max().item() <= 1e-3 * max(1.0, gr.abs().max().item())
+        g = p.grad.cpu()
+        rows.append((rl2(g, ga[k]), rl2(gb[k], ga[k]), k))
+        num += (g - ga[k]).pow(2).sum().item()
+        fnum += (gb[k] - ga[k]).pow(2).sum().item()
+        den += ga[k].pow(2).sum().item()
+    rows.sort(reverse=True)
+    tight = sorted(r[0] for r in rows)[len(rows) // 2]
+    print(f"\nC3 step (8 x 2048, stock PVDS): loss {loss.item():.6f} vs {ref_loss:.6f} (rel {rel:.2e}); gradients, relative L2: "
+          f"all tensors together {(num / den) ** 0.5:.2e} (oracle vs itself at 1 thread: {(fnum / den) ** 0.5:.2e}), median "
+          f"tensor {tight:.2e}; worst: " + "; ".join(f"{k} {e:.1e} (oracle floor {f:.1e})" for e, f, k in rows[:3]))
+    assert rel <= 1e-5
+    bad = [(k, e, f) for e, f, k in rows if e > max(1e-3, 4 * f)]
+    assert not bad, bad[:5]
+    assert (num / den) ** 0.5 <= max(5e-4, 4 * (fnum / den) ** 0.5)
+    assert tight < 1e-4
 
 
 def pvdl(extra, npoints):
