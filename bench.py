@@ -41,47 +41,65 @@ SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6
 CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample per network evaluation (PVDS)
 
 
-def conv_roofline(model, B, reps=10):
-    """Second kernel = the 3x3x3 voxel convolution (csrc/conv3d.hip) in its dense split form, timed on the widest
-    instance (fp_layers.2.{1,2} second conv: C 128->128, r=16, folded AdaGN+Swish operand transform, GroupNorm
-    statistics epilogue; the sampler runs this layer through the voxel-level compact variant of the same kernel, whose
-    work depends on the occupancy, so the dense form is the one with a well-defined FLOP count) with HIP events on the
-    stream the kernel is launched on (torch's current stream).
-    `achieved` counts ALGORITHMIC fp32 FLOPs (2*27*Cin*Cout per voxel). Default arithmetic: bf16x6 split
-    operands on the bf16 matrix pipe (six MFMA products per fp32 product), so `peak` is the dense bf16 MFMA
-    peak / 6; with P2PB_CONV_MATH=fp32 it is the exact-fp32 MFMA kernel against the fp32 MFMA peak."""
+def conv_roofline(model, x_start, reps=10):
+    """Second kernel = the 3x3x3 voxel convolution AS THE SAMPLER RUNS IT: conv3d_k3_compact_kernel on the widest
+    r = 16 instance (fp_layers.2.1, second convolution, C 128 -> 128: far-field form, folded AdaGN + Swish operand
+    transform, GroupNorm statistics epilogue). The kernel computes only the outputs within two voxels of an occupied
+    voxel (set D2, csrc/conv3d.hip) and writes analytic constants elsewhere, so its work depends on the occupancy of the
+    input: the launch is captured from ONE real network evaluation of the bench's own patches (same tensors, same
+    lists), then re-issued `reps` times between HIP events on the stream it is launched on.
+    `achieved` counts the ALGORITHMIC FLOPs of what the layer must produce with this formulation: 2*27*Cin*Cout per LISTED
+    output voxel (the exact-constant voxels cost no matrix work by construction); `dense_equivalent` is the same
+    launch priced as the dense convolution the reference runs (all 16^3 voxels)."""
     from p2p_bridge_amd import fused
 
     pv = model.model.fp_layers[2][1]
-    conv = pv.voxel_layers[4]
-    C, r = conv.in_channels, pv.resolution
-    x = torch.randn(B, r, r, r, C, device="cuda")  # voxel-major grids, as in PVConv._voxel_branch_fused
-    sc, sh = torch.rand(B, C, device="cuda") + 0.5, torch.randn(B, C, device="cuda")
-    flops = 2.0 * B * r ** 3 * 27 * conv.in_channels * conv.out_channels  # algorithmic FLOPs of one launch
+    target = pv.voxel_layers[4]
+    captured = {}
+    orig = fused.conv3d_k3_compact
+
+    def spy(x, conv, lists, counts, which, *a, **k):
+        if conv is target and "args" not in captured:
+            captured["args"] = (x, conv, lists, counts, which) + a
+            captured["kw"] = k
+        return orig(x, conv, lists, counts, which, *a, **k)
+
+    fused.conv3d_k3_compact = spy
+    try:
+        model.eval()
+        with torch.no_grad():
+            model.model(x_start, torch.full((x_start.shape[0],), 500.0, device=x_start.device))
+        model.train()
+    finally:
+        fused.conv3d_k3_compact = orig
+    if "args" not in captured:
+        return None
+    args, kw = captured["args"], captured["kw"]
+    x, conv, lists, counts, which = args[:5]
+    B, r, C = x.shape[0], x.shape[1], x.shape[4]
+    listed = int(counts[which].sum().item())
+    flops = 2.0 * 27 * conv.in_channels * conv.out_channels * listed
+    dense = 2.0 * 27 * conv.in_channels * conv.out_channels * B * r ** 3
     with torch.no_grad():
         for _ in range(3):
-            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True, channels_last=True)
+            orig(*args, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fused.conv3d_k3(x, conv, sc, sh, swish=True, compact=True, channels_last=True)
+            orig(*args, **kw)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
-    split = fused.conv_math() == "bf16x6"
-    peak = SPLIT_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
-    kname = "conv3d_k3_split_kernel" if split else "conv3d_k3_kernel"
-    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": pmc_traffic(split),
-            "traffic_basis": "profiles/r01_pmc_*.csv: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch; algorithmic "
-                             f"input + output = {4 * B * r ** 3 * (conv.in_channels + conv.out_channels)} B, the 6x10x10 "
-                             "halo of a 4x8x8 brick re-reads the input 2.34x, about half of it absorbed by the per-XCD L2 (XCD-aware order)",
-            "kernel": f"{kname}<{r},compact,2,XF,voxel-major> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
-                      f"(fp_layers.2.1.voxel_layers.4)",
-            "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
-                           "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(SPLIT_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / SPLIT_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": f"conv3d_k3_compact_kernel<{r},XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
+                      f"(fp_layers.2.1.voxel_layers.4, the launch the sampler issues)",
+            "listed_output_voxels": listed, "grid_voxels": B * r ** 3,
+            "listed_fraction": round(listed / float(B * r ** 3), 4),
+            "dense_equivalent_tflops": round(dense / (ms * 1e-3) / 1e12, 2),
+            "peak_basis": "dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 accumulate)",
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 
@@ -117,7 +135,10 @@ def gemm_roofline(model, B, P, reps=10):
     traffic = None
     try:
         vals = {}
-        for line in open(os.path.join(ROOT, "profiles", "r01_pmc_pw_split_512_1024_pool.csv")):
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_pw_split_512_1024_pool.csv")
+        if not os.path.exists(pmc):
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_pw_split_512_1024_pool.csv")
+        for line in open(pmc):
             k, v = line.split(",")[:2]
             if k in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[k] = float(v)
@@ -126,31 +147,14 @@ def gemm_roofline(model, B, P, reps=10):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_basis": "profiles/r01_pmc_pw_split_512_1024_pool.csv: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch "
+            "traffic_basis": "profiles/r0N_pmc_pw_split_512_1024_pool.csv (latest round): (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch "
                              "(FETCH_SIZE counts half of 8- and 16-byte-per-lane streaming reads on gfx950: calibrated on a "
                              f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 6 * ci * co} B: "
                              "the activations are staged by 8 output-channel blocks, the per-XCD L2 absorbs 3/4 of that",
-            "kernel": f"pw_split_kernel<XF=true,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)",
+            "kernel": f"pw_split_kernel<XF=true,POOL=true,WM=4> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)",
             "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
                            "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
-
-
-def pmc_traffic(split):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 --pmc passes (separate FETCH_SIZE /
-    WRITE_SIZE passes, tools/pmc_run.sh): counters are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md
-    prescribes for 16-byte-per-lane streaming reads on gfx950 (the voxel-major staging loads), WRITE_SIZE as is.
-    None when the summary file is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_conv3d_split_r16_c128.csv" if split else "r01_pmc_conv3d_k3_r16_c128.csv")
-    try:
-        vals = {}
-        for line in open(path):
-            k, v = line.split(",")[:2]
-            if k in ("FETCH_SIZE", "WRITE_SIZE"):
-                vals[k] = float(v)
-        return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
-    except (OSError, KeyError, ValueError):
-        return None
 
 
 def conv_math_note():
@@ -274,7 +278,7 @@ def main():
     res["config"]["conv_math"] = conv_math_note()
     if rank == 0:
         res["roofline"] = gemm_roofline(model, args.batch, args.points)
-        res["roofline"]["second_kernel"] = conv_roofline(model, args.batch)  # the voxel convolution, same protocol
+        res["roofline"]["second_kernel"] = conv_roofline(model, x_start)  # the voxel convolution the sampler runs
         evals = args.T
         res["roofline"]["sampler_dense_tflops"] = round(
             61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval

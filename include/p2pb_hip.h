@@ -149,13 +149,21 @@ int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *
  * backward ACCUMULATES into gradxyz1/2 (caller zero-fills, metrics/chamfer3D/dist_chamfer_3D.py:77-83). */
 int p2pb_chamfer_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2,
                          int *idx1, int *idx2, void *stream);
+/* the same with scratch (p2pb_chamfer_ws_bytes(b, n, m) bytes): small batches split the target cloud over more
+ * workgroups and combine through 64-bit atomicMin keys (distance bits, index) -- identical results */
+size_t p2pb_chamfer_ws_bytes(int b, int n, int m);
+int p2pb_chamfer_forward_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist1, float *dist2,
+                            int *idx1, int *idx2, void *ws, void *stream);
 int p2pb_chamfer_backward(int b, int n, int m, const float *xyz1, const float *xyz2, float *gradxyz1,
                           float *gradxyz2, const float *graddist1, const float *graddist2, const int *idx1,
                           const int *idx2, void *stream);
 
 /* PyTorchEMD: replaces ApproxMatchForward / MatchCostForward / MatchCostBackward
  * (metrics/PyTorchEMD/cuda/emd_kernel.cu:177,264,377; kernels :33,:211,:300,:347).
- *   xyz1 f32[b,n,3], xyz2 f32[b,m,3] -> match f32[b,m,n]; temp f32[b,2(n+m)] scratch */
+ *   xyz1 f32[b,n,3], xyz2 f32[b,m,3] -> match f32[b,m,n]; temp = p2pb_approxmatch_temp_floats(b,n,m) floats of scratch:
+ *   the reference's 2(n+m) per cloud (emd_kernel.cu:34) plus the partial sums of the chunked launches used when the
+ *   batch alone cannot fill the chip */
+size_t p2pb_approxmatch_temp_floats(int b, int n, int m);
 int p2pb_approxmatch_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
                              float *temp, void *stream);
 int p2pb_matchcost_forward(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,

@@ -9,21 +9,30 @@
 
 #define EMD_TILE 1024
 
+// Small batches (evaluation runs one 10k..50k-point cloud at a time) leave a (points / 256) x batch grid far below the
+// chip's 256 CUs -- B = 4, N = 8192 is 128 workgroups -- so the inner loop over the OTHER cloud is split over
+// blockIdx.y into `chunks` ranges: the PART forms write one partial sum per (chunk, point) and a tiny *_fin kernel adds
+// the partials in ascending chunk order (fixed order: deterministic; the sum is chunk-sequential instead of fully
+// sequential, a few ulps, far inside approxmatch's __expf tolerance). chunks == 1 keeps the single-pass kernels.
+
 // suml_k = 1e-9 + sum_l exp(level*d_kl) * remainR_l ; ratioL_k = remainL_k / suml_k      (:58-88)
-__global__ __launch_bounds__(256) void am_ratio_l_kernel(int n, int m, float level, const float *__restrict__ xyz1,
+template <bool PART>
+__global__ __launch_bounds__(256) void am_ratio_l_kernel(int n, int m, int lchunk, float level,
+                                                         const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2,
                                                          const float *__restrict__ remainL,
                                                          const float *__restrict__ remainR,
-                                                         float *__restrict__ ratioL) {
+                                                         float *__restrict__ ratioL, float *__restrict__ part) {
   __shared__ float buf[EMD_TILE * 4];
-  const int b = blockIdx.y;
+  const int b = PART ? blockIdx.z : blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   const bool ok = k < n;
   const float *p = xyz1 + ((size_t)b * n + (ok ? k : 0)) * 3;
   const float x1 = p[0], y1 = p[1], z1 = p[2];
-  float suml = 1e-9f;
-  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
-    const int ln = min(EMD_TILE, m - l0);
+  float suml = PART ? 0.0f : 1e-9f;
+  const int lo = PART ? blockIdx.y * lchunk : 0, hi = PART ? min(m, lo + lchunk) : m;
+  for (int l0 = lo; l0 < hi; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, hi - l0);
     __syncthreads();
     for (int l = threadIdx.x; l < ln; l += 256) {
       const float *q = xyz2 + ((size_t)b * m + l0 + l) * 3;
@@ -38,23 +47,47 @@ __global__ __launch_bounds__(256) void am_ratio_l_kernel(int n, int m, float lev
       suml += __expf(d) * buf[l * 4 + 3];
     }
   }
-  if (ok) ratioL[(size_t)b * n + k] = __fdiv_rn(remainL[(size_t)b * n + k], suml);
+  if (!ok) return;
+  if (PART) part[((size_t)blockIdx.y * gridDim.z + b) * n + k] = suml;
+  else ratioL[(size_t)b * n + k] = __fdiv_rn(remainL[(size_t)b * n + k], suml);
+}
+
+__global__ __launch_bounds__(256) void am_ratio_l_fin_kernel(int n, int chunks, const float *__restrict__ part,
+                                                             const float *__restrict__ remainL,
+                                                             float *__restrict__ ratioL) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  float suml = 1e-9f;
+  for (int c = 0; c < chunks; ++c) suml += part[((size_t)c * gridDim.y + b) * n + k];
+  ratioL[(size_t)b * n + k] = __fdiv_rn(remainL[(size_t)b * n + k], suml);
 }
 
 // sumr_l = remainR_l * sum_k exp(level*d_kl)*ratioL_k ; consumption ; ratioR ; remainR update   (:90-122)
-__global__ __launch_bounds__(256) void am_ratio_r_kernel(int n, int m, float level, const float *__restrict__ xyz1,
+__device__ __forceinline__ void am_ratio_r_finish(float sumr, size_t i, float *__restrict__ remainR,
+                                                  float *__restrict__ ratioR) {
+  const float rr = remainR[i];
+  sumr *= rr;
+  const float consumption = fminf(__fdiv_rn(rr, sumr + 1e-9f), 1.0f);
+  ratioR[i] = consumption * rr;
+  remainR[i] = fmaxf(0.0f, rr - sumr);
+}
+
+template <bool PART>
+__global__ __launch_bounds__(256) void am_ratio_r_kernel(int n, int m, int kchunk, float level,
+                                                         const float *__restrict__ xyz1,
                                                          const float *__restrict__ xyz2,
                                                          const float *__restrict__ ratioL, float *__restrict__ remainR,
-                                                         float *__restrict__ ratioR) {
+                                                         float *__restrict__ ratioR, float *__restrict__ part) {
   __shared__ float buf[EMD_TILE * 4];
-  const int b = blockIdx.y;
+  const int b = PART ? blockIdx.z : blockIdx.y;
   const int l = blockIdx.x * 256 + threadIdx.x;
   const bool ok = l < m;
   const float *q = xyz2 + ((size_t)b * m + (ok ? l : 0)) * 3;
   const float x2 = q[0], y2 = q[1], z2 = q[2];
   float sumr = 0;
-  for (int k0 = 0; k0 < n; k0 += EMD_TILE) {
-    const int kn = min(EMD_TILE, n - k0);
+  const int lo = PART ? blockIdx.y * kchunk : 0, hi = PART ? min(n, lo + kchunk) : n;
+  for (int k0 = lo; k0 < hi; k0 += EMD_TILE) {
+    const int kn = min(EMD_TILE, hi - k0);
     __syncthreads();
     for (int k = threadIdx.x; k < kn; k += 256) {
       const float *p = xyz1 + ((size_t)b * n + k0 + k) * 3;
@@ -69,23 +102,30 @@ __global__ __launch_bounds__(256) void am_ratio_r_kernel(int n, int m, float lev
       sumr += w;
     }
   }
-  if (ok) {
-    const float rr = remainR[(size_t)b * m + l];
-    sumr *= rr;
-    const float consumption = fminf(__fdiv_rn(rr, sumr + 1e-9f), 1.0f);
-    ratioR[(size_t)b * m + l] = consumption * rr;
-    remainR[(size_t)b * m + l] = fmaxf(0.0f, rr - sumr);
-  }
+  if (!ok) return;
+  if (PART) part[((size_t)blockIdx.y * gridDim.z + b) * m + l] = sumr;
+  else am_ratio_r_finish(sumr, (size_t)b * m + l, remainR, ratioR);
+}
+
+__global__ __launch_bounds__(256) void am_ratio_r_fin_kernel(int m, int chunks, const float *__restrict__ part,
+                                                             float *__restrict__ remainR, float *__restrict__ ratioR) {
+  const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= m) return;
+  float sumr = 0.0f;
+  for (int c = 0; c < chunks; ++c) sumr += part[((size_t)c * gridDim.y + b) * m + l];
+  am_ratio_r_finish(sumr, (size_t)b * m + l, remainR, ratioR);
 }
 
 // match[l,k] += exp(level*d)*ratioL_k*ratioR_l ; remainL_k -= sum_l (...)                          (:124-160)
-__global__ __launch_bounds__(256) void am_match_kernel(int n, int m, float level, const float *__restrict__ xyz1,
+template <bool PART>
+__global__ __launch_bounds__(256) void am_match_kernel(int n, int m, int lchunk, float level,
+                                                       const float *__restrict__ xyz1,
                                                        const float *__restrict__ xyz2,
                                                        const float *__restrict__ ratioL,
                                                        const float *__restrict__ ratioR, float *__restrict__ remainL,
-                                                       float *__restrict__ match) {
+                                                       float *__restrict__ match, float *__restrict__ part) {
   __shared__ float buf[EMD_TILE * 4];
-  const int b = blockIdx.y;
+  const int b = PART ? blockIdx.z : blockIdx.y;
   const int k = blockIdx.x * 256 + threadIdx.x;
   const bool ok = k < n;
   const float *p = xyz1 + ((size_t)b * n + (ok ? k : 0)) * 3;
@@ -93,8 +133,9 @@ __global__ __launch_bounds__(256) void am_match_kernel(int n, int m, float level
   const float rl = ok ? ratioL[(size_t)b * n + k] : 0.0f;
   float *mt = match + (size_t)b * n * m;
   float suml = 0;
-  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
-    const int ln = min(EMD_TILE, m - l0);
+  const int lo = PART ? blockIdx.y * lchunk : 0, hi = PART ? min(m, lo + lchunk) : m;
+  for (int l0 = lo; l0 < hi; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, hi - l0);
     __syncthreads();
     for (int l = threadIdx.x; l < ln; l += 256) {
       const float *q = xyz2 + ((size_t)b * m + l0 + l) * 3;
@@ -113,7 +154,18 @@ __global__ __launch_bounds__(256) void am_match_kernel(int n, int m, float level
       }
     }
   }
-  if (ok) remainL[(size_t)b * n + k] = fmaxf(0.0f, remainL[(size_t)b * n + k] - suml);
+  if (!ok) return;
+  if (PART) part[((size_t)blockIdx.y * gridDim.z + b) * n + k] = suml;
+  else remainL[(size_t)b * n + k] = fmaxf(0.0f, remainL[(size_t)b * n + k] - suml);
+}
+
+__global__ __launch_bounds__(256) void am_match_fin_kernel(int n, int chunks, const float *__restrict__ part,
+                                                           float *__restrict__ remainL) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  float suml = 0.0f;
+  for (int c = 0; c < chunks; ++c) suml += part[((size_t)c * gridDim.y + b) * n + k];
+  remainL[(size_t)b * n + k] = fmaxf(0.0f, remainL[(size_t)b * n + k] - suml);
 }
 
 __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float *__restrict__ remainL,
@@ -124,6 +176,21 @@ __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float *
   if (i < m) remainR[(size_t)b * m + i] = multiR;
 }
 
+// chunks of the inner cloud per launch: enough workgroups for ~4 per CU, chunks of whole LDS tiles
+static int am_chunks(int b, int n, int m) {
+  const long base = (long)cdiv(n < m ? n : m, 256) * b;
+  const int inner = n > m ? n : m;
+  int c = 1;
+  while (base * c < 1024 && inner / (c * 2) >= EMD_TILE) c *= 2;
+  return c;
+}
+
+extern "C" size_t p2pb_approxmatch_temp_floats(int b, int n, int m) {
+  const int c = am_chunks(b, n, m);
+  return (size_t)b * (n + m) * 2 + (c > 1 ? (size_t)c * b * (n > m ? n : m) : 0);
+}
+
+// temp: p2pb_approxmatch_temp_floats(b, n, m) floats (the reference's 2(n+m) per cloud + the chunk partials)
 extern "C" int p2pb_approxmatch_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
                                         float *temp, void *stream) {
   if (b <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
@@ -132,20 +199,35 @@ extern "C" int p2pb_approxmatch_forward(int b, int n, int m, const float *xyz1, 
   if (e != 0) return e;
   const float multiL = n >= m ? 1.0f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.0f;
   // temp holds the same four work arrays as the reference (emd_kernel.cu:34), laid out array-major:
-  //   temp = remainL[b][n] | remainR[b][m] | ratioL[b][n] | ratioR[b][m]      (2(n+m) floats per cloud)
+  //   temp = remainL[b][n] | remainR[b][m] | ratioL[b][n] | ratioR[b][m] | partials[chunks][b][max(n,m)]
   float *remainL = temp, *remainR = remainL + (size_t)b * n, *ratioL = remainR + (size_t)b * m,
-        *ratioR = ratioL + (size_t)b * n;
+        *ratioR = ratioL + (size_t)b * n, *part = ratioR + (size_t)b * m;
+  const int chunks = am_chunks(b, n, m);
+  const int lch = (cdiv(m, chunks) + EMD_TILE - 1) / EMD_TILE * EMD_TILE, kch = (cdiv(n, chunks) + EMD_TILE - 1) / EMD_TILE * EMD_TILE;
+  const int lc = cdiv(m, lch), kc = cdiv(n, kch);
   hipLaunchKernelGGL(am_init_kernel, dim3(cdiv(n > m ? n : m, 256), b), dim3(256), 0, s, n, m, multiL, multiR,
                      remainL, remainR);
   for (int j = 7; j >= -2; --j) {
     float level = -powf(4.0f, (float)j);
     if (j == -2) level = 0;
-    hipLaunchKernelGGL(am_ratio_l_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, level, xyz1, xyz2, remainL,
-                       remainR, ratioL);
-    hipLaunchKernelGGL(am_ratio_r_kernel, dim3(cdiv(m, 256), b), dim3(256), 0, s, n, m, level, xyz1, xyz2, ratioL,
-                       remainR, ratioR);
-    hipLaunchKernelGGL(am_match_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, level, xyz1, xyz2, ratioL, ratioR,
-                       remainL, match);
+    if (chunks == 1) {
+      hipLaunchKernelGGL(am_ratio_l_kernel<false>, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, m, level, xyz1, xyz2,
+                         remainL, remainR, ratioL, (float *)nullptr);
+      hipLaunchKernelGGL(am_ratio_r_kernel<false>, dim3(cdiv(m, 256), b), dim3(256), 0, s, n, m, n, level, xyz1, xyz2,
+                         ratioL, remainR, ratioR, (float *)nullptr);
+      hipLaunchKernelGGL(am_match_kernel<false>, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, m, level, xyz1, xyz2,
+                         ratioL, ratioR, remainL, match, (float *)nullptr);
+    } else {
+      hipLaunchKernelGGL(am_ratio_l_kernel<true>, dim3(cdiv(n, 256), lc, b), dim3(256), 0, s, n, m, lch, level, xyz1,
+                         xyz2, remainL, remainR, ratioL, part);
+      hipLaunchKernelGGL(am_ratio_l_fin_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, lc, part, remainL, ratioL);
+      hipLaunchKernelGGL(am_ratio_r_kernel<true>, dim3(cdiv(m, 256), kc, b), dim3(256), 0, s, n, m, kch, level, xyz1,
+                         xyz2, ratioL, remainR, ratioR, part);
+      hipLaunchKernelGGL(am_ratio_r_fin_kernel, dim3(cdiv(m, 256), b), dim3(256), 0, s, m, kc, part, remainR, ratioR);
+      hipLaunchKernelGGL(am_match_kernel<true>, dim3(cdiv(n, 256), lc, b), dim3(256), 0, s, n, m, lch, level, xyz1, xyz2,
+                         ratioL, ratioR, remainL, match, part);
+      hipLaunchKernelGGL(am_match_fin_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, lc, part, remainL);
+    }
   }
   return p2pb_launch_status();
 }

@@ -566,7 +566,10 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // positions -- the 128 x 128 tiling moves 10.7 GB through L2 for the 512 -> 1024 x 262144 GEMM (6.4 GB of it the
 // pre-split weights, re-read by 2048 position blocks), 256 x 256 moves 5.3 GB.
 template <bool XF, bool POOL, int WM, int NB>
-__global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : 4)) void pw_split_kernel(int cin, int cout, int P, int nslots,
+#ifndef PWS_WM4_WAVES
+#define PWS_WM4_WAVES 4
+#endif
+__global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVES)) void pw_split_kernel(int cin, int cout, int P, int nslots,
                                                        const float *__restrict__ in, const u32x4 *__restrict__ wp,
                                                        const float *__restrict__ bias,
                                                        const float *__restrict__ bias_b,
@@ -618,7 +621,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : 4)) void pw_
     const int pl = ONE ? pblk + 64 * bsel + lane : pblk + 128 * (WM == 2 ? q : bsel) + 2 * lane;
     voff[q] = (unsigned)(pl < P ? pl : P - (ONE ? 1 : 2)) * 4u;  // clamped lanes stage garbage that is never stored
   }
-  f32x2 braw[NBW][8];
+  float braw[NBW][8][ONE ? 1 : 2];  // (plain floats: an f32x2 with a dead half cost the 256-channel form 37 spilled VGPRs)
   auto load_b = [&](int ci0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -626,8 +629,13 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : 4)) void pw_
       auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, P * 4, 0x00020000);
 #pragma unroll
       for (int q = 0; q < NBW; ++q) {
-        if (!ONE) braw[q][i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q], 0, 0));
-        else braw[q][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[q], 0, 0));
+        if constexpr (!ONE) {
+          const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff[q], 0, 0));
+          braw[q][i][0] = v[0];
+          braw[q][i][1] = v[1];
+        } else {
+          braw[q][i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[q], 0, 0));
+        }
       }
     }
   };

@@ -24,8 +24,9 @@ def _chamfer_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
     check(idx1, I32, "idx1"), check(idx2, I32, "idx2")
     b, n, _ = xyz1.shape
     m = xyz2.shape[1]
-    rc = lib().p2pb_chamfer_forward(_i(b), _i(n), _i(m), ptr(xyz1), ptr(xyz2), ptr(dist1), ptr(dist2), ptr(idx1),
-                                    ptr(idx2), stream_ptr())
+    ws = torch.empty(int(lib().p2pb_chamfer_ws_bytes(_i(b), _i(n), _i(m))), dtype=torch.uint8, device=xyz1.device)
+    rc = lib().p2pb_chamfer_forward_ws(_i(b), _i(n), _i(m), ptr(xyz1), ptr(xyz2), ptr(dist1), ptr(dist2), ptr(idx1),
+                                       ptr(idx2), ptr(ws), stream_ptr())
     return 1 if rc == 0 else 0
 
 
@@ -52,7 +53,7 @@ def _approxmatch_forward(xyz1, xyz2):
     if xyz2.shape[0] != b or d != 3 or xyz2.shape[2] != 3:
         raise RuntimeError("Check failed: shapes")  # CHECK_EQ in emd_kernel.cu:184-186
     match = torch.empty(b, m, n, dtype=F32, device=xyz1.device)
-    temp = torch.empty(b, (n + m) * 2, dtype=F32, device=xyz1.device)
+    temp = torch.empty(int(lib().p2pb_approxmatch_temp_floats(_i(b), _i(n), _i(m))), dtype=F32, device=xyz1.device)
     call("p2pb_approxmatch_forward", _i(b), _i(n), _i(m), ptr(xyz1), ptr(xyz2), ptr(match), ptr(temp), stream_ptr())
     return match
 

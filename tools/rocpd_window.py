@@ -1,19 +1,22 @@
-"""Per-network-evaluation kernel breakdown of the TIMED sample in a rocprofv3 rocpd DB of bench.py
-(window = from the 31st to the 60th level-0 FPS launch, i.e. the second sample's 30 evaluations)."""
+"""Per-network-evaluation kernel breakdown of the TIMED sample in a rocprofv3 rocpd DB of `bench.py --steps 1
+--warmup 1`: the level-0 FPS launches mark the evaluations -- 33 for the warm-up sample (3 eager steps around the graph
+capture + 30 replays), 30 for the timed sample, then `tail` more from bench.py's roofline section (conv_roofline runs one
+eager evaluation to capture the launch it times). Window = the 30 launches before the tail."""
 import sqlite3
 import sys
 
 
-def main(path, out=None, top=45):
+def main(path, out=None, top=45, tail=1, T=30):
     cur = sqlite3.connect(path).cursor()
     fps = [r for r in cur.execute("select start,end from kernels where name like '%fps_kernel<512, 16%' order by start")]
-    n = len(fps) // 2
+    tail = int(tail)
+    n = len(fps) - tail - T
     t0 = fps[n][0]
-    t1 = fps[-1][0] + (fps[-1][0] - fps[-2][0])
+    t1 = fps[n + T][0] if n + T < len(fps) else fps[-1][0] + (fps[-1][0] - fps[-2][0])
     rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels "
                             "where start>=? and start<? group by name order by 3 desc", (t0, t1)))
     tot = sum(r[2] for r in rows)
-    ev = len(fps) - n
+    ev = T
     lines = [f"# window {(t1 - t0) / 1e6:.1f} ms = {ev} network evaluations, {(t1 - t0) / 1e6 / ev:.2f} ms/eval wall, "
              f"{tot / ev:.2f} ms/eval kernel time", "pct,calls_per_eval,avg_us,ms_per_eval,kernel"]
     for r in rows[:top]:
