@@ -12,7 +12,7 @@ def main(path, out=None, top=45, tail=1, T=30):
     tail = int(tail)
     n = len(fps) - tail - T
     t0 = fps[n][0]
-    t1 = fps[n + T][0] if n + T < len(fps) else fps[-1][0] + (fps[-1][0] - fps[-2][0])
+    t1 = fps[n + T - 1][0] + (fps[n + T - 1][0] - fps[n + T - 2][0])  # (the roofline launches follow the last evaluation)
     rows = list(cur.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels "
                             "where start>=? and start<? group by name order by 3 desc", (t0, t1)))
     tot = sum(r[2] for r in rows)
