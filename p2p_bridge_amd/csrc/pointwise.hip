@@ -443,7 +443,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
   for (int pb = 0; pb < NB; ++pb) {  // the wave's NB blocks of 64 positions (even / odd tiles 2 pb, 2 pb + 1)
   const int p = pblk + 128 * pb + 2 * (wn * 32 + l31);
   const bool pok = p < P;
-  if (out_pm) {  // point-major output f32[b, P, cout]; no statistics in this form
+  if (WM == 2 && out_pm) {  // point-major output f32[b, P, cout]; no statistics in this form (128-channel form only)
     float *ob = out + (size_t)b * P * cout;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -808,7 +808,8 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
-  const bool wm4 = wm_env ? wm_env == 4 : (cout >= 512 && (long)((P + 127) / 128) * ((cout + 255) / 256) * b >= 1024);
+  const bool wm4 = !out_pm && (wm_env ? wm_env == 4
+                                       : (cout >= 512 && (long)((P + 127) / 128) * ((cout + 255) / 256) * b >= 1024));
   // (NB = 2, 256 positions per workgroup, halves the weight traffic through L2 -- 10.7 -> 5.3 GB for the 512 -> 1024
   // launch -- but costs a wave per SIMD: measured 4 % / 7 % SLOWER with 256 / 128 channels; only NB = 1 is instantiated)
   dim3 grid((P + 127) / 128, wm4 ? (cout + 255) / 256 : (cout + 127) / 128, b);

@@ -321,6 +321,10 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
   return p2pb_launch_status();
 }
 
+__global__ void fps_set_flags_kernel(int b, int *__restrict__ flags) {
+  for (int i = threadIdx.x; i < b; i += 64) flags[i] = 1;
+}
+
 // ws = [b][2][FPS_G] tagged words | [b] error flags (+ pad) | [b][n] fallback distances
 static size_t fps_coop_head_bytes(int b) { return ((size_t)b * 2 * FPS_G * sizeof(u64) + (size_t)b * sizeof(int) + 15) & ~(size_t)15; }
 extern "C" size_t p2pb_fps_coop_ws_bytes(int b, int n) {
@@ -356,6 +360,10 @@ extern "C" int p2pb_furthest_point_sampling_coop(int b, int n, int m, const floa
   u64 *keys = (u64 *)ws;
   int *err = (int *)(keys + (size_t)b * 2 * FPS_G);
   float *dist = (float *)((char *)ws + head);
+  // test hook: raise every cloud's flag up front, so the on-device fallback recomputes everything (tests/ check that
+  // the indices are the same and that the flags report it)
+  static const bool force_fallback = getenv("P2PB_FPS_COOP_TEST_FALLBACK") != nullptr;
+  if (force_fallback) hipLaunchKernelGGL(fps_set_flags_kernel, dim3(1), dim3(64), 0, s, b, err);
   for (int b0 = 0; b0 < b; b0 += per_launch) {
     const int nb = b - b0 < per_launch ? b - b0 : per_launch;
     dim3 grid(FPS_G, nb);

@@ -223,3 +223,30 @@ def test_install_dropin_reference_names():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_fps_coop_flag_and_device_fallback():
+    """large-cloud FPS (cooperative 64-workgroup kernel): any batch size in one call (six clouds = two launches of four /
+    two), same indices as the oracle; with every cloud's "lost a peer" flag raised up front (test hook) the
+    single-workgroup kernel recomputes all of them ON THE DEVICE -- identical indices, and the flags report it"""
+    import subprocess
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, ".")
+from oracle import cpu_ops, net_ref
+from p2p_bridge_amd import pointnet2_batch_cuda as ext
+x, _ = net_ref.synthetic_patches(6, 20000, seed=9)
+ref = cpu_ops.furthest_point_sampling_forward(x, 700)
+got = ext.furthest_point_sampling_forward(x.cuda(), 700)
+assert torch.equal(got.cpu(), ref)
+print("FALLBACKS", ext.fps_coop_fallbacks())
+'''
+    env = dict(os.environ)
+    env.pop("P2PB_FPS_COOP_TEST_FALLBACK", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=240)
+    assert r.returncode == 0 and "FALLBACKS 0" in r.stdout, r.stderr[-2000:]
+    env["P2PB_FPS_COOP_TEST_FALLBACK"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=240)
+    assert r.returncode == 0 and "FALLBACKS 6" in r.stdout, r.stderr[-2000:]
