@@ -6,6 +6,7 @@
 // points (phases are separated by the stream order), which keeps every per-thread summation in the
 // reference's ascending order while using the whole chip.
 #include "common.h"
+#include <stdlib.h>
 
 #define EMD_TILE 1024
 
@@ -178,6 +179,8 @@ __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float *
 
 // chunks of the inner cloud per launch: enough workgroups for ~4 per CU, chunks of whole LDS tiles
 static int am_chunks(int b, int n, int m) {
+  static const char *force = getenv("P2PB_AM_CHUNKS");  // "1": single-pass kernels (A/B and parity experiments)
+  if (force && atoi(force) == 1) return 1;
   const long base = (long)cdiv(n < m ? n : m, 256) * b;
   const int inner = n > m ? n : m;
   int c = 1;

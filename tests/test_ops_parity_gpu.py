@@ -1,6 +1,8 @@
 """HIP kernels (through the C ABI, via the drop-in modules) vs the CPU oracle on identical seeded inputs.
 Integer outputs are asserted bit-exact; fp outputs bit-exact where the kernel is deterministic and
 order-matched, with a stated tolerance where the op uses fp32 atomics or __expf."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -166,6 +168,23 @@ def test_chamfer(met, B, N, M):
     assert torch.allclose(G1.cpu(), g1, rtol=1e-4, atol=1e-5) and torch.allclose(G2.cpu(), g2, rtol=1e-4, atol=1e-5)
 
 
+def test_chamfer_ties_across_target_chunks(met):
+    """the target cloud holds every point twice (index j and j + 2048): a small batch splits the targets over several
+    workgroups and combines with a 64-bit atomicMin on (distance bits, index) -- the LOWEST index must win the tie,
+    like the reference's first strict minimum (chamfer3D.cu:60-100)"""
+    g = torch.Generator().manual_seed(5)
+    half = torch.rand(1, 2048, 3, generator=g)
+    tgt = torch.cat([half, half], dim=1).contiguous()
+    qry = torch.cat([half[:, :700] + 1e-3, torch.rand(1, 300, 3, generator=g)], dim=1).contiguous()
+    z = lambda n, dt: torch.zeros(1, n, dtype=dt)
+    d1, d2, i1, i2 = z(1000, torch.float32), z(4096, torch.float32), z(1000, torch.int32), z(4096, torch.int32)
+    cpu_ops.chamfer_forward(qry, tgt, d1, d2, i1, i2)
+    assert i1.max().item() < 2048  # the oracle keeps the first of the two copies
+    D1, D2, I1, I2 = d1.cuda() * 0, d2.cuda() * 0, i1.cuda() * 0, i2.cuda() * 0
+    assert met.chamfer_3D.forward(qry.cuda(), tgt.cuda(), D1, D2, I1, I2) == 1
+    eq(I1, i1, "idx1"), eq(I2, i2, "idx2"), eq(D1, d1, "dist1"), eq(D2, d2, "dist2")
+
+
 def test_emd_known_answer_and_parity(met, golden_dir):
     """the reference's own KAT (metrics/PyTorchEMD/test_emd_loss.py) + oracle parity on random clouds.
     __expf vs expf: tolerance 2e-3 relative on match / cost (documented in DESIGN.md)."""
@@ -181,7 +200,7 @@ def test_emd_known_answer_and_parity(met, golden_dir):
     assert np.allclose(g2.cpu().numpy(), k["g2"], rtol=1e-3, atol=1e-4)
 
     g = torch.Generator().manual_seed(0)
-    for (B, N, M) in [(2, 512, 512), (2, 300, 200), (1, 1024, 2048)]:
+    for (B, N, M) in [(2, 512, 512), (2, 300, 200), (1, 1024, 2048)]:  # (the last one takes the chunked launches)
         a, b_ = torch.rand(B, N, 3, generator=g), torch.rand(B, M, 3, generator=g)
         m0 = cpu_ops.approxmatch_forward(a, b_)
         c0 = cpu_ops.matchcost_forward(a, b_, m0)
@@ -194,6 +213,41 @@ def test_emd_known_answer_and_parity(met, golden_dir):
         r1 = met.emd_cuda.matchcost_backward(gc.cuda(), a.cuda(), b_.cuda(), m1)
         for x0, x1 in zip(r0, r1):
             assert torch.allclose(x1.cpu(), x0, rtol=5e-3, atol=1e-4)
+
+
+def test_approxmatch_chunked_equals_single_pass(tmp_path):
+    """small batches split the inner cloud over blockIdx.y and add the partial sums in chunk order (csrc/emd.hip): same
+    match matrix as the single-pass kernels (P2PB_AM_CHUNKS=1) up to the summation order -- checked at sizes where
+    approxmatch itself is too ill-conditioned (n != m, 4096^2) for a 2e-3 comparison with the expf-based oracle"""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys, torch
+sys.path.insert(0, ".")
+from p2p_bridge_amd import metric_modules as met
+g = torch.Generator().manual_seed(3)
+out = []
+for (B, N, M) in [(1, 4096, 4096), (2, 3000, 2500), (1, 2048, 8192), (3, 2048, 2048)]:
+    a, b = torch.rand(B, N, 3, generator=g).cuda(), torch.rand(B, M, 3, generator=g).cuda()
+    m = met.emd_cuda.approxmatch_forward(a, b)
+    out.append((m.cpu(), met.emd_cuda.matchcost_forward(a, b, m).cpu()))
+torch.save(out, sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("chunked", "single"):
+        env = dict(os.environ)
+        env.pop("P2PB_AM_CHUNKS", None)
+        if mode == "single":
+            env["P2PB_AM_CHUNKS"] = "1"
+        f = str(tmp_path / (mode + ".pt"))
+        r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, cwd=root, env=env, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[mode] = torch.load(f)
+    for (m1, c1), (m0, c0) in zip(res["chunked"], res["single"]):
+        assert (m1 - m0).abs().max().item() <= 2e-6 + 1e-5 * m0.abs().max().item()
+        assert torch.allclose(c1, c0, rtol=1e-5)
 
 
 def _auction(mod, x1, x2, eps, iters, device):
