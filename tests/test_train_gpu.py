@@ -105,6 +105,15 @@ def _worker(rank, world, port, out):
     loss.backward()
     if rank == 0:
         torch.save({k: p.grad.cpu() for k, p in model.model.module.named_parameters()}, out)
+    # three full runner steps under DDP (alignment, GradScaler, clip, AdamW, EMA, loss all-reduce): every parameter must
+    # take part in every backward (DDP raises on the next step otherwise) and the ranks must stay in lockstep
+    batches = T.synthetic_punet_batches(2, 1024, seed=100 * rank, device=model.device)
+    hist = T.train(cfg, model, batches, steps=3, distributed=True, rank=rank, world=world)
+    assert len(hist) == 3 and all(h == h for h in hist)
+    flat = torch.cat([p.detach().flatten() for p in model.model.parameters()])
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    assert all(torch.equal(o, flat) for o in other), "ranks diverged"
     dist.barrier()
     dist.destroy_process_group()
 
