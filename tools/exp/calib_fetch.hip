@@ -12,6 +12,11 @@ __global__ void read8(const f2 *p, size_t n, float *out) {
   }
   if (s == 123.456f) out[0] = s;
 }
+__global__ void read4(const float *p, size_t n, float *out) {  // 4 B / lane: the 256-channel GEMM's activation loads
+  float s = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += p[i];
+  if (s == 123.456f) out[0] = s;
+}
 __global__ void read16(const f4 *p, size_t n, float *out) {
   float s = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -22,6 +27,7 @@ __global__ void read16(const f4 *p, size_t n, float *out) {
 }
 extern "C" void calib(void *buf, size_t bytes, float *out) {
   for (int r = 0; r < 3; ++r) {
+    hipLaunchKernelGGL(read4, dim3(4096), dim3(256), 0, 0, (const float *)buf, bytes / 4, out);
     hipLaunchKernelGGL(read8, dim3(4096), dim3(256), 0, 0, (const f2 *)buf, bytes / 8, out);
     hipLaunchKernelGGL(read16, dim3(4096), dim3(256), 0, 0, (const f4 *)buf, bytes / 16, out);
   }
