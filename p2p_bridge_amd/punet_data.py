@@ -1,21 +1,25 @@
 """PU-Net training data: augmentation transforms, on-the-fly paired patches, per-patch normalisation.
 
-Host-side mirror of the reference's dataloaders/punet.py (`NormalizeUnitSphere` :16-47, the noise models :50-150,
-`RandomScale` :153-163, `RandomRotate` :166-193, `standard_train_transforms[_clean]` :196-224, `PointCloudDataset`
-:228-253, `make_patches_for_pcl_pair` :321-343, `PairedPatchDataset` :346-421, `get_dataset` :284-307): same classes,
-dictionary keys (`pcl_clean`, `pcl_noisy`, `center`, `scale`, `noise_std` -> `noisy_points`, `clean_points`, `center`,
-`scale`) and -- deliberately -- the same random-number calls in the same order (`random.uniform`, `torch.randn_like`,
-`np.random.*`, `random.choice`, `torch.randperm`), so that a run seeded like the reference draws the same augmentation
-(tests/golden/punet_transforms.npz was produced by the reference's own classes).
+Provides what the reference's dataloaders/punet.py provides, under the same public names and with the same dictionary
+keys (`pcl_clean`, `pcl_noisy`, `center`, `scale`, `noise_std` -> `noisy_points`, `clean_points`, `center`, `scale`):
+`NormalizeUnitSphere` (:16-47), the noise models `AddNoise` / `AddLaplacianNoise` / `AddUniformBallNoise` /
+`AddCovNoise` / `AddDiscreteNoise` (:50-150), `RandomScale` (:153-163), `RandomRotate` (:166-193),
+`standard_train_transforms[_clean]` (:196-224), `PointCloudDataset` (:228-253), `make_patches_for_pcl_pair` (:321-343),
+`PairedPatchDataset` (:346-421), `get_dataset` (:284-307).
 
-What is different: the transforms are device-agnostic torch code (a whole batch of clouds can be augmented on the GPU),
-and the K-nearest-neighbour patch extraction -- `pytorch3d.ops.knn_points(..., return_sorted=False)` in the reference --
-is the exact K-NN selection kernel of csrc/knn.hip (p2p_bridge_amd.denoise.knn_points): the SET of points of a patch is
-defined exactly, their order inside the patch is unspecified in the reference (return_sorted=False) and ascending
-(distance, index) here. pytorch3d is absent from /root/reference: that boundary is "parity unpinned".
+Design: every transform is a small object with `__call__(data) -> data`; the noise models share one base class and only
+say how their perturbation is drawn. What is deliberately kept from the reference is the ORDER AND KIND OF THE RANDOM
+DRAWS (python `random` for scalars, `torch.randn_like` / `np.random.*` for fields, `random.choice`, `torch.randperm`)
+and the floating-point expressions the draws go through, so that a run seeded like the reference sees bit-identical
+augmentations: tests/golden/punet_transforms.npz was produced by the reference's own classes and is reproduced exactly
+(tests/test_punet_data.py). The code is device-agnostic torch, so clouds may live on the GPU.
+
+The K-nearest-neighbour patch extraction -- `pytorch3d.ops.knn_points(..., return_sorted=False)` in the reference -- is
+the exact K-NN selection kernel of csrc/knn.hip (p2p_bridge_amd.denoise.knn_points): the SET of points of a patch is
+defined exactly; their order inside the patch is unspecified in the reference and ascending (distance, index) here.
+pytorch3d is absent from /root/reference: that boundary is "parity unpinned".
 """
 import math
-import numbers
 import os
 import random
 
@@ -23,196 +27,232 @@ import numpy as np
 import torch
 from torch.utils.data import Dataset
 
+__all__ = ["Compose", "NormalizeUnitSphere", "AddNoise", "AddLaplacianNoise", "AddUniformBallNoise", "AddCovNoise",
+           "AddDiscreteNoise", "RandomScale", "RandomRotate", "standard_train_transforms",
+           "standard_train_transforms_clean", "PointCloudDataset", "make_patches_for_pcl_pair", "normalize_patch_pair",
+           "PairedPatchDataset", "get_dataset"]
+
+_CLOUD_KEYS = ("pcl_clean", "pcl_noisy")
+
 
 class Compose:
-    """torchvision.transforms.Compose"""
+    """apply transforms left to right (what torchvision.transforms.Compose does for the reference)"""
 
     def __init__(self, transforms):
         self.transforms = list(transforms)
 
     def __call__(self, data):
-        for t in self.transforms:
-            data = t(data)
+        for step in self.transforms:
+            data = step(data)
         return data
+
+
+def _map_clouds(data, fn):
+    """apply `fn` to every cloud present in the sample dict (clean first, then noisy)"""
+    for key in _CLOUD_KEYS:
+        if key in data:
+            data[key] = fn(data[key])
+    return data
 
 
 class NormalizeUnitSphere:
+    """bounding-box centre to the origin, farthest point to radius 1; records `center` and `scale`"""
+
     @staticmethod
     def normalize(pcl, center=None, scale=None):
-        """pcl f32[N,3]: bounding-box centre, max-norm scale (:19-34)"""
         if center is None:
-            center = (pcl.max(dim=0, keepdim=True)[0] + pcl.min(dim=0, keepdim=True)[0]) / 2
-        pcl = pcl - center
+            hi, lo = pcl.max(dim=0, keepdim=True)[0], pcl.min(dim=0, keepdim=True)[0]
+            center = (hi + lo) / 2
+        shifted = pcl - center
         if scale is None:
-            scale = (pcl ** 2).sum(dim=1, keepdim=True).sqrt().max(dim=0, keepdim=True)[0]
-        return pcl / scale, center, scale
+            radii = (shifted ** 2).sum(dim=1, keepdim=True).sqrt()
+            scale = radii.max(dim=0, keepdim=True)[0]
+        return shifted / scale, center, scale
 
     def __call__(self, data):
-        assert "pcl_noisy" not in data, "Point clouds must be normalized before applying noise perturbation."
-        data["pcl_clean"], data["center"], data["scale"] = self.normalize(data["pcl_clean"])
+        if "pcl_noisy" in data:
+            raise AssertionError("Point clouds must be normalized before applying noise perturbation.")
+        unit, center, scale = self.normalize(data["pcl_clean"])
+        data.update(pcl_clean=unit, center=center, scale=scale)
         return data
 
 
-class AddNoise:
+class _Perturbation:
+    """pcl_noisy = pcl_clean + draw(...); subclasses define the draw and the value recorded as `noise_std`"""
+
+    records_std = True
+
+    def draw(self, clean):
+        """-> (noise tensor like `clean`, value to record as noise_std)"""
+        raise NotImplementedError
+
+    def __call__(self, data):
+        clean = data["pcl_clean"]
+        noise, level = self.draw(clean)
+        data["pcl_noisy"] = clean + noise
+        if self.records_std:
+            data["noise_std"] = level
+        return data
+
+
+def _from_numpy(array, like):
+    return torch.FloatTensor(array).to(like)
+
+
+class _RangedStd(_Perturbation):
     def __init__(self, noise_std_min, noise_std_max):
         self.noise_std_min, self.noise_std_max = noise_std_min, noise_std_max
 
-    def __call__(self, data):
-        noise_std = random.uniform(self.noise_std_min, self.noise_std_max)
-        data["pcl_noisy"] = data["pcl_clean"] + torch.randn_like(data["pcl_clean"]) * noise_std
-        data["noise_std"] = noise_std
-        return data
+    def _std(self):
+        return random.uniform(self.noise_std_min, self.noise_std_max)
 
 
-class AddLaplacianNoise:
-    def __init__(self, noise_std_min, noise_std_max):
-        self.noise_std_min, self.noise_std_max = noise_std_min, noise_std_max
+class AddNoise(_RangedStd):
+    """isotropic Gaussian, sigma ~ U[min, max] per cloud"""
 
-    def __call__(self, data):
-        noise_std = random.uniform(self.noise_std_min, self.noise_std_max)
-        noise = torch.FloatTensor(np.random.laplace(0, noise_std, size=tuple(data["pcl_clean"].shape))).to(data["pcl_clean"])
-        data["pcl_noisy"] = data["pcl_clean"] + noise
-        data["noise_std"] = noise_std
-        return data
+    def draw(self, clean):
+        std = self._std()
+        return torch.randn_like(clean) * std, std
 
 
-class AddUniformBallNoise:
+class AddLaplacianNoise(_RangedStd):
+    def draw(self, clean):
+        std = self._std()
+        return _from_numpy(np.random.laplace(0, std, size=tuple(clean.shape)), clean), std
+
+
+class AddUniformBallNoise(_Perturbation):
+    """uniform in a ball of radius `scale` (inverse-CDF radius, uniform direction)"""
+
+    records_std = False
+
     def __init__(self, scale):
         self.scale = scale
 
-    def __call__(self, data):
-        n = data["pcl_clean"].shape[0]
-        phi = np.random.uniform(0, 2 * np.pi, size=n)
-        costheta = np.random.uniform(-1, 1, size=n)
-        u = np.random.uniform(0, 1, size=n)
-        theta = np.arccos(costheta)
-        r = self.scale * u ** (1 / 3)
-        noise = np.zeros([n, 3])
-        noise[:, 0] = r * np.sin(theta) * np.cos(phi)
-        noise[:, 1] = r * np.sin(theta) * np.sin(phi)
-        noise[:, 2] = r * np.cos(theta)
-        data["pcl_noisy"] = data["pcl_clean"] + torch.FloatTensor(noise).to(data["pcl_clean"])
-        return data
+    def draw(self, clean):
+        count = clean.shape[0]
+        azimuth = np.random.uniform(0, 2 * np.pi, size=count)
+        polar = np.arccos(np.random.uniform(-1, 1, size=count))
+        radius = self.scale * np.random.uniform(0, 1, size=count) ** (1 / 3)
+        planar = radius * np.sin(polar)
+        offsets = np.stack([planar * np.cos(azimuth), planar * np.sin(azimuth), radius * np.cos(polar)], axis=1)
+        return _from_numpy(offsets, clean), None
 
 
-class AddCovNoise:
+class AddCovNoise(_Perturbation):
     def __init__(self, cov, std_factor=1.0):
         self.cov = torch.FloatTensor(cov)
         self.std_factor = std_factor
 
-    def __call__(self, data):
-        n = data["pcl_clean"].shape[0]
-        noise = torch.FloatTensor(np.random.multivariate_normal(np.zeros(3), self.cov.numpy(), n)).to(data["pcl_clean"])
-        data["pcl_noisy"] = data["pcl_clean"] + noise * self.std_factor
-        data["noise_std"] = self.std_factor
-        return data
+    def draw(self, clean):
+        sample = np.random.multivariate_normal(np.zeros(3), self.cov.numpy(), clean.shape[0])
+        return _from_numpy(sample, clean) * self.std_factor, self.std_factor
 
 
-class AddDiscreteNoise:
+class AddDiscreteNoise(_Perturbation):
+    """a unit step along one of the six axis directions for the points whose uniform draw lands in that direction's
+    decile (the reference hard-codes 0.1 per direction and never uses `prob`, :140); scaled by `scale`"""
+
+    _directions = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32)
+
     def __init__(self, scale, prob=0.1):
         self.scale, self.prob = scale, prob
-        self.template = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], dtype=np.float32)
+        self.template = self._directions
 
-    def __call__(self, data):
-        n = data["pcl_clean"].shape[0]
-        uni = np.random.uniform(size=n)
-        noise = np.zeros([n, 3])
-        for i in range(self.template.shape[0]):  # (the reference hard-codes 0.1 per direction, not self.prob, :140)
-            noise[np.logical_and(0.1 * i <= uni, uni < 0.1 * (i + 1))] = self.template[i].reshape(1, 3)
-        data["pcl_noisy"] = data["pcl_clean"] + torch.FloatTensor(noise).to(data["pcl_clean"]) * self.scale
-        data["noise_std"] = self.scale
-        return data
+    def draw(self, clean):
+        u = np.random.uniform(size=clean.shape[0])
+        k = np.arange(self.template.shape[0])
+        in_bin = (0.1 * k[None, :] <= u[:, None]) & (u[:, None] < 0.1 * (k[None, :] + 1))
+        steps = np.where(in_bin.any(axis=1)[:, None], self.template[in_bin.argmax(axis=1)], 0.0).astype(np.float64)
+        return _from_numpy(steps, clean) * self.scale, self.scale
 
 
 class RandomScale:
     def __init__(self, scales):
-        assert isinstance(scales, (tuple, list)) and len(scales) == 2
+        if not (isinstance(scales, (tuple, list)) and len(scales) == 2):
+            raise AssertionError("scales must be a (low, high) pair")
         self.scales = scales
 
     def __call__(self, data):
-        scale = random.uniform(*self.scales)
-        data["pcl_clean"] = data["pcl_clean"] * scale
-        if "pcl_noisy" in data:
-            data["pcl_noisy"] = data["pcl_noisy"] * scale
-        return data
+        factor = random.uniform(*self.scales)
+        return _map_clouds(data, lambda cloud: cloud * factor)
+
+
+def _axis_rotation(axis, angle):
+    """row-vector rotation matrix about coordinate axis 0 / 1 / 2 (points are multiplied from the left)"""
+    s, c = math.sin(angle), math.cos(angle)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    rows = [[1 if a == b else 0 for b in range(3)] for a in range(3)]
+    rows[i][i], rows[i][j], rows[j][i], rows[j][j] = c, s, -s, c
+    return rows
 
 
 class RandomRotate:
     def __init__(self, degrees=180.0, axis=0):
-        if isinstance(degrees, numbers.Number):
+        if isinstance(degrees, (int, float)):
             degrees = (-abs(degrees), abs(degrees))
-        assert isinstance(degrees, (tuple, list)) and len(degrees) == 2
+        if not (isinstance(degrees, (tuple, list)) and len(degrees) == 2):
+            raise AssertionError("degrees must be a number or a (low, high) pair")
         self.degrees, self.axis = degrees, axis
 
     def __call__(self, data):
-        degree = math.pi * random.uniform(*self.degrees) / 180.0
-        sin, cos = math.sin(degree), math.cos(degree)
-        if self.axis == 0:
-            matrix = [[1, 0, 0], [0, cos, sin], [0, -sin, cos]]
-        elif self.axis == 1:
-            matrix = [[cos, 0, -sin], [0, 1, 0], [sin, 0, cos]]
-        else:
-            matrix = [[cos, sin, 0], [-sin, cos, 0], [0, 0, 1]]
-        matrix = torch.tensor(matrix).to(data["pcl_clean"])
-        data["pcl_clean"] = torch.matmul(data["pcl_clean"], matrix)
-        if "pcl_noisy" in data:
-            data["pcl_noisy"] = torch.matmul(data["pcl_noisy"], matrix)
-        return data
+        angle = math.pi * random.uniform(*self.degrees) / 180.0
+        matrix = torch.tensor(_axis_rotation(self.axis, angle)).to(data["pcl_clean"])
+        return _map_clouds(data, lambda cloud: torch.matmul(cloud, matrix))
+
+
+def _augmentations(scale_d, rotate):
+    steps = [RandomScale([1.0 - scale_d, 1.0 + scale_d])]
+    if rotate:
+        steps += [RandomRotate(axis=a) for a in range(3)]
+    return steps
 
 
 def standard_train_transforms(noise_std_min, noise_std_max, scale_d=0.2, rotate=True):
-    t = [NormalizeUnitSphere(), AddNoise(noise_std_min=noise_std_min, noise_std_max=noise_std_max),
-         RandomScale([1.0 - scale_d, 1.0 + scale_d])]
-    if rotate:
-        t += [RandomRotate(axis=0), RandomRotate(axis=1), RandomRotate(axis=2)]
-    return Compose(t)
+    return Compose([NormalizeUnitSphere(), AddNoise(noise_std_min=noise_std_min, noise_std_max=noise_std_max)]
+                   + _augmentations(scale_d, rotate))
 
 
 def standard_train_transforms_clean(scale_d=0.2, rotate=True):
-    t = [NormalizeUnitSphere(), RandomScale([1.0 - scale_d, 1.0 + scale_d])]
-    if rotate:
-        t += [RandomRotate(axis=0), RandomRotate(axis=1), RandomRotate(axis=2)]
-    return Compose(t)
+    return Compose([NormalizeUnitSphere()] + _augmentations(scale_d, rotate))
 
 
 class PointCloudDataset(Dataset):
-    """`<root>/<dataset>/pointclouds/<split>/<resolution>/*.xyz` (:228-253); `device`: where the clouds are kept"""
+    """the `.xyz` clouds of `<root>/<dataset>/pointclouds/<split>/<resolution>/`; `device`: where they are kept"""
 
     def __init__(self, root, dataset, split, resolution, transform=None, device=None):
         super().__init__()
         self.pcl_dir = os.path.join(root, dataset, "pointclouds", split, resolution)
         self.transform = transform
-        self.pointclouds, self.pointcloud_names = [], []
-        for fn in sorted(os.listdir(self.pcl_dir)):
-            if fn[-3:] != "xyz":
-                continue
-            pcl = torch.FloatTensor(np.loadtxt(os.path.join(self.pcl_dir, fn), dtype=np.float32))
-            self.pointclouds.append(pcl if device is None else pcl.to(device))
-            self.pointcloud_names.append(fn[:-4])
+        files = sorted(f for f in os.listdir(self.pcl_dir) if f.endswith("xyz"))
+        self.pointcloud_names = [f[:-4] for f in files]
+        clouds = (torch.FloatTensor(np.loadtxt(os.path.join(self.pcl_dir, f), dtype=np.float32)) for f in files)
+        self.pointclouds = [c if device is None else c.to(device) for c in clouds]
 
     def __len__(self):
         return len(self.pointclouds)
 
     def __getitem__(self, idx):
-        data = {"pcl_clean": self.pointclouds[idx].clone(), "name": self.pointcloud_names[idx]}
-        return self.transform(data) if self.transform is not None else data
+        sample = {"pcl_clean": self.pointclouds[idx].clone(), "name": self.pointcloud_names[idx]}
+        return sample if self.transform is None else self.transform(sample)
 
 
 def make_patches_for_pcl_pair(pcl_A, pcl_B, patch_size, num_patches, ratio):
-    """pcl_A f32[N,3], pcl_B f32[rN,3] -> (P, M, 3), (P, rM, 3): K-NN patches of both clouds around `num_patches` random
-    seed points of A (:321-343). On a HIP device the K-NN is csrc/knn.hip; there is no CPU path."""
+    """pcl_A f32[N,3], pcl_B f32[rN,3] -> (P, M, 3), (P, rM, 3): the K nearest neighbours, in both clouds, of
+    `num_patches` random points of A. The K-NN is csrc/knn.hip (HIP device tensors; there is no CPU path)."""
     from .denoise import knn_points
 
-    n = pcl_A.size(0)
-    seed_idx = torch.randperm(n)[:num_patches].to(pcl_A.device)
-    seed = pcl_A[seed_idx].unsqueeze(0).contiguous()
-    pat_A = knn_points(seed, pcl_A.unsqueeze(0).contiguous(), K=patch_size, return_nn=True).knn[0]
-    pat_B = knn_points(seed, pcl_B.unsqueeze(0).contiguous(), K=int(ratio * patch_size), return_nn=True).knn[0]
-    return pat_A, pat_B
+    picks = torch.randperm(pcl_A.size(0))[:num_patches].to(pcl_A.device)
+    seeds = pcl_A[picks].unsqueeze(0).contiguous()
+
+    def around(cloud, k):
+        return knn_points(seeds, cloud.unsqueeze(0).contiguous(), K=k, return_nn=True).knn[0]
+
+    return around(pcl_A, patch_size), around(pcl_B, int(ratio * patch_size))
 
 
 def normalize_patch_pair(data):
-    """centre on the clean patch's centroid, scale by the noisy patch's max norm (:403-421)"""
+    """centre both patches on the CLEAN patch's centroid, scale both by the NOISY patch's largest radius"""
     center = data["pcl_clean"].mean(dim=0)
     noisy, clean = data["pcl_noisy"] - center, data["pcl_clean"] - center
     scale = torch.max(torch.norm(noisy, dim=1))
@@ -220,6 +260,9 @@ def normalize_patch_pair(data):
 
 
 class PairedPatchDataset(Dataset):
+    """(noisy, clean) patch pairs cut from the clouds of several resolutions, on the fly (one random resolution and one
+    random seed point per item) or pre-cut (`num_patches` per cloud)"""
+
     def __init__(self, datasets, patch_ratio, on_the_fly=True, patch_size=1000, num_patches=1000, transform=None):
         super().__init__()
         self.datasets = datasets
@@ -230,38 +273,40 @@ class PairedPatchDataset(Dataset):
         if not on_the_fly:
             self.make_patches()
 
+    def _cut(self, cloud_sample, count):
+        return make_patches_for_pcl_pair(cloud_sample["pcl_noisy"], cloud_sample["pcl_clean"], patch_size=self.patch_size,
+                                         num_patches=count, ratio=self.patch_ratio)
+
     def make_patches(self):
         for dataset in self.datasets:
-            for data in dataset:
-                pn, pc = make_patches_for_pcl_pair(data["pcl_noisy"], data["pcl_clean"], patch_size=self.patch_size,
-                                                   num_patches=self.num_patches, ratio=self.patch_ratio)
-                self.patches += [(pn[i], pc[i]) for i in range(pn.size(0))]
+            for cloud_sample in dataset:
+                noisy, clean = self._cut(cloud_sample, self.num_patches)
+                self.patches.extend(zip(noisy, clean))
 
     def __len__(self):
-        return len(self.patches) if not self.on_the_fly else self.len_datasets * self.num_patches
+        return self.len_datasets * self.num_patches if self.on_the_fly else len(self.patches)
 
     def __getitem__(self, idx):
         if self.on_the_fly:
-            dset = random.choice(self.datasets)
-            pcl = dset[idx % len(dset)]
-            pn, pc = make_patches_for_pcl_pair(pcl["pcl_noisy"], pcl["pcl_clean"], patch_size=self.patch_size,
-                                               num_patches=1, ratio=self.patch_ratio)
-            data = {"pcl_noisy": pn[0], "pcl_clean": pc[0]}
+            source = random.choice(self.datasets)
+            noisy, clean = self._cut(source[idx % len(source)], 1)
+            pair = {"pcl_noisy": noisy[0], "pcl_clean": clean[0]}
         else:
-            data = {"pcl_noisy": self.patches[idx][0].clone(), "pcl_clean": self.patches[idx][1].clone()}
+            noisy, clean = self.patches[idx]
+            pair = {"pcl_noisy": noisy.clone(), "pcl_clean": clean.clone()}
         if self.transform is not None:
-            data = self.transform(data)
-        return normalize_patch_pair(data)
+            pair = self.transform(pair)
+        return normalize_patch_pair(pair)
 
 
 def get_dataset(dataset_root, split, dataset="PUNet", noise_min=0.010, noise_max=0.020, aug_rotate=True,
                 patch_size=2048, resolutions=("10000_poisson", "30000_poisson", "50000_poisson"), device=None):
-    """:284-307. device: keep the clouds (and therefore build the patches) on that HIP device; the K-NN needs one."""
+    """the training / test set of the reference's PUNet branch. device: keep the clouds (and therefore cut the patches)
+    on that HIP device -- the K-NN kernel needs one."""
     if noise_max > 0:
         transform = standard_train_transforms(noise_std_max=noise_max, noise_std_min=noise_min, rotate=aug_rotate)
     else:
         transform = standard_train_transforms_clean(rotate=aug_rotate)
-    return PairedPatchDataset(
-        datasets=[PointCloudDataset(root=dataset_root, dataset=dataset, split=split, resolution=r, transform=transform,
-                                    device=device) for r in resolutions],
-        patch_size=patch_size, patch_ratio=1.0, on_the_fly=True)
+    clouds = [PointCloudDataset(root=dataset_root, dataset=dataset, split=split, resolution=r, transform=transform,
+                                device=device) for r in resolutions]
+    return PairedPatchDataset(datasets=clouds, patch_size=patch_size, patch_ratio=1.0, on_the_fly=True)
