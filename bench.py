@@ -80,13 +80,17 @@ def conv_roofline(model, x_start, reps=10):
     listed = int(counts[which].sum().item())
     flops = 2.0 * 27 * conv.in_channels * conv.out_channels * listed
     dense = 2.0 * 27 * conv.in_channels * conv.out_channels * B * r ** 3
-    with torch.no_grad():
+    arena = fused.StatsArena()  # the launch adds its statistics to accumulators, as inside an evaluation
+    arena.begin(x.device)
+    with torch.no_grad(), fused.use_arena(arena):
         for _ in range(3):
+            arena.off = 0
             orig(*args, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
+            arena.off = 0
             orig(*args, **kw)
         e1.record()
         torch.cuda.synchronize()
@@ -116,16 +120,37 @@ def gemm_roofline(model, B, P, reps=10):
     conv = model.model.global_pnet.mlp2.shared_mlp_1.mlp[0]
     ci, co = conv.in_channels, conv.out_channels
     x = torch.randn(B, ci, P, device="cuda")
-    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
     flops = 2.0 * B * P * ci * co
-    with torch.no_grad():
+    arena = fused.StatsArena()
+    arena.begin(x.device)
+    with torch.no_grad(), fused.use_arena(arena):
+        groups = 8
+        if fused.gn_acc_enabled("pws"):
+            # as in the sampler: the operand's GroupNorm is folded in the kernel's prologue from the accumulators the
+            # previous layer filled (here: x's own statistics, written in the accumulators' fixed-point format), and the
+            # kernel adds its output's statistics to accumulators of its own
+            acc_in = fused.Acc(B, ci, groups, False, x.device)
+            xd = x.double()
+            tot = torch.stack([xd.sum(2).view(B, groups, -1).sum(2), (xd * xd).sum(2).view(B, groups, -1).sum(2)], -1)
+            fl = torch.floor(tot)
+            acc_in.group.view(B, groups, 4, -1)[..., 0] = torch.stack([fl, torch.floor((tot - fl) * 2.0 ** 44)], -1).long().view(B, groups, 4)
+            from p2p_bridge_amd.pvcnn_unet import _group_norm_of
+
+            prev = _group_norm_of(model.model.global_pnet.mlp2.shared_mlp_0.mlp[1])
+            sc, sh = fused.Fold(acc_in, prev.weight, prev.bias, None, prev.eps, float(P)), None
+        else:
+            groups = None
+            sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
+        mark = arena.off
         for _ in range(3):
-            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
+            arena.off = mark
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False, acc_groups=groups)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
+            arena.off = mark
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False, acc_groups=groups)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

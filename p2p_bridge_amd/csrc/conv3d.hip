@@ -481,11 +481,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
                                                              const float *__restrict__ in_sub, int skip_zero,
                                                              const int *__restrict__ brick_list,
                                                              const int *__restrict__ brick_count,
-                                                             float *__restrict__ out, float *__restrict__ stats_part) {
+                                                             float *__restrict__ out, float *__restrict__ stats_part,
+                                                             GnFold fold, GnAcc gacc) {
   using G = SplitGeom<R>;
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
   constexpr int PLANE = HD * HH * HW;
   constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;
+  // folded norm of the operand, per input channel of this sample: [scale | shift], from the caller's arrays or folded
+  // here from the producer's accumulators (common.h gn_fold_table); published by the first barrier of the stage loop
+  __shared__ float xtab[XF ? 2 * P2PB_FOLD_MAXC : 2];
   constexpr int BH = R / G::TH, BW = R / G::TW;
   constexpr int R3 = R * R * R;
   // tile[split][khalf][voxel] : 8 bf16 (16 bytes) = channels khalf*8 .. khalf*8+7 of the staged chunk
@@ -609,6 +613,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
     }
   };
   stage_load(0);
+  if (XF) xf_table(xtab, fold, in_scale, in_shift, b, cin);
 
   for (int ci0 = 0; ci0 < cin; ci0 += CONV_SCK) {
     __syncthreads();
@@ -618,8 +623,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
       float sc = 1.0f, sh = 0.0f, sub = 0.0f;
       const bool cok = ci0 + c < cin;
       if (XF && cok) {
-        sc = in_scale[b * cin + ci0 + c];
-        sh = in_shift[b * cin + ci0 + c];
+        sc = xtab[ci0 + c];
+        sh = xtab[cin + ci0 + c];
         if (in_sub) sub = in_sub[b * cin + ci0 + c];
       }
 #pragma unroll
@@ -664,6 +669,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
   }
 
   float *outb = out + (size_t)b * cout * R3;
+  GnRun grun = {-1, 0.0, 0.0};
   int vox[NT], cls[NT];
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
@@ -697,7 +703,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
         s1 += v;
         s2 += v * v;
       }
-      if (stats_part) {
+      if (gacc.group) {  // order-independent accumulators (sampler path): consecutive channels of a group first
+        s1 = halfwave_sum_to_last(s1);
+        s2 = halfwave_sum_to_last(s2);
+        if (l31 == 31 && cok) gn_run_add(grun, gacc, b, co, s1, s2);
+      } else if (stats_part) {
         // the brick's four statistics slots: wave column wn fills slot wn for its channels; with two wave rows
         // only two columns exist and slots 2, 3 are zeroed
         s1 = halfwave_sum_to_last(s1);
@@ -727,6 +737,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
       }
     }
   }
+  if (gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
 }
 
 // weights [cout][cin][3][3][3] -> packed [27][cin_pad/8][2][cout_pad][4] (zero padded):
@@ -784,9 +795,16 @@ extern "C" size_t p2pb_conv3d_k3_stats_floats(int b, int cout, int r) {
 // far-field constants of a folded operand transform: a[b,c] = xf(base[c]) with the SAME device function the
 // staging code uses (bit-identical), i.e. the value of swish(affine(conv0 output)) where conv0 saw only zeros
 __global__ void far_value_kernel(int c, const float *__restrict__ base, const float *__restrict__ scale,
-                                 const float *__restrict__ shift, int swish, float *__restrict__ a) {
+                                 const float *__restrict__ shift, int swish, float *__restrict__ a, GnFold fold) {
   const int b = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch < c) a[(size_t)b * c + ch] = xf_apply(base[ch], scale[(size_t)b * c + ch], shift[(size_t)b * c + ch], swish);
+  if (ch >= c) return;
+  float sc, sh;
+  if (fold.group) gn_fold_channel(fold, b, c, ch, sc, sh);
+  else {
+    sc = scale[(size_t)b * c + ch];
+    sh = shift[(size_t)b * c + ch];
+  }
+  a[(size_t)b * c + ch] = xf_apply(base[ch], sc, sh, swish);
 }
 
 // T[b, tap, co] = sum_ci W[tap][ci][co] * a[b,ci]  (one thread per output channel, weights read coalesced)
@@ -829,11 +847,19 @@ __global__ __launch_bounds__(256) void class_bias_kernel(int cout, const float *
 extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
                                         const float *in_shift, int in_swish, const float *wt_packed,
                                         const float *bias, float *a, float *k_out, float *tap_ws, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
+  return p2pb_conv3d_k3_far_field_fx(b, cin, cout, prev_bias, nullptr, in_scale, in_shift, in_swish, wt_packed, bias, a,
+                                     k_out, tap_ws, stream);
+}
+
+extern "C" int p2pb_conv3d_k3_far_field_fx(int b, int cin, int cout, const float *prev_bias,
+                                           const p2pb_gn_fold *in_fold, const float *in_scale, const float *in_shift,
+                                           int in_swish, const float *wt_packed, const float *bias, float *a,
+                                           float *k_out, float *tap_ws, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !gn_fold_ok(in_fold, cin)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
   hipLaunchKernelGGL(far_value_kernel, dim3(cdiv(cin, 256), b), dim3(256), 0, s, cin, prev_bias, in_scale, in_shift,
-                     in_swish, a);
+                     in_swish, a, gn_fold_arg(in_fold));
   hipLaunchKernelGGL(tap_sum_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cin, cout, nchunk, cout_pad,
                      wt_packed, a, tap_ws);
   hipLaunchKernelGGL(class_bias_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cout, tap_ws, bias, k_out);
@@ -867,16 +893,18 @@ template <int R, int MT>
 static int conv_launch_split(int b, int cin, int cout, const float *in, const void *wt, const float *bias,
                              const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                              const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count,
-                             float *out, float *stats_part, bool cl, hipStream_t s) {
+                             float *out, float *stats_part, bool cl, hipStream_t s, const GnFold &fold = GnFold(),
+                             const GnAcc &gacc = GnAcc()) {
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
+  if ((in_scale || fold.group) && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
   if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
   const unsigned short *w = (const unsigned short *)wt;
 #define LAUNCH(XF, CL)                                                                                                \
   hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
                      in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,  \
-                     out, stats_part)
-  if (in_scale != nullptr) {
+                     out, stats_part, fold, gacc)
+  if (in_scale != nullptr || fold.group != nullptr) {
     if (cl) LAUNCH(true, true);
     else LAUNCH(true, false);
   } else {
@@ -981,7 +1009,7 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
                                                           const float *__restrict__ out_class,
                                                           const int *__restrict__ brick_list,
                                                           const int *__restrict__ brick_count, float *__restrict__ out,
-                                                          float *__restrict__ stats_part) {
+                                                          float *__restrict__ stats_part, GnAcc gacc) {
   constexpr int TD = 4, TH = 8, TW = 8, BH = R / TH, BW = R / TW, NBRICK = (R / TD) * BH * BW, R3 = R * R * R;
   __shared__ int ncls[27];
   if ((int)blockIdx.x >= *brick_count) return;
@@ -1029,7 +1057,26 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
     float *ob = out + (size_t)b * cout * R3 + (d * R + h) * R + w;
     for (int co = 0; co < cout; ++co) ob[(size_t)co * R3] = kb ? kb[cls * cout + co] : bias[co];
   }
-  if (stats_part) {
+  if (gacc.group) {
+    for (int c0 = 0; c0 < cout; c0 += 256) {  // (whole waves: gn_wave_add reduces across the lanes)
+      const int co = c0 + t;
+      float s1 = 0.0f, s2 = 0.0f;
+      if (co < cout) {
+        if (kb) {
+          for (int c = 0; c < 27; ++c) {
+            const float v = kb[c * cout + co], n = (float)ncls[c];
+            s1 += n * v;
+            s2 += n * v * v;
+          }
+        } else {
+          const float v = bias[co];
+          s1 = 256.0f * v;
+          s2 = 256.0f * v * v;
+        }
+      }
+      if ((c0 + (t & ~63)) < cout) gn_wave_add(gacc, b, co < cout ? co : -1, s1, s2);
+    }
+  } else if (stats_part) {
     for (int co = t; co < cout; co += 256) {
       float s1 = 0.0f, s2 = 0.0f;
       if (kb) {
@@ -1071,7 +1118,22 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
                                          const float *bias, const float *out_class, const float *in_scale,
                                          const float *in_shift, int in_swish, const float *in_sub, int flags,
                                          float *out, float *stats_part, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
+  return p2pb_conv3d_k3_forward_fx(b, cin, cout, r, in, wt_packed, bias, out_class, nullptr, in_scale, in_shift,
+                                   in_swish, in_sub, flags, out, stats_part, nullptr, stream);
+}
+
+// the same with the sampler path's statistics plumbing: in_fold (instead of in_scale / in_shift) = fold the operand's
+// norm here from the producer's accumulators; out_acc (instead of stats_part) = add this output's statistics to
+// accumulators. Split pack only (flags bit 2).
+extern "C" int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
+                                         const float *bias, const float *out_class, const p2pb_gn_fold *in_fold,
+                                         const float *in_scale, const float *in_shift, int in_swish,
+                                         const float *in_sub, int flags, float *out, float *stats_part,
+                                         const p2pb_gn_acc *out_acc, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout)) return P2PB_EINVAL;
+  const GnFold fold = gn_fold_arg(in_fold);
+  const GnAcc gacc = gn_acc_arg(out_acc, cout);
+  if ((fold.group || gacc.group) && !(flags & 4)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int skip = flags & 1;
   const bool compact = (flags & 2) != 0;
@@ -1084,9 +1146,9 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
     const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 256;
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s)                          \
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc)              \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s)
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc)
     switch (r) {
       case 32: GOS(32);
       case 16: GOS(16);
@@ -1122,13 +1184,30 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
                                              const int *active_list, const int *active_count,
                                              const int *inactive_list, const int *inactive_count, float *out,
                                              float *stats_part, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || (r != 16 && r != 32) || !active_list || !inactive_list) return P2PB_EINVAL;
+  return p2pb_conv3d_k3_forward_sparse_fx(b, cin, cout, r, in, wt_packed, bias, out_class, nullptr, in_scale, in_shift,
+                                          in_swish, in_sub, flags, active_list, active_count, inactive_list,
+                                          inactive_count, out, stats_part, nullptr, stream);
+}
+
+extern "C" int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
+                                                const float *bias, const float *out_class,
+                                                const p2pb_gn_fold *in_fold, const float *in_scale,
+                                                const float *in_shift, int in_swish, const float *in_sub, int flags,
+                                                const int *active_list, const int *active_count,
+                                                const int *inactive_list, const int *inactive_count, float *out,
+                                                float *stats_part, const p2pb_gn_acc *out_acc, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || (r != 16 && r != 32) || !active_list || !inactive_list ||
+      !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout))
+    return P2PB_EINVAL;
+  const GnFold fold = gn_fold_arg(in_fold);
+  const GnAcc gacc = gn_acc_arg(out_acc, cout);
+  if ((fold.group || gacc.group) && !(flags & 4)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int total = conv_bricks(r) * b;
   const bool cl = (flags & 8) != 0;
 #define FILL(RR, CL)                                                                                          \
   hipLaunchKernelGGL((conv3d_fill_kernel<RR, CL>), dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list, \
-                     inactive_count, out, stats_part)
+                     inactive_count, out, stats_part, gacc)
   if (r == 32) {
     if (cl) FILL(32, true);
     else FILL(32, false);
@@ -1141,9 +1220,9 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
   if (flags & 4) {
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s)                    \
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc)        \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s)
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc)
     if (r == 32) { GOS(32); }
     GOS(16);
 #undef GOS
@@ -1276,7 +1355,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
                                                                 const float *__restrict__ in_sub, int skip_zero,
                                                                 const unsigned char *__restrict__ alist,
                                                                 const int *__restrict__ acount,
-                                                                float *__restrict__ out, float *__restrict__ stats_part) {
+                                                                float *__restrict__ out, float *__restrict__ stats_part,
+                                                                GnFold fold, GnAcc gacc) {
   using G = SplitGeom<R>;
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
   constexpr int PLANE = HD * HH * HW;
@@ -1287,6 +1367,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
   __shared__ unsigned char lst[256];
   __shared__ int ncls[27];
   __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
+  __shared__ float xtab[XF ? 2 * P2PB_FOLD_MAXC : 2];  // folded norm of the operand (see the split kernel)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -1307,6 +1388,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
   const int count = acount[(size_t)b * NBRICK + brick];
   lst[tid] = alist[((size_t)b * NBRICK + brick) * 256 + tid];
   if (tid < 27) ncls[tid] = 0;
+  if (XF) xf_table(xtab, fold, in_scale, in_shift, b, cin);
   __syncthreads();
   const int ntiles = (count + 31) >> 5;
   auto vox_of = [&](int l, int &cls) {
@@ -1389,8 +1471,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
         float sc = 1.0f, sh = 0.0f, sub = 0.0f;
         const bool cok = ci0 + c < cin;
         if (XF && cok) {
-          sc = in_scale[b * cin + ci0 + c];
-          sh = in_shift[b * cin + ci0 + c];
+          sc = xtab[ci0 + c];
+          sh = xtab[cin + ci0 + c];
           if (in_sub) sub = in_sub[b * cin + ci0 + c];
         }
 #pragma unroll
@@ -1528,7 +1610,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
       outb[(size_t)vx * cout + cob + c] = kb ? kb[cls * cout + cob + c] : bias[cob + c];
     }
   }
-  if (stats_part) {
+  if (gacc.group) {
+    if (l31 == 31) {  // the wave columns' active sums
+      GnRun grun = {-1, 0.0, 0.0};
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        if (co < cout) gn_run_add(grun, gacc, b, co, wstat[wave][khalf][r][0], wstat[wave][khalf][r][1]);
+      }
+      gn_run_flush(grun, gacc, b);
+    }
+    if ((tid & ~63) < cw) {  // the constants' sums
+      const int co = cob + tid;
+      float s1 = 0.0f, s2 = 0.0f;
+      if (tid < cw) {
+        if (kb) {
+          for (int c = 0; c < 27; ++c) {
+            const float x = kb[c * cout + co], n = (float)ncls[c];
+            s1 += n * x;
+            s2 += n * x * x;
+          }
+        } else {
+          const float x = bias[co];
+          s1 = (float)ninact * x;
+          s2 = (float)ninact * x * x;
+        }
+      }
+      gn_wave_add(gacc, b, tid < cw ? co : -1, s1, s2);
+    }
+  } else if (stats_part) {
     // slots of the brick: [0, WN) = the wave columns' active sums, WN = the constants' sums, the rest zero
     float *sp = stats_part + (((size_t)b * NBRICK + brick) * 4) * cout * 2;
     if (l31 == 31) {
@@ -1578,7 +1688,23 @@ extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, c
                                               const float *in_shift, int in_swish, const float *in_sub,
                                               const unsigned char *alist, const int *acount, float *out,
                                               float *stats_part, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || !alist || !acount || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
+  return p2pb_conv3d_k3_forward_compact_fx(b, cin, cout, r, in, wt_split, bias, out_class, nullptr, in_scale, in_shift,
+                                           in_swish, in_sub, alist, acount, out, stats_part, nullptr, stream);
+}
+
+extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r, const float *in, const void *wt_split,
+                                                 const float *bias, const float *out_class,
+                                                 const p2pb_gn_fold *in_fold, const float *in_scale,
+                                                 const float *in_shift, int in_swish, const float *in_sub,
+                                                 const unsigned char *alist, const int *acount, float *out,
+                                                 float *stats_part, const p2pb_gn_acc *out_acc, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !alist || !acount || (r != 8 && r != 16 && r != 32) ||
+      !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout))
+    return P2PB_EINVAL;
+  const GnFold fold = gn_fold_arg(in_fold);
+  const GnAcc gacc = gn_acc_arg(out_acc, cout);
+  const bool xf = in_scale != nullptr || fold.group != nullptr;
+  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   const unsigned short *w = (const unsigned short *)wt_split;
@@ -1586,13 +1712,13 @@ extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, c
   dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
 #define LAUNCH(RR, WMV, XF)                                                                                          \
   hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in, w, \
-                     bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part)
+                     bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part, fold, gacc)
 #define GO(RR)                                                   \
   if (wm1) {                                                     \
-    if (in_scale) LAUNCH(RR, 1, true);                           \
+    if (xf) LAUNCH(RR, 1, true);                                 \
     else LAUNCH(RR, 1, false);                                   \
   } else {                                                       \
-    if (in_scale) LAUNCH(RR, 2, true);                           \
+    if (xf) LAUNCH(RR, 2, true);                                 \
     else LAUNCH(RR, 2, false);                                   \
   }
   if (r == 32) { GO(32) } else if (r == 16) { GO(16) } else { GO(8) }
@@ -1727,5 +1853,65 @@ extern "C" int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean
   if (b <= 0 || c <= 0 || hidden <= 0) return P2PB_EINVAL;
   hipLaunchKernelGGL(se_gate_affine_kernel, dim3(b), dim3(256), (size_t)(c + hidden) * sizeof(float),
                      (hipStream_t)stream, c, hidden, chmean, w1, w2, scale, shift, aff_a, aff_b);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same two steps on the sampler path's accumulators (common.h: fixed-point group / channel sums added by the
+// producers' epilogues). gn_fold_params_kernel is the stand-alone finisher for consumers that take scale / shift
+// arrays; se_gate_affine_fold_kernel folds the norm itself (it is the consumer of the second convolution's statistics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_fold_params_kernel(int c, GnFold fold, float *__restrict__ scale,
+                                                             float *__restrict__ shift, float *__restrict__ chmean) {
+  const int b = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  float sc, sh, cm;
+  gn_fold_channel(fold, b, c, ch, sc, sh, chmean ? &cm : nullptr);
+  scale[(size_t)b * c + ch] = sc;
+  shift[(size_t)b * c + ch] = sh;
+  if (chmean) chmean[(size_t)b * c + ch] = cm;
+}
+
+extern "C" int p2pb_gn_fold_params(int b, int c, const p2pb_gn_fold *fold, float *scale, float *shift, float *chmean,
+                                   void *stream) {
+  if (b <= 0 || c <= 0 || !fold || !fold->group || !gn_fold_ok(fold, c) || !scale || !shift ||
+      (chmean && !fold->channel))
+    return P2PB_EINVAL;
+  hipLaunchKernelGGL(gn_fold_params_kernel, dim3(cdiv(c, 256), b), dim3(256), 0, (hipStream_t)stream, c, *fold, scale,
+                     shift, chmean);
+  return p2pb_launch_status();
+}
+
+__global__ __launch_bounds__(256) void se_gate_affine_fold_kernel(int c, int hidden, GnFold fold,
+                                                                  const float *__restrict__ w1,
+                                                                  const float *__restrict__ w2,
+                                                                  float *__restrict__ aff_a, float *__restrict__ aff_b) {
+  extern __shared__ float se_sm[];  // c means + c scales + c shifts + hidden activations
+  float *mean = se_sm, *sc = se_sm + c, *sh = se_sm + 2 * c, *hid = se_sm + 3 * c;
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < c; i += 256) gn_fold_channel(fold, b, c, i, sc[i], sh[i], &mean[i]);
+  __syncthreads();
+  for (int h = t; h < hidden; h += 256) {
+    float acc = 0.0f;
+    for (int i = 0; i < c; ++i) acc = __fmaf_rn(w1[(size_t)h * c + i], mean[i], acc);
+    hid[h] = fmaxf(acc, 0.0f);
+  }
+  __syncthreads();
+  for (int i = t; i < c; i += 256) {
+    float acc = 0.0f;
+    for (int h = 0; h < hidden; ++h) acc = __fmaf_rn(w2[(size_t)i * hidden + h], hid[h], acc);
+    const float gate = 1.0f / (1.0f + expf(-acc));
+    aff_a[(size_t)b * c + i] = sc[i] * gate;
+    aff_b[(size_t)b * c + i] = sh[i] * gate;
+  }
+}
+
+// fold (group + channel accumulators of the grid the gate squeezes) -> aff_a, aff_b f32[b,c]
+extern "C" int p2pb_se_gate_affine_fx(int b, int c, int hidden, const p2pb_gn_fold *fold, const float *w1,
+                                      const float *w2, float *aff_a, float *aff_b, void *stream) {
+  if (b <= 0 || c <= 0 || hidden <= 0 || !fold || !fold->group || !fold->channel || !gn_fold_ok(fold, c))
+    return P2PB_EINVAL;
+  hipLaunchKernelGGL(se_gate_affine_fold_kernel, dim3(b), dim3(256), (size_t)(3 * c + hidden) * sizeof(float),
+                     (hipStream_t)stream, c, hidden, *fold, w1, w2, aff_a, aff_b);
   return p2pb_launch_status();
 }

@@ -211,7 +211,11 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
                                                       const float *__restrict__ in_scale,
                                                       const float *__restrict__ in_shift, int in_swish,
                                                       float *__restrict__ out, float *__restrict__ stats_part,
-                                                      float *__restrict__ mm_out, int pool_g, int out_pm) {
+                                                      float *__restrict__ mm_out, int pool_g, int out_pm, GnFold fold,
+                                                      GnAcc gacc) {
+  // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
+  // producer's accumulators (common.h) -- the one barrier of this kernel
+  __shared__ float xtab[XF ? 2 * P2PB_FOLD_MAXC : 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
@@ -249,6 +253,10 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
   };
   load_b(0, bnxt);
   load_a(0, a_nxt);
+  if (XF) {
+    xf_table(xtab, fold, in_scale, in_shift, b, cin);
+    __syncthreads();
+  }
 
   for (int ci0 = 0; ci0 < cin; ci0 += PWW_CK) {
     // rotate (the vmcnt wait lands here), request the next chunk, then multiply the current one
@@ -263,10 +271,8 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
     if (XF) {
 #pragma unroll
       for (int kk = 0; kk < PWW_CK / 2; ++kk) {
-        // wave-uniform indices: the folded norm parameters travel through the scalar cache
-        const int ca = b * cin + min(ci0 + 2 * kk, cin - 1), cb = b * cin + min(ci0 + 2 * kk + 1, cin - 1);
-        const float sca = in_scale[ca], scb = in_scale[cb], sha = in_shift[ca], shb = in_shift[cb];
-        const float sc = khalf ? scb : sca, sh = khalf ? shb : sha;
+        const int cx = min(ci0 + 2 * kk + khalf, cin - 1);  // (uniform per half-wave: two LDS broadcasts)
+        const float sc = xtab[cx], sh = xtab[cin + cx];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           float v = bcur[kk][s] * sc + sh;
@@ -319,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
   // statistics slots keep the 64-position granularity of the narrow kernel: this wave fills slot `slot`
   // with its 128-position sums and zeroes slot + 1
   const int slot = (blockIdx.x * 4 + wave) * 2;
+  GnRun grun = {-1, 0.0, 0.0};
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -360,7 +367,9 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       if (STATS) {
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
-        if (l31 == 31 && co < cout) {
+        if (gacc.group) {
+          if (l31 == 31 && co < cout) gn_run_add(grun, gacc, b, co, s1, s2);
+        } else if (l31 == 31 && co < cout) {
           if (slot < nslots) {
             float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
             q[0] = s1;
@@ -375,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       }
     }
   }
+  if (STATS && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
 }
 
 __global__ void pw_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, const float *__restrict__ w,
@@ -438,7 +448,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
                                              int wm, int wn, int l31, int khalf, int cout, int P, int nslots,
                                              const float *__restrict__ bias, const float *__restrict__ bias_b,
                                              float *__restrict__ out, float *__restrict__ stats_part,
-                                             float *__restrict__ mm_out, int pool_u, int out_pm) {
+                                             float *__restrict__ mm_out, int pool_u, int out_pm, const GnAcc &gacc) {
 #pragma unroll
   for (int pb = 0; pb < NB; ++pb) {  // the wave's NB blocks of 64 positions (even / odd tiles 2 pb, 2 pb + 1)
   const int p = pblk + 128 * pb + 2 * (wn * 32 + l31);
@@ -524,7 +534,14 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
                                     : (pok ? fmaxf(v0, v1) : -INFINITY);
       }
   };
-  if (stats_part) {
+  if (gacc.group) {  // order-independent accumulators: one add per (wave, group) -- common.h gn_wave_add
+    float tv[32];
+    rowvals(0, tv);
+    const float s1 = rowreduce32<RowAdd>(tv);
+    rowvals(1, tv);
+    const float s2 = rowreduce32<RowAdd>(tv);
+    gn_wave_add(gacc, b, rco < cout ? rco : -1, s1, s2);
+  } else if (stats_part) {
     float tv[32];
     rowvals(0, tv);
     const float s1 = rowreduce32<RowAdd>(tv);
@@ -576,8 +593,9 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
                                                        const float *__restrict__ in_scale,
                                                        const float *__restrict__ in_shift, int in_swish,
                                                        float *__restrict__ out, float *__restrict__ stats_part,
-                                                       float *__restrict__ mm_out, int pool_u, int out_pm) {
-  extern __shared__ u32x4 pws_lds[];  // [A: WM/2 blocks of 128 channels][B: NB blocks of 128 positions]
+                                                       float *__restrict__ mm_out, int pool_u, int out_pm, GnFold fold,
+                                                       GnAcc gacc) {
+  extern __shared__ u32x4 pws_lds[];  // [A: WM/2 blocks of 128 channels][B: NB blocks of 128 positions][XF: 2 cin floats]
   constexpr int NT = 128 * WM;
   constexpr int BS = 128 * NB;  // 16-byte groups per (kstep, split, khalf) row of the B tile
   u32x4 *lds_b = pws_lds + (WM / 2) * PWS_TILE;
@@ -653,6 +671,10 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
                                          (__attribute__((address_space(3))) void *)(dst + i * NT + wave * 64), 16, 0, 0);
   };
   load_b(0);
+  // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
+  // producer's accumulators (common.h); published by the barrier at the top of the first stage
+  float *xtab = (float *)(pws_lds + (WM / 2 + NB) * PWS_TILE);
+  if (XF) xf_table(xtab, fold, in_scale, in_shift, b, cin);
 
   for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
     __syncthreads();  // everyone is done reading the previous stage
@@ -680,8 +702,8 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
       if (XF) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const int c = b * cin + min(ci0 + 8 * bgrp + i, cin - 1);
-          const float sc = in_scale[c], sh = in_shift[c];
+          const int c = min(ci0 + 8 * bgrp + i, cin - 1);
+          const float sc = xtab[c], sh = xtab[cin + c];
 #pragma unroll
           for (int q = 0; q < NBW; ++q)
 #pragma unroll
@@ -761,7 +783,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
   }
   if (!mact) return;
   pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
-                             stats_part, mm_out, pool_u, out_pm);
+                             stats_part, mm_out, pool_u, out_pm, gacc);
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
@@ -805,7 +827,9 @@ extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float 
 
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
-                           float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
+                           float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s,
+                           const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
+  const bool xf = in_scale != nullptr || fold.group != nullptr;
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
@@ -819,22 +843,25 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
 #define LAUNCHW(XF, PL, WM, NB)                                                                                     \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
-    const int lds = (WM / 2 + NB) * PWS_TILE * 16;                                                                    \
+    const int lds = (WM / 2 + NB) * PWS_TILE * 16 + (XF ? 2 * cin * 4 : 0);                                           \
     if (!once) {                                                                                                     \
       (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB>,                                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
+                                (WM / 2 + NB) * PWS_TILE * 16 + 2 * P2PB_FOLD_MAXC * 4);                               \
       once = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, w,   \
-                       bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm);          \
+                       bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fold,     \
+                       gacc);                                                                                        \
   } while (0)
 #define LAUNCH(XF, PL)                    \
   do {                                    \
     if (wm4) LAUNCHW(XF, PL, 4, 1);        \
     else LAUNCHW(XF, PL, 2, 1);            \
   } while (0)
-  if (in_scale && minmax) LAUNCH(true, true);
-  else if (in_scale) LAUNCH(true, false);
+  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
+  if (xf && minmax) LAUNCH(true, true);
+  else if (xf) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
@@ -850,14 +877,17 @@ static bool pw_wide_ok(int P, const float *in, const float *out) {
 template <int MT>
 static int pw_launch(int b, int cin, int cout, int P, const float *in, const float *wp, const float *bias,
                      const float *bias_b, const float *in_scale, const float *in_shift, int in_swish, float *out,
-                     float *stats_part, float *minmax, int pool_g, int out_pm, hipStream_t s) {
-  const bool xf = in_scale != nullptr, st = stats_part != nullptr;
+                     float *stats_part, float *minmax, int pool_g, int out_pm, hipStream_t s,
+                     const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
+  const bool xf = in_scale != nullptr || fold.group != nullptr, st = stats_part != nullptr || gacc.group != nullptr;
+  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   if (pw_wide_ok(P, in, out)) {
     dim3 grid((P + 511) / 512, (cout + 32 * MT - 1) / (32 * MT), b);
     const int nslots = (P + 255) / 256 * 4;
 #define LAUNCH(XF, ST, PL)                                                                                         \
   hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, nslots, \
-                     in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm)
+                     in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm, fold, \
+                     gacc)
     if (minmax) {
       if (xf) LAUNCH(true, true, true);
       else LAUNCH(false, true, true);
@@ -868,7 +898,7 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
 #undef LAUNCH
     return p2pb_launch_status();
   }
-  if (minmax || out_pm) return P2PB_EINVAL;
+  if (minmax || out_pm || fold.group || gacc.group) return P2PB_EINVAL;  // (the unaligned fallback: arrays / partials only)
   dim3 grid((P + 255) / 256, (cout + 32 * MT - 1) / (32 * MT), b);
 #define LAUNCH(XF, ST)                                                                                            \
   hipLaunchKernelGGL((pw_conv_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, in, wp, bias, \
@@ -885,21 +915,35 @@ extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, c
                                            const float *bias, const float *bias_b, const float *in_scale,
                                            const float *in_shift, int in_swish, int flags, float *out,
                                            float *stats_part, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out) return P2PB_EINVAL;
+  return p2pb_pointwise_conv_forward_fx(b, cin, cout, npos, in, wp_any, bias, bias_b, nullptr, in_scale, in_shift,
+                                        in_swish, flags, out, stats_part, nullptr, stream);
+}
+
+// in_fold / out_acc: the sampler path's statistics plumbing (include/p2pb_hip.h "GroupNorm statistics without a
+// finishing launch"); 16-byte rows required with either
+extern "C" int p2pb_pointwise_conv_forward_fx(int b, int cin, int cout, int npos, const float *in, const void *wp_any,
+                                              const float *bias, const float *bias_b, const p2pb_gn_fold *in_fold,
+                                              const float *in_scale, const float *in_shift, int in_swish, int flags,
+                                              float *out, float *stats_part, const p2pb_gn_acc *out_acc,
+                                              void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out || !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout))
+    return P2PB_EINVAL;
+  const GnFold fold = gn_fold_arg(in_fold);
+  const GnAcc gacc = gn_acc_arg(out_acc, cout);
   hipStream_t s = (hipStream_t)stream;
   const int out_pm = (flags & 32) != 0;  // point-major output f32[b, npos, cout]
-  if (out_pm && stats_part) return P2PB_EINVAL;
+  if (out_pm && (stats_part || gacc.group)) return P2PB_EINVAL;
   if (flags & 4) {  // wp is the split pack
     if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           nullptr, 0, out_pm, s);
+                           nullptr, 0, out_pm, s, fold, gacc);
   }
   const float *wp = (const float *)wp_any;
   // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, nullptr, 0, out_pm, s)
+                                  stats_part, nullptr, 0, out_pm, s, fold, gacc)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, nullptr, 0, out_pm, s);
+                                  stats_part, nullptr, 0, out_pm, s, fold, gacc);
 }
 
 // pool_u = neighbourhood size (4, 8, 16, 32 or 64 consecutive positions) or 0 for the global pool
@@ -920,18 +964,33 @@ extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int np
                                                 const float *in_scale, const float *in_shift, int in_swish, int flags,
                                                 float *out, float *stats_part, int pool_u, float *minmax,
                                                 void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !stats_part || !minmax) return P2PB_EINVAL;
+  return p2pb_pointwise_conv_pool_forward_fx(b, cin, cout, npos, in, wp_any, bias, bias_b, nullptr, in_scale, in_shift,
+                                             in_swish, flags, out, stats_part, nullptr, pool_u, minmax, stream);
+}
+
+extern "C" int p2pb_pointwise_conv_pool_forward_fx(int b, int cin, int cout, int npos, const float *in,
+                                                   const void *wp_any, const float *bias, const float *bias_b,
+                                                   const p2pb_gn_fold *in_fold, const float *in_scale,
+                                                   const float *in_shift, int in_swish, int flags, float *out,
+                                                   float *stats_part, const p2pb_gn_acc *out_acc, int pool_u,
+                                                   float *minmax, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !minmax || !gn_fold_ok(in_fold, cin) ||
+      !gn_acc_ok(out_acc, cout))
+    return P2PB_EINVAL;
+  const GnFold fold = gn_fold_arg(in_fold);
+  const GnAcc gacc = gn_acc_arg(out_acc, cout);
+  if (!stats_part && !gacc.group) return P2PB_EINVAL;
   if (!p2pb_pointwise_pool_supported(npos, pool_u) || !pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (flags & 4)
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           minmax, pool_u, 0, s);
+                           minmax, pool_u, 0, s, fold, gacc);
   const float *wp = (const float *)wp_any;
   const int g = pool_lanes(pool_u);
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, minmax, g, 0, s)
+                                  stats_part, minmax, g, 0, s, fold, gacc)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, minmax, g, 0, s);
+                                  stats_part, minmax, g, 0, s, fold, gacc);
 }
 
 // y = max(act(scale*min + shift), act(scale*max + shift)):
@@ -977,6 +1036,53 @@ extern "C" int p2pb_minmax_act(int b, int c, int m, int nslots, const float *min
   const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(minmax_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, m, nslots, minmax, scale,
                      shift, swish, y, total);
+  return p2pb_launch_status();
+}
+
+// the same with the norm folded here from the producer's accumulators: one (sample, channel) row per workgroup row
+// (neighbour max) or one thread per (sample, channel) (global pool)
+__global__ __launch_bounds__(256) void minmax_act_fold_kernel(int c, int m, int nslots, const float *__restrict__ mm,
+                                                              GnFold fold, int swish, float *__restrict__ y, int bc_n) {
+  int bc;
+  if (nslots == 0) bc = blockIdx.y;
+  else {
+    bc = blockIdx.x * 256 + threadIdx.x;
+    if (bc >= bc_n) return;
+  }
+  const int b = bc / c, ch = bc % c;
+  float sc, sh;
+  gn_fold_channel(fold, b, c, ch, sc, sh);
+  auto act_max = [&](float mn, float mx) {
+    float lo = mn * sc + sh, hi = mx * sc + sh;
+    if (swish) {
+      lo = swishf(lo);
+      hi = swishf(hi);
+    }
+    return fmaxf(lo, hi);
+  };
+  if (nslots == 0) {
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
+      const float2 v = *(const float2 *)(mm + ((size_t)bc * m + j) * 2);
+      y[(size_t)bc * m + j] = act_max(v.x, v.y);
+    }
+  } else {
+    float mn = INFINITY, mx = -INFINITY;
+    for (int sl = 0; sl < nslots; ++sl) {
+      const float2 v = *(const float2 *)(mm + (((size_t)b * nslots + sl) * c + ch) * 2);
+      mn = fminf(mn, v.x);
+      mx = fmaxf(mx, v.y);
+    }
+    y[bc] = act_max(mn, mx);
+  }
+}
+
+extern "C" int p2pb_minmax_act_fx(int b, int c, int m, int nslots, const float *minmax, const p2pb_gn_fold *fold,
+                                  int swish, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || m <= 0 || nslots < 0 || !fold || !fold->group || !gn_fold_ok(fold, c)) return P2PB_EINVAL;
+  // (one fold per wave: a workgroup takes up to 4096 elements of its row)
+  const dim3 grid = nslots == 0 ? dim3(cdiv(m, 4096), b * c) : dim3(cdiv((long)b * c, 256));
+  hipLaunchKernelGGL(minmax_act_fold_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, m, nslots, minmax, *fold, swish,
+                     y, b * c);
   return p2pb_launch_status();
 }
 

@@ -18,6 +18,150 @@ _i, _f, _d = ctypes.c_int, ctypes.c_float, ctypes.c_double
 F32 = torch.float32
 
 
+# ------------------------------------------------------------------ GroupNorm statistics without a finishing launch
+# (include/p2pb_hip.h "p2pb_gn_acc / p2pb_gn_fold", csrc/common.h). A producer called with acc_groups=G adds its output's
+# {sum, sum of squares} to fixed-point accumulators taken from the evaluation's arena and returns an `Acc`; norm_affine
+# turns that into a `Fold`, which the consumers' in_scale argument accepts in place of the (scale, shift) arrays -- they
+# fold the norm in their prologue. Consumers that only take arrays call Fold.arrays() (one small launch, as before).
+
+
+class _GnAccStruct(ctypes.Structure):
+    _fields_ = [("group", ctypes.c_void_p), ("channel", ctypes.c_void_p), ("groups", ctypes.c_int)]
+
+
+class _GnFoldStruct(ctypes.Structure):
+    _fields_ = [("group", ctypes.c_void_p), ("channel", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
+                ("beta", ctypes.c_void_p), ("style", ctypes.c_void_p), ("style_stride", ctypes.c_int),
+                ("groups", ctypes.c_int), ("eps", ctypes.c_float), ("count", ctypes.c_double)]
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+class StatsArena:
+    """all accumulators of one network evaluation in one int64 buffer, zeroed by ONE fill at the top of the evaluation
+    (begin). Owned by the network module; grown buffers are kept (a captured graph may still point into an old one)."""
+
+    def __init__(self):
+        self.buf, self.off, self.need, self._kept = None, 0, 0, []
+
+    def begin(self, device):
+        if self.buf is None or self.buf.device != device or self.need > self.buf.numel():
+            if self.buf is not None:
+                self._kept.append(self.buf)
+            self.buf = torch.empty(max(self.need, 1 << 18), dtype=torch.int64, device=device)
+        self.off = self.need = 0
+        self.buf.zero_()
+
+    def take(self, n, device):
+        self.need += n
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            return torch.zeros(n, dtype=torch.int64, device=device)  # first evaluation of a larger shape: begin() regrows
+        out = self.buf[self.off:self.off + n]
+        self.off += n
+        return out
+
+
+_arena = None  # the evaluation in progress (set by use_arena)
+
+
+class use_arena:
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        global _arena
+        self.prev, _arena = _arena, self.arena
+        return self.arena
+
+    def __exit__(self, *a):
+        global _arena
+        _arena = self.prev
+
+
+GN_ACC_DEFAULT = "pws,conv8,conv16"
+
+
+def gn_acc_enabled(kind=None) -> bool:
+    """which producers add their statistics to accumulators (the others write per-slot partials, finished by one
+    gn_affine launch per layer, as in round 2). The chip retires ~14 G 64-bit atomics/s (12 ns each on one 128-byte line:
+    tools/exp/atomic_contention.hip), so the form pays where a workgroup produces >~ 1000 outputs per atomic: the
+    LDS-tiled GEMM (`pws`) and the convolutions on the coarse grids (`conv8`, `conv16`); the streaming kernels
+    (`pww`, `gsub`, `interp`) and the 32^3 convolutions (`conv32`) lose more in their epilogues than the launch costs.
+    P2PB_GN_ACC: comma list of kinds, `1` = all, `0` = none."""
+    v = os.environ.get("P2PB_GN_ACC", GN_ACC_DEFAULT)
+    if v == "0":
+        return False
+    if v == "1" or kind is None:
+        return True
+    return kind in v.split(",")
+
+
+GN_LINE = 16  # int64 per 128-byte line: every word of the group accumulators sits on its own line (csrc/common.h)
+
+
+class Acc:
+    """the accumulators one producer adds to: group i64[b,groups,4,GN_LINE] (word 0 of each line), channel i64[b,c,2] | None"""
+
+    def __init__(self, b, c, groups, want_channel, device):
+        ng = b * groups * 4 * GN_LINE
+        n = ng + (b * c * 2 if want_channel else 0)
+        buf = _arena.take(n, device) if _arena is not None else torch.zeros(n, dtype=torch.int64, device=device)
+        self.b, self.c, self.groups = b, c, groups
+        self.group = buf[:ng]
+        self.channel = buf[ng:] if want_channel else None
+        self.struct = _GnAccStruct(_addr(self.group), _addr(self.channel), groups)
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+
+class Fold:
+    """GroupNorm (+ AdaGN style) of a tensor whose statistics sit in `acc`, to be folded by the consumer"""
+
+    def __init__(self, acc, gamma, beta, style, eps, count):
+        stride = 0
+        if style is not None:
+            if style.stride(1) != 1 or style.shape[1] != 2 * acc.c:
+                style = style.contiguous()
+            stride = style.stride(0)
+        self.acc, self.gamma, self.beta, self.style = acc, gamma, beta, style  # (keeps the tensors alive)
+        self.b, self.c = acc.b, acc.c
+        self.struct = _GnFoldStruct(_addr(acc.group), _addr(acc.channel), _addr(gamma), _addr(beta), _addr(style), stride,
+                                    acc.groups, float(eps), float(count))
+        self._arrays = None
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.struct)
+
+    def arrays(self, want_mean=False):
+        """scale, shift (, chmean) f32[b,c] through the stand-alone finisher, for consumers that take arrays"""
+        if self._arrays is None or (want_mean and self._arrays[2] is None):
+            dev = self.acc.group.device
+            scale = torch.empty(self.b, self.c, dtype=F32, device=dev)
+            shift = torch.empty_like(scale)
+            chmean = torch.empty_like(scale) if want_mean else None
+            call("p2pb_gn_fold_params", _i(self.b), _i(self.c), self.ref, ptr(scale), ptr(shift), ptr(chmean), stream_ptr())
+            self._arrays = (scale, shift, chmean)
+        return self._arrays if want_mean else self._arrays[:2]
+
+
+def _split_fold(in_scale, in_shift):
+    """consumer argument -> (fold ref | None, scale, shift)"""
+    if isinstance(in_scale, Fold):
+        return in_scale.ref, None, None
+    return None, in_scale, in_shift
+
+
+def _arrays_of(in_scale, in_shift):
+    if isinstance(in_scale, Fold):
+        return in_scale.arrays()
+    return in_scale, in_shift
+
+
 def conv_math() -> str:
     """arithmetic of the voxel convolutions: "bf16x6" (default: fp32 operands as three bf16 terms, six bf16 MFMA
     products per fp32 product, fp32 accumulate -- fp32-faithful, csrc/conv3d.hip) or "fp32" (exact-fp32 MFMA);
@@ -58,7 +202,8 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
 
 
 def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
-              skip_zero=False, compact=False, math=None, force_split=False, channels_last=False):
+              skip_zero=False, compact=False, math=None, force_split=False, channels_last=False, acc_groups=None,
+              acc_channel=False):
     """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None); with
     channels_last the grids are voxel-major, x f32[B,r,r,r,Cin] -> y f32[B,r,r,r,Cout] (the layout of the fused
     voxel branch: contiguous channels for the staging loads, the stores, voxelize and devoxelize).
@@ -69,14 +214,20 @@ def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in
     split = force_split or use_split(co, math)
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
-    st = None
-    if stats:
+    st = acc = None
+    if not split:
+        in_scale, in_shift = _arrays_of(in_scale, in_shift)  # (the exact-fp32 kernels take arrays / write partials)
+    if stats and split and acc_groups and gn_acc_enabled(f"conv{r}"):
+        acc = Acc(b, co, acc_groups, acc_channel, x.device)
+    elif stats:
         nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     flags = (1 if skip_zero else 0) | (2 if compact else 0) | (4 if split else 0) | (8 if channels_last else 0)
-    call("p2pb_conv3d_k3_forward_ex", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st), stream_ptr())
-    return y, st
+    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
+    call("p2pb_conv3d_k3_forward_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class), fold,
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st),
+         None if acc is None else acc.ref, stream_ptr())
+    return y, (acc if acc is not None else st)
 
 
 def brick_lists(cnt, r):
@@ -92,7 +243,7 @@ def brick_lists(cnt, r):
 
 
 def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                     out_class=None, math=None, channels_last=False):
+                     out_class=None, math=None, channels_last=False, acc_groups=None, acc_channel=False):
     """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second"""
     check(x, F32, "x")
     b, ci, r = (x.shape[0], x.shape[4], x.shape[1]) if channels_last else (x.shape[0], x.shape[1], x.shape[2])
@@ -100,14 +251,22 @@ def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None
     split = use_split(co, math)
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
-    nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
-    st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    st = acc = None
+    if not split:
+        in_scale, in_shift = _arrays_of(in_scale, in_shift)
+    if split and acc_groups and gn_acc_enabled(f"conv{r}"):
+        acc = Acc(b, co, acc_groups, acc_channel, x.device)
+    else:
+        nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
+        st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     act, ina = lists[2 * which], lists[2 * which + 1]
+    ca, ci_ = counts[2 * which:], counts[2 * which + 1:]
     flags = (4 if split else 0) | (8 if channels_last else 0)
-    call("p2pb_conv3d_k3_forward_sparse", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(act),
-         ptr(counts[2 * which:]), ptr(ina), ptr(counts[2 * which + 1:]), ptr(y), ptr(st), stream_ptr())
-    return y, st
+    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
+    call("p2pb_conv3d_k3_forward_sparse_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
+         ptr(out_class), fold, ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(act), ptr(ca),
+         ptr(ina), ptr(ci_), ptr(y), ptr(st), None if acc is None else acc.ref, stream_ptr())
+    return y, (acc if acc is not None else st)
 
 
 def active_lists(cnt, r):
@@ -123,7 +282,7 @@ def active_lists(cnt, r):
 
 
 def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                      out_class=None):
+                      out_class=None, acc_groups=None, acc_channel=False):
     """compact sparse conv on voxel-major grids (csrc/conv3d.hip): only the listed outputs of every brick are computed,
     the others get their constant. which = 0: first convolution of a PVConv (set D1); which = 1: second one in
     far-field form (set D2; in_sub / out_class from conv3d_far_field). x f32[B,r,r,r,Cin] -> (y f32[B,r,r,r,Cout], stats)"""
@@ -132,25 +291,33 @@ def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=Non
     co = conv.out_channels
     wt = pack_conv3d_weight(conv, True)
     y = torch.empty(b, r, r, r, co, dtype=F32, device=x.device)
-    nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
-    st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
-    call("p2pb_conv3d_k3_forward_compact", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(lists[which]), ptr(counts[which]), ptr(y), ptr(st),
-         stream_ptr())
-    return y, st
+    st = acc = None
+    if acc_groups and gn_acc_enabled(f"conv{r}"):
+        acc = Acc(b, co, acc_groups, acc_channel, x.device)
+    else:
+        nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
+        st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    al, ac = lists[which], counts[which]
+    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
+    call("p2pb_conv3d_k3_forward_compact_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
+         ptr(out_class), fold, ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(al), ptr(ac), ptr(y), ptr(st),
+         None if acc is None else acc.ref, stream_ptr())
+    return y, (acc if acc is not None else st)
 
 
 def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
     """far-field constants for the sparse form of `conv` applied to swish(affine(prev conv output)):
     a f32[B,Cin] (operand value where the previous conv saw only zeros, i.e. where its output == prev_bias) and
     K f32[B,27,Cout] (conv(a)+bias per boundary class)"""
-    b, ci = in_scale.shape
+    b, ci = (in_scale.b, in_scale.c) if isinstance(in_scale, Fold) else in_scale.shape
     co = conv.out_channels
     wt = pack_conv3d_weight(conv)
-    a = torch.empty(b, ci, dtype=F32, device=in_scale.device)
-    k = torch.empty(b, 27, co, dtype=F32, device=in_scale.device)
-    ws = torch.empty(b, 27, co, dtype=F32, device=in_scale.device)
-    call("p2pb_conv3d_k3_far_field", _i(b), _i(ci), _i(co), ptr(prev_bias), ptr(in_scale), ptr(in_shift),
+    dev = prev_bias.device
+    a = torch.empty(b, ci, dtype=F32, device=dev)
+    k = torch.empty(b, 27, co, dtype=F32, device=dev)
+    ws = torch.empty(b, 27, co, dtype=F32, device=dev)
+    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
+    call("p2pb_conv3d_k3_far_field_fx", _i(b), _i(ci), _i(co), ptr(prev_bias), fold, ptr(in_scale), ptr(in_shift),
          _i(int(swish)), ptr(wt), ptr(conv.bias), ptr(a), ptr(k), ptr(ws), stream_ptr())
     return a, k
 
@@ -172,6 +339,16 @@ def gn_affine_params(part, count_per_channel, groups, gamma, beta, style=None, e
     return scale, shift, chmean
 
 
+def se_gate_affine_fold(fold, fc1_weight, fc2_weight):
+    """the same from a Fold whose accumulators include the per-channel sums: the gate kernel folds the norm itself"""
+    dev = fc1_weight.device
+    a = torch.empty(fold.b, fold.c, dtype=F32, device=dev)
+    bb = torch.empty_like(a)
+    call("p2pb_se_gate_affine_fx", _i(fold.b), _i(fold.c), _i(fc1_weight.shape[0]), fold.ref, ptr(fc1_weight),
+         ptr(fc2_weight), ptr(a), ptr(bb), stream_ptr())
+    return a, bb
+
+
 def se_gate_affine(chmean, fc1_weight, fc2_weight, scale, shift):
     """SE3d gate folded into the devoxelisation affine: (scale, shift) * sigmoid(W2 relu(W1 chmean))"""
     b, c = chmean.shape
@@ -188,9 +365,11 @@ def devoxelize_affine(grid, vcoords, r, aff_a, aff_b, channels_last=False, add=N
     b, c = (grid.shape[0], grid.shape[4]) if channels_last else grid.shape[:2]
     n = vcoords.shape[2]
     out = torch.empty(b, c, n, dtype=F32, device=grid.device)
+    aff_a, aff_b = _arrays_of(aff_a, aff_b)
     aff_a, aff_b = aff_a.contiguous(), aff_b.contiguous()  # (named: temporaries inside the argument list could be freed
     if channels_last:                                      #  and their blocks reused before the launch)
         h, hs, hb = add if add is not None else (None, None, None)
+        hs, hb = _arrays_of(hs, hb)
         call("p2pb_trilinear_devoxelize_cl_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
              ptr(aff_a), ptr(aff_b), ptr(h), ptr(hs), ptr(hb), ptr(out), stream_ptr())
     else:
@@ -291,7 +470,7 @@ def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
 
 
 def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
-            use_bias=True, pool_u=None, store=True, math=None, point_major=False):
+            use_bias=True, pool_u=None, store=True, math=None, point_major=False, acc_groups=None):
     """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None).
     pool_u (0 = all positions, or the neighbourhood size): also returns the {min, max} tensor minmax_act()
     pools from -> (y | None, stats, minmax); store=False skips writing y altogether.
@@ -305,7 +484,7 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         # elementwise pre-pass (1 read + 1 write of the input) is cheaper than the recomputations. With the
         # XCD-aware workgroup order the blocks of one activation tile run side by side and up to 8 recomputations
         # measure faster than the extra pass (+0.9 % end to end), so the pass starts at 9 blocks (> 1024 channels)
-        x = affine_act(x, in_scale, in_shift, swish)
+        x = affine_act(x, *_arrays_of(in_scale, in_shift), swish)
         in_scale = in_shift = None
         swish = False
     wp = pack_pointwise_weight(conv, ci_lo, ci_hi, split)
@@ -315,21 +494,28 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         y = torch.empty(b, p, co, dtype=F32, device=x.device)
     else:
         y = torch.empty(b, co, p, dtype=F32, device=x.device) if (store or pool_u is None) else None
-    st = None
-    if stats or pool_u is not None:
+    st = acc = None
+    aligned = p % 4 == 0 and x.data_ptr() % 16 == 0  # (the unaligned fallback kernel takes arrays / writes partials)
+    if not aligned:
+        in_scale, in_shift = _arrays_of(in_scale, in_shift)
+    if (stats or pool_u is not None) and aligned and acc_groups and gn_acc_enabled("pws" if split else "pww"):
+        acc = Acc(b, co, acc_groups, False, x.device)
+    elif stats or pool_u is not None:
         nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     bias = conv.bias if use_bias else None
+    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
+    aref = None if acc is None else acc.ref
     if pool_u is None:
-        call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
-             ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), stream_ptr())
-        return y, st
+        call("p2pb_pointwise_conv_forward_fx", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b), fold,
+             ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), aref, stream_ptr())
+        return y, (acc if acc is not None else st)
     nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(pool_u), flags)
     mm = torch.empty((b, nmm // (b * co * 2), co, 2) if pool_u == 0 else (b, co, p // pool_u, 2), dtype=F32,
                      device=x.device)
-    call("p2pb_pointwise_conv_pool_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), _i(pool_u), ptr(mm), stream_ptr())
-    return y, st, mm
+    call("p2pb_pointwise_conv_pool_forward_fx", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b), fold,
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), aref, _i(pool_u), ptr(mm), stream_ptr())
+    return y, (acc if acc is not None else st), mm
 
 
 def minmax_act(mm, scale, shift, swish=True, global_pool=False):
@@ -338,17 +524,20 @@ def minmax_act(mm, scale, shift, swish=True, global_pool=False):
     if global_pool:
         b, nslots, c, _ = mm.shape
         y = torch.empty(b, c, dtype=F32, device=mm.device)
-        call("p2pb_minmax_act", _i(b), _i(c), _i(1), _i(nslots), ptr(mm), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
-             stream_ptr())
+        m = 1
     else:
         b, c, m, _ = mm.shape
+        nslots = 0
         y = torch.empty(b, c, m, dtype=F32, device=mm.device)
-        call("p2pb_minmax_act", _i(b), _i(c), _i(m), _i(0), ptr(mm), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
+    if isinstance(scale, Fold):
+        call("p2pb_minmax_act_fx", _i(b), _i(c), _i(m), _i(nslots), ptr(mm), scale.ref, _i(int(swish)), ptr(y), stream_ptr())
+    else:
+        call("p2pb_minmax_act", _i(b), _i(c), _i(m), _i(nslots), ptr(mm), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
              stream_ptr())
     return y
 
 
-def group_sub(z, cx, idx, point_major=False):
+def group_sub(z, cx, idx, point_major=False, acc_groups=None):
     """z f32[B,C,N], cx f32[B,C,M] | None, idx i32[B,M,U] -> (y f32[B,C,M*U] = z[:, :, idx] - cx[:, :, :, None],
     GroupNorm partials f32[B,nslots,C,2]): the grouped output of a set abstraction's first layer when that layer
     was applied to the ungrouped points (csrc/neighbors.hip group_sub_kernel). point_major: z f32[B,N,C] and
@@ -360,15 +549,19 @@ def group_sub(z, cx, idx, point_major=False):
         b, c, n = z.shape
     m, u = idx.shape[1], idx.shape[2]
     y = torch.empty(b, c, m * u, dtype=F32, device=z.device)
-    nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
-    st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
+    st = acc = None
+    if acc_groups and gn_acc_enabled("gsub"):
+        acc = Acc(b, c, acc_groups, False, z.device)
+    else:
+        nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
+        st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
     ws = None if point_major else torch.empty(b * (n + m) * c, dtype=F32, device=z.device)
-    call("p2pb_group_sub", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st), ptr(ws),
-         stream_ptr())
-    return y, st
+    call("p2pb_group_sub_fx", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st),
+         None if acc is None else acc.ref, ptr(ws), stream_ptr())
+    return y, (acc if acc is not None else st)
 
 
-def interp_add(cz, idx, w, add=None, bias=None, point_major=False):
+def interp_add(cz, idx, w, add=None, bias=None, point_major=False, acc_groups=None):
     """cz f32[B,C,M] (point_major: f32[B,M,C]), idx i32[B,3,N], w f32[B,3,N], add f32[B,C,N] | None, bias f32[C] | None
     -> (y f32[B,C,N] = sum_k w_k cz[:, :, idx_k] + add (+ bias), GroupNorm partials f32[B,nslots,C,2])"""
     check(cz, F32, "cz")
@@ -378,17 +571,22 @@ def interp_add(cz, idx, w, add=None, bias=None, point_major=False):
         b, c, m = cz.shape
     n = idx.shape[2]
     y = torch.empty(b, c, n, dtype=F32, device=cz.device)
-    nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(n), _i(1))
-    st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=cz.device)
+    st = acc = None
+    if acc_groups and gn_acc_enabled("interp"):
+        acc = Acc(b, c, acc_groups, False, cz.device)
+    else:
+        nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(n), _i(1))
+        st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=cz.device)
     ws = None if point_major else torch.empty(b * m * c, dtype=F32, device=cz.device)
-    call("p2pb_three_interpolate_add", _i(b), _i(c), _i(m), _i(n), ptr(cz), ptr(idx), ptr(w), ptr(add), ptr(bias),
-         ptr(y), ptr(st), ptr(ws), stream_ptr())
-    return y, st
+    call("p2pb_three_interpolate_add_fx", _i(b), _i(c), _i(m), _i(n), ptr(cz), ptr(idx), ptr(w), ptr(add), ptr(bias),
+         ptr(y), ptr(st), None if acc is None else acc.ref, ptr(ws), stream_ptr())
+    return y, (acc if acc is not None else st)
 
 
 def affine_act(x, scale, shift, swish=True, residual=None):
     """swish(x*scale[b,c]+shift[b,c]) (+ residual), x f32[B,C,P]"""
     b, c, p = x.shape
+    scale, shift = _arrays_of(scale, shift)
     y = torch.empty_like(x)
     if residual is not None:
         residual = residual.contiguous()
@@ -401,6 +599,7 @@ def affine_act_max(x, scale, shift, m, u, swish=True):
     """max over the last (neighbour) axis of swish(x*scale+shift): x f32[B,C,m*u] -> f32[B,C,m];
     u == 0: max over the whole row -> f32[B,C]"""
     b, c = x.shape[:2]
+    scale, shift = _arrays_of(scale, shift)
     y = torch.empty((b, c, m) if u else (b, c), dtype=F32, device=x.device)
     call("p2pb_affine_act_max", _i(b), _i(c), _i(m), _i(u), ptr(x), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
          stream_ptr())
