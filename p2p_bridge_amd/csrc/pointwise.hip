@@ -203,7 +203,7 @@ __device__ __forceinline__ void group_minmax(float &mn, float &mx, int g) {
 //   max_p act(scale*x_p + shift) = max(act(scale*min_p x_p + shift), act(scale*max_p x_p + shift)),
 // and the pooled tensor is produced by p2pb_minmax_act from 2/U-th of the data without the layer's
 // output ever being written or re-read.
-template <int MT, bool XF, bool STATS, bool POOL>
+template <int MT, bool XF, bool STATS, bool POOL, bool FX>  // FX: see pw_split_kernel
 __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int cout_pad, int P, int nslots,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias,
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
                                                       GnAcc gacc) {
   // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
   // producer's accumulators (common.h) -- the one barrier of this kernel
-  __shared__ float xtab[XF ? 2 * P2PB_FOLD_MAXC : 2];
+  __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
   };
   load_b(0, bnxt);
   load_a(0, a_nxt);
-  if (XF) {
+  const bool folded = FX && XF && fold.group != nullptr;  // (the caller's arrays: scalar loads, no LDS, no barrier)
+  if (folded) {
     xf_table(xtab, fold, in_scale, in_shift, b, cin);
     __syncthreads();
   }
@@ -271,8 +272,17 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
     if (XF) {
 #pragma unroll
       for (int kk = 0; kk < PWW_CK / 2; ++kk) {
-        const int cx = min(ci0 + 2 * kk + khalf, cin - 1);  // (uniform per half-wave: two LDS broadcasts)
-        const float sc = xtab[cx], sh = xtab[cin + cx];
+        float sc, sh;
+        if (folded) {
+          const int cx = min(ci0 + 2 * kk + khalf, cin - 1);  // (uniform per half-wave: two LDS broadcasts)
+          sc = xtab[cx];
+          sh = xtab[cin + cx];
+        } else {  // wave-uniform indices: the folded norm parameters travel through the scalar cache
+          const int ca = b * cin + min(ci0 + 2 * kk, cin - 1), cb = b * cin + min(ci0 + 2 * kk + 1, cin - 1);
+          const float sca = in_scale[ca], scb = in_scale[cb], sha = in_shift[ca], shb = in_shift[cb];
+          sc = khalf ? scb : sca;
+          sh = khalf ? shb : sha;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           float v = bcur[kk][s] * sc + sh;
@@ -367,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       if (STATS) {
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
-        if (gacc.group) {
+        if (FX && gacc.group) {
           if (l31 == 31 && co < cout) gn_run_add(grun, gacc, b, co, s1, s2);
         } else if (l31 == 31 && co < cout) {
           if (slot < nslots) {
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       }
     }
   }
-  if (STATS && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
+  if (FX && STATS && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
 }
 
 __global__ void pw_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, const float *__restrict__ w,
@@ -582,7 +592,10 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // tiles), every A fragment feeds four MFMAs instead of two and the weight tile is streamed from L2 once per 256
 // positions -- the 128 x 128 tiling moves 10.7 GB through L2 for the 512 -> 1024 x 262144 GEMM (6.4 GB of it the
 // pre-split weights, re-read by 2048 position blocks), 256 x 256 moves 5.3 GB.
-template <bool XF, bool POOL, int WM, int NB>
+// FX: the statistics plumbing of the sampler path (operand norm folded here from accumulators / output statistics added
+// to accumulators) is compiled in. A separate instantiation, because merely carrying the two argument structs through
+// the stage loop costs the plain form 5 % (scalar registers: the row descriptors already fill the SGPR file).
+template <bool XF, bool POOL, int WM, int NB, bool FX>
 #ifndef PWS_WM4_WAVES
 #define PWS_WM4_WAVES 4
 #endif
@@ -673,8 +686,11 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
   load_b(0);
   // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
   // producer's accumulators (common.h); published by the barrier at the top of the first stage
+  // (the caller's arrays keep travelling through the scalar cache: an LDS broadcast at the top of the transform phase
+  //  costs this kernel 1.2 % -- measured)
   float *xtab = (float *)(pws_lds + (WM / 2 + NB) * PWS_TILE);
-  if (XF) xf_table(xtab, fold, in_scale, in_shift, b, cin);
+  const bool folded = FX && XF && fold.group != nullptr;
+  if (folded) xf_table(xtab, fold, in_scale, in_shift, b, cin);
 
   for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
     __syncthreads();  // everyone is done reading the previous stage
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int c = min(ci0 + 8 * bgrp + i, cin - 1);
-          const float sc = xtab[c], sh = xtab[cin + c];
+          const float sc = folded ? xtab[c] : in_scale[b * cin + c], sh = folded ? xtab[cin + c] : in_shift[b * cin + c];
 #pragma unroll
           for (int q = 0; q < NBW; ++q)
 #pragma unroll
@@ -783,7 +799,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
   }
   if (!mact) return;
   pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
-                             stats_part, mm_out, pool_u, out_pm, gacc);
+                             stats_part, mm_out, pool_u, out_pm, FX ? gacc : GnAcc());
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
@@ -830,6 +846,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s,
                            const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
   const bool xf = in_scale != nullptr || fold.group != nullptr;
+  const bool fx = fold.group != nullptr || gacc.group != nullptr;
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
@@ -840,24 +857,29 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
   // 72 KB of dynamic LDS (above the 64 KB default): opt in once per instantiation
-#define LAUNCHW(XF, PL, WM, NB)                                                                                     \
+#define LAUNCHW(XF, PL, WM, NB, FXV)                                                                                \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
-    const int lds = (WM / 2 + NB) * PWS_TILE * 16 + (XF ? 2 * cin * 4 : 0);                                           \
+    const int lds = (WM / 2 + NB) * PWS_TILE * 16 + (fold.group ? 2 * cin * 4 : 0);                                   \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB>,                                        \
+      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
                                 (WM / 2 + NB) * PWS_TILE * 16 + 2 * P2PB_FOLD_MAXC * 4);                               \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, w,   \
-                       bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fold,     \
+    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
+                       w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fold,  \
                        gacc);                                                                                        \
+  } while (0)
+#define LAUNCHF(XF, PL, WM, NB)                          \
+  do {                                                   \
+    if (fx) LAUNCHW(XF, PL, WM, NB, true);                \
+    else LAUNCHW(XF, PL, WM, NB, false);                  \
   } while (0)
 #define LAUNCH(XF, PL)                    \
   do {                                    \
-    if (wm4) LAUNCHW(XF, PL, 4, 1);        \
-    else LAUNCHW(XF, PL, 2, 1);            \
+    if (wm4) LAUNCHF(XF, PL, 4, 1);        \
+    else LAUNCHF(XF, PL, 2, 1);            \
   } while (0)
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   if (xf && minmax) LAUNCH(true, true);
@@ -865,6 +887,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   else if (minmax) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
+#undef LAUNCHF
 #undef LAUNCHW
   return p2pb_launch_status();
 }
@@ -884,10 +907,16 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
   if (pw_wide_ok(P, in, out)) {
     dim3 grid((P + 511) / 512, (cout + 32 * MT - 1) / (32 * MT), b);
     const int nslots = (P + 255) / 256 * 4;
-#define LAUNCH(XF, ST, PL)                                                                                         \
-  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, nslots, \
-                     in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm, fold, \
-                     gacc)
+    const bool fx = fold.group != nullptr || gacc.group != nullptr;
+#define LAUNCHX(XF, ST, PL, FXV)                                                                                      \
+  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL, FXV>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P,      \
+                     nslots, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm, \
+                     fold, gacc)
+#define LAUNCH(XF, ST, PL)             \
+  do {                                 \
+    if (fx) LAUNCHX(XF, ST, PL, true);  \
+    else LAUNCHX(XF, ST, PL, false);    \
+  } while (0)
     if (minmax) {
       if (xf) LAUNCH(true, true, true);
       else LAUNCH(false, true, true);
@@ -896,6 +925,7 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
     else if (st) LAUNCH(false, true, false);
     else LAUNCH(false, false, false);
 #undef LAUNCH
+#undef LAUNCHX
     return p2pb_launch_status();
   }
   if (minmax || out_pm || fold.group || gacc.group) return P2PB_EINVAL;  // (the unaligned fallback: arrays / partials only)

@@ -80,16 +80,18 @@ class use_arena:
         _arena = self.prev
 
 
-GN_ACC_DEFAULT = "pws,conv8,conv16"
+GN_ACC_DEFAULT = "0"
 
 
 def gn_acc_enabled(kind=None) -> bool:
-    """which producers add their statistics to accumulators (the others write per-slot partials, finished by one
-    gn_affine launch per layer, as in round 2). The chip retires ~14 G 64-bit atomics/s (12 ns each on one 128-byte line:
-    tools/exp/atomic_contention.hip), so the form pays where a workgroup produces >~ 1000 outputs per atomic: the
-    LDS-tiled GEMM (`pws`) and the convolutions on the coarse grids (`conv8`, `conv16`); the streaming kernels
-    (`pww`, `gsub`, `interp`) and the 32^3 convolutions (`conv32`) lose more in their epilogues than the launch costs.
-    P2PB_GN_ACC: comma list of kinds, `1` = all, `0` = none."""
+    """which producers add their statistics to accumulators; the others write per-slot partials, finished by one
+    gn_affine launch per layer (the round-2 path). OFF by default -- built, verified and measured in round 2, it does not
+    pay on this chip: the 48 finishing launches of an evaluation cost ~0.2 ms under hipGraph replay (not the 0.6 ms the
+    profiler's per-launch overhead suggested), while the chip retires only ~14 G 64-bit atomics/s (12 ns each on one
+    128-byte line: tools/exp/atomic_contention.hip, profiles/r02_atomic_contention.txt) and the folded prologue + the
+    extra kernel arguments cost the dominant GEMM 5 %. Best measured subset `pws,conv8,conv16` (LDS-tiled GEMM + coarse
+    grids: 27 of 48 launches gone): -2.5 % end to end; all producers (`1`): -5 %.
+    P2PB_GN_ACC: comma list of kinds out of pws, pww, conv8, conv16, conv32, gsub, interp; `1` = all; `0` = none."""
     v = os.environ.get("P2PB_GN_ACC", GN_ACC_DEFAULT)
     if v == "0":
         return False

@@ -264,11 +264,12 @@ def test_network_acc_vs_partials(monkeypatch):
     outs = {}
     from p2p_bridge_amd import fused
 
-    for mode in ("1", fused.GN_ACC_DEFAULT, "0"):
+    assert fused.GN_ACC_DEFAULT == "0"  # (the product default: measured, the accumulators do not pay -- fused.gn_acc_enabled)
+    for mode in ("1", "pws,conv8,conv16", "0"):
         monkeypatch.setenv("P2PB_GN_ACC", mode)
         with torch.no_grad():
             outs[mode] = model.model(x, t)
-    for mode in ("1", fused.GN_ACC_DEFAULT):
+    for mode in ("1", "pws,conv8,conv16"):
         err = (outs[mode] - outs["0"]).abs().max().item()
         print(f"acc ({mode}) vs partials:", err)
         assert err < 2e-5 * outs["0"].abs().max().item() + 1e-6
