@@ -367,7 +367,9 @@ class P2PB(nn.Module):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: calls from OTHER threads during the capture (the RCCL watchdog of a multi-rank run polling its
+            # events) must not invalidate it; this thread's own calls are still checked
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 o_x, o_0 = self._one_step(net, s_x, s_c, None, s_cond, clip, s_n)
             entry = self._graphs[key] = (fp, g, s_x, s_c, s_n, s_cond, o_x, o_0)
         _, g, s_x, s_c, s_n, s_cond, o_x, o_0 = entry
