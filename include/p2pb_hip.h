@@ -106,6 +106,11 @@ int p2pb_furthest_point_sampling(int b, int n, int m, const float *coords, float
  * the device, so idx is valid either way). P2PB_EINVAL when the device cannot hold 64 workgroups at once. */
 size_t p2pb_fps_coop_ws_bytes(int b, int n);
 int p2pb_furthest_point_sampling_coop(int b, int n, int m, const float *coords, void *ws, int *idx, void *stream);
+/* The same indices for large clouds from ONE workgroup per cloud with exact pruning (sampling.hip: a 16^3 grid over the
+ * cloud; a round only revisits the cells whose bounding box is closer to the new sample than their current maximum --
+ * ~n/j points in round j instead of n). Any n >= 1; ws: p2pb_fps_grid_ws_bytes(b, n) bytes, 16-byte aligned. */
+size_t p2pb_fps_grid_ws_bytes(int b, int n);
+int p2pb_furthest_point_sampling_grid(int b, int n, int m, const float *coords, void *ws, int *idx, void *stream);
 
 /* point <-> triangle-mesh squared distances (P2M metric): replace pytorch3d._C.point_face_dist_forward /
  * face_point_dist_forward as called by metrics/p2m.py:66,131 for one (mesh, cloud) pair. points f32[np,3],

@@ -32,7 +32,7 @@ SYMBOLS = [
     "p2pb_gn_fold_params", "p2pb_conv3d_k3_forward_fx", "p2pb_conv3d_k3_forward_sparse_fx",
     "p2pb_conv3d_k3_forward_compact_fx", "p2pb_conv3d_k3_far_field_fx", "p2pb_se_gate_affine_fx",
     "p2pb_pointwise_conv_forward_fx", "p2pb_pointwise_conv_pool_forward_fx", "p2pb_minmax_act_fx", "p2pb_group_sub_fx",
-    "p2pb_three_interpolate_add_fx",
+    "p2pb_three_interpolate_add_fx", "p2pb_fps_grid_ws_bytes", "p2pb_furthest_point_sampling_grid",
 ]
 
 _lib = None
@@ -53,6 +53,7 @@ def lib():
         _lib.p2pb_target_arch.restype = ctypes.c_char_p
         _lib.p2pb_avg_voxelize_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_knn_points_ws_bytes.restype = ctypes.c_size_t
+        _lib.p2pb_fps_grid_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_three_nn_cells_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_fps_coop_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_conv3d_k3_packed_floats.restype = ctypes.c_size_t

@@ -381,3 +381,289 @@ extern "C" int p2pb_furthest_point_sampling_coop(int b, int n, int m, const floa
                        dist + (size_t)bi * n, idx + (size_t)bi * m, (const int *)(err + bi));
   return p2pb_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Large clouds, pruned (exact): a round of FPS only changes the running distance of points closer to the new sample
+// than their current value, and after j samples that is a neighbourhood of ~n/j points -- 1.4 M updates in all for
+// 50000 -> 12500 instead of 625 M. The cloud is binned into a 16^3 grid over its bounding box (fps_grid_build_kernel:
+// (x, y, z, id) records contiguous per cell + every cell's tight bounding box); ONE workgroup per cloud then keeps,
+// per cell, the 64-bit key of its farthest point (distance bits | tie-key: the reference's total order, so any
+// reduction order gives the reference's winner) and that point's coordinates, in the registers of the lane that owns
+// the cell. A round: every lane tests its four cells -- the squared distance from the new sample to the cell's box is a
+// LOWER bound of sqdist3 for every point inside, in fp32 too, because subtraction, multiplication and fma are monotone
+// under rounding, so a cell whose bound is >= its current maximum cannot change and is skipped; the wave recomputes
+// the others (all 64 lanes on one cell, exactly fps_kernel's arithmetic: sqdist3, fminf); then the argmax over the
+// cell keys, lane -> wave -> 16 slots in LDS, ONE barrier, the winner's coordinates riding along so that no dependent
+// global load sits on the round's critical path. (First version: a shared list of cells built with LDS atomics and
+// three barriers per round -- 2.4 us per round, of which 0.64 the list and 1.4 the barriers + reductions.)
+// Same indices as fps_kernel / the oracle for any cloud (duplicates, lattices, degenerate boxes included).
+// ------------------------------------------------------------------------------------------------
+#define FG_G 16
+#define FG_CELLS (FG_G * FG_G * FG_G)
+
+__global__ __launch_bounds__(1024) void fps_grid_build_kernel(int n, const float *__restrict__ coords,
+                                                              int *__restrict__ cell_start, float4 *__restrict__ rec,
+                                                              float *__restrict__ cbox) {
+  __shared__ int cnt[FG_CELLS];
+  __shared__ int part[1024];
+  __shared__ float red[6][16];
+  __shared__ float sbox[4];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float *c = coords + (size_t)b * 3 * n;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int k = t; k < n; k += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = c[k + (size_t)a * n];
+      lo[a] = fminf(lo[a], v);
+      hi[a] = fmaxf(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+    }
+    if (lane == 0) {
+      red[a][wave] = lo[a];
+      red[3 + a][wave] = hi[a];
+    }
+  }
+  for (int i = t; i < FG_CELLS; i += 1024) cnt[i] = 0;
+  __syncthreads();
+  if (t == 0) {
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+      float l = INFINITY, h = -INFINITY;
+      for (int w = 0; w < 16; ++w) {
+        l = fminf(l, red[a][w]);
+        h = fmaxf(h, red[3 + a][w]);
+      }
+      sbox[a] = l;
+      ext = fmaxf(ext, h - l);
+    }
+    sbox[3] = fmaxf(ext, 1e-12f) / FG_G;
+  }
+  __syncthreads();
+  const float inv = 1.0f / sbox[3];
+  auto cell_of = [&](int k) {  // (any deterministic binning will do: the boxes below are the points' own)
+    int q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float f = (c[k + (size_t)a * n] - sbox[a]) * inv;
+      q[a] = f >= 0.0f ? min((int)f, FG_G - 1) : 0;  // (NaN coordinates land in cell 0)
+    }
+    return (q[2] * FG_G + q[1]) * FG_G + q[0];
+  };
+  for (int k = t; k < n; k += 1024) atomicAdd(&cnt[cell_of(k)], 1);
+  __syncthreads();
+  int c4[4], tot = 0;  // exclusive scan of the 4096 counts: thread t owns cells 4t .. 4t+3
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c4[i] = cnt[4 * t + i];
+    tot += c4[i];
+  }
+  part[t] = tot;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - tot;
+  int *cs = cell_start + (size_t)b * (FG_CELLS + 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    cs[4 * t + i] = run;
+    cnt[4 * t + i] = run;  // becomes the fill cursor
+    run += c4[i];
+  }
+  if (t == 1023) cs[FG_CELLS] = run;
+  __syncthreads();
+  float4 *rc = rec + (size_t)b * n;
+  for (int k = t; k < n; k += 1024)
+    rc[atomicAdd(&cnt[cell_of(k)], 1)] = make_float4(c[k], c[k + (size_t)n], c[k + (size_t)2 * n], __int_as_float(k));
+  __syncthreads();
+  float *bx = cbox + (size_t)b * FG_CELLS * 6;  // the tight box of every cell's points
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cell = 4 * t + i, s0 = cs[cell], s1 = s0 + c4[i];
+    float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int x = s0; x < s1; ++x) {
+      const float4 r = rc[x];
+      l[0] = fminf(l[0], r.x), h[0] = fmaxf(h[0], r.x);
+      l[1] = fminf(l[1], r.y), h[1] = fmaxf(h[1], r.y);
+      l[2] = fminf(l[2], r.z), h[2] = fmaxf(h[2], r.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      bx[(size_t)cell * 6 + a] = l[a];
+      bx[(size_t)cell * 6 + 3 + a] = h[a];
+    }
+  }
+}
+
+// Cell ownership: wave w owns, in every (cy, cz) row of the grid, the cell with cx = (w - 3 cy - 9 cz) mod 16, lane l its
+// rows l, l + 64, l + 128, l + 192. The 27 cells of a 3x3x3 neighbourhood differ by dx + 3 dy + 9 dz, all distinct
+// in [-13, 13], so they fall on the 16 waves at most two apiece: the cells a sample can change are spread over the
+// waves by construction, every wave deals with its own without a list, an atomic or a barrier, and the only
+// workgroup-wide step of a round is the final argmax over 16 per-wave maxima.
+__device__ __forceinline__ int fg_cell(int wave, int row) {
+  const int cy = row & 15, cz = row >> 4;
+  return ((wave - 3 * cy - 9 * cz) & 15) + 16 * cy + 256 * cz;
+}
+
+__global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const float *__restrict__ coords,
+                                                        const int *__restrict__ cell_start,
+                                                        const float4 *__restrict__ rec, const float *__restrict__ cbox,
+                                                        float *__restrict__ mind, int *__restrict__ indices) {
+  __shared__ u64 slots[2][16];      // per-wave maxima (double-buffered by round parity: one barrier per round)
+  __shared__ float sxyz[2][16][4];  // ... and the coordinates of those points
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
+  const float *c = coords + (size_t)b * 3 * n;
+  const int *cs = cell_start + (size_t)b * (FG_CELLS + 1);
+  const float4 *rc = rec + (size_t)b * n;
+  const float *bxp = cbox + (size_t)b * FG_CELLS * 6;
+  float *md = mind + (size_t)b * n;
+  int *out = indices + (size_t)b * m;
+
+  // this lane's four cells: record range, tight box, key of the farthest point (distance bits | tie-key: the
+  // reference's total order) and that point's coordinates -- all in registers
+  int s0[4], cn[4];
+  float blo[4][3], bhi[4][3], cmax[4], cx[4], cy[4], cz[4];
+  u64 ckey[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cell = fg_cell(wave, lane + 64 * i);
+    s0[i] = cs[cell];
+    cn[i] = cs[cell + 1] - s0[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      blo[i][a] = bxp[(size_t)cell * 6 + a];
+      bhi[i][a] = bxp[(size_t)cell * 6 + 3 + a];
+    }
+    cmax[i] = cn[i] > 0 ? 1e38f : -1.0f;  // every point starts at 1e38 (PN2/pvcnn_sampling.cpp:56)
+    ckey[i] = 0;
+    cx[i] = cy[i] = cz[i] = 0.0f;
+  }
+  for (int k = t; k < n; k += 1024) md[k] = 1e38f;
+  if (t < 32) slots[t >> 4][t & 15] = 0;
+  if (t == 0) out[0] = 0;
+  float sx = c[0], sy = c[n], sz = c[(size_t)2 * n];  // sample 0 = point 0
+  __syncthreads();
+
+  for (int j = 1; j < m; ++j) {
+    // ---- the wave's cells this sample can change: the squared distance to the cell's box bounds sqdist3 of every
+    // point inside from below (also in fp32: the operations are monotone under rounding), so bound >= current
+    // maximum means nothing in the cell changes. Round 1 visits every cell: that is what initialises the keys.
+    // (Handing several cells of a wave to 16-lane rows through LDS so that their load latencies overlap measured
+    //  20 % SLOWER than taking them one after the other with all 64 lanes: a wave rarely has more than two.)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dx = fmaxf(fmaxf(blo[i][0] - sx, sx - bhi[i][0]), 0.0f);
+      const float dy = fmaxf(fmaxf(blo[i][1] - sy, sy - bhi[i][1]), 0.0f);
+      const float dz = fmaxf(fmaxf(blo[i][2] - sz, sz - bhi[i][2]), 0.0f);
+      const bool hit = cn[i] > 0 && (j == 1 || !(sqdist3(dx, dy, dz) >= cmax[i]));
+      unsigned long long todo = __ballot(hit);
+      while (todo) {  // (wave-uniform) all 64 lanes recompute one cell with exactly fps_kernel's arithmetic
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int p0 = __builtin_amdgcn_readlane(s0[i], src), pn = __builtin_amdgcn_readlane(cn[i], src);
+        u64 best = 0;
+        float bxv = 0.0f, byv = 0.0f, bzv = 0.0f;
+        for (int i0 = 0; i0 < pn; i0 += 256) {  // four points per lane in flight
+          float4 r[4];
+          float dold[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k = i0 + 64 * q + lane;
+            if (k < pn) {
+              r[q] = rc[p0 + k];
+              dold[q] = md[p0 + k];
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k = i0 + 64 * q + lane;
+            if (k < pn) {
+              const float d = sqdist3(r[q].x - sx, r[q].y - sy, r[q].z - sz);
+              const float d2 = fminf(d, dold[q]);
+              if (d2 != dold[q]) md[p0 + k] = d2;
+              const u64 key = fps_key(d2, __float_as_int(r[q].w));
+              if (key > best) {
+                best = key;
+                bxv = r[q].x, byv = r[q].y, bzv = r[q].z;
+              }
+            }
+          }
+        }
+        const u64 wbest = wave_max_u64(best);
+        const int from = __builtin_ctzll(__ballot(best == wbest));  // (keys are unique: the point index is part of them)
+        const float wx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bxv), from));
+        const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, byv), from));
+        const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bzv), from));
+        if (lane == src) {
+          ckey[i] = wbest;
+          cmax[i] = __uint_as_float((unsigned)(wbest >> 32) - 1u);
+          cx[i] = wx, cy[i] = wy, cz[i] = wz;
+        }
+      }
+    }
+    // ---- argmax: lane -> wave -> 16 slots
+    u64 key = ckey[0];
+    float kx = cx[0], ky = cy[0], kz = cz[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (ckey[i] > key) {
+        key = ckey[i];
+        kx = cx[i], ky = cy[i], kz = cz[i];
+      }
+    const u64 wkey = wave_max_u64(key);
+    if (key == wkey && (wkey != 0 ? true : lane == 0)) {  // (an all-empty wave: lane 0 writes the zero key)
+      slots[j & 1][wave] = wkey;
+      sxyz[j & 1][wave][0] = kx;
+      sxyz[j & 1][wave][1] = ky;
+      sxyz[j & 1][wave][2] = kz;
+    }
+    __syncthreads();
+    const u64 mine = slots[j & 1][t & 15];
+    const u64 v = row_max_u64(mine);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 15);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
+    const u64 fin = ((u64)hi << 32) | lo;
+    const int ws = __builtin_ctzll(__ballot(lane < 16 && mine == fin));
+    sx = sxyz[j & 1][ws][0];
+    sy = sxyz[j & 1][ws][1];
+    sz = sxyz[j & 1][ws][2];
+    if (t == 0) out[j] = fps_key_index(fin);
+  }
+}
+
+static size_t fps_grid_head_bytes(int b) { return (((size_t)b * (FG_CELLS + 1) * 4) + 15) & ~(size_t)15; }
+// cell_start i32[b][G^3+1] | cell boxes f32[b][G^3][6] | records float4[b][n] | running distances f32[b][n]
+extern "C" size_t p2pb_fps_grid_ws_bytes(int b, int n) {
+  return fps_grid_head_bytes(b) + (size_t)b * ((size_t)FG_CELLS * 6 * 4 + (size_t)n * 20);
+}
+
+// coords f32[b,3,n] -> idx i32[b,m], the indices of p2pb_furthest_point_sampling, for any n >= 1 (meant for n > 16384);
+// ws: p2pb_fps_grid_ws_bytes(b, n) bytes, 16-byte aligned. One workgroup per cloud.
+extern "C" int p2pb_furthest_point_sampling_grid(int b, int n, int m, const float *coords, void *ws, int *idx,
+                                                 void *stream) {
+  if (b <= 0 || n <= 0 || n >= (1 << 29) || m < 0 || !ws) return P2PB_EINVAL;
+  if (m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  // per-cloud regions are laid out array by array so that one launch serves the batch
+  char *w = (char *)ws;
+  int *cell_start = (int *)w;
+  w += fps_grid_head_bytes(b);
+  float *cbox = (float *)w;
+  w += (size_t)b * FG_CELLS * 6 * 4;
+  float4 *rec = (float4 *)w;
+  w += (size_t)b * n * 16;
+  float *mind = (float *)w;
+  hipLaunchKernelGGL(fps_grid_build_kernel, dim3(b), dim3(1024), 0, s, n, coords, cell_start, rec, cbox);
+  hipLaunchKernelGGL(fps_grid_kernel, dim3(b), dim3(1024), 0, s, n, m, coords, cell_start, rec, cbox, mind, idx);
+  return p2pb_launch_status();
+}

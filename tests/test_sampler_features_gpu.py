@@ -242,7 +242,7 @@ got = ext.furthest_point_sampling_forward(x.cuda(), 700)
 assert torch.equal(got.cpu(), ref)
 print("FALLBACKS", ext.fps_coop_fallbacks())
 '''
-    env = dict(os.environ)
+    env = dict(os.environ, P2PB_FPS_BIG="coop")  # (the default large-cloud kernel is the pruned one: tests/test_fps_grid_gpu.py)
     env.pop("P2PB_FPS_COOP_TEST_FALLBACK", None)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=240)
