@@ -55,7 +55,7 @@ def farthest_point_sampling(pcls, num_pnts):
     if num > n:
         raise ValueError(f"farthest_point_sampling: num_pnts={num} > N={n}")
     coords = pcls.transpose(1, 2).contiguous()
-    # (large clouds -- the merge of all patch outputs -- take the cooperative multi-workgroup kernel inside)
+    # (large clouds -- the merge of all patch outputs -- take the pruned large-cloud kernel inside: csrc/sampling.hip fps_grid_kernel)
     idx = _ext.furthest_point_sampling_forward(coords, num).long()  # [B,num]
     sampled = torch.gather(pcls, 1, idx[..., None].expand(b, num, 3))
     return sampled, [idx[i] for i in range(b)]

@@ -4,7 +4,7 @@ Host-side mirror of the reference's denoise_room.py (`create_patches` :352-421, 
 `update_prediction_noisy_batches` :263-289, `main` :424-577) with the device doing the work the reference gives to a
 sklearn KD-tree, numba and fpsample:
 
-    centres     third_party/pvcnn furthest_point_sample over the whole room            csrc/sampling.hip (cooperative FPS)
+    centres     third_party/pvcnn furthest_point_sample over the whole room            csrc/sampling.hip (pruned large-cloud FPS)
     patches     KDTree.query_radius(centres, r = 0.3 | 0.5)                            csrc/room.hip radius_count / fill
     resample    small patches: random duplicates + 1 % jitter; large: FPS subsets      host RNG draws + csrc/sampling.hip
     sampler     per-patch centre and scale (NOT the object pipeline's global scale)    P2PB.sample (hipGraph replay)
