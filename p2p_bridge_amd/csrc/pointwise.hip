@@ -802,6 +802,196 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
                              stats_part, mm_out, pool_u, out_pm, FX ? gacc : GnAcc());
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same 256-channel x 128-position tile with the two halves of a stage given to DIFFERENT waves ("warp
+// specialisation"): waves 0-3 only multiply (2 x 2 over the tile: 128 channels x 64 positions each, 128 accumulator
+// registers), waves 4-7 only stage -- LDS-DMA of the next stage's weight tile, next stage's activations loaded one
+// stage further ahead, folded norm + Swish, split, LDS writes -- into the OTHER of two LDS buffers; one s_barrier per
+// stage swaps them. In pw_split_kernel every wave does both, so a workgroup's matrix phase and its staging phase
+// exclude each other and the weight tile's DMA latency (L2 -> LDS, ~1 us) sits between two barriers of every stage;
+// only the second co-resident workgroup fills the matrix pipe meanwhile (measured: 49 % busy). Here one math wave and
+// one staging wave share each SIMD for the whole kernel: the matrix pipe sees an uninterrupted MFMA stream (96 per
+// stage and wave, fragments re-read per 16-channel step), VALU / LDS-write / DMA work issues beside it, and a math
+// wave reads 18 fragments per 48 MFMAs instead of 12 per 24. One workgroup per CU (2 x 72 KB of LDS, 8 waves).
+// Plain statistics form only (per-slot partials; no accumulator plumbing).
+// MEASURED (round 2, 512 -> 1024 x 8192 x 32, tools/exp_pw_big.py): correct (1.7e-6 vs fp64) but 2.03 ms against
+// pw_split_kernel's 1.59. Timing-only ablations of THIS kernel (-DPWS_EXP_*): staging waves alone (no MFMAs) 1.52 ms,
+// math waves alone (no DMA, no transform / split / LDS writes) 1.37 ms, no DMA 1.69, no transform / split 1.47: four
+// staging waves per CU are too few to hide the DMA's and the loads' latency (each side alone is as slow as the whole
+// symmetric kernel), the math waves read their 18 fragments in one burst per 16-channel step (the four of them
+// together: 73 KB through the LDS port while the matrix pipe idles), and a per-stage barrier adds the two sides'
+// variances. OFF unless P2PB_PW_WS=1; kept as the starting point for a 12-wave form (8 staging + 4 math waves, rolling
+// fragment reads to fit 170 registers).
+// ------------------------------------------------------------------------------------------------
+// wait + workgroup barrier as ONE opaque instruction pair: the "memory" clobber keeps the compiler from moving LDS /
+// global accesses across it, and nothing but the stated counters is waited for (__syncthreads() would drain the
+// activation loads that are meant to stay in flight across the barrier)
+#define PWS_WAIT_BARRIER(cnt) asm volatile("s_waitcnt " cnt "\n\ts_barrier" ::: "memory")
+template <bool XF, bool POOL>
+__global__ __launch_bounds__(512, 1) void pw_split_ws_kernel(int cin, int cout, int P, int nslots,
+                                                             const float *__restrict__ in, const u32x4 *__restrict__ wp,
+                                                             const float *__restrict__ bias,
+                                                             const float *__restrict__ bias_b,
+                                                             const float *__restrict__ in_scale,
+                                                             const float *__restrict__ in_shift, int in_swish,
+                                                             float *__restrict__ out, float *__restrict__ stats_part,
+                                                             float *__restrict__ mm_out, int pool_u) {
+  extern __shared__ u32x4 pws_lds[];  // two buffers of [A: 2 blocks of 128 channels | B: 128 positions]
+  constexpr int BUF = 3 * PWS_TILE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, khalf = lane >> 5;
+  // XCD-aware order, as pw_split_kernel
+  const int ncoblk = gridDim.y;
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned vid = nblk % 8 == 0 ? (lin % 8) * (nblk / 8) + lin / 8 : lin;
+  const int bx = (vid / ncoblk) % gridDim.x, by = vid % ncoblk;
+  const int b = vid / (ncoblk * gridDim.x);
+  const int pblk = bx * 128, co0 = by * 256;
+  const int nblk128 = (cout + 127) / 128;
+  const int nstage = (cin + PWS_CK - 1) / PWS_CK;
+
+  if (wave >= 4) {
+    // ================= staging waves: channel group lw (8 channels) of every stage, lane l positions 2l, 2l+1
+    const int lw = wave - 4, ltid = tid - 256;
+    const float *inb = in + (size_t)b * cin * P;
+    const int pl = pblk + 2 * lane;
+    const unsigned voff = (unsigned)(pl < P ? pl : P - 2) * 4u;  // clamped lanes stage garbage that is never stored
+    float braw[8][2];
+    auto load_b = [&](int st) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = min(st * PWS_CK + 8 * lw + i, cin - 1);  // beyond cin: finite garbage x zero weights
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, P * 4, 0x00020000);
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
+        braw[i][0] = v[0];
+        braw[i][1] = v[1];
+      }
+    };
+    const bool second_ok = by * 2 + 1 < nblk128;  // odd block count: the last workgroup has one block only
+    auto dma_a = [&](int st, u32x4 *dst) {  // 12 asynchronous 16-byte loads per lane: lane i of a wave lands at base + 16 i
+#ifdef PWS_EXP_NODMA
+      return;
+#endif
+      const u32x4 *src = wp + ((size_t)st * nblk128 + by * 2) * PWS_TILE;
+#pragma unroll
+      for (int i = 0; i < 12; ++i)
+        if (second_ok || i * 256 + ltid < PWS_TILE)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256 + ltid),
+                                           (__attribute__((address_space(3))) void *)(dst + i * 256 + lw * 64), 16, 0, 0);
+    };
+    auto stage_b = [&](int st, u32x4 *lds_b) {  // transform + split + write the registers of stage st
+#ifdef PWS_EXP_NOSTAGE
+      return;
+#endif
+      if (XF) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int c = b * cin + min(st * PWS_CK + 8 * lw + i, cin - 1);
+          const float sc = in_scale[c], sh = in_shift[c];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            float v = braw[i][e] * sc + sh;
+            if (in_swish) v = swishf(v);
+            braw[i][e] = v;
+          }
+        }
+      }
+      const int kstep = lw >> 1, kh = lw & 1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        u32x4 qq[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned p0, p1, p2;
+          split3(braw[2 * i][e], braw[2 * i + 1][e], p0, p1, p2);
+          qq[0][i] = p0;
+          qq[1][i] = p1;
+          qq[2][i] = p2;
+        }
+        // slot of position p of the block: (p & 1) * 64 + (p >> 1)   (even / odd de-interleaved)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * 128 + e * 64 + lane] = qq[s];
+      }
+    };
+    // prologue: stage 0 into buffer 0, stage 1's activations requested
+    dma_a(0, pws_lds);
+    load_b(0);
+    stage_b(0, pws_lds + 2 * PWS_TILE);
+    if (nstage > 1) {
+      load_b(1);
+      PWS_WAIT_BARRIER("vmcnt(8) lgkmcnt(0)");  // LDS writes done; all but the 8 newest loads done, i.e. the DMA
+    } else {
+      PWS_WAIT_BARRIER("vmcnt(0) lgkmcnt(0)");
+    }
+    for (int st = 0; st < nstage; ++st) {
+      if (st + 1 < nstage) {
+        u32x4 *buf = pws_lds + ((st + 1) & 1) * BUF;
+        dma_a(st + 1, buf);             // 12 DMA loads behind the 8 activation loads of stage st + 1
+        stage_b(st + 1, buf + 2 * PWS_TILE);  // (the compiler waits for exactly those 8: vmcnt(12))
+        if (st + 2 < nstage) {
+          load_b(st + 2);
+          PWS_WAIT_BARRIER("vmcnt(8) lgkmcnt(0)");
+        } else {
+          PWS_WAIT_BARRIER("vmcnt(0) lgkmcnt(0)");
+        }
+      } else {
+        PWS_WAIT_BARRIER("lgkmcnt(0)");
+      }  // (the barrier: math is done with buffer st & 1, buffer (st + 1) & 1 is complete)
+    }
+    return;
+  }
+
+  // ================= math waves: 2 (M) x 2 (N); a wave owns 128 channels x 64 positions
+  const int wm2 = wave >> 1, wn = wave & 1;
+  const bool mact = by * 2 + wm2 < nblk128;  // this wave's 128-channel block exists (wave-uniform)
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+  PWS_WAIT_BARRIER("lgkmcnt(0)");  // buffer 0 is complete
+  for (int st = 0; st < nstage; ++st) {
+#ifdef PWS_EXP_NOMATH
+    if (false) {
+#else
+    if (mact) {
+#endif
+      const u32x4 *lds_a = pws_lds + (st & 1) * BUF + wm2 * PWS_TILE;
+      const u32x4 *lds_b = pws_lds + (st & 1) * BUF + 2 * PWS_TILE;
+#pragma unroll
+      for (int kstep = 0; kstep < 2; ++kstep) {
+        u32x4 af[3][4], bf[3][2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n) bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * 128 + n * 64 + wn * 32 + l31];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) af[s][m] = lds_a[((kstep * 3 + s) * 2 + khalf) * 128 + m * 32 + l31];
+        }
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[t]][m]),
+                                                                  __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
+      }
+    }
+    PWS_WAIT_BARRIER("lgkmcnt(0)");  // (LDS reads of this buffer retired before the staging waves may overwrite it)
+  }
+  if (!mact) return;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    pws_epilogue<POOL, 4, 1>(*(f32x16(*)[2][2]) & acc[2 * h], b, bx, (int)gridDim.x, pblk, co0, 2 * wm2 + h, wn, l31, khalf,
+                             cout, P, nslots, bias, bias_b, out, stats_part, mm_out, pool_u, 0, GnAcc());
+}
+
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
 // channel = chunk*32 + kstep*16 + khalf*8 + idx
 __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, const float *__restrict__ w,
@@ -882,6 +1072,28 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     else LAUNCHF(XF, PL, 2, 1);            \
   } while (0)
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
+  // the 256-channel layers without statistics plumbing: math and staging on different waves (pw_split_ws_kernel)
+  static const int ws_env = getenv("P2PB_PW_WS") ? atoi(getenv("P2PB_PW_WS")) : 0;
+  if (wm4 && !fx && ws_env) {
+    const int lds = 2 * 3 * PWS_TILE * 16;
+#define LAUNCHS(XF, PL)                                                                                              \
+  do {                                                                                                               \
+    static bool once = false;                                                                                        \
+    if (!once) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void *)pw_split_ws_kernel<XF, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                lds);                                                                                \
+      once = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((pw_split_ws_kernel<XF, PL>), grid, dim3(512), lds, s, cin, cout, P, nslots, in, w, bias, bias_b, \
+                       in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                               \
+  } while (0)
+    if (xf && minmax) LAUNCHS(true, true);
+    else if (xf) LAUNCHS(true, false);
+    else if (minmax) LAUNCHS(false, true);
+    else LAUNCHS(false, false);
+#undef LAUNCHS
+    return p2pb_launch_status();
+  }
   if (xf && minmax) LAUNCH(true, true);
   else if (xf) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
