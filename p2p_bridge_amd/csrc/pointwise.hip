@@ -821,7 +821,10 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 // symmetric kernel), the math waves read their 18 fragments in one burst per 16-channel step (the four of them
 // together: 73 KB through the LDS port while the matrix pipe idles), and a per-stage barrier adds the two sides'
 // variances. OFF unless P2PB_PW_WS=1; kept as the starting point for a 12-wave form (8 staging + 4 math waves, rolling
-// fragment reads to fit 170 registers).
+// fragment reads to fit 170 registers). (Also measured and removed: symmetric waves with 16-channel stages into the
+// other of two 36 KB buffers -- same LDS as pw_split_kernel, two workgroups per CU, DMA and loads of stage s + 1 issued
+// before the MFMAs of stage s, one barrier per stage: correct, 1.73 ms against 1.58; 24 MFMAs per barrier, 4-byte
+// loads and 8-byte LDS writes cost more than the hidden DMA latency buys.)
 // ------------------------------------------------------------------------------------------------
 // wait + workgroup barrier as ONE opaque instruction pair: the "memory" clobber keeps the compiler from moving LDS /
 // global accesses across it, and nothing but the stated counters is waited for (__syncthreads() would drain the
@@ -1074,7 +1077,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   // the 256-channel layers without statistics plumbing: math and staging on different waves (pw_split_ws_kernel)
   static const int ws_env = getenv("P2PB_PW_WS") ? atoi(getenv("P2PB_PW_WS")) : 0;
-  if (wm4 && !fx && ws_env) {
+  if (wm4 && !fx && ws_env == 1) {
     const int lds = 2 * 3 * PWS_TILE * 16;
 #define LAUNCHS(XF, PL)                                                                                              \
   do {                                                                                                               \
