@@ -98,7 +98,7 @@ class SE3d(nn.Module):
         self.channel = channel
 
     def forward(self, x):
-        s = x.mean(-1).mean(-1).mean(-1)
+        s = x.mean((2, 3, 4))  # (the reference's .mean(-1).mean(-1).mean(-1) in one reduction: same value to rounding)
         return x * self.fc(s).view(x.shape[0], x.shape[1], 1, 1, 1)
 
 
@@ -193,6 +193,14 @@ class StyleBank:
     def evaluate(self, cond):
         self._refresh()
         return _Styles(cond, F.linear(cond, self.weight, self.bias), self.slices)
+
+    def evaluate_train(self, cond):
+        """the same ONE GEMM under autograd (training): the concatenation is part of the graph, so its backward hands
+        every AdaGN's Linear its own gradient slice -- 3 GEMMs per step instead of 3 per AdaGN (~140 launches fewer)"""
+        self._refresh()  # (slices only depend on the shapes)
+        w = torch.cat([m.emd.weight for m in self.mods], dim=0)
+        b = torch.cat([m.emd.bias for m in self.mods], dim=0)
+        return _Styles(cond, F.linear(cond, w, b), self.slices)
 
 
 class _Styles:
@@ -946,10 +954,10 @@ class PVCNN2Unet(nn.Module):
                 e = self.embed_feats
                 feats = dense.pointwise(dense.conv_norm_act(src, e[0], e[1], None, swish=True), e[3])
         cond = self.global_pnet(coords) if self.global_pnet is not None else None
-        if use_fused and cond is not None:
+        if cond is not None and x.is_cuda:
             if self._style_bank is None:
                 self._style_bank = StyleBank(self)
-            cond = self._style_bank.evaluate(cond)
+            cond = self._style_bank.evaluate(cond) if use_fused else self._style_bank.evaluate_train(cond)
         feats = torch.cat([coords, feats], dim=1)
         time_emb = None
         if t is not None:
