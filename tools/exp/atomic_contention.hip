@@ -1,6 +1,6 @@
 // How fast are 64-bit device-scope atomic adds without return when many waves hit the same place? One lane per wave
 // adds to acc[(wave_global % spread) * stride_bytes / 8]. Prints ns per atomic for spread = 1 (one address) and for
-// several strides (same line / neighbouring sectors / separate lines).   hipcc --offload-arch=gfx950 -O3 ... && ./a.out
+// several strides (same line / neighbouring sectors / separate lines).   hipcc --offload-arch=gfx950 -O3 tools/exp/atomic_contention.hip -o tools/exp/atomic_contention (built here, run on the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned long long *acc, int spread, int stride8, int reps) {
