@@ -146,9 +146,90 @@ def punet_transforms():
     print("punet_transforms.npz", os.path.getsize(os.path.join(OUT, "punet_transforms.npz")))
 
 
+
+
+
+def room_data():
+    """tests/golden/room_data.npz: the reference's OWN dataloaders (arkitscenes.py, scannetpp.py: ArkitNPZ, ScanNetPP,
+    NPZFolderTest) run on small synthetic npz trees with a seeded numpy RNG -> the input arrays and every output field.
+    python tools/make_golden_extra.py --room"""
+    import importlib
+    import shutil
+    import tempfile
+
+    ref_import.install()
+    tmp = tempfile.mkdtemp()
+    cwd = os.getcwd()
+    rng = np.random.RandomState(3)
+    out = {}
+    try:
+        # ---- ARKit: <root>/train/<room>/<visit>/points_0.npz with faro / iphone (xyz + rgb) and a feature array
+        faro = np.concatenate([rng.rand(300, 3) * [4, 3, 2.5] + [10, -5, 1], rng.rand(300, 3)], 1).astype(np.float32)
+        iphone = np.concatenate([rng.rand(200, 3) * [4, 3, 2.5] + [10, -5, 1], rng.rand(200, 3)], 1).astype(np.float32)
+        dino = rng.randn(200, 8).astype(np.float32)
+        d = os.path.join(tmp, "arkit", "train", "room1", "visitA")
+        os.makedirs(d)
+        np.savez(os.path.join(d, "points_0.npz"), faro=faro, iphone=iphone, dino=dino)
+        out.update(arkit_faro=faro, arkit_iphone=iphone, arkit_dino=dino)
+        ak = importlib.import_module("dataloaders.arkitscenes")
+        ds = ak.ArkitNPZ(os.path.join(tmp, "arkit"), mode="training", features="dino", augment=True)
+        for seed in (0, 1, 2, 3):  # both outcomes of the augmentation coin
+            np.random.seed(seed)
+            s = ds[0]
+            for k in ("hr_points", "lr_points", "hr_colors", "lr_colors", "lr_features"):
+                out[f"arkit_s{seed}_{k}"] = s[k].numpy()
+            out[f"arkit_s{seed}_center"], out[f"arkit_s{seed}_scale"] = np.asarray(s["center"]), np.asarray(s["scale"])
+        # ---- ScanNet++: <root>/<scene>/points_0.npz with clean / noisy (+ features), splits/ relative to the cwd
+        clean = np.concatenate([rng.rand(250, 3) * 5 - 1, rng.rand(250, 3)], 1)  # float64 on purpose
+        noisy = clean + np.concatenate([0.02 * rng.randn(250, 3), np.zeros((250, 3))], 1)
+        feats = rng.randn(250, 6).astype(np.float32)
+        os.makedirs(os.path.join(tmp, "snpp", "scene_a"))
+        os.makedirs(os.path.join(tmp, "snpp", "scene_b"))
+        np.savez(os.path.join(tmp, "snpp", "scene_a", "points_0.npz"), clean=clean, noisy=noisy, features=feats)
+        np.savez(os.path.join(tmp, "snpp", "scene_b", "points_0.npz"), clean=clean[:100], noisy=noisy[:100], features=feats[:100],
+                 center=np.zeros(3), scale=np.float64(2.0))
+        os.makedirs(os.path.join(tmp, "splits"))
+        open(os.path.join(tmp, "splits", "snpp_train.txt"), "w").write("scene_a\nscene_missing\n")
+        open(os.path.join(tmp, "splits", "snpp_val.txt"), "w").write("scene_b\n")
+        out.update(snpp_clean=clean, snpp_noisy=noisy, snpp_features=feats)
+        os.chdir(tmp)
+        sp = importlib.import_module("dataloaders.scannetpp")
+        ds = sp.ScanNetPP(os.path.join(tmp, "snpp"), mode="training", additional_features=True, augment=True)
+        assert len(ds) == 1
+        for seed in (0, 1, 2, 3):
+            np.random.seed(seed)
+            s = ds[0]
+            for k in ("noisy_points", "clean_points", "noisy_colors", "clean_colors", "noisy_features"):
+                out[f"snpp_s{seed}_{k}"] = s[k].numpy()
+            out[f"snpp_s{seed}_center"], out[f"snpp_s{seed}_scale"] = np.asarray(s["center"]), np.asarray(s["scale"])
+        dv = sp.ScanNetPP(os.path.join(tmp, "snpp"), mode="validation", additional_features=False, augment=True)
+        np.random.seed(5)
+        s = dv[0]  # stored center / scale: used as they are, nothing subtracted; validation never rotates
+        out.update(snpp_val_noisy_points=s["noisy_points"].numpy(), snpp_val_clean_points=s["clean_points"].numpy(),
+                   snpp_val_center=np.asarray(s["center"]), snpp_val_scale=np.asarray(s["scale"]))
+        # ---- flat test folder
+        pts = (rng.rand(150, 3) * 3 + 7).astype(np.float32)
+        os.makedirs(os.path.join(tmp, "flat"))
+        np.savez(os.path.join(tmp, "flat", "a.npz"), points=pts, dino=dino[:150])
+        s = sp.NPZFolderTest(os.path.join(tmp, "flat"), features="dino")[0]
+        out.update(flat_points=pts, flat_train_points=s["train_points"].numpy(), flat_center=np.asarray(s["train_points_center"]),
+                   flat_scale=np.asarray(s["train_points_scale"]), flat_features=s["features"].numpy())
+        ut = importlib.import_module("dataloaders.utils")
+        r, th = ut.random_rotate_pointcloud_horizontally(pts.T.copy(), theta=0.7)
+        out.update(rot_in=pts.T.copy(), rot_out=r, rot_theta=np.float64(th))
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(OUT, "room_data.npz"), **out)
+    print("room_data.npz", os.path.getsize(os.path.join(OUT, "room_data.npz")))
+
+
 if __name__ == "__main__":
     if "--punet" in sys.argv:
         punet_transforms()
+    elif "--room" in sys.argv:
+        room_data()
     else:
         main()
         punet_transforms()
+        room_data()
