@@ -7,6 +7,9 @@ emd.hip, p2m.hip). Same function / class names, arguments and result keys as the
   write_array_to_xyz             utils/utils.py:5-10            (the file format the next stage reads back)
   input_iter                     evaluate_objects.py:48-67      (noisy cloud normalised to the unit sphere)
   get_metrics                    models/evaluation.py:206-246   (CD x 1000, EMD x 1000, model loss)
+  evaluate, save_ptc             models/evaluation.py:64-203    (the in-training evaluation: sample the validation batches,
+                                                                 score prediction / input / condition against the ground truth;
+                                                                 the reference's matplotlib / wandb pictures are out of scope)
   calculate_cd, calculate_emd_exact_cuda   metrics/metrics.py:19-53, 111-136  (the `fast=False` branch)
   Evaluator / update_summary     models/evaluation.py:356-452   (cd_sph + p2f per shape, means, Summary_<dataset>.csv)
   denoise_and_evaluate           evaluate_objects.py:127-209 `sample` (resolutions x noise levels)
@@ -29,7 +32,7 @@ from . import metrics as M
 from .punet_data import NormalizeUnitSphere
 
 __all__ = ["load_xyz", "load_off", "write_array_to_xyz", "input_iter", "get_metrics", "calculate_cd",
-           "calculate_emd_exact_cuda", "Evaluator", "update_summary", "denoise_and_evaluate"]
+           "calculate_emd_exact_cuda", "evaluate", "save_ptc", "Evaluator", "update_summary", "denoise_and_evaluate"]
 
 
 # ------------------------------------------------------------------------------------------------ files
@@ -147,6 +150,54 @@ def get_metrics(gt, pred, model=None, fast: bool = True) -> Tuple[float, float, 
     cd = float(np.mean(calculate_cd(pred, gt))) * 1000
     loss = float(np.mean(model.loss(pred, gt).detach().cpu().numpy())) if model is not None else 0
     return cd, float(np.mean(calculate_emd_exact_cuda(pred, gt))) * 1000, loss
+
+
+def save_ptc(name: str, ptc, out_dir: str, step: int) -> None:
+    np.save("%s/%03d_%s.npy" % (out_dir, step, name), ptc.cpu().numpy())
+
+
+def _cfg(cfg, *path, default=None):
+    for key in path:
+        if cfg is None:
+            return default
+        cfg = cfg.get(key) if isinstance(cfg, dict) else getattr(cfg, key, None)
+    return default if cfg is None else cfg
+
+
+@torch.no_grad()
+def evaluate(model, val_loader, cfg, step: int, sampling: bool = False, save_npy: bool = False, fast: bool = False) -> dict:
+    """sample the first `cfg.sampling.accum_iter` validation batches and score them: {"cd", "emd", "mse"} of the
+    prediction, "*_noisy" of the sampler's input and "*_cond" of the condition cloud (PVDCond models) against the ground
+    truth, over the largest multiple of 128 points. save_npy (with sampling): `<cfg.out_sampling>/<step>_{pred,noisy,gt,cond}.npy`"""
+    from .train import get_data_batch
+
+    device = next(model.parameters()).device
+    preds, starts, gts, conds = [], [], [], []
+    for i, batch in enumerate(val_loader):
+        data = get_data_batch(batch=batch, cfg=cfg)
+        x_gt, x_cond, x_start = (None if t is None else t.to(device) for t in (data["x_gt"], data["x_cond"], data["x_start"]))
+        out = model.sample(x_start=x_start, x_cond=x_cond, clip=bool(_cfg(cfg, "diffusion", "clip", default=False)),
+                           use_ema=bool(_cfg(cfg, "use_ema", default=False)), verbose=False)
+        preds.append(out["x_pred"]), starts.append(out["x_start"]), gts.append(x_gt)
+        if _cfg(cfg, "model", "type") == "PVDCond" and x_cond is not None:
+            conds.append(x_cond[:, :3, :])
+        if i >= int(_cfg(cfg, "sampling", "accum_iter", default=1)) - 1:
+            break
+    pred, x_gt = torch.cat(preds), torch.cat(gts)
+    x_start = torch.cat(starts) if starts and starts[0] is not None else None
+    x_cond = torch.cat(conds) if conds else None
+    n = pred.shape[-1] - pred.shape[-1] % 128
+    pred, x_gt = pred[..., :n], x_gt[..., :n]
+    metrics = dict(zip(("cd", "emd", "mse"), get_metrics(x_gt, pred, model=model, fast=fast)))
+    for tag, cloud in (("noisy", x_start), ("cond", x_cond)):
+        if cloud is not None:
+            metrics.update(zip((f"cd_{tag}", f"emd_{tag}", f"mse_{tag}"), get_metrics(x_gt, cloud[..., :n], model=model, fast=fast)))
+    if sampling and save_npy:
+        out_dir = _cfg(cfg, "out_sampling")
+        for name, cloud in (("pred", pred), ("noisy", x_start), ("gt", x_gt), ("cond", x_cond)):
+            if cloud is not None:
+                save_ptc(name, cloud[..., :n], out_dir, step)
+    return metrics
 
 
 # ------------------------------------------------------------------------------------------------ per-shape evaluation

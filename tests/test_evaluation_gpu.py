@@ -211,3 +211,30 @@ def test_denoise_write_score_loop_with_the_real_sampler(ev, tmp_path):
         assert torch.isfinite(res).all() and (res - again).abs().max() <= 1e-6 + 1e-6 * again.abs().max()
         assert len(os.listdir(os.path.join(d, "steps", name))) == 2
     assert os.path.exists(os.path.join(d, "Summary_PUNet.csv"))
+
+
+def test_in_training_evaluate(ev, tmp_path):
+    """models/evaluation.py:76-203 without its pictures: the metrics of two accumulated validation batches equal
+    get_metrics on the concatenated sampler outputs; the npy dumps hold what was scored"""
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd import train as T
+
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    cfg = json.load(open(os.path.join(g, "tiny_cfg.json")))
+    w = np.load(os.path.join(g, "tiny_weights.npz"))
+    model = product.build_model(cfg, {k: torch.from_numpy(w[k]).float() for k in w.files}, device="cuda:0")
+    cfg = dict(cfg, sampling={"accum_iter": 2}, out_sampling=str(tmp_path))
+    cfg["data"] = dict(cfg["data"], dataset="PUNet")
+    it = T.synthetic_punet_batches(2, 1000, seed=4, device="cuda")
+    batches = [next(it) for _ in range(3)]  # the third is not consumed
+    torch.manual_seed(0)
+    m = ev.evaluate(model, batches, cfg, step=7, sampling=True, save_npy=True, fast=True)
+    assert set(m) == {"cd", "emd", "mse", "cd_noisy", "emd_noisy", "mse_noisy"}
+    pred, gt, noisy = (torch.from_numpy(np.load(os.path.join(str(tmp_path), "007_%s.npy" % n))) for n in ("pred", "gt", "noisy"))
+    assert pred.shape == (4, 3, 896) and gt.shape == pred.shape  # two batches of two, 1000 -> 896 = 7 x 128 points
+    want = torch.cat([b["clean_points"] for b in batches[:2]]).transpose(1, 2)[..., :896].cpu()
+    assert torch.equal(gt, want)
+    cd, emd, mse = ev.get_metrics(gt.cuda(), pred.cuda(), model=model, fast=True)
+    assert abs(cd - m["cd"]) < 1e-6 * cd and abs(emd - m["emd"]) < 1e-5 * emd and abs(mse - m["mse"]) < 1e-6 * abs(mse) + 1e-9
+    cdn, _, _ = ev.get_metrics(gt.cuda(), noisy.cuda(), model=model, fast=True)
+    assert abs(cdn - m["cd_noisy"]) < 1e-6 * cdn
