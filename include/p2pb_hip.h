@@ -33,6 +33,16 @@ extern "C" {
 /* library / device info --------------------------------------------------------------------- */
 int p2pb_version(void);            /* ABI version, bumps on signature change */
 const char *p2pb_target_arch(void); /* "gfx950" */
+/* Arithmetic of the split-operand matrix kernels (conv3d_k3 *_forward, pointwise_conv *_forward with >= 128 channels).
+ * The reference's layers are cuDNN / cuBLAS convolutions in fp32, which on its Ampere+ targets run as TF32
+ * (torch.backends.cudnn.allow_tf32 defaults to True; train.py:221 also sets float32_matmul_precision("high")).
+ * gfx950 has no TF32: an fp32 operand is split into bf16 terms x0 + x1 + x2 and a product is the sum of
+ *   6 terms (default): x2y0 + x1y1 + x0y2 + x1y0 + x0y1 + x0y0 -- within a quarter ulp of fp32;
+ *   3 terms:           x1y0 + x0y1 + x0y0                      -- relative error <= 2^-16 per product (TF32: 2^-11),
+ * accumulated in fp32. Process-wide; takes effect at the next launch (a captured graph keeps what it captured).
+ * -> 0, or P2PB_EINVAL for anything but 3 or 6. */
+int p2pb_set_split_terms(int terms);
+int p2pb_get_split_terms(void);
 
 /* Voxelization.forward normalisation (models/pvcnn.py:215-228): centre on the mean, divide by
  * 2*max-norm (+eps), +0.5, *r, clamp [0,r-1]; also the half-to-even rounded int voxel coords.

@@ -4,6 +4,15 @@
 extern "C" int p2pb_version(void) { return 1; }
 extern "C" const char *p2pb_target_arch(void) { return "gfx950"; }
 
+// products per split operand pair in the bf16 matrix kernels (common.h)
+int p2pb_g_split_terms = 6;
+extern "C" int p2pb_set_split_terms(int terms) {
+  if (terms != 6 && terms != 3) return P2PB_EINVAL;
+  p2pb_g_split_terms = terms;
+  return 0;
+}
+extern "C" int p2pb_get_split_terms(void) { return p2pb_g_split_terms; }
+
 // Zero-fill as an ordinary kernel node. hipMemsetAsync is avoided on purpose: under hipGraph stream
 // capture its memset node did not re-execute reliably on replay here (stale voxel counts -> OOB list
 // writes -> GPU memory fault after a few replays), a kernel node always does.

@@ -8,6 +8,8 @@
 #define P2PB_WAVE 64
 
 static inline int p2pb_launch_status() { return (int)hipGetLastError(); }
+// 6 (default: fp32-faithful) or 3 products per split operand pair; defined in abi.hip, set by p2pb_set_split_terms
+extern int p2pb_g_split_terms;
 
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 

@@ -422,12 +422,15 @@ __device__ __forceinline__ int lane_w(int l31) {
 // x0y1, y0 at the top of the tap (it is first needed by the third product) -- every LDS read has >= 2 NT MFMAs
 // in front of its first use without a second fragment buffer; A fragments come straight from L2, one tap ahead.
 // The scheduling barriers pin this order, else every load sinks to its first use.
-template <int NT, int HH, int HW, int PLANE>
+// TERMS == 3 (p2pb_set_split_terms): x1y0 + x0y1 + x0y0 only -- neither the low weight plane nor the low activation
+// plane is read; a dropped term is <= 2^-16 |x*y| (x1 <= 2^-8 |x|).
+template <int NT, int HH, int HW, int PLANE, int TERMS>
 __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, const u32x4 *wchunk,
                                            size_t wsplit_stride, size_t wtap_stride, const int (&nbase)[NT], int khalf) {
+  constexpr int NP = TERMS == 6 ? 3 : 2;  // operand planes in use
   u32x4 a_cur[3], bf[3][NT];
 #pragma unroll
-  for (int s = 0; s < 3; ++s) a_cur[s] = wchunk[s * wsplit_stride];
+  for (int s = 0; s < NP; ++s) a_cur[s] = wchunk[s * wsplit_stride];
   auto load_b = [&](int s, int toff) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
@@ -438,7 +441,7 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
       acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[pa]),
                                                        __builtin_bit_cast(bf16x8, bf[pb][n]), acc[n], 0, 0, 0);
   };
-  load_b(2, 0);
+  if constexpr (TERMS == 6) load_b(2, 0);
   load_b(1, 0);
 #pragma unroll
   for (int tap = 0; tap < CONV_NTAPS; ++tap) {
@@ -447,25 +450,28 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     u32x4 a_nxt[3];
     if (tap + 1 < CONV_NTAPS) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
+      for (int s = 0; s < NP; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
     }
     load_b(0, toff);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_term(0, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (tap + 1 < CONV_NTAPS) load_b(2, toff_n);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_term(1, 1);
-    mfma_term(2, 0);
-    mfma_term(1, 0);
+    if constexpr (TERMS == 6) {
+      mfma_term(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (tap + 1 < CONV_NTAPS) load_b(2, toff_n);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_term(1, 1);
+      mfma_term(2, 0);
+      mfma_term(1, 0);
+    }
     mfma_term(0, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TERMS == 3) mfma_term(1, 0);
     mfma_term(0, 0);
     if (tap + 1 < CONV_NTAPS) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) a_cur[s] = a_nxt[s];
+      for (int s = 0; s < NP; ++s) a_cur[s] = a_nxt[s];
     }
   }
 }
@@ -473,7 +479,7 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
 // FX: the sampler path's statistics plumbing (operand norm folded here from accumulators / output statistics added to
 // accumulators, common.h) is compiled in -- a separate instantiation (voxel-major form only), so that the plain form
 // carries neither the two argument structs nor the table
-template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX>
+template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX, int TERMS>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
             q[2][i] = p2;
           }
 #pragma unroll
-          for (int s = 0; s < 3; ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
+          for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
         }
       }
     }
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 
     const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
     const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
-    split_taps<NT, HH, HW, PLANE>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
+    split_taps<NT, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
   }
 
   float *outb = out + (size_t)b * cout * R3;
@@ -906,20 +912,25 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
   const unsigned short *w = (const unsigned short *)wt;
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
   if (fx && !cl) return P2PB_EINVAL;  // (the statistics plumbing exists in the voxel-major form only)
-#define LAUNCH(XF, CL, FXV)                                                                                           \
-  hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, FXV>), grid, dim3(256), 0, s, cin, cout, nchunk,       \
+  const bool terms3 = p2pb_g_split_terms == 3 && !fx && cl;  // (three-term form: voxel-major, no statistics plumbing)
+#define LAUNCHT(XF, CL, FXV, TM)                                                                                      \
+  hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk,   \
                      cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list,     \
                      brick_count, out, stats_part, fold, gacc)
+#define LAUNCH(XF, CL, FXV) LAUNCHT(XF, CL, FXV, 6)
   if (in_scale != nullptr || fold.group != nullptr) {
     if (fx) LAUNCH(true, true, true);
+    else if (terms3) LAUNCHT(true, true, false, 3);
     else if (cl) LAUNCH(true, true, false);
     else LAUNCH(true, false, false);
   } else {
     if (fx) LAUNCH(false, true, true);
+    else if (terms3) LAUNCHT(false, true, false, 3);
     else if (cl) LAUNCH(false, true, false);
     else LAUNCH(false, false, false);
   }
 #undef LAUNCH
+#undef LAUNCHT
   return p2pb_launch_status();
 }
 
@@ -1352,7 +1363,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
   return p2pb_launch_status();
 }
 
-template <int R, int WM, bool XF, bool FX>  // FX: see conv3d_k3_split_kernel
+template <int R, int WM, bool XF, bool FX, int TERMS>  // FX, TERMS: see conv3d_k3_split_kernel
 __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                                 const float *__restrict__ in,
                                                                 const unsigned short *__restrict__ wt,
@@ -1508,7 +1519,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
               q[2][i] = p2;
             }
 #pragma unroll
-            for (int s = 0; s < 3; ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
+            for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
           }
         }
       }
@@ -1521,7 +1532,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
       if (!any || NTC == 0) continue;
       const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
       const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
-      split_taps<NA, HH, HW, PLANE>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
+      split_taps<NA, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
     }
     if (NTC == 0) return;
 
@@ -1720,14 +1731,16 @@ extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r
   const bool wm1 = cout <= 32;  // one M-tile per workgroup, tiles dealt to four wave columns
   dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
-#define LAUNCHX(RR, WMV, XF, FXV)                                                                                     \
-  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, FXV>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad,   \
+  const bool terms3 = p2pb_g_split_terms == 3 && !fx;
+#define LAUNCHX(RR, WMV, XF, FXV, TM)                                                                                 \
+  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
                      in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part,   \
                      fold, gacc)
 #define LAUNCH(RR, WMV, XF)               \
   do {                                    \
-    if (fx) LAUNCHX(RR, WMV, XF, true);    \
-    else LAUNCHX(RR, WMV, XF, false);      \
+    if (fx) LAUNCHX(RR, WMV, XF, true, 6);           \
+    else if (terms3) LAUNCHX(RR, WMV, XF, false, 3); \
+    else LAUNCHX(RR, WMV, XF, false, 6);             \
   } while (0)
 #define GO(RR)                                                   \
   if (wm1) {                                                     \

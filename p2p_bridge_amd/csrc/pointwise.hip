@@ -595,7 +595,9 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // FX: the statistics plumbing of the sampler path (operand norm folded here from accumulators / output statistics added
 // to accumulators) is compiled in. A separate instantiation, because merely carrying the two argument structs through
 // the stage loop costs the plain form 5 % (scalar registers: the row descriptors already fill the SGPR file).
-template <bool XF, bool POOL, int WM, int NB, bool FX>
+// TERMS: products per operand pair -- 6 (fp32-faithful, the default) or 3 (x1y0 + x0y1 + x0y0: the low planes are neither
+// fetched, written nor read; relative error per product <= 2^-16, see conv3d.hip) -- selected by p2pb_set_split_terms
+template <bool XF, bool POOL, int WM, int NB, bool FX, int TERMS>
 #ifndef PWS_WM4_WAVES
 #define PWS_WM4_WAVES 4
 #endif
@@ -679,7 +681,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
     const bool second_ok = WM == 2 || by * 2 + 1 < nblk128;  // odd block count: the last workgroup has one block only
 #pragma unroll
     for (int i = 0; i < 6; ++i)
-      if (second_ok || i * NT + tid < PWS_TILE)
+      if ((second_ok || i * NT + tid < PWS_TILE) && (TERMS == 6 || (((i * NT + wave * 64) % PWS_TILE) / 256) % 3 != 2))
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * NT + tid),
                                          (__attribute__((address_space(3))) void *)(dst + i * NT + wave * 64), 16, 0, 0);
   };
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
           const int blk = WM == 2 ? q : (NB == 2 ? bsel : 0);
           const int slot = blk * 128 + (ONE ? (lane & 1) * 64 + 32 * bsel + (lane >> 1) : e * 64 + lane);
 #pragma unroll
-          for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * BS + slot] = qq[s];
+          for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s) lds_b[((kstep * 3 + s) * 2 + kh) * BS + slot] = qq[s];
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this stage's A tile has landed
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
     for (int kstep = 0; kstep < 2; ++kstep) {
       u32x4 af[3][2];
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #ifdef PWS_A_DIRECT
@@ -781,12 +783,12 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
       for (int nb = 0; nb < NB; ++nb) {
         u32x4 bf[3][2];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s)
 #pragma unroll
           for (int n = 0; n < 2; ++n)
             bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * BS + nb * 128 + n * 64 + wn * 32 + l31];
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 6 - TERMS; t < 6; ++t)
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1040,6 +1042,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
                            const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
   const bool xf = in_scale != nullptr || fold.group != nullptr;
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
+  const bool terms3 = p2pb_g_split_terms == 3;  // (plain form only: the accumulator plumbing stays on six terms)
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
@@ -1050,24 +1053,25 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
   // 72 KB of dynamic LDS (above the 64 KB default): opt in once per instantiation
-#define LAUNCHW(XF, PL, WM, NB, FXV)                                                                                \
+#define LAUNCHW(XF, PL, WM, NB, FXV, TM)                                                                              \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
     const int lds = (WM / 2 + NB) * PWS_TILE * 16 + (fold.group ? 2 * cin * 4 : 0);                                   \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV>,                                   \
+      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV, TM>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
                                 (WM / 2 + NB) * PWS_TILE * 16 + 2 * P2PB_FOLD_MAXC * 4);                               \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
+    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV, TM>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
                        w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fold,  \
                        gacc);                                                                                        \
   } while (0)
 #define LAUNCHF(XF, PL, WM, NB)                          \
   do {                                                   \
-    if (fx) LAUNCHW(XF, PL, WM, NB, true);                \
-    else LAUNCHW(XF, PL, WM, NB, false);                  \
+    if (fx) LAUNCHW(XF, PL, WM, NB, true, 6);             \
+    else if (terms3) LAUNCHW(XF, PL, WM, NB, false, 3);   \
+    else LAUNCHW(XF, PL, WM, NB, false, 6);               \
   } while (0)
 #define LAUNCH(XF, PL)                    \
   do {                                    \

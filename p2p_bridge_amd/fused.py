@@ -164,19 +164,41 @@ def _arrays_of(in_scale, in_shift):
     return in_scale, in_shift
 
 
+CONV_MATHS = ("bf16x6", "bf16x3", "fp32")
+SPLIT_MATHS = ("bf16x6", "bf16x3")
+_conv_math_override = None
+
+
 def conv_math() -> str:
-    """arithmetic of the voxel convolutions: "bf16x6" (default: fp32 operands as three bf16 terms, six bf16 MFMA
-    products per fp32 product, fp32 accumulate -- fp32-faithful, csrc/conv3d.hip) or "fp32" (exact-fp32 MFMA);
-    chosen with P2PB_CONV_MATH"""
-    m = os.environ.get("P2PB_CONV_MATH", "bf16x6")
-    if m not in ("bf16x6", "fp32"):
-        raise ValueError(f"P2PB_CONV_MATH must be bf16x6 or fp32, got {m!r}")
+    """arithmetic of the voxel convolutions and the >= 128-channel 1x1 layers, P2PB_CONV_MATH / set_conv_math():
+      "bf16x6" (default) fp32 operands as three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulate --
+               fp32-faithful (csrc/conv3d.hip); every parity number in DESIGN.md is quoted on it;
+      "bf16x3" the same kernels keeping three of the six products (include/p2pb_hip.h p2pb_set_split_terms): <= 2^-16
+               relative per product, 32x tighter than the TF32 the reference's cuDNN convolutions run in;
+      "fp32"   the exact-fp32 MFMA kernels"""
+    m = _conv_math_override or os.environ.get("P2PB_CONV_MATH", "bf16x6")
+    if m not in CONV_MATHS:
+        raise ValueError(f"P2PB_CONV_MATH must be one of {CONV_MATHS}, got {m!r}")
     return m
+
+
+def set_conv_math(name):
+    """-> the previous setting; None returns to the environment's. Process-wide (the split kernels read one global, set
+    through p2pb_set_split_terms); a captured hipGraph keeps the kernels it captured."""
+    global _conv_math_override
+    prev = conv_math()
+    if name is not None and name not in CONV_MATHS:
+        raise ValueError(f"conv math must be one of {CONV_MATHS}, got {name!r}")
+    _conv_math_override = name
+    rc = lib().p2pb_set_split_terms(3 if conv_math() == "bf16x3" else 6)
+    if rc != 0:
+        raise RuntimeError(f"p2pb_set_split_terms -> {rc}")
+    return prev
 
 
 def use_split(cout: int, math=None) -> bool:
     """bf16x6 split-operand kernel unless P2PB_CONV_MATH=fp32 (or math="fp32") asks for the exact-fp32 MFMA one"""
-    return (math or conv_math()) == "bf16x6"
+    return (math or conv_math()) in SPLIT_MATHS
 
 
 def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
@@ -467,7 +489,7 @@ PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/exp_
 def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
     """the bf16x6 GEMM (csrc/pointwise.hip pw_split_kernel) for the matrix-bound layers; narrow layers are
     HBM-bound and stay on the streaming fp32 kernel"""
-    return ((math or conv_math()) == "bf16x6" and ci >= PW_SPLIT_MIN_CIN and co >= PW_SPLIT_MIN_COUT
+    return ((math or conv_math()) in SPLIT_MATHS and ci >= PW_SPLIT_MIN_CIN and co >= PW_SPLIT_MIN_COUT
             and npos % 4 == 0)
 
 

@@ -458,7 +458,7 @@ def compact_plan():
 
     from . import fused
 
-    if fused.conv_math() != "bf16x6":  # the compact kernel exists in the split-operand arithmetic only
+    if fused.conv_math() not in fused.SPLIT_MATHS:  # the compact kernel exists in the split-operand arithmetic only
         return set(), set()
     spec = os.environ.get("P2PB_COMPACT", "16:16")
     parts = (spec.split(":") + [""])[:2]
