@@ -36,8 +36,25 @@ PVDS = dict(
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
-# the split kernel spends six bf16 MFMA products per fp32 product: its matrix-pipe ceiling in fp32-equivalent FLOP/s
+# (v_mfma_f32_32x32x16_f16 runs at the same rate.) A split kernel spends three (f16x3, the default) or six (bf16x6)
+# 16-bit MFMA products per fp32 product: its matrix-pipe ceiling in fp32-equivalent FLOP/s
 SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6
+
+
+def split_products():
+    from p2p_bridge_amd import fused
+
+    return 3 if fused.conv_math() == "f16x3" else 6
+
+
+def split_peak_tflops():
+    return BF16_MFMA_PEAK_TFLOPS / split_products()
+
+
+def split_peak_basis():
+    return (f"dense 16-bit MFMA peak 2516.6 / {split_products()} products per fp32 product "
+            + ("(f16x3: fp16-pair split operands, fp32 accumulate)" if split_products() == 3
+               else "(bf16x6 split operands, fp32 accumulate)"))
 CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample per network evaluation (PVDS)
 
 
@@ -96,14 +113,14 @@ def conv_roofline(model, x_start, reps=10):
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(SPLIT_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / SPLIT_PEAK_TFLOPS, 4), "traffic": None,
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(split_peak_tflops(), 1), "unit": "TFLOP/s",
+            "frac": round(achieved / split_peak_tflops(), 4), "traffic": None,
             "kernel": f"conv3d_k3_compact_kernel<{r},XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
                       f"(fp_layers.2.1.voxel_layers.4, the launch the sampler issues)",
             "listed_output_voxels": listed, "grid_voxels": B * r ** 3,
             "listed_fraction": round(listed / float(B * r ** 3), 4),
             "dense_equivalent_tflops": round(dense / (ms * 1e-3) / 1e12, 2),
-            "peak_basis": "dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 accumulate)",
+            "peak_basis": split_peak_basis(),
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 
@@ -156,7 +173,7 @@ def gemm_roofline(model, B, P, reps=10):
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
     split = fused.use_split_pw(ci, co, P, None)
-    peak = SPLIT_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
+    peak = split_peak_tflops() if split else F32_MFMA_PEAK_TFLOPS
     traffic = None
     try:
         vals = {}
@@ -177,8 +194,8 @@ def gemm_roofline(model, B, P, reps=10):
                              f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 6 * ci * co} B: "
                              "the activations are staged by 8 output-channel blocks, the per-XCD L2 absorbs 3/4 of that",
             "kernel": f"pw_split_kernel<XF=true,POOL=true,WM=4> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)",
-            "peak_basis": ("dense bf16 MFMA peak 2516.6 / 6 products per fp32 product (bf16x6 split operands, fp32 "
-                           "accumulate)" if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"),
+            "peak_basis": split_peak_basis() if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+            "frac_of_six_product_ceiling": round(achieved / SPLIT_PEAK_TFLOPS, 4) if split else None,
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 
@@ -186,12 +203,13 @@ def conv_math_note():
     from p2p_bridge_amd import fused
 
     m = fused.conv_math()
+    if m == "f16x3":
+        return ("fp32 operands, fp32 accumulate, fp32 results; products through the 16-bit matrix pipe as f16x3: every "
+                "operand an fp16 pair of its scaled value (22 significand bits), 3 exact MFMA products per fp32 product, "
+                "<= 3 * 2^-22 relative; error vs fp64 at or below the exact-fp32 MFMA kernel's (tests/test_conv_math_gpu.py)")
     if m == "bf16x6":
-        return ("fp32 results; voxel-conv products as bf16x6 split operands (3 bf16 terms each, 6 MFMA products, fp32 "
-                "accumulate; error vs fp64 equal to the fp32 MFMA kernel's)")
-    if m == "bf16x3":
-        return ("NOT the default: bf16x3 split operands (3 of the 6 products, <= 2^-16 relative per product; the "
-                "reference's cuDNN convolutions run in TF32, 2^-11)")
+        return ("fp32 results; products as bf16x6 split operands (3 bf16 terms each, 6 MFMA products, fp32 accumulate; "
+                "error vs fp64 equal to the fp32 MFMA kernel's)")
     return "exact-fp32 MFMA"
 
 
@@ -323,12 +341,13 @@ def main():
 
 
 def alt_math_leg(cfg, sd, x_start, args):
-    """NOT `value`: the same workload in the opt-in three-product arithmetic (fused.set_conv_math("bf16x3"): <= 2^-16
-    relative per product; the reference's cuDNN convolutions run in TF32, 2^-11), timed the same way on a fresh model
-    (its own captured graph), and how far its result is from the default's"""
+    """NOT `value`: the same workload in the other split arithmetic (bf16x6: six products, no range contract), timed the
+    same way on a fresh model (its own captured graph), and how far ONE network evaluation on identical inputs is from the
+    default's (a free-running 30-step sampler amplifies any difference through neighbour-index decisions, so its end
+    points are not comparable)"""
     from p2p_bridge_amd import fused, p2pb as product
 
-    fused.set_conv_math("bf16x3")
+    fused.set_conv_math("bf16x6")
     try:
         model = product.build_model(cfg, sd, device=str(x_start.device))
         run = lambda: model.sample(x_start=x_start, steps=args.T, log_count=1, verbose=False, graph=bool(args.graph))
@@ -340,19 +359,17 @@ def alt_math_leg(cfg, sd, x_start, args):
             out = run()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        # one network evaluation on identical inputs in both arithmetics (a free-running 30-step sampler amplifies any
-        # difference through neighbour-index decisions, so its end points are not comparable)
         t = torch.full((x_start.shape[0],), 500.0, device=x_start.device)
         model.eval()
         with torch.no_grad():
-            e3 = model.model(x_start, t).clone()
+            e6 = model.model(x_start, t).clone()
             fused.set_conv_math(None)
-            e6 = model.model(x_start, t)
+            e3 = model.model(x_start, t)
         diff = float((e3 - e6).abs().max().item())
         assert torch.isfinite(out["x_pred"]).all()
     finally:
         fused.set_conv_math(None)
-    return {"conv_math": "bf16x3 (opt-in, P2PB_CONV_MATH=bf16x3; not the headline)",
+    return {"conv_math": "bf16x6 (P2PB_CONV_MATH=bf16x6; not the headline)",
             "value": round(args.batch * args.points * args.steps / dt, 1), "unit": "points/s",
             "ms_per_step": round(dt / args.steps * 1e3, 2), "max_abs_diff_of_one_evaluation_vs_default": diff}
 

@@ -36,11 +36,16 @@ const char *p2pb_target_arch(void); /* "gfx950" */
 /* Arithmetic of the split-operand matrix kernels (conv3d_k3 *_forward, pointwise_conv *_forward with >= 128 channels).
  * The reference's layers are cuDNN / cuBLAS convolutions in fp32, which on its Ampere+ targets run as TF32
  * (torch.backends.cudnn.allow_tf32 defaults to True; train.py:221 also sets float32_matmul_precision("high")).
- * gfx950 has no TF32: an fp32 operand is split into bf16 terms x0 + x1 + x2 and a product is the sum of
- *   6 terms (default): x2y0 + x1y1 + x0y2 + x1y0 + x0y1 + x0y0 -- within a quarter ulp of fp32;
- *   3 terms:           x1y0 + x0y1 + x0y0                      -- relative error <= 2^-16 per product (TF32: 2^-11),
- * accumulated in fp32. Process-wide; takes effect at the next launch (a captured graph keeps what it captured).
- * -> 0, or P2PB_EINVAL for anything but 3 or 6. */
+ * gfx950 has no TF32: an fp32 operand is split into 16-bit terms and a product is a sum of matrix products, fp32 accumulate:
+ *    6 (default) bf16 terms x0 + x1 + x2: x2y0 + x1y1 + x0y2 + x1y0 + x0y1 + x0y0 -- within a quarter ulp of fp32;
+ *    3           the same split:          x1y0 + x0y1 + x0y0 -- <= 3 * 2^-18 relative per product (TF32: 2^-11);
+ *   16           fp16 pair h0 + h1 of the SCALED operand, h1g0 + h0g1 + h0g0 -- <= 3 * 2^-22 relative per product inside
+ *                fp16's range: activations are multiplied by 4 and saturate at |x| = 16376, below |x| = 2^-5 the
+ *                representation error is an absolute 2^-27; weights get a per-tensor power-of-two scale at pack time.
+ * Process-wide; takes effect at the next launch (a captured graph keeps what it captured). The *_pack_weights_split
+ * functions pack for the arithmetic selected when they are called: packs made under 6 / 3 are interchangeable, a pack
+ * made under 16 is only valid under 16 (and vice versa) -- re-pack after such a switch.
+ * -> 0, or P2PB_EINVAL for anything but 3, 6 or 16. */
 int p2pb_set_split_terms(int terms);
 int p2pb_get_split_terms(void);
 

@@ -71,7 +71,7 @@ def lib():
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here = stale library
         # products per split operand pair (include/p2pb_hip.h; fused.conv_math / set_conv_math)
-        _lib.p2pb_set_split_terms(3 if os.environ.get("P2PB_CONV_MATH") == "bf16x3" else 6)
+        _lib.p2pb_set_split_terms(6 if os.environ.get("P2PB_CONV_MATH") in ("bf16x6", "fp32") else 16)
     return _lib
 
 

@@ -5,9 +5,9 @@ extern "C" int p2pb_version(void) { return 1; }
 extern "C" const char *p2pb_target_arch(void) { return "gfx950"; }
 
 // products per split operand pair in the bf16 matrix kernels (common.h)
-int p2pb_g_split_terms = 6;
+int p2pb_g_split_terms = SPLIT_F16X3;
 extern "C" int p2pb_set_split_terms(int terms) {
-  if (terms != 6 && terms != 3) return P2PB_EINVAL;
+  if (terms != SPLIT_BF16X6 && terms != SPLIT_F16X3) return P2PB_EINVAL;
   p2pb_g_split_terms = terms;
   return 0;
 }

@@ -8,7 +8,7 @@
 #define P2PB_WAVE 64
 
 static inline int p2pb_launch_status() { return (int)hipGetLastError(); }
-// 6 (default: fp32-faithful) or 3 products per split operand pair; defined in abi.hip, set by p2pb_set_split_terms
+// arithmetic of the split-operand kernels: SPLIT_F16X3 (default) or SPLIT_BF16X6; defined in abi.hip, p2pb_set_split_terms
 extern int p2pb_g_split_terms;
 
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
@@ -48,6 +48,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // (a, b) -> the three bf16 terms of each, packed as pairs (a in the low half): x = x0 + x1 + x2 with
 // x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round-to-nearest-even (v_cvt_pk_bf16_f32); both
@@ -62,6 +63,61 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned 
   p0 = __builtin_bit_cast(unsigned, q0);
   p1 = __builtin_bit_cast(unsigned, q1);
   p2 = __builtin_bit_cast(unsigned, q2);
+}
+
+// ---- fp16-pair split (SPLIT_F16X3): x*S = h0 + h1 with h0 = fp16(x*S), h1 = fp16(x*S - h0), round-to-nearest-even ----
+// fp16 carries 11 significand bits, so two terms carry 22 and a product evaluated as h1*g0 + h0*g1 + h0*g0 (fp16 x fp16
+// is exact in fp32) misses the exact one by <= 3 * 2^-22 |x*y| -- three matrix products instead of the six of the bf16
+// split, at the price of fp16's exponent range. Activations are scaled by SPLIT_F16_SX and saturated at the largest
+// finite fp16 (|x| < 16376 is exact range); below |x*S| = 2^-3 the low term is subnormal and the representation error
+// is an ABSOLUTE 2^-25 / S (3.7e-9) instead of a relative 2^-22. Weights get a per-tensor power-of-two scale chosen at
+// pack time from max |w| (always in range); 1 / (S_x * S_w) is stored behind the packed weights and applied to the
+// accumulators (exact: a power of two).
+#define SPLIT_BF16X6 6
+#define SPLIT_BF16X3 3
+#define SPLIT_F16X3 16
+#define SPLIT_F16_SX 4.0f
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h(float a, float b, unsigned &p0, unsigned &p1) {
+  f32x2 v = {__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+  const f16x2 q0 = __builtin_convertvector(v, f16x2);
+  v = v - __builtin_convertvector(q0, f32x2);
+  const f16x2 q1 = __builtin_convertvector(v, f16x2);
+  p0 = __builtin_bit_cast(unsigned, q0);
+  p1 = __builtin_bit_cast(unsigned, q1);
+}
+// the split of one staged pair in the arithmetic MODE (6 / 3: bf16 terms; 16: fp16 pair of the scaled value)
+template <int MODE>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned &p0, unsigned &p1, unsigned &p2) {
+  if constexpr (MODE == SPLIT_F16X3) {
+    split2h(a * SPLIT_F16_SX, b * SPLIT_F16_SX, p0, p1);
+    p2 = 0u;
+  } else {
+    split3(a, b, p0, p1, p2);
+  }
+}
+constexpr __host__ __device__ int split_planes(int mode) { return mode == SPLIT_BF16X6 ? 3 : 2; }
+template <int MODE>
+__device__ __forceinline__ f32x16 split_mfma(const u32x4 &a, const u32x4 &b, const f32x16 &c) {
+  if constexpr (MODE == SPLIT_F16X3)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// pack-time weight scale of the fp16 mode: the power of two that brings max |w| into [2^13, 2^14)
+__device__ __forceinline__ float f16_weight_scale(float wmax) {
+  if (!(wmax > 0.0f)) return 1.0f;
+  int e;
+  (void)frexpf(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)
+  return ldexpf(1.0f, 14 - e);
+}
+// max |w| of a tensor into *slot (uint bits of a non-negative float order like the float), slot zeroed before
+static __global__ void absmax_bits_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ slot) {
+  float m = 0.0f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(slot, __builtin_bit_cast(unsigned, m));
 }
 
 // ---- 32 rows x 32 lanes -> one row total per lane ("reduce-scatter" over the half-wave) ----

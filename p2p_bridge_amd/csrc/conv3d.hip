@@ -32,7 +32,6 @@
 #include "common.h"
 #include <type_traits>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define CONV_CK 8  // input channels per LDS stage
@@ -372,11 +371,18 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
 // are those of the fp32 kernel; the split happens once per staged element and is reused by 27 taps.
 // ================================================================================================
 #define CONV_SCK 16  // input channels per LDS stage of the split kernel = K of one bf16 MFMA
+// byte offset of the trailer {max|w| bits, 1 / (S_x S_w)} behind a split pack (fp16 mode, common.h)
+static __host__ __device__ size_t conv_split_trailer_bytes(int nchunk, int cout_pad) {
+  return (size_t)27 * nchunk * 3 * 2 * cout_pad * 8 * sizeof(unsigned short);
+}
 
 // packed weights: wt[tap][chunk16][split 3][khalf 2][cout_pad][8 bf16]; element idx = channel chunk*16 + khalf*8 + idx
+// mode SPLIT_F16X3 (common.h): planes 0, 1 = the fp16 pair of w * S_w, plane 2 unused; trailer = {max|w| bits, 1 / (S_x S_w)}
 __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
-                                        unsigned short *__restrict__ wt) {
+                                        unsigned short *__restrict__ wt, int mode, float *__restrict__ trailer) {
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;  // one thread per (tap, chunk, khalf, co, idx)
+  const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(trailer[0]) : 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int idx = (int)(e & 7);
     size_t q = e >> 3;
@@ -388,7 +394,12 @@ __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout
     const int ci = chunk * CONV_SCK + kh * 8 + idx;
     const float x = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 27 + tap] : 0.0f;
     unsigned p0, p1, p2;
-    split3(x, 0.0f, p0, p1, p2);
+    if (mode == SPLIT_F16X3) {
+      split2h(x * sw, 0.0f, p0, p1);
+      p2 = 0u;
+    } else {
+      split3(x, 0.0f, p0, p1, p2);
+    }
     const unsigned p[3] = {p0, p1, p2};
     for (int s = 0; s < 3; ++s)
       wt[((((size_t)(tap * nchunk + chunk) * 3 + s) * 2 + kh) * cout_pad + co) * 8 + idx] = (unsigned short)(p[s] & 0xffff);
@@ -422,12 +433,14 @@ __device__ __forceinline__ int lane_w(int l31) {
 // x0y1, y0 at the top of the tap (it is first needed by the third product) -- every LDS read has >= 2 NT MFMAs
 // in front of its first use without a second fragment buffer; A fragments come straight from L2, one tap ahead.
 // The scheduling barriers pin this order, else every load sinks to its first use.
-// TERMS == 3 (p2pb_set_split_terms): x1y0 + x0y1 + x0y0 only -- neither the low weight plane nor the low activation
-// plane is read; a dropped term is <= 2^-16 |x*y| (x1 <= 2^-8 |x|).
+// TERMS == SPLIT_F16X3 (the default, p2pb_set_split_terms): the fp16-pair split of common.h -- two operand planes, three
+// products h1g0, h0g1, h0g0 (<= 3 * 2^-22 |x*y| inside fp16's range); the third plane of tile / pack is then unused.
+// (The same three products of the bf16 split -- TERMS == SPLIT_BF16X3, <= 3 * 2^-18 -- were measured at the same speed
+// and 6.4e-5 network error, at the 1e-4 parity bar instead of inside it: superseded, not instantiated.)
 template <int NT, int HH, int HW, int PLANE, int TERMS>
 __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, const u32x4 *wchunk,
                                            size_t wsplit_stride, size_t wtap_stride, const int (&nbase)[NT], int khalf) {
-  constexpr int NP = TERMS == 6 ? 3 : 2;  // operand planes in use
+  constexpr int NP = split_planes(TERMS);  // operand planes in use
   u32x4 a_cur[3], bf[3][NT];
 #pragma unroll
   for (int s = 0; s < NP; ++s) a_cur[s] = wchunk[s * wsplit_stride];
@@ -438,8 +451,7 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
   auto mfma_term = [&](int pa, int pb) {
 #pragma unroll
     for (int n = 0; n < NT; ++n)
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_cur[pa]),
-                                                       __builtin_bit_cast(bf16x8, bf[pb][n]), acc[n], 0, 0, 0);
+      acc[n] = split_mfma<TERMS>(a_cur[pa], bf[pb][n], acc[n]);
   };
   if constexpr (TERMS == 6) load_b(2, 0);
   load_b(1, 0);
@@ -467,7 +479,7 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     __builtin_amdgcn_sched_barrier(0);
     if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TERMS == 3) mfma_term(1, 0);
+    if constexpr (TERMS != 6) mfma_term(1, 0);
     mfma_term(0, 0);
     if (tap + 1 < CONV_NTAPS) {
 #pragma unroll
@@ -655,13 +667,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             unsigned p0, p1, p2;
-            split3(stg[h * 8 + 2 * i][j], stg[h * 8 + 2 * i + 1][j], p0, p1, p2);
+            split_pair<TERMS>(stg[h * 8 + 2 * i][j], stg[h * 8 + 2 * i + 1][j], p0, p1, p2);
             q[0][i] = p0;
             q[1][i] = p1;
             q[2][i] = p2;
           }
 #pragma unroll
-          for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
+          for (int s = 0; s < split_planes(TERMS); ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
         }
       }
     }
@@ -676,6 +688,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
     const u32x4 *wchunk = (const u32x4 *)wt + (((size_t)(ci0 / CONV_SCK) * 3) * 2 + khalf) * cout_pad + co0 + l31;
     const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
     split_taps<NT, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
+  }
+  if constexpr (TERMS == SPLIT_F16X3) {  // 1 / (S_x S_w): a power of two stored behind the pack
+    const float oscale = ((const float *)((const char *)wt + conv_split_trailer_bytes(nchunk, cout_pad)))[1];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] *= oscale;
   }
 
   float *outb = out + (size_t)b * cout * R3;
@@ -784,15 +803,25 @@ extern "C" size_t p2pb_conv3d_k3_packed_floats(int cout, int cin) {
 
 extern "C" size_t p2pb_conv3d_k3_split_packed_bytes(int cout, int cin) {
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
-  return (size_t)27 * nchunk * 3 * 2 * cout_pad * 8 * sizeof(unsigned short);
+  return (size_t)27 * nchunk * 3 * 2 * cout_pad * 8 * sizeof(unsigned short) + 16;  // + trailer (fp16 mode's scales)
 }
 
 extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float *w, void *wt_split, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;
+  // the pack is made for the arithmetic selected NOW (p2pb_set_split_terms); callers re-pack after a switch to / from 16
+  float *trailer = (float *)((char *)wt_split + conv_split_trailer_bytes(nchunk, cout_pad));
+  const int mode = p2pb_g_split_terms;
+  if (mode == SPLIT_F16X3) {
+    const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin * 27,
+                       (unsigned *)trailer);
+  }
   hipLaunchKernelGGL(conv3d_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, (unsigned short *)wt_split);
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, (unsigned short *)wt_split, mode,
+                     trailer);
   return p2pb_launch_status();
 }
 
@@ -912,20 +941,22 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
   const unsigned short *w = (const unsigned short *)wt;
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
   if (fx && !cl) return P2PB_EINVAL;  // (the statistics plumbing exists in the voxel-major form only)
-  const bool terms3 = p2pb_g_split_terms == 3 && !fx && cl;  // (three-term form: voxel-major, no statistics plumbing)
+  const bool f16 = p2pb_g_split_terms == SPLIT_F16X3;
 #define LAUNCHT(XF, CL, FXV, TM)                                                                                      \
   hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk,   \
                      cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list,     \
                      brick_count, out, stats_part, fold, gacc)
-#define LAUNCH(XF, CL, FXV) LAUNCHT(XF, CL, FXV, 6)
+#define LAUNCH(XF, CL, FXV)                           \
+  do {                                                \
+    if (f16) LAUNCHT(XF, CL, FXV, SPLIT_F16X3);        \
+    else LAUNCHT(XF, CL, FXV, 6);                      \
+  } while (0)
   if (in_scale != nullptr || fold.group != nullptr) {
     if (fx) LAUNCH(true, true, true);
-    else if (terms3) LAUNCHT(true, true, false, 3);
     else if (cl) LAUNCH(true, true, false);
     else LAUNCH(true, false, false);
   } else {
     if (fx) LAUNCH(false, true, true);
-    else if (terms3) LAUNCHT(false, true, false, 3);
     else if (cl) LAUNCH(false, true, false);
     else LAUNCH(false, false, false);
   }
@@ -1513,13 +1544,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               unsigned p0, p1, p2;
-              split3(stg[h * 8 + 2 * i][j], stg[h * 8 + 2 * i + 1][j], p0, p1, p2);
+              split_pair<TERMS>(stg[h * 8 + 2 * i][j], stg[h * 8 + 2 * i + 1][j], p0, p1, p2);
               q[0][i] = p0;
               q[1][i] = p1;
               q[2][i] = p2;
             }
 #pragma unroll
-            for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
+            for (int s = 0; s < split_planes(TERMS); ++s) tile[(s * 2 + h) * PLANE + e] = q[s];
           }
         }
       }
@@ -1535,6 +1566,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
       split_taps<NA, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
     }
     if (NTC == 0) return;
+    if constexpr (TERMS == SPLIT_F16X3) {
+      const float oscale = ((const float *)((const char *)wt + conv_split_trailer_bytes(nchunk, cout_pad)))[1];
+#pragma unroll
+      for (int n = 0; n < NA; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] *= oscale;
+    }
 
     // ---- the active outputs: bias / class constant, 16-byte voxel-major stores, statistics
     int ovox[NA], ocls[NA];
@@ -1731,15 +1769,17 @@ extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r
   const bool wm1 = cout <= 32;  // one M-tile per workgroup, tiles dealt to four wave columns
   dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
-  const bool terms3 = p2pb_g_split_terms == 3 && !fx;
+  const int mode = p2pb_g_split_terms;
 #define LAUNCHX(RR, WMV, XF, FXV, TM)                                                                                 \
   hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
                      in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part,   \
                      fold, gacc)
 #define LAUNCH(RR, WMV, XF)               \
   do {                                    \
-    if (fx) LAUNCHX(RR, WMV, XF, true, 6);           \
-    else if (terms3) LAUNCHX(RR, WMV, XF, false, 3); \
+    if (mode == SPLIT_F16X3) {                       \
+      if (fx) LAUNCHX(RR, WMV, XF, true, SPLIT_F16X3);  \
+      else LAUNCHX(RR, WMV, XF, false, SPLIT_F16X3);    \
+    } else if (fx) LAUNCHX(RR, WMV, XF, true, 6);    \
     else LAUNCHX(RR, WMV, XF, false, 6);             \
   } while (0)
 #define GO(RR)                                                   \

@@ -17,7 +17,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define PW_CK 16  // input channels per register stage (2 sub-chunks of 8): 3 waves/SIMD stay resident (32 -> 2)
@@ -595,8 +594,8 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // FX: the statistics plumbing of the sampler path (operand norm folded here from accumulators / output statistics added
 // to accumulators) is compiled in. A separate instantiation, because merely carrying the two argument structs through
 // the stage loop costs the plain form 5 % (scalar registers: the row descriptors already fill the SGPR file).
-// TERMS: products per operand pair -- 6 (fp32-faithful, the default) or 3 (x1y0 + x0y1 + x0y0: the low planes are neither
-// fetched, written nor read; relative error per product <= 2^-16, see conv3d.hip) -- selected by p2pb_set_split_terms
+// TERMS: the arithmetic (common.h, p2pb_set_split_terms) -- SPLIT_F16X3 (default: fp16-pair split, three products, two
+// operand planes: the third is neither fetched, written nor read) or SPLIT_BF16X6 (three bf16 terms, six products)
 template <bool XF, bool POOL, int WM, int NB, bool FX, int TERMS>
 #ifndef PWS_WM4_WAVES
 #define PWS_WM4_WAVES 4
@@ -743,7 +742,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
           for (int i = 0; i < 4; ++i) {
             unsigned p0, p1, p2;
 #ifndef PWS_EXP_NOSPLIT
-            split3(braw[q][2 * i][e], braw[q][2 * i + 1][e], p0, p1, p2);
+            split_pair<TERMS>(braw[q][2 * i][e], braw[q][2 * i + 1][e], p0, p1, p2);
 #else
             p0 = __builtin_bit_cast(unsigned, braw[q][2 * i][e]), p1 = __builtin_bit_cast(unsigned, braw[q][2 * i + 1][e]), p2 = p0 ^ p1;
 #endif
@@ -755,7 +754,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
           const int blk = WM == 2 ? q : (NB == 2 ? bsel : 0);
           const int slot = blk * 128 + (ONE ? (lane & 1) * 64 + 32 * bsel + (lane >> 1) : e * 64 + lane);
 #pragma unroll
-          for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s) lds_b[((kstep * 3 + s) * 2 + kh) * BS + slot] = qq[s];
+          for (int s = 0; s < split_planes(TERMS); ++s) lds_b[((kstep * 3 + s) * 2 + kh) * BS + slot] = qq[s];
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this stage's A tile has landed
@@ -769,7 +768,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
     for (int kstep = 0; kstep < 2; ++kstep) {
       u32x4 af[3][2];
 #pragma unroll
-      for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s)
+      for (int s = 0; s < split_planes(TERMS); ++s)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #ifdef PWS_A_DIRECT
@@ -783,23 +782,31 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
       for (int nb = 0; nb < NB; ++nb) {
         u32x4 bf[3][2];
 #pragma unroll
-        for (int s = 0; s < (TERMS == 6 ? 3 : 2); ++s)
+        for (int s = 0; s < split_planes(TERMS); ++s)
 #pragma unroll
           for (int n = 0; n < 2; ++n)
             bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * BS + nb * 128 + n * 64 + wn * 32 + l31];
 #pragma unroll
-        for (int t = 6 - TERMS; t < 6; ++t)
+        for (int t = (TERMS == 6 ? 0 : 3); t < 6; ++t)
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-              acc[m][2 * nb + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[t]][m]),
-                                                                           __builtin_bit_cast(bf16x8, bf[PB[t]][n]),
-                                                                           acc[m][2 * nb + n], 0, 0, 0);
+              acc[m][2 * nb + n] = split_mfma<TERMS>(af[PA[t]][m], bf[PB[t]][n], acc[m][2 * nb + n]);
       }
     }
   }
   if (!mact) return;
+  if constexpr (TERMS == SPLIT_F16X3) {  // 1 / (S_x S_w), a power of two, stored behind the pack
+    const int nblk128 = WM == 2 ? ncoblk : (cout + 127) / 128;
+    const float oscale = ((const float *)(wp + (size_t)((cin + PWS_CK - 1) / PWS_CK) * nblk128 * PWS_TILE))[1];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2 * NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] *= oscale;
+  }
   pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
                              stats_part, mm_out, pool_u, out_pm, FX ? gacc : GnAcc());
 }
@@ -999,9 +1006,12 @@ __global__ __launch_bounds__(512, 1) void pw_split_ws_kernel(int cin, int cout, 
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
 // channel = chunk*32 + kstep*16 + khalf*8 + idx
+// mode SPLIT_F16X3: planes 0, 1 hold the fp16 pair of w * S_w (plane 2 unused); trailer = {max|w| bits, 1 / (S_x S_w)}
 __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, const float *__restrict__ w,
-                                     unsigned short *__restrict__ wp) {
+                                     unsigned short *__restrict__ wp, int mode, float *__restrict__ trailer) {
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;  // (chunk, coblk, kstep, khalf, co, idx)
+  const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(trailer[0]) : 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int idx = (int)(e & 7);
     size_t q = e >> 3;
@@ -1015,7 +1025,12 @@ __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, 
     const int co = cb * 128 + col, ci = chunk * PWS_CK + ks * 16 + kh * 8 + idx;
     const float x = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
     unsigned p0, p1, p2;
-    split3(x, 0.0f, p0, p1, p2);
+    if (mode == SPLIT_F16X3) {
+      split2h(x * sw, 0.0f, p0, p1);
+      p2 = 0u;
+    } else {
+      split3(x, 0.0f, p0, p1, p2);
+    }
     const unsigned pp[3] = {p0, p1, p2};
     for (int s = 0; s < 3; ++s)
       wp[((((((size_t)chunk * ncoblk + cb) * 2 + ks) * 3 + s) * 2 + kh) * 128 + col) * 8 + idx] = (unsigned short)(pp[s] & 0xffff);
@@ -1024,15 +1039,24 @@ __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, 
 
 extern "C" size_t p2pb_pointwise_split_packed_bytes(int cout, int cin) {
   const size_t nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
-  return nchunk * ncoblk * (2 * 3 * 2 * 128) * 16;
+  return nchunk * ncoblk * (2 * 3 * 2 * 128) * 16 + 16;  // + trailer {max|w| bits, output scale, -, -} (fp16 mode)
 }
 
 extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w, void *wp, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;
+  // the pack is made for the arithmetic selected NOW (p2pb_set_split_terms); callers re-pack after a switch
+  float *trailer = (float *)((char *)wp + (size_t)nchunk * ncoblk * PWS_TILE * 16);
+  const int mode = p2pb_g_split_terms;
+  if (mode == SPLIT_F16X3) {
+    const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin,
+                       (unsigned *)trailer);
+  }
   hipLaunchKernelGGL(pw_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp);
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp, mode, trailer);
   return p2pb_launch_status();
 }
 
@@ -1042,7 +1066,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
                            const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
   const bool xf = in_scale != nullptr || fold.group != nullptr;
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
-  const bool terms3 = p2pb_g_split_terms == 3;  // (plain form only: the accumulator plumbing stays on six terms)
+  const int mode = p2pb_g_split_terms;
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
@@ -1069,8 +1093,10 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   } while (0)
 #define LAUNCHF(XF, PL, WM, NB)                          \
   do {                                                   \
-    if (fx) LAUNCHW(XF, PL, WM, NB, true, 6);             \
-    else if (terms3) LAUNCHW(XF, PL, WM, NB, false, 3);   \
+    if (fx) {                                             \
+      if (mode == SPLIT_F16X3) LAUNCHW(XF, PL, WM, NB, true, SPLIT_F16X3); \
+      else LAUNCHW(XF, PL, WM, NB, true, 6);              \
+    } else if (mode == SPLIT_F16X3) LAUNCHW(XF, PL, WM, NB, false, SPLIT_F16X3); \
     else LAUNCHW(XF, PL, WM, NB, false, 6);               \
   } while (0)
 #define LAUNCH(XF, PL)                    \
@@ -1081,7 +1107,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   // the 256-channel layers without statistics plumbing: math and staging on different waves (pw_split_ws_kernel)
   static const int ws_env = getenv("P2PB_PW_WS") ? atoi(getenv("P2PB_PW_WS")) : 0;
-  if (wm4 && !fx && ws_env == 1) {
+  if (wm4 && !fx && ws_env == 1 && mode == SPLIT_BF16X6) {
     const int lds = 2 * 3 * PWS_TILE * 16;
 #define LAUNCHS(XF, PL)                                                                                              \
   do {                                                                                                               \

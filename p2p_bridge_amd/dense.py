@@ -87,7 +87,8 @@ class _Conv3dK3(torch.autograd.Function):
         co = gy.shape[1]
         gx = None
         if ctx.needs_input_grad[0]:
-            gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True)
+            with fused.split_math("bf16x6"):  # gradients have no scale an fp16-pair split could rely on
+                gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True)
         gw = gb = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gw = torch.empty(co, ci, 3, 3, 3, dtype=F32, device=x.device)
@@ -122,7 +123,8 @@ class _Pointwise(torch.autograd.Function):
         co = gy.shape[1]
         gx = None
         if ctx.needs_input_grad[0]:
-            gx, _ = fused.pw_conv(gy, _dgrad_holder(conv, "pw"), stats=False, use_bias=False)
+            with fused.split_math("bf16x6"):
+                gx, _ = fused.pw_conv(gy, _dgrad_holder(conv, "pw"), stats=False, use_bias=False)
         gw = gb = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             gw = torch.empty(co, ci, dtype=F32, device=x.device)

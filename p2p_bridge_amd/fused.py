@@ -164,19 +164,26 @@ def _arrays_of(in_scale, in_shift):
     return in_scale, in_shift
 
 
-CONV_MATHS = ("bf16x6", "bf16x3", "fp32")
-SPLIT_MATHS = ("bf16x6", "bf16x3")
+CONV_MATHS = ("f16x3", "bf16x6", "fp32")
+SPLIT_MATHS = ("f16x3", "bf16x6")
+CONV_MATH_DEFAULT = "f16x3"
+_SPLIT_TERMS = {"f16x3": 16, "bf16x6": 6, "fp32": 6}  # p2pb_set_split_terms codes
 _conv_math_override = None
 
 
 def conv_math() -> str:
-    """arithmetic of the voxel convolutions and the >= 128-channel 1x1 layers, P2PB_CONV_MATH / set_conv_math():
-      "bf16x6" (default) fp32 operands as three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulate --
-               fp32-faithful (csrc/conv3d.hip); every parity number in DESIGN.md is quoted on it;
-      "bf16x3" the same kernels keeping three of the six products (include/p2pb_hip.h p2pb_set_split_terms): <= 2^-16
-               relative per product, 32x tighter than the TF32 the reference's cuDNN convolutions run in;
+    """arithmetic of the voxel convolutions and the >= 128-channel 1x1 layers, P2PB_CONV_MATH / set_conv_math(); fp32
+    operands, fp32 accumulation and fp32 results in every case -- what differs is how an fp32 product reaches the
+    16-bit matrix pipe (gfx950 has no TF32, and multiplies fp32 at 1/16 of the 16-bit rate):
+      "f16x3"  (default) every operand as an fp16 pair h0 + h1 of its scaled value (22 significand bits), a product as
+               h1g0 + h0g1 + h0g0 -- three exact matrix products, <= 3 * 2^-22 relative per product, measured at or below
+               the exact-fp32 MFMA kernel's error against fp64 (csrc/common.h SPLIT_F16X3). Range contract: activations
+               (after the folded norm) are scaled by 4 and saturate at |x| = 16376; below |x| = 2^-5 the representation
+               error is an absolute 2^-27; weights are scaled per tensor at pack time (any finite weights);
+      "bf16x6" three bf16 terms per operand, six products: within a quarter ulp of fp32 at any magnitude, 1.2x slower end
+               to end; the gradient pass of train() always uses it (gradients have no scale the fp16 range could rely on);
       "fp32"   the exact-fp32 MFMA kernels"""
-    m = _conv_math_override or os.environ.get("P2PB_CONV_MATH", "bf16x6")
+    m = _conv_math_override or os.environ.get("P2PB_CONV_MATH", CONV_MATH_DEFAULT)
     if m not in CONV_MATHS:
         raise ValueError(f"P2PB_CONV_MATH must be one of {CONV_MATHS}, got {m!r}")
     return m
@@ -190,14 +197,29 @@ def set_conv_math(name):
     if name is not None and name not in CONV_MATHS:
         raise ValueError(f"conv math must be one of {CONV_MATHS}, got {name!r}")
     _conv_math_override = name
-    rc = lib().p2pb_set_split_terms(3 if conv_math() == "bf16x3" else 6)
+    rc = lib().p2pb_set_split_terms(_SPLIT_TERMS[conv_math()])
     if rc != 0:
         raise RuntimeError(f"p2pb_set_split_terms -> {rc}")
     return prev
 
 
+class split_math:
+    """`with split_math("bf16x6"):` -- the split kernels launched (and the weights packed) inside use that arithmetic,
+    whatever the process-wide setting; a host-side integer, no device work. train()'s data-gradient pass runs under it."""
+
+    def __init__(self, name):
+        self.terms = _SPLIT_TERMS[name]
+
+    def __enter__(self):
+        self.prev = lib().p2pb_get_split_terms()
+        lib().p2pb_set_split_terms(self.terms)
+
+    def __exit__(self, *exc):
+        lib().p2pb_set_split_terms(self.prev)
+
+
 def use_split(cout: int, math=None) -> bool:
-    """bf16x6 split-operand kernel unless P2PB_CONV_MATH=fp32 (or math="fp32") asks for the exact-fp32 MFMA one"""
+    """split-operand kernel unless P2PB_CONV_MATH=fp32 (or math="fp32") asks for the exact-fp32 MFMA one"""
     return (math or conv_math()) in SPLIT_MATHS
 
 
@@ -211,6 +233,8 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
     if cache is None or cache[0] != key:
         cache = conv._p2pb_packed = (key, {})
     packs = cache[1]
+    if split:
+        split = "f16" if lib().p2pb_get_split_terms() == 16 else "bf16"  # the pack follows the arithmetic selected now
     if split not in packs:
         co, ci = w.shape[:2]
         assert tuple(w.shape[2:]) == (3, 3, 3) and conv.padding == (1, 1, 1) and conv.stride == (1, 1, 1)
@@ -463,6 +487,8 @@ def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None, split=False) -> torch.Tenso
     if cache is None or cache[0] != key:
         cache = conv._p2pb_packed_pw = (key, {})
     packs = cache[1]
+    if split:
+        split = "f16" if lib().p2pb_get_split_terms() == 16 else "bf16"
     k = (ci_lo, ci_hi, split)
     if k not in packs:
         co = w.shape[0]

@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import PVDS, SPLIT_PEAK_TFLOPS  # noqa: E402
+from bench import PVDS, split_peak_tflops  # noqa: E402
 from p2p_bridge_amd import fused, p2pb as product  # noqa: E402
 from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet  # noqa: E402
 from p2p_bridge_amd.synthetic import synthetic_patches  # noqa: E402
@@ -43,7 +43,8 @@ with torch.no_grad():
 for k, o in origs.items():
     setattr(fused, k, o)
 
-print(f"# voxel convolutions of one evaluation, B = {B}, {N} points; peak = {SPLIT_PEAK_TFLOPS:.1f} TFLOP/s (bf16x6)")
+SPLIT_PEAK_TFLOPS = split_peak_tflops()
+print(f"# voxel convolutions of one evaluation, B = {B}, {N} points; peak = {SPLIT_PEAK_TFLOPS:.1f} TFLOP/s ({fused.conv_math()})")
 print("layer,form,r,cin,cout,operand,ms,work_fraction,TFLOPs_dense_equivalent,TFLOPs_on_work,frac_of_peak_on_work")
 arena = fused.StatsArena()
 arena.begin(x_start.device)

@@ -28,4 +28,5 @@ with torch.no_grad():
     e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 20
 fl = 2.0 * B * P * ci * co
-print(f"WM={os.environ.get('P2PB_PW_WM', 'auto')}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s fp32-eq  frac {fl / ms / 1e9 / 419.4:.3f}")
+peak = 2516.6 / (3 if fused.conv_math() == "f16x3" else 6)
+print(f"WM={os.environ.get('P2PB_PW_WM', 'auto')} {fused.conv_math()}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s fp32-eq  frac {fl / ms / 1e9 / peak:.3f} of {peak:.1f}")
