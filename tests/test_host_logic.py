@@ -136,6 +136,8 @@ def test_conv_math_switch(monkeypatch):
     from p2p_bridge_amd import fused
 
     monkeypatch.delenv("P2PB_CONV_MATH", raising=False)
+    assert fused.conv_math() == "f16x3" and fused.use_split(32) and fused.use_split(256)
+    monkeypatch.setenv("P2PB_CONV_MATH", "bf16x6")
     assert fused.conv_math() == "bf16x6" and fused.use_split(32) and fused.use_split(256)
     assert fused.use_split_pw(512, 1024, 8192) and not fused.use_split_pw(64, 128, 8192)
     assert not fused.use_split_pw(512, 1024, 8190)  # rows must be 16-byte aligned
