@@ -177,9 +177,8 @@ def gemm_roofline(model, B, P, reps=10):
     traffic = None
     try:
         vals = {}
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_pw_split_512_1024_pool.csv")
-        if not os.path.exists(pmc):
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_pw_split_512_1024_pool.csv")
+        pmc = next(q for q in (os.path.join(ROOT, "profiles", f"{t}_pmc_pw_split_512_1024_pool.csv") for t in ("r02f", "r02", "r01"))
+                   if os.path.exists(q))
         for line in open(pmc):
             k, v = line.split(",")[:2]
             if k in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -263,6 +262,7 @@ def main():
     ap.add_argument("--T", type=int, default=30)
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-math", action="store_true", help="skip the bf16x6 comparison leg (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL over xGMI); gloo only with --dry-run")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only, no GPU work (CPU self-test of the N-rank path)")
@@ -330,7 +330,7 @@ def main():
         evals = args.T
         res["roofline"]["sampler_dense_tflops"] = round(
             61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval
-        if world == 1 and "P2PB_CONV_MATH" not in os.environ:
+        if world == 1 and "P2PB_CONV_MATH" not in os.environ and not args.no_alt_math:
             res["alt_math"] = alt_math_leg(cfg, sd, x_start, args)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, args.points, args.T)

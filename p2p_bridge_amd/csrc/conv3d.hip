@@ -491,8 +491,11 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
 // FX: the sampler path's statistics plumbing (operand norm folded here from accumulators / output statistics added to
 // accumulators, common.h) is compiled in -- a separate instantiation (voxel-major form only), so that the plain form
 // carries neither the two argument structs nor the table
+#ifndef CONV_F16_WAVES
+#define CONV_F16_WAVES 2  // (waves per SIMD the f16x3 forms are compiled for; their two-plane tile would fit three workgroups)
+#endif
 template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX, int TERMS>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
+__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
                                                              const float *__restrict__ bias,
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_split_kernel(int cin, int co
   constexpr int BH = R / G::TH, BW = R / G::TW;
   constexpr int R3 = R * R * R;
   // tile[split][khalf][voxel] : 8 bf16 (16 bytes) = channels khalf*8 .. khalf*8+7 of the staged chunk
-  __shared__ u32x4 tile[3 * 2 * PLANE];
+  __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -1395,7 +1398,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
 }
 
 template <int R, int WM, bool XF, bool FX, int TERMS>  // FX, TERMS: see conv3d_k3_split_kernel
-__global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
+__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                                 const float *__restrict__ in,
                                                                 const unsigned short *__restrict__ wt,
                                                                 const float *__restrict__ bias,
@@ -1413,7 +1416,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_compact_kernel(int cin, int 
   constexpr int BH = R / G::TH, BW = R / G::TW, BD = R / G::TD, NBRICK = BD * BH * BW;
   constexpr int R3 = R * R * R;
   constexpr int WN = 4 / WM;
-  __shared__ u32x4 tile[3 * 2 * PLANE];
+  __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
   __shared__ unsigned char lst[256];
   __shared__ int ncls[27];
   __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
