@@ -412,11 +412,20 @@ int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float 
                                 void *stream);
 /* flags bit 5: point-major output, out f32[b,npos,cout] (what p2pb_group_sub / p2pb_three_interpolate_add gather
  * whole rows from); stats_part must be NULL.
- * flags bit 2: wp is the split pack below and the GEMM runs in the bf16x6 form (three bf16 terms per fp32
+ * flags bit 2: wp is the split pack below and the GEMM runs in the split-operand form (p2pb_set_split_terms; bf16x6: three bf16 terms per fp32
  * operand, six MFMA products, fp32 accumulate -- see the conv3d split pack); needs npos % 4 == 0 and
  * 16-byte aligned in/out. Meant for the matrix-bound layers (wide channel counts). */
 size_t p2pb_pointwise_split_packed_bytes(int cout, int cin);
 int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w /* [cout][cin] */, void *wp, void *stream);
+/* flags bit 6 (with bit 2, f16x3 arithmetic, npos % 128 == 0, no in_scale / in_fold / out_acc, channel-major output):
+ * `in` is not f32[b,cin,npos] but the operand already transformed and split by p2pb_pointwise_presplit -- for wide layers
+ * whose operand would otherwise be transformed and split once per output-channel block of 256 (the global embedding's
+ * 512 -> 1024 layer, models/pvcnn.py:905-932: four times). The folded norm + Swish of in_scale / in_shift / in_swish
+ * (NULL: none) is applied by the pre-pass; the GEMM's results are bit-identical to the one-call form.
+ *   in f32[b,cin,npos] -> xs: p2pb_pointwise_presplit_bytes(b,cin,npos) bytes (4 per element; 0 = unsupported shape) */
+size_t p2pb_pointwise_presplit_bytes(int b, int cin, int npos);
+int p2pb_pointwise_presplit(int b, int cin, int npos, const float *in, const float *in_scale, const float *in_shift,
+                            int in_swish, void *xs, void *stream);
 /* The same GEMM with the max-pool that follows the layer (set abstraction: max over the pool_u = 4..64
  * neighbours, models/pvcnn.py:414; Pnet2Stage: pool_u = 0, max over all positions, :923,930) prepared in the
  * epilogue: minmax receives {min, max} of the raw output per pooling group (pool_u > 0: f32[b,cout,npos/pool_u,2];

@@ -596,7 +596,11 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // the stage loop costs the plain form 5 % (scalar registers: the row descriptors already fill the SGPR file).
 // TERMS: the arithmetic (common.h, p2pb_set_split_terms) -- SPLIT_F16X3 (default: fp16-pair split, three products, two
 // operand planes: the third is neither fetched, written nor read) or SPLIT_BF16X6 (three bf16 terms, six products)
-template <bool XF, bool POOL, int WM, int NB, bool FX, int TERMS>
+// PRE (f16x3 only): `in` is the operand ALREADY transformed and split by pw_presplit_kernel, stored as the LDS image of
+// every (sample, 128-position block, 32-channel stage) -- the B tile then arrives by LDS-DMA like the weight tile and the
+// kernel has no VALU staging at all. For layers whose operand would otherwise be transformed and split once per
+// output-channel block (4x for the 512 -> 1024 layer); results are bit-identical to the staged form.
+template <bool XF, bool POOL, int WM, int NB, bool FX, int TERMS, bool PRE = false>
 #ifndef PWS_WM4_WAVES
 #define PWS_WM4_WAVES 4
 #endif
@@ -684,7 +688,18 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * NT + tid),
                                          (__attribute__((address_space(3))) void *)(dst + i * NT + wave * 64), 16, 0, 0);
   };
-  load_b(0);
+  if constexpr (!PRE) load_b(0);
+  // the pre-split B tile of stage `chunk` -> LDS, asynchronously (rows (kstep, plane, khalf) of the image -> the tile's rows)
+  auto dma_b = [&](int chunk) {
+    const u32x4 *src = (const u32x4 *)in + (((size_t)b * gridDim.x + bx) * ((cin + PWS_CK - 1) / PWS_CK) + chunk) * 1024;
+#pragma unroll
+    for (int i = 0; i < 1024 / NT; ++i) {
+      const int e = i * NT + wave * 64, rg = e >> 7;
+      u32x4 *dst = lds_b + (((rg >> 2) * 3 + ((rg >> 1) & 1)) * 2 + (rg & 1)) * BS + (e & 127);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * NT + tid),
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
+  };
   // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
   // producer's accumulators (common.h); published by the barrier at the top of the first stage
   // (the caller's arrays keep travelling through the scalar cache: an LDS broadcast at the top of the transform phase
@@ -712,8 +727,9 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 #elif !defined(PWS_EXP_NODMA)
     dma_a(ci0 / PWS_CK);  // lands while B is transformed and split below
 #endif
+    if constexpr (PRE) dma_b(ci0 / PWS_CK);
     // ---- stage B: transform + split
-    {
+    if constexpr (!PRE) {
       constexpr int NE = ONE ? 1 : 2;
 #ifndef PWS_EXP_NOXF
       if (XF) {
@@ -759,7 +775,8 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this stage's A tile has landed
     __syncthreads();
-    if (ci0 + PWS_CK < cin) load_b(ci0 + PWS_CK);  // next stage's B loads fly during the MFMAs
+    if constexpr (!PRE)
+      if (ci0 + PWS_CK < cin) load_b(ci0 + PWS_CK);  // next stage's B loads fly during the MFMAs
     if (!mact) continue;
 #ifdef PWS_EXP_NOMFMA
     continue;
@@ -1060,34 +1077,95 @@ extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float 
   return p2pb_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Operand of a split GEMM, transformed and split ONCE (f16x3): xs[b][P / 128][chunk32][kstep 2][plane 2][khalf 2][slot 128]
+// of 16-byte groups = 8 consecutive channels as fp16 -- exactly the B tile pw_split_kernel<PRE> DMAs per stage. Same
+// arithmetic as the in-kernel staging (folded norm -> Swish -> split_pair): the GEMM's results do not change.
+// 4 bytes per element in, 4 out. grid (P / 128, chunks, b).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pw_presplit_kernel(int cin, int P, const float *__restrict__ in,
+                                                          const float *__restrict__ in_scale,
+                                                          const float *__restrict__ in_shift, int in_swish,
+                                                          u32x4 *__restrict__ xs) {
+  const int b = blockIdx.z, chunk = blockIdx.y, pblk = blockIdx.x;
+  const float *inb = in + (size_t)b * cin * P + (size_t)pblk * 128;
+  u32x4 *tile = xs + (((size_t)b * gridDim.x + pblk) * gridDim.y + chunk) * 1024;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int item = threadIdx.x + 256 * j;
+    const int pl = item & 127, ks = item >> 8, kh = (item >> 7) & 1;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = min(chunk * PWS_CK + ks * 16 + kh * 8 + i, cin - 1);  // beyond cin: finite garbage x zero weights
+      float x = inb[(size_t)c * P + pl];
+      if (in_scale) {
+        x = x * in_scale[b * cin + c] + in_shift[b * cin + c];
+        if (in_swish) x = swishf(x);
+      }
+      v[i] = x;
+    }
+    u32x4 q0, q1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned p0, p1, p2;
+      split_pair<SPLIT_F16X3>(v[2 * i], v[2 * i + 1], p0, p1, p2);
+      q0[i] = p0;
+      q1[i] = p1;
+    }
+    const int slot = (pl & 1) * 64 + (pl >> 1);
+    tile[((ks * 2 + 0) * 2 + kh) * 128 + slot] = q0;
+    tile[((ks * 2 + 1) * 2 + kh) * 128 + slot] = q1;
+  }
+}
+
+extern "C" size_t p2pb_pointwise_presplit_bytes(int b, int cin, int npos) {
+  if (b <= 0 || cin <= 0 || npos <= 0 || npos % 128) return 0;
+  return (size_t)b * (npos / 128) * ((cin + PWS_CK - 1) / PWS_CK) * 1024 * 16;
+}
+
+extern "C" int p2pb_pointwise_presplit(int b, int cin, int npos, const float *in, const float *in_scale,
+                                       const float *in_shift, int in_swish, void *xs, void *stream) {
+  if (b <= 0 || cin <= 0 || npos <= 0 || npos % 128 || !in || !xs || (in_scale == nullptr) != (in_shift == nullptr))
+    return P2PB_EINVAL;
+  if (p2pb_g_split_terms != SPLIT_F16X3) return P2PB_EINVAL;  // (the image is the f16x3 tile)
+  hipLaunchKernelGGL(pw_presplit_kernel, dim3(npos / 128, (cin + PWS_CK - 1) / PWS_CK, b), dim3(256), 0, (hipStream_t)stream,
+                     cin, npos, in, in_scale, in_shift, in_swish, (u32x4 *)xs);
+  return p2pb_launch_status();
+}
+
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s,
-                           const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
+                           const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc(), bool pre = false) {
   const bool xf = in_scale != nullptr || fold.group != nullptr;
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
   const int mode = p2pb_g_split_terms;
+  if (pre && (xf || fx || mode != SPLIT_F16X3 || P % 128 || out_pm)) return P2PB_EINVAL;
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
                                        : (cout >= 512 && (long)((P + 127) / 128) * ((cout + 255) / 256) * b >= 1024));
   // (NB = 2, 256 positions per workgroup, halves the weight traffic through L2 -- 10.7 -> 5.3 GB for the 512 -> 1024
   // launch -- but costs a wave per SIMD: measured 4 % / 7 % SLOWER with 256 / 128 channels; only NB = 1 is instantiated)
-  dim3 grid((P + 127) / 128, wm4 ? (cout + 255) / 256 : (cout + 127) / 128, b);
+  static const int nb_env = getenv("P2PB_PW_NB") ? atoi(getenv("P2PB_PW_NB")) : 0;  // experiment: 256-position workgroups
+  const bool nb2 = wm4 && nb_env == 2 && mode == SPLIT_F16X3 && !fx && !pre;
+  dim3 grid((P + (nb2 ? 255 : 127)) / (nb2 ? 256 : 128), wm4 ? (cout + 255) / 256 : (cout + 127) / 128, b);
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
   // 72 KB of dynamic LDS (above the 64 KB default): opt in once per instantiation
-#define LAUNCHW(XF, PL, WM, NB, FXV, TM)                                                                              \
+#define LAUNCHW(XF, PL, WM, NB, FXV, TM) LAUNCHP(XF, PL, WM, NB, FXV, TM, false)
+#define LAUNCHP(XF, PL, WM, NB, FXV, TM, PR)                                                                              \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
     const int lds = (WM / 2 + NB) * PWS_TILE * 16 + (fold.group ? 2 * cin * 4 : 0);                                   \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV, TM>,                                   \
+      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV, TM, PR>,                                   \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
                                 (WM / 2 + NB) * PWS_TILE * 16 + 2 * P2PB_FOLD_MAXC * 4);                               \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV, TM>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
+    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV, TM, PR>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
                        w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fold,  \
                        gacc);                                                                                        \
   } while (0)
@@ -1101,7 +1179,8 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   } while (0)
 #define LAUNCH(XF, PL)                    \
   do {                                    \
-    if (wm4) LAUNCHF(XF, PL, 4, 1);        \
+    if (nb2) LAUNCHW(XF, PL, 4, 2, false, SPLIT_F16X3); \
+    else if (wm4) LAUNCHF(XF, PL, 4, 1);   \
     else LAUNCHF(XF, PL, 2, 1);            \
   } while (0)
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
@@ -1127,6 +1206,13 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
 #undef LAUNCHS
     return p2pb_launch_status();
   }
+  if (pre) {
+    if (wm4 && minmax) LAUNCHP(false, true, 4, 1, false, SPLIT_F16X3, true);
+    else if (wm4) LAUNCHP(false, false, 4, 1, false, SPLIT_F16X3, true);
+    else if (minmax) LAUNCHP(false, true, 2, 1, false, SPLIT_F16X3, true);
+    else LAUNCHP(false, false, 2, 1, false, SPLIT_F16X3, true);
+    return p2pb_launch_status();
+  }
   if (xf && minmax) LAUNCH(true, true);
   else if (xf) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
@@ -1134,6 +1220,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
 #undef LAUNCH
 #undef LAUNCHF
 #undef LAUNCHW
+#undef LAUNCHP
   return p2pb_launch_status();
 }
 
@@ -1208,11 +1295,12 @@ extern "C" int p2pb_pointwise_conv_forward_fx(int b, int cin, int cout, int npos
   hipStream_t s = (hipStream_t)stream;
   const int out_pm = (flags & 32) != 0;  // point-major output f32[b, npos, cout]
   if (out_pm && (stats_part || gacc.group)) return P2PB_EINVAL;
-  if (flags & 4) {  // wp is the split pack
+  if (flags & 4) {  // wp is the split pack; flags & 64: `in` is the pre-split operand (p2pb_pointwise_presplit)
     if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           nullptr, 0, out_pm, s, fold, gacc);
+                           nullptr, 0, out_pm, s, fold, gacc, (flags & 64) != 0);
   }
+  if (flags & 64) return P2PB_EINVAL;
   const float *wp = (const float *)wp_any;
   // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
@@ -1259,7 +1347,8 @@ extern "C" int p2pb_pointwise_conv_pool_forward_fx(int b, int cin, int cout, int
   hipStream_t s = (hipStream_t)stream;
   if (flags & 4)
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           minmax, pool_u, 0, s, fold, gacc);
+                           minmax, pool_u, 0, s, fold, gacc, (flags & 64) != 0);
+  if (flags & 64) return P2PB_EINVAL;
   const float *wp = (const float *)wp_any;
   const int g = pool_lanes(pool_u);
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
