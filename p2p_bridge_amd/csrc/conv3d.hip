@@ -34,6 +34,19 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Translation units: this file is compiled TWICE (p2p_bridge_amd/build.py), in parallel. The primary object holds
+// everything and instantiates the split kernels in the default f16x3 arithmetic; -DCONV_TU=6 builds only the bf16x6
+// instantiations of the split kernels behind two bridge functions (conv3d_tu6_split / conv3d_tu6_compact) -- every
+// extern "C" entry point is compiled out there, every non-template kernel is static.
+#ifndef CONV_TU
+#define CONV_TU 0
+#endif
+#if CONV_TU == 6
+#define CONV_TERMS SPLIT_BF16X6
+#else
+#define CONV_TERMS SPLIT_F16X3
+#endif
+
 #define CONV_CK 8  // input channels per LDS stage
 
 // brick = TD x TH x TW voxels = 8 N-tiles of 32 (2 for R = 4); an N-tile = ND x NH x TW voxels
@@ -378,7 +391,7 @@ static __host__ __device__ size_t conv_split_trailer_bytes(int nchunk, int cout_
 
 // packed weights: wt[tap][chunk16][split 3][khalf 2][cout_pad][8 bf16]; element idx = channel chunk*16 + khalf*8 + idx
 // mode SPLIT_F16X3 (common.h): planes 0, 1 = the fp16 pair of w * S_w, plane 2 unused; trailer = {max|w| bits, 1 / (S_x S_w)}
-__global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
+static __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
                                         unsigned short *__restrict__ wt, int mode, float *__restrict__ trailer) {
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;  // one thread per (tap, chunk, khalf, co, idx)
   const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(trailer[0]) : 1.0f;
@@ -775,7 +788,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 // weights [cout][cin][3][3][3] -> packed [27][cin_pad/8][2][cout_pad][4] (zero padded):
 // element (tap, chunk, khalf, co, kk) = W[co][chunk*8 + 2*kk + khalf][tap], so that the four k-pair
 // values one lane needs for a tap are one aligned 16-byte load and lanes 0..31 read 512 contiguous bytes
-__global__ void conv3d_pack_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
+static __global__ void conv3d_pack_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
                                    float *__restrict__ wt) {
   const size_t total = (size_t)27 * nchunk * 8 * cout_pad;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
@@ -790,6 +803,7 @@ __global__ void conv3d_pack_kernel(int cout, int cin, int nchunk, int cout_pad, 
   }
 }
 
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, float *wt_packed, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
@@ -827,16 +841,19 @@ extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float 
                      trailer);
   return p2pb_launch_status();
 }
+#endif
 
 static int conv_bricks(int r) { return r == 32 ? 128 : r == 16 ? 16 : r == 8 ? 2 : 1; }  // both geometries
 
+#if CONV_TU != 6
 extern "C" size_t p2pb_conv3d_k3_stats_floats(int b, int cout, int r) {
   return (size_t)b * conv_bricks(r) * 4 * cout * 2;
 }
+#endif
 
 // far-field constants of a folded operand transform: a[b,c] = xf(base[c]) with the SAME device function the
 // staging code uses (bit-identical), i.e. the value of swish(affine(conv0 output)) where conv0 saw only zeros
-__global__ void far_value_kernel(int c, const float *__restrict__ base, const float *__restrict__ scale,
+static __global__ void far_value_kernel(int c, const float *__restrict__ base, const float *__restrict__ scale,
                                  const float *__restrict__ shift, int swish, float *__restrict__ a, GnFold fold) {
   const int b = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
   if (ch >= c) return;
@@ -850,7 +867,7 @@ __global__ void far_value_kernel(int c, const float *__restrict__ base, const fl
 }
 
 // T[b, tap, co] = sum_ci W[tap][ci][co] * a[b,ci]  (one thread per output channel, weights read coalesced)
-__global__ __launch_bounds__(256) void tap_sum_kernel(int cin, int cout, int nchunk, int cout_pad,
+static __global__ __launch_bounds__(256) void tap_sum_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                       const float *__restrict__ wt, const float *__restrict__ a,
                                                       float *__restrict__ tsum) {
   const int tap = blockIdx.y, b = blockIdx.z;
@@ -866,7 +883,7 @@ __global__ __launch_bounds__(256) void tap_sum_kernel(int cin, int cout, int nch
 
 // K[b, class, co] = bias[co] + sum over the taps that stay inside the grid for that boundary class of T[b,tap,co]
 // (the convolution of the constant field a with zero padding)
-__global__ __launch_bounds__(256) void class_bias_kernel(int cout, const float *__restrict__ tsum,
+static __global__ __launch_bounds__(256) void class_bias_kernel(int cout, const float *__restrict__ tsum,
                                                          const float *__restrict__ bias, float *__restrict__ k_out) {
   const int cls = blockIdx.y, b = blockIdx.z;
   const int co = blockIdx.x * 256 + threadIdx.x;
@@ -886,6 +903,7 @@ __global__ __launch_bounds__(256) void class_bias_kernel(int cout, const float *
 
 // a f32[b,cin] = far-field operand constants, k_out f32[b,27,cout] = per-boundary-class output constants,
 // tap_ws f32[b,27,cout] scratch
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
                                         const float *in_shift, int in_swish, const float *wt_packed,
                                         const float *bias, float *a, float *k_out, float *tap_ws, void *stream) {
@@ -907,6 +925,7 @@ extern "C" int p2pb_conv3d_k3_far_field_fx(int b, int cin, int cout, const float
   hipLaunchKernelGGL(class_bias_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cout, tap_ws, bias, k_out);
   return p2pb_launch_status();
 }
+#endif
 
 template <int R, bool COMPACT, int MT>
 static int conv_launch(int b, int cin, int cout, const float *in, const float *wt, const float *bias,
@@ -931,6 +950,11 @@ static int conv_launch(int b, int cin, int cout, const float *in, const float *w
   return p2pb_launch_status();
 }
 
+// the bf16x6 instantiations live in the -DCONV_TU=6 object
+int conv3d_tu6_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
+                     const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                     const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
+                     float *stats_part, bool cl, hipStream_t s, const GnFold &fold, const GnAcc &gacc);
 template <int R, int MT>
 static int conv_launch_split(int b, int cin, int cout, const float *in, const void *wt, const float *bias,
                              const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
@@ -944,16 +968,16 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
   const unsigned short *w = (const unsigned short *)wt;
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
   if (fx && !cl) return P2PB_EINVAL;  // (the statistics plumbing exists in the voxel-major form only)
-  const bool f16 = p2pb_g_split_terms == SPLIT_F16X3;
+#if CONV_TU != 6
+  if (p2pb_g_split_terms == SPLIT_BF16X6)
+    return conv3d_tu6_split(R, MT, b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero,
+                            brick_list, brick_count, out, stats_part, cl, s, fold, gacc);
+#endif
 #define LAUNCHT(XF, CL, FXV, TM)                                                                                      \
   hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk,   \
                      cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list,     \
                      brick_count, out, stats_part, fold, gacc)
-#define LAUNCH(XF, CL, FXV)                           \
-  do {                                                \
-    if (f16) LAUNCHT(XF, CL, FXV, SPLIT_F16X3);        \
-    else LAUNCHT(XF, CL, FXV, 6);                      \
-  } while (0)
+#define LAUNCH(XF, CL, FXV) LAUNCHT(XF, CL, FXV, CONV_TERMS)
   if (in_scale != nullptr || fold.group != nullptr) {
     if (fx) LAUNCH(true, true, true);
     else if (cl) LAUNCH(true, true, false);
@@ -967,6 +991,26 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
 #undef LAUNCHT
   return p2pb_launch_status();
 }
+#if CONV_TU == 6
+int conv3d_tu6_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
+                     const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                     const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
+                     float *stats_part, bool cl, hipStream_t s, const GnFold &fold, const GnAcc &gacc) {
+#define GOB(RR)                                                                                                        \
+  return mt == 2 ? conv_launch_split<RR, 2>(b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, \
+                                            skip_zero, brick_list, brick_count, out, stats_part, cl, s, fold, gacc)      \
+                 : conv_launch_split<RR, 1>(b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, \
+                                            skip_zero, brick_list, brick_count, out, stats_part, cl, s, fold, gacc)
+  switch (r) {
+    case 32: GOB(32);
+    case 16: GOB(16);
+    case 8: GOB(8);
+    case 4: GOB(4);
+    default: return P2PB_EINVAL;
+  }
+#undef GOB
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Brick activity from the voxel occupancy (cnt of avg_voxelize), compact 4x8x8 bricks:
@@ -1005,7 +1049,7 @@ __global__ __launch_bounds__(256) void brick_flags_kernel(const int *__restrict_
 }
 
 // single workgroup: compaction of up to 1024*PER entries into active/inactive lists for both convolutions
-__global__ __launch_bounds__(1024) void brick_compact_kernel(int total, const unsigned char *__restrict__ flags,
+static __global__ __launch_bounds__(1024) void brick_compact_kernel(int total, const unsigned char *__restrict__ flags,
                                                             int *__restrict__ lists, int *__restrict__ counts) {
   __shared__ int wsum[16];
   const int t = threadIdx.x;
@@ -1044,6 +1088,7 @@ __global__ __launch_bounds__(1024) void brick_compact_kernel(int total, const un
 
 // lists i32[4][b*NBRICK] = {active conv0, inactive conv0, active conv1, inactive conv1}, counts i32[4];
 // flags_ws: b*NBRICK*2 bytes of scratch. r in {16, 32}.
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned char *flags_ws, int *lists, int *counts,
                                        void *stream) {
   if (b <= 0 || (r != 16 && r != 32)) return P2PB_EINVAL;
@@ -1054,6 +1099,7 @@ extern "C" int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned ch
   hipLaunchKernelGGL(brick_compact_kernel, dim3(1), dim3(1024), 0, s, nb * b, flags_ws, lists, counts);
   return p2pb_launch_status();
 }
+#endif
 
 // inactive bricks: the convolution's output there is a known constant per channel (bias, or the
 // boundary-class constant K): write it and the brick's exact {sum, sum of squares} partials
@@ -1160,6 +1206,7 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
 // bias per boundary class; stats_part (optional) receives per-(b, slot, cout) {sum, sum of squares} of the
 // output. flags: bit 0 = skip all-zero operand tiles (exact), bit 1 = compact 4x8x8 bricks, bit 2 = wt_packed is
 // the split pack (p2pb_conv3d_k3_pack_weights_split) -> bf16x6 kernel. r in {4,8,16,32}.
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
                                       const float *bias, const float *in_scale, const float *in_shift, int in_swish,
                                       float *out, float *stats_part, void *stream) {
@@ -1174,10 +1221,12 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
   return p2pb_conv3d_k3_forward_fx(b, cin, cout, r, in, wt_packed, bias, out_class, nullptr, in_scale, in_shift,
                                    in_swish, in_sub, flags, out, stats_part, nullptr, stream);
 }
+#endif
 
 // the same with the sampler path's statistics plumbing: in_fold (instead of in_scale / in_shift) = fold the operand's
 // norm here from the producer's accumulators; out_acc (instead of stats_part) = add this output's statistics to
 // accumulators. Split pack only (flags bit 2).
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                          const float *bias, const float *out_class, const p2pb_gn_fold *in_fold,
                                          const float *in_scale, const float *in_shift, int in_swish,
@@ -1228,9 +1277,11 @@ extern "C" int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const 
   }
 #undef GO
 }
+#endif
 
 // list-driven sparse form: MFMA workgroups only for the `active` (sample, brick) pairs, constants for the
 // `inactive` ones (lists from p2pb_conv3d_brick_lists). Compact geometry; r in {16, 32}.
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                              const float *bias, const float *out_class, const float *in_scale,
                                              const float *in_shift, int in_swish, const float *in_sub, int flags,
@@ -1290,6 +1341,7 @@ extern "C" int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r,
   GO(16);
 #undef GO
 }
+#endif
 
 // ================================================================================================
 // Compact form of the split kernel: voxel-level sparsity inside the bricks.
@@ -1387,6 +1439,7 @@ __global__ __launch_bounds__(256) void active_lists_kernel(const int *__restrict
 }
 
 // lists u8[2][b][NBRICK][256], counts i32[2][b][NBRICK]; r in {8, 16, 32}
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned char *lists, int *counts, void *stream) {
   if (b <= 0 || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -1396,6 +1449,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
   else hipLaunchKernelGGL(active_lists_kernel<8>, dim3(nbrick, b), dim3(256), 0, s, cnt, lists, counts, b);
   return p2pb_launch_status();
 }
+#endif
 
 template <int R, int WM, bool XF, bool FX, int TERMS>  // FX, TERMS: see conv3d_k3_split_kernel
 __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
@@ -1744,6 +1798,61 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 
 // in f32[b,r,r,r,cin] -> out f32[b,r,r,r,cout] (voxel-major), wt = split pack; alist/acount = ONE set of
 // p2pb_conv3d_active_lists (D1 for a first convolution, D2 for a second one in far-field form). r in {8,16,32}.
+// the bf16x6 instantiations live in the -DCONV_TU=6 object
+int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
+                       const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                       const float *in_sub, const unsigned char *alist, const int *acount, float *out, float *stats_part,
+                       hipStream_t s, const GnFold &fold, const GnAcc &gacc);
+static int conv_launch_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
+                               const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                               const float *in_sub, const unsigned char *alist, const int *acount, float *out,
+                               float *stats_part, hipStream_t s, const GnFold &fold, const GnAcc &gacc) {
+  const bool xf = in_scale != nullptr || fold.group != nullptr;
+  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
+#if CONV_TU != 6
+  if (p2pb_g_split_terms == SPLIT_BF16X6)
+    return conv3d_tu6_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
+                              acount, out, stats_part, s, fold, gacc);
+#endif
+  const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
+  const unsigned short *w = (const unsigned short *)wt_split;
+  const bool wm1 = cout <= 32;  // one M-tile per workgroup, tiles dealt to four wave columns
+  dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
+  const bool fx = fold.group != nullptr || gacc.group != nullptr;
+#define LAUNCHX(RR, WMV, XF, FXV, TM)                                                                                 \
+  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
+                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part,   \
+                     fold, gacc)
+#define LAUNCH(RR, WMV, XF)                          \
+  do {                                               \
+    if (fx) LAUNCHX(RR, WMV, XF, true, CONV_TERMS);   \
+    else LAUNCHX(RR, WMV, XF, false, CONV_TERMS);     \
+  } while (0)
+#define GO(RR)                                                   \
+  if (wm1) {                                                     \
+    if (xf) LAUNCH(RR, 1, true);                                 \
+    else LAUNCH(RR, 1, false);                                   \
+  } else {                                                       \
+    if (xf) LAUNCH(RR, 2, true);                                 \
+    else LAUNCH(RR, 2, false);                                   \
+  }
+  if (r == 32) { GO(32) } else if (r == 16) { GO(16) } else { GO(8) }
+#undef GO
+#undef LAUNCH
+#undef LAUNCHX
+  return p2pb_launch_status();
+}
+#if CONV_TU == 6
+int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
+                       const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                       const float *in_sub, const unsigned char *alist, const int *acount, float *out, float *stats_part,
+                       hipStream_t s, const GnFold &fold, const GnAcc &gacc) {
+  return conv_launch_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist, acount,
+                             out, stats_part, s, fold, gacc);
+}
+#endif
+
+#if CONV_TU != 6
 extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split,
                                               const float *bias, const float *out_class, const float *in_scale,
                                               const float *in_shift, int in_swish, const float *in_sub,
@@ -1764,41 +1873,10 @@ extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r
     return P2PB_EINVAL;
   const GnFold fold = gn_fold_arg(in_fold);
   const GnAcc gacc = gn_acc_arg(out_acc, cout);
-  const bool xf = in_scale != nullptr || fold.group != nullptr;
-  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
-  const unsigned short *w = (const unsigned short *)wt_split;
-  const bool wm1 = cout <= 32;  // one M-tile per workgroup, tiles dealt to four wave columns
-  dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
-  const bool fx = fold.group != nullptr || gacc.group != nullptr;
-  const int mode = p2pb_g_split_terms;
-#define LAUNCHX(RR, WMV, XF, FXV, TM)                                                                                 \
-  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
-                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part,   \
-                     fold, gacc)
-#define LAUNCH(RR, WMV, XF)               \
-  do {                                    \
-    if (mode == SPLIT_F16X3) {                       \
-      if (fx) LAUNCHX(RR, WMV, XF, true, SPLIT_F16X3);  \
-      else LAUNCHX(RR, WMV, XF, false, SPLIT_F16X3);    \
-    } else if (fx) LAUNCHX(RR, WMV, XF, true, 6);    \
-    else LAUNCHX(RR, WMV, XF, false, 6);             \
-  } while (0)
-#define GO(RR)                                                   \
-  if (wm1) {                                                     \
-    if (xf) LAUNCH(RR, 1, true);                                 \
-    else LAUNCH(RR, 1, false);                                   \
-  } else {                                                       \
-    if (xf) LAUNCH(RR, 2, true);                                 \
-    else LAUNCH(RR, 2, false);                                   \
-  }
-  if (r == 32) { GO(32) } else if (r == 16) { GO(16) } else { GO(8) }
-#undef GO
-#undef LAUNCH
-#undef LAUNCHX
-  return p2pb_launch_status();
+  return conv_launch_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
+                             acount, out, stats_part, (hipStream_t)stream, fold, gacc);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm(+AdaGN) folded to a per-(sample, channel) affine:  AdaGN(GN(x)) == x*scale + shift.
@@ -1812,7 +1890,7 @@ extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r
 // one workgroup per (sample, group). Thread t accumulates channel (t mod cg) over the slots
 // t/cg, t/cg + 256/cg, ... (adjacent threads read adjacent channels: coalesced), the 256/cg partial
 // accumulators per channel are then summed in ascending order -- a fixed order, so deterministic.
-__global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int nslots, double count_per_channel,
+static __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int nslots, double count_per_channel,
                                                         const float *__restrict__ part, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, const float *__restrict__ style,
                                                         int style_stride, float eps, float *__restrict__ scale,
@@ -1872,6 +1950,7 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups, int n
 
 // part: f32[b, nslots, c, 2]; gamma/beta f32[c] or NULL; style = rows of (factor[c] | bias[c]) with a row pitch of
 // style_stride floats (a column slice of the one style GEMM of the evaluation), or NULL -> scale/shift/chmean f32[b,c]
+#if CONV_TU != 6
 extern "C" int p2pb_gn_affine_params_ex(int b, int c, int groups, int nslots, double count_per_channel,
                                         const float *part, const float *gamma, const float *beta, const float *style,
                                         int style_stride, float eps, float *scale, float *shift, float *chmean,
@@ -1890,13 +1969,14 @@ extern "C" int p2pb_gn_affine_params(int b, int c, int groups, int nslots, doubl
   return p2pb_gn_affine_params_ex(b, c, groups, nslots, count_per_channel, part, gamma, beta, style, style_stride, eps,
                                   scale, shift, chmean, nullptr, stream);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Squeeze-excite gate (models/modules.py:362-378: Linear(c, c/8, no bias) -> ReLU -> Linear(c/8, c, no bias) ->
 // Sigmoid on the per-channel mean of the normalised grid) folded into the devoxelisation affine:
 //   gate = sigmoid(W2 relu(W1 chmean)),  aff_a = scale * gate,  aff_b = shift * gate.   One workgroup per sample.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void se_gate_affine_kernel(int c, int hidden, const float *__restrict__ chmean,
+static __global__ __launch_bounds__(256) void se_gate_affine_kernel(int c, int hidden, const float *__restrict__ chmean,
                                                              const float *__restrict__ w1, const float *__restrict__ w2,
                                                              const float *__restrict__ scale,
                                                              const float *__restrict__ shift, float *__restrict__ aff_a,
@@ -1921,6 +2001,7 @@ __global__ __launch_bounds__(256) void se_gate_affine_kernel(int c, int hidden, 
   }
 }
 
+#if CONV_TU != 6
 extern "C" int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,
                                    const float *scale, const float *shift, float *aff_a, float *aff_b, void *stream) {
   if (b <= 0 || c <= 0 || hidden <= 0) return P2PB_EINVAL;
@@ -1928,13 +2009,14 @@ extern "C" int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean
                      (hipStream_t)stream, c, hidden, chmean, w1, w2, scale, shift, aff_a, aff_b);
   return p2pb_launch_status();
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // The same two steps on the sampler path's accumulators (common.h: fixed-point group / channel sums added by the
 // producers' epilogues). gn_fold_params_kernel is the stand-alone finisher for consumers that take scale / shift
 // arrays; se_gate_affine_fold_kernel folds the norm itself (it is the consumer of the second convolution's statistics).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn_fold_params_kernel(int c, GnFold fold, float *__restrict__ scale,
+static __global__ __launch_bounds__(256) void gn_fold_params_kernel(int c, GnFold fold, float *__restrict__ scale,
                                                              float *__restrict__ shift, float *__restrict__ chmean) {
   const int b = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
   if (ch >= c) return;
@@ -1945,6 +2027,7 @@ __global__ __launch_bounds__(256) void gn_fold_params_kernel(int c, GnFold fold,
   if (chmean) chmean[(size_t)b * c + ch] = cm;
 }
 
+#if CONV_TU != 6
 extern "C" int p2pb_gn_fold_params(int b, int c, const p2pb_gn_fold *fold, float *scale, float *shift, float *chmean,
                                    void *stream) {
   if (b <= 0 || c <= 0 || !fold || !fold->group || !gn_fold_ok(fold, c) || !scale || !shift ||
@@ -1954,8 +2037,9 @@ extern "C" int p2pb_gn_fold_params(int b, int c, const p2pb_gn_fold *fold, float
                      shift, chmean);
   return p2pb_launch_status();
 }
+#endif
 
-__global__ __launch_bounds__(256) void se_gate_affine_fold_kernel(int c, int hidden, GnFold fold,
+static __global__ __launch_bounds__(256) void se_gate_affine_fold_kernel(int c, int hidden, GnFold fold,
                                                                   const float *__restrict__ w1,
                                                                   const float *__restrict__ w2,
                                                                   float *__restrict__ aff_a, float *__restrict__ aff_b) {
@@ -1980,6 +2064,7 @@ __global__ __launch_bounds__(256) void se_gate_affine_fold_kernel(int c, int hid
 }
 
 // fold (group + channel accumulators of the grid the gate squeezes) -> aff_a, aff_b f32[b,c]
+#if CONV_TU != 6
 extern "C" int p2pb_se_gate_affine_fx(int b, int c, int hidden, const p2pb_gn_fold *fold, const float *w1,
                                       const float *w2, float *aff_a, float *aff_b, void *stream) {
   if (b <= 0 || c <= 0 || hidden <= 0 || !fold || !fold->group || !fold->channel || !gn_fold_ok(fold, c))
@@ -1988,3 +2073,4 @@ extern "C" int p2pb_se_gate_affine_fx(int b, int c, int hidden, const p2pb_gn_fo
                      (hipStream_t)stream, c, hidden, *fold, w1, w2, aff_a, aff_b);
   return p2pb_launch_status();
 }
+#endif
