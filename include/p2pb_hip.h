@@ -417,6 +417,10 @@ int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float 
  * 16-byte aligned in/out. Meant for the matrix-bound layers (wide channel counts). */
 size_t p2pb_pointwise_split_packed_bytes(int cout, int cin);
 int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w /* [cout][cin] */, void *wp, void *stream);
+/* flags bit 7 (with bit 2, f16x3 arithmetic, 16-byte rows, no in_fold / out_acc): a NARROW layer (cin or cout < 128) on
+ * the split pack -- the register-tiled kernel of the fp32 pack with its products on the 16-bit matrix pipe (three MFMAs of
+ * K = 16 instead of eight exact-fp32 ones of K = 2 per 32x32x16 block); outputs, statistics and minmax in the layout of the
+ * fp32-pack form (p2pb_pointwise_minmax_floats takes the same flags). */
 /* flags bit 6 (with bit 2, f16x3 arithmetic, npos % 128 == 0, no in_scale / in_fold / out_acc, channel-major output):
  * `in` is not f32[b,cin,npos] but the operand already transformed and split by p2pb_pointwise_presplit -- for wide layers
  * whose operand would otherwise be transformed and split once per output-channel block of 256 (the global embedding's

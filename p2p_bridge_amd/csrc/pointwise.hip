@@ -202,7 +202,12 @@ __device__ __forceinline__ void group_minmax(float &mn, float &mx, int g) {
 //   max_p act(scale*x_p + shift) = max(act(scale*min_p x_p + shift), act(scale*max_p x_p + shift)),
 // and the pooled tensor is produced by p2pb_minmax_act from 2/U-th of the data without the layer's
 // output ever being written or re-read.
-template <int MT, bool XF, bool STATS, bool POOL, bool FX>  // FX: see pw_split_kernel
+// TERMS == SPLIT_F16X3: the same tiling, operand path and epilogue with the products on the 16-bit matrix pipe (fp16-pair
+// split, three MFMAs of K = 16 instead of eight exact-fp32 ones of K = 2: 5.3x fewer matrix cycles -- the exact-fp32
+// MFMAs were HALF the time of the set-abstraction neighbourhood layers, tools/exp_pw_wide_pool.py). `wp` is then the split
+// pack of pw_split_kernel (fragments read straight from L1 / L2, output scale in its trailer); 16 input channels per step:
+// lane (l31, khalf) loads rows 8 khalf .. + 7 of the step for its four positions, transforms and splits them once.
+template <int MT, bool XF, bool STATS, bool POOL, bool FX, int TERMS = 0>  // FX: see pw_split_kernel
 __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int cout_pad, int P, int nslots,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias,
@@ -231,6 +236,83 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][s][r] = 0.0f;
 
+  if constexpr (TERMS == SPLIT_F16X3) {
+    constexpr int PWS_TILE_ = 2 * 3 * 2 * 128;  // (PWS_TILE of the split pack, defined below)
+    const u32x4 *wp4 = (const u32x4 *)wp;
+    const int ncoblk128 = (cout + 127) / 128, nchunk32 = (cin + 31) / 32;
+    const u32x4 *wtile = wp4 + (size_t)(co0 >> 7) * PWS_TILE_ + khalf * 128 + (co0 & 127) + l31;
+    const unsigned voffh = (unsigned)(khalf * 8 * P + pc) * 4u, rowb = (unsigned)P * 4u;
+    f32x4 braw[8];
+    u32x4 a_nx[MT][2];
+    auto load_bh = [&](int ci0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = min(ci0 + i, cin - 1);  // rows at or beyond cin: zero records -> hardware zeros (x zero weights)
+        const int rec = ci0 + i < cin ? (int)((unsigned)(cin - row) * rowb) : 0;
+        auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, rec, 0x00020000);
+        braw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voffh, 0, 0));
+      }
+    };
+    auto load_ah = [&](int ci0) {
+      const u32x4 *t = wtile + (size_t)(ci0 >> 5) * ncoblk128 * PWS_TILE_ + ((ci0 >> 4) & 1) * (3 * 2 * 128);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a_nx[m][pl] = t[pl * 256 + m * 32];
+    };
+    load_bh(0);
+    load_ah(0);
+    for (int ci0 = 0; ci0 < cin; ci0 += 16) {
+      if (XF) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ca = b * cin + min(ci0 + i, cin - 1), cb = b * cin + min(ci0 + 8 + i, cin - 1);
+          const float sca = in_scale[ca], scb = in_scale[cb], sha = in_shift[ca], shb = in_shift[cb];
+          const float sc = khalf ? scb : sca, sh = khalf ? shb : sha;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float v = braw[i][t] * sc + sh;
+            if (in_swish) v = swishf(v);
+            braw[i][t] = v;
+          }
+        }
+      }
+      u32x4 pl0[4], pl1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          unsigned p0, p1, p2;
+          split_pair<SPLIT_F16X3>(braw[2 * i][t], braw[2 * i + 1][t], p0, p1, p2);
+          pl0[t][i] = p0;
+          pl1[t][i] = p1;
+        }
+      u32x4 a_cu[MT][2];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) a_cu[m][pl] = a_nx[m][pl];
+      if (ci0 + 16 < cin) {  // the next step's loads fly during the MFMAs
+        load_ah(ci0 + 16);
+        load_bh(ci0 + 16);
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][1], pl0[t], acc[m][t]);
+          acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][0], pl1[t], acc[m][t]);
+          acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][0], pl0[t], acc[m][t]);
+        }
+    }
+    const float oscale = ((const float *)(wp4 + (size_t)nchunk32 * ncoblk128 * PWS_TILE_))[1];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][t][r] *= oscale;
+  }
   const unsigned voff = (unsigned)(khalf * P + pc) * 4u;
   const unsigned rowbytes = (unsigned)P * 4u;
   f32x4 bcur[PWW_CK / 2], bnxt[PWW_CK / 2];
@@ -250,15 +332,17 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
 #pragma unroll
     for (int m = 0; m < MT; ++m) dst[m] = *(const f32x4 *)(wbase + (size_t)chunk * wchunk_stride + (size_t)m * 32 * 4);
   };
-  load_b(0, bnxt);
-  load_a(0, a_nxt);
+  if constexpr (TERMS == 0) {
+    load_b(0, bnxt);
+    load_a(0, a_nxt);
+  }
   const bool folded = FX && XF && fold.group != nullptr;  // (the caller's arrays: scalar loads, no LDS, no barrier)
   if (folded) {
     xf_table(xtab, fold, in_scale, in_shift, b, cin);
     __syncthreads();
   }
 
-  for (int ci0 = 0; ci0 < cin; ci0 += PWW_CK) {
+  for (int ci0 = 0; TERMS == 0 && ci0 < cin; ci0 += PWW_CK) {
     // rotate (the vmcnt wait lands here), request the next chunk, then multiply the current one
 #pragma unroll
     for (int kk = 0; kk < PWW_CK / 2; ++kk) bcur[kk] = bnxt[kk];
@@ -290,6 +374,13 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
         }
       }
     }
+#ifdef PWW_EXP_NOMFMA  // timing experiment: the loop without its matrix instructions (one per chunk keeps the operands live)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        acc[m][s][0] += a_cur[m][s] * bcur[s][s];
+#else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -297,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
 #pragma unroll
         for (int s = 0; s < 4; ++s)
           acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][kk], bcur[kk][s], acc[m][s], 0, 0, 0);
+#endif
   }
 
   if (out_pm) {  // point-major output f32[b, P, cout] (the consumer gathers whole rows); no statistics in this form
@@ -1233,21 +1325,24 @@ template <int MT>
 static int pw_launch(int b, int cin, int cout, int P, const float *in, const float *wp, const float *bias,
                      const float *bias_b, const float *in_scale, const float *in_shift, int in_swish, float *out,
                      float *stats_part, float *minmax, int pool_g, int out_pm, hipStream_t s,
-                     const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
+                     const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc(), bool split_pack = false) {
   const bool xf = in_scale != nullptr || fold.group != nullptr, st = stats_part != nullptr || gacc.group != nullptr;
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
+  const bool fx = fold.group != nullptr || gacc.group != nullptr;
+  // split_pack: wp is the f16x3 split pack (flags bits 2 + 7): plain statistics form, 16-byte rows, f16x3 selected
+  if (split_pack && (fx || !pw_wide_ok(P, in, out) || p2pb_g_split_terms != SPLIT_F16X3)) return P2PB_EINVAL;
   if (pw_wide_ok(P, in, out)) {
     dim3 grid((P + 511) / 512, (cout + 32 * MT - 1) / (32 * MT), b);
     const int nslots = (P + 255) / 256 * 4;
-    const bool fx = fold.group != nullptr || gacc.group != nullptr;
-#define LAUNCHX(XF, ST, PL, FXV)                                                                                      \
-  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL, FXV>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P,      \
+#define LAUNCHX(XF, ST, PL, FXV, TM)                                                                                  \
+  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL, FXV, TM>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P,  \
                      nslots, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm, \
                      fold, gacc)
-#define LAUNCH(XF, ST, PL)             \
-  do {                                 \
-    if (fx) LAUNCHX(XF, ST, PL, true);  \
-    else LAUNCHX(XF, ST, PL, false);    \
+#define LAUNCH(XF, ST, PL)                                        \
+  do {                                                            \
+    if (split_pack) LAUNCHX(XF, ST, PL, false, SPLIT_F16X3);       \
+    else if (fx) LAUNCHX(XF, ST, PL, true, 0);                     \
+    else LAUNCHX(XF, ST, PL, false, 0);                            \
   } while (0)
     if (minmax) {
       if (xf) LAUNCH(true, true, true);
@@ -1295,6 +1390,13 @@ extern "C" int p2pb_pointwise_conv_forward_fx(int b, int cin, int cout, int npos
   hipStream_t s = (hipStream_t)stream;
   const int out_pm = (flags & 32) != 0;  // point-major output f32[b, npos, cout]
   if (out_pm && (stats_part || gacc.group)) return P2PB_EINVAL;
+  if ((flags & 4) && (flags & 128)) {  // narrow layer on the split pack: the wide tiling with f16x3 products
+    const float *wsp = (const float *)wp_any;
+    return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                    stats_part, nullptr, 0, out_pm, s, fold, gacc, true)
+                     : pw_launch<1>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                    stats_part, nullptr, 0, out_pm, s, fold, gacc, true);
+  }
   if (flags & 4) {  // wp is the split pack; flags & 64: `in` is the pre-split operand (p2pb_pointwise_presplit)
     if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
@@ -1318,7 +1420,8 @@ extern "C" int p2pb_pointwise_pool_supported(int npos, int pool_u) {
 }
 
 extern "C" size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int pool_u, int flags) {
-  if (pool_u == 0) return (size_t)b * ((flags & 4) ? (npos + 127) / 128 * 2 : (npos + 511) / 512 * 4) * cout * 2;
+  const bool split_tiling = (flags & 4) && !(flags & 128);  // (bit 7: the wide tiling on the split pack)
+  if (pool_u == 0) return (size_t)b * (split_tiling ? (npos + 127) / 128 * 2 : (npos + 511) / 512 * 4) * cout * 2;
   return (size_t)b * cout * (npos / pool_u) * 2;
 }
 
@@ -1345,6 +1448,14 @@ extern "C" int p2pb_pointwise_conv_pool_forward_fx(int b, int cin, int cout, int
   if (!stats_part && !gacc.group) return P2PB_EINVAL;
   if (!p2pb_pointwise_pool_supported(npos, pool_u) || !pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if ((flags & 4) && (flags & 128)) {
+    const float *wsp = (const float *)wp_any;
+    const int gl = pool_lanes(pool_u);
+    return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                    stats_part, minmax, gl, 0, s, fold, gacc, true)
+                     : pw_launch<1>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
+                                    stats_part, minmax, gl, 0, s, fold, gacc, true);
+  }
   if (flags & 4)
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
                            minmax, pool_u, 0, s, fold, gacc, (flags & 64) != 0);

@@ -512,6 +512,12 @@ def pool_supported(npos: int, pool_u: int) -> bool:
 PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/exp_pw.py)
 
 
+def use_wide_f16(ci: int, co: int) -> bool:
+    """narrow 1x1 layers on the 16-bit matrix pipe too (csrc/pointwise.hip pw_wide_kernel<TERMS = f16x3>): from
+    P2PB_WIDE_F16_MIN_CIN input channels up (default 16: below that a 16-channel step is mostly padding)"""
+    return ci >= int(os.environ.get("P2PB_WIDE_F16_MIN_CIN", "16"))
+
+
 def use_presplit(b: int, co: int, npos: int) -> bool:
     """pre-split operand for a split GEMM (csrc/pointwise.hip pw_presplit_kernel + pw_split_kernel<PRE>): f16x3 only,
     256-channel workgroups (the rule of pw_launch_split) and at least P2PB_PRESPLIT_BLOCKS of them per activation tile.
@@ -547,9 +553,13 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         x = affine_act(x, *_arrays_of(in_scale, in_shift), swish)
         in_scale = in_shift = None
         swish = False
-    wp = pack_pointwise_weight(conv, ci_lo, ci_hi, split)
     point_major = point_major and not stats and pool_u is None and p % 4 == 0
-    pre = 0
+    # narrow layers in the f16x3 arithmetic: the wide (register-tiled) kernel on the split pack (flags 4 | 128)
+    wide_h = (not split and math is None and conv_math() == "f16x3" and lib().p2pb_get_split_terms() == 16 and p % 4 == 0
+              and x.data_ptr() % 16 == 0 and use_wide_f16(ci, co) and not (acc_groups and gn_acc_enabled("pww"))
+              and not isinstance(in_scale, Fold))
+    wp = pack_pointwise_weight(conv, ci_lo, ci_hi, split or wide_h)
+    pre = 128 if wide_h else 0
     if (split and in_scale is not None and not isinstance(in_scale, Fold) and not point_major and p % 128 == 0
             and x.is_contiguous() and use_presplit(b, co, p)):
         # f16x3: transform + split the operand ONCE (csrc/pointwise.hip pw_presplit_kernel) instead of once per
@@ -558,7 +568,7 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         call("p2pb_pointwise_presplit", _i(b), _i(ci), _i(p), ptr(x), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(xs),
              stream_ptr())
         x, in_scale, in_shift, swish, pre = xs, None, None, False, 64
-    flags = _i((4 if split else 0) | (32 if point_major else 0) | pre)
+    flags = _i((4 if (split or wide_h) else 0) | (32 if point_major else 0) | pre)
     if point_major:
         y = torch.empty(b, p, co, dtype=F32, device=x.device)
     else:

@@ -211,3 +211,42 @@ def test_presplit_operand_is_bit_identical(fused, monkeypatch, pool, ci):
     # the C ABI refuses what the image cannot describe
     lib = fused.lib()
     assert lib.p2pb_pointwise_presplit_bytes(4, 64, 100) == 0 and lib.p2pb_pointwise_presplit_bytes(4, 40, 256) == 4 * 2 * 2 * 16384
+
+
+@pytest.mark.parametrize("ci,co,P,pool,xf", [(32, 64, 4096, 32, True), (64, 128, 2048, None, True), (35, 128, 1024, None, False),
+                                               (128, 64, 1024, 0, True), (19, 24, 512, None, False)])
+def test_narrow_layers_on_the_f16_pipe(fused, monkeypatch, ci, co, P, pool, xf):
+    """pw_wide_kernel<TERMS = f16x3>: the register-tiled kernel of the narrow layers with its products on the 16-bit pipe
+    (ragged channel counts, pooling epilogue, statistics): within the f16x3 bound of fp64, statistics and pooled
+    {min, max} consistent with its own outputs; P2PB_WIDE_F16_MIN_CIN switches back to the exact-fp32 MFMA form"""
+    torch.manual_seed(ci * co)
+    B = 3
+    x = torch.randn(B, ci, P, device="cuda") * 2
+    conv = torch.nn.Conv1d(ci, co, 1).cuda()
+    sc = (torch.rand(B, ci, device="cuda") + 0.5) if xf else None
+    sh = torch.randn(B, ci, device="cuda") if xf else None
+    kw = dict(swish=True) if xf else {}
+    if pool is not None:
+        kw["pool_u"] = pool
+    assert not fused.use_split_pw(ci, co, P) and fused.use_wide_f16(ci, co)
+    with torch.no_grad():
+        xin = swish(x.double() * sc[:, :, None].double() + sh[:, :, None].double()) if xf else x.double()
+        ref = torch.nn.functional.conv1d(xin, conv.weight.double(), conv.bias.double())
+        mag = torch.nn.functional.conv1d(xin.abs(), conv.weight.double().abs()) + 1e-300
+        a = fused.pw_conv(x, conv, sc, sh, **kw)
+        monkeypatch.setenv("P2PB_WIDE_F16_MIN_CIN", "1000000")
+        f = fused.pw_conv(x, conv, sc, sh, **kw)
+    y, y32 = a[0], f[0]
+    assert not torch.equal(y, y32)
+    assert ((y - ref).abs() / mag).max().item() < BOUND_F16 and ((y32 - ref).abs() / mag).max().item() < ACC
+    n = P if pool in (None, 0) else P
+    s1 = a[1].double().sum(1)  # [B, co, 2]: sum, sum of squares over positions
+    assert torch.allclose(s1[..., 0], y.double().sum(2), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(s1[..., 1], (y.double() ** 2).sum(2), rtol=1e-5, atol=1e-3)
+    if pool == 32:
+        mm = a[2]  # [B, co, P / 32, 2]
+        g = y.view(B, co, P // 32, 32)
+        assert torch.equal(mm[..., 0], g.min(-1).values) and torch.equal(mm[..., 1], g.max(-1).values)
+    if pool == 0:
+        mm = a[2]  # per-wave partials [B, slots, co, 2]
+        assert torch.equal(mm[..., 0].min(1).values, y.min(2).values) and torch.equal(mm[..., 1].max(1).values, y.max(2).values)

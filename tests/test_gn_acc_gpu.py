@@ -12,6 +12,13 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def narrow_layers_on_fp32_mfma(monkeypatch):
+    """the accumulator forms of the narrow 1x1 kernel exist in the exact-fp32 arithmetic only: compare like with like
+    (the plain form would otherwise take the f16x3 path of pw_wide_kernel and differ in the last bits)"""
+    monkeypatch.setenv("P2PB_WIDE_F16_MIN_CIN", "1000000")
+
 FRAC = float(2 ** 44)
 
 
