@@ -473,10 +473,18 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
     const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
     u32x4 a_nxt[3];
+#ifdef CONV_EXP_NOA  // timing experiment: one weight fragment set for all taps (no A stream through the L1)
+#pragma unroll
+    for (int s = 0; s < NP; ++s) a_nxt[s] = a_cur[s];
+#else
     if (tap + 1 < CONV_NTAPS) {
 #pragma unroll
       for (int s = 0; s < NP; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
     }
+#endif
+#ifdef CONV_EXP_NOB  // timing experiment: the B fragments of tap 0 for all taps (no LDS reads in the tap loop)
+    if (tap == 0)
+#endif
     load_b(0, toff);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TERMS == 6) {
@@ -490,7 +498,9 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     }
     mfma_term(0, 1);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef CONV_EXP_NOB
     if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TERMS != 6) mfma_term(1, 0);
     mfma_term(0, 0);
