@@ -36,16 +36,16 @@ const char *p2pb_target_arch(void); /* "gfx950" */
 /* Arithmetic of the split-operand matrix kernels (conv3d_k3 *_forward, pointwise_conv *_forward with >= 128 channels).
  * The reference's layers are cuDNN / cuBLAS convolutions in fp32, which on its Ampere+ targets run as TF32
  * (torch.backends.cudnn.allow_tf32 defaults to True; train.py:221 also sets float32_matmul_precision("high")).
- * gfx950 has no TF32: an fp32 operand is split into 16-bit terms and a product is a sum of matrix products, fp32 accumulate:
- *    6 (default) bf16 terms x0 + x1 + x2: x2y0 + x1y1 + x0y2 + x1y0 + x0y1 + x0y0 -- within a quarter ulp of fp32;
- *    3           the same split:          x1y0 + x0y1 + x0y0 -- <= 3 * 2^-18 relative per product (TF32: 2^-11);
- *   16           fp16 pair h0 + h1 of the SCALED operand, h1g0 + h0g1 + h0g0 -- <= 3 * 2^-22 relative per product inside
+ * gfx950 has no TF32: an fp32 operand is split into 16-bit terms and a product is a sum of EXACT matrix products of the
+ * terms, accumulated in fp32 (operands, accumulation and results stay fp32):
+ *   16 (default) fp16 pair h0 + h1 of the SCALED operand, h1g0 + h0g1 + h0g0 -- <= 3 * 2^-22 relative per product inside
  *                fp16's range: activations are multiplied by 4 and saturate at |x| = 16376, below |x| = 2^-5 the
- *                representation error is an absolute 2^-27; weights get a per-tensor power-of-two scale at pack time.
+ *                representation error is an absolute 2^-27; weights get a per-tensor power-of-two scale at pack time;
+ *    6           bf16 terms x0 + x1 + x2: x2y0 + x1y1 + x0y2 + x1y0 + x0y1 + x0y0 -- within a quarter ulp of fp32 at any
+ *                magnitude (use it for operands without a usable scale: gradients).
  * Process-wide; takes effect at the next launch (a captured graph keeps what it captured). The *_pack_weights_split
- * functions pack for the arithmetic selected when they are called: packs made under 6 / 3 are interchangeable, a pack
- * made under 16 is only valid under 16 (and vice versa) -- re-pack after such a switch.
- * -> 0, or P2PB_EINVAL for anything but 3, 6 or 16. */
+ * functions pack for the arithmetic selected when they are called: re-pack after a switch.
+ * -> 0, or P2PB_EINVAL for anything but 6 or 16. */
 int p2pb_set_split_terms(int terms);
 int p2pb_get_split_terms(void);
 
@@ -213,9 +213,11 @@ int p2pb_auction_backward(int b, int n, const float *xyz1, const float *xyz2, fl
  * Weights are pre-packed once: w f32[cout,cin,3,3,3] -> wt_packed f32[p2pb_conv3d_k3_packed_floats()]. */
 size_t p2pb_conv3d_k3_packed_floats(int cout, int cin);
 int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, float *wt_packed, void *stream);
-/* The split pack: every weight as three bf16 terms (w = w0 + w1 + w2) for the bf16x6 form of the same
- * convolution -- six bf16 MFMA products per fp32 product, fp32 accumulate, dropped terms < 2^-26 |x*w|
- * (conv3d.hip: fp32-faithful, 1.6x the fp32 matrix-core rate). Selected by flags bit 2 below. */
+/* The split pack: every weight as 16-bit terms for the split-operand form of the same convolution, in the arithmetic
+ * selected by p2pb_set_split_terms WHEN THE PACK IS MADE -- 16: an fp16 pair of w * S_w (S_w = the power of two that
+ * brings max |w| into [2^13, 2^14), found on the device; 1 / (4 S_w) is stored behind the pack), three MFMA products per
+ * fp32 product; 6: three bf16 terms, six products, dropped terms < 2^-26 |x*w|. fp32 accumulate either way
+ * (conv3d.hip). Selected by flags bit 2 below. */
 size_t p2pb_conv3d_k3_split_packed_bytes(int cout, int cin);
 int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float *w, void *wt_split, void *stream);
 /* out[b,cout,r,r,r] = conv(xf(in[b,cin,r,r,r])) + bias;  xf(x) = x when in_scale == NULL, else
