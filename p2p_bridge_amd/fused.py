@@ -683,3 +683,54 @@ def affine_act_max(x, scale, shift, m, u, swish=True):
     call("p2pb_affine_act_max", _i(b), _i(c), _i(m), _i(u), ptr(x), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
          stream_ptr())
     return y
+
+
+class operand_audit:
+    """`with operand_audit() as rows: model.model(x, t)` -- the f16x3 range contract checked on real data: for every
+    split-operand launch inside, (kind, operand shape, max |operand after the folded norm + Swish|, max |w|) is appended
+    to `rows` (one host synchronisation per launch: a diagnostic, not for timed runs). `.worst` = the largest operand;
+    `.ok` = it is inside the exact range (|x| < 16376) with a factor 4 to spare. A checkpoint whose activations leave
+    that range should run `P2PB_CONV_MATH=bf16x6`."""
+    LIMIT = 16376.0
+
+    def __enter__(self):
+        import sys
+        self.rows, self._mod = [], sys.modules[__name__]
+        self._orig = {k: getattr(self._mod, k) for k in ("pw_conv", "conv3d_k3", "conv3d_k3_sparse", "conv3d_k3_compact")}
+        names = {"pw_conv": ("in_scale", "in_shift", "swish"), "conv3d_k3": ("in_scale", "in_shift", "swish"),
+                 "conv3d_k3_sparse": (None, None, None, "in_scale", "in_shift", "swish"),
+                 "conv3d_k3_compact": (None, None, None, "in_scale", "in_shift", "swish")}
+
+        def wrap(kind, orig):
+            def f(x, conv, *a, **k):
+                kw = dict(k)
+                for n, v in zip(names[kind], a):
+                    if n:
+                        kw[n] = v
+                sc, sh = _arrays_of(kw.get("in_scale"), kw.get("in_shift"))
+                cl = kw.get("channels_last", kind == "conv3d_k3_compact")
+                v = x
+                if sc is not None:
+                    shape = [x.shape[0]] + ([1] * (x.dim() - 2) + [-1] if cl else [-1] + [1] * (x.dim() - 2))
+                    v = x * sc.view(shape) + sh.view(shape)
+                    if kw.get("swish"):
+                        v = v * torch.sigmoid(v)
+                self.rows.append((kind, tuple(x.shape), float(v.abs().max()), float(conv.weight.abs().max())))
+                return orig(x, conv, *a, **k)
+            return f
+
+        for k, o in self._orig.items():
+            setattr(self._mod, k, wrap(k, o))
+        return self
+
+    def __exit__(self, *exc):
+        for k, o in self._orig.items():
+            setattr(self._mod, k, o)
+
+    @property
+    def worst(self):
+        return max((r[2] for r in self.rows), default=0.0)
+
+    @property
+    def ok(self):
+        return self.worst < self.LIMIT / 4

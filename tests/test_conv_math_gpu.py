@@ -250,3 +250,22 @@ def test_narrow_layers_on_the_f16_pipe(fused, monkeypatch, ci, co, P, pool, xf):
     if pool == 0:
         mm = a[2]  # per-wave partials [B, slots, co, 2]
         assert torch.equal(mm[..., 0].min(1).values, y.min(2).values) and torch.equal(mm[..., 1].max(1).values, y.max(2).values)
+
+
+def test_operand_audit(fused):
+    """the range contract checked on a real evaluation: every split launch of the tiny network reports its largest operand"""
+    from p2p_bridge_amd import p2pb as product
+    cfg = json.load(open(os.path.join(G, "tiny_cfg.json")))
+    w = np.load(os.path.join(G, "tiny_weights.npz"))
+    sd = {k: torch.from_numpy(w[k]).float() for k in w.files}
+    run = np.load(os.path.join(G, "tiny_run.npz"))
+    model = product.build_model(cfg, sd, device="cuda")
+    model.eval()
+    x, t = torch.from_numpy(run["x_start"]).cuda(), torch.from_numpy(run["t"]).cuda()
+    with torch.no_grad():
+        ref = model.model(x, t)
+        with fused.operand_audit() as audit:
+            out = model.model(x, t)
+    assert torch.equal(out, ref) and len(audit.rows) > 10
+    assert audit.ok and 0.1 < audit.worst < 1000, audit.worst
+    assert fused.pw_conv.__name__ == "pw_conv"  # the wrappers are gone
