@@ -811,7 +811,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+        for (int s = 0; s < split_planes(TERMS); ++s)
 #pragma unroll
           for (int m = 0; m < 2; ++m)
             areg[ks][s][m] = src[((ks * 3 + s) * 2 + khalf) * 128 + (wm & 1) * 64 + m * 32 + l31];
