@@ -224,7 +224,7 @@ def use_split(cout: int, math=None) -> bool:
 
 
 def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
-    """packed copy of a Conv3d weight (fp32 [27][cin_pad][cout_pad], or split=True the 3 x bf16 pack of the bf16x6
+    """packed copy of a Conv3d weight (fp32 [27][cin_pad][cout_pad], or split=True the 16-bit pack of the split-operand
     kernel), cached on the module and refreshed when the parameter is modified in place (optimizer step /
     load_state_dict) or replaced"""
     w = conv.weight
@@ -478,7 +478,7 @@ def enabled(module: torch.nn.Module, x: torch.Tensor) -> bool:
 
 def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None, split=False) -> torch.Tensor:
     """packed copy of a k=1 Conv1d/Conv2d (or Linear) weight [co, ci(,1(,1))], optionally an input-channel
-    slice; fp32 pack or (split) the 3 x bf16 pack of the bf16x6 kernel; cached on the module like
+    slice; fp32 pack or (split) the 16-bit pack of the split-operand kernel in the arithmetic selected now; cached like
     pack_conv3d_weight"""
     w = conv.weight
     ci_hi = w.shape[1] if ci_hi is None else ci_hi
@@ -529,7 +529,7 @@ def use_presplit(b: int, co: int, npos: int) -> bool:
 
 
 def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
-    """the bf16x6 GEMM (csrc/pointwise.hip pw_split_kernel) for the matrix-bound layers; narrow layers are
+    """the split-operand GEMM (csrc/pointwise.hip pw_split_kernel) for the matrix-bound layers; narrow layers are
     HBM-bound and stay on the streaming fp32 kernel"""
     return ((math or conv_math()) in SPLIT_MATHS and ci >= PW_SPLIT_MIN_CIN and co >= PW_SPLIT_MIN_COUT
             and npos % 4 == 0)
