@@ -269,3 +269,24 @@ def test_operand_audit(fused):
     assert torch.equal(out, ref) and len(audit.rows) > 10
     assert audit.ok and 0.1 < audit.worst < 1000, audit.worst
     assert fused.pw_conv.__name__ == "pw_conv"  # the wrappers are gone
+
+
+def test_conv_f16_saturation_and_weight_scale(fused):
+    """the voxel convolution under the same contract as the GEMM: an operand beyond the exact range saturates at 16376
+    (finite outputs, equal to the convolution of the clamped grid), weights of any magnitude keep the relative bound"""
+    torch.manual_seed(4)
+    B, C, C1, r = 2, 32, 64, 8
+    grid = torch.randn(B, r, r, r, C, device="cuda") * 10
+    grid[0, 3, 4, 5, 7] = 3e9
+    grid[1, 0, 0, 0, 0] = -1e30
+    for wgain in (1.0, 2.0 ** -18, 5e3):
+        conv = torch.nn.Conv3d(C, C1, 3, padding=1).cuda()
+        with torch.no_grad():
+            conv.weight.mul_(wgain)
+            conv.bias.zero_()
+            y = fused.conv3d_k3(grid, conv, compact=True, channels_last=True)[0]
+            g64 = grid.clamp(-16376.0, 16376.0).permute(0, 4, 1, 2, 3).double()
+            ref = torch.nn.functional.conv3d(g64, conv.weight.double(), None, padding=1).permute(0, 2, 3, 4, 1)
+            mag = torch.nn.functional.conv3d(g64.abs(), conv.weight.double().abs(), padding=1).permute(0, 2, 3, 4, 1) + 1e-300
+        assert torch.isfinite(y).all()
+        assert ((y - ref).abs() / mag).max().item() < BOUND_F16, wgain
