@@ -438,3 +438,91 @@ def synthetic_patches(B, N, seed=0):
     noisy, clean = noisy - c, clean - c
     sc = noisy.norm(dim=-1).max(dim=1).values.view(B, 1, 1)
     return (noisy / sc).transpose(1, 2).contiguous(), (clean / sc).transpose(1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------- training losses (models/loss.py:9-62)
+class _Auction(torch.autograd.Function):
+    """metrics/emd_assignment/emd_module.py:30-90 over the C oracle's auction: forward -> (squared matched distances,
+    assignment); backward -> gradient to xyz1 ONLY (the reference returns zeros for xyz2, :85-89)"""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, eps, iters):
+        b, n, _ = xyz1.shape
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        f = lambda *s: torch.zeros(*s)
+        i = lambda *s: torch.zeros(*s, dtype=torch.int32)
+        dist, assignment, assignment_inv = f(b, n), i(b, n) - 1, i(b, n) - 1
+        ops.auction_forward(xyz1, xyz2, dist, assignment, f(b, n), assignment_inv, i(b, n), f(b, n), f(b, n),
+                            i(b * n), i(512), i(512), i(512), i(b * n), eps, iters)
+        ctx.save_for_backward(xyz1, xyz2, assignment)
+        return dist, assignment
+
+    @staticmethod
+    def backward(ctx, graddist, _gi):
+        xyz1, xyz2, assignment = ctx.saved_tensors
+        g1 = torch.zeros_like(xyz1)
+        ops.auction_backward(xyz1, xyz2, g1, graddist.contiguous(), assignment)
+        return g1, torch.zeros_like(xyz2), None, None
+
+
+def emd_loss_terms(pred, gt, eps=0.005, iters=50):
+    """pred, gt [B,N,3] -> (dist [B,N], assignment [B,N]) as emdModule()(pred, gt, eps, iters) returns them"""
+    return _Auction.apply(pred, gt, eps, iters)
+
+
+class _Chamfer(torch.autograd.Function):
+    """metrics/chamfer3D/dist_chamfer_3D.py:44-86 over the C oracle's nm_distance / its gradient"""
+
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        d1, d2 = torch.zeros(b, n), torch.zeros(b, m)
+        i1, i2 = torch.zeros(b, n, dtype=torch.int32), torch.zeros(b, m, dtype=torch.int32)
+        ops.chamfer_forward(xyz1, xyz2, d1, d2, i1, i2)
+        ctx.save_for_backward(xyz1, xyz2, i1, i2)
+        return d1, d2, i1, i2
+
+    @staticmethod
+    def backward(ctx, gd1, gd2, _a, _b):
+        xyz1, xyz2, i1, i2 = ctx.saved_tensors
+        g1, g2 = torch.zeros_like(xyz1), torch.zeros_like(xyz2)
+        ops.chamfer_backward(xyz1, xyz2, g1, g2, gd1.contiguous(), gd2.contiguous(), i1, i2)
+        return g1, g2
+
+
+def chamfer_terms(a, b):
+    return _Chamfer.apply(a, b)
+
+
+def per_sample_loss(kind, pred, gt):
+    """models/loss.py:46-62 on [B,3,N] tensors (+ 'chamfer': symmetric CD-L2 through chamfer_3DFunction, the entry the
+    build adds for BASELINE config 3's "Chamfer loss")"""
+    if kind == "mse":
+        return ((pred - gt) ** 2).flatten(1).mean(dim=1)
+    if kind == "mse_sum":
+        return ((pred - gt) ** 2).flatten(1).sum(dim=1)
+    if kind == "l1":
+        return (pred - gt).abs().flatten(1).mean(dim=1)
+    p, q = pred.transpose(1, 2).contiguous(), gt.transpose(1, 2).contiguous()
+    if kind == "emd":
+        d, _ = emd_loss_terms(p, q, 0.005, 50)
+        return torch.sqrt(d).flatten(1).mean(dim=1)
+    if kind == "chamfer":
+        d1, d2, _, _ = chamfer_terms(p, q)
+        return d1.mean(dim=1) + d2.mean(dim=1)
+    raise ValueError(kind)
+
+
+def bridge_loss(net, cfg, x0, x1, steps, x_cond=None, loss_type=None):
+    """P2PB.forward (models/p2pb.py:373-413) for given per-sample steps, ot_ode bridges (no q_sample noise):
+    -> (loss, pred, gt)"""
+    diff = cfg["diffusion"]
+    sch = make_schedule(diff)
+    e = lambda a: a[steps].view(-1, 1, 1)
+    xt = (e(sch["mu_x0"]) * x0 + e(sch["mu_x1"]) * x1).detach()
+    gt = ((xt - x0) / e(sch["std_fwd"])).detach() if diff.get("objective", "pred_noise") == "pred_noise" else x0
+    pred = net(xt, sch["noise_levels"][steps], x_cond)
+    loss = per_sample_loss(loss_type or diff.get("loss_type", "mse"), pred, gt)
+    return loss.mean() * diff.get("loss_multiplier", 1.0), pred, gt

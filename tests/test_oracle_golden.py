@@ -233,3 +233,90 @@ def test_chamfer_matches_bruteforce():
     D = ((a.double()[:, :, None] - b_.double()[:, None]) ** 2).sum(-1)
     assert torch.equal(i1.long(), D.argmin(2)) and torch.equal(i2.long(), D.argmin(1))
     assert torch.allclose(d1.double(), D.min(2).values, atol=1e-6)
+
+
+# ---- round 3: the conditional sampler (BASELINE configs 4-5) and the non-mse losses, pinned to the reference's own run
+def _cond_case(tiny, tag):
+    import copy
+
+    cfg, sd, run = tiny
+    g = _load("tiny_cond.npz")
+    cfg = copy.deepcopy(cfg)
+    cfg["model"]["extra_feature_channels"] = 3
+    cfg["model"]["PVD"]["feat_embed_dim"] = {"embed": 8, "raw": 3}[tag]
+    man = json.load(open(os.path.join(GOLDEN, f"manifest_tiny_cond_{tag}.json")))
+    extra = {k[len(tag) + 3:]: _t(g[k]).float() for k in g.files if k.startswith(tag + ".w.")}
+    sd = {**{k: v for k, v in sd.items() if k in man}, **extra}
+    assert {k: list(v.shape) for k, v in sd.items()} == man
+    return cfg, sd, run, g
+
+
+@pytest.mark.parametrize("tag", ["embed", "raw"])
+def test_conditional_net_and_sampler_bit_exact(tiny, tag):
+    """`P2PB.sample(x_start=, x_cond=)` (models/p2pb.py:304-320 -> unet_pvc.py:171-176 `cat([x, x_cond])`) with 3 extra
+    channels, through embed_feats ('embed') and straight into the first stage ('raw'): oracle == the reference's own
+    run (tools/make_golden_extra.py --cond), network output and the 5-step chain, bit for bit."""
+    cfg, sd, run, g = _cond_case(tiny, tag)
+    net = net_ref.RefNet(cfg, sd, vox_mode="torch")
+    xc = _t(g["x_cond"])
+    with torch.no_grad():
+        out = net(_t(run["x_start"]), _t(g["t"]), xc)
+    assert np.array_equal(out.numpy(), g[f"{tag}.net_out"])
+    s = net_ref.sample(net, cfg, _t(run["x_start"]), x_cond=xc, steps=5, log_count=5)
+    assert np.array_equal(s["x_chain"].numpy(), g[f"{tag}.x_chain"])
+    assert np.array_equal(s["x_pred"].numpy(), g[f"{tag}.x_pred"])
+    assert not np.array_equal(g[f"{tag}.x_chain"], run["x_chain_T5"])  # the condition matters
+
+
+def _bridge_pred(net, cfg, run, steps, x_cond=None):
+    sch = net_ref.make_schedule(cfg["diffusion"])
+    x0, x1 = _t(run["clean"]), _t(run["x_start"])
+    e = lambda a: a[steps].view(-1, 1, 1)
+    xt = e(sch["mu_x0"]) * x0 + e(sch["mu_x1"]) * x1
+    gt = (xt - x0) / e(sch["std_fwd"])
+    return net(xt, sch["noise_levels"][steps], x_cond), gt
+
+
+@pytest.mark.parametrize("tag", ["embed", "raw"])
+def test_conditional_training_loss_and_grads(tiny, tag):
+    """P2PB.forward(x0, x1, x_cond) (models/p2pb.py:373-413) with the extra channels: loss + two gradient tensors"""
+    cfg, sd, run, g = _cond_case(tiny, tag)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    net = net_ref.RefNet(cfg, {}, vox_mode="torch")
+    net.sd, net.training = sd, True
+    pred, gt = _bridge_pred(net, cfg, run, _t(g["loss_steps"]), _t(g["x_cond"]))
+    loss = ((pred - gt) ** 2).mean(dim=(1, 2)).mean()
+    exp = float(g[f"{tag}.loss"])
+    assert abs(loss.item() - exp) <= 1e-6 * abs(exp)
+    loss.backward()
+    for name, key in (("grad_classifier.2.weight", "classifier.2.weight"),
+                      ("grad_sa0", "sa_layers.0.0.point_features.layers.0.weight")):
+        e = g[f"{tag}.{name}"]
+        assert np.abs(sd[key].grad.numpy() - e).max() <= 1e-5 * max(1.0, np.abs(e).max()), name
+
+
+def test_emd_training_loss_and_grads(tiny):
+    """diffusion.loss_type = "emd" (models/loss.py:32-43 -> emd_module.py:30-90): the oracle's auction reproduces the
+    assignment and distances of the reference's own run on the same prediction, and loss + gradients through
+    orc_auction_bwd (gradient to the prediction only, emd_module.py:85-89) match the reference's."""
+    cfg, sd, run = tiny
+    g = _load("tiny_cond.npz")
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    net = net_ref.RefNet(cfg, {}, vox_mode="torch")
+    net.sd, net.training = sd, True
+    pred, gt = _bridge_pred(net, cfg, run, _t(g["loss_steps"]))
+    p, q = pred.transpose(1, 2).contiguous(), gt.transpose(1, 2).contiguous()
+    assert np.abs(p.detach().numpy() - g["emd.pred"]).max() < 1e-5
+    eps, iters = float(g["emd.eps_iters"][0]), int(g["emd.eps_iters"][1])
+    # the auction on the reference's own operands: same assignment, same distances
+    d0, a0 = net_ref.emd_loss_terms(_t(g["emd.pred"]), _t(g["emd.gt"]), eps, iters)
+    assert np.array_equal(a0.numpy(), g["emd.assignment"])
+    assert np.array_equal(d0.numpy(), g["emd.dist"])
+    d, _ = net_ref.emd_loss_terms(p, q, eps, iters)
+    loss = torch.sqrt(d).mean(dim=1).mean()
+    exp = float(g["emd.loss"])
+    assert abs(loss.item() - exp) <= 1e-5 * abs(exp)
+    loss.backward()
+    for k in ("classifier.2.weight", "embedf.0.weight"):
+        e = g["emd.grad_" + k]
+        assert np.abs(sd[k].grad.numpy() - e).max() <= 1e-4 * max(1.0, np.abs(e).max()), k

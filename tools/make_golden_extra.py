@@ -224,12 +224,127 @@ def room_data():
     print("room_data.npz", os.path.getsize(os.path.join(OUT, "room_data.npz")))
 
 
+def conditional():
+    """Round-3 additions: the CONDITIONAL sampler and the non-mse training losses, from the reference's own Python.
+    python tools/make_golden_extra.py --cond
+
+      tiny_cond.npz   the tiny config with model.extra_feature_channels = 3 (BASELINE configs 4-5 are
+                      `model.sample(x_start, x_cond=rgb/dino)`, denoise_room.py:119-174, models/p2pb.py:304-320,
+                      models/unet_pvc.py:171-176), in two forms:
+                        embed.*  feat_embed_dim = 8: the extra channels go through embed_feats (every parameter keeps its
+                                 shape, tiny_weights.npz is used as it is)
+                        raw.*    feat_embed_dim = 3 (== extra): no embed_feats, the raw channels enter the first stage;
+                                 the parameters whose shape changes are seeded, fp16-rounded and stored as raw.w.*
+                      each: x_cond, t, net(x_start, t, x_cond), the 5-step `P2PB.sample(x_start=, x_cond=)` chain, and
+                      P2PB.forward(x0, x1, x_cond) (mse, fixed steps) with two gradient tensors
+                      emd.*    P2PB.forward with diffusion.loss_type = "emd" (models/loss.py:32-43, the auction through the
+                               C oracle standing in for emd_assignment) on the unconditional tiny network: loss, the
+                               assignment the auction produced, two gradient tensors
+    """
+    unet, p2pb = ref_import.load_models()
+    from oracle import net_ref
+
+    raw = json.load(open(os.path.join(OUT, "tiny_cfg.json")))
+    w = np.load(os.path.join(OUT, "tiny_weights.npz"))
+    sd = {k: torch.from_numpy(w[k]).float() for k in w.files}
+    x_start, clean = net_ref.synthetic_patches(2, 1024, seed=0)
+    g = torch.Generator().manual_seed(21)
+    x_cond = torch.rand(2, 3, 1024, generator=g)  # rgb in [0, 1)
+    t = torch.tensor([500.0, 123.0])
+    steps = torch.tensor([10, 700])
+    out = {"x_cond": x_cond.numpy(), "t": t.numpy(), "loss_steps": steps.numpy()}
+    _randint = torch.randint
+
+    def fixed_steps_loss(model, net, *args, **kw):
+        torch.randint = lambda *a, **k: steps.clone()
+        try:
+            model.model.train()
+            for p in net.parameters():
+                p.grad = None
+            loss = model(*args, **kw)
+            loss.backward()
+        finally:
+            torch.randint = _randint
+        return loss
+
+    for tag, fdim in (("embed", 8), ("raw", 3)):
+        r = json.loads(json.dumps(raw))
+        r["model"]["extra_feature_channels"] = 3
+        r["model"]["PVD"]["feat_embed_dim"] = fdim
+        cfg = ref_import.to_attr(r)
+        cfg.gpu = "cpu"
+        torch.manual_seed(9)
+        net = unet.PVCNN2Unet(cfg)
+        full = net.state_dict()
+        extra = {k: v.half().float() for k, v in full.items() if k not in sd or sd[k].shape != v.shape}
+        assert (tag == "embed") == (not extra), (tag, sorted(extra))
+        net.load_state_dict({**{k: v for k, v in sd.items() if k in full}, **extra})
+        json.dump({k: list(v.shape) for k, v in full.items()},
+                  open(os.path.join(OUT, f"manifest_tiny_cond_{tag}.json"), "w"), indent=0)
+        net.eval()
+        with torch.no_grad():
+            out[f"{tag}.net_out"] = net(x_start, t, x_cond=x_cond).numpy()
+        model = p2pb.P2PB(cfg, net)
+        s = model.sample(x_start=x_start, x_cond=x_cond, steps=5, verbose=False, log_count=5)
+        out[f"{tag}.x_chain"], out[f"{tag}.x_pred"] = s["x_chain"].numpy(), s["x_pred"].numpy()
+        loss = fixed_steps_loss(model, net, clean.clone(), x_start.clone(), x_cond=x_cond)
+        out[f"{tag}.loss"] = loss.detach().numpy()
+        out[f"{tag}.grad_classifier.2.weight"] = net.classifier[2].weight.grad.numpy()
+        out[f"{tag}.grad_sa0"] = net.sa_layers[0][0].point_features.layers[0].weight.grad.numpy()
+        for k, v in extra.items():
+            out[f"{tag}.w.{k}"] = v.half().numpy()
+
+    # ---- loss_type = emd through the reference's own models/loss.py ---------------------------------
+    r = json.loads(json.dumps(raw))
+    r["diffusion"]["loss_type"] = "emd"
+    cfg = ref_import.to_attr(r)
+    cfg.gpu = "cpu"
+    net = unet.PVCNN2Unet(cfg)
+    net.load_state_dict(sd)
+    model = p2pb.P2PB(cfg, net)
+    import importlib
+
+    emd_mod = importlib.import_module("metrics.emd_assignment.emd_module")
+    seen = {}
+    _fwd = emd_mod.emdFunction.forward
+
+    def spy(ctx, xyz1, xyz2, eps, iters):
+        d, a = _fwd(ctx, xyz1, xyz2, eps, iters)
+        seen.update(pred=xyz1.detach().clone(), gt=xyz2.detach().clone(), dist=d.detach().clone(),
+                    assignment=a.detach().clone(), eps=eps, iters=iters)
+        return d, a
+
+    # emd_module.py:41-54,85-86 hard-code `.cuda()` / `device="cuda"`: on this CPU-only host both are made no-ops for
+    # the duration of the call (placement only; the arithmetic is the reference's Python + the C oracle's auction)
+    _zeros, _cuda = torch.zeros, torch.Tensor.cuda
+    emd_mod.emdFunction.forward = staticmethod(spy)
+    torch.zeros = lambda *a, **k: _zeros(*a, **{kk: v for kk, v in k.items() if kk != "device"})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        loss = fixed_steps_loss(model, net, clean.clone(), x_start.clone())
+    finally:
+        emd_mod.emdFunction.forward = staticmethod(_fwd)
+        torch.zeros, torch.Tensor.cuda = _zeros, _cuda
+    out["emd.loss"] = loss.detach().numpy()
+    out["emd.pred"], out["emd.gt"] = seen["pred"].numpy(), seen["gt"].numpy()
+    out["emd.dist"], out["emd.assignment"] = seen["dist"].numpy(), seen["assignment"].numpy().astype(np.int32)
+    out["emd.eps_iters"] = np.array([seen["eps"], seen["iters"]], dtype=np.float64)
+    out["emd.grad_classifier.2.weight"] = net.classifier[2].weight.grad.numpy()
+    out["emd.grad_embedf.0.weight"] = net.embedf[0].weight.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "tiny_cond.npz"), **out)
+    print("tiny_cond.npz", os.path.getsize(os.path.join(OUT, "tiny_cond.npz")),
+          {k: float(out[k]) for k in ("embed.loss", "raw.loss", "emd.loss")})
+
+
 if __name__ == "__main__":
     if "--punet" in sys.argv:
         punet_transforms()
     elif "--room" in sys.argv:
         room_data()
+    elif "--cond" in sys.argv:
+        conditional()
     else:
         main()
         punet_transforms()
         room_data()
+        conditional()
