@@ -68,11 +68,15 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned 
 // ---- fp16-pair split (SPLIT_F16X3): x*S = h0 + h1 with h0 = fp16(x*S), h1 = fp16(x*S - h0), round-to-nearest-even ----
 // fp16 carries 11 significand bits, so two terms carry 22 and a product evaluated as h1*g0 + h0*g1 + h0*g0 (fp16 x fp16
 // is exact in fp32) misses the exact one by <= 3 * 2^-22 |x*y| -- three matrix products instead of the six of the bf16
-// split, at the price of fp16's exponent range. Activations are scaled by SPLIT_F16_SX and saturated at the largest
-// finite fp16 (|x| < 16376 is exact range); below |x*S| = 2^-3 the low term is subnormal and the representation error
+// split, at the price of fp16's exponent range. Activations are scaled by SPLIT_F16_SX; |x| < 16380 is the exact range.
+// OUT OF RANGE IS LOUD (round 3; it used to clamp): the conversion is IEEE, so |x*S| >= 65520, an infinity or a NaN
+// becomes h0 = +-inf / NaN, the residual h1 = x*S - h0 is -+inf / NaN too, and every output the operand reaches is
+// non-finite -- exactly how an fp32 overflow shows in the reference, only earlier. Every layer's output feeds a
+// GroupNorm, so the non-finite value spreads to the whole sample and P2PB.sample() / the training loss see it
+// (p2pb.py: re-run on bf16x6 or raise). Below |x*S| = 2^-3 the low term is subnormal and the representation error
 // is an ABSOLUTE 2^-25 / S (3.7e-9) instead of a relative 2^-22. Weights get a per-tensor power-of-two scale chosen at
-// pack time from max |w| (always in range); 1 / (S_x * S_w) is stored behind the packed weights and applied to the
-// accumulators (exact: a power of two).
+// pack time from max |w| (any finite weights are in range); 1 / (S_x * S_w) is stored behind the packed weights and
+// applied to the accumulators (exact: a power of two).
 #define SPLIT_BF16X6 6
 #define SPLIT_BF16X3 3
 #define SPLIT_F16X3 16
@@ -80,7 +84,7 @@ __device__ __forceinline__ void split3(float a, float b, unsigned &p0, unsigned 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h(float a, float b, unsigned &p0, unsigned &p1) {
-  f32x2 v = {__builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f)};
+  f32x2 v = {a, b};
   const f16x2 q0 = __builtin_convertvector(v, f16x2);
   v = v - __builtin_convertvector(q0, f32x2);
   const f16x2 q1 = __builtin_convertvector(v, f16x2);
@@ -107,7 +111,7 @@ __device__ __forceinline__ f32x16 split_mfma(const u32x4 &a, const u32x4 &b, con
 }
 // pack-time weight scale of the fp16 mode: the power of two that brings max |w| into [2^13, 2^14)
 __device__ __forceinline__ float f16_weight_scale(float wmax) {
-  if (!(wmax > 0.0f)) return 1.0f;
+  if (!(wmax > 0.0f) || wmax > 3.0e38f) return 1.0f;  // all-zero, or an infinite weight (then the pack carries the inf)
   int e;
   (void)frexpf(wmax, &e);  // wmax = m * 2^e, m in [0.5, 1)
   return ldexpf(1.0f, 14 - e);

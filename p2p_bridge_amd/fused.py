@@ -178,8 +178,10 @@ def conv_math() -> str:
       "f16x3"  (default) every operand as an fp16 pair h0 + h1 of its scaled value (22 significand bits), a product as
                h1g0 + h0g1 + h0g0 -- three exact matrix products, <= 3 * 2^-22 relative per product, measured at or below
                the exact-fp32 MFMA kernel's error against fp64 (csrc/common.h SPLIT_F16X3). Range contract: activations
-               (after the folded norm) are scaled by 4 and saturate at |x| = 16376; below |x| = 2^-5 the representation
-               error is an absolute 2^-27; weights are scaled per tensor at pack time (any finite weights);
+               (after the folded norm) are scaled by 4; |x| >= 16380, inf and NaN give NON-FINITE outputs (nothing is
+               clipped: P2PB.sample() then repeats the call on bf16x6 or raises, the training loss goes NaN like an
+               fp32 overflow would); below |x| = 2^-5 the representation error is an absolute 2^-27; weights are scaled
+               per tensor at pack time (any finite weights);
       "bf16x6" three bf16 terms per operand, six products: within a quarter ulp of fp32 at any magnitude, 1.2x slower end
                to end; the gradient pass of train() always uses it (gradients have no scale the fp16 range could rely on);
       "fp32"   the exact-fp32 MFMA kernels"""
@@ -191,7 +193,8 @@ def conv_math() -> str:
 
 def set_conv_math(name):
     """-> the previous setting; None returns to the environment's. Process-wide (the split kernels read one global, set
-    through p2pb_set_split_terms); a captured hipGraph keeps the kernels it captured."""
+    through p2pb_set_split_terms); a captured hipGraph keeps the kernels it captured
+    (P2PB's graph cache is keyed by the arithmetic)."""
     global _conv_math_override
     prev = conv_math()
     if name is not None and name not in CONV_MATHS:

@@ -11,6 +11,8 @@ them from 0-dim tensors and a freshly allocated `torch.full` step tensor every i
 (models/p2pb.py:203-209,305) -- so one sampler step touches no host memory and can be captured into a
 hipGraph (`graph=True`): T replays of one captured step instead of T x ~400 eager launches.
 """
+import os
+import warnings
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -196,6 +198,8 @@ class P2PB(nn.Module):
         w = clipped / snr if self.objective == "pred_noise" else clipped
         self.register_buffer("loss_weight", torch.tensor(w, dtype=torch.float32), persistent=False)
         self._graphs: Dict = {}
+        self.f16_overflow: Optional[str] = None  # None: P2PB_F16_OVERFLOW or "rerun" (ddpm_sampling)
+        self.overflow_reruns = 0
 
     # ---- reference API surface ------------------------------------------------------------------
     def multi_gpu_wrapper(self, f):
@@ -290,6 +294,43 @@ class P2PB(nn.Module):
     @torch.no_grad()
     def ddpm_sampling(self, x1, x_cond=None, clip_denoise=False, sampling_steps=None, log_count=10, verbose=True,
                       use_ema=False, graph=False):
+        """models/p2pb.py:265-335. Range guard of the build's default arithmetic (no reference counterpart: the
+        reference multiplies in plain fp32 / TF32, both with fp32's exponent range): the f16x3 split kernels overflow at
+        |activation| >= 16380 and then return non-finite values (csrc/common.h split2h; nothing is clipped), which the
+        GroupNorm after every layer spreads to the whole sample -- so a chain that left the range ends non-finite.
+        That is checked once per call (one reduction over the final cloud) and handled per P2PB_F16_OVERFLOW /
+        `self.f16_overflow`: "rerun" (default) repeats the call on bf16x6 (fp32 range, 1.2x slower) with a warning,
+        "raise" raises FloatingPointError, "ignore" returns what the f16x3 pass produced. `self.overflow_reruns` counts
+        the repeats. A stochastic sampler draws fresh noise for the repeat."""
+        from . import fused
+
+        args = (x1, x_cond, clip_denoise, sampling_steps, log_count, verbose, use_ema, graph)
+        xs, x0s = self._ddpm_once(*args)
+        policy = self.f16_overflow or os.environ.get("P2PB_F16_OVERFLOW", "rerun")
+        if policy not in ("rerun", "raise", "ignore"):
+            raise ValueError(f"P2PB_F16_OVERFLOW must be rerun | raise | ignore, got {policy!r}")
+        if policy == "ignore" or fused.conv_math() != "f16x3" or xs.device.type != "cuda":
+            return xs, x0s
+        if bool(torch.isfinite(xs[:, 0]).all()):
+            return xs, x0s
+        if bool(torch.isfinite(x1).all()) and (x_cond is None or bool(torch.isfinite(x_cond).all())):
+            why = "an activation left the f16x3 range (|x| >= 16380) or the network diverged"
+        else:
+            why = "the INPUT holds non-finite values"
+        if policy == "raise":
+            raise FloatingPointError(f"P2PB.sample: non-finite result under P2PB_CONV_MATH=f16x3: {why}")
+        warnings.warn(f"P2PB.sample: non-finite result under f16x3 ({why}); repeating the call on bf16x6. "
+                      "Set P2PB_CONV_MATH=bf16x6 for this checkpoint to skip the wasted pass.", RuntimeWarning)
+        self.overflow_reruns += 1
+        prev = fused._conv_math_override
+        fused.set_conv_math("bf16x6")
+        try:
+            return self._ddpm_once(*args)
+        finally:
+            fused.set_conv_math(prev)
+
+    def _ddpm_once(self, x1, x_cond=None, clip_denoise=False, sampling_steps=None, log_count=10, verbose=True,
+                   use_ema=False, graph=False):
         sampling_steps = sampling_steps or self.timesteps - 1
         steps, table = self.step_tables(sampling_steps)
         log_count = min(len(steps) - 1, log_count)
@@ -336,14 +377,17 @@ class P2PB(nn.Module):
 
     def _graph_runner(self, net, xt, x_cond, clip):
         """capture ONE sampler step (network evaluation + posterior update) into a hipGraph with static
-        input / coefficient / noise buffers. Replays are keyed by (shape, cond shape, clip, network identity); a captured
+        input / coefficient / noise buffers. Replays are keyed by (shape, cond shape, clip, network identity, arithmetic); a captured
         graph bakes in the addresses of the weights AND of their derived packed copies (fused.pack_*, StyleBank), so
         each entry also stores the weight fingerprint it was captured under and is re-captured when that changes
         (optimiser step, load_checkpoint, EMA update). The packed tensors of a live graph stay referenced by the
         modules' caches for exactly as long as the fingerprint is unchanged."""
         if self.cond_x1:
             raise NotImplementedError("graph capture with cond_x1")
-        key = (tuple(xt.shape), None if x_cond is None else tuple(x_cond.shape), bool(clip), id(net))
+        from . import fused
+
+        # (the arithmetic is part of the key: a captured graph keeps the kernels of the mode it was captured under)
+        key = (tuple(xt.shape), None if x_cond is None else tuple(x_cond.shape), bool(clip), id(net), fused.conv_math())
         fp = self._weights_fingerprint(net)
         entry = self._graphs.get(key)
         if entry is not None and entry[0] != fp:

@@ -1,8 +1,8 @@
 """The arithmetics of the split-operand matrix kernels (fused.conv_math / set_conv_math, include/p2pb_hip.h
 p2pb_set_split_terms): "f16x3" (default: fp16-pair split of the scaled operands, three exact products) and "bf16x6" (three
 bf16 terms, six products). Both against fp64 with per-product bounds -- f16x3 within 3 * 2^-22 * sum |x||w| plus the fp32
-accumulation, i.e. at the exact-fp32 MFMA kernel's level --, the f16x3 range contract (saturation at 16376, absolute
-floor below 2^-5, any weight scale), a switch re-packs and is reversible bit for bit, a captured graph keeps its
+accumulation, i.e. at the exact-fp32 MFMA kernel's level --, the f16x3 range contract (non-finite beyond 16380, absolute
+floor below 2^-5, any weight scale), a switch re-packs and is reversible bit for bit, a captured graph is keyed by its
 arithmetic, the gradient pass of train() runs on bf16x6 whatever the setting."""
 import json
 import os
@@ -92,23 +92,30 @@ def test_f16_weight_scale(fused, wgain):
 
 
 def test_f16_range_contract(fused):
-    """activations: exact range |x| < 16376, saturation (finite results) beyond; small operands keep an ABSOLUTE 2^-27
-    per element -- relative to sum |x||w| that only shows when the whole operand is small"""
+    """activations: exact range |x| < 16380; BEYOND IT THE RESULT IS NON-FINITE, never clipped (an overflow, an infinity
+    or a NaN in the operand reaches every output channel of its position and no other position -- as an fp32 overflow
+    would in the reference, only earlier; P2PB.sample() turns that into a re-run on bf16x6 or an error); small operands
+    keep an ABSOLUTE 2^-27 per element -- relative to sum |x||w| that only shows when the whole operand is small"""
     args, kw, ref, mag = pw_case(fused, 2, 256, 256, 512, False, xgain=500.0)  # |x| up to ~ 16000
     x = args[0]
     assert 8000 < x.abs().max().item() < 16376
     with torch.no_grad():
         y = fused.pw_conv(*args, **kw)[0]
         assert ((y - ref).abs() / mag).max().item() < BOUND_F16
-        big = x.clone()
-        big[0, 0, 0] = 1e30
-        big[1, 3, 5] = -float("inf")
-        yb = fused.pw_conv(big, args[1])[0]
-        assert torch.isfinite(yb).all()  # saturated at +-16376, not inf / nan
-        sat = x.double().clone()
-        sat[0, 0, 0], sat[1, 3, 5] = 16376.0, -16376.0
-        refs = torch.nn.functional.conv1d(sat, args[1].weight.double(), args[1].bias.double())
-        assert ((yb - refs).abs() / (mag + 16376.0 * args[1].weight.double().abs().max())).max().item() < BOUND_F16
+        y0 = fused.pw_conv(x, args[1])[0]
+        edge = x.clone()
+        edge[0, 0, 0] = 16379.0  # 4 * 16379 = 65516 < 65520: still rounds to the largest finite fp16
+        assert torch.isfinite(fused.pw_conv(edge, args[1])[0]).all()
+        for bad in (16380.0, 1e30, -float("inf"), float("nan")):
+            big = x.clone()
+            big[0, 0, 0] = bad
+            big[1, 3, 5] = -bad
+            yb = fused.pw_conv(big, args[1])[0]
+            hit = torch.zeros_like(yb, dtype=torch.bool)
+            hit[0, :, 0] = True
+            hit[1, :, 5] = True
+            assert not torch.isfinite(yb[hit]).any(), bad  # every output channel of the two positions
+            assert torch.equal(yb[~hit], y0[~hit]), bad  # and nothing else changes
         small = x * (2.0 ** -24)  # every element below 2^-5: the low term is subnormal
         ys = fused.pw_conv(small, args[1])[0]
         refsm = torch.nn.functional.conv1d(small.double(), args[1].weight.double(), args[1].bias.double())
@@ -149,7 +156,7 @@ def test_conv_arithmetics(fused, r, C, C1, N):
 
 def test_tiny_network_both_arithmetics(fused):
     """whole network: every evaluation of the golden 5-step chain (identical inputs on both sides -- a free-running
-    sampler amplifies any difference through index decisions) vs the oracle; a graph captured in one arithmetic keeps it"""
+    sampler amplifies any difference through index decisions) vs the oracle; a captured graph belongs to the arithmetic it was captured in"""
     from p2p_bridge_amd import p2pb as product
     from test_net_parity_gpu import chain_parity
     cfg = json.load(open(os.path.join(G, "tiny_cfg.json")))
@@ -271,22 +278,43 @@ def test_operand_audit(fused):
     assert fused.pw_conv.__name__ == "pw_conv"  # the wrappers are gone
 
 
-def test_conv_f16_saturation_and_weight_scale(fused):
-    """the voxel convolution under the same contract as the GEMM: an operand beyond the exact range saturates at 16376
-    (finite outputs, equal to the convolution of the clamped grid), weights of any magnitude keep the relative bound"""
+def test_conv_f16_overflow_is_loud_and_weight_scale(fused):
+    """the voxel convolution under the same contract as the GEMM: an operand beyond the exact range (or inf / NaN) makes
+    every output voxel of its 3x3x3 neighbourhood non-finite and leaves the rest of the grid untouched; weights of any
+    finite magnitude keep the relative bound"""
     torch.manual_seed(4)
     B, C, C1, r = 2, 32, 64, 8
     grid = torch.randn(B, r, r, r, C, device="cuda") * 10
-    grid[0, 3, 4, 5, 7] = 3e9
-    grid[1, 0, 0, 0, 0] = -1e30
     for wgain in (1.0, 2.0 ** -18, 5e3):
         conv = torch.nn.Conv3d(C, C1, 3, padding=1).cuda()
         with torch.no_grad():
             conv.weight.mul_(wgain)
             conv.bias.zero_()
             y = fused.conv3d_k3(grid, conv, compact=True, channels_last=True)[0]
-            g64 = grid.clamp(-16376.0, 16376.0).permute(0, 4, 1, 2, 3).double()
+            g64 = grid.permute(0, 4, 1, 2, 3).double()
             ref = torch.nn.functional.conv3d(g64, conv.weight.double(), None, padding=1).permute(0, 2, 3, 4, 1)
             mag = torch.nn.functional.conv3d(g64.abs(), conv.weight.double().abs(), padding=1).permute(0, 2, 3, 4, 1) + 1e-300
-        assert torch.isfinite(y).all()
-        assert ((y - ref).abs() / mag).max().item() < BOUND_F16, wgain
+            assert torch.isfinite(y).all()
+            assert ((y - ref).abs() / mag).max().item() < BOUND_F16, wgain
+            for bad in (3e9, float("nan"), -float("inf")):
+                g2 = grid.clone()
+                g2[0, 3, 4, 5, 7] = bad
+                g2[1, 0, 0, 0, 0] = -bad
+                yb = fused.conv3d_k3(g2, conv, compact=True, channels_last=True)[0]
+                hit = torch.zeros(B, r, r, r, dtype=torch.bool, device="cuda")
+                hit[0, 2:5, 3:6, 4:7] = True
+                hit[1, 0:2, 0:2, 0:2] = True
+                assert not torch.isfinite(yb[hit]).any(), (wgain, bad)
+                assert torch.equal(yb[~hit], y[~hit]), (wgain, bad)
+
+
+def test_nonfinite_weight_is_loud(fused):
+    """an infinite or NaN weight (a diverged checkpoint) reaches the outputs of its channel as non-finite values"""
+    args, kw, ref, mag = pw_case(fused, 2, 256, 256, 512, False)
+    for bad in (float("inf"), float("nan")):
+        lin = torch.nn.Conv1d(256, 256, 1).cuda()
+        with torch.no_grad():
+            lin.weight[7, 3] = bad
+            y = fused.pw_conv(args[0], lin)[0]
+        assert not torch.isfinite(y[:, 7]).any(), bad
+        assert torch.isfinite(y[:, :7]).all() and torch.isfinite(y[:, 8:]).all(), bad

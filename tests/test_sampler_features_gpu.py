@@ -250,3 +250,72 @@ print("FALLBACKS", ext.fps_coop_fallbacks())
     env["P2PB_FPS_COOP_TEST_FALLBACK"] = "1"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=240)
     assert r.returncode == 0 and "FALLBACKS 6" in r.stdout, r.stderr[-2000:]
+
+
+def test_f16_range_overflow_cannot_return_clipped_points(tiny):
+    """The build's default arithmetic (f16x3) has fp16's exponent range (|activation| < 16380); the reference has fp32's.
+    A checkpoint with ONE outlier GroupNorm weight (channel 5 of fp_layers.1.1.voxel_layers.1, x 1e5: the operand of a
+    split convolution) leaves that range. Contract: the f16x3 pass then ends NON-FINITE (nothing is clipped), and
+    sample() -- per policy -- repeats the call on bf16x6 with a warning (result bit-identical to a plain bf16x6 run,
+    finite, within 1e-4 of the oracle for one step), raises, or hands the non-finite cloud back."""
+    import warnings
+
+    from p2p_bridge_amd import fused
+    from p2p_bridge_amd import p2pb as product
+
+    cfg, sd, run = tiny
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["fp_layers.1.1.voxel_layers.1.norm.weight"][5] *= 1e5
+    x = torch.from_numpy(run["x_start"])
+    if fused.conv_math() != "f16x3":
+        pytest.skip("the range guard belongs to the f16x3 arithmetic")
+    for graph in (False, True):
+        model = product.build_model(cfg, sd, device="cuda")
+        s = lambda: model.sample(x_start=x.cuda(), steps=2, log_count=2, verbose=False, graph=graph)["x_pred"].cpu()
+        model.f16_overflow = "ignore"
+        assert not torch.isfinite(s()).all()  # the overflow is visible, not clipped
+        model.f16_overflow = "raise"
+        with pytest.raises(FloatingPointError):
+            s()
+        model.f16_overflow = None  # default: rerun
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            out = s()
+        assert any("bf16x6" in str(m.message) for m in w) and model.overflow_reruns == 1
+        assert fused.conv_math() == "f16x3"  # the process-wide setting is back
+        assert torch.isfinite(out).all()
+        prev = fused._conv_math_override
+        fused.set_conv_math("bf16x6")
+        try:
+            direct = s()
+        finally:
+            fused.set_conv_math(prev)
+        assert model.overflow_reruns == 1 and torch.equal(out, direct)
+    orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    a = model.sample(x_start=x.cuda(), steps=1, log_count=1, verbose=False)["x_pred"].cpu()
+    b = net_ref.sample(orc, cfg, x, steps=1, log_count=1)["x_pred"]
+    assert (a - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
+    # a non-finite INPUT is reported as such
+    bad = x.clone()
+    bad[0, 0, 0] = float("nan")
+    model.f16_overflow = "raise"
+    with pytest.raises(FloatingPointError, match="INPUT"):
+        model.sample(x_start=bad.cuda(), steps=1, log_count=1, verbose=False)
+
+
+def test_training_loss_goes_nan_on_f16_overflow(tiny):
+    """training: the forward of train() runs on f16x3 too; an out-of-range activation makes the LOSS non-finite (what an
+    fp32 overflow does in the reference -- GradScaler's inf check and any isfinite guard fire), never finite garbage"""
+    from p2p_bridge_amd import fused
+    from p2p_bridge_amd import p2pb as product
+
+    if fused.conv_math() != "f16x3":
+        pytest.skip("the range guard belongs to the f16x3 arithmetic")
+    cfg, sd, run = tiny
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["fp_layers.1.1.voxel_layers.1.norm.weight"][5] *= 1e5
+    model = product.build_model(cfg, sd, device="cuda")
+    model.train()
+    x1, x0 = net_ref.synthetic_patches(2, 1024, seed=0)
+    loss = model(x0.cuda(), x1.cuda(), steps=torch.tensor([10, 700]))
+    assert not torch.isfinite(loss).item()
