@@ -171,10 +171,16 @@ def test_tiny_network_both_arithmetics(fused):
     fused.set_conv_math("bf16x6")
     m6 = product.build_model(cfg, sd, device="cuda")
     e6 = chain_parity(m6, orc, x, chain, 5)
-    yh_replay = mh.sample(x_start=x.cuda(), steps=5, log_count=5, verbose=False, graph=True)["x_pred"].cpu()
+    y6_graph = mh.sample(x_start=x.cuda(), steps=5, log_count=5, verbose=False, graph=True)["x_pred"].cpu()
+    y6_eager = mh.sample(x_start=x.cuda(), steps=5, log_count=5, verbose=False)["x_pred"].cpu()
     fused.set_conv_math(None)
+    yh_replay = mh.sample(x_start=x.cuda(), steps=5, log_count=5, verbose=False, graph=True)["x_pred"].cpu()
     print(f"tiny network vs oracle over the golden chain: f16x3 {eh:.2e}, bf16x6 {e6:.2e}")
     assert eh < 2e-5 and e6 < 2e-5  # (the parity bar is 1e-4)
+    # the arithmetic is part of the graph key (round 3: the range guard's bf16x6 repeat must not replay f16x3 kernels):
+    # a switch captures a second graph in the new arithmetic, switching back replays the first one
+    assert len(mh._graphs) == 2 and not torch.equal(y6_graph, yh)
+    assert (y6_graph - y6_eager).abs().max().item() < 1e-5
     assert torch.equal(yh_replay, yh)
 
 
