@@ -423,15 +423,6 @@ int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w /* [cout
  * the split pack -- the register-tiled kernel of the fp32 pack with its products on the 16-bit matrix pipe (three MFMAs of
  * K = 16 instead of eight exact-fp32 ones of K = 2 per 32x32x16 block); outputs, statistics and minmax in the layout of the
  * fp32-pack form (p2pb_pointwise_minmax_floats takes the same flags). */
-/* flags bit 6 (with bit 2, f16x3 arithmetic, npos % 128 == 0, no in_scale / in_fold / out_acc, channel-major output):
- * `in` is not f32[b,cin,npos] but the operand already transformed and split by p2pb_pointwise_presplit -- for wide layers
- * whose operand would otherwise be transformed and split once per output-channel block of 256 (the global embedding's
- * 512 -> 1024 layer, models/pvcnn.py:905-932: four times). The folded norm + Swish of in_scale / in_shift / in_swish
- * (NULL: none) is applied by the pre-pass; the GEMM's results are bit-identical to the one-call form.
- *   in f32[b,cin,npos] -> xs: p2pb_pointwise_presplit_bytes(b,cin,npos) bytes (4 per element; 0 = unsupported shape) */
-size_t p2pb_pointwise_presplit_bytes(int b, int cin, int npos);
-int p2pb_pointwise_presplit(int b, int cin, int npos, const float *in, const float *in_scale, const float *in_shift,
-                            int in_swish, void *xs, void *stream);
 /* The same GEMM with the max-pool that follows the layer (set abstraction: max over the pool_u = 4..64
  * neighbours, models/pvcnn.py:414; Pnet2Stage: pool_u = 0, max over all positions, :923,930) prepared in the
  * epilogue: minmax receives {min, max} of the raw output per pooling group (pool_u > 0: f32[b,cout,npos/pool_u,2];

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("P2PB_LIB_PATH") or os.path.join(_HERE, "libp2pb_hip.s
 
 # every symbol include/p2pb_hip.h declares (tests/test_abi.py checks the two lists agree)
 SYMBOLS = [
-    "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_get_split_terms", "p2pb_pointwise_presplit_bytes", "p2pb_pointwise_presplit", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
+    "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_get_split_terms", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
     "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_trilinear_devoxelize_forward",
     "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats",
     "p2pb_gather_features_forward", "p2pb_gather_features_backward", "p2pb_furthest_point_sampling",
@@ -64,7 +64,6 @@ def lib():
         _lib.p2pb_pointwise_minmax_floats.restype = ctypes.c_size_t
         _lib.p2pb_group_sub_stats_floats.restype = ctypes.c_size_t
         _lib.p2pb_pointwise_split_packed_bytes.restype = ctypes.c_size_t
-        _lib.p2pb_pointwise_presplit_bytes.restype = ctypes.c_size_t
         _lib.p2pb_conv3d_k3_wgrad_ws_floats.restype = ctypes.c_size_t
         _lib.p2pb_chamfer_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_approxmatch_temp_floats.restype = ctypes.c_size_t

@@ -374,13 +374,6 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
         }
       }
     }
-#ifdef PWW_EXP_NOMFMA  // timing experiment: the loop without its matrix instructions (one per chunk keeps the operands live)
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-        acc[m][s][0] += a_cur[m][s] * bcur[s][s];
-#else
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -388,7 +381,6 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
 #pragma unroll
         for (int s = 0; s < 4; ++s)
           acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][kk], bcur[kk][s], acc[m][s], 0, 0, 0);
-#endif
   }
 
   if (out_pm) {  // point-major output f32[b, P, cout] (the consumer gathers whole rows); no statistics in this form
@@ -541,6 +533,7 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
 
 #define PWS_TILE (2 * 3 * 2 * 128)                     // 16-byte groups per operand tile (24 KB)
 #define PWS_LDS_BYTES (2 * PWS_TILE * 16)               // A + B
+#include "pw_pingpong.h"  // the >= 256-channel / 256-position-block form of the f16x3 arithmetic (round 3)
 
 // Epilogue of the split-operand GEMM kernels for one wave's 64 channels x NB x 64 positions: bias, stores (channel- or
 // point-major), GroupNorm partials per 64-position slot, optional {min, max} for the pooling that follows.
@@ -688,11 +681,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // the stage loop costs the plain form 5 % (scalar registers: the row descriptors already fill the SGPR file).
 // TERMS: the arithmetic (common.h, p2pb_set_split_terms) -- SPLIT_F16X3 (default: fp16-pair split, three products, two
 // operand planes: the third is neither fetched, written nor read) or SPLIT_BF16X6 (three bf16 terms, six products)
-// PRE (f16x3 only): `in` is the operand ALREADY transformed and split by pw_presplit_kernel, stored as the LDS image of
-// every (sample, 128-position block, 32-channel stage) -- the B tile then arrives by LDS-DMA like the weight tile and the
-// kernel has no VALU staging at all. For layers whose operand would otherwise be transformed and split once per
-// output-channel block (4x for the 512 -> 1024 layer); results are bit-identical to the staged form.
-template <bool XF, bool POOL, int WM, int NB, bool FX, int TERMS, bool PRE = false>
+template <bool XF, bool POOL, int WM, int NB, bool FX, int TERMS>
 #ifndef PWS_WM4_WAVES
 #define PWS_WM4_WAVES 4
 #endif
@@ -780,18 +769,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * NT + tid),
                                          (__attribute__((address_space(3))) void *)(dst + i * NT + wave * 64), 16, 0, 0);
   };
-  if constexpr (!PRE) load_b(0);
-  // the pre-split B tile of stage `chunk` -> LDS, asynchronously (rows (kstep, plane, khalf) of the image -> the tile's rows)
-  auto dma_b = [&](int chunk) {
-    const u32x4 *src = (const u32x4 *)in + (((size_t)b * gridDim.x + bx) * ((cin + PWS_CK - 1) / PWS_CK) + chunk) * 1024;
-#pragma unroll
-    for (int i = 0; i < 1024 / NT; ++i) {
-      const int e = i * NT + wave * 64, rg = e >> 7;
-      u32x4 *dst = lds_b + (((rg >> 2) * 3 + ((rg >> 1) & 1)) * 2 + (rg & 1)) * BS + (e & 127);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * NT + tid),
-                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    }
-  };
+  load_b(0);
   // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
   // producer's accumulators (common.h); published by the barrier at the top of the first stage
   // (the caller's arrays keep travelling through the scalar cache: an LDS broadcast at the top of the transform phase
@@ -802,28 +780,10 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 
   for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
     __syncthreads();  // everyone is done reading the previous stage
-#ifdef PWS_A_DIRECT
-    // experiment: A fragments straight from L1 / L2 into registers (issued here, consumed after the staging phase)
-    u32x4 areg[2][3][2];
-    {
-      const int nblk128 = WM == 2 ? ncoblk : (cout + 127) / 128;
-      const u32x4 *src = wp + ((size_t)(ci0 / PWS_CK) * nblk128 + by * (WM / 2) + (wm >> 1)) * PWS_TILE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int s = 0; s < split_planes(TERMS); ++s)
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            areg[ks][s][m] = src[((ks * 3 + s) * 2 + khalf) * 128 + (wm & 1) * 64 + m * 32 + l31];
-    }
-#elif !defined(PWS_EXP_NODMA)
     dma_a(ci0 / PWS_CK);  // lands while B is transformed and split below
-#endif
-    if constexpr (PRE) dma_b(ci0 / PWS_CK);
     // ---- stage B: transform + split
-    if constexpr (!PRE) {
+    {
       constexpr int NE = ONE ? 1 : 2;
-#ifndef PWS_EXP_NOXF
       if (XF) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -839,7 +799,6 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
             }
         }
       }
-#endif
       const int kstep = bgrp >> 1, kh = bgrp & 1;
 #pragma unroll
       for (int q = 0; q < NBW; ++q)
@@ -849,11 +808,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             unsigned p0, p1, p2;
-#ifndef PWS_EXP_NOSPLIT
             split_pair<TERMS>(braw[q][2 * i][e], braw[q][2 * i + 1][e], p0, p1, p2);
-#else
-            p0 = __builtin_bit_cast(unsigned, braw[q][2 * i][e]), p1 = __builtin_bit_cast(unsigned, braw[q][2 * i + 1][e]), p2 = p0 ^ p1;
-#endif
             qq[0][i] = p0;
             qq[1][i] = p1;
             qq[2][i] = p2;
@@ -867,12 +822,8 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this stage's A tile has landed
     __syncthreads();
-    if constexpr (!PRE)
-      if (ci0 + PWS_CK < cin) load_b(ci0 + PWS_CK);  // next stage's B loads fly during the MFMAs
+    if (ci0 + PWS_CK < cin) load_b(ci0 + PWS_CK);  // next stage's B loads fly during the MFMAs
     if (!mact) continue;
-#ifdef PWS_EXP_NOMFMA
-    continue;
-#endif
 #pragma unroll
     for (int kstep = 0; kstep < 2; ++kstep) {
       u32x4 af[3][2];
@@ -880,11 +831,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
       for (int s = 0; s < split_planes(TERMS); ++s)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-#ifdef PWS_A_DIRECT
-          af[s][m] = areg[kstep][s][m];
-#else
           af[s][m] = lds_a[(wm >> 1) * PWS_TILE + ((kstep * 3 + s) * 2 + khalf) * 128 + (wm & 1) * 64 + m * 32 + l31];
-#endif
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
       // the B fragments of one position block (2 tiles x 3 terms) at a time: 24 registers live instead of 24 NB
 #pragma unroll
@@ -918,199 +865,6 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
   }
   pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
                              stats_part, mm_out, pool_u, out_pm, FX ? gacc : GnAcc());
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same 256-channel x 128-position tile with the two halves of a stage given to DIFFERENT waves ("warp
-// specialisation"): waves 0-3 only multiply (2 x 2 over the tile: 128 channels x 64 positions each, 128 accumulator
-// registers), waves 4-7 only stage -- LDS-DMA of the next stage's weight tile, next stage's activations loaded one
-// stage further ahead, folded norm + Swish, split, LDS writes -- into the OTHER of two LDS buffers; one s_barrier per
-// stage swaps them. In pw_split_kernel every wave does both, so a workgroup's matrix phase and its staging phase
-// exclude each other and the weight tile's DMA latency (L2 -> LDS, ~1 us) sits between two barriers of every stage;
-// only the second co-resident workgroup fills the matrix pipe meanwhile (measured: 49 % busy). Here one math wave and
-// one staging wave share each SIMD for the whole kernel: the matrix pipe sees an uninterrupted MFMA stream (96 per
-// stage and wave, fragments re-read per 16-channel step), VALU / LDS-write / DMA work issues beside it, and a math
-// wave reads 18 fragments per 48 MFMAs instead of 12 per 24. One workgroup per CU (2 x 72 KB of LDS, 8 waves).
-// Plain statistics form only (per-slot partials; no accumulator plumbing).
-// MEASURED (round 2, 512 -> 1024 x 8192 x 32, tools/exp_pw_big.py): correct (1.7e-6 vs fp64) but 2.03 ms against
-// pw_split_kernel's 1.59. Timing-only ablations of THIS kernel (-DPWS_EXP_*): staging waves alone (no MFMAs) 1.52 ms,
-// math waves alone (no DMA, no transform / split / LDS writes) 1.37 ms, no DMA 1.69, no transform / split 1.47: four
-// staging waves per CU are too few to hide the DMA's and the loads' latency (each side alone is as slow as the whole
-// symmetric kernel), the math waves read their 18 fragments in one burst per 16-channel step (the four of them
-// together: 73 KB through the LDS port while the matrix pipe idles), and a per-stage barrier adds the two sides'
-// variances. OFF unless P2PB_PW_WS=1; kept as the starting point for a 12-wave form (8 staging + 4 math waves, rolling
-// fragment reads to fit 170 registers). (Also measured and removed: symmetric waves with 16-channel stages into the
-// other of two 36 KB buffers -- same LDS as pw_split_kernel, two workgroups per CU, DMA and loads of stage s + 1 issued
-// before the MFMAs of stage s, one barrier per stage: correct, 1.73 ms against 1.58; 24 MFMAs per barrier, 4-byte
-// loads and 8-byte LDS writes cost more than the hidden DMA latency buys.)
-// ------------------------------------------------------------------------------------------------
-// wait + workgroup barrier as ONE opaque instruction pair: the "memory" clobber keeps the compiler from moving LDS /
-// global accesses across it, and nothing but the stated counters is waited for (__syncthreads() would drain the
-// activation loads that are meant to stay in flight across the barrier)
-#define PWS_WAIT_BARRIER(cnt) asm volatile("s_waitcnt " cnt "\n\ts_barrier" ::: "memory")
-template <bool XF, bool POOL>
-__global__ __launch_bounds__(512, 1) void pw_split_ws_kernel(int cin, int cout, int P, int nslots,
-                                                             const float *__restrict__ in, const u32x4 *__restrict__ wp,
-                                                             const float *__restrict__ bias,
-                                                             const float *__restrict__ bias_b,
-                                                             const float *__restrict__ in_scale,
-                                                             const float *__restrict__ in_shift, int in_swish,
-                                                             float *__restrict__ out, float *__restrict__ stats_part,
-                                                             float *__restrict__ mm_out, int pool_u) {
-  extern __shared__ u32x4 pws_lds[];  // two buffers of [A: 2 blocks of 128 channels | B: 128 positions]
-  constexpr int BUF = 3 * PWS_TILE;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, khalf = lane >> 5;
-  // XCD-aware order, as pw_split_kernel
-  const int ncoblk = gridDim.y;
-  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
-  const unsigned vid = nblk % 8 == 0 ? (lin % 8) * (nblk / 8) + lin / 8 : lin;
-  const int bx = (vid / ncoblk) % gridDim.x, by = vid % ncoblk;
-  const int b = vid / (ncoblk * gridDim.x);
-  const int pblk = bx * 128, co0 = by * 256;
-  const int nblk128 = (cout + 127) / 128;
-  const int nstage = (cin + PWS_CK - 1) / PWS_CK;
-
-  if (wave >= 4) {
-    // ================= staging waves: channel group lw (8 channels) of every stage, lane l positions 2l, 2l+1
-    const int lw = wave - 4, ltid = tid - 256;
-    const float *inb = in + (size_t)b * cin * P;
-    const int pl = pblk + 2 * lane;
-    const unsigned voff = (unsigned)(pl < P ? pl : P - 2) * 4u;  // clamped lanes stage garbage that is never stored
-    float braw[8][2];
-    auto load_b = [&](int st) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = min(st * PWS_CK + 8 * lw + i, cin - 1);  // beyond cin: finite garbage x zero weights
-        auto rs = __builtin_amdgcn_make_buffer_rsrc((void *)(inb + (size_t)row * P), 0, P * 4, 0x00020000);
-        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0));
-        braw[i][0] = v[0];
-        braw[i][1] = v[1];
-      }
-    };
-    const bool second_ok = by * 2 + 1 < nblk128;  // odd block count: the last workgroup has one block only
-    auto dma_a = [&](int st, u32x4 *dst) {  // 12 asynchronous 16-byte loads per lane: lane i of a wave lands at base + 16 i
-#ifdef PWS_EXP_NODMA
-      return;
-#endif
-      const u32x4 *src = wp + ((size_t)st * nblk128 + by * 2) * PWS_TILE;
-#pragma unroll
-      for (int i = 0; i < 12; ++i)
-        if (second_ok || i * 256 + ltid < PWS_TILE)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i * 256 + ltid),
-                                           (__attribute__((address_space(3))) void *)(dst + i * 256 + lw * 64), 16, 0, 0);
-    };
-    auto stage_b = [&](int st, u32x4 *lds_b) {  // transform + split + write the registers of stage st
-#ifdef PWS_EXP_NOSTAGE
-      return;
-#endif
-      if (XF) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int c = b * cin + min(st * PWS_CK + 8 * lw + i, cin - 1);
-          const float sc = in_scale[c], sh = in_shift[c];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            float v = braw[i][e] * sc + sh;
-            if (in_swish) v = swishf(v);
-            braw[i][e] = v;
-          }
-        }
-      }
-      const int kstep = lw >> 1, kh = lw & 1;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        u32x4 qq[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          unsigned p0, p1, p2;
-          split3(braw[2 * i][e], braw[2 * i + 1][e], p0, p1, p2);
-          qq[0][i] = p0;
-          qq[1][i] = p1;
-          qq[2][i] = p2;
-        }
-        // slot of position p of the block: (p & 1) * 64 + (p >> 1)   (even / odd de-interleaved)
-#pragma unroll
-        for (int s = 0; s < 3; ++s) lds_b[((kstep * 3 + s) * 2 + kh) * 128 + e * 64 + lane] = qq[s];
-      }
-    };
-    // prologue: stage 0 into buffer 0, stage 1's activations requested
-    dma_a(0, pws_lds);
-    load_b(0);
-    stage_b(0, pws_lds + 2 * PWS_TILE);
-    if (nstage > 1) {
-      load_b(1);
-      PWS_WAIT_BARRIER("vmcnt(8) lgkmcnt(0)");  // LDS writes done; all but the 8 newest loads done, i.e. the DMA
-    } else {
-      PWS_WAIT_BARRIER("vmcnt(0) lgkmcnt(0)");
-    }
-    for (int st = 0; st < nstage; ++st) {
-      if (st + 1 < nstage) {
-        u32x4 *buf = pws_lds + ((st + 1) & 1) * BUF;
-        dma_a(st + 1, buf);             // 12 DMA loads behind the 8 activation loads of stage st + 1
-        stage_b(st + 1, buf + 2 * PWS_TILE);  // (the compiler waits for exactly those 8: vmcnt(12))
-        if (st + 2 < nstage) {
-          load_b(st + 2);
-          PWS_WAIT_BARRIER("vmcnt(8) lgkmcnt(0)");
-        } else {
-          PWS_WAIT_BARRIER("vmcnt(0) lgkmcnt(0)");
-        }
-      } else {
-        PWS_WAIT_BARRIER("lgkmcnt(0)");
-      }  // (the barrier: math is done with buffer st & 1, buffer (st + 1) & 1 is complete)
-    }
-    return;
-  }
-
-  // ================= math waves: 2 (M) x 2 (N); a wave owns 128 channels x 64 positions
-  const int wm2 = wave >> 1, wn = wave & 1;
-  const bool mact = by * 2 + wm2 < nblk128;  // this wave's 128-channel block exists (wave-uniform)
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-  PWS_WAIT_BARRIER("lgkmcnt(0)");  // buffer 0 is complete
-  for (int st = 0; st < nstage; ++st) {
-#ifdef PWS_EXP_NOMATH
-    if (false) {
-#else
-    if (mact) {
-#endif
-      const u32x4 *lds_a = pws_lds + (st & 1) * BUF + wm2 * PWS_TILE;
-      const u32x4 *lds_b = pws_lds + (st & 1) * BUF + 2 * PWS_TILE;
-#pragma unroll
-      for (int kstep = 0; kstep < 2; ++kstep) {
-        u32x4 af[3][4], bf[3][2];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-#pragma unroll
-          for (int n = 0; n < 2; ++n) bf[s][n] = lds_b[((kstep * 3 + s) * 2 + khalf) * 128 + n * 64 + wn * 32 + l31];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) af[s][m] = lds_a[((kstep * 3 + s) * 2 + khalf) * 128 + m * 32 + l31];
-        }
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};  // small terms first
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[PA[t]][m]),
-                                                                  __builtin_bit_cast(bf16x8, bf[PB[t]][n]), acc[m][n], 0, 0, 0);
-      }
-    }
-    PWS_WAIT_BARRIER("lgkmcnt(0)");  // (LDS reads of this buffer retired before the staging waves may overwrite it)
-  }
-  if (!mact) return;
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-    pws_epilogue<POOL, 4, 1>(*(f32x16(*)[2][2]) & acc[2 * h], b, bx, (int)gridDim.x, pblk, co0, 2 * wm2 + h, wn, l31, khalf,
-                             cout, P, nslots, bias, bias_b, out, stats_part, mm_out, pool_u, 0, GnAcc());
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
@@ -1169,95 +923,34 @@ extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float 
   return p2pb_launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------
-// Operand of a split GEMM, transformed and split ONCE (f16x3): xs[b][P / 128][chunk32][kstep 2][plane 2][khalf 2][slot 128]
-// of 16-byte groups = 8 consecutive channels as fp16 -- exactly the B tile pw_split_kernel<PRE> DMAs per stage. Same
-// arithmetic as the in-kernel staging (folded norm -> Swish -> split_pair): the GEMM's results do not change.
-// 4 bytes per element in, 4 out. grid (P / 128, chunks, b).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pw_presplit_kernel(int cin, int P, const float *__restrict__ in,
-                                                          const float *__restrict__ in_scale,
-                                                          const float *__restrict__ in_shift, int in_swish,
-                                                          u32x4 *__restrict__ xs) {
-  const int b = blockIdx.z, chunk = blockIdx.y, pblk = blockIdx.x;
-  const float *inb = in + (size_t)b * cin * P + (size_t)pblk * 128;
-  u32x4 *tile = xs + (((size_t)b * gridDim.x + pblk) * gridDim.y + chunk) * 1024;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int item = threadIdx.x + 256 * j;
-    const int pl = item & 127, ks = item >> 8, kh = (item >> 7) & 1;
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int c = min(chunk * PWS_CK + ks * 16 + kh * 8 + i, cin - 1);  // beyond cin: finite garbage x zero weights
-      float x = inb[(size_t)c * P + pl];
-      if (in_scale) {
-        x = x * in_scale[b * cin + c] + in_shift[b * cin + c];
-        if (in_swish) x = swishf(x);
-      }
-      v[i] = x;
-    }
-    u32x4 q0, q1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned p0, p1, p2;
-      split_pair<SPLIT_F16X3>(v[2 * i], v[2 * i + 1], p0, p1, p2);
-      q0[i] = p0;
-      q1[i] = p1;
-    }
-    const int slot = (pl & 1) * 64 + (pl >> 1);
-    tile[((ks * 2 + 0) * 2 + kh) * 128 + slot] = q0;
-    tile[((ks * 2 + 1) * 2 + kh) * 128 + slot] = q1;
-  }
-}
-
-extern "C" size_t p2pb_pointwise_presplit_bytes(int b, int cin, int npos) {
-  if (b <= 0 || cin <= 0 || npos <= 0 || npos % 128) return 0;
-  return (size_t)b * (npos / 128) * ((cin + PWS_CK - 1) / PWS_CK) * 1024 * 16;
-}
-
-extern "C" int p2pb_pointwise_presplit(int b, int cin, int npos, const float *in, const float *in_scale,
-                                       const float *in_shift, int in_swish, void *xs, void *stream) {
-  if (b <= 0 || cin <= 0 || npos <= 0 || npos % 128 || !in || !xs || (in_scale == nullptr) != (in_shift == nullptr))
-    return P2PB_EINVAL;
-  if (p2pb_g_split_terms != SPLIT_F16X3) return P2PB_EINVAL;  // (the image is the f16x3 tile)
-  hipLaunchKernelGGL(pw_presplit_kernel, dim3(npos / 128, (cin + PWS_CK - 1) / PWS_CK, b), dim3(256), 0, (hipStream_t)stream,
-                     cin, npos, in, in_scale, in_shift, in_swish, (u32x4 *)xs);
-  return p2pb_launch_status();
-}
-
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s,
-                           const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc(), bool pre = false) {
+                           const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
   const bool xf = in_scale != nullptr || fold.group != nullptr;
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
   const int mode = p2pb_g_split_terms;
-  if (pre && (xf || fx || mode != SPLIT_F16X3 || P % 128 || out_pm)) return P2PB_EINVAL;
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
                                        : (cout >= 512 && (long)((P + 127) / 128) * ((cout + 255) / 256) * b >= 1024));
-  // (NB = 2, 256 positions per workgroup, halves the weight traffic through L2 -- 10.7 -> 5.3 GB for the 512 -> 1024
-  // launch -- but costs a wave per SIMD: measured 4 % / 7 % SLOWER with 256 / 128 channels; only NB = 1 is instantiated)
-  static const int nb_env = getenv("P2PB_PW_NB") ? atoi(getenv("P2PB_PW_NB")) : 0;  // experiment: 256-position workgroups
-  const bool nb2 = wm4 && nb_env == 2 && mode == SPLIT_F16X3 && !fx && !pre;
-  dim3 grid((P + (nb2 ? 255 : 127)) / (nb2 ? 256 : 128), wm4 ? (cout + 255) / 256 : (cout + 127) / 128, b);
+  // (256-position workgroups of THIS kernel -- half the weight traffic through L2 at one wave per SIMD less -- measured
+  //  4 % / 7 % slower and are not instantiated; the 256 x 256 tile lives in pw_pingpong.h, with the pipeline it needs)
+  dim3 grid((P + 127) / 128, wm4 ? (cout + 255) / 256 : (cout + 127) / 128, b);
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
   // 72 KB of dynamic LDS (above the 64 KB default): opt in once per instantiation
-#define LAUNCHW(XF, PL, WM, NB, FXV, TM) LAUNCHP(XF, PL, WM, NB, FXV, TM, false)
-#define LAUNCHP(XF, PL, WM, NB, FXV, TM, PR)                                                                              \
+#define LAUNCHW(XF, PL, WM, NB, FXV, TM)                                                                                  \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
     const int lds = (WM / 2 + NB) * PWS_TILE * 16 + (fold.group ? 2 * cin * 4 : 0);                                   \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV, TM, PR>,                                   \
+      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV, TM>,                                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
                                 (WM / 2 + NB) * PWS_TILE * 16 + 2 * P2PB_FOLD_MAXC * 4);                               \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV, TM, PR>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
+    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV, TM>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in,  \
                        w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fold,  \
                        gacc);                                                                                        \
   } while (0)
@@ -1271,38 +964,34 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   } while (0)
 #define LAUNCH(XF, PL)                    \
   do {                                    \
-    if (nb2) LAUNCHW(XF, PL, 4, 2, false, SPLIT_F16X3); \
-    else if (wm4) LAUNCHF(XF, PL, 4, 1);   \
+    if (wm4) LAUNCHF(XF, PL, 4, 1);        \
     else LAUNCHF(XF, PL, 2, 1);            \
   } while (0)
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
-  // the 256-channel layers without statistics plumbing: math and staging on different waves (pw_split_ws_kernel)
-  static const int ws_env = getenv("P2PB_PW_WS") ? atoi(getenv("P2PB_PW_WS")) : 0;
-  if (wm4 && !fx && ws_env == 1 && mode == SPLIT_BF16X6) {
-    const int lds = 2 * 3 * PWS_TILE * 16;
-#define LAUNCHS(XF, PL)                                                                                              \
+  // Round 3: the layers that qualified for 256-channel workgroups AND come in whole 256 x 256 tiles with an even number
+  // of 32-channel stages run the ping-pong kernel (pw_pingpong.h: one 8-wave workgroup per CU, 160 KB of LDS, weight
+  // DMA two stages ahead, the two waves of a SIMD in opposite phase): 512 -> 1024 x 8192 x 32 in 0.88 ms against 1.04-1.15
+  // (tools/exp/pp). P2PB_PW_PP=0 keeps pw_split_kernel (A/B timing).
+  static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 1;
+  if (pp_env && wm4 && !fx && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 256 == 0 && P % 256 == 0 &&
+      (!minmax || pool_u == 0)) {
+    dim3 pgrid(P / 256, cout / 256, b);
+#define LAUNCHPP(XF, PL)                                                                                             \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void *)pw_split_ws_kernel<XF, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                lds);                                                                                \
+      (void)hipFuncSetAttribute((const void *)pw_pingpong_kernel<XF, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                PP_LDS_BYTES);                                                                       \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((pw_split_ws_kernel<XF, PL>), grid, dim3(512), lds, s, cin, cout, P, nslots, in, w, bias, bias_b, \
-                       in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                               \
+    hipLaunchKernelGGL((pw_pingpong_kernel<XF, PL>), pgrid, dim3(512), PP_LDS_BYTES, s, cin, cout, P, P / 64, in, w,  \
+                       bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                  \
   } while (0)
-    if (xf && minmax) LAUNCHS(true, true);
-    else if (xf) LAUNCHS(true, false);
-    else if (minmax) LAUNCHS(false, true);
-    else LAUNCHS(false, false);
-#undef LAUNCHS
-    return p2pb_launch_status();
-  }
-  if (pre) {
-    if (wm4 && minmax) LAUNCHP(false, true, 4, 1, false, SPLIT_F16X3, true);
-    else if (wm4) LAUNCHP(false, false, 4, 1, false, SPLIT_F16X3, true);
-    else if (minmax) LAUNCHP(false, true, 2, 1, false, SPLIT_F16X3, true);
-    else LAUNCHP(false, false, 2, 1, false, SPLIT_F16X3, true);
+    if (xf && minmax) LAUNCHPP(true, true);
+    else if (xf) LAUNCHPP(true, false);
+    else if (minmax) LAUNCHPP(false, true);
+    else LAUNCHPP(false, false);
+#undef LAUNCHPP
     return p2pb_launch_status();
   }
   if (xf && minmax) LAUNCH(true, true);
@@ -1312,7 +1001,6 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
 #undef LAUNCH
 #undef LAUNCHF
 #undef LAUNCHW
-#undef LAUNCHP
   return p2pb_launch_status();
 }
 
@@ -1397,12 +1085,11 @@ extern "C" int p2pb_pointwise_conv_forward_fx(int b, int cin, int cout, int npos
                      : pw_launch<1>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
                                     stats_part, nullptr, 0, out_pm, s, fold, gacc, true);
   }
-  if (flags & 4) {  // wp is the split pack; flags & 64: `in` is the pre-split operand (p2pb_pointwise_presplit)
+  if (flags & 4) {  // wp is the split pack
     if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           nullptr, 0, out_pm, s, fold, gacc, (flags & 64) != 0);
+                           nullptr, 0, out_pm, s, fold, gacc);
   }
-  if (flags & 64) return P2PB_EINVAL;
   const float *wp = (const float *)wp_any;
   // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
@@ -1458,8 +1145,7 @@ extern "C" int p2pb_pointwise_conv_pool_forward_fx(int b, int cin, int cout, int
   }
   if (flags & 4)
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           minmax, pool_u, 0, s, fold, gacc, (flags & 64) != 0);
-  if (flags & 64) return P2PB_EINVAL;
+                           minmax, pool_u, 0, s, fold, gacc);
   const float *wp = (const float *)wp_any;
   const int g = pool_lanes(pool_u);
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,

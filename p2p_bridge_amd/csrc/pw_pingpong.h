@@ -27,9 +27,6 @@
 #pragma once
 
 #define PP_CK 32
-#ifndef PP_PRIO
-#define PP_PRIO 0
-#endif
 #define PP_TILE 2048  // 16-byte groups per operand tile per stage (32 KB)
 #define PP_LDS_BYTES (5 * PP_TILE * 16)  // A x 3, B x 2: all 160 KB of the CU
 
@@ -41,26 +38,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
                                                              const float *__restrict__ in_scale,
                                                              const float *__restrict__ in_shift, int in_swish,
                                                              float *__restrict__ out, float *__restrict__ stats_part,
-                                                             float *__restrict__ mm_out, int pool_u
-#ifdef PP_TRACE
-                                                             , long long *__restrict__ trace
-#endif
-                                                             ) {
-#ifdef PP_TRACE  // s_memtime stamps of the phases of waves 0 and 4 of three workgroups: trace[wg][half][stage][8]
-#define PP_T(k) do { if (trace_on) { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) trace_p[(k)] = t_; } } while (0)
-#else
-#define PP_T(k) do { } while (0)
-#endif
+                                                             float *__restrict__ mm_out, int pool_u) {
   extern __shared__ u32x4 pp_lds[];  // [A0 | A1 | A2 | B0 | B1], 32 KB each
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, khalf = lane >> 5;
   const int wm = wave & 3, wn = wave >> 2;  // MFMA tile: 64 channels x 128 positions; waves w, w + 4 share a SIMD
-#ifdef PP_SWAP
-  const int grp = 1 - (wave >> 2);
-#else
   const int grp = wave >> 2;                // 0: multiply first, 1: stage first
-#endif
   const int cg = wave & 3, half = wave >> 2;  // staging share: channels 8 cg .. 8 cg + 7 of the stage, positions 128 half ..
   // XCD-aware order (pw_split_kernel): the channel blocks of one activation tile run side by side on one XCD
   const int ncoblk = gridDim.y;
@@ -72,11 +56,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   const int pblk = bx * 256, co0 = by * 256;
   const int nstage = cin / PP_CK;
   const int nblk128 = cout / 128;
-#ifdef PP_TRACE
-  const int trace_wg = lin == 0 ? 0 : (lin == 1000 ? 1 : (lin == 3001 ? 2 : -1));
-  const bool trace_on = trace_wg >= 0 && (wave & 3) == 0;
-  long long *trace_p = trace + ((size_t)(trace_wg < 0 ? 0 : trace_wg) * 2 + (wave >> 2)) * 17 * 8;
-#endif
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -187,7 +166,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
                                        (__attribute__((address_space(3))) void *)(dst + e), 16, 0, 0);
     }
   };
-  auto stage_b = [&](int s, int buf, int set, int tr = -1) {  // braw (raw activations of stage s) -> transformed, split, into buffer buf
+  auto stage_b = [&](int s, int buf, int set) {  // braw (raw activations of stage s) -> transformed, split, into buffer buf
 #ifdef PP_EXP_NOSTAGE
     return;
 #endif
@@ -236,7 +215,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
 #pragma unroll
         for (int e = 0; e < 2; ++e) y[i][e] = braw[i][e] * SPLIT_F16_SX;
     }
-    if (tr >= 0) PP_T(tr);
     u32x4 *lb = pp_lds + (3 + buf) * PP_TILE;
     const int kstep = cg >> 1, kh = cg & 1;
     u32x4 q0[2], q1[2];

@@ -521,16 +521,6 @@ def use_wide_f16(ci: int, co: int) -> bool:
     return ci >= int(os.environ.get("P2PB_WIDE_F16_MIN_CIN", "16"))
 
 
-def use_presplit(b: int, co: int, npos: int) -> bool:
-    """pre-split operand for a split GEMM (csrc/pointwise.hip pw_presplit_kernel + pw_split_kernel<PRE>): f16x3 only,
-    256-channel workgroups (the rule of pw_launch_split) and at least P2PB_PRESPLIT_BLOCKS of them per activation tile.
-    OFF by default (P2PB_PRESPLIT_BLOCKS=0): measured on the 512 -> 1024 layer the pre-pass + DMA-only GEMM take 1.23 ms
-    against 1.16 for the GEMM that stages its operand itself (bit-identical results)"""
-    nblk = int(os.environ.get("P2PB_PRESPLIT_BLOCKS", "0"))
-    wm4 = co >= 512 and ((npos + 127) // 128) * ((co + 255) // 256) * b >= 1024
-    return nblk > 0 and lib().p2pb_get_split_terms() == 16 and wm4 and (co + 255) // 256 >= nblk
-
-
 def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
     """the split-operand GEMM (csrc/pointwise.hip pw_split_kernel) for the matrix-bound layers; narrow layers are
     HBM-bound and stay on the streaming fp32 kernel"""
@@ -563,14 +553,6 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
               and not isinstance(in_scale, Fold))
     wp = pack_pointwise_weight(conv, ci_lo, ci_hi, split or wide_h)
     pre = 128 if wide_h else 0
-    if (split and in_scale is not None and not isinstance(in_scale, Fold) and not point_major and p % 128 == 0
-            and x.is_contiguous() and use_presplit(b, co, p)):
-        # f16x3: transform + split the operand ONCE (csrc/pointwise.hip pw_presplit_kernel) instead of once per
-        # 256-channel block of the output; the GEMM then DMAs its B tiles like its weight tiles
-        xs = torch.empty(lib().p2pb_pointwise_presplit_bytes(_i(b), _i(ci), _i(p)), dtype=torch.uint8, device=x.device)
-        call("p2pb_pointwise_presplit", _i(b), _i(ci), _i(p), ptr(x), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(xs),
-             stream_ptr())
-        x, in_scale, in_shift, swish, pre = xs, None, None, False, 64
     flags = _i((4 if (split or wide_h) else 0) | (32 if point_major else 0) | pre)
     if point_major:
         y = torch.empty(b, p, co, dtype=F32, device=x.device)

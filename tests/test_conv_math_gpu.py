@@ -200,32 +200,6 @@ def test_training_gradient_pass_is_bf16x6(fused):
     assert fused.lib().p2pb_get_split_terms() == 16
 
 
-@pytest.mark.parametrize("pool,ci", [(None, 512), (0, 512), (None, 200)])
-def test_presplit_operand_is_bit_identical(fused, monkeypatch, pool, ci):
-    """the wide layers' operand transformed + split once by pw_presplit_kernel and DMA'd into the GEMM's B tiles: the same
-    values as the in-kernel staging (ragged channel count included), statistics and pooled {min, max} too"""
-    torch.manual_seed(11)
-    B, co, P = 32, 1024, 1024
-    x = torch.randn(B, ci, P, device="cuda") * 3
-    conv = torch.nn.Conv1d(ci, co, 1).cuda()
-    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
-    kw = dict(swish=True) if pool is None else dict(swish=True, pool_u=pool)
-    assert not fused.use_presplit(B, co, P)  # an experiment: off by default (slower than the self-staging GEMM)
-    with torch.no_grad():
-        b = fused.pw_conv(x, conv, sc, sh, **kw)
-        monkeypatch.setenv("P2PB_PRESPLIT_BLOCKS", "4")
-        assert fused.use_presplit(B, co, P) and not fused.use_presplit(B, 256, P) and not fused.use_presplit(2, co, P)
-        a = fused.pw_conv(x, conv, sc, sh, **kw)
-    for u, v in zip(a, b):
-        assert torch.equal(u, v)
-    xin = swish(x[:2].double() * sc[:2, :, None].double() + sh[:2, :, None].double())
-    ref = torch.nn.functional.conv1d(xin, conv.weight.double(), conv.bias.double())
-    assert ((a[0][:2] - ref).abs() / ref.abs().max()).max().item() < 1e-6
-    # the C ABI refuses what the image cannot describe
-    lib = fused.lib()
-    assert lib.p2pb_pointwise_presplit_bytes(4, 64, 100) == 0 and lib.p2pb_pointwise_presplit_bytes(4, 40, 256) == 4 * 2 * 2 * 16384
-
-
 @pytest.mark.parametrize("ci,co,P,pool,xf", [(32, 64, 4096, 32, True), (64, 128, 2048, None, True), (35, 128, 1024, None, False),
                                                (128, 64, 1024, 0, True), (19, 24, 512, None, False)])
 def test_narrow_layers_on_the_f16_pipe(fused, monkeypatch, ci, co, P, pool, xf):

@@ -45,13 +45,7 @@ int main(int argc, char **argv) {
     if (rc) { printf("old kernel rc %d\n", rc); exit(1); }
   };
   CK(hipFuncSetAttribute((const void *)pw_pingpong_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES));
-#ifdef PP_TRACE
-  long long *trace;
-  CK(hipMalloc(&trace, 3 * 2 * 17 * 8 * 8)); CK(hipMemset(trace, 0, 3 * 2 * 17 * 8 * 8));
-#define TRACE_ARG , trace
-#else
 #define TRACE_ARG
-#endif
   auto new_k = [&] {
     hipLaunchKernelGGL((pw_pingpong_kernel<true, true>), dim3(P / 256, co / 256, B), dim3(512), PP_LDS_BYTES, 0, ci, co, P, nslots, x,
                        (const u32x4 *)wp, bias, nullptr, sc, sh, 1, nullptr, st1, mm1, 0 TRACE_ARG);
@@ -69,23 +63,6 @@ int main(int argc, char **argv) {
     printf("pass %d: pw_split %.4f ms (%.1f TF/s)   pingpong %.4f ms (%.1f TF/s, frac %.3f of 838.9)\n", pass, ms_old / reps,
            fl / (ms_old / reps) / 1e9, ms_new / reps, fl / (ms_new / reps) / 1e9, fl / (ms_new / reps) / 1e9 / 838.9);
   }
-#ifdef PP_TRACE
-  {
-    std::vector<long long> tr(3 * 2 * 17 * 8);
-    CK(hipMemcpy(tr.data(), trace, tr.size() * 8, hipMemcpyDeviceToHost));
-    for (int wg = 0; wg < 3; ++wg) {
-      const long long t00 = tr[((wg * 2 + 0) * 17 + 1) * 8];
-      for (int h = 0; h < 2; ++h) {
-        printf("wg %d half %d (stamps relative to half 0's first; columns: top, after dma, after multiply, k3, k4, k5)\n", wg, h);
-        for (int s = 1; s <= 16; ++s) {
-          printf("  s%2d:", s - 1);
-          for (int k = 0; k < 8; ++k) printf(" %7lld", tr[((wg * 2 + h) * 17 + s) * 8 + k] - t00);
-          printf("\n");
-        }
-      }
-    }
-  }
-#endif
   if (getenv("PP_CPUREF")) {  // small shapes: fp64 reference of the new kernel's per-slot sums, error by (slot, 64-channel block)
     std::vector<float> bq2(nst);
     CK(hipMemcpy(bq2.data(), st1, nst * 4, hipMemcpyDeviceToHost));
