@@ -125,13 +125,15 @@ def conv_roofline(model, x_start, reps=10):
 
 
 def gemm_roofline(model, B, P, reps=10):
-    """Dominant kernel of the sampler (largest share of the critical stream in profiles/r01*_per_eval.csv):
-    pw_split_kernel<XF=true, POOL=true> on the global embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels
-    over all P points of every patch; models/pvcnn.py:905-932): split-operand (bf16x6) GEMM that applies the previous
-    layer's folded GroupNorm + Swish to its operand on load and whose epilogue emits the GroupNorm statistics and
-    the per-channel {min, max} the max-pool is formed from -- the 1024-channel output is never written. Timed live
-    with HIP events on torch's current stream, launched exactly as the sampler launches it.
-    `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
+    """Dominant kernel of the sampler (largest share of the critical stream in profiles/r0N*_per_eval.csv): the global
+    embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels over all P points of every patch;
+    models/pvcnn.py:905-932) -- since round 3 pw_pingpong_kernel<XF=true, POOL=true> (csrc/pw_pingpong.h; pw_split_kernel
+    under P2PB_PW_PP=0 or for shapes outside whole 256 x 256 tiles): split-operand GEMM in the arithmetic fused.conv_math()
+    selects (f16x3 by default) that applies the previous layer's folded GroupNorm + Swish to its operand on load and whose
+    epilogue emits the GroupNorm statistics and the per-channel {min, max} the max-pool is formed from -- the
+    1024-channel output is never written. Timed live with HIP events on torch's current stream, launched exactly as
+    the sampler launches it, right after the timed sampler runs (a warm chip: 10-15 % slower than the same launch from
+    a cold start, tools/exp/pp). `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
     from p2p_bridge_amd import fused
 
     conv = model.model.global_pnet.mlp2.shared_mlp_1.mlp[0]
@@ -177,8 +179,9 @@ def gemm_roofline(model, B, P, reps=10):
     traffic = None
     try:
         vals = {}
-        pmc = next(q for q in (os.path.join(ROOT, "profiles", f"{t}_pmc_pw_split_512_1024_pool.csv") for t in ("r02f", "r02", "r01"))
-                   if os.path.exists(q))
+        pingpong = split and fused.conv_math() == "f16x3" and os.environ.get("P2PB_PW_PP", "1") != "0" and P % 256 == 0 and B * (P // 128) * (co // 256) >= 1024
+        names = ([f"r03_pmc_pw_pingpong_512_1024_pool.csv"] if pingpong else []) + [f"{t}_pmc_pw_split_512_1024_pool.csv" for t in ("r02f", "r02", "r01")]
+        pmc = next(q for q in (os.path.join(ROOT, "profiles", n) for n in names) if os.path.exists(q))
         for line in open(pmc):
             k, v = line.split(",")[:2]
             if k in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -188,11 +191,13 @@ def gemm_roofline(model, B, P, reps=10):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
-            "traffic_basis": "profiles/r0N_pmc_pw_split_512_1024_pool.csv (latest round): (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch "
+            "traffic_basis": f"profiles/{os.path.basename(pmc) if traffic is not None else 'r0N_pmc_pw_*_512_1024_pool.csv'}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch "
                              "(FETCH_SIZE counts half of 8- and 16-byte-per-lane streaming reads on gfx950: calibrated on a "
-                             f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 6 * ci * co} B: "
-                             "the activations are staged by 8 output-channel blocks, the per-XCD L2 absorbs 3/4 of that",
-            "kernel": f"pw_split_kernel<XF=true,POOL=true,WM=4> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)",
+                             f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 4 * ci * co} B: "
+                             "the activation tile is staged once per 256-channel block (4 x for this layer), the blocks of one "
+                             "tile run side by side on one XCD and share it in that XCD's L2",
+            "kernel": (f"pw_pingpong_kernel<XF=true,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)" if traffic is not None and "pingpong" in pmc
+                       else f"pw_split_kernel<XF=true,POOL=true,WM=4> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)"),
             "peak_basis": split_peak_basis() if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
             "frac_of_six_product_ceiling": round(achieved / SPLIT_PEAK_TFLOPS, 4) if split else None,
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
@@ -315,14 +320,19 @@ def main():
     for _ in range(args.steps):
         out = one()
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0  # this rank's own work (reported per rank; NOT what `value` is computed from)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dt = sharding.max_over_ranks(dt, device="cuda")
+    dt_local = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt_local, device="cuda")
     assert torch.isfinite(out["x_pred"]).all()
 
     res = result_line(args, world, dt, dist)
+    # every rank's own time / throughput and the device it ran on, gathered over the process group (collective)
+    res["ranks"] = sharding.rank_evidence(dt_own, args.batch * args.points * args.steps, local_rank)
+    if world > 1:
+        assert res["ranks"]["distinct_devices"] == world, res["ranks"]
     res["config"]["conv_math"] = conv_math_note()
     if rank == 0:
         res["roofline"] = gemm_roofline(model, args.batch, args.points)
@@ -399,10 +409,13 @@ def dry_run(args, dist, rank, world):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         time.sleep(0.01 * (rank + 1))
+    dt_own = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    dt = sharding.max_over_ranks(time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt_local)
     res = result_line(args, world, dt, dist)
+    res["ranks"] = sharding.rank_evidence(dt_own, args.batch * args.points * args.steps, None)
     res["dry_run"] = True
     res["data"] = "none (dry run: launch / rendezvous / timing protocol only)"
     if rank == 0:

@@ -108,10 +108,11 @@ class _LinearAttentionCore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, qkv, heads):
-        from ._lib import call, ptr, stream_ptr
+        from ._lib import call, check, ptr, stream_ptr
         import ctypes
 
         qkv = qkv.contiguous()
+        check(qkv, torch.float32, "qkv")  # (raw pointers go to the kernel: device, dtype and layout are checked here)
         b, c3, n = qkv.shape
         dh = c3 // (3 * heads)
         out = torch.empty(b, heads * dh, n, dtype=qkv.dtype, device=qkv.device)
@@ -134,6 +135,9 @@ class _LinearAttentionCore(torch.autograd.Function):
         heads = ctx.heads
         dq = torch.empty_like(qkv)
         g = g.contiguous()
+        from ._lib import check
+
+        check(g, torch.float32, "grad_out")
         call("p2pb_linear_attention_backward", ctypes.c_int(b), ctypes.c_int(heads), ctypes.c_int(c3 // (3 * heads)),
              ctypes.c_int(n), ptr(qkv), ptr(ctxm), ptr(g), ptr(dq), stream_ptr())
         return dq, None

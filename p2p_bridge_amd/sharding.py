@@ -44,6 +44,36 @@ def max_over_ranks(seconds: float, device=None) -> float:
     return t.item()
 
 
+def rank_evidence(seconds: float, units: float, device_index: Optional[int] = None) -> dict:
+    """What proves from the JSON line alone that N ranks ran on N distinct GPUs over RCCL (the
+    reference only logs `world_size`, train.py:38): every rank's own wall time and throughput, the device each rank was
+    bound to (index, name, PCI bus id, uuid) gathered over the process group, the host names, and the RCCL version.
+    Collective: every rank must call it. Returns {"per_rank": [...], "distinct_devices": n, "rccl_version": ...}."""
+    me = {"rank": dist.get_rank() if dist.is_initialized() else 0, "host": socket.gethostname(), "pid": os.getpid(),
+          "seconds": round(seconds, 6), "value": round(units / seconds, 1) if seconds > 0 else None,
+          "device": None, "device_name": None, "pci_bus_id": None, "uuid": None}
+    if device_index is not None and torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(device_index)
+        me.update(device=torch.cuda.current_device(), device_name=pr.name,
+                  pci_bus_id=getattr(pr, "pci_bus_id", None), uuid=str(getattr(pr, "uuid", "")) or None)
+        if me["pci_bus_id"] is not None:
+            me["pci_bus_id"] = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        rows = [None] * dist.get_world_size()
+        dist.all_gather_object(rows, me)
+    else:
+        rows = [me]
+    rows.sort(key=lambda r: r["rank"])
+    keys = {(r["host"], r["pci_bus_id"] or r["uuid"] or r["device"]) for r in rows if r["device"] is not None}
+    rccl = None
+    if device_index is not None and torch.cuda.is_available():
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 (a build without the binding: leave it out rather than fail the bench)
+            rccl = None
+    return {"per_rank": rows, "distinct_devices": len(keys), "rccl_version": rccl}
+
+
 # ---------------------------------------------------------------------------- one process per GPU: launching
 
 

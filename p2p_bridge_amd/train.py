@@ -210,10 +210,14 @@ def save_checkpoint(path, step, model, optimizer):
 
 def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, distributed: bool = False,
           rank: int = 0, world: int = 1, output_dir: Optional[str] = None, log: Optional[Callable] = None,
-          align: bool = True, evaluate: Optional[Callable] = None):
-    """the reference's loop (train.py:107-211) over `steps` optimiser steps. Returns the list of logged mean losses."""
+          align: bool = True, evaluate: Optional[Callable] = None, ckpt: Optional[Dict] = None, restart: bool = False):
+    """the reference's loop (train.py:107-211) over `steps` optimiser steps. Returns the list of logged mean losses.
+    ckpt: a checkpoint dictionary already loaded into `model` (p2pb.load_checkpoint): the optimiser state is restored from
+    it and, unless `restart`, training continues at ckpt["step"] + 1 (models/model_loader.py:13-61,114-165)."""
     tr = _get(cfg, "training")
-    optimizer, sched = load_optim_sched(cfg, model)
+    optimizer, sched = load_optim_sched(cfg, model, ckpt, restart)
+    if ckpt is not None and not restart and "step" in ckpt:
+        start_step = int(ckpt["step"]) + 1
     align_fn = make_align_fn() if (align and _get(_get(cfg, "data"), "dataset") == "PUNet") else None
     on_gpu = model.device.type == "cuda"
     scaler = torch.amp.GradScaler("cuda", enabled=bool(_get(tr, "amp", False))) if on_gpu else None
@@ -240,9 +244,46 @@ def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, 
                 dist.barrier()
             model.eval()
             if rank == 0:
-                evaluate(model, step + 1)
+                try:  # (train.py:193-199: a failing evaluation is logged, it must not leave the other ranks waiting in
+                    # the next gradient all-reduce)
+                    evaluate(model, step + 1)
+                except Exception as e:  # noqa: BLE001
+                    (log or print)({"step": step, "evaluation_error": repr(e)})
             model.train()
     return history
+
+
+def allreduce_share(cfg, model, batches, steps: int = 3) -> Optional[float]:
+    """(t_sync - t_nosync) / t_sync over `steps` forward + backward passes each: what DDP's bucketed gradient all-reduce
+    (RCCL over xGMI) adds to a step beyond the kernels it overlaps with. Collective; None without DDP."""
+    net = model.model
+    if not hasattr(net, "no_sync"):
+        return None
+    import contextlib
+
+    on_gpu = model.device.type == "cuda"
+
+    def timed(sync: bool) -> float:
+        if on_gpu:
+            torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            data = get_data_batch(next(batches), cfg, None)
+            with (contextlib.nullcontext() if sync else net.no_sync()):
+                model(data["x_gt"], data["x_start"], data["x_cond"]).backward()
+        if on_gpu:
+            torch.cuda.synchronize()
+        dist.barrier()
+        for p in net.parameters():
+            p.grad = None
+        return time.perf_counter() - t0
+
+    timed(True)
+    a, b_ = timed(True), timed(False)
+    t = torch.tensor([a, b_], dtype=torch.float64, device=model.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return round(max(0.0, (t[0] - t[1]).item() / t[0].item()), 4)
 
 
 # ----------------------------------------------------------------------------------------- entry point
@@ -256,6 +297,8 @@ def main(argv=None):
     ap.add_argument("--npoints", type=int, default=2048)
     ap.add_argument("--no-align", action="store_true")
     ap.add_argument("--output-dir", default=None)
+    ap.add_argument("--resume", default=None, help="checkpoint (step_*.pth) to continue from: weights, EMA, optimiser, step")
+    ap.add_argument("--restart", action="store_true", help="with --resume: load the network only, start at step 0")
     args = ap.parse_args(argv)
     from . import p2pb as product
     from . import sharding
@@ -273,23 +316,34 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     cfg = copy.deepcopy(PVDS_PUNET_TRAIN)
     cfg["data"]["npoints"] = args.npoints
+    if args.bs % world:
+        raise SystemExit(f"--bs {args.bs} is not divisible by the {world} ranks (train.py:226 divides the global batch)")
     cfg["training"]["bs"] = args.bs // world
     cfg["training"]["log_interval"] = 1
     cfg["gpu"] = f"cuda:{local_rank}"
     torch.manual_seed(int(cfg["training"]["seed"]))  # identical initial weights on every rank (DDP broadcasts rank 0's anyway)
     model = product.P2PB(cfg, PVCNN2Unet(cfg))
+    ckpt = None
+    if args.resume:
+        ckpt = torch.load(args.resume, map_location="cpu")
+        product.load_checkpoint(model, ckpt, use_ema=True, restart=args.restart)
     if mode == "rank":
         ddp_wrap(model, local_rank)
     batches = synthetic_punet_batches(cfg["training"]["bs"], args.npoints, seed=1000 * rank, device=model.device)
     t0 = time.perf_counter()
     hist = train(cfg, model, batches, args.steps, distributed=mode == "rank", rank=rank, world=world,
-                 output_dir=args.output_dir, align=not args.no_align,
-                 log=lambda d: print(json.dumps(d), flush=True))
+                 output_dir=args.output_dir, align=not args.no_align, ckpt=ckpt, restart=args.restart,
+                 log=(lambda d: print(json.dumps(d), flush=True)) if rank == 0 else None)
     torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # self-evidence of the N-rank run (collective): every rank's time and device, RCCL's version, and the measured share
+    # of a step that is gradient all-reduce not hidden behind the backward kernels (steps with / without DDP's sync)
+    ranks = sharding.rank_evidence(dt, float(args.steps * cfg["training"]["bs"]), local_rank)
+    share = allreduce_share(cfg, model, batches) if mode == "rank" else None
     if rank == 0:
-        dt = time.perf_counter() - t0
         print(json.dumps({"steps": args.steps, "world": world, "global_batch": cfg["training"]["bs"] * world,
-                          "s_per_step": dt / args.steps, "final_loss": hist[-1] if hist else None}), flush=True)
+                          "s_per_step": dt / args.steps, "final_loss": hist[-1] if hist else None,
+                          "exposed_allreduce_share_of_step": share, "ranks": ranks}), flush=True)
     if mode == "rank":
         dist.barrier()
         dist.destroy_process_group()

@@ -45,6 +45,13 @@ def test_bench_gpus2_spawns_two_ranks():
     assert res["config"]["parallelism"] == "patch-shard x2" and res["scaling"] == "weak"
     # max over ranks: rank 1's stand-in step is 20 ms, rank 0's 10 ms
     assert res["ms_per_step"] >= 19.0
+    # the line is self-evidencing: every rank's own time / throughput gathered over the process group (two distinct
+    # processes), `value` = all ranks' units over the SLOWEST rank's time; device fields are filled on a GPU run
+    rk = res["ranks"]["per_rank"]
+    assert [r["rank"] for r in rk] == [0, 1] and rk[0]["pid"] != rk[1]["pid"]
+    assert rk[1]["seconds"] > rk[0]["seconds"] and abs(max(r["seconds"] for r in rk) * 1e3 / 2 - res["ms_per_step"]) < 5.0
+    assert all(set(r) >= {"host", "device", "device_name", "pci_bus_id", "uuid", "value"} for r in rk)
+    assert res["ranks"]["distinct_devices"] == 0 and res["ranks"]["rccl_version"] is None  # (gloo dry run: no devices)
 
 
 def test_bench_under_torchrun_world2():

@@ -180,6 +180,20 @@ def test_linear_attention_core_fwd_bwd(b, c, heads, n):
     assert (y_train - y_fused).abs().max().item() < 1e-5 * max(1.0, y_train.abs().max().item())
 
 
+def test_linear_attention_core_preconditions():
+    """the core hands raw pointers to the kernels: host tensors and non-fp32 tensors are refused like every other op
+    (PN2/utils.hpp:7-18 CHECK_CUDA / CHECK_IS_FLOAT), instead of a fault or reinterpreted halves"""
+    from p2p_bridge_amd.pvcnn_unet import _LinearAttentionCore
+
+    with pytest.raises(RuntimeError, match="CUDA"):
+        _LinearAttentionCore.apply(torch.randn(1, 96, 64), 4)
+    with pytest.raises(RuntimeError, match="float"):
+        _LinearAttentionCore.apply(torch.randn(1, 96, 64, device="cuda").half(), 4)
+    q = torch.randn(1, 96, 64, device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="float"):
+        _LinearAttentionCore.apply(q, 4).backward(torch.ones(1, 32, 64, device="cuda", dtype=torch.float64))
+
+
 def test_install_dropin_reference_names():
     """install_dropin() registers the five extension modules under the names the reference's Python imports
     (SURVEY 8b), including `_pvcnn_backend` with FPS called `furthest_point_sampling`

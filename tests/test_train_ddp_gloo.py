@@ -77,8 +77,13 @@ def _ddp_worker(rank, world, port, out):
     dist.all_gather(other, flat)
     assert all(torch.equal(o, flat) for o in other)
     assert any(not torch.equal(a, b) for a, b in zip(after, before))
+    # the N-rank evidence of `python -m p2p_bridge_amd.train --gpus N`'s final line (collectives: every rank calls them)
+    from p2p_bridge_amd import sharding
+
+    share = T.allreduce_share(cfg, model, iter([{k: v[lo:hi] for k, v in batch(8, 64, seed=20 + i).items()} for i in range(9)]))
+    ev = sharding.rank_evidence(0.1 * (rank + 1), 10.0, None)
     if rank == 0:
-        torch.save({"grads": grads, "summed_loss": summed}, out)
+        torch.save({"grads": grads, "summed_loss": summed, "share": share, "evidence": ev}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,6 +105,10 @@ def test_ddp_world2_grads_equal_single_rank(tmp_path):
     for k, p in model.model.named_parameters():
         assert torch.allclose(got["grads"][k], p.grad, rtol=1e-5, atol=1e-7), k
     assert got["summed_loss"].item() > 0
+    assert got["share"] is not None and 0.0 <= got["share"] <= 1.0
+    rk = got["evidence"]["per_rank"]
+    assert [r["rank"] for r in rk] == [0, 1] and rk[0]["pid"] != rk[1]["pid"] and rk[1]["seconds"] == 0.2
+    assert rk[0]["value"] == 100.0 and got["evidence"]["rccl_version"] is None  # (gloo on CPU)
 
 
 def test_train_step_order_and_checkpoint(tmp_path):
@@ -124,6 +133,37 @@ def test_train_step_order_and_checkpoint(tmp_path):
     opt, _ = T.load_optim_sched(cfg, model, ck)
     assert isinstance(opt, torch.optim.AdamW) and opt.param_groups[0]["lr"] == 3e-4
     assert opt.state_dict()["state"], "optimizer state restored from the checkpoint"
+    # resume (models/model_loader.py:114-165 + train.py:94-105): weights + EMA + optimiser state + step from the checkpoint;
+    # the continued run logs steps 5, 6 and moves the weights on from the checkpoint's
+    logged = []
+    T.train(cfg2, fresh, (batch(4, 64, seed=50 + s) for s in range(100)), steps=2, log=logged.append, align=False, ckpt=ck)
+    assert [d["step"] for d in logged] == [5, 6] and int(fresh.ema.step.item()) == 6
+    assert any(not torch.equal(a, b) for a, b in zip(fresh.model.parameters(), model.model.parameters()))
+    # restart: network only, step 0
+    cfg3, again = make()
+    product.load_checkpoint(again, ck, restart=True)
+    logged = []
+    T.train(cfg3, again, (batch(4, 64, seed=60 + s) for s in range(100)), steps=1, log=logged.append, align=False, ckpt=ck,
+            restart=True)
+    assert [d["step"] for d in logged] == [0]
+
+
+def test_failing_evaluation_does_not_stop_training():
+    """train.py:193-199: the in-training evaluation runs under try / except on rank 0 -- an exception there is logged and
+    the step loop goes on (otherwise the other ranks would hang in the next gradient all-reduce)"""
+    from p2p_bridge_amd import train as T
+
+    cfg, model = make({"viz_interval": 2})
+    logged = []
+
+    def bad_eval(m, step):
+        raise RuntimeError("boom at %d" % step)
+
+    hist = T.train(cfg, model, (batch(4, 64, seed=s) for s in range(100)), steps=4, log=logged.append, align=False,
+                   evaluate=bad_eval)
+    assert len(hist) == 4
+    errs = [d for d in logged if "evaluation_error" in d]
+    assert len(errs) == 2 and "boom" in errs[0]["evaluation_error"]
 
 
 def test_get_data_batch_and_align_hook():
