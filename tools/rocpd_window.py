@@ -6,10 +6,12 @@ import sqlite3
 import sys
 
 
-def main(path, out=None, top=45, tail=1, T=30):
+def main(path, out=None, top=45, tail=1, T=30, marker="fps_kernel<512, 16"):
+    """marker: a kernel launched exactly once per network evaluation (PVDS at 8192 points: the level-0 FPS instance;
+    PVDL at 50000 points: `fps_grid_kernel`)"""
     cur = sqlite3.connect(path).cursor()
-    fps = [r for r in cur.execute("select start,end from kernels where name like '%fps_kernel<512, 16%' order by start")]
-    tail = int(tail)
+    fps = [r for r in cur.execute("select start,end from kernels where name like ? order by start", (f"%{marker}%",))]
+    tail, T, top = int(tail), int(T), int(top)
     n = len(fps) - tail - T
     t0 = fps[n][0]
     t1 = fps[n + T - 1][0] + (fps[n + T - 1][0] - fps[n + T - 2][0])  # (the roofline launches follow the last evaluation)
@@ -28,4 +30,4 @@ def main(path, out=None, top=45, tail=1, T=30):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, *sys.argv[3:])
