@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the bf16x6 comparison leg (profiling runs)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the config-3 training-step leg")
     ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL over xGMI); gloo only with --dry-run")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only, no GPU work (CPU self-test of the N-rank path)")
@@ -342,12 +343,62 @@ def main():
             61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval
         if world == 1 and "P2PB_CONV_MATH" not in os.environ and not args.no_alt_math:
             res["alt_math"] = alt_math_leg(cfg, sd, x_start, args)
+        if world == 1 and not args.no_train_step:
+            del model  # (free the sampler's graph pool first)
+            res["train_step"] = train_step_leg()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, args.points, args.T)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def train_step_leg(steps=8, warmup=4, B=8, N=2048):
+    """NOT `value`: BASELINE config 3's per-GPU training step (PVDS_PUNet, 8 patches x 2048 points = global batch 64 over
+    8 GPUs, MSE bridge loss, grad clip 1.0, AdamW) on this one GPU, eager, the reference's order of operations
+    (train.py:107-143; the auction alignment of the data loader is left out: it is timed in profiles/*_metrics_timing.txt).
+    dense FLOPs of a step = 3 x forward (forward, data gradient, weight gradient) = 3 x 61.35 GFLOP x N / 8192 per patch
+    (SURVEY 8d); the forward runs in fused.conv_math(), the data-gradient pass in bf16x6, the weight-gradient GEMMs in
+    P2PB_TRAIN_MATH (bf16x3)."""
+    import copy
+
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.synthetic import synthetic_patches
+
+    cfg = copy.deepcopy(PVDS)
+    cfg["data"]["npoints"] = N
+    torch.manual_seed(0)
+    model = product.build_model(cfg, device="cuda")
+    model.train()
+    params = list(model.model.parameters())
+    opt = torch.optim.AdamW(params, lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-5)
+    x1, x0 = synthetic_patches(B, N, seed=0)
+    x1, x0 = x1.cuda(), x0.cuda()
+
+    def step():
+        opt.zero_grad()
+        loss = model(x0, x1)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        return loss
+
+    for _ in range(warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    flop = 3.0 * 61.35e9 * N / 8192.0 * B
+    return {"workload": f"PVDS_PUNet training step, {B} patches x {N} points per GPU (BASELINE configs[2] = global batch 64 on 8 GPUs), "
+                        "mse bridge loss, clip 1.0, AdamW; eager, hand-written dense forward / backward kernels",
+            "ms_per_step": round(dt * 1e3, 2), "patches_per_s": round(B / dt, 1), "points_per_s": round(B * N / dt, 1),
+            "dense_tflops": round(flop / dt / 1e12, 2), "frac_of_f16x3_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3), 4),
+            "frac_of_bf16x6_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6), 4), "steps": steps, "warmup": warmup,
+            "final_loss": round(float(loss), 5)}
 
 
 def alt_math_leg(cfg, sd, x_start, args):
