@@ -180,8 +180,11 @@ def gemm_roofline(model, B, P, reps=10):
     try:
         vals = {}
         pingpong = split and fused.conv_math() == "f16x3" and os.environ.get("P2PB_PW_PP", "1") != "0" and P % 256 == 0 and B * (P // 128) * (co // 256) >= 1024
-        names = ([f"r03_pmc_pw_pingpong_512_1024_pool.csv"] if pingpong else []) + [f"{t}_pmc_pw_split_512_1024_pool.csv" for t in ("r02f", "r02", "r01")]
-        pmc = next(q for q in (os.path.join(ROOT, "profiles", n) for n in names) if os.path.exists(q))
+        import glob
+
+        cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_pw_pingpong_512_1024_pool.csv")), reverse=True) if pingpong else [])
+        cands += [os.path.join(ROOT, "profiles", f"{t}_pmc_pw_split_512_1024_pool.csv") for t in ("r02f", "r02", "r01")]
+        pmc = next(q for q in cands if os.path.exists(q))  # (newest round's PMC passes of the kernel this launch runs)
         for line in open(pmc):
             k, v = line.split(",")[:2]
             if k in ("FETCH_SIZE", "WRITE_SIZE"):
