@@ -180,12 +180,16 @@ int p2pb_chamfer_backward(int b, int n, int m, const float *xyz1, const float *x
 
 /* PyTorchEMD: replaces ApproxMatchForward / MatchCostForward / MatchCostBackward
  * (metrics/PyTorchEMD/cuda/emd_kernel.cu:177,264,377; kernels :33,:211,:300,:347).
- *   xyz1 f32[b,n,3], xyz2 f32[b,m,3] -> match f32[b,m,n]; temp = p2pb_approxmatch_temp_floats(b,n,m) floats of scratch:
- *   the reference's 2(n+m) per cloud (emd_kernel.cu:34) plus the partial sums of the chunked launches used when the
- *   batch alone cannot fill the chip */
+ *   xyz1 f32[b,n,3], xyz2 f32[b,m,3] -> match f32[b,m,n]; temp = the reference's scratch, 2(n+m) floats per cloud
+ *   (emd_kernel.cu:34). p2pb_approxmatch_temp_floats(b,n,m) = that plus the partial sums of the chunked launches the _ws
+ *   entry point uses when the batch alone cannot fill the chip */
 size_t p2pb_approxmatch_temp_floats(int b, int n, int m);
 int p2pb_approxmatch_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
                              float *temp, void *stream);
+/* explicit scratch size: temp_floats >= p2pb_approxmatch_temp_floats() enables the chunked kernels (small batches of large
+ * clouds); the plain entry point above keeps the reference's contract (temp = 2 (n + m) b floats, emd_kernel.cu:34) */
+int p2pb_approxmatch_forward_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                                size_t temp_floats, void *stream);
 int p2pb_matchcost_forward(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
                            float *cost, void *stream);
 int p2pb_matchcost_backward(int b, int n, int m, const float *grad_cost, const float *xyz1, const float *xyz2,
@@ -264,6 +268,20 @@ int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, const float 
                                    const float *in_shift, int in_swish, const float *in_sub,
                                    const unsigned char *alist, const int *acount, float *out, float *stats_part,
                                    void *stream);
+/* Pre-split operand grids ("S format", round 3; conv3d.hip PreStage). The split kernels' staging phase -- load, folded
+ * norm + Swish, fp16-pair split, LDS write, repeated for every brick halo and channel block that touches a voxel -- can be
+ * done ONCE per element by the operand's producer: S = u32x4[b][r^3][ceil(cin/16)][2 planes][2 khalf], 8 fp16 per entry
+ * (h0 | h1 of 4 x value), 4 bytes per (voxel, channel) with the channels zero-padded to a multiple of 16. The f16x3
+ * kernels then stage with LDS-DMA alone. Bit-identical outputs. Producers: p2pb_avg_voxelize_cl_gather_split (a first
+ * convolution's operand straight from the voxeliser) and p2pb_conv3d_presplit (y f32[b,nvox,c] voxel-major -> S, applying
+ * swish?(y*in_scale + in_shift) - in_sub; in_scale == NULL: the plain split). Consumers: p2pb_conv3d_k3_forward_fx /
+ * _sparse_fx with flags bit 4 (16; needs bits 2 and 3, no in_scale / in_sub / in_fold / out_acc) and
+ * p2pb_conv3d_k3_forward_compact_pre. f16x3 arithmetic only (P2PB_EINVAL under bf16x6). */
+int p2pb_conv3d_presplit(int b, int c, long nvox, const float *y, const float *in_scale, const float *in_shift,
+                         int in_swish, const float *in_sub, void *out_split, void *stream);
+int p2pb_conv3d_k3_forward_compact_pre(int b, int cin, int cout, int r, const void *in_split, const void *wt_split,
+                                       const float *bias, const float *out_class, const unsigned char *alist,
+                                       const int *acount, float *out, float *stats_part, void *stream);
 /* a[b,cin] = xf(prev_bias[cin]) (the operand's far-field constant) and k_out[b,27,cout] = conv(a) + bias per
  * boundary class, for p2pb_conv3d_k3_forward_ex */
 int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
@@ -377,6 +395,10 @@ int p2pb_avg_voxelize_cl_forward(int b, int c, int n, int r, const int *coords, 
 int p2pb_voxel_sort(int b, int n, int r, const int *coords, int *ind, int *cnt, void *ws, void *stream);
 int p2pb_avg_voxelize_cl_gather(int b, int c, int n, int r, const float *feat, const int *cnt, const void *ws,
                                 float *out, float *feat_t, void *stream);
+/* the same straight into the pre-split operand format of the voxel convolutions (S format above):
+ * out_split = b * r^3 * ceil(c/16) * 64 bytes */
+int p2pb_avg_voxelize_cl_gather_split(int b, int c, int n, int r, const float *feat, const int *cnt, const void *ws,
+                                      void *out_split, float *feat_t, void *stream);
 int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float *coords, const float *grid,
                                         const float *aff_a, const float *aff_b, const float *add /* f32[b,c,n] or NULL */,
                                         const float *add_scale, const float *add_shift, float *outs, void *stream);

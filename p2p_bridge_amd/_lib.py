@@ -14,7 +14,8 @@ LIB_PATH = os.environ.get("P2PB_LIB_PATH") or os.path.join(_HERE, "libp2pb_hip.s
 # every symbol include/p2pb_hip.h declares (tests/test_abi.py checks the two lists agree)
 SYMBOLS = [
     "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_get_split_terms", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
-    "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_trilinear_devoxelize_forward",
+    "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_avg_voxelize_cl_gather_split", "p2pb_conv3d_presplit",
+    "p2pb_conv3d_k3_forward_compact_pre", "p2pb_trilinear_devoxelize_forward",
     "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats",
     "p2pb_gather_features_forward", "p2pb_gather_features_backward", "p2pb_furthest_point_sampling",
     "p2pb_fps_coop_ws_bytes", "p2pb_furthest_point_sampling_coop", "p2pb_point_face_dist", "p2pb_face_point_dist", "p2pb_knn_points_ws_bytes", "p2pb_knn_points", "p2pb_three_nn_interpolate_forward", "p2pb_three_nn_interpolate_backward", "p2pb_three_nn", "p2pb_three_nn_cells", "p2pb_three_nn_cells_ws_bytes",
@@ -28,7 +29,7 @@ SYMBOLS = [
     "p2pb_pointwise_stats_floats", "p2pb_pointwise_conv_forward", "p2pb_affine_act", "p2pb_affine_act_max",
     "p2pb_pointwise_split_packed_bytes", "p2pb_pointwise_pack_weights_split", "p2pb_pointwise_pool_supported", "p2pb_pointwise_minmax_floats", "p2pb_pointwise_conv_pool_forward",
     "p2pb_minmax_act", "p2pb_linear_attention_forward", "p2pb_linear_attention_backward",
-    "p2pb_approxmatch_temp_floats", "p2pb_chamfer_ws_bytes", "p2pb_chamfer_forward_ws", "p2pb_radius_count", "p2pb_radius_fill", "p2pb_merge_accumulate", "p2pb_merge_finish", "p2pb_gn_affine_params_ex", "p2pb_norm_act_backward", "p2pb_conv3d_k3_wgrad_ws_floats", "p2pb_conv3d_k3_wgrad", "p2pb_pointwise_wgrad_ws_floats", "p2pb_pointwise_wgrad",
+    "p2pb_approxmatch_temp_floats", "p2pb_approxmatch_forward_ws", "p2pb_chamfer_ws_bytes", "p2pb_chamfer_forward_ws", "p2pb_radius_count", "p2pb_radius_fill", "p2pb_merge_accumulate", "p2pb_merge_finish", "p2pb_gn_affine_params_ex", "p2pb_norm_act_backward", "p2pb_conv3d_k3_wgrad_ws_floats", "p2pb_conv3d_k3_wgrad", "p2pb_pointwise_wgrad_ws_floats", "p2pb_pointwise_wgrad",
     "p2pb_gn_fold_params", "p2pb_conv3d_k3_forward_fx", "p2pb_conv3d_k3_forward_sparse_fx",
     "p2pb_conv3d_k3_forward_compact_fx", "p2pb_conv3d_k3_far_field_fx", "p2pb_se_gate_affine_fx",
     "p2pb_pointwise_conv_forward_fx", "p2pb_pointwise_conv_pool_forward_fx", "p2pb_minmax_act_fx", "p2pb_group_sub_fx",

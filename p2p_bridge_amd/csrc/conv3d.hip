@@ -511,13 +511,139 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
   }
 }
 
+// The tap loop of the PRE = true kernels (f16x3): split_taps' B schedule, with the A fragments (weights) in a ring of
+// three tap slots loaded TWO taps ahead and carried across stages -- a[t % 3] is tap t's; on entry a[0], a[1] hold taps
+// 0, 1 of this stage, on exit those of the next one (has_next). Memory returns are in order per wave, so the first A load
+// issued behind the LDS-DMA burst of the next stage cannot return before that burst has landed: with two taps of weights
+// already in registers the burst has two taps of MFMAs (>= 768 cycles) to do so. Weights come through a buffer descriptor:
+// per-lane byte offset wv (one register) + a scalar offset per (stage, tap, plane) -- no 64-bit address per tap.
+__device__ __forceinline__ u32x4 conv_wload(__amdgpu_buffer_rsrc_t rs, unsigned wv, unsigned so) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wv, so, 0));
+}
+#ifndef CONV_PRE_AD
+#define CONV_PRE_AD 2  // taps of weight prefetch; the ring has CONV_PRE_AD + 1 slots, which must divide 27 (2 or 8)
+#endif
+static_assert(27 % (CONV_PRE_AD + 1) == 0, "the ring position of tap 0 must be the same in every stage");
+template <int NT, int HH, int HW, int PLANE>
+__device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, __amdgpu_buffer_rsrc_t rsw,
+                                               unsigned wv, unsigned sbase, unsigned stage_bytes, unsigned tap_bytes,
+                                               unsigned plane_bytes, bool has_next, const int (&nbase)[NT], int khalf,
+                                               u32x4 (&a)[CONV_PRE_AD + 1][2]) {
+  u32x4 bf[2][NT];
+  auto load_b = [&](int s, int toff) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+  };
+  load_b(1, 0);
+#pragma unroll
+  for (int tap = 0; tap < CONV_NTAPS; ++tap) {
+    const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+    const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
+    constexpr int AD = CONV_PRE_AD;
+    const int cur = tap % (AD + 1), nx2 = (tap + AD) % (AD + 1);
+#ifndef CONV_PRE_NOA  // (timing experiment: no weight stream in the loop)
+    if (tap + AD < CONV_NTAPS) {
+      const unsigned so = sbase + (unsigned)(tap + AD) * tap_bytes;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a[nx2][s] = conv_wload(rsw, wv, so + s * plane_bytes);
+    } else if (has_next) {
+      const unsigned so = sbase + stage_bytes + (unsigned)(tap + AD - CONV_NTAPS) * tap_bytes;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a[nx2][s] = conv_wload(rsw, wv, so + s * plane_bytes);
+    }
+#endif
+#ifdef CONV_PRE_NOB  // (timing experiment: the B fragments of tap 0 for all taps)
+    if (tap == 0)
+#endif
+    load_b(0, toff);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], bf[1][n], acc[n]);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef CONV_PRE_NOB
+    if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][1], bf[0][n], acc[n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], bf[0][n], acc[n]);
+  }
+}
+
+// ---- pre-split operand grids ("S format", round 3) ---------------------------------------------------------------
+// The staging phase of the split kernels -- load fp32, folded norm + Swish, fp16-pair split, LDS write, redone for every
+// brick whose 6x10x10 halo holds the voxel (2.34 x) and for every output-channel block -- is half of their time on the
+// f16x3 arithmetic. PRE = true kernels take the operand ALREADY transformed and split, in the exact byte layout of the LDS
+// tile, and bring a stage into LDS with LDS-DMA (buffer_load_dwordx4 ... lds: no registers, no VALU, no ds_write):
+//     S[b][voxel][chunk16][plane 2][khalf 2] of 16 bytes = 8 fp16  (h0 | h1 of 4 x value, channels chunk*16 + khalf*8 + i)
+// i.e. 4 bytes per (voxel, channel) like the fp32 grid it replaces, channel count padded to a multiple of 16. Producers:
+// the voxeliser for a first convolution (voxelize.hip vox_gather_cl_split_kernel: no extra pass), conv3d_presplit_kernel for
+// a second one (one elementwise pass over y1 once its GroupNorm statistics are folded). Same transform, same split, same
+// products in the same order as the staging code below: outputs are bit-identical to the PRE = false kernels.
+// The stage loop is double-buffered (2 x 37.5 KB, two workgroups per CU) with ONE barrier per stage: wait for my DMA of
+// stage k, barrier, issue the DMA of stage k + 1 into the other buffer, 27 taps on buffer k. Halo slots outside the grid
+// carry an out-of-range buffer offset: the hardware's zero lands in LDS.
+typedef int conv_i32x4 __attribute__((ext_vector_type(4)));
+template <int R, int HD, int HH, int HW>
+struct PreStage {
+  static constexpr int PLANE = HD * HH * HW, NF = 4 * PLANE, NJ = (NF + 255) / 256;
+  unsigned off[NJ];  // byte offset of (voxel, stage 0, quarter) from the sample's base; 0x80000000: outside the grid
+  __device__ __forceinline__ void init(int tid, int d0, int h0, int w0, int nchunk) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int f = tid + j * 256;
+      const int q = f / PLANE, e = f % PLANE;
+      const int dz = e / (HH * HW), hy = (e / HW) % HH, wx = e % HW;
+      const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = w0 - 1 + wx;
+      const bool ok = f < NF && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
+      off[j] = ok ? ((unsigned)((d * R + h) * R + w) * (unsigned)(nchunk * 4) + (unsigned)q) * 16u : 0x80000000u;
+    }
+  }
+  // stage `chunk` of the sample behind rs -> buf[0 .. NF); every wave issues its 64-slot runs (lane l lands at run + l).
+  // Issued as inline assembly ON PURPOSE: the compiler's wait-count pass assumes that any ds_read may alias the
+  // destination of an LDS-DMA it knows of and puts `s_waitcnt vmcnt(0)` in front of the first fragment read after the
+  // burst -- which serialises the DMA of stage k + 1 with the taps of stage k (separate __shared__ objects do not help
+  // with this compiler). The hand-written form is invisible to that pass; the kernel orders it itself: the builtin
+  // s_waitcnt vmcnt(0) + barrier at the top of the next stage. (The pass's own waits for the weight loads it DOES know of
+  // can only be stricter than needed: per-wave memory returns are in order.)
+  __device__ __forceinline__ void issue(conv_i32x4 rs, int chunk, u32x4 *buf, int tid) const {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)buf);
+    const unsigned so = (unsigned)chunk * 64u;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int f0 = j * 256 + wave * 64;  // wave-uniform
+      if (f0 < NF) {
+        const unsigned m0v = base + (unsigned)f0 * 16u;
+        if (f0 + lane < NF)
+          asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                       :
+                       : "v"(off[j]), "s"(rs), "s"(so), "s"(m0v)
+                       : "memory", "m0");
+      }
+    }
+  }
+};
+// buffer descriptor words for the inline-assembly DMA above (what __builtin_amdgcn_make_buffer_rsrc(p, 0, bytes, 0x00020000)
+// builds), forced into scalar registers
+__device__ __forceinline__ conv_i32x4 conv_make_rsrc(const void *p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  conv_i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
 // FX: the sampler path's statistics plumbing (operand norm folded here from accumulators / output statistics added to
 // accumulators, common.h) is compiled in -- a separate instantiation (voxel-major form only), so that the plain form
 // carries neither the two argument structs nor the table
 #ifndef CONV_F16_WAVES
 #define CONV_F16_WAVES 2  // (waves per SIMD the f16x3 forms are compiled for; their two-plane tile would fit three workgroups)
 #endif
-template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX, int TERMS>
+template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX, int TERMS, bool PRE = false>
 __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
@@ -539,8 +665,13 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];
   constexpr int BH = R / G::TH, BW = R / G::TW;
   constexpr int R3 = R * R * R;
-  // tile[split][khalf][voxel] : 8 bf16 (16 bytes) = channels khalf*8 .. khalf*8+7 of the staged chunk
+  // tile[split][khalf][voxel] : 8 bf16 (16 bytes) = channels khalf*8 .. khalf*8+7 of the staged chunk (PRE: two buffers)
+  static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF && CL && !FX), "pre-split operands: f16x3, voxel-major, no fold");
   __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
+  // (PRE: the second stage buffer is its OWN object, and the stage loop is unrolled by two with the roles fixed, so that
+  //  the compiler can tell the LDS-DMA into one buffer from the fragment reads of the other -- with one array it waits
+  //  vmcnt(0) for the DMA burst of stage k + 1 in front of the first ds_read of stage k)
+  __shared__ u32x4 tile2[PRE ? split_planes(TERMS) * 2 * PLANE : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -604,6 +735,43 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     nbase[s] = ((td + jd) * HH + (th + jh)) * HW + jw;
   }
 
+  f32x16 acc[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+
+  if constexpr (PRE) {
+    // `in` = the pre-split operand grid (S format): LDS-DMA stages, two buffers, one barrier per stage
+    PreStage<R, HD, HH, HW> ps;
+    ps.init(tid, d0, h0, w0, nchunk);
+    const conv_i32x4 sg = conv_make_rsrc((const u32x4 *)in + (size_t)b * R3 * nchunk * 4, (unsigned)(R3 * nchunk * 64));
+    ps.issue(sg, 0, tile, tid);
+    // weights: [tap][stage][plane 3][khalf 2][cout_pad] of 16 bytes
+    const unsigned stage_bytes = 6u * cout_pad * 16u, tap_bytes = (unsigned)nchunk * stage_bytes, plane_bytes = 2u * cout_pad * 16u;
+    auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, 27 * (int)tap_bytes, 0x00020000);
+    const unsigned wv = (unsigned)(khalf * cout_pad + co0 + l31) * 16u;
+    u32x4 aring[CONV_PRE_AD + 1][2];
+#pragma unroll
+    for (int t = 0; t < CONV_PRE_AD; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
+    auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
+#ifndef CONV_PRE_NOBAR  // (timing experiment: stages not ordered)
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): my share of stage k has landed (and the weights of its first taps)
+      __syncthreads();                     // everyone's has; the other buffer is no longer read
+#endif
+#ifndef CONV_PRE_NODMA  // (timing experiment: no operand stream)
+      if (k + 1 < nchunk) ps.issue(sg, k + 1, nxt, tid);
+#endif
+      split_taps_pre<NT, HH, HW, PLANE>(acc, cur, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
+                                        k + 1 < nchunk, nbase, khalf, aring);
+    };
+    for (int k = 0; k < nchunk; k += 2) {
+      stage(k, tile, tile2);
+      if (k + 1 < nchunk) stage(k + 1, tile2, tile);
+    }
+  } else {
   constexpr int NP = (PLANE + 255) / 256;
   int soff[NP];
 #pragma unroll
@@ -614,12 +782,6 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     const bool ok = e < PLANE && (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
     soff[j] = ok ? (d * R + h) * R + w : -1;
   }
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int s = 0; s < NT; ++s)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
 
   const float *inb = in + (size_t)b * cin * R3;
   float stg[CONV_SCK][NP];
@@ -715,6 +877,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
     split_taps<NT, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
   }
+  }  // !PRE
   if constexpr (TERMS == SPLIT_F16X3) {  // 1 / (S_x S_w): a power of two stored behind the pack
     const float oscale = ((const float *)((const char *)wt + conv_split_trailer_bytes(nchunk, cout_pad)))[1];
 #pragma unroll
@@ -970,7 +1133,7 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
                              const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                              const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count,
                              float *out, float *stats_part, bool cl, hipStream_t s, const GnFold &fold = GnFold(),
-                             const GnAcc &gacc = GnAcc()) {
+                             const GnAcc &gacc = GnAcc(), bool pre = false) {
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   if ((in_scale || fold.group) && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
@@ -979,15 +1142,29 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
   const bool fx = fold.group != nullptr || gacc.group != nullptr;
   if (fx && !cl) return P2PB_EINVAL;  // (the statistics plumbing exists in the voxel-major form only)
 #if CONV_TU != 6
-  if (p2pb_g_split_terms == SPLIT_BF16X6)
+  if (p2pb_g_split_terms == SPLIT_BF16X6) {
+    if (pre) return P2PB_EINVAL;  // (the S format is the f16x3 arithmetic's)
     return conv3d_tu6_split(R, MT, b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero,
                             brick_list, brick_count, out, stats_part, cl, s, fold, gacc);
+  }
 #endif
 #define LAUNCHT(XF, CL, FXV, TM)                                                                                      \
   hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk,   \
                      cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list,     \
                      brick_count, out, stats_part, fold, gacc)
 #define LAUNCH(XF, CL, FXV) LAUNCHT(XF, CL, FXV, CONV_TERMS)
+  if (pre) {  // `in` is the pre-split operand grid (S format): f16x3, voxel-major, transform already applied
+#if CONV_TU != 6
+    if constexpr (R >= 8) {
+      if (!cl || in_scale || in_sub || fold.group || gacc.group) return P2PB_EINVAL;
+      hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, false, true, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s,
+                         cin, cout, nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0,
+                         brick_list, brick_count, out, stats_part, fold, gacc);
+      return p2pb_launch_status();
+    }
+#endif
+    return P2PB_EINVAL;
+  }
   if (in_scale != nullptr || fold.group != nullptr) {
     if (fx) LAUNCH(true, true, true);
     else if (cl) LAUNCH(true, true, false);
@@ -1250,6 +1427,8 @@ extern "C" int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const 
   const int skip = flags & 1;
   const bool compact = (flags & 2) != 0;
   const bool cl = (flags & 8) != 0;  // voxel-major tensors in[b,r,r,r,cin], out[b,r,r,r,cout]
+  const bool pre = (flags & 16) != 0;  // `in` is the pre-split operand grid (p2pb_conv3d_presplit / ..._cl_gather_split)
+  if (pre && (flags & 12) != 12) return P2PB_EINVAL;
   // 64 output channels per workgroup unless that leaves fewer than 2 workgroups per CU (small grids)
   const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= 512;
   if (flags & 4) {  // wt_packed is the split (3 x bf16) pack; always the compact tiling (same results, same slots)
@@ -1259,9 +1438,9 @@ extern "C" int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const 
     const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= wide_min;
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc)              \
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc, pre)         \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc)
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc, pre)
     switch (r) {
       case 32: GOS(32);
       case 16: GOS(16);
@@ -1320,6 +1499,8 @@ extern "C" int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r,
   hipStream_t s = (hipStream_t)stream;
   const int total = conv_bricks(r) * b;
   const bool cl = (flags & 8) != 0;
+  const bool pre = (flags & 16) != 0;  // `in` is the pre-split operand grid
+  if (pre && (flags & 12) != 12) return P2PB_EINVAL;
 #define FILL(RR, CL)                                                                                          \
   hipLaunchKernelGGL((conv3d_fill_kernel<RR, CL>), dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list, \
                      inactive_count, out, stats_part, gacc)
@@ -1335,9 +1516,9 @@ extern "C" int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r,
   if (flags & 4) {
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc)        \
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc, pre)   \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc)
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc, pre)
     if (r == 32) { GOS(32); }
     GOS(16);
 #undef GOS
@@ -1462,7 +1643,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
 }
 #endif
 
-template <int R, int WM, bool XF, bool FX, int TERMS>  // FX, TERMS: see conv3d_k3_split_kernel
+template <int R, int WM, bool XF, bool FX, int TERMS, bool PRE = false>  // FX, TERMS, PRE: see conv3d_k3_split_kernel
 __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                                 const float *__restrict__ in,
                                                                 const unsigned short *__restrict__ wt,
@@ -1481,7 +1662,9 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   constexpr int BH = R / G::TH, BW = R / G::TW, BD = R / G::TD, NBRICK = BD * BH * BW;
   constexpr int R3 = R * R * R;
   constexpr int WN = 4 / WM;
+  static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF && !FX), "pre-split operands: f16x3, no fold");
   __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
+  __shared__ u32x4 tile2[PRE ? split_planes(TERMS) * 2 * PLANE : 1];  // (its own object: see the split kernel)
   __shared__ unsigned char lst[256];
   __shared__ int ncls[27];
   __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
@@ -1581,6 +1764,34 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
+    if constexpr (PRE) {  // `in` = the pre-split operand grid: LDS-DMA stages, two buffers, one barrier per stage
+      PreStage<R, HD, HH, HW> ps;
+      ps.init(tid, d0, h0, w0, nchunk);
+      const conv_i32x4 sg = conv_make_rsrc((const u32x4 *)in + (size_t)b * R3 * nchunk * 4, (unsigned)(R3 * nchunk * 64));
+      ps.issue(sg, 0, tile, tid);
+      const unsigned stage_bytes = 6u * cout_pad * 16u, tap_bytes = (unsigned)nchunk * stage_bytes, plane_bytes = 2u * cout_pad * 16u;
+      auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, 27 * (int)tap_bytes, 0x00020000);
+      const unsigned wv = (unsigned)(khalf * cout_pad + co0 + l31) * 16u;
+      u32x4 aring[CONV_PRE_AD + 1][2];
+      if (NTC > 0) {
+#pragma unroll
+        for (int t = 0; t < CONV_PRE_AD; ++t)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
+      }
+      auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+        __syncthreads();
+        if (k + 1 < nchunk) ps.issue(sg, k + 1, nxt, tid);
+        if (NTC > 0)
+          split_taps_pre<NA, HH, HW, PLANE>(acc, cur, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
+                                            k + 1 < nchunk, nbase, khalf, aring);
+      };
+      for (int k = 0; k < nchunk; k += 2) {
+        stage(k, tile, tile2);
+        if (k + 1 < nchunk) stage(k + 1, tile2, tile);
+      }
+    } else {
     stage_load(0);
     for (int ci0 = 0; ci0 < cin; ci0 += CONV_SCK) {
       __syncthreads();
@@ -1633,6 +1844,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       const size_t wsplit_stride = (size_t)2 * cout_pad, wtap_stride = (size_t)nchunk * 3 * 2 * cout_pad;
       split_taps<NA, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
     }
+    }  // !PRE
     if (NTC == 0) return;
     if constexpr (TERMS == SPLIT_F16X3) {
       const float oscale = ((const float *)((const char *)wt + conv_split_trailer_bytes(nchunk, cout_pad)))[1];
@@ -1817,10 +2029,11 @@ int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const v
 static int conv_launch_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                                const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                                const float *in_sub, const unsigned char *alist, const int *acount, float *out,
-                               float *stats_part, hipStream_t s, const GnFold &fold, const GnAcc &gacc) {
+                               float *stats_part, hipStream_t s, const GnFold &fold, const GnAcc &gacc, bool pre = false) {
   const bool xf = in_scale != nullptr || fold.group != nullptr;
   if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
 #if CONV_TU != 6
+  if (pre && (p2pb_g_split_terms == SPLIT_BF16X6 || xf || in_sub || gacc.group)) return P2PB_EINVAL;
   if (p2pb_g_split_terms == SPLIT_BF16X6)
     return conv3d_tu6_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
                               acount, out, stats_part, s, fold, gacc);
@@ -1847,6 +2060,24 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
     if (xf) LAUNCH(RR, 2, true);                                 \
     else LAUNCH(RR, 2, false);                                   \
   }
+#if CONV_TU != 6
+#define GOPRE(RR)                                                                                                          \
+  do {                                                                                                                     \
+    if (wm1)                                                                                                               \
+      hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 1, false, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
+                         nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0, alist, acount, out, \
+                         stats_part, fold, gacc);                                                                          \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 2, false, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
+                         nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0, alist, acount, out, \
+                         stats_part, fold, gacc);                                                                          \
+  } while (0)
+  if (pre) {
+    if (r == 32) GOPRE(32); else if (r == 16) GOPRE(16); else GOPRE(8);
+    return p2pb_launch_status();
+  }
+#undef GOPRE
+#endif
   if (r == 32) { GO(32) } else if (r == 16) { GO(16) } else { GO(8) }
 #undef GO
 #undef LAUNCH
@@ -1886,6 +2117,89 @@ extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r
   const GnAcc gacc = gn_acc_arg(out_acc, cout);
   return conv_launch_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
                              acount, out, stats_part, (hipStream_t)stream, fold, gacc);
+}
+#endif
+
+#if CONV_TU != 6
+// the compact form on a pre-split operand grid (S format, see PreStage): in_split u32x4[b][r^3][ceil(cin/16)][4]
+extern "C" int p2pb_conv3d_k3_forward_compact_pre(int b, int cin, int cout, int r, const void *in_split,
+                                                  const void *wt_split, const float *bias, const float *out_class,
+                                                  const unsigned char *alist, const int *acount, float *out,
+                                                  float *stats_part, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !in_split || !alist || !acount || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
+  return conv_launch_compact(b, cin, cout, r, (const float *)in_split, wt_split, bias, out_class, nullptr, nullptr, 0,
+                             nullptr, alist, acount, out, stats_part, (hipStream_t)stream, GnFold(), GnAcc(), true);
+}
+
+// y f32[b][nvox][c] (voxel-major) -> S format u32x4[b][nvox][ceil(c/16)][2 planes][2 khalf]: the operand transform of
+// the split kernels' staging phase (folded norm + Swish - far-field value, then the fp16-pair split of 4 x value), once
+// per element.
+#define PRESPLIT_VT 128  // voxels per workgroup
+static __global__ __launch_bounds__(256) void conv3d_presplit_kernel(int c, int nchunk, int nvox, const float *__restrict__ y,
+                                                                     const float *__restrict__ in_scale,
+                                                                     const float *__restrict__ in_shift, int in_swish,
+                                                                     const float *__restrict__ in_sub,
+                                                                     u32x4 *__restrict__ out) {
+  // a thread keeps ONE group of 8 channels (its scale / shift / far-field value in registers) and walks the voxels of the
+  // workgroup's tile: 256 / ng voxels per pass, a voxel's row read and written by ng neighbouring lanes (coalesced)
+  const int b = blockIdx.y, ng = nchunk * 2, vpp = 256 / ng;
+  const int g = threadIdx.x % ng, vl = threadIdx.x / ng, c0 = g * 8;
+  if (vl >= vpp) return;
+  float sc[8], sh[8], sub[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = c0 + i;
+    const bool ok = ch < c && in_scale != nullptr;
+    sc[i] = ok ? in_scale[b * c + ch] : 1.0f;
+    sh[i] = ok ? in_shift[b * c + ch] : 0.0f;
+    sub[i] = (ok && in_sub) ? in_sub[b * c + ch] : 0.0f;
+  }
+  const int v0 = blockIdx.x * PRESPLIT_VT, v1 = min(v0 + PRESPLIT_VT, nvox);
+  const bool quad = (c & 3) == 0;
+  for (int v = v0 + vl; v < v1; v += vpp) {
+    const float *src = y + ((size_t)b * nvox + v) * c + c0;
+    float x[8];
+    if (quad) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (c0 + 4 * q < c) t = *(const f32x4 *)(src + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[4 * q + i] = t[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = c0 + i < c ? src[i] : 0.0f;
+    }
+    if (in_scale) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (c0 + i < c) x[i] = xf_apply(x[i], sc[i], sh[i], in_swish) - sub[i];
+    }
+    u32x4 p0, p1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned a0, a1, a2;
+      split_pair<SPLIT_F16X3>(x[2 * i], x[2 * i + 1], a0, a1, a2);
+      p0[i] = a0;
+      p1[i] = a1;
+    }
+    u32x4 *dst = out + (((size_t)b * nvox + v) * nchunk + (g >> 1)) * 4 + (g & 1);
+    dst[0] = p0;
+    dst[2] = p1;
+  }
+}
+
+// y f32[b, nvox, c] -> out_split (S format, b * nvox * ceil(c/16) * 64 bytes); in_scale / in_shift / in_sub f32[b,c] or NULL
+extern "C" int p2pb_conv3d_presplit(int b, int c, long nvox, const float *y, const float *in_scale, const float *in_shift,
+                                    int in_swish, const float *in_sub, void *out_split, void *stream) {
+  if (b <= 0 || c <= 0 || nvox <= 0 || nvox > 0x7fffffffL / 64 || !y || !out_split || (in_scale && !in_shift)) return P2PB_EINVAL;
+  const int nchunk = (c + CONV_SCK - 1) / CONV_SCK;
+  if (nchunk * 2 > 256) return P2PB_EINVAL;  // (<= 2048 channels)
+  const dim3 grid(cdiv(nvox, PRESPLIT_VT), b);
+  hipLaunchKernelGGL(conv3d_presplit_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, nchunk, (int)nvox, y, in_scale,
+                     in_shift, in_swish, in_sub, (u32x4 *)out_split);
+  return p2pb_launch_status();
 }
 #endif
 

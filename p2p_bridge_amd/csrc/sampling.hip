@@ -284,7 +284,7 @@ template <int THREADS, int PPT>
 static void fps_launch(int b, int n, int m, const float *coords, int *idx, hipStream_t s) {
   const size_t base = 2 * 16 * sizeof(u64);
   const size_t xyz = (size_t)3 * n * sizeof(float);
-  if (base + xyz <= 144 * 1024) {
+  if (base + xyz <= 160 * 1024) {  // (the whole LDS of a CU: 12500-point clouds, level 1 of BASELINE configs 4-5, fit)
     hipLaunchKernelGGL((fps_kernel<THREADS, PPT, true>), dim3(b), dim3(THREADS), base + xyz, s, n, m, coords, idx);
   } else {
     hipLaunchKernelGGL((fps_kernel<THREADS, PPT, false>), dim3(b), dim3(THREADS), base, s, n, m, coords, idx);

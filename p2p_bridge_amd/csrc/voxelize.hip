@@ -333,6 +333,56 @@ __global__ __launch_bounds__(256) void vox_gather_cl_occ_kernel(int c, int n, in
   }
 }
 
+// The grid straight in the pre-split operand format of the voxel convolutions (conv3d.hip "S format"): out
+// u32x4[b][r^3][ceil(c/16)][2 planes][2 khalf], the fp16 pair (h0 | h1) of 4 x mean for channels chunk*16 + khalf*8 + i --
+// 4 bytes per (voxel, channel) like the fp32 grid, channels padded with zeros to a multiple of 16. A thread owns 8
+// consecutive channels of one voxel; same means (ascending point order) as the kernels above, then the split the
+// convolution's staging phase would apply -- the first convolution of a PVConv then stages with LDS-DMA alone.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void vox_gather_cl_split_kernel(int c, int nchunk, int n, int r3,
+                                                                  const int *__restrict__ cnt, const int *__restrict__ cur,
+                                                                  const int *__restrict__ slist,
+                                                                  const float *__restrict__ feat_t, u32x4 *__restrict__ out) {
+  const int b = blockIdx.y, ng = nchunk * 2;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)r3 * ng) return;
+  const int v = (int)(e / ng), g = (int)(e % ng), ch = g * 8;
+  const int cn = cnt[(size_t)b * r3 + v];
+  float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  if (cn > 0 && ch < c) {
+    const int *seg = slist + (size_t)b * n + (cur[(size_t)b * r3 + v] - cn);
+    const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
+    const float *f = feat_t + (size_t)b * n * c + ch;
+    for (int q = 0; q < cn; ++q) {
+      const float *fq = f + (size_t)seg[q] * c;
+      if (ALIGNED) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (ch + 4 * h < c) {
+            const vox_f32x4 x = *(const vox_f32x4 *)(fq + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[4 * h + i] += x[i] * div;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (ch + i < c) acc[i] += fq[i] * div;
+      }
+    }
+  }
+  u32x4 p0, p1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    unsigned a0, a1, a2;
+    split_pair<SPLIT_F16X3>(acc[2 * i], acc[2 * i + 1], a0, a1, a2);
+    p0[i] = a0;
+    p1[i] = a1;
+  }
+  u32x4 *dst = out + (((size_t)b * r3 + v) * nchunk + (g >> 1)) * 4 + (g & 1);
+  dst[0] = p0;
+  dst[2] = p1;
+}
+
 // The coordinate-only half of the voxelisation (occupancy counts + per-voxel sorted point lists): it depends on
 // the voxel coordinates alone, so the sampler runs it once per (level, resolution) on the geometry stream and every
 // PVConv of that level reuses it. ws: p2pb_avg_voxelize_ws_bytes(b,n,r) bytes, consumed by ..._cl_gather.
@@ -386,6 +436,26 @@ extern "C" int p2pb_avg_voxelize_cl_gather(int b, int c, int n, int r, const flo
     hipLaunchKernelGGL(vox_gather_cl_all_kernel<true>, grid, dim3(256), 0, s, c, n, r3, cnt, cur, slist, feat_t, out);
   else
     hipLaunchKernelGGL(vox_gather_cl_all_kernel<false>, grid, dim3(256), 0, s, c, n, r3, cnt, cur, slist, feat_t, out);
+  return p2pb_launch_status();
+}
+
+// The feature half, straight into the pre-split operand format (S format) of the voxel convolutions:
+// out_split b * r^3 * ceil(c/16) * 64 bytes; feat_t f32[b, n, c] scratch
+extern "C" int p2pb_avg_voxelize_cl_gather_split(int b, int c, int n, int r, const float *feat, const int *cnt, const void *ws,
+                                                 void *out_split, float *feat_t, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || !ws || !feat_t || !out_split) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int r3 = r * r * r, nchunk = (c + 15) / 16;
+  const int *cur = (const int *)ws;
+  const int *slist = cur + (size_t)b * r3 + (size_t)b * n;
+  hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, feat, feat_t);
+  const dim3 grid((unsigned)cdiv((size_t)r3 * nchunk * 2, 256), b);
+  if ((c & 3) == 0)
+    hipLaunchKernelGGL(vox_gather_cl_split_kernel<true>, grid, dim3(256), 0, s, c, nchunk, n, r3, cnt, cur, slist, feat_t,
+                       (u32x4 *)out_split);
+  else
+    hipLaunchKernelGGL(vox_gather_cl_split_kernel<false>, grid, dim3(256), 0, s, c, nchunk, n, r3, cnt, cur, slist, feat_t,
+                       (u32x4 *)out_split);
   return p2pb_launch_status();
 }
 

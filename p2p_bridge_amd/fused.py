@@ -252,9 +252,37 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
     return packs[split]
 
 
+def conv_pre_plan(r: int):
+    """(first, second): does the first / second convolution of a PVConv at resolution r take its operand as a pre-split
+    grid (S format, include/p2pb_hip.h: the voxeliser / one elementwise pass apply the operand transform and the
+    fp16-pair split ONCE per element, the convolution stages with LDS-DMA alone; bit-identical outputs)?
+    P2PB_CONV_PRE="<first>:<second>" lists resolutions, default below; f16x3 arithmetic only."""
+    if conv_math() != "f16x3" or lib().p2pb_get_split_terms() != 16 or gn_acc_enabled():
+        return False, False
+    spec = os.environ.get("P2PB_CONV_PRE", CONV_PRE_DEFAULT)
+    parts = (spec.split(":") + [""])[:2]
+    first, second = ({int(t) for t in q.split(",") if t.strip()} for q in parts)
+    return int(r) in first, int(r) in second
+
+
+CONV_PRE_DEFAULT = "8,16,32:8,16"
+
+
+def conv3d_presplit(y, in_scale=None, in_shift=None, swish=False, in_sub=None):
+    """y f32[B,r,r,r,C] (voxel-major) -> its pre-split operand grid: swish?(y*scale + shift) - sub, split into the fp16
+    pair of 4 x value, in the byte layout of the convolutions' LDS tile (f32-typed storage [B,r,r,r,ceil(C/16)*16])"""
+    check(y, F32, "y")
+    b, r, c = y.shape[0], y.shape[1], y.shape[4]
+    out = torch.empty(b, r, r, r, (c + 15) // 16 * 16, dtype=F32, device=y.device)
+    in_scale, in_shift = _arrays_of(in_scale, in_shift)
+    call("p2pb_conv3d_presplit", _i(b), _i(c), ctypes.c_long(r * r * r), ptr(y), ptr(in_scale), ptr(in_shift), _i(int(swish)),
+         ptr(in_sub), ptr(out), stream_ptr())
+    return out
+
+
 def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
               skip_zero=False, compact=False, math=None, force_split=False, channels_last=False, acc_groups=None,
-              acc_channel=False):
+              acc_channel=False, pre=False):
     """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None); with
     channels_last the grids are voxel-major, x f32[B,r,r,r,Cin] -> y f32[B,r,r,r,Cout] (the layout of the fused
     voxel branch: contiguous channels for the staging loads, the stores, voxelize and devoxelize).
@@ -263,6 +291,9 @@ def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in
     b, ci, r = (x.shape[0], x.shape[4], x.shape[1]) if channels_last else (x.shape[0], x.shape[1], x.shape[2])
     co = conv.out_channels
     split = force_split or use_split(co, math)
+    if pre:  # x is the pre-split operand grid of conv3d_presplit / voxelize_cl_gather(split=True)
+        assert split and channels_last and in_scale is None and in_sub is None and x.shape[4] == (conv.in_channels + 15) // 16 * 16
+        ci = conv.in_channels
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
     st = acc = None
@@ -273,7 +304,7 @@ def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in
     elif stats:
         nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
-    flags = (1 if skip_zero else 0) | (2 if compact else 0) | (4 if split else 0) | (8 if channels_last else 0)
+    flags = (1 if skip_zero else 0) | (2 if compact else 0) | (4 if split else 0) | (8 if channels_last else 0) | (16 if pre else 0)
     fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
     call("p2pb_conv3d_k3_forward_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class), fold,
          ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st),
@@ -294,12 +325,16 @@ def brick_lists(cnt, r):
 
 
 def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                     out_class=None, math=None, channels_last=False, acc_groups=None, acc_channel=False):
-    """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second"""
+                     out_class=None, math=None, channels_last=False, acc_groups=None, acc_channel=False, pre=False):
+    """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second;
+    pre: x is the pre-split operand grid (conv3d_presplit / voxelize_cl_gather(split=True))"""
     check(x, F32, "x")
     b, ci, r = (x.shape[0], x.shape[4], x.shape[1]) if channels_last else (x.shape[0], x.shape[1], x.shape[2])
     co = conv.out_channels
     split = use_split(co, math)
+    if pre:
+        assert split and channels_last and in_scale is None and in_sub is None and x.shape[4] == (conv.in_channels + 15) // 16 * 16
+        ci = conv.in_channels
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
     st = acc = None
@@ -312,7 +347,7 @@ def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     act, ina = lists[2 * which], lists[2 * which + 1]
     ca, ci_ = counts[2 * which:], counts[2 * which + 1:]
-    flags = (4 if split else 0) | (8 if channels_last else 0)
+    flags = (4 if split else 0) | (8 if channels_last else 0) | (16 if pre else 0)
     fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
     call("p2pb_conv3d_k3_forward_sparse_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
          ptr(out_class), fold, ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(act), ptr(ca),
@@ -333,7 +368,7 @@ def active_lists(cnt, r):
 
 
 def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                      out_class=None, acc_groups=None, acc_channel=False):
+                      out_class=None, acc_groups=None, acc_channel=False, pre=False):
     """compact sparse conv on voxel-major grids (csrc/conv3d.hip): only the listed outputs of every brick are computed,
     the others get their constant. which = 0: first convolution of a PVConv (set D1); which = 1: second one in
     far-field form (set D2; in_sub / out_class from conv3d_far_field). x f32[B,r,r,r,Cin] -> (y f32[B,r,r,r,Cout], stats)"""
@@ -349,6 +384,11 @@ def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=Non
         nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     al, ac = lists[which], counts[which]
+    if pre:  # x is the pre-split operand grid
+        assert in_scale is None and in_sub is None and acc is None and x.shape[4] == (conv.in_channels + 15) // 16 * 16
+        call("p2pb_conv3d_k3_forward_compact_pre", _i(b), _i(conv.in_channels), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
+             ptr(out_class), ptr(al), ptr(ac), ptr(y), ptr(st), stream_ptr())
+        return y, st
     fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
     call("p2pb_conv3d_k3_forward_compact_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
          ptr(out_class), fold, ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(al), ptr(ac), ptr(y), ptr(st),
@@ -442,13 +482,20 @@ def voxel_sort(vox, r):
     return cnt, ws
 
 
-def voxelize_cl_gather(features, cnt, ws, r):
-    """feature half of voxelize_cl: features f32[B,C,N] + (cnt, ws) of voxel_sort -> grid f32[B,r,r,r,C]"""
+def voxelize_cl_gather(features, cnt, ws, r, split=False):
+    """feature half of voxelize_cl: features f32[B,C,N] + (cnt, ws) of voxel_sort -> grid f32[B,r,r,r,C];
+    split: the grid as the pre-split operand of a voxel convolution instead (S format, f32-typed storage
+    [B,r,r,r,ceil(C/16)*16]; conv3d_k3*(..., pre=True))"""
     check(features, F32, "features")
     b, c, n = features.shape
     r = int(r)
-    out = torch.empty(b, r, r, r, c, dtype=F32, device=features.device)
     feat_t = torch.empty(b, n, c, dtype=F32, device=features.device)
+    if split:
+        out = torch.empty(b, r, r, r, (c + 15) // 16 * 16, dtype=F32, device=features.device)
+        call("p2pb_avg_voxelize_cl_gather_split", _i(b), _i(c), _i(n), _i(r), ptr(features), ptr(cnt), ptr(ws), ptr(out),
+             ptr(feat_t), stream_ptr())
+        return out
+    out = torch.empty(b, r, r, r, c, dtype=F32, device=features.device)
     call("p2pb_avg_voxelize_cl_gather", _i(b), _i(c), _i(n), _i(r), ptr(features), ptr(cnt), ptr(ws), ptr(out),
          ptr(feat_t), stream_ptr())
     return out

@@ -54,7 +54,8 @@ def _approxmatch_forward(xyz1, xyz2):
         raise RuntimeError("Check failed: shapes")  # CHECK_EQ in emd_kernel.cu:184-186
     match = torch.empty(b, m, n, dtype=F32, device=xyz1.device)
     temp = torch.empty(int(lib().p2pb_approxmatch_temp_floats(_i(b), _i(n), _i(m))), dtype=F32, device=xyz1.device)
-    call("p2pb_approxmatch_forward", _i(b), _i(n), _i(m), ptr(xyz1), ptr(xyz2), ptr(match), ptr(temp), stream_ptr())
+    call("p2pb_approxmatch_forward_ws", _i(b), _i(n), _i(m), ptr(xyz1), ptr(xyz2), ptr(match), ptr(temp),
+         ctypes.c_size_t(temp.numel()), stream_ptr())
     return match
 
 

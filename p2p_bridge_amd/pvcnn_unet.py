@@ -372,9 +372,13 @@ class PVConv(nn.Module):
         lists = counts = None
         # the grids of this branch are voxel-major [B,r,r,r,C]: contiguous channels for the convolutions' staging
         # loads and stores, and coalesced voxelize / devoxelize (csrc/voxelize.hip)
+        # pre-split operand grids (fused.conv_pre_plan): the voxeliser writes the first convolution's operand already
+        # split, one elementwise pass does the same for the second one -- the convolutions then stage with LDS-DMA alone
+        pre1 = pre2 = False
         if geo_v is not None:  # coordinate-only half (voxel coordinates, sort, brick lists) came from the geometry stream
             vcoords, cnt, ws, lists, counts = geo_v
-            v = fused.voxelize_cl_gather(features.contiguous(), cnt, ws, r)
+            pre1, pre2 = fused.conv_pre_plan(r)
+            v = fused.voxelize_cl_gather(features.contiguous(), cnt, ws, r, split=pre1)
         else:
             vcoords, vox = L.voxel_coords(coords.detach().contiguous(), r, self.voxelization.normalize,
                                           self.voxelization.eps)
@@ -388,30 +392,45 @@ class PVConv(nn.Module):
             if lists is None:
                 lists, counts = fused.active_lists(cnt, r)
             if r in c1:
-                y1, st1 = fused.conv3d_k3_compact(v, vl[0], lists, counts, 0, acc_groups=g1)
+                y1, st1 = fused.conv3d_k3_compact(v, vl[0], lists, counts, 0, acc_groups=g1, pre=pre1)
             else:
-                y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, acc_groups=g1)
+                y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, acc_groups=g1, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
             if r in c2:
                 a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
-                y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
-                                                  acc_groups=g2, acc_channel=True)
+                if pre2:
+                    y2, st2 = fused.conv3d_k3_compact(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
+                                                      out_class=k, acc_groups=g2, acc_channel=True, pre=True)
+                else:
+                    y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
+                                                      acc_groups=g2, acc_channel=True)
+            elif pre2:
+                y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True,
+                                          acc_groups=g2, acc_channel=True, pre=True)
             else:
                 y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True,
                                           acc_groups=g2, acc_channel=True)
         elif r >= 32 and self.sparse_conv:  # at r = 16 every 4x8x8 brick touches the surface: dense is faster
             if lists is None:
                 lists, counts = fused.brick_lists(cnt, r)
-            y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0, channels_last=True, acc_groups=g1)
+            y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0, channels_last=True, acc_groups=g1, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
             a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
-            y2, st2 = fused.conv3d_k3_sparse(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
-                                             channels_last=True, acc_groups=g2, acc_channel=True)
+            if pre2:
+                y2, st2 = fused.conv3d_k3_sparse(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
+                                                 out_class=k, channels_last=True, acc_groups=g2, acc_channel=True, pre=True)
+            else:
+                y2, st2 = fused.conv3d_k3_sparse(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
+                                                 channels_last=True, acc_groups=g2, acc_channel=True)
         else:
-            y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, acc_groups=g1)
+            y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, acc_groups=g1, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
-            y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True,
-                                      acc_groups=g2, acc_channel=True)
+            if pre2:
+                y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True,
+                                          acc_groups=g2, acc_channel=True, pre=True)
+            else:
+                y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True,
+                                          acc_groups=g2, acc_channel=True)
         se = vl[6] if len(vl) > 6 else None
         sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
         if isinstance(sc2, fused.Fold):  # accumulators: the gate kernel folds the norm itself

@@ -34,7 +34,7 @@ def spy(kind, orig):
     return f
 
 
-origs = {k: getattr(fused, k) for k in ("conv3d_k3", "conv3d_k3_compact", "conv3d_k3_sparse")}
+origs = {k: getattr(fused, k) for k in ("conv3d_k3", "conv3d_k3_compact", "conv3d_k3_sparse", "conv3d_presplit")}
 for k, o in origs.items():
     setattr(fused, k, spy(k, o))
 model.eval()
@@ -51,6 +51,22 @@ arena.begin(x_start.device)
 total = 0.0
 with torch.no_grad(), fused.use_arena(arena):
     for kind, orig, a, k in calls:
+        if kind == "conv3d_presplit":  # the elementwise pass that writes a second convolution's operand pre-split
+            for _ in range(2):
+                orig(*a, **k)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                orig(*a, **k)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            total += ms
+            y = a[0]
+            print(f"(operand of the next row),presplit pass,{y.shape[1]},{y.shape[4]},-,folded norm+Swish -> S format,{ms:.4f},1.000,-,-,-"
+                  f"  # {2 * y.numel() * 4 / ms / 1e6:.0f} GB/s")
+            continue
         x, conv = a[0], a[1]
         r, ci, co = x.shape[1], conv.in_channels, conv.out_channels
         vox = B * r ** 3
@@ -64,6 +80,7 @@ with torch.no_grad(), fused.use_arena(arena):
             form = f"brick-list(conv {which + 1})"
         else:
             work, form = vox, "dense"
+        pre = bool(k.get("pre"))
         xf = len(a) > 5 and a[5] is not None or k.get("in_scale") is not None or (kind == "conv3d_k3" and len(a) > 2 and a[2] is not None)
         for _ in range(2):
             arena.off = 0
@@ -79,6 +96,6 @@ with torch.no_grad(), fused.use_arena(arena):
         ms = e0.elapsed_time(e1) / 10
         total += ms
         fl = 2.0 * 27 * ci * co
-        print(f"{names.get(id(conv), '?')},{form},{r},{ci},{co},{'folded norm+Swish' if xf else 'plain'},{ms:.4f},"
+        print(f"{names.get(id(conv), '?')},{form},{r},{ci},{co},{'pre-split (LDS-DMA)' if pre else 'folded norm+Swish' if xf else 'plain'},{ms:.4f},"
               f"{work / vox:.3f},{fl * vox / ms / 1e9:.1f},{fl * work / ms / 1e9:.1f},{fl * work / ms / 1e9 / SPLIT_PEAK_TFLOPS:.3f}")
 print(f"# sum {total:.3f} ms per evaluation")

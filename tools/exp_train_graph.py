@@ -17,12 +17,18 @@ opt = torch.optim.AdamW(params, lr=1e-4, capturable=True)
 x1, x0 = synthetic_patches(B, 2048, seed=0)
 x1, x0 = x1.cuda(), x0.cuda()
 steps = torch.randint(0, 1000, (B,), device="cuda")
+MODE = os.environ.get("MODE", "full")  # fwd | fwdbwd | clip | full: how much of the step is captured (bisecting a capture fault)
 def step():
+    if MODE == "fwd":
+        with torch.no_grad():
+            return model(x0, x1, steps=steps)
     opt.zero_grad(set_to_none=True)
     loss = model(x0, x1, steps=steps)
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(params, 1.0)
-    opt.step()
+    if MODE in ("clip", "full"):
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+    if MODE == "full":
+        opt.step()
     return loss
 for _ in range(3): l = step()
 torch.cuda.synchronize(); t0 = time.time()
@@ -42,4 +48,4 @@ for _ in range(10):
     steps.copy_(torch.randint(0, 1000, (B,), device="cuda"))
     g.replay()
 torch.cuda.synchronize(); graph = (time.time() - t0) / 10
-print(f"train step (B={B}, N=2048): eager {eager * 1e3:.1f} ms, hipGraph {graph * 1e3:.1f} ms; loss {float(l):.4f} / {float(lg):.4f}")
+print(f"[{MODE}] train step (B={B}, N=2048): eager {eager * 1e3:.1f} ms, hipGraph {graph * 1e3:.1f} ms; loss {float(l):.4f} / {float(lg):.4f}")
