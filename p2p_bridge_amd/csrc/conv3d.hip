@@ -529,18 +529,27 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
                                                unsigned wv, unsigned sbase, unsigned stage_bytes, unsigned tap_bytes,
                                                unsigned plane_bytes, bool has_next, const int (&nbase)[NT], int khalf,
                                                u32x4 (&a)[CONV_PRE_AD + 1][2]) {
-  u32x4 bf[2][NT];
-  auto load_b = [&](int s, int toff) {
+  // B fragments: plane 1 (h1) in one register set, plane 0 (h0) in TWO (tap parity): every ds_read_b128 is issued a full
+  // eight MFMAs (>= 256 cycles) before its first use -- with a single h0 set its reads could only start once the
+  // previous tap's last product had issued, four MFMAs (128 cycles, about one LDS latency under load) ahead of their use.
+  //   tap t:  [A loads of tap t + AD]  G1: a0(t) x h1(t)  | read h1(t+1) |  G2: a1(t) x h0(t)  | read h0(t+1) |  G3: a0(t) x h0(t)
+  // (same three products in the same order as split_taps: bit-identical accumulators)
+  u32x4 b1[NT], b0[2][NT];
+  auto load_b1 = [&](int toff) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
+    for (int n = 0; n < NT; ++n) b1[n] = tile[(2 + khalf) * PLANE + nbase[n] + toff];
   };
-  load_b(1, 0);
+  auto load_b0 = [&](int set, int toff) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b0[set][n] = tile[khalf * PLANE + nbase[n] + toff];
+  };
+  load_b1(0);
+  load_b0(0, 0);
 #pragma unroll
   for (int tap = 0; tap < CONV_NTAPS; ++tap) {
-    const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
     const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
     constexpr int AD = CONV_PRE_AD;
-    const int cur = tap % (AD + 1), nx2 = (tap + AD) % (AD + 1);
+    const int cur = tap % (AD + 1), nx2 = (tap + AD) % (AD + 1), par = tap & 1;
 #ifndef CONV_PRE_NOA  // (timing experiment: no weight stream in the loop)
     if (tap + AD < CONV_NTAPS) {
       const unsigned so = sbase + (unsigned)(tap + AD) * tap_bytes;
@@ -552,22 +561,28 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
       for (int s = 0; s < 2; ++s) a[nx2][s] = conv_wload(rsw, wv, so + s * plane_bytes);
     }
 #endif
-#ifdef CONV_PRE_NOB  // (timing experiment: the B fragments of tap 0 for all taps)
-    if (tap == 0)
-#endif
-    load_b(0, toff);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], bf[1][n], acc[n]);
+    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], b1[n], acc[n]);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef CONV_PRE_NOB  // (timing experiment: the B fragments of tap 0 for all taps)
+    if (tap + 1 < CONV_NTAPS) load_b1(toff_n);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][1], b0[par][n], acc[n]);
     __builtin_amdgcn_sched_barrier(0);
 #ifndef CONV_PRE_NOB
-    if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
+    if (tap + 1 < CONV_NTAPS) load_b0(par ^ 1, toff_n);
+#else
+    if (tap + 1 < CONV_NTAPS) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b0[par ^ 1][n] = b0[par][n];
+    }
 #endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][1], bf[0][n], acc[n]);
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], bf[0][n], acc[n]);
+    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], b0[par][n], acc[n]);
   }
 }
 
@@ -584,6 +599,19 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
 // The stage loop is double-buffered (2 x 37.5 KB, two workgroups per CU) with ONE barrier per stage: wait for my DMA of
 // stage k, barrier, issue the DMA of stage k + 1 into the other buffer, 27 taps on buffer k. Halo slots outside the grid
 // carry an out-of-range buffer offset: the hardware's zero lands in LDS.
+#ifdef CONV_TIMELINE  // experiment builds only (tools/exp_conv_timeline.py): s_memtime stamps of one wave per workgroup
+__device__ unsigned long long *conv_tl_buf;
+extern "C" int p2pb_conv_timeline_set(void *p) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(conv_tl_buf), &p, sizeof(p));
+}
+#define CONV_TL_INIT const unsigned tl_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); int tl_n = 0;
+#define CONV_TL(tid_) do { if ((tid_) == 0 && conv_tl_buf && tl_n < 15) conv_tl_buf[(size_t)tl_lin * 16 + 1 + tl_n++] = __builtin_readcyclecounter(); } while (0)
+#define CONV_TL_ID(tid_) do { if ((tid_) == 0 && conv_tl_buf) conv_tl_buf[(size_t)tl_lin * 16] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } while (0)
+#else
+#define CONV_TL_INIT
+#define CONV_TL(tid_)
+#define CONV_TL_ID(tid_)
+#endif
 typedef int conv_i32x4 __attribute__((ext_vector_type(4)));
 template <int R, int HD, int HH, int HW>
 struct PreStage {
@@ -740,13 +768,27 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   for (int s = 0; s < NT; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[s][r] = 0.0f;
+  // The epilogue's additive constants are fetched HERE, sixteen loads in one batch under the stage loop. Left inside the
+  // epilogue's (branchy) row loop the compiler issued them one at a time, each followed by its own vmcnt(0): sixteen
+  // serialised L2 round trips per wave, 64 more for the boundary-class constants of a second convolution -- a timeline of
+  // the r = 32 C64 launch (tools/exp_conv_timeline.py) showed 43 k of a workgroup's 144 k cycles in the epilogue.
+  float bvr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    bvr[r] = (co < cout && !out_class) ? bias[co] : 0.0f;
+  }
 
   if constexpr (PRE) {
     // `in` = the pre-split operand grid (S format): LDS-DMA stages, two buffers, one barrier per stage
+    CONV_TL_INIT
+    CONV_TL_ID(tid);
+    CONV_TL(tid);  // 0: start (after the index arithmetic above)
     PreStage<R, HD, HH, HW> ps;
     ps.init(tid, d0, h0, w0, nchunk);
     const conv_i32x4 sg = conv_make_rsrc((const u32x4 *)in + (size_t)b * R3 * nchunk * 4, (unsigned)(R3 * nchunk * 64));
     ps.issue(sg, 0, tile, tid);
+    CONV_TL(tid);  // 1: first DMA issued
     // weights: [tap][stage][plane 3][khalf 2][cout_pad] of 16 bytes
     const unsigned stage_bytes = 6u * cout_pad * 16u, tap_bytes = (unsigned)nchunk * stage_bytes, plane_bytes = 2u * cout_pad * 16u;
     auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, 27 * (int)tap_bytes, 0x00020000);
@@ -761,16 +803,22 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): my share of stage k has landed (and the weights of its first taps)
       __syncthreads();                     // everyone's has; the other buffer is no longer read
 #endif
+      CONV_TL(tid);  // 2 + 2k: stage k released
 #ifndef CONV_PRE_NODMA  // (timing experiment: no operand stream)
       if (k + 1 < nchunk) ps.issue(sg, k + 1, nxt, tid);
 #endif
       split_taps_pre<NT, HH, HW, PLANE>(acc, cur, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
                                         k + 1 < nchunk, nbase, khalf, aring);
+      CONV_TL(tid);  // 3 + 2k: taps of stage k issued
     };
     for (int k = 0; k < nchunk; k += 2) {
       stage(k, tile, tile2);
       if (k + 1 < nchunk) stage(k + 1, tile2, tile);
     }
+#ifdef CONV_TIMELINE
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (tid == 0 && conv_tl_buf) conv_tl_buf[(size_t)tl_lin * 16 + 14] = __builtin_readcyclecounter();  // 14: accumulators final
+#endif
   } else {
   constexpr int NP = (PLANE + 255) / 256;
   int soff[NP];
@@ -888,6 +936,20 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 
   float *outb = out + (size_t)b * cout * R3;
   GnRun grun = {-1, 0.0, 0.0};
+  // boundary-class constants of a second convolution: the workgroup's [27][32 MT] slice of K[b] goes through LDS (the
+  // operand tile is free now) -- one cooperative fetch instead of a dependent global load per (row, N-tile)
+  constexpr int NCW = 32 * MT;
+  float *kl = (float *)tile;
+  if (out_class) {
+    __syncthreads();  // every wave is done with the last stage's fragments
+    const float *kb = out_class + (size_t)b * 27 * cout;
+    const int cob = co0 - 32 * wm;
+    for (int e = tid; e < 27 * NCW; e += 256) {
+      const int c = e % NCW, co = cob + c;
+      kl[e] = co < cout ? kb[(e / NCW) * cout + co] : 0.0f;
+    }
+    __syncthreads();
+  }
   int vox[NT], cls[NT];
 #pragma unroll
   for (int s = 0; s < NT; ++s) {
@@ -909,13 +971,13 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       const int r = 4 * g + i;
       const int co = co0 + i + 8 * g + 4 * khalf;
       const bool cok = co < cout;
-      const float bv = (cok && !out_class) ? bias[co] : 0.0f;
+      const float bv = bvr[r];
       float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
       for (int s = 0; s < NT; ++s) {
         if (!nact[s]) continue;
         float v = acc[s][r] + bv;
-        if (out_class && cok) v += out_class[((size_t)b * 27 + cls[s]) * cout + co];
+        if (out_class && cok) v += kl[cls[s] * NCW + 32 * wm + i + 8 * g + 4 * khalf];
         if (CL) vv[s][i] = v;
         else if (cok) outb[(size_t)co * R3 + vox[s]] = v;
         s1 += v;
@@ -956,6 +1018,13 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     }
   }
   if (FX && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
+#ifdef CONV_TIMELINE
+  if constexpr (PRE) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (tid == 0 && conv_tl_buf)  // 15: epilogue stores issued and acknowledged
+      conv_tl_buf[(size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 16 + 15] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // weights [cout][cin][3][3][3] -> packed [27][cin_pad/8][2][cout_pad][4] (zero padded):
@@ -1763,6 +1832,12 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     for (int i = 0; i < NA; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float bvr[16];  // the epilogue's bias values, fetched in one batch under the stage loop (see the split kernel)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      bvr[r] = (NTC > 0 && co < cout && !out_class) ? bias[co] : 0.0f;
+    }
 
     if constexpr (PRE) {  // `in` = the pre-split operand grid: LDS-DMA stages, two buffers, one barrier per stage
       PreStage<R, HD, HH, HW> ps;
@@ -1845,6 +1920,20 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       split_taps<NA, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
     }
     }  // !PRE
+    // boundary-class constants of a second convolution: the workgroup's [27][32 WM] slice of K[b] through LDS (the operand
+    // tile is free now; every wave takes part, also those without a tile) instead of a dependent global load per
+    // (row, tile) in the epilogue
+    constexpr int NCW = 32 * WM;
+    float *kl = (float *)tile;
+    if (out_class) {
+      __syncthreads();
+      const float *kbs = out_class + (size_t)b * 27 * cout;
+      for (int e = tid; e < 27 * NCW; e += 256) {
+        const int c = e % NCW, co = cob + c;
+        kl[e] = co < cout ? kbs[(e / NCW) * cout + co] : 0.0f;
+      }
+      __syncthreads();
+    }
     if (NTC == 0) return;
     if constexpr (TERMS == SPLIT_F16X3) {
       const float oscale = ((const float *)((const char *)wt + conv_split_trailer_bytes(nchunk, cout_pad)))[1];
@@ -1871,12 +1960,12 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
         const int r = 4 * g + i;
         const int co = co0 + i + 8 * g + 4 * khalf;
         const bool cok = co < cout;
-        const float bv = (cok && !out_class) ? bias[co] : 0.0f;
+        const float bv = bvr[r];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int n = 0; n < NA; ++n) {
           float x = acc[n][r] + bv;
-          if (out_class && cok) x += out_class[((size_t)b * 27 + ocls[n]) * cout + co];
+          if (out_class && cok) x += kl[ocls[n] * NCW + 32 * wm + i + 8 * g + 4 * khalf];
           vv[n][i] = x;
           if (oact[n]) {
             s1 += x;

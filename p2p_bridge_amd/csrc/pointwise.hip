@@ -49,6 +49,17 @@ __global__ __launch_bounds__(256, 3) void pw_conv_kernel(int cin, int cout, int 
   const bool pok[2] = {pl[0] < P, pl[1] < P};
   const float *inb = in + (size_t)b * cin * P;
   const int nchunk8 = (cin + 7) >> 3;
+  __shared__ float pwc_bias[32 * MT];  // bias (+ per-sample bias) through LDS: see pw_wide_kernel
+  if (tid < 32 * MT) {
+    const int co = co0 + tid;
+    float v = 0.0f;
+    if (co < cout) {
+      v = bias ? bias[co] : 0.0f;
+      if (bias_b) v += bias_b[(size_t)b * cout + co];
+    }
+    pwc_bias[tid] = v;
+  }
+  __syncthreads();
 
   f32x16 acc[MT][2];
 #pragma unroll
@@ -133,11 +144,7 @@ __global__ __launch_bounds__(256, 3) void pw_conv_kernel(int cin, int cout, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      float bv = 0.0f;
-      if (co < cout) {
-        bv = bias ? bias[co] : 0.0f;
-        if (bias_b) bv += bias_b[(size_t)b * cout + co];
-      }
+      const float bv = pwc_bias[co - co0];
       float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -227,6 +234,19 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
   const bool pok = p < P;
   const int pc = pok ? p : P - 4;  // clamped lanes multiply garbage that is never stored
   const float *inb = in + (size_t)b * cin * P;
+  // bias (+ per-sample bias) of the workgroup's channels through LDS: fetched from global memory inside the epilogue's row
+  // loops they were one serialised L2 round trip per row (conv3d.hip, tools/exp_conv_timeline.py)
+  __shared__ float pww_bias[32 * MT];
+  if (tid < 32 * MT) {
+    const int co = co0 + tid;
+    float v = 0.0f;
+    if (co < cout) {
+      v = bias ? bias[co] : 0.0f;
+      if (bias_b) v += bias_b[(size_t)b * cout + co];
+    }
+    pww_bias[tid] = v;
+  }
+  __syncthreads();
 
   f32x16 acc[MT][4];
 #pragma unroll
@@ -392,13 +412,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
         const int cq = co0 + m * 32 + 8 * g + 4 * khalf;
         float bv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          bv[i] = 0.0f;
-          if (cq + i < cout) {
-            bv[i] = bias ? bias[cq + i] : 0.0f;
-            if (bias_b) bv[i] += bias_b[(size_t)b * cout + cq + i];
-          }
-        }
+        for (int i = 0; i < 4; ++i) bv[i] = pww_bias[cq + i - co0];
         if (pok && cq < cout) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -424,11 +438,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-      float bv = 0.0f;
-      if (co < cout) {
-        bv = bias ? bias[co] : 0.0f;
-        if (bias_b) bv += bias_b[(size_t)b * cout + co];
-      }
+      const float bv = pww_bias[co - co0];
       const f32x4 v = {acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv};
       float s1 = 0.0f, s2 = 0.0f;
       if (co < cout && pok) {
@@ -542,7 +552,11 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
                                              int wm, int wn, int l31, int khalf, int cout, int P, int nslots,
                                              const float *__restrict__ bias, const float *__restrict__ bias_b,
                                              float *__restrict__ out, float *__restrict__ stats_part,
-                                             float *__restrict__ mm_out, int pool_u, int out_pm, const GnAcc &gacc) {
+                                             float *__restrict__ mm_out, int pool_u, int out_pm, const GnAcc &gacc,
+                                             const float *sb) {
+  // sb: the workgroup's bias (+ per-sample bias) values [64 WM], staged in LDS by the kernel's prologue. Fetched from
+  // global memory inside the row loops below they were one L2 round trip each, serialised by the loops' branches (the
+  // same finding as in the convolutions' epilogue, conv3d.hip / tools/exp_conv_timeline.py).
 #pragma unroll
   for (int pb = 0; pb < NB; ++pb) {  // the wave's NB blocks of 64 positions (even / odd tiles 2 pb, 2 pb + 1)
   const int p = pblk + 128 * pb + 2 * (wn * 32 + l31);
@@ -556,13 +570,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
         const int cq = co0 + wm * 64 + m * 32 + 8 * g + 4 * khalf;
         float bv[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          bv[i] = 0.0f;
-          if (cq + i < cout) {
-            bv[i] = bias ? bias[cq + i] : 0.0f;
-            if (bias_b) bv[i] += bias_b[(size_t)b * cout + cq + i];
-          }
-        }
+        for (int i = 0; i < 4; ++i) bv[i] = sb[cq + i - co0];
         if (pok && cq < cout) {
 #pragma unroll
           for (int n = 0; n < 2; ++n) {
@@ -590,11 +598,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
       const bool cok = co < cout;
-      float bv = 0.0f;
-      if (cok) {
-        bv = bias ? bias[co] : 0.0f;
-        if (bias_b) bv += bias_b[(size_t)b * cout + co];
-      }
+      const float bv = sb[co - co0];
       acc[m][2 * pb][r] += bv;
       acc[m][2 * pb + 1][r] += bv;
       const f32x2 v = {acc[m][2 * pb][r], acc[m][2 * pb + 1][r]};
@@ -716,6 +720,16 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
   const int pblk = bx * (128 * NB), co0 = by * (64 * WM);
   const float *inb = in + (size_t)b * cin * P;
   const bool mact = co0 + wm * 64 < cout;  // this wave's 64 channels exist (wave-uniform)
+  __shared__ float pws_bias[64 * WM];  // bias (+ per-sample bias) of the workgroup's channels; published by the stage barriers
+  if (tid < 64 * WM) {
+    const int co = co0 + tid;
+    float v = 0.0f;
+    if (co < cout) {
+      v = bias ? bias[co] : 0.0f;
+      if (bias_b) v += bias_b[(size_t)b * cout + co];
+    }
+    pws_bias[tid] = v;
+  }
 
   f32x16 acc[2][2 * NB];  // [M-tile][position block * 2 + even/odd tile]
 #pragma unroll
@@ -864,7 +878,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
         for (int r = 0; r < 16; ++r) acc[m][n][r] *= oscale;
   }
   pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
-                             stats_part, mm_out, pool_u, out_pm, FX ? gacc : GnAcc());
+                             stats_part, mm_out, pool_u, out_pm, FX ? gacc : GnAcc(), pws_bias);
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],

@@ -727,6 +727,10 @@ class operand_audit:
 
     def __enter__(self):
         import sys
+        # the audit reads fp32 operands: inside it the convolutions stage fp32 themselves (same operand values as the
+        # pre-split path, whose grids hold fp16 pairs)
+        self._pre = os.environ.get("P2PB_CONV_PRE")
+        os.environ["P2PB_CONV_PRE"] = ":"
         self.rows, self._mod = [], sys.modules[__name__]
         self._orig = {k: getattr(self._mod, k) for k in ("pw_conv", "conv3d_k3", "conv3d_k3_sparse", "conv3d_k3_compact")}
         names = {"pw_conv": ("in_scale", "in_shift", "swish"), "conv3d_k3": ("in_scale", "in_shift", "swish"),
@@ -758,6 +762,10 @@ class operand_audit:
     def __exit__(self, *exc):
         for k, o in self._orig.items():
             setattr(self._mod, k, o)
+        if self._pre is None:
+            os.environ.pop("P2PB_CONV_PRE", None)
+        else:
+            os.environ["P2PB_CONV_PRE"] = self._pre
 
     @property
     def worst(self):

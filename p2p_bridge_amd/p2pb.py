@@ -200,6 +200,7 @@ class P2PB(nn.Module):
         self._graphs: Dict = {}
         self.f16_overflow: Optional[str] = None  # None: P2PB_F16_OVERFLOW or "rerun" (ddpm_sampling)
         self.overflow_reruns = 0
+        self.sample_chains = None  # None: automatic (see _sampler_chains)
 
     # ---- reference API surface ------------------------------------------------------------------
     def multi_gpu_wrapper(self, f):
@@ -349,6 +350,14 @@ class P2PB(nn.Module):
         xt = x1.detach().to(self.device)
         xs, x0s = [], []
         rev = steps[::-1]
+        chains = self._sampler_chains(xt) if graph else 1
+        if chains > 1:
+            try:
+                return self._ddpm_chains(net, xt, x_cond, clip_denoise, rev, table, log_steps, chains)
+            finally:
+                if ema_was_training:
+                    self.ema.ema_model.train()
+                self.model.train()
         runner = self._graph_runner(net, xt, x_cond, clip_denoise) if graph else None
         try:
             for i, prev in enumerate(rev[1:]):
@@ -369,13 +378,81 @@ class P2PB(nn.Module):
         flip = lambda z: torch.flip(torch.stack(z, dim=1), dims=(1,))
         return flip(xs), flip(x0s)
 
+    def _sampler_chains(self, xt) -> int:
+        """how many independent sub-batches the graph sampler runs side by side (`self.sample_chains` / P2PB_SAMPLE_CHAINS;
+        default 1). Built for the large clouds of BASELINE configs 4-5 (50000 points), which spend half of an evaluation in
+        the level-0 farthest-point sampling -- a 12500-round dependent chain on ONE workgroup per cloud -- while the dense
+        layers behind it wait: samples are independent, so the batch is cut into chains that each replay
+        their own captured step on their own stream, started a fraction of a step apart, and one chain's FPS runs under
+        the other chains' dense layers. Same arithmetic per sample, same results. MEASURED (profiles/r03b_pvdl_chains.txt):
+        no gain -- 2 chains 42.2 -> 44.1 / 49.9 -> 49.6 / 63.9 -> 62.9 ms per evaluation at B = 4 / 8 / 16, 4 chains 1.5-1.9 x
+        SLOWER: what follows the FPS is a chain of ~300 dependent launches whose length does not shrink with the
+        sub-batch, and four graphs' branches queue behind each other's 26 ms FPS kernels in the hardware queues. Off by
+        default; kept as an option with its test."""
+        v = self.sample_chains if self.sample_chains is not None else os.environ.get("P2PB_SAMPLE_CHAINS")
+        k = int(v) if v not in (None, "", "auto") else 1
+        return max(1, min(k, xt.shape[0]))
+
+    def _ddpm_chains(self, net, xt, x_cond, clip, rev, table, log_steps, chains):
+        """the reverse chain of _ddpm_once for `chains` sub-batches, each with its own captured step, static buffers and
+        stream; chain c starts c / chains of a step after chain 0 (a device-side delay, measured on chain 0's first step)"""
+        B = xt.shape[0]
+        cuts = [(B * c) // chains for c in range(chains + 1)]
+        parts = [slice(cuts[c], cuts[c + 1]) for c in range(chains)]
+        main = torch.cuda.current_stream()
+        runners = [self._graph_runner(net, xt[p], None if x_cond is None else x_cond[p], clip, chain=c)
+                   for c, p in enumerate(parts)]  # (captures happen here, one after the other, on the calling stream)
+        streams = self._chain_streams = (getattr(self, "_chain_streams", None) or [])
+        while len(streams) < chains:
+            streams.append(torch.cuda.Stream(device=xt.device))
+        x_c = [xt[p] for p in parts]
+        logs = [([], []) for _ in parts]
+        nsteps = len(rev) - 1
+        for i, prev in enumerate(rev[1:]):
+            noise = torch.randn_like(xt) if (not self.ot_ode and prev > 0) else None  # (one draw for the whole batch: the
+            if noise is not None and i > 0:                                            #  generator's order of the plain path)
+                drawn = torch.cuda.Event()
+                drawn.record(main)
+                for c in range(chains):
+                    streams[c].wait_event(drawn)  # (the draw happens on the calling stream, the chains consume it on theirs)
+            if i == 0:
+                # chain 0's first step alone, timed: the stagger of the other chains is a fraction of it
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+                x_c[0], x0 = runners[0](x_c[0], table[0], None if noise is None else noise[parts[0]])
+                e1.record(main)
+                if prev in log_steps:
+                    logs[0][0].append(x_c[0].clone()), logs[0][1].append(x0.clone())
+                e1.synchronize()
+                step_ms = e0.elapsed_time(e1)
+                for c in range(chains):
+                    streams[c].wait_stream(main)
+                    if c > 0 and nsteps > 1:
+                        with torch.cuda.stream(streams[c]):
+                            torch.cuda._sleep(int(step_ms * c / chains * 1.8e6))  # (~1.8 GHz spin clock; only the phase matters)
+            for c in range(chains):
+                if i == 0 and c == 0:
+                    continue
+                with torch.cuda.stream(streams[c]):
+                    x_c[c], x0 = runners[c](x_c[c], table[i], None if noise is None else noise[parts[c]])
+                    if prev in log_steps:
+                        logs[c][0].append(x_c[c].clone()), logs[c][1].append(x0.clone())
+                    if noise is not None:
+                        noise.record_stream(streams[c])
+        for c in range(chains):
+            main.wait_stream(streams[c])
+        flip = lambda z: torch.flip(torch.stack(z, dim=1), dims=(1,))
+        xs = torch.cat([flip(l[0]) for l in logs], dim=0)
+        x0s = torch.cat([flip(l[1]) for l in logs], dim=0)
+        return xs, x0s
+
     @staticmethod
     def _weights_fingerprint(net):
         """identity + in-place version of every parameter and buffer: an optimiser step, load_state_dict, an EMA update
         or a replaced parameter all change it"""
         return tuple((t.data_ptr(), t._version) for t in list(net.parameters()) + list(net.buffers()))
 
-    def _graph_runner(self, net, xt, x_cond, clip):
+    def _graph_runner(self, net, xt, x_cond, clip, chain=0):
         """capture ONE sampler step (network evaluation + posterior update) into a hipGraph with static
         input / coefficient / noise buffers. Replays are keyed by (shape, cond shape, clip, network identity, arithmetic); a captured
         graph bakes in the addresses of the weights AND of their derived packed copies (fused.pack_*, StyleBank), so
@@ -387,7 +464,7 @@ class P2PB(nn.Module):
         from . import fused
 
         # (the arithmetic is part of the key: a captured graph keeps the kernels of the mode it was captured under)
-        key = (tuple(xt.shape), None if x_cond is None else tuple(x_cond.shape), bool(clip), id(net), fused.conv_math())
+        key = (tuple(xt.shape), None if x_cond is None else tuple(x_cond.shape), bool(clip), id(net), fused.conv_math(), chain)
         fp = self._weights_fingerprint(net)
         entry = self._graphs.get(key)
         if entry is not None and entry[0] != fp:

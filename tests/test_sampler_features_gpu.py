@@ -333,3 +333,34 @@ def test_training_loss_goes_nan_on_f16_overflow(tiny):
     x1, x0 = net_ref.synthetic_patches(2, 1024, seed=0)
     loss = model(x0.cuda(), x1.cuda(), steps=torch.tensor([10, 700]))
     assert not torch.isfinite(loss).item()
+
+
+@pytest.mark.parametrize("stochastic", [False, True])
+def test_interleaved_sampler_chains_match_the_plain_graph_sampler(tiny, stochastic):
+    """P2PB.sample(graph=True) with the batch cut into 2 / 3 independent chains on their own streams (the default for the
+    50000-point clouds of BASELINE configs 4-5, where one chain's farthest-point sampling then runs under the other
+    chains' dense layers; models/p2pb.py:304-320 per sample): same x_pred and x_chain as the one-chain sampler -- per
+    sample the same arithmetic; equal up to the GEMM tile forms a smaller sub-batch may select (1e-5 here) -- with and
+    without the stochastic posterior (one noise draw per step for the whole batch, sliced per chain)."""
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.synthetic import synthetic_patches
+
+    cfg, sd, _ = tiny
+    cfg = copy.deepcopy(cfg)
+    cfg["diffusion"]["ot_ode"] = not stochastic
+    model = product.build_model(cfg, sd, device="cuda")
+    x, _ = synthetic_patches(5, 1024, seed=4)
+    x = x.cuda()
+    outs = []
+    for chains in (1, 2, 3):
+        model.sample_chains = chains
+        torch.manual_seed(11)
+        outs.append(model.sample(x_start=x, steps=4, log_count=4, verbose=False, graph=True))
+        # a second call replays the captured graphs of every chain
+        torch.manual_seed(11)
+        again = model.sample(x_start=x, steps=4, log_count=4, verbose=False, graph=True)
+        assert torch.equal(again["x_pred"], outs[-1]["x_pred"])
+    assert outs[0]["x_chain"].shape == outs[1]["x_chain"].shape == outs[2]["x_chain"].shape
+    for o in outs[1:]:
+        assert (o["x_pred"] - outs[0]["x_pred"]).abs().max().item() < 1e-5
+        assert (o["x_chain"] - outs[0]["x_chain"]).abs().max().item() < 1e-5
