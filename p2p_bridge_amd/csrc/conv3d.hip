@@ -592,7 +592,10 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
 // f16x3 arithmetic. PRE = true kernels take the operand ALREADY transformed and split, in the exact byte layout of the LDS
 // tile, and bring a stage into LDS with LDS-DMA (buffer_load_dwordx4 ... lds: no registers, no VALU, no ds_write):
 //     S[b][voxel][chunk16][plane 2][khalf 2] of 16 bytes = 8 fp16  (h0 | h1 of 4 x value, channels chunk*16 + khalf*8 + i)
-// i.e. 4 bytes per (voxel, channel) like the fp32 grid it replaces, channel count padded to a multiple of 16. Producers:
+// i.e. 4 bytes per (voxel, channel) like the fp32 grid it replaces, channel count padded to a multiple of 16. (A PLANAR
+// order [chunk][plane][khalf][voxel] -- 160-byte runs per DMA instruction instead of one cache line per lane -- was built
+// and measured: the convolutions alone 6 % faster, the bench 1.4 % SLOWER, because both producers then write through an
+// LDS transpose or read strided; profiles/README.md.) Producers:
 // the voxeliser for a first convolution (voxelize.hip vox_gather_cl_split_kernel: no extra pass), conv3d_presplit_kernel for
 // a second one (one elementwise pass over y1 once its GroupNorm statistics are folded). Same transform, same split, same
 // products in the same order as the staging code below: outputs are bit-identical to the PRE = false kernels.
@@ -606,10 +609,12 @@ extern "C" int p2pb_conv_timeline_set(void *p) {
 }
 #define CONV_TL_INIT const unsigned tl_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); int tl_n = 0;
 #define CONV_TL(tid_) do { if ((tid_) == 0 && conv_tl_buf && tl_n < 15) conv_tl_buf[(size_t)tl_lin * 16 + 1 + tl_n++] = __builtin_readcyclecounter(); } while (0)
+#define CONV_TL_AT(tid_, slot_) do { if ((tid_) == 0 && conv_tl_buf) conv_tl_buf[(size_t)tl_lin * 16 + 1 + (slot_)] = __builtin_readcyclecounter(); } while (0)
 #define CONV_TL_ID(tid_) do { if ((tid_) == 0 && conv_tl_buf) conv_tl_buf[(size_t)tl_lin * 16] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } while (0)
 #else
 #define CONV_TL_INIT
 #define CONV_TL(tid_)
+#define CONV_TL_AT(tid_, slot_)
 #define CONV_TL_ID(tid_)
 #endif
 typedef int conv_i32x4 __attribute__((ext_vector_type(4)));
@@ -668,11 +673,19 @@ __device__ __forceinline__ conv_i32x4 conv_make_rsrc(const void *p, unsigned byt
 // FX: the sampler path's statistics plumbing (operand norm folded here from accumulators / output statistics added to
 // accumulators, common.h) is compiled in -- a separate instantiation (voxel-major form only), so that the plain form
 // carries neither the two argument structs nor the table
+// CONV_PRE_SINGLE (experiment builds): the PRE kernels with ONE operand buffer (38 KB) and three workgroups per CU instead
+// of two buffers and two workgroups: a stage's DMA is then issued and awaited between two barriers (its latency covered
+// by the other two workgroups instead of by the workgroup's own taps)
+#ifdef CONV_PRE_SINGLE
+#define CONV_PRE_WAVES(PRE_) ((PRE_) ? 3 : CONV_F16_WAVES)
+#else
+#define CONV_PRE_WAVES(PRE_) CONV_F16_WAVES
+#endif
 #ifndef CONV_F16_WAVES
 #define CONV_F16_WAVES 2  // (waves per SIMD the f16x3 forms are compiled for; their two-plane tile would fit three workgroups)
 #endif
 template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX, int TERMS, bool PRE = false>
-__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
+__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
                                                              const float *__restrict__ bias,
@@ -699,7 +712,11 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   // (PRE: the second stage buffer is its OWN object, and the stage loop is unrolled by two with the roles fixed, so that
   //  the compiler can tell the LDS-DMA into one buffer from the fragment reads of the other -- with one array it waits
   //  vmcnt(0) for the DMA burst of stage k + 1 in front of the first ds_read of stage k)
+#ifdef CONV_PRE_SINGLE
+  __shared__ u32x4 tile2[1];
+#else
   __shared__ u32x4 tile2[PRE ? split_planes(TERMS) * 2 * PLANE : 1];
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -787,7 +804,9 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     PreStage<R, HD, HH, HW> ps;
     ps.init(tid, d0, h0, w0, nchunk);
     const conv_i32x4 sg = conv_make_rsrc((const u32x4 *)in + (size_t)b * R3 * nchunk * 4, (unsigned)(R3 * nchunk * 64));
+#ifndef CONV_PRE_SINGLE
     ps.issue(sg, 0, tile, tid);
+#endif
     CONV_TL(tid);  // 1: first DMA issued
     // weights: [tap][stage][plane 3][khalf 2][cout_pad] of 16 bytes
     const unsigned stage_bytes = 6u * cout_pad * 16u, tap_bytes = (unsigned)nchunk * stage_bytes, plane_bytes = 2u * cout_pad * 16u;
@@ -799,6 +818,17 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 #pragma unroll
       for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
     auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
+#ifdef CONV_PRE_SINGLE
+      __syncthreads();  // every wave is done with the previous stage's fragments
+      ps.issue(sg, k, tile, tid);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      __syncthreads();
+      CONV_TL(tid);
+      split_taps_pre<NT, HH, HW, PLANE>(acc, tile, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
+                                        k + 1 < nchunk, nbase, khalf, aring);
+      CONV_TL(tid);
+      return;
+#endif
 #ifndef CONV_PRE_NOBAR  // (timing experiment: stages not ordered)
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): my share of stage k has landed (and the weights of its first taps)
       __syncthreads();                     // everyone's has; the other buffer is no longer read
@@ -987,7 +1017,11 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
         if (l31 == 31 && cok) gn_run_add(grun, gacc, b, co, s1, s2);
-      } else if (stats_part) {
+      }
+#ifdef CONV_EXP_NOSTATS  // (timing experiment: no statistics)
+      else if (s1 == 12345.678f && stats_part) stats_part[0] = s2;
+#endif
+      else if (stats_part) {
         // the brick's four statistics slots: wave column wn fills slot wn for its channels; with two wave rows
         // only two columns exist and slots 2, 3 are zeroed
         s1 = halfwave_sum_to_last(s1);
@@ -1004,7 +1038,12 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
         }
       }
     }
+#ifdef CONV_EXP_NOSTORE  // (timing experiment: outputs not stored)
+    if (vv[0][0] == 12345.678f) outb[0] = vv[NT - 1][3];
+    if (false) {
+#else
     if (CL) {
+#endif
       const int cq = co0 + 8 * g + 4 * khalf;
 #pragma unroll
       for (int s = 0; s < NT; ++s) {
@@ -1713,7 +1752,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
 #endif
 
 template <int R, int WM, bool XF, bool FX, int TERMS, bool PRE = false>  // FX, TERMS, PRE: see conv3d_k3_split_kernel
-__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
+__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                                 const float *__restrict__ in,
                                                                 const unsigned short *__restrict__ wt,
                                                                 const float *__restrict__ bias,
@@ -1733,7 +1772,11 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   constexpr int WN = 4 / WM;
   static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF && !FX), "pre-split operands: f16x3, no fold");
   __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
+#ifdef CONV_PRE_SINGLE
+  __shared__ u32x4 tile2[1];
+#else
   __shared__ u32x4 tile2[PRE ? split_planes(TERMS) * 2 * PLANE : 1];  // (its own object: see the split kernel)
+#endif
   __shared__ unsigned char lst[256];
   __shared__ int ncls[27];
   __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
@@ -1755,12 +1798,16 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   const int cob = coblk * (32 * WM);  // first channel of the workgroup
   const int co0 = cob + 32 * wm;      // first channel of this wave's M-tile
 
+  CONV_TL_INIT
+  CONV_TL_ID(tid);
+  CONV_TL(tid);  // 0: start
   const int count = acount[(size_t)b * NBRICK + brick];
   lst[tid] = alist[((size_t)b * NBRICK + brick) * 256 + tid];
   if (tid < 27) ncls[tid] = 0;
   const bool folded = FX && XF && fold.group != nullptr;
   if (folded) xf_table(xtab, fold, in_scale, in_shift, b, cin);
   __syncthreads();
+  CONV_TL(tid);  // 1: brick list in LDS
   const int ntiles = (count + 31) >> 5;
   auto vox_of = [&](int l, int &cls) {
     const int d = d0 + (l >> 6), h = h0 + ((l >> 3) & 7), w = w0 + (l & 7);
@@ -1843,7 +1890,10 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       PreStage<R, HD, HH, HW> ps;
       ps.init(tid, d0, h0, w0, nchunk);
       const conv_i32x4 sg = conv_make_rsrc((const u32x4 *)in + (size_t)b * R3 * nchunk * 4, (unsigned)(R3 * nchunk * 64));
+#ifndef CONV_PRE_SINGLE
       ps.issue(sg, 0, tile, tid);
+#endif
+      CONV_TL(tid);  // 2: first DMA issued
       const unsigned stage_bytes = 6u * cout_pad * 16u, tap_bytes = (unsigned)nchunk * stage_bytes, plane_bytes = 2u * cout_pad * 16u;
       auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, 27 * (int)tap_bytes, 0x00020000);
       const unsigned wv = (unsigned)(khalf * cout_pad + co0 + l31) * 16u;
@@ -1855,12 +1905,24 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
           for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
       }
       auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
+#ifdef CONV_PRE_SINGLE
+        __syncthreads();
+        ps.issue(sg, k, tile, tid);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (NTC > 0)
+          split_taps_pre<NA, HH, HW, PLANE>(acc, tile, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
+                                            k + 1 < nchunk, nbase, khalf, aring);
+        return;
+#endif
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
         __syncthreads();
+        if (k < 4) CONV_TL_AT(tid, 3 + 2 * k);  // stage k released (k < 4)
         if (k + 1 < nchunk) ps.issue(sg, k + 1, nxt, tid);
         if (NTC > 0)
           split_taps_pre<NA, HH, HW, PLANE>(acc, cur, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
                                             k + 1 < nchunk, nbase, khalf, aring);
+        if (k < 4) CONV_TL_AT(tid, 4 + 2 * k);  // its taps issued
       };
       for (int k = 0; k < nchunk; k += 2) {
         stage(k, tile, tile2);
@@ -1920,6 +1982,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       split_taps<NA, HH, HW, PLANE, TERMS>(acc, tile, wchunk, wsplit_stride, wtap_stride, nbase, khalf);
     }
     }  // !PRE
+    CONV_TL_AT(tid, 11);  // stage loop done
     // boundary-class constants of a second convolution: the workgroup's [27][32 WM] slice of K[b] through LDS (the operand
     // tile is free now; every wave takes part, also those without a tile) instead of a dependent global load per
     // (row, tile) in the epilogue
@@ -1934,6 +1997,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       }
       __syncthreads();
     }
+    CONV_TL_AT(tid, 12);  // class constants staged
     if (NTC == 0) return;
     if constexpr (TERMS == SPLIT_F16X3) {
       const float oscale = ((const float *)((const char *)wt + conv_split_trailer_bytes(nchunk, cout_pad)))[1];
@@ -1999,6 +2063,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     else run(std::integral_constant<int, 4>{});
   }
   __syncthreads();
+  CONV_TL_AT(tid, 13);  // active outputs stored
 
   // ---- the brick's other voxels: their constant, and its exact share of the statistics
   const int ninact = 256 - count;
@@ -2106,6 +2171,10 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       }
     }
   }
+#ifdef CONV_TIMELINE
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  CONV_TL_AT(tid, 14);  // constants + statistics written
+#endif
 }
 
 // in f32[b,r,r,r,cin] -> out f32[b,r,r,r,cout] (voxel-major), wt = split pack; alist/acount = ONE set of

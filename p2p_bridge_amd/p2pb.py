@@ -385,13 +385,15 @@ class P2PB(nn.Module):
         layers behind it wait: samples are independent, so the batch is cut into chains that each replay
         their own captured step on their own stream, started a fraction of a step apart, and one chain's FPS runs under
         the other chains' dense layers. Same arithmetic per sample, same results. MEASURED (profiles/r03b_pvdl_chains.txt):
-        no gain -- 2 chains 42.2 -> 44.1 / 49.9 -> 49.6 / 63.9 -> 62.9 ms per evaluation at B = 4 / 8 / 16, 4 chains 1.5-1.9 x
-        SLOWER: what follows the FPS is a chain of ~300 dependent launches whose length does not shrink with the
-        sub-batch, and four graphs' branches queue behind each other's 26 ms FPS kernels in the hardware queues. Off by
-        default; kept as an option with its test."""
+        no gain THERE -- 2 chains 42.2 -> 44.1 / 49.9 -> 49.6 / 63.9 -> 62.9 ms per evaluation at B = 4 / 8 / 16, 4 chains
+        1.5-1.9 x SLOWER: what follows the FPS is a chain of ~300 dependent launches whose length does not shrink with the
+        sub-batch, and four graphs' branches queue behind each other's 26 ms FPS kernels in the hardware queues."""
         v = self.sample_chains if self.sample_chains is not None else os.environ.get("P2PB_SAMPLE_CHAINS")
-        k = int(v) if v not in (None, "", "auto") else 1
-        return max(1, min(k, xt.shape[0]))
+        B, N = xt.shape[0], xt.shape[2]
+        # automatic: two chains for large batches of small clouds (config 2: +1.4 %, A/B 954-959 -> 968-973 k points/s: the
+        # ~50 small launches of one chain's evaluation run under the other chain's GEMMs), one otherwise
+        k = int(v) if v not in (None, "", "auto") else (2 if (B >= 16 and B % 2 == 0 and N <= 16384) else 1)
+        return max(1, min(k, B))
 
     def _ddpm_chains(self, net, xt, x_cond, clip, rev, table, log_steps, chains):
         """the reverse chain of _ddpm_once for `chains` sub-batches, each with its own captured step, static buffers and

@@ -18,31 +18,46 @@ lib = _lib.lib()
 buf = torch.zeros(16 * 65536, dtype=torch.int64, device="cuda")
 rc = lib.p2pb_conv_timeline_set(ctypes.c_void_p(buf.data_ptr()))
 assert rc == 0, rc
+import builtins  # noqa: E402
 import runpy  # noqa: E402
+
+builtins._p2pb_tl_buf = buf
 
 runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_conv_instances.py"))  # issues the launch 4 x
 torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(-1, 16)
 t = t[t[:, 1] != 0]
 ids, st = t[:, 0], t[:, 1:].astype(np.float64)
-nst = int(((st[0, 2:13] != 0).sum()) // 2)
+q = lambda a: f"{np.mean(a):.0f} (p10 {np.percentile(a, 10):.0f}, p90 {np.percentile(a, 90):.0f})"
+if os.environ["WHICH"] == "compact":
+    # slots: 0 start, 1 list in LDS, 2 first DMA issued, 3 + 2k / 4 + 2k stage k released / taps issued (k < 4), 11 loop done,
+    # 12 class constants staged, 13 active outputs stored, 14 constants + statistics written
+    print(f"{len(t)} workgroups (compact form); shader cycles (s_memtime), wave 0")
+    print("life", q(st[:, 14] - st[:, 0]))
+    print("start -> brick list in LDS", q(st[:, 1] - st[:, 0]))
+    has = st[:, 2] != 0
+    print(f"workgroups with a stage loop: {has.sum()}")
+    s2 = st[has]
+    print("list -> first DMA issued", q(s2[:, 2] - s2[:, 1]))
+    print("first DMA issued -> stage 0 released", q(s2[:, 3] - s2[:, 2]))
+    for k in range(4):
+        print(f"stage {k}: taps", q(s2[:, 4 + 2 * k] - s2[:, 3 + 2 * k]), "; to the next release", q((s2[:, 5 + 2 * k] if k < 3 else s2[:, 4 + 2 * k]) - s2[:, 4 + 2 * k]))
+    print("stage loop in all (first release -> loop done)", q(s2[:, 11] - s2[:, 3]))
+    print("class constants through LDS", q(s2[:, 12] - s2[:, 11]))
+    print("epilogue of the active outputs (-> barrier)", q(s2[:, 13] - s2[:, 12]))
+    print("constants + statistics of the other voxels", q(s2[:, 14] - s2[:, 13]))
+    sys.exit(0)
+nst = int(((st[0, 2:12] != 0).sum()) // 2)
 print(f"{len(t)} workgroups, {nst} stages; all times in shader cycles (s_memtime), wave 0 of each workgroup")
-life = st[:, 14] - st[:, 0]
-print(f"life {life.mean():.0f} (min {life.min():.0f}, max {life.max():.0f}); prologue to first DMA issued {np.mean(st[:, 1] - st[:, 0]):.0f}; "
-      f"first DMA issued -> stage 0 released {np.mean(st[:, 2] - st[:, 1]):.0f}")
+print("life", q(st[:, 14] - st[:, 0]), "; start -> first DMA issued", q(st[:, 1] - st[:, 0]), "; -> stage 0 released", q(st[:, 2] - st[:, 1]))
 for k in range(nst):
     rel, end = st[:, 2 + 2 * k], st[:, 3 + 2 * k]
     nxt = st[:, 4 + 2 * k] if k + 1 < nst else st[:, 13]
-    print(f"stage {k}: taps {np.mean(end - rel):.0f} (min {np.min(end - rel):.0f}); end of taps -> next release / accumulators final {np.mean(nxt - end):.0f}")
-print(f"epilogue (accumulators final -> stores acknowledged) {np.mean(st[:, 14] - st[:, 13]):.0f}")
-# co-residency: same XCC and same CU (HW_ID: cu_id bits 11:8, sh 12, se 15:13 on gfx9)
+    print(f"stage {k}: taps", q(end - rel), "; end of taps -> next release / accumulators final", q(nxt - end))
+print("epilogue (accumulators final -> stores acknowledged)", q(st[:, 14] - st[:, 13]))
 hw = ids & 0xffffffff
 xcc = (ids >> 32) & 0xf
 cu = (xcc << 16) | (hw & 0xff00)
-order = np.argsort(st[:, 0])
-span = st[:, 14].max() - st[:, 0].min()
-print(f"launch span {span:.0f} cycles; {len(np.unique(cu))} distinct (xcc, cu) ids")
-# matrix-phase overlap on each CU: fraction of the time at least one / both resident workgroups are inside a taps phase
 ev = []
 for c in np.unique(cu)[:64]:
     rows = st[cu == c]
@@ -59,4 +74,4 @@ for c in np.unique(cu)[:64]:
     tot = rows[:, 14].max() - rows[:, 0].min()
     ev.append((one / tot, two / tot, len(rows)))
 ev = np.array(ev)
-print(f"per CU (first 64): workgroups {ev[:, 2].mean():.1f}; time with >= 1 workgroup in a taps phase {ev[:, 0].mean():.2f}, with >= 2 {ev[:, 1].mean():.2f} of the CU's span")
+print(f"{len(np.unique(cu))} distinct (xcc, cu) ids; per CU (first 64): workgroups {ev[:, 2].mean():.1f}; time with >= 1 workgroup in a taps phase {ev[:, 0].mean():.2f}, with >= 2 {ev[:, 1].mean():.2f} of the CU's span")
