@@ -458,6 +458,13 @@ int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const f
                                      const float *bias, const float *bias_b, const float *in_scale,
                                      const float *in_shift, int in_swish, int flags, float *out, float *stats_part,
                                      int pool_u, float *minmax, void *stream);
+/* The same for the grouped tensor of a set abstraction WITHOUT building it: operand[ci, (mi, ui)] = zt[b, idx[b,mi,ui], ci]
+ * - cxt[b, mi, ci] gathered on load from the point-major rows zt f32[b,n,cin] / cxt f32[b,m,cin] (or NULL) -- exactly what
+ * p2pb_group_sub would have written as f32[b,cin,m*u] (call it with out = NULL for the statistics in_scale / in_shift are
+ * folded from). Split pack, f16x3 arithmetic, cin % 8 == 0; minmax f32[b,cout,m,2]; the output itself is never stored. */
+int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, int m, int u, const float *zt, const float *cxt,
+                                    const int *idx, const void *wp_split, const float *bias, const float *in_scale,
+                                    const float *in_shift, int in_swish, float *stats_part, float *minmax, void *stream);
 /* y = max(act(scale*min+shift), act(scale*max+shift)); nslots == 0: minmax f32[b,c,m,2] -> y f32[b,c,m];
  * nslots > 0: minmax f32[b,nslots,c,2] (reduced over nslots first) -> y f32[b,c] */
 int p2pb_minmax_act(int b, int c, int m, int nslots, const float *minmax, const float *scale, const float *shift,

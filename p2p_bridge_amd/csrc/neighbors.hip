@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void group_sub_kernel(int c, int n, int m, int
       const int cr = gacc.group ? wave * per + k : wave + 4 * k;
       const float v = tile[cr & 63][pt];  // zero outside the tensor: statistics unaffected
       if (k < per && c0 + cr < c) {
-        if (p0 + pt < mu) out[((size_t)b * c + c0 + cr) * mu + p0 + pt] = v;
+        if (out && p0 + pt < mu) out[((size_t)b * c + c0 + cr) * mu + p0 + pt] = v;  // (out == NULL: statistics only)
         const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
         if ((lane & 31) == 31) {
           if (gacc.group) gn_run_add(grun, gacc, b, c0 + cr, s1, s2);

@@ -214,7 +214,17 @@ __device__ __forceinline__ void group_minmax(float &mn, float &mx, int g) {
 // MFMAs were HALF the time of the set-abstraction neighbourhood layers, tools/exp_pw_wide_pool.py). `wp` is then the split
 // pack of pw_split_kernel (fragments read straight from L1 / L2, output scale in its trailer); 16 input channels per step:
 // lane (l31, khalf) loads rows 8 khalf .. + 7 of the step for its four positions, transforms and splits them once.
-template <int MT, bool XF, bool STATS, bool POOL, bool FX, int TERMS = 0>  // FX: see pw_split_kernel
+// GATHER (f16x3 form only): the operand is the GROUPED tensor of a set abstraction without ever being built --
+// operand[ci, p] = zt[idx[p]][ci] - cxt[p / gu][ci] from point-major rows zt f32[b, gn, cin] (`in`), cxt f32[b, P / gu, cin]
+// and the neighbour lists idx i32[b, P] (csrc/neighbors.hip group_sub_kernel's arithmetic, bit for bit): a lane fetches the
+// 8-channel piece of its four positions' rows (32 contiguous bytes each, L2-resident: the ungrouped tensor is 1 MB per
+// sample) instead of four channel-major quads of a 268 MB tensor that group_sub wrote and this kernel read back.
+struct PwGather {
+  const float *cxt;  // f32[b, P / gu, cin] or NULL
+  const int *idx;    // i32[b, P]
+  int gn, gu;        // points per cloud, neighbours per centre
+};
+template <int MT, bool XF, bool STATS, bool POOL, bool FX, int TERMS = 0, bool GATHER = false>  // FX: see pw_split_kernel
 __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int cout_pad, int P, int nslots,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias,
@@ -223,7 +233,8 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
                                                       const float *__restrict__ in_shift, int in_swish,
                                                       float *__restrict__ out, float *__restrict__ stats_part,
                                                       float *__restrict__ mm_out, int pool_g, int out_pm, GnFold fold,
-                                                      GnAcc gacc) {
+                                                      GnAcc gacc, PwGather gat = PwGather()) {
+  static_assert(!GATHER || TERMS == SPLIT_F16X3, "the gathered operand exists in the f16x3 form");
   // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
   // producer's accumulators (common.h) -- the one barrier of this kernel
   __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];
@@ -264,7 +275,42 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
     const unsigned voffh = (unsigned)(khalf * 8 * P + pc) * 4u, rowb = (unsigned)P * 4u;
     f32x4 braw[8];
     u32x4 a_nx[MT][2];
+    // GATHER: this lane's four neighbour rows and its centre row (positions pc .. pc + 3 share a centre: gu % 4 == 0)
+    int gid[4] = {0, 0, 0, 0};
+    const float *grow[4] = {nullptr, nullptr, nullptr, nullptr}, *gcen = nullptr;
+    if constexpr (GATHER) {
+      const int *ip = gat.idx + (size_t)b * P + pc;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        gid[t] = ip[t];
+        grow[t] = in + ((size_t)b * gat.gn + gid[t]) * cin;
+      }
+      if (gat.cxt) gcen = gat.cxt + ((size_t)b * (P / gat.gu) + pc / gat.gu) * cin;
+    }
     auto load_bh = [&](int ci0) {
+      if constexpr (GATHER) {
+        // rows are point-major: channels ci0 + 8 khalf .. + 7 of position t are 32 contiguous bytes (cin % 8 == 0)
+        const int cb = ci0 + 8 * khalf;
+        f32x4 cen[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+        if (gcen && cb < cin) {
+          cen[0] = *(const f32x4 *)(gcen + cb);
+          cen[1] = *(const f32x4 *)(gcen + cb + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 r0 = {0.0f, 0.0f, 0.0f, 0.0f}, r1 = r0;
+          if (cb < cin) {
+            r0 = *(const f32x4 *)(grow[t] + cb);
+            r1 = *(const f32x4 *)(grow[t] + cb + 4);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            braw[i][t] = gcen ? r0[i] - cen[0][i] : r0[i];          // (group_sub_kernel: v = z; v -= cx)
+            braw[4 + i][t] = gcen ? r1[i] - cen[1][i] : r1[i];
+          }
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int row = min(ci0 + i, cin - 1);  // rows at or beyond cin: zero records -> hardware zeros (x zero weights)
@@ -1167,6 +1213,36 @@ extern "C" int p2pb_pointwise_conv_pool_forward_fx(int b, int cin, int cout, int
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
                                   stats_part, minmax, g, 0, s, fold, gacc);
 }
+
+// The last layer of a set abstraction's MLP on the GROUPED tensor without building it (pw_wide_kernel<GATHER>):
+//   operand[ci, (mi, ui)] = zt[b, idx[b, mi, ui], ci] - cxt[b, mi, ci]   (zt f32[b,n,cin], cxt f32[b,m,cin] point-major,
+//   idx i32[b,m,u]: what p2pb_group_sub writes out as f32[b,cin,m*u]), folded norm + Swish applied on load, then the
+//   1x1 convolution with the statistics + neighbourhood {min, max} epilogue of p2pb_pointwise_conv_pool_forward (output
+//   never stored). wp_split = the split pack; f16x3 arithmetic; cin % 8 == 0, u in {4, 8, 16, 32, 64}.
+extern "C" int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, int m, int u, const float *zt,
+                                               const float *cxt, const int *idx, const void *wp_split, const float *bias,
+                                               const float *in_scale, const float *in_shift, int in_swish,
+                                               float *stats_part, float *minmax, void *stream) {
+  const long npos = (long)m * u;
+  if (b <= 0 || cin <= 0 || cout <= 0 || n <= 0 || m <= 0 || !zt || !idx || !wp_split || !in_scale || !in_shift ||
+      !stats_part || !minmax || (cin & 7) || npos > 0x7fffffffL || !p2pb_pointwise_pool_supported((int)npos, u) || u == 0 ||
+      cin > P2PB_FOLD_MAXC || p2pb_g_split_terms != SPLIT_F16X3 || (((uintptr_t)zt | (uintptr_t)cxt) & 15))
+    return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int P = (int)npos, nslots = (P + 255) / 256 * 4, gl = pool_lanes(u);
+  const PwGather gat = {cxt, idx, n, u};
+  const float *wsp = (const float *)wp_split;
+#define LAUNCHG(MTV)                                                                                                      \
+  hipLaunchKernelGGL((pw_wide_kernel<MTV, true, true, true, false, SPLIT_F16X3, true>),                                   \
+                     dim3((P + 511) / 512, (cout + 32 * MTV - 1) / (32 * MTV), b), dim3(256), 0, s, cin, cout,             \
+                     pw_cout_pad(cout), P, nslots, zt, wsp, bias, (const float *)nullptr, in_scale, in_shift, in_swish,    \
+                     (float *)nullptr, stats_part, minmax, gl, 0, GnFold(), GnAcc(), gat)
+  if (cout > 32) LAUNCHG(2);
+  else LAUNCHG(1);
+#undef LAUNCHG
+  return p2pb_launch_status();
+}
+
 
 // y = max(act(scale*min + shift), act(scale*max + shift)):
 //   nslots == 0: minmax f32[b, c, m, 2] -> y f32[b, c, m]      (set-abstraction neighbour max)

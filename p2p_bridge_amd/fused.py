@@ -648,7 +648,35 @@ def minmax_act(mm, scale, shift, swish=True, global_pool=False):
     return y
 
 
-def group_sub(z, cx, idx, point_major=False, acc_groups=None):
+def gather_pool_supported(ci: int, co: int, m: int, u: int) -> bool:
+    """can pw_conv_pool_gather run the last set-abstraction layer ci -> co over (m centres x u neighbours) on the gathered
+    operand? (the narrow-layer f16x3 kernel: not the LDS-tiled GEMM's shapes; 32-byte row pieces; a supported pool)"""
+    return (conv_math() == "f16x3" and lib().p2pb_get_split_terms() == 16 and not gn_acc_enabled() and ci % 8 == 0
+            and not use_split_pw(ci, co, m * u) and use_wide_f16(ci, co) and pool_supported(m * u, u) and u > 0
+            and os.environ.get("P2PB_SA_GATHER", "1") != "0")
+
+
+def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True):
+    """the last 1x1 layer of a set abstraction on the grouped tensor WITHOUT building it: operand[ci, (m, u)] =
+    zt[b, idx[b,m,u], ci] - cxt[b, m, ci] gathered on load (zt f32[B,N,Ci], cxt f32[B,M,Ci] point-major, idx i32[B,M,U]:
+    what group_sub would write as f32[B,Ci,M*U]), folded norm + Swish on load, statistics + neighbourhood {min, max}
+    epilogue -> (stats partials f32[B,nslots,Co,2], minmax f32[B,Co,M,2])"""
+    check(zt, F32, "zt")
+    b, n, ci = zt.shape
+    m, u = idx.shape[1], idx.shape[2]
+    co = conv.weight.shape[0]
+    p = m * u
+    wp = pack_pointwise_weight(conv, 0, None, True)
+    in_scale, in_shift = _arrays_of(in_scale, in_shift)
+    nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
+    st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=zt.device)
+    mm = torch.empty(b, co, m, 2, dtype=F32, device=zt.device)
+    call("p2pb_pointwise_conv_pool_gather", _i(b), _i(ci), _i(co), _i(n), _i(m), _i(u), ptr(zt), ptr(cxt), ptr(idx), ptr(wp),
+         ptr(conv.bias), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(st), ptr(mm), stream_ptr())
+    return st, mm
+
+
+def group_sub(z, cx, idx, point_major=False, acc_groups=None, stats_only=False):
     """z f32[B,C,N], cx f32[B,C,M] | None, idx i32[B,M,U] -> (y f32[B,C,M*U] = z[:, :, idx] - cx[:, :, :, None],
     GroupNorm partials f32[B,nslots,C,2]): the grouped output of a set abstraction's first layer when that layer
     was applied to the ungrouped points (csrc/neighbors.hip group_sub_kernel). point_major: z f32[B,N,C] and
@@ -659,7 +687,8 @@ def group_sub(z, cx, idx, point_major=False, acc_groups=None):
     else:
         b, c, n = z.shape
     m, u = idx.shape[1], idx.shape[2]
-    y = torch.empty(b, c, m * u, dtype=F32, device=z.device)
+    # stats_only: only the GroupNorm partials of the grouped tensor (the consumer gathers it itself: pw_conv_pool_gather)
+    y = None if stats_only else torch.empty(b, c, m * u, dtype=F32, device=z.device)
     st = acc = None
     if acc_groups and gn_acc_enabled("gsub"):
         acc = Acc(b, c, acc_groups, False, z.device)

@@ -536,9 +536,20 @@ class PointNetSAModule(nn.Module):
                 pm = xin.shape[2] % 4 == 0 and cen.shape[2] % 4 == 0  # both GEMMs can write point-major rows
                 z, _ = fused.pw_conv(xin, conv0, stats=False, point_major=pm)
                 cx, _ = fused.pw_conv(cen, conv0, stats=False, ci_lo=0, ci_hi=3, use_bias=False, point_major=pm)
-                y, st = fused.group_sub(z, cx, nidx, point_major=pm, acc_groups=norm_groups(mlp.layers[1]))
                 M, U = nidx.shape[1], nidx.shape[2]
-                data.features = mlp._run_fused(y.view(y.shape[0], y.shape[1], M, U), data.cond, True, None, first=st)
+                c1 = conv0.weight.shape[0]
+                if pm and len(mlp.layers) == 6 and fused.gather_pool_supported(c1, mlp.layers[3].weight.shape[0], M, U):
+                    # two-layer MLP: the grouped tensor [B, C1, M, U] (268 MB at the first level of the bench) is never
+                    # built -- one pass over the gathered rows for its GroupNorm statistics, then the last layer gathers
+                    # its operand itself and emits the statistics + {min, max} the max-pool is formed from
+                    _, st = fused.group_sub(z, cx, nidx, point_major=True, stats_only=True)
+                    sc, sh = norm_affine(mlp.layers[1], st, M * U, data.cond)
+                    st2, mm = fused.pw_conv_pool_gather(z, cx, nidx, mlp.layers[3], sc, sh, True)
+                    sc2, sh2 = norm_affine(mlp.layers[4], st2, M * U, data.cond)
+                    data.features = fused.minmax_act(mm, sc2, sh2)
+                else:
+                    y, st = fused.group_sub(z, cx, nidx, point_major=pm, acc_groups=norm_groups(mlp.layers[1]))
+                    data.features = mlp._run_fused(y.view(y.shape[0], y.shape[1], M, U), data.cond, True, None, first=st)
             else:
                 grouped = L._ext.group_concat(coords.contiguous(), centers, data.features.contiguous(), nidx)
                 data.features = mlp.run(grouped, data.cond, reduce_max=True)

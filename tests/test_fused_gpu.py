@@ -421,3 +421,33 @@ def test_conv3d_compact_matches_dense(fused, r, C, C1, C2, N):
         xin = swish(y1d.double() * sc[:, None, None, None, :] + sh[:, None, None, None, :]).permute(0, 4, 1, 2, 3)
         ref = torch.nn.functional.conv3d(xin, conv2.weight.double(), conv2.bias.double(), padding=1)
         assert rel_err(y2c.permute(0, 4, 1, 2, 3), ref) < TOL
+
+
+@pytest.mark.parametrize("B,N,M,U,C1,C2", [(2, 2048, 256, 32, 32, 64), (3, 500, 100, 16, 64, 128), (1, 300, 37, 8, 40, 24), (2, 1024, 64, 32, 32, 64)])
+def test_set_abstraction_last_layer_on_the_gathered_operand(fused, B, N, M, U, C1, C2):
+    """pw_conv_pool_gather (pw_wide_kernel<GATHER>): the last 1x1 layer of a set abstraction reads z[idx] - cx itself
+    instead of the grouped tensor group_sub would write (models/pvcnn.py:117-126, :414): statistics partials and
+    neighbourhood {min, max} are BIT-identical to the two-kernel path, and group_sub(stats_only=True) returns the same
+    partials without writing the tensor"""
+    if fused.conv_math() != "f16x3":
+        pytest.skip("f16x3 form")
+    torch.manual_seed(B * 7 + U)
+    z = torch.randn(B, N, C1, device="cuda")
+    cx = torch.randn(B, M, C1, device="cuda")
+    idx = torch.randint(0, N, (B, M, U), device="cuda", dtype=torch.int32)
+    conv = torch.nn.Conv2d(C1, C2, 1).cuda()
+    sc, sh = torch.rand(B, C1, device="cuda") + 0.5, torch.randn(B, C1, device="cuda")
+    with torch.no_grad():
+        y, st = fused.group_sub(z, cx, idx, point_major=True)
+        _, st_only = fused.group_sub(z, cx, idx, point_major=True, stats_only=True)
+        assert _ is None and torch.equal(st, st_only)
+        ref = (z.gather(1, idx.view(B, M * U, 1).long().expand(-1, -1, C1)).view(B, M, U, C1) - cx[:, :, None, :]).permute(0, 3, 1, 2)
+        assert torch.equal(y.view(B, C1, M, U), ref)
+        assert fused.gather_pool_supported(C1, C2, M, U)
+        _, st_a, mm_a = fused.pw_conv(y, conv, sc, sh, swish=True, pool_u=U, store=False)
+        st_b, mm_b = fused.pw_conv_pool_gather(z, cx, idx, conv, sc, sh, True)
+        assert torch.equal(st_a, st_b) and torch.equal(mm_a, mm_b)
+        # and against fp64: max over the neighbourhood of the layer's raw output
+        h = swish(ref.double() * sc[:, :, None, None] + sh[:, :, None, None])
+        out = torch.einsum("oc,bcmu->bomu", conv.weight.view(C2, C1).double(), h) + conv.bias.double()[None, :, None, None]
+        assert rel_err(mm_b[..., 1], out.amax(-1)) < TOL and rel_err(mm_b[..., 0], out.amin(-1)) < TOL
