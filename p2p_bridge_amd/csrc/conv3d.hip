@@ -473,18 +473,10 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
     const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
     u32x4 a_nxt[3];
-#ifdef CONV_EXP_NOA  // timing experiment: one weight fragment set for all taps (no A stream through the L1)
-#pragma unroll
-    for (int s = 0; s < NP; ++s) a_nxt[s] = a_cur[s];
-#else
     if (tap + 1 < CONV_NTAPS) {
 #pragma unroll
       for (int s = 0; s < NP; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
     }
-#endif
-#ifdef CONV_EXP_NOB  // timing experiment: the B fragments of tap 0 for all taps (no LDS reads in the tap loop)
-    if (tap == 0)
-#endif
     load_b(0, toff);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TERMS == 6) {
@@ -498,9 +490,7 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     }
     mfma_term(0, 1);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef CONV_EXP_NOB
     if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TERMS != 6) mfma_term(1, 0);
     mfma_term(0, 0);
@@ -520,9 +510,7 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
 __device__ __forceinline__ u32x4 conv_wload(__amdgpu_buffer_rsrc_t rs, unsigned wv, unsigned so) {
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wv, so, 0));
 }
-#ifndef CONV_PRE_AD
-#define CONV_PRE_AD 2  // taps of weight prefetch; the ring has CONV_PRE_AD + 1 slots, which must divide 27 (2 or 8)
-#endif
+#define CONV_PRE_AD 2  // taps of weight prefetch; the ring has CONV_PRE_AD + 1 slots, which must divide 27 (8 measured +-0)
 static_assert(27 % (CONV_PRE_AD + 1) == 0, "the ring position of tap 0 must be the same in every stage");
 template <int NT, int HH, int HW, int PLANE>
 __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, __amdgpu_buffer_rsrc_t rsw,
@@ -550,7 +538,6 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
     const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
     constexpr int AD = CONV_PRE_AD;
     const int cur = tap % (AD + 1), nx2 = (tap + AD) % (AD + 1), par = tap & 1;
-#ifndef CONV_PRE_NOA  // (timing experiment: no weight stream in the loop)
     if (tap + AD < CONV_NTAPS) {
       const unsigned so = sbase + (unsigned)(tap + AD) * tap_bytes;
 #pragma unroll
@@ -560,26 +547,16 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
 #pragma unroll
       for (int s = 0; s < 2; ++s) a[nx2][s] = conv_wload(rsw, wv, so + s * plane_bytes);
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], b1[n], acc[n]);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef CONV_PRE_NOB  // (timing experiment: the B fragments of tap 0 for all taps)
     if (tap + 1 < CONV_NTAPS) load_b1(toff_n);
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][1], b0[par][n], acc[n]);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef CONV_PRE_NOB
     if (tap + 1 < CONV_NTAPS) load_b0(par ^ 1, toff_n);
-#else
-    if (tap + 1 < CONV_NTAPS) {
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b0[par ^ 1][n] = b0[par][n];
-    }
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], b0[par][n], acc[n]);
@@ -673,19 +650,11 @@ __device__ __forceinline__ conv_i32x4 conv_make_rsrc(const void *p, unsigned byt
 // FX: the sampler path's statistics plumbing (operand norm folded here from accumulators / output statistics added to
 // accumulators, common.h) is compiled in -- a separate instantiation (voxel-major form only), so that the plain form
 // carries neither the two argument structs nor the table
-// CONV_PRE_SINGLE (experiment builds): the PRE kernels with ONE operand buffer (38 KB) and three workgroups per CU instead
-// of two buffers and two workgroups: a stage's DMA is then issued and awaited between two barriers (its latency covered
-// by the other two workgroups instead of by the workgroup's own taps)
-#ifdef CONV_PRE_SINGLE
-#define CONV_PRE_WAVES(PRE_) ((PRE_) ? 3 : CONV_F16_WAVES)
-#else
-#define CONV_PRE_WAVES(PRE_) CONV_F16_WAVES
-#endif
 #ifndef CONV_F16_WAVES
 #define CONV_F16_WAVES 2  // (waves per SIMD the f16x3 forms are compiled for; their two-plane tile would fit three workgroups)
 #endif
 template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX, int TERMS, bool PRE = false>
-__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
+__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
                                                              const float *__restrict__ bias,
@@ -712,11 +681,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
   // (PRE: the second stage buffer is its OWN object, and the stage loop is unrolled by two with the roles fixed, so that
   //  the compiler can tell the LDS-DMA into one buffer from the fragment reads of the other -- with one array it waits
   //  vmcnt(0) for the DMA burst of stage k + 1 in front of the first ds_read of stage k)
-#ifdef CONV_PRE_SINGLE
-  __shared__ u32x4 tile2[1];
-#else
   __shared__ u32x4 tile2[PRE ? split_planes(TERMS) * 2 * PLANE : 1];
-#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -804,9 +769,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
     PreStage<R, HD, HH, HW> ps;
     ps.init(tid, d0, h0, w0, nchunk);
     const conv_i32x4 sg = conv_make_rsrc((const u32x4 *)in + (size_t)b * R3 * nchunk * 4, (unsigned)(R3 * nchunk * 64));
-#ifndef CONV_PRE_SINGLE
     ps.issue(sg, 0, tile, tid);
-#endif
     CONV_TL(tid);  // 1: first DMA issued
     // weights: [tap][stage][plane 3][khalf 2][cout_pad] of 16 bytes
     const unsigned stage_bytes = 6u * cout_pad * 16u, tap_bytes = (unsigned)nchunk * stage_bytes, plane_bytes = 2u * cout_pad * 16u;
@@ -818,25 +781,10 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
 #pragma unroll
       for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
     auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
-#ifdef CONV_PRE_SINGLE
-      __syncthreads();  // every wave is done with the previous stage's fragments
-      ps.issue(sg, k, tile, tid);
-      __builtin_amdgcn_s_waitcnt(0x0f70);
-      __syncthreads();
-      CONV_TL(tid);
-      split_taps_pre<NT, HH, HW, PLANE>(acc, tile, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
-                                        k + 1 < nchunk, nbase, khalf, aring);
-      CONV_TL(tid);
-      return;
-#endif
-#ifndef CONV_PRE_NOBAR  // (timing experiment: stages not ordered)
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): my share of stage k has landed (and the weights of its first taps)
       __syncthreads();                     // everyone's has; the other buffer is no longer read
-#endif
       CONV_TL(tid);  // 2 + 2k: stage k released
-#ifndef CONV_PRE_NODMA  // (timing experiment: no operand stream)
       if (k + 1 < nchunk) ps.issue(sg, k + 1, nxt, tid);
-#endif
       split_taps_pre<NT, HH, HW, PLANE>(acc, cur, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
                                         k + 1 < nchunk, nbase, khalf, aring);
       CONV_TL(tid);  // 3 + 2k: taps of stage k issued
@@ -1017,11 +965,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
         if (l31 == 31 && cok) gn_run_add(grun, gacc, b, co, s1, s2);
-      }
-#ifdef CONV_EXP_NOSTATS  // (timing experiment: no statistics)
-      else if (s1 == 12345.678f && stats_part) stats_part[0] = s2;
-#endif
-      else if (stats_part) {
+      } else if (stats_part) {
         // the brick's four statistics slots: wave column wn fills slot wn for its channels; with two wave rows
         // only two columns exist and slots 2, 3 are zeroed
         s1 = halfwave_sum_to_last(s1);
@@ -1038,12 +982,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
         }
       }
     }
-#ifdef CONV_EXP_NOSTORE  // (timing experiment: outputs not stored)
-    if (vv[0][0] == 12345.678f) outb[0] = vv[NT - 1][3];
-    if (false) {
-#else
     if (CL) {
-#endif
       const int cq = co0 + 8 * g + 4 * khalf;
 #pragma unroll
       for (int s = 0; s < NT; ++s) {
@@ -1752,7 +1691,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
 #endif
 
 template <int R, int WM, bool XF, bool FX, int TERMS, bool PRE = false>  // FX, TERMS, PRE: see conv3d_k3_split_kernel
-__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
+__global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                                 const float *__restrict__ in,
                                                                 const unsigned short *__restrict__ wt,
                                                                 const float *__restrict__ bias,
@@ -1772,11 +1711,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
   constexpr int WN = 4 / WM;
   static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF && !FX), "pre-split operands: f16x3, no fold");
   __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
-#ifdef CONV_PRE_SINGLE
-  __shared__ u32x4 tile2[1];
-#else
   __shared__ u32x4 tile2[PRE ? split_planes(TERMS) * 2 * PLANE : 1];  // (its own object: see the split kernel)
-#endif
   __shared__ unsigned char lst[256];
   __shared__ int ncls[27];
   __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
@@ -1890,9 +1825,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
       PreStage<R, HD, HH, HW> ps;
       ps.init(tid, d0, h0, w0, nchunk);
       const conv_i32x4 sg = conv_make_rsrc((const u32x4 *)in + (size_t)b * R3 * nchunk * 4, (unsigned)(R3 * nchunk * 64));
-#ifndef CONV_PRE_SINGLE
       ps.issue(sg, 0, tile, tid);
-#endif
       CONV_TL(tid);  // 2: first DMA issued
       const unsigned stage_bytes = 6u * cout_pad * 16u, tap_bytes = (unsigned)nchunk * stage_bytes, plane_bytes = 2u * cout_pad * 16u;
       auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)wt, 0, 27 * (int)tap_bytes, 0x00020000);
@@ -1905,16 +1838,6 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_PRE_WAVES(PRE) : 2
           for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
       }
       auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
-#ifdef CONV_PRE_SINGLE
-        __syncthreads();
-        ps.issue(sg, k, tile, tid);
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        if (NTC > 0)
-          split_taps_pre<NA, HH, HW, PLANE>(acc, tile, rsw, wv, (unsigned)k * stage_bytes, stage_bytes, tap_bytes, plane_bytes,
-                                            k + 1 < nchunk, nbase, khalf, aring);
-        return;
-#endif
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
         __syncthreads();
         if (k < 4) CONV_TL_AT(tid, 3 + 2 * k);  // stage k released (k < 4)

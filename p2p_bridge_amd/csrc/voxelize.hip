@@ -383,6 +383,44 @@ __global__ __launch_bounds__(256) void vox_gather_cl_split_kernel(int c, int nch
   dst[2] = p1;
 }
 
+// Occupied voxels only, after a streaming zero-fill of the split grid (the fp16 pair of 0 is all-zero bits): the form for
+// channel counts that are not a multiple of 4 (the 3 + 32 channels of the first PVConv: scalar point-row loads, and at
+// r = 32 at most a quarter of the voxels is occupied -- the one-pass kernel above took 159 us per 16 patches there)
+__global__ __launch_bounds__(256) void vox_gather_cl_occ_split_kernel(int c, int nchunk, int n, int r3,
+                                                                      const int *__restrict__ cnt, const int *__restrict__ cur,
+                                                                      const int *__restrict__ occ, const int *__restrict__ nocc,
+                                                                      const int *__restrict__ slist,
+                                                                      const float *__restrict__ feat_t, u32x4 *__restrict__ out) {
+  const int b = blockIdx.y, ng = nchunk * 2;
+  const size_t total = (size_t)nocc[b] * ng;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int k = (int)(e / ng), g = (int)(e % ng), ch = g * 8;
+    const int v = occ[(size_t)b * n + k];
+    const int cn = cnt[(size_t)b * r3 + v];
+    const int *seg = slist + (size_t)b * n + (cur[(size_t)b * r3 + v] - cn);
+    const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
+    const float *f = feat_t + (size_t)b * n * c + ch;
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    for (int q = 0; q < cn; ++q) {
+      const float *fq = f + (size_t)seg[q] * c;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (ch + i < c) acc[i] += fq[i] * div;
+    }
+    u32x4 p0, p1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned a0, a1, a2;
+      split_pair<SPLIT_F16X3>(acc[2 * i], acc[2 * i + 1], a0, a1, a2);
+      p0[i] = a0;
+      p1[i] = a1;
+    }
+    u32x4 *dst = out + (((size_t)b * r3 + v) * nchunk + (g >> 1)) * 4 + (g & 1);
+    dst[0] = p0;
+    dst[2] = p1;
+  }
+}
+
 // The coordinate-only half of the voxelisation (occupancy counts + per-voxel sorted point lists): it depends on
 // the voxel coordinates alone, so the sampler runs it once per (level, resolution) on the geometry stream and every
 // PVConv of that level reuses it. ws: p2pb_avg_voxelize_ws_bytes(b,n,r) bytes, consumed by ..._cl_gather.
@@ -449,6 +487,18 @@ extern "C" int p2pb_avg_voxelize_cl_gather_split(int b, int c, int n, int r, con
   const int *cur = (const int *)ws;
   const int *slist = cur + (size_t)b * r3 + (size_t)b * n;
   hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, feat, feat_t);
+  static const int onepass = getenv("P2PB_VOX_ONEPASS") ? atoi(getenv("P2PB_VOX_ONEPASS")) : -1;  // (A/B switch: 0 / 1 force)
+  if (onepass == 0 || (onepass < 0 && (c & 3) != 0)) {  // zero-fill + occupied voxels only (the rule of p2pb_avg_voxelize_cl_gather)
+    const int *occ = slist + (size_t)b * n;
+    const int *nocc = occ + (size_t)b * n;
+    const int maxocc = n < r3 ? n : r3;
+    const int e = p2pb_zero_async(out_split, (size_t)b * r3 * nchunk * 64, s);
+    if (e != 0) return e;
+    const size_t nwg = cdiv((size_t)maxocc * nchunk * 2, 256);
+    hipLaunchKernelGGL(vox_gather_cl_occ_split_kernel, dim3((unsigned)(nwg > 65536 ? 65536 : nwg), b), dim3(256), 0, s, c,
+                       nchunk, n, r3, cnt, cur, occ, nocc, slist, feat_t, (u32x4 *)out_split);
+    return p2pb_launch_status();
+  }
   const dim3 grid((unsigned)cdiv((size_t)r3 * nchunk * 2, 256), b);
   if ((c & 3) == 0)
     hipLaunchKernelGGL(vox_gather_cl_split_kernel<true>, grid, dim3(256), 0, s, c, nchunk, n, r3, cnt, cur, slist, feat_t,
