@@ -240,7 +240,10 @@ def cpu_baseline(sd, n_points, T, patches=2, budget_s=20.0):
     x, _ = net_ref.synthetic_patches(patches, n_points, seed=0)
     net = net_ref.RefNet(PVDS, sd, vox_mode="tree")
     host = os.cpu_count() or 1
-    cores = min(host, 32)  # threads actually used: beyond ~32 these small per-patch ops only contend
+    # threads actually used: 16 -- measured on the GPU box's host (2 x 64-core EPYC 9575F, 256 hardware threads;
+    # tools/exp_cpu_threads.sh -> profiles/r03b_cpu_baseline_threads.txt: 8 / 16 / 32 / 64 / 128 / 256 threads =
+    # 1508 / 1523 / 1264 / 700 / 195 / 7 points/s): beyond that these small per-patch ops only contend
+    cores = min(host, int(os.environ.get("P2PB_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     from oracle import cpu_ops

@@ -26,6 +26,15 @@
 // order: deterministic), {min, max} per slot for the global pooling (pool_u == 0 only), optional channel-major stores.
 #pragma once
 
+#ifdef PP_TIMELINE  // experiment builds (tools/exp_pp_timeline.py): s_memtime at four points of wave 0, kept in scalar
+__device__ unsigned long long *pp_tl_buf;  // registers and stored at the very end (a store in between would shift the
+extern "C" int p2pb_pp_timeline_set(void *p) {  // hand-counted vmcnt waits of the stage loop)
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(pp_tl_buf), &p, sizeof(p));
+}
+#define PP_TL(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define PP_TL(var)
+#endif
 #define PP_CK 32
 #define PP_TILE 2048  // 16-byte groups per operand tile per stage (32 KB)
 #define PP_LDS_BYTES (5 * PP_TILE * 16)  // A x 3, B x 2: all 160 KB of the CU
@@ -264,6 +273,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     }
   };
 
+  PP_TL(tl0);
   if (grp == 1) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every arbitration otherwise (+4..8 %)
   // ---- prologue. VMEM queue, oldest first: loads(0) loads(1) DMA(0) DMA(1) | loads(2)
   load_b(0, 0);
@@ -274,6 +284,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   stage_b(0, 0, 0);
   load_b(2, 0);
   PP_BARRIER(12);  // DMA(0) has landed
+  PP_TL(tl1);
   // Interval s (between barriers s and s + 1): half 0 runs [DMA A(s+2); multiply(s); stage B(s+1); loads(s+3)], half 1
   // [DMA A(s+2); stage B(s+1); loads(s+3); multiply(s)] -- written as ONE loop body with the multiply in common code
   // (half 1 is the same stream rotated by half an interval: its staging sits behind the barrier), because a two-sided
@@ -316,6 +327,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     }
   }
   PP_VMCNT(0);  // nothing of this workgroup may still be on its way into LDS when the waves retire
+  PP_TL(tl2);
 
 #ifdef PP_EXP_NOEPI
   {
@@ -394,4 +406,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
       q[1] = mx;
     }
   }
+#ifdef PP_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0 && pp_tl_buf) {
+    unsigned long long *q = pp_tl_buf + (size_t)lin * 4;
+    q[0] = tl0, q[1] = tl1, q[2] = tl2, q[3] = __builtin_readcyclecounter();
+  }
+#endif
 }

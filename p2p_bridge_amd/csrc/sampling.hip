@@ -303,8 +303,10 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
     (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)fps_kernel<1024, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     (void)hipFuncSetAttribute((const void *)fps_kernel<512, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    (void)hipFuncSetAttribute((const void *)fps_kernel<512, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     attr_set = true;
   }
+  static const bool fps_mid_wide = !(getenv("P2PB_FPS_MID") && atoi(getenv("P2PB_FPS_MID")) == 1024);
   if (n <= 64) fps_launch<64, 1>(b, n, m, coords, idx, s);
   else if (n <= 128) fps_launch<64, 2>(b, n, m, coords, idx, s);
   else if (n <= 256) fps_launch<64, 4>(b, n, m, coords, idx, s);
@@ -313,7 +315,8 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
   else if (n <= 2048) fps_launch<256, 8>(b, n, m, coords, idx, s);
   else if (n <= 4096) fps_launch<1024, 4>(b, n, m, coords, idx, s);
   else if (n <= 8192) fps_launch<512, 16>(b, n, m, coords, idx, s);  // 8 waves: 1.71 ms vs 2.10 with 16 x 8 points
-  else if (n <= 16384) fps_launch<1024, 16>(b, n, m, coords, idx, s);
+  else if (n <= 16384 && fps_mid_wide) fps_launch<512, 32>(b, n, m, coords, idx, s);  // 8 waves x 32 points per lane: the round is
+  else if (n <= 16384) fps_launch<1024, 16>(b, n, m, coords, idx, s);                  // bound by the reduction ACROSS waves (A/B: P2PB_FPS_MID=1024)
   else {
     if (!dist_ws) return P2PB_EINVAL;
     hipLaunchKernelGGL(fps_big_kernel, dim3(b), dim3(1024), 0, s, n, m, coords, dist_ws, idx, (const int *)nullptr);
