@@ -22,8 +22,9 @@
 // (32 KB, THREE buffers: DMA'd two stages ahead); B tile = [kstep][plane][khalf][256 positions] x 16 B (32 KB, two buffers), position p at slot p (lane l of N-tile n reads
 // slot 32 n + l: 16 consecutive 16-byte slots per LDS service group, conflict-free; staging lane l writes slots 2l and
 // 2l + 1 with two b128 stores, 32-byte stride: conflict-free).
-// Outputs exactly as pw_split_kernel: per-(sample, 64-position slot, channel) {sum, sum of squares} partials (fixed
-// order: deterministic), {min, max} per slot for the global pooling (pool_u == 0 only), optional channel-major stores.
+// Outputs in pw_split_kernel's layout: per-(sample, 64-position slot, channel) {sum, sum of squares} partials (fixed
+// order: deterministic; a wave's 128 positions land in its even slot, zero in the odd one), {min, max} per slot for the
+// global pooling (pool_u == 0 only; the wave's extrema in both of its slots), optional channel-major stores.
 #pragma once
 
 #ifdef PP_TIMELINE  // experiment builds (tools/exp_pp_timeline.py): s_memtime at four points of wave 0, kept in scalar
@@ -370,40 +371,51 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   }
   const int rm = l31 >> 4, rr = l31 & 15;
   const int rco = co0 + wm * 64 + rm * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * khalf;  // this lane's row after a rowreduce32
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {  // the wave's two 64-position slots
-    const int slot = (pw0 >> 6) + j;
+  // ONE reduction set per wave (its 128 positions = two 64-position slots of the partials' layout): the four tiles of a row
+  // are combined per lane first, then one reduce-scatter per statistic -- 4 instead of 8 (the epilogue was 21 k of a
+  // workgroup's 112 k cycles, profiles/r03b_pingpong_timeline.txt, nearly all of it these reductions). The sums go to the
+  // wave's even slot and zero to the odd one; the extrema (whose consumer takes a min / max over slots) go to both.
+  {
+    const int slot = pw0 >> 6;  // even
     float tv[32];
     if (stats_part) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tv[m * 16 + r] = acc[m][2 * j][r] + acc[m][2 * j + 1][r];
+        for (int r = 0; r < 16; ++r) tv[m * 16 + r] = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
       const float s1 = rowreduce32<RowAdd>(tv);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          tv[m * 16 + r] = acc[m][2 * j][r] * acc[m][2 * j][r] + acc[m][2 * j + 1][r] * acc[m][2 * j + 1][r];
+          tv[m * 16 + r] = (acc[m][0][r] * acc[m][0][r] + acc[m][1][r] * acc[m][1][r]) +
+                           (acc[m][2][r] * acc[m][2][r] + acc[m][3][r] * acc[m][3][r]);
       const float s2 = rowreduce32<RowAdd>(tv);
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
       q[0] = s1;
       q[1] = s2;
+      float *z = q + (size_t)cout * 2;  // slot + 1
+      z[0] = 0.0f;
+      z[1] = 0.0f;
     }
     if (POOL && pool_u == 0) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tv[m * 16 + r] = fminf(acc[m][2 * j][r], acc[m][2 * j + 1][r]);
+        for (int r = 0; r < 16; ++r)
+          tv[m * 16 + r] = fminf(fminf(acc[m][0][r], acc[m][1][r]), fminf(acc[m][2][r], acc[m][3][r]));
       const float mn = rowreduce32<RowMin>(tv);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tv[m * 16 + r] = fmaxf(acc[m][2 * j][r], acc[m][2 * j + 1][r]);
+        for (int r = 0; r < 16; ++r)
+          tv[m * 16 + r] = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
       const float mx = rowreduce32<RowMax>(tv);
       float *q = mm_out + (((size_t)b * (P / 64) + slot) * cout + rco) * 2;
       q[0] = mn;
       q[1] = mx;
+      q[(size_t)cout * 2] = mn;  // slot + 1
+      q[(size_t)cout * 2 + 1] = mx;
     }
   }
 #ifdef PP_TIMELINE
