@@ -47,6 +47,9 @@ const char *p2pb_target_arch(void); /* "gfx950" */
  * functions pack for the arithmetic selected when they are called: re-pack after a switch.
  * -> 0, or P2PB_EINVAL for anything but 6 or 16. */
 int p2pb_set_split_terms(int terms);
+/* the same for the CALLING THREAD only (0 clears it): a temporary switch, e.g. around one backward pass, that other
+ * threads' launches and weight packs do not see; p2pb_get_split_terms returns what a launch from this thread would use */
+int p2pb_set_split_terms_thread(int terms);
 int p2pb_get_split_terms(void);
 
 /* Voxelization.forward normalisation (models/pvcnn.py:215-228): centre on the mean, divide by

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("P2PB_LIB_PATH") or os.path.join(_HERE, "libp2pb_hip.s
 
 # every symbol include/p2pb_hip.h declares (tests/test_abi.py checks the two lists agree)
 SYMBOLS = [
-    "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_get_split_terms", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
+    "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_set_split_terms_thread", "p2pb_get_split_terms", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
     "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_avg_voxelize_cl_gather_split", "p2pb_conv3d_presplit",
     "p2pb_conv3d_k3_forward_compact_pre", "p2pb_trilinear_devoxelize_forward",
     "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats",

@@ -4,14 +4,25 @@
 extern "C" int p2pb_version(void) { return 1; }
 extern "C" const char *p2pb_target_arch(void) { return "gfx950"; }
 
-// products per split operand pair in the bf16 matrix kernels (common.h)
-int p2pb_g_split_terms = SPLIT_F16X3;
+// Arithmetic of the split-operand kernels (common.h SPLIT_*): a process-wide default (p2pb_set_split_terms: set_conv_math)
+// and a per-THREAD override (p2pb_set_split_terms_thread: `with fused.split_math(...)`, e.g. the bf16x6 data-gradient pass
+// that train() runs on the autograd thread) -- so a temporary switch on one thread cannot pair another thread's f16 weight
+// pack with a bf16x6 kernel (round-2 advice). Every launcher and pack reads p2pb_split_terms_now().
+#include <atomic>
+static std::atomic<int> g_split_terms{SPLIT_F16X3};
+static thread_local int tl_split_terms = 0;  // 0: no override on this thread
+int p2pb_split_terms_now() { return tl_split_terms ? tl_split_terms : g_split_terms.load(std::memory_order_relaxed); }
 extern "C" int p2pb_set_split_terms(int terms) {
   if (terms != SPLIT_BF16X6 && terms != SPLIT_F16X3) return P2PB_EINVAL;
-  p2pb_g_split_terms = terms;
+  g_split_terms.store(terms, std::memory_order_relaxed);
   return 0;
 }
-extern "C" int p2pb_get_split_terms(void) { return p2pb_g_split_terms; }
+extern "C" int p2pb_set_split_terms_thread(int terms) {  // 0 clears the calling thread's override
+  if (terms != 0 && terms != SPLIT_BF16X6 && terms != SPLIT_F16X3) return P2PB_EINVAL;
+  tl_split_terms = terms;
+  return 0;
+}
+extern "C" int p2pb_get_split_terms(void) { return p2pb_split_terms_now(); }  // what a launch from THIS thread would use
 
 // Zero-fill as an ordinary kernel node. hipMemsetAsync is avoided on purpose: under hipGraph stream
 // capture its memset node did not re-execute reliably on replay here (stale voxel counts -> OOB list

@@ -9,7 +9,8 @@
 
 static inline int p2pb_launch_status() { return (int)hipGetLastError(); }
 // arithmetic of the split-operand kernels: SPLIT_F16X3 (default) or SPLIT_BF16X6; defined in abi.hip, p2pb_set_split_terms
-extern int p2pb_g_split_terms;
+int p2pb_split_terms_now();  // the calling thread's override, else the process default (abi.hip)
+#define p2pb_g_split_terms (p2pb_split_terms_now())
 
 static inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 

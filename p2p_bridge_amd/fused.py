@@ -9,6 +9,7 @@ Training keeps the unfused autograd graph (pvcnn_unet.PVConv.forward).
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -206,6 +207,9 @@ def set_conv_math(name):
     return prev
 
 
+_split_math_depth = {}  # thread id -> the override in force on that thread (0: none)
+
+
 class split_math:
     """`with split_math("bf16x6"):` -- the split kernels launched (and the weights packed) inside use that arithmetic,
     whatever the process-wide setting; a host-side integer, no device work. train()'s data-gradient pass runs under it."""
@@ -214,11 +218,15 @@ class split_math:
         self.terms = _SPLIT_TERMS[name]
 
     def __enter__(self):
-        self.prev = lib().p2pb_get_split_terms()
-        lib().p2pb_set_split_terms(self.terms)
+        # a per-THREAD override in the library (include/p2pb_hip.h): launches and weight packs of other threads keep the
+        # process-wide arithmetic; nesting restores the outer override
+        self.prev = _split_math_depth.get(threading.get_ident(), 0)
+        _split_math_depth[threading.get_ident()] = self.terms
+        lib().p2pb_set_split_terms_thread(self.terms)
 
     def __exit__(self, *exc):
-        lib().p2pb_set_split_terms(self.prev)
+        _split_math_depth[threading.get_ident()] = self.prev
+        lib().p2pb_set_split_terms_thread(self.prev)
 
 
 def use_split(cout: int, math=None) -> bool:

@@ -55,3 +55,33 @@ def test_product_never_imports_oracle():
         src = open(f).read()
         assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
         assert "cpu_ops" not in src, f
+
+
+def test_split_terms_thread_override_is_per_thread():
+    """p2pb_set_split_terms_thread (fused.split_math): a temporary arithmetic switch on one thread is invisible to the
+    others; the process-wide setter still reaches every thread without an override (no GPU needed: host state only)"""
+    import threading
+
+    from p2p_bridge_amd import _lib
+
+    lib = _lib.lib()
+    base = lib.p2pb_get_split_terms()
+    seen = {}
+
+    def worker():
+        assert lib.p2pb_set_split_terms_thread(6) == 0
+        seen["inside"] = lib.p2pb_get_split_terms()
+        ev1.set()
+        ev2.wait(5)
+        assert lib.p2pb_set_split_terms_thread(0) == 0
+        seen["cleared"] = lib.p2pb_get_split_terms()
+
+    ev1, ev2 = threading.Event(), threading.Event()
+    t = threading.Thread(target=worker)
+    t.start()
+    ev1.wait(5)
+    seen["other_thread"] = lib.p2pb_get_split_terms()
+    ev2.set()
+    t.join()
+    assert seen == {"inside": 6, "other_thread": base, "cleared": base}
+    assert lib.p2pb_set_split_terms_thread(5) != 0  # not an arithmetic
