@@ -2309,12 +2309,26 @@ static __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups
   const int nt = 256 / cg;  // partial accumulators per channel
   const int k = t % cg, j = t / cg;
   double s = 0.0, q = 0.0;
-  if (j < nt)
-    for (int sl = j; sl < nslots; sl += nt) {
-      const float *p = part + (((size_t)b * nslots + sl) * c + g0 + k) * 2;
+  if (j < nt) {  // (same order, four slots' loads in flight: the plain loop was one L2 round trip per slot)
+    const float *p0 = part + ((size_t)b * nslots * c + g0 + k) * 2;
+    const size_t pitch = (size_t)c * 2;
+    int sl = j;
+    for (; sl + 3 * nt < nslots; sl += 4 * nt) {
+      f32x2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const f32x2 *)(p0 + (size_t)(sl + u * nt) * pitch);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s += (double)v[u][0];
+        q += (double)v[u][1];
+      }
+    }
+    for (; sl < nslots; sl += nt) {
+      const float *p = p0 + (size_t)sl * pitch;
       s += (double)p[0];
       q += (double)p[1];
     }
+  }
   rs[t] = s;
   rq[t] = q;
   __syncthreads();

@@ -425,8 +425,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int nsplit, int ntap,
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t n = cc * ntap, row = n + nbias;
   if (i >= (db ? row : n)) return;
+  // same ascending order (same bits); eight partials in flight per thread -- the plain loop was one L2 round trip per
+  // addend (23 us per launch, 52 launches per training step)
   float s = 0.0f;
-  for (int k = 0; k < nsplit; ++k) s += part[(size_t)k * row + i];
+  int k = 0;
+  for (; k + 8 <= nsplit; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + j) * row + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < nsplit; ++k) s += part[(size_t)k * row + i];
   if (i < n) dw[(i % cc) * ntap + i / cc] = s;
   else db[i - n] = s;
 }
