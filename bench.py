@@ -362,7 +362,7 @@ def main():
 
 def train_step_leg(steps=8, warmup=4, B=8, N=2048):
     """NOT `value`: BASELINE config 3's per-GPU training step (PVDS_PUNet, 8 patches x 2048 points = global batch 64 over
-    8 GPUs, MSE bridge loss, grad clip 1.0, AdamW) on this one GPU, eager, the reference's order of operations
+    8 GPUs, MSE bridge loss, grad clip 1.0, AdamW) on this one GPU, the reference's order of operations
     (train.py:107-143; the auction alignment of the data loader is left out: it is timed in profiles/*_metrics_timing.txt).
     dense FLOPs of a step = 3 x forward (forward, data gradient, weight gradient) = 3 x 61.35 GFLOP x N / 8192 per patch
     (SURVEY 8d); the forward runs in fused.conv_math(), the data-gradient pass in bf16x6, the weight-gradient GEMMs in
@@ -377,34 +377,48 @@ def train_step_leg(steps=8, warmup=4, B=8, N=2048):
     torch.manual_seed(0)
     model = product.build_model(cfg, device="cuda")
     model.train()
-    params = list(model.model.parameters())
-    opt = torch.optim.AdamW(params, lr=3e-4, betas=(0.9, 0.999), weight_decay=1e-5)
+    from p2p_bridge_amd import train as T
+
+    tcfg = copy.deepcopy(cfg)
+    tcfg["training"] = copy.deepcopy(T.PVDS_PUNET_TRAIN["training"])
     x1, x0 = synthetic_patches(B, N, seed=0)
     x1, x0 = x1.cuda(), x0.cuda()
 
-    def step():
-        opt.zero_grad()
+    def timed(step_fn, n_warm, n):
+        for _ in range(n_warm):
+            loss = step_fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step_fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, float(loss)
+
+    # eager: zero_grad -> loss -> backward -> clip + AdamW (optim.ClipAdamW, three launches) -> scheduler -> EMA
+    opt, sched = T.load_optim_sched(tcfg, model, fused=True, skip_nonfinite=True)
+
+    def eager():
+        opt.zero_grad(set_to_none=True)
         loss = model(x0, x1)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
         opt.step()
-        return loss
+        sched.step()
+        if model.ema is not None:
+            model.ema.update()
+        return loss.detach()
 
-    for _ in range(warmup):
-        loss = step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    eager_dt, _ = timed(eager, warmup, steps)
+    # the same step as one captured hipGraph (train.GraphedStep, `python -m p2p_bridge_amd.train --graph`)
+    stepper = T.GraphedStep(model, opt, sched, warmup=1)
+    dt, loss = timed(lambda: stepper(x0, x1), warmup + 2, steps)
     flop = 3.0 * 61.35e9 * N / 8192.0 * B
     return {"workload": f"PVDS_PUNet training step, {B} patches x {N} points per GPU (BASELINE configs[2] = global batch 64 on 8 GPUs), "
-                        "mse bridge loss, clip 1.0, AdamW; eager, hand-written dense forward / backward kernels",
-            "ms_per_step": round(dt * 1e3, 2), "patches_per_s": round(B / dt, 1), "points_per_s": round(B * N / dt, 1),
+                        "mse bridge loss, clip 1.0, AdamW, scheduler, EMA; hand-written forward / backward / optimiser kernels, the step "
+                        "captured as one hipGraph (train.GraphedStep); eager_ms_per_step = the same step launched eagerly",
+            "ms_per_step": round(dt * 1e3, 2), "eager_ms_per_step": round(eager_dt * 1e3, 2), "patches_per_s": round(B / dt, 1), "points_per_s": round(B * N / dt, 1),
             "dense_tflops": round(flop / dt / 1e12, 2), "frac_of_f16x3_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3), 4),
             "frac_of_bf16x6_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6), 4), "steps": steps, "warmup": warmup,
-            "final_loss": round(float(loss), 5)}
+            "final_loss": round(loss, 5)}
 
 
 def alt_math_leg(cfg, sd, x_start, args):

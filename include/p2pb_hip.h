@@ -523,6 +523,26 @@ int p2pb_merge_accumulate(int npatch, int k, const float *pred, const int *idx, 
                           int *counts, void *stream);
 int p2pb_merge_finish(int n, const double *sums, const int *counts, const float *original, float *out, void *stream);
 
+/* ---- optimiser tail of a training step: clip_grad_norm_ + Adam / AdamW in three launches (csrc/optim.hip) ----
+ * replaces torch.nn.utils.clip_grad_norm_(model.parameters(), clip) + torch.optim.AdamW/Adam.step() of the reference's
+ * loop (train.py:127-133, models/model_loader.py:13-33); same arithmetic, per element, as torch's _single_tensor_adam.
+ *   table   device array of n_tensors entries {float *param, *grad, *exp_avg, *exp_avg_sq; int64 numel}
+ *           (p2pb_optim_entry_bytes() each)
+ *   chunks  device int32[nchunks][2] = (tensor index, chunk index within the tensor), p2pb_optim_chunk() elements per chunk
+ *   partial device f64[nchunks] scratch
+ *   ctl     device f64[8]: [0] updates applied so far (in/out), [1] learning rate (in: the host writes it, so a captured
+ *           graph follows a scheduler), [2] gradient norm before clipping (out), [3] clip coefficient applied (out),
+ *           [4] 1.0 when this update was skipped (out), [5], [6] bias corrections (scratch)
+ *   max_norm <= 0: no clipping (gradients are not rewritten). decoupled: AdamW (p *= 1 - lr wd) / Adam (g += wd p).
+ *   skip_nonfinite: a non-finite gradient norm leaves parameters, moments and the step count untouched (what the
+ *           GradScaler of the reference's loop does to optimizer.step()).
+ * -> 0 or a hipError_t code */
+size_t p2pb_optim_entry_bytes(void);
+int p2pb_optim_chunk(void);
+int p2pb_optim_clip_adam_step(int nchunks, const void *table, const int *chunks, double *partial, double *ctl, double max_norm,
+                              double beta1, double beta2, double eps, double weight_decay, int decoupled, int skip_nonfinite,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,7 @@ SYMBOLS = [
     "p2pb_conv3d_k3_forward_compact_fx", "p2pb_conv3d_k3_far_field_fx", "p2pb_se_gate_affine_fx",
     "p2pb_pointwise_conv_forward_fx", "p2pb_pointwise_conv_pool_forward_fx", "p2pb_minmax_act_fx", "p2pb_group_sub_fx",
     "p2pb_three_interpolate_add_fx", "p2pb_fps_grid_ws_bytes", "p2pb_furthest_point_sampling_grid",
+    "p2pb_optim_entry_bytes", "p2pb_optim_chunk", "p2pb_optim_clip_adam_step",
 ]
 
 _lib = None
@@ -69,6 +70,7 @@ def lib():
         _lib.p2pb_chamfer_ws_bytes.restype = ctypes.c_size_t
         _lib.p2pb_approxmatch_temp_floats.restype = ctypes.c_size_t
         _lib.p2pb_pointwise_wgrad_ws_floats.restype = ctypes.c_size_t
+        _lib.p2pb_optim_entry_bytes.restype = ctypes.c_size_t
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here = stale library
         # products per split operand pair (include/p2pb_hip.h; fused.conv_math / set_conv_math)

@@ -316,3 +316,31 @@ static inline GnFold gn_fold_arg(const p2pb_gn_fold *f) { return (f && f->group)
 
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);
+
+// ---- scatter-add backward passes (devoxelise, grouping, three-NN interpolation): rows accumulated in LDS ----
+// Each of these gradients is a scatter into rows gx[b, channel, 0..L) with L a grid (r^3) or a point count; with global
+// fp32 atomics the chip retires ~14 G adds/s (profiles/r02_atomic_contention.txt), 0.55 ms for the 8.4 M adds of the
+// r = 32 devoxelisation. A workgroup instead owns CH rows of one sample in LDS (CH * L floats <= 128 KB): it zeroes them,
+// adds every contribution with ds_add_f32, and writes the rows out once, coalesced -- no zero-fill launch, no HBM atomics,
+// and the output is written exactly once. Rows longer than the LDS take the global-atomic kernels.
+#define SCAT_THREADS 512
+#define SCAT_LDS_MAX (128 * 1024)
+// channels per workgroup: as many rows as fit 64 KB (two workgroups per CU), at most `cap`; one row up to 128 KB; 0 = no fit
+static inline int scat_rows(long L, int c, int cap) {
+  if (L * 4 > SCAT_LDS_MAX) return 0;
+  int ch = (int)((64 * 1024) / (L * 4));
+  if (ch < 1) ch = 1;
+  if (ch > cap) ch = cap;
+  if (ch > c) ch = c;
+  return ch;
+}
+__device__ __forceinline__ void scat_zero(float *rows, int count) {
+  for (int i = threadIdx.x * 4; i < count; i += SCAT_THREADS * 4) *(float4 *)(rows + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+}
+// rows[j][0..L) -> gx[(b * c + c0 + j)][0..L) for the nch rows of this workgroup; L * 4 bytes need not be 16-aligned
+__device__ __forceinline__ void scat_store(const float *rows, int L, int Lp, int nch, float *gx_rows) {
+  __syncthreads();
+  for (int j = 0; j < nch; ++j)
+    for (int i = threadIdx.x; i < L; i += SCAT_THREADS) gx_rows[(size_t)j * L + i] = rows[j * Lp + i];
+}

@@ -324,10 +324,48 @@ __global__ __launch_bounds__(256) void grouping_grad_kernel(int c, int n, int mu
   for (int l = c0; l < c1; ++l) atomicAdd(gx + ((size_t)b * c + l) * n + id, gy[((size_t)b * c + l) * mu + q]);
 }
 
+// rows of CH channels in LDS (common.h "scatter-add backward passes")
+template <int CH>
+__global__ __launch_bounds__(SCAT_THREADS) void grouping_grad_lds_kernel(int c, int n, int Lp, int mu, const float *__restrict__ gy,
+                                                                        const int *__restrict__ idx, float *__restrict__ gx) {
+  extern __shared__ float rows[];
+  const int b = blockIdx.y, c0 = blockIdx.x * CH, nch = min(CH, c - c0);
+  scat_zero(rows, CH * Lp);
+  const int *ib = idx + (size_t)b * mu;
+  const float *g0 = gy + ((size_t)b * c + c0) * mu;
+  for (int q = threadIdx.x; q < mu; q += SCAT_THREADS) {
+    const int id = ib[q];
+#pragma unroll
+    for (int j = 0; j < CH; ++j)
+      if (j < nch) atomicAdd(rows + j * Lp + id, g0[(size_t)j * mu + q]);
+  }
+  scat_store(rows, n, Lp, nch, gx + ((size_t)b * c + c0) * n);
+}
+
+template <int CH>
+static int grouping_grad_lds_launch(int b, int c, int n, int mu, const float *gy, const int *idx, float *gx, hipStream_t s) {
+  const int Lp = (n + 3) & ~3;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void *)grouping_grad_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_LDS_MAX);
+    once = true;
+  }
+  hipLaunchKernelGGL(grouping_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(SCAT_THREADS), sizeof(float) * (size_t)CH * Lp, s, c, n,
+                     Lp, mu, gy, idx, gx);
+  return p2pb_launch_status();
+}
+
 extern "C" int p2pb_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *idx,
                                       float *grad_x, void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  switch (scat_rows(n, c, 8)) {
+    case 0: break;
+    case 1: return grouping_grad_lds_launch<1>(b, c, n, m * u, grad_y, idx, grad_x, s);
+    case 2: case 3: return grouping_grad_lds_launch<2>(b, c, n, m * u, grad_y, idx, grad_x, s);
+    case 8: return grouping_grad_lds_launch<8>(b, c, n, m * u, grad_y, idx, grad_x, s);
+    default: return grouping_grad_lds_launch<4>(b, c, n, m * u, grad_y, idx, grad_x, s);
+  }
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * n, s);
   if (e != 0) return e;
   constexpr int CC = 8;
@@ -847,10 +885,59 @@ __global__ __launch_bounds__(256) void three_interp_grad_kernel(int c, int n, in
   }
 }
 
+template <int CH>
+__global__ __launch_bounds__(SCAT_THREADS) void three_interp_grad_lds_kernel(int c, int n, int m, int Lp, const float *__restrict__ gy,
+                                                                            const int *__restrict__ indices,
+                                                                            const float *__restrict__ weights, float *__restrict__ gx) {
+  extern __shared__ float rows[];
+  const int b = blockIdx.y, c0 = blockIdx.x * CH, nch = min(CH, c - c0);
+  scat_zero(rows, CH * Lp);
+  const int *id = indices + (size_t)b * 3 * n;
+  const float *w = weights + (size_t)b * 3 * n;
+  const float *g0 = gy + ((size_t)b * c + c0) * n;
+  for (int j = threadIdx.x; j < n; j += SCAT_THREADS) {
+    const int a0 = id[j], a1 = id[j + n], a2 = id[j + 2 * n];
+    const float w0 = w[j], w1 = w[j + n], w2 = w[j + 2 * n];
+#pragma unroll
+    for (int l = 0; l < CH; ++l) {
+      if (l < nch) {
+        const float g = g0[(size_t)l * n + j];
+        float *o = rows + l * Lp;
+        atomicAdd(o + a0, g * w0);
+        atomicAdd(o + a1, g * w1);
+        atomicAdd(o + a2, g * w2);
+      }
+    }
+  }
+  scat_store(rows, m, Lp, nch, gx + ((size_t)b * c + c0) * m);
+}
+
+template <int CH>
+static int three_interp_grad_lds_launch(int b, int c, int n, int m, const float *gy, const int *idx, const float *w, float *gx,
+                                        hipStream_t s) {
+  const int Lp = (m + 3) & ~3;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void *)three_interp_grad_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              SCAT_LDS_MAX);
+    once = true;
+  }
+  hipLaunchKernelGGL(three_interp_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(SCAT_THREADS), sizeof(float) * (size_t)CH * Lp, s, c,
+                     n, m, Lp, gy, idx, w, gx);
+  return p2pb_launch_status();
+}
+
 extern "C" int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
                                                   const float *w, float *grad_x, void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  switch (scat_rows(m, c, 8)) {
+    case 0: break;
+    case 1: return three_interp_grad_lds_launch<1>(b, c, n, m, grad_y, idx, w, grad_x, s);
+    case 2: case 3: return three_interp_grad_lds_launch<2>(b, c, n, m, grad_y, idx, w, grad_x, s);
+    case 8: return three_interp_grad_lds_launch<8>(b, c, n, m, grad_y, idx, w, grad_x, s);
+    default: return three_interp_grad_lds_launch<4>(b, c, n, m, grad_y, idx, w, grad_x, s);
+  }
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * m, s);
   if (e != 0) return e;
   constexpr int CC = 16;

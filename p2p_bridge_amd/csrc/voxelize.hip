@@ -742,10 +742,63 @@ __global__ __launch_bounds__(256) void devox_grad_kernel(int c, int n, int r3, c
   }
 }
 
+// the same with the CH grids of a workgroup in LDS (common.h "scatter-add backward passes"); Lp = r3 rounded up to 4
+template <int CH>
+__global__ __launch_bounds__(SCAT_THREADS) void devox_grad_lds_kernel(int c, int n, int r3, int Lp, const int *__restrict__ inds,
+                                                                     const float *__restrict__ wgts, const float *__restrict__ gy,
+                                                                     float *__restrict__ gx) {
+  extern __shared__ float rows[];
+  const int b = blockIdx.y, c0 = blockIdx.x * CH, nch = min(CH, c - c0);
+  scat_zero(rows, CH * Lp);
+  const int *ib = inds + (size_t)b * 8 * n;
+  const float *wb = wgts + (size_t)b * 8 * n;
+  const float *g0 = gy + ((size_t)b * c + c0) * n;
+  for (int i = threadIdx.x; i < n; i += SCAT_THREADS) {
+    int idx[8];
+    float w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      idx[q] = ib[(size_t)q * n + i];
+      w[q] = wb[(size_t)q * n + i];
+    }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      if (j < nch) {
+        const float g = g0[(size_t)j * n + i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) atomicAdd(rows + j * Lp + idx[q], w[q] * g);
+      }
+    }
+  }
+  scat_store(rows, r3, Lp, nch, gx + ((size_t)b * c + c0) * r3);
+}
+
+template <int CH>
+static int devox_grad_lds_launch(int b, int c, int n, int r3, const int *inds, const float *wgts, const float *gy, float *gx,
+                                 hipStream_t s) {
+  const int Lp = (r3 + 3) & ~3;
+  const size_t lds = sizeof(float) * (size_t)CH * Lp;
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void *)devox_grad_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_LDS_MAX);
+    once = true;
+  }
+  hipLaunchKernelGGL(devox_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(SCAT_THREADS), lds, s, c, n, r3, Lp, inds, wgts, gy, gx);
+  return p2pb_launch_status();
+}
+
 extern "C" int p2pb_trilinear_devoxelize_backward(int b, int c, int n, int r3, const int *inds, const float *wgts,
                                                   const float *grad_y, float *grad_x, void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || r3 <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  switch (scat_rows(r3, c, 16)) {
+    case 0: break;
+    case 1: return devox_grad_lds_launch<1>(b, c, n, r3, inds, wgts, grad_y, grad_x, s);
+    case 2: case 3: return devox_grad_lds_launch<2>(b, c, n, r3, inds, wgts, grad_y, grad_x, s);
+    case 4: case 5: case 6: case 7: return devox_grad_lds_launch<4>(b, c, n, r3, inds, wgts, grad_y, grad_x, s);
+    case 16: return devox_grad_lds_launch<16>(b, c, n, r3, inds, wgts, grad_y, grad_x, s);
+    default: return devox_grad_lds_launch<8>(b, c, n, r3, inds, wgts, grad_y, grad_x, s);
+  }
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * r3, s);
   if (e != 0) return e;
   constexpr int CC = 16;

@@ -76,10 +76,13 @@ class _Conv3dK3(torch.autograd.Function):
         ctx.conv = conv
         st = st if st is not None else _empty(x)
         ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output's gradient: a fill launch per layer)
         return y, st
 
     @staticmethod
     def backward(ctx, gy, _gst=None):
+        if gy is None:
+            return None, None, None, None, None
         (x,) = ctx.saved_tensors
         conv = ctx.conv
         gy = gy.contiguous()
@@ -112,10 +115,13 @@ class _Pointwise(torch.autograd.Function):
         ctx.conv = conv
         st = st if st is not None else _empty(x)
         ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output's gradient: a fill launch per layer)
         return y, st
 
     @staticmethod
     def backward(ctx, gy, _gst=None):
+        if gy is None:
+            return None, None, None, None, None
         (x,) = ctx.saved_tensors
         conv = ctx.conv
         gy = gy.contiguous()

@@ -113,6 +113,8 @@ class EMA(nn.Module):
         self.ema_model = copy.deepcopy(model).requires_grad_(False)
         self.register_buffer("initted", torch.tensor(False))
         self.register_buffer("step", torch.tensor(0))
+        self._mirror = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_mirror", None))
 
     @property
     def online_model(self):
@@ -120,13 +122,20 @@ class EMA(nn.Module):
 
     @torch.no_grad()
     def copy_params_from_model_to_ema(self):
-        for pe, p in zip(self.ema_model.parameters(), self.online_model.parameters()):
-            pe.copy_(p.detach())
-        for be, b_ in zip(self.ema_model.buffers(), self.online_model.buffers()):
-            be.copy_(b_)
+        dst = list(self.ema_model.parameters()) + list(self.ema_model.buffers())
+        src = [p.detach() for p in self.online_model.parameters()] + list(self.online_model.buffers())
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def _host_counters(self):
+        """`step` / `initted` mirrored on the host (read back once, and again after a checkpoint load): the update decides
+        what to do from them without waiting for the GPU every training step"""
+        if self._mirror is None:
+            self._mirror = [int(self.step.item()), bool(self.initted.item())]
+        return self._mirror
 
     def get_current_decay(self) -> float:
-        epoch = max(int(self.step.item()) - self.update_after_step - 1, 0)
+        epoch = max(self._host_counters()[0] - self.update_after_step - 1, 0)
         if epoch <= 0:
             return 0.0
         value = 1.0 - (1.0 + epoch / self.inv_gamma) ** (-self.power)
@@ -136,24 +145,32 @@ class EMA(nn.Module):
     def update(self, model: Optional[nn.Module] = None):
         if model is not None:
             self._online[0] = model
-        step = int(self.step.item())
+        mirror = self._host_counters()
+        step = mirror[0]
         self.step += 1
+        mirror[0] += 1
         if step % self.update_every != 0:
             return
         if step <= self.update_after_step:
             self.copy_params_from_model_to_ema()
             return
-        if not bool(self.initted.item()):
+        if not mirror[1]:
             self.copy_params_from_model_to_ema()
             self.initted.fill_(True)
+            mirror[1] = True
         decay = self.get_current_decay()
-        for pe, p in zip(self.ema_model.parameters(), self.online_model.parameters()):
-            pe.lerp_(p.detach(), 1.0 - decay)
+        pe = list(self.ema_model.parameters())
+        if pe:  # ema.lerp_(online, 1 - decay) per tensor, in multi-tensor launches
+            torch._foreach_lerp_(pe, [p.detach() for p in self.online_model.parameters()], 1.0 - decay)
+        fe, fo = [], []
         for be, b_ in zip(self.ema_model.buffers(), self.online_model.buffers()):
             if be.is_floating_point():
-                be.lerp_(b_, 1.0 - decay)
+                fe.append(be)
+                fo.append(b_)
             else:
                 be.copy_(b_)
+        if fe:
+            torch._foreach_lerp_(fe, fo, 1.0 - decay)
 
     def forward(self, *a, **k):
         return self.ema_model(*a, **k)
@@ -558,6 +575,7 @@ def load_checkpoint(model: "P2PB", ckpt, use_ema: bool = True, restart: bool = F
             for name in ("initted", "step"):
                 if name in ema_dict:
                     getattr(model.ema, name).copy_(ema_dict[name].reshape(()))
+            model.ema._mirror = None  # (the host mirror of step / initted is read back at the next update)
     return int(ckpt["step"]) + 1 if "step" in ckpt else 0
 
 

@@ -53,18 +53,36 @@ PVDS_PUNET_TRAIN = dict(  # configs/PVDS_PUNet.yaml (network + diffusion + train
 # ----------------------------------------------------------------------------------------- optimiser / scheduler
 
 
-def load_optim_sched(cfg, model, ckpt: Optional[Dict] = None, restart: bool = False):
-    """models/model_loader.py:13-61"""
+def fused_optim_default(model) -> bool:
+    """clip + AdamW on csrc/optim.hip (optim.ClipAdamW) unless P2PB_FUSED_OPTIM=0: GPU models only"""
+    dev = getattr(model, "device", None)
+    return os.environ.get("P2PB_FUSED_OPTIM", "1") != "0" and dev is not None and torch.device(dev).type == "cuda"
+
+
+def load_optim_sched(cfg, model, ckpt: Optional[Dict] = None, restart: bool = False, fused: Optional[bool] = None,
+                     skip_nonfinite: bool = False):
+    """models/model_loader.py:13-61. fused (default: on a GPU): optim.ClipAdamW -- the same update and state dictionary with
+    the gradient clipping of the step (training.grad_clip) folded in, three launches instead of PyTorch's per-tensor ones;
+    train_step() then leaves clip_grad_norm_ out."""
     tr = _get(cfg, "training")
     oc = _get(tr, "optimizer")
     kind = _get(oc, "type")
     kw = dict(lr=_get(oc, "lr"), weight_decay=_get(oc, "weight_decay"), betas=(_get(oc, "beta1"), _get(oc, "beta2")))
-    if kind == "Adam":
-        optimizer = optim.Adam(model.parameters(), **kw)
-    elif kind == "AdamW":
-        optimizer = optim.AdamW(model.parameters(), **kw)
-    else:
+    if kind not in ("Adam", "AdamW"):
         raise NotImplementedError(kind)
+    if fused is None:
+        fused = fused_optim_default(model)
+    if fused:
+        from .optim import ClipAdamW
+
+        clip = _get(tr, "grad_clip")
+        max_norm = _get(clip, "value") if _get(clip, "enabled", False) else None
+        optimizer = ClipAdamW(model.parameters(), max_norm=max_norm, decoupled=(kind == "AdamW"), skip_nonfinite=skip_nonfinite,
+                              **kw)
+    elif kind == "Adam":
+        optimizer = optim.Adam(model.parameters(), **kw)
+    else:
+        optimizer = optim.AdamW(model.parameters(), **kw)
     sc = _get(tr, "scheduler")
     skind = _get(sc, "type")
     if skind == "ExponentialLR":
@@ -188,7 +206,7 @@ def train_step(model, optimizer, lr_scheduler, batches: Iterator[Dict], cfg, ali
     if scaler is not None:
         scaler.unscale_(optimizer)
     clip = _get(tr, "grad_clip")
-    if _get(clip, "enabled", False):
+    if _get(clip, "enabled", False) and not getattr(optimizer, "max_norm", 0.0):  # (optim.ClipAdamW clips inside its step)
         torch.nn.utils.clip_grad_norm_(model.parameters(), _get(clip, "value"))
     if scaler is not None:
         scaler.step(optimizer)
@@ -203,6 +221,76 @@ def train_step(model, optimizer, lr_scheduler, batches: Iterator[Dict], cfg, ali
     return loss_accum
 
 
+class GraphedStep:
+    """The optimiser step of train_step() as ONE hipGraph: zero_grad -> loss = model(x_gt, x_start, x_cond) -> backward ->
+    clip + AdamW (optim.ClipAdamW), captured once with static input buffers and replayed per step -- about 1200 kernel
+    launches a step at BASELINE config 3's shape, which the eager loop cannot issue as fast as the GPU runs them.
+    Same order of operations as the reference's loop (train.py:107-143); what stays on the host, outside the graph: the data
+    side (get_data_batch and its auction alignment), the draw of the bridge steps (torch.randint on the CPU generator, as
+    P2PB.forward draws them: the host random stream is the eager loop's), the LR scheduler (the learning rate is read from
+    the optimiser's control block) and the EMA update. The first `warmup` calls run eagerly (they are real steps; the
+    capture needs warmed-up allocators and packed weights), the next call captures and replays.
+    Not for DDP (the bucketed all-reduce inside the backward is left to the eager loop), accumulation_steps > 1 or a
+    GradScaler: the loss is fp32 throughout, so the scaler only contributes its skip-the-step-on-overflow,
+    which ClipAdamW(skip_nonfinite=True) does on the device."""
+
+    def __init__(self, model, optimizer, lr_scheduler=None, warmup: int = 3):
+        from .optim import ClipAdamW
+
+        if not isinstance(optimizer, ClipAdamW):
+            raise TypeError("GraphedStep needs optim.ClipAdamW (load_optim_sched(..., fused=True))")
+        if hasattr(model.model, "module"):
+            raise NotImplementedError("GraphedStep: single-process training (DDP steps run eagerly)")
+        self.model, self.optimizer, self.sched, self.warmup = model, optimizer, lr_scheduler, int(warmup)
+        self.calls, self.graph, self.static = 0, None, None
+        self.side = torch.cuda.Stream()
+
+    def _step(self, x_gt, x_start, x_cond, steps):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self.model(x_gt, x_start, x_cond, steps=steps)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()  # (a live loss would keep the AccumulateGrad nodes of this stream alive into the capture)
+
+    def _after(self):
+        if self.sched is not None:
+            self.sched.step()
+        if self.model.ema is not None:
+            self.model.ema.update()
+
+    def __call__(self, x_gt, x_start, x_cond=None) -> torch.Tensor:
+        steps = torch.randint(0, self.model.timesteps, (x_gt.shape[0],))
+        self.calls += 1
+        if self.calls <= self.warmup:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                loss = self._step(x_gt, x_start, x_cond, steps.to(x_gt.device))
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._after()
+            return loss
+        if self.graph is None:
+            self.static = dict(x_gt=x_gt.clone(), x_start=x_start.clone(), x_cond=None if x_cond is None else x_cond.clone(),
+                               steps=steps.to(x_gt.device))
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.static["loss"] = self._step(self.static["x_gt"], self.static["x_start"], self.static["x_cond"],
+                                                 self.static["steps"])
+        st = self.static
+        if x_gt.shape != st["x_gt"].shape or (x_cond is None) != (st["x_cond"] is None):
+            raise RuntimeError(f"GraphedStep was captured for batches of shape {tuple(st['x_gt'].shape)}")
+        st["x_gt"].copy_(x_gt, non_blocking=True)
+        st["x_start"].copy_(x_start, non_blocking=True)
+        if x_cond is not None:
+            st["x_cond"].copy_(x_cond, non_blocking=True)
+        st["steps"].copy_(steps, non_blocking=True)
+        self.optimizer.sync_lr()
+        self.graph.replay()
+        self.optimizer.bump_versions()  # (a replay changes the weights without autograd seeing it: caches keyed on _version)
+        self._after()
+        return st["loss"].clone()
+
+
 def save_checkpoint(path, step, model, optimizer):
     """train.py:168-175"""
     torch.save({"step": step, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict()}, path)
@@ -210,12 +298,15 @@ def save_checkpoint(path, step, model, optimizer):
 
 def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, distributed: bool = False,
           rank: int = 0, world: int = 1, output_dir: Optional[str] = None, log: Optional[Callable] = None,
-          align: bool = True, evaluate: Optional[Callable] = None, ckpt: Optional[Dict] = None, restart: bool = False):
+          align: bool = True, evaluate: Optional[Callable] = None, ckpt: Optional[Dict] = None, restart: bool = False,
+          graph: bool = False):
     """the reference's loop (train.py:107-211) over `steps` optimiser steps. Returns the list of logged mean losses.
     ckpt: a checkpoint dictionary already loaded into `model` (p2pb.load_checkpoint): the optimiser state is restored from
-    it and, unless `restart`, training continues at ckpt["step"] + 1 (models/model_loader.py:13-61,114-165)."""
+    it and, unless `restart`, training continues at ckpt["step"] + 1 (models/model_loader.py:13-61,114-165).
+    graph: the step as one captured hipGraph (GraphedStep; single process, accumulation_steps 1)."""
     tr = _get(cfg, "training")
-    optimizer, sched = load_optim_sched(cfg, model, ckpt, restart)
+    graph = bool(graph) and not distributed and int(_get(tr, "accumulation_steps", 1)) == 1 and model.device.type == "cuda"
+    optimizer, sched = load_optim_sched(cfg, model, ckpt, restart, fused=True if graph else None, skip_nonfinite=graph)
     if ckpt is not None and not restart and "step" in ckpt:
         start_step = int(ckpt["step"]) + 1
     align_fn = make_align_fn() if (align and _get(_get(cfg, "data"), "dataset") == "PUNet") else None
@@ -223,8 +314,13 @@ def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, 
     scaler = torch.amp.GradScaler("cuda", enabled=bool(_get(tr, "amp", False))) if on_gpu else None
     model.train()
     history = []
+    stepper = GraphedStep(model, optimizer, sched) if graph else None
     for step in range(start_step, start_step + steps):
-        loss_accum = train_step(model, optimizer, sched, batches, cfg, align_fn, scaler, distributed)
+        if stepper is not None:
+            data = get_data_batch(next(batches), cfg, align_fn)
+            loss_accum = stepper(data["x_gt"], data["x_start"], data["x_cond"])
+        else:
+            loss_accum = train_step(model, optimizer, sched, batches, cfg, align_fn, scaler, distributed)
         if step % int(_get(tr, "log_interval", 10)) == 0:
             mean_loss = loss_accum.item() / world
             history.append(mean_loss)
@@ -296,6 +392,7 @@ def main(argv=None):
     ap.add_argument("--bs", type=int, default=64, help="GLOBAL batch (divided over the GPUs like train.py:226)")
     ap.add_argument("--npoints", type=int, default=2048)
     ap.add_argument("--no-align", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="the optimiser step as one captured hipGraph (single GPU)")
     ap.add_argument("--output-dir", default=None)
     ap.add_argument("--resume", default=None, help="checkpoint (step_*.pth) to continue from: weights, EMA, optimiser, step")
     ap.add_argument("--restart", action="store_true", help="with --resume: load the network only, start at step 0")
@@ -332,7 +429,7 @@ def main(argv=None):
     batches = synthetic_punet_batches(cfg["training"]["bs"], args.npoints, seed=1000 * rank, device=model.device)
     t0 = time.perf_counter()
     hist = train(cfg, model, batches, args.steps, distributed=mode == "rank", rank=rank, world=world,
-                 output_dir=args.output_dir, align=not args.no_align, ckpt=ckpt, restart=args.restart,
+                 output_dir=args.output_dir, align=not args.no_align, ckpt=ckpt, restart=args.restart, graph=args.graph,
                  log=(lambda d: print(json.dumps(d), flush=True)) if rank == 0 else None)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

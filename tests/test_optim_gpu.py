@@ -1,0 +1,190 @@
+"""clip + Adam / AdamW on csrc/optim.hip (optim.ClipAdamW) against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW / Adam
+(the reference's step, train.py:127-133 with models/model_loader.py:13-33), and the step captured as one hipGraph
+(train.GraphedStep) against the eager step. fp32; tolerance: one rounding of the update per step (the two evaluate the same
+expression, fused differently), stated at each comparison."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1,), (3,), (17, 5), (64, 32, 3, 3, 3), (8192,), (8193,), (128, 257), (100003,), (512, 1024)]
+
+
+def _params(seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).cuda()) for s in SHAPES]
+
+
+def _grads(ps, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(p.shape, generator=g) * scale).cuda() for p in ps]
+
+
+@pytest.mark.parametrize("kind,wd,max_norm", [("AdamW", 1e-5, 1.0), ("AdamW", 0.05, None), ("Adam", 1e-2, 0.5), ("Adam", 0.0, 1.0)])
+def test_matches_torch_over_steps(kind, wd, max_norm):
+    from p2p_bridge_amd.optim import ClipAdamW
+
+    a, b = _params(0), _params(0)
+    ref = (torch.optim.AdamW if kind == "AdamW" else torch.optim.Adam)(a, lr=3e-4, betas=(0.9, 0.999), weight_decay=wd)
+    opt = ClipAdamW(b, lr=3e-4, betas=(0.9, 0.999), weight_decay=wd, max_norm=max_norm, decoupled=kind == "AdamW")
+    for step in range(12):
+        scale = [1e-3, 1.0, 30.0][step % 3]  # below / around / far above the clipping threshold
+        for p, q, g in zip(a, b, _grads(a, 100 + step, scale)):
+            p.grad, q.grad = g.clone(), g.clone()
+        norm = torch.nn.utils.clip_grad_norm_(a, max_norm) if max_norm else None
+        ref.step()
+        opt.step()
+        if max_norm:
+            assert abs(opt.grad_norm() - float(norm)) <= 2e-6 * float(norm)
+        for p, q in zip(a, b):
+            # the clipped gradient is written back (p.grad after clip_grad_norm_): one fp32 multiply, coefficient within 2 ulp
+            torch.testing.assert_close(q.grad, p.grad, rtol=1e-6, atol=0)
+            for key in ("exp_avg", "exp_avg_sq"):
+                x, y = opt.state[q][key], ref.state[p][key]
+                assert (x - y).abs().max().item() <= 2e-6 * y.abs().max().item()
+            torch.testing.assert_close(q, p, rtol=0, atol=2e-8 + 1e-8 * step)  # parameters ~0.1 (ulp 7e-9), updates ~3e-4
+    assert opt.steps_applied() == 12
+    assert all(q._version >= 12 for q in b)  # autograd sees the in-place updates (packed-weight caches key on _version)
+
+
+def test_state_dict_is_torchs_and_round_trips():
+    from p2p_bridge_amd.optim import ClipAdamW
+
+    a, b = _params(1), _params(1)
+    ref = torch.optim.AdamW(a, lr=1e-3, weight_decay=1e-5)
+    for step in range(3):
+        for p, g in zip(a, _grads(a, step, 0.1)):
+            p.grad = g
+        ref.step()
+    sd = ref.state_dict()
+    for p, q in zip(a, b):
+        q.data.copy_(p.data)
+    opt = ClipAdamW(b, lr=1e-3, weight_decay=1e-5)
+    opt.load_state_dict(copy.deepcopy(sd))  # a checkpoint of the reference's optimiser (train.py:168-175) continues here
+    for step in range(3, 6):
+        for p, q, g in zip(a, b, _grads(a, step, 0.1)):
+            p.grad, q.grad = g.clone(), g.clone()
+        ref.step()
+        opt.step()
+    for p, q in zip(a, b):
+        torch.testing.assert_close(q, p, rtol=0, atol=1e-7)  # (parameters up to 0.5: 2 ulp)
+    mine, theirs = opt.state_dict(), ref.state_dict()
+    assert mine["state"].keys() == theirs["state"].keys()
+    for k in theirs["state"]:
+        assert set(mine["state"][k]) == {"step", "exp_avg", "exp_avg_sq"}
+        assert float(mine["state"][k]["step"]) == float(theirs["state"][k]["step"]) == 6.0
+    back = torch.optim.AdamW(a, lr=1e-3, weight_decay=1e-5)
+    back.load_state_dict(mine)  # and torch's optimiser takes ours
+
+
+def test_non_finite_gradient_norm_skips_the_update_when_asked():
+    from p2p_bridge_amd.optim import ClipAdamW
+
+    b = _params(2)
+    opt = ClipAdamW(b, lr=1e-3, max_norm=1.0, skip_nonfinite=True)
+    for q, g in zip(b, _grads(b, 0, 0.1)):
+        q.grad = g
+    opt.step()
+    before = [q.detach().clone() for q in b]
+    m = [opt.state[q]["exp_avg"].clone() for q in b]
+    for q, g in zip(b, _grads(b, 1, 0.1)):
+        q.grad = g
+    b[3].grad.view(-1)[5] = float("inf")
+    opt.step()
+    assert opt.last_step_skipped() and opt.steps_applied() == 1
+    assert all(torch.equal(q, p) for q, p in zip(b, before)) and all(torch.equal(opt.state[q]["exp_avg"], x) for q, x in zip(b, m))
+    for q, g in zip(b, _grads(b, 2, 0.1)):
+        q.grad = g
+    opt.step()
+    assert not opt.last_step_skipped() and opt.steps_applied() == 2 and not torch.equal(b[0], before[0])
+
+
+def test_cpu_parameters_are_refused():
+    from p2p_bridge_amd.optim import ClipAdamW
+
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ClipAdamW([p]).step()
+
+
+def _tiny(dropout=0.0):
+    from p2p_bridge_amd import train as T
+
+    cfg = json.load(open(os.path.join(GOLDEN, "tiny_cfg.json")))
+    cfg["training"] = copy.deepcopy(T.PVDS_PUNET_TRAIN["training"])
+    cfg["training"]["scheduler"] = dict(type="ExponentialLR", lr_gamma=0.7)
+    cfg["model"]["dropout"] = dropout
+    cfg["gpu"] = "cuda:0"
+    w = np.load(os.path.join(GOLDEN, "tiny_weights.npz"))
+    return cfg, {k: torch.from_numpy(w[k]).float() for k in w.files}
+
+
+def test_fused_and_graphed_steps_follow_the_reference_step():
+    """7 optimiser steps on the tiny network, four ways: the reference's order with torch's clip_grad_norm_ + AdamW (twice),
+    the same loop with optim.ClipAdamW, and GraphedStep (3 eager warm-up steps + capture + 3 replays). Same host random
+    stream (bridge steps), no device randomness (dropout 0, ot_ode), a scheduler that changes the learning rate every step.
+    Losses agree to 1e-4 relative. Parameters: the backward scatters with fp32 atomics and Adam divides by sqrt(v), so
+    where a gradient is noise-level the sign of the update is too -- two runs of the SAME torch loop differ by whole
+    learning-rate steps in single elements. The fused and graphed runs must sit within that run-to-run spread (relative L2
+    of the parameter change: 3x, floor 2 %)."""
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd import train as T
+
+    cfg, sd = _tiny()
+    batches = [next(T.synthetic_punet_batches(2, 1024, seed=50 + i, device=torch.device("cuda:0"))) for i in range(7)]
+    runs = {}
+    for mode in ("torch", "torch2", "fused", "graph"):
+        model = product.build_model(cfg, sd, device="cuda:0")
+        model.train()
+        assert not model.add_x1_noise
+        opt, sched = T.load_optim_sched(cfg, model, fused=not mode.startswith("torch"), skip_nonfinite=True)
+        assert isinstance(opt, torch.optim.AdamW) == mode.startswith("torch")
+        stepper = T.GraphedStep(model, opt, sched, warmup=3) if mode == "graph" else None
+        torch.manual_seed(11)
+        losses = []
+        for bt in batches:
+            data = T.get_data_batch(bt, cfg, None)
+            if stepper is not None:
+                losses.append(float(stepper(data["x_gt"], data["x_start"], data["x_cond"])))
+            else:
+                losses.append(float(T.train_step(model, opt, sched, iter([bt]), cfg, None, None)))
+        assert stepper is None or stepper.graph is not None
+        assert abs(opt.param_groups[0]["lr"] - 3e-4 * 0.7 ** 7) < 1e-12 and int(model.ema.step.item()) == 7
+        assert mode.startswith("torch") or opt.steps_applied() == 7
+        runs[mode] = (losses, torch.cat([p.detach().flatten() for p in model.model.parameters()]))
+    start = torch.cat([p.detach().flatten() for p in product.build_model(cfg, sd, device="cuda:0").model.parameters()])
+    ref_losses, ref = runs["torch"]
+    assert ref_losses[-1] != ref_losses[0]
+    moved = (ref - start).norm().item()
+    spread = (runs["torch2"][1] - ref).norm().item() / moved
+    print(f"\n7 steps: |parameter change| {moved:.3e}; relative L2 difference torch / torch {spread:.3e}", end="")
+    for mode in ("fused", "graph"):
+        np.testing.assert_allclose(runs[mode][0], ref_losses, rtol=1e-4)
+        diff = (runs[mode][1] - ref).norm().item() / moved
+        print(f", {mode} / torch {diff:.3e}", end="")
+        assert moved > 1e-3 and diff < max(3 * spread, 2e-2)
+    print()
+
+
+def test_train_runs_graphed(tmp_path):
+    """train(graph=True): the loop of the runner with the captured step, checkpoint written from it"""
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd import train as T
+
+    cfg, sd = _tiny(dropout=0.1)
+    cfg["training"].update(log_interval=1, save_interval=6)
+    model = product.build_model(cfg, sd, device="cuda:0")
+    logs = []
+    hist = T.train(cfg, model, T.synthetic_punet_batches(2, 1024, seed=5, device=model.device), steps=6, output_dir=str(tmp_path),
+                   log=logs.append, graph=True)
+    assert len(hist) == 6 and all(np.isfinite(h) and h > 0 for h in hist) and all(d["netgradNorm"] > 0 for d in logs)
+    ck = torch.load(os.path.join(tmp_path, "step_6.pth"), map_location="cpu")
+    assert all(float(s["step"]) == 6.0 for s in ck["optimizer_state"]["state"].values())

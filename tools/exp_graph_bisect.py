@@ -1,13 +1,13 @@
 """Which part of the training step breaks hipGraph capture (tools/exp_train_graph.py: hipStreamEndCapture faults once the
 backward is inside)? One small forward + backward per building block, each captured alone in its own process:
-    for w in conv3d pointwise normact voxel devox group gather interp attention pvconv sa fp net; do WHAT=$w python tools/exp_graph_bisect.py; done"""
+    for w in conv3d pointwise normact voxel devox group gather interp attention pvconv net; do WHAT=$w python tools/exp_graph_bisect.py; done"""
 import copy, os, sys, faulthandler
 faulthandler.enable()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from p2p_bridge_amd import dense, layers as L, p2pb
-from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet, PVConv, PointNetSAModule, PointNetFPModule, LinearAttention, PVCData
+from p2p_bridge_amd.pvcnn_unet import PVConv, LinearAttention, PVCData
 WHAT = os.environ.get("WHAT", "conv3d")
 dev = "cuda"
 torch.manual_seed(0)
@@ -39,14 +39,14 @@ elif WHAT in ("group", "gather", "interp"):
         idx = L._ext.furthest_point_sampling_forward(xyz.contiguous(), 128)
         cen = L._ext.gather_features_forward(xyz.contiguous(), idx)
         if WHAT == "gather":
-            return L.gather(feat, idx).square().mean() if hasattr(L, "gather") else L.Gather.apply(feat, idx).square().mean()
+            return L.pvcnn_gather(feat, idx).square().mean()
         if WHAT == "group":
             nidx = L.ball_query(cen, xyz.contiguous(), 0.3, 16)
             return L.pvcnn_grouping(feat, nidx).square().mean()
-        small = L.Gather.apply(feat, idx)
+        small = L.pvcnn_gather(feat, idx)
         return L.nearest_neighbor_interpolate(xyz.contiguous(), cen, small).square().mean()
 elif WHAT == "attention":
-    att = P(LinearAttention(64, heads=4)); x = torch.randn(B, 64, 32, device=dev, requires_grad=True)
+    att = P(LinearAttention(64, heads=4)); x = torch.randn(B, 64, 256, device=dev, requires_grad=True)
     f = lambda: att(x).square().mean()
 elif WHAT == "pvconv":
     m = P(PVConv(16, 32, 8, cond_dim=0)); feat = torch.randn(B, 16, N, device=dev, requires_grad=True)
@@ -55,8 +55,9 @@ elif WHAT == "net":
     cfg = copy.deepcopy(bench.PVDS); cfg["data"]["npoints"] = 2048
     model = p2pb.build_model(cfg, device=dev); model.train(); params.extend(model.model.parameters())
     from p2p_bridge_amd.synthetic import synthetic_patches
-    x1, x0 = synthetic_patches(2, 2048, seed=0); x1, x0 = x1.cuda(), x0.cuda()
-    steps = torch.randint(0, 1000, (2,), device=dev)
+    NB = int(os.environ.get('NB', 2))
+    x1, x0 = synthetic_patches(NB, 2048, seed=0); x1, x0 = x1.cuda(), x0.cuda()
+    steps = torch.randint(0, 1000, (NB,), device=dev)
     f = lambda: model(x0, x1, steps=steps)
 else:
     raise SystemExit("unknown WHAT")

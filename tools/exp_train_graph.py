@@ -29,7 +29,7 @@ def step():
         torch.nn.utils.clip_grad_norm_(params, 1.0)
     if MODE == "full":
         opt.step()
-    return loss
+    return loss.detach()  # a live loss keeps the AccumulateGrad nodes of the default stream alive -> the capture faults
 for _ in range(3): l = step()
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): l = step()

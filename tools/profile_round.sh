@@ -29,7 +29,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_metrics -o m -
 db=$(find $out/prof_metrics -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $db $out/${tag}_metrics_kernel_stats.csv > /dev/null
 # 4) training step (config-3 shape)
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_train -o t -- python $R/tools/exp_train_step.py > $out/prof_train.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_train -o t -- env GRAPH=0 python $R/tools/exp_train_step.py > $out/prof_train.log 2>&1
 db=$(find $out/prof_train -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $db $out/${tag}_train_step_kernel_stats.csv > /dev/null
 python $R/tools/exp_train_step.py 2>&1 | tail -1 > $out/${tag}_train_step_timing.txt
