@@ -523,6 +523,17 @@ int p2pb_merge_accumulate(int npatch, int k, const float *pred, const int *idx, 
                           int *counts, void *stream);
 int p2pb_merge_finish(int n, const double *sums, const int *counts, const float *original, float *out, void *stream);
 
+/* ---- packs of the ADJOINT (data-gradient) operator, read straight from the forward layer's weight ----
+ * dX of a layer is the same convolution kernel on dY with the transposed weight (and the taps point-reflected for the
+ * 3x3x3 convolution). These pack variants take the FORWARD weight -- w_forward f32[cin][cout][27] resp. f32[cin][cout],
+ * where cout / cin are the adjoint operator's (cout = the layer's input channels) -- and produce the pack the forward
+ * kernels take; same sizes and arithmetic selection as the non-adjoint functions (p2pb_*_packed_bytes / _floats).
+ * Replaces the flipped / transposed weight copies an autograd backward would make (the reference gets dX from
+ * cuDNN / cuBLAS: models/pvcnn.py:265-282 Conv3d, :162-205 SharedMLP). -> 0 or P2PB_EINVAL */
+int p2pb_conv3d_k3_pack_weights_split_adjoint(int cout, int cin, const float *w_forward, void *wt_split, void *stream);
+int p2pb_pointwise_pack_weights_adjoint(int cout, int cin, const float *w_forward, float *wp, void *stream);
+int p2pb_pointwise_pack_weights_split_adjoint(int cout, int cin, const float *w_forward, void *wp, void *stream);
+
 /* ---- optimiser tail of a training step: clip_grad_norm_ + Adam / AdamW in three launches (csrc/optim.hip) ----
  * replaces torch.nn.utils.clip_grad_norm_(model.parameters(), clip) + torch.optim.AdamW/Adam.step() of the reference's
  * loop (train.py:127-133, models/model_loader.py:13-33); same arithmetic, per element, as torch's _single_tensor_adam.

@@ -391,8 +391,12 @@ static __host__ __device__ size_t conv_split_trailer_bytes(int nchunk, int cout_
 
 // packed weights: wt[tap][chunk16][split 3][khalf 2][cout_pad][8 bf16]; element idx = channel chunk*16 + khalf*8 + idx
 // mode SPLIT_F16X3 (common.h): planes 0, 1 = the fp16 pair of w * S_w, plane 2 unused; trailer = {max|w| bits, 1 / (S_x S_w)}
+// w element (co, ci, tap) at w[co * s_co + ci * s_ci + (flip ? 26 - tap : tap)]: (cin * 27, 27, no flip) for a layer's own
+// weight; (27, cout * 27, flip) packs the ADJOINT (data-gradient) operator straight from the forward weight [cin][cout][27]
+// -- a correlation's adjoint is the correlation with the point-reflected kernel and the channel roles swapped
 static __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
-                                        unsigned short *__restrict__ wt, int mode, float *__restrict__ trailer) {
+                                        unsigned short *__restrict__ wt, int mode, float *__restrict__ trailer, long s_co,
+                                        long s_ci, int flip) {
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;  // one thread per (tap, chunk, khalf, co, idx)
   const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(trailer[0]) : 1.0f;
   if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
@@ -405,7 +409,7 @@ static __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, i
     q >>= 1;
     const int chunk = (int)(q % nchunk), tap = (int)(q / nchunk);
     const int ci = chunk * CONV_SCK + kh * 8 + idx;
-    const float x = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * 27 + tap] : 0.0f;
+    const float x = (co < cout && ci < cin) ? w[(size_t)co * s_co + (size_t)ci * s_ci + (flip ? 26 - tap : tap)] : 0.0f;
     unsigned p0, p1, p2;
     if (mode == SPLIT_F16X3) {
       split2h(x * sw, 0.0f, p0, p1);
@@ -1043,7 +1047,7 @@ extern "C" size_t p2pb_conv3d_k3_split_packed_bytes(int cout, int cin) {
   return (size_t)27 * nchunk * 3 * 2 * cout_pad * 8 * sizeof(unsigned short) + 16;  // + trailer (fp16 mode's scales)
 }
 
-extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float *w, void *wt_split, void *stream) {
+static int conv_pack_split(int cout, int cin, const float *w, void *wt_split, bool adjoint, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;
@@ -1058,8 +1062,14 @@ extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float 
   }
   hipLaunchKernelGGL(conv3d_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                      dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, (unsigned short *)wt_split, mode,
-                     trailer);
+                     trailer, adjoint ? 27L : (long)cin * 27, adjoint ? (long)cout * 27 : 27L, adjoint ? 1 : 0);
   return p2pb_launch_status();
+}
+extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float *w, void *wt_split, void *stream) {
+  return conv_pack_split(cout, cin, w, wt_split, false, stream);
+}
+extern "C" int p2pb_conv3d_k3_pack_weights_split_adjoint(int cout, int cin, const float *w_forward, void *wt_split, void *stream) {
+  return conv_pack_split(cout, cin, w_forward, wt_split, true, stream);
 }
 #endif
 

@@ -1,7 +1,7 @@
 // normact.hip -- GroupNorm (+ AdaGN style) (+ Swish) for TRAINING: the backward pass of
 //     y = act( GN_groups(x) * gamma_c + beta_c ) * factor_bc + bias_bc )           act = Swish or identity
 // (models/modules.py:341-358 AdaGN.forward, torch.nn.GroupNorm, Swish :14-19; SharedMLP's conv -> norm -> Swish triple,
-// models/pvcnn.py:162-205) in three launches instead of the ~20 elementwise / reduction kernels the eager autograd graph
+// models/pvcnn.py:162-205) in two launches instead of the ~20 elementwise / reduction kernels the eager autograd graph
 // runs per layer. The forward pass is the inference machinery: the producing convolution emits {sum, sum of squares}
 // partials, gn_affine_kernel folds the norm to a per-(sample, channel) affine  u = A x + B  (p2pb_gn_affine_params_ex
 // additionally returns the group mean / rstd this file needs), p2pb_affine_act applies it.
@@ -75,75 +75,72 @@ __global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *
   }
 }
 
-// one workgroup per GROUP: thread t < cg owns channel g*cg + t and walks the samples (parameter gradients summed over b
-// in ascending order); the per-(sample, group) sums behind the dx coefficients are formed from an LDS table by thread
-// j = sample, serially over the cg channels -- fixed order, two barriers per 16 samples
-#define NA_BCH 16
-__global__ __launch_bounds__(256) void na_bwd_params_kernel(int nb, int c, int groups, double count_per_channel,
-                                                            const float *__restrict__ rows,
-                                                            const float *__restrict__ mean_rstd,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta,
-                                                            const float *__restrict__ style, int style_stride,
-                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                            float *__restrict__ dstyle, float *__restrict__ coef) {
-  __shared__ double w1[NA_BCH][256], w2[NA_BCH][256];
-  const int g = blockIdx.x, t = threadIdx.x;
-  const int cg = c / groups, ch = g * cg + t;
-  const bool on = t < cg;
-  const double ga = (on && gamma) ? (double)gamma[ch] : 1.0, be = (on && beta) ? (double)beta[ch] : 0.0;
-  double dga = 0.0, dbe = 0.0;
-  const double n = count_per_channel * cg;
-  for (int b0 = 0; b0 < nb; b0 += NA_BCH) {
-    const int nbb = min(NA_BCH, nb - b0);
-    if (on)
-      for (int j = 0; j < nbb; ++j) {
-        const int b = b0 + j;
-        const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
-        const double s1 = (double)rows[((size_t)b * c + ch) * 2], s2 = (double)rows[((size_t)b * c + ch) * 2 + 1];
-        const double t1 = s1, t2 = rstd * (s2 - mu * s1);
-        double f = 1.0;
-        if (style) {
-          f = (double)style[(size_t)b * style_stride + ch];
-          dstyle[(size_t)b * 2 * c + ch] = (float)(ga * t2 + be * t1);  // d factor
-          dstyle[(size_t)b * 2 * c + c + ch] = (float)t1;               // d bias
-        }
-        dga += f * t2;
-        dbe += f * t1;
-        w1[j][t] = ga * f * t1;
-        w2[j][t] = ga * f * t2;
-      }
-    __syncthreads();
-    if (t < nbb) {
-      const int b = b0 + t;
-      double m1 = 0.0, m2 = 0.0;
-      for (int k = 0; k < cg; ++k) {
-        m1 += w1[t][k];
-        m2 += w2[t][k];
-      }
-      m1 /= n;
-      m2 /= n;
-      const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
-      coef[((size_t)b * groups + g) * 2] = (float)(-rstd * rstd * m2);
-      coef[((size_t)b * groups + g) * 2 + 1] = (float)(-rstd * m1 + mu * rstd * rstd * m2);
-    }
-    __syncthreads();
-  }
-  if (on) {
-    if (dgamma) dgamma[ch] = (float)dga;
-    if (dbeta) dbeta[ch] = (float)dbe;
-  }
-}
-
-// dx = gu * A + x * c2 + c3
-__global__ __launch_bounds__(256) void na_bwd_apply_kernel(int c, int groups, int P, const float *__restrict__ x,
+// dx = gu * A + x * c2 + c3, with the parameter pass folded into the prologue (it used to be a launch of its own: eight
+// workgroups of serial fp64 arithmetic, 8 us of latency per layer on the step's critical path). Every workgroup of row
+// (b, ch) forms the two group coefficients of (b, g) itself -- thread k < cg evaluates channel g*cg + k's terms in fp64,
+// thread 0 adds them in ascending channel order (the order of the old kernel: same bits) -- and the first workgroup of the
+// row also writes the row's parameter gradients: dstyle[b, ch], and for b == 0 dgamma / dbeta summed over the samples in
+// ascending order.
+__global__ __launch_bounds__(256) void na_bwd_apply_kernel(int nb, int c, int groups, int P, const float *__restrict__ x,
                                                            const float *__restrict__ gy,
                                                            const float *__restrict__ scale,
                                                            const float *__restrict__ shift, int swish,
-                                                           const float *__restrict__ coef, float *__restrict__ dx) {
-  const int bc = blockIdx.y, b = bc / c, ch = bc % c, g = ch / (c / groups);
+                                                           const float *__restrict__ rows,
+                                                           const float *__restrict__ mean_rstd,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta,
+                                                           const float *__restrict__ style, int style_stride,
+                                                           float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                           float *__restrict__ dstyle, float *__restrict__ dx) {
+  __shared__ double w1[256], w2[256];
+  __shared__ float cf[2];
+  const int bc = blockIdx.y, b = bc / c, ch = bc % c, cg = c / groups, g = ch / cg, t = threadIdx.x;
+  const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
+  if (t < cg) {
+    const int k = g * cg + t;
+    const double ga = gamma ? (double)gamma[k] : 1.0;
+    const double s1 = (double)rows[((size_t)b * c + k) * 2], s2 = (double)rows[((size_t)b * c + k) * 2 + 1];
+    const double f = style ? (double)style[(size_t)b * style_stride + k] : 1.0;
+    w1[t] = ga * f * s1;
+    w2[t] = ga * f * (rstd * (s2 - mu * s1));
+  }
+  __syncthreads();
+  if (t == 0) {
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = 0; k < cg; ++k) {
+      m1 += w1[k];
+      m2 += w2[k];
+    }
+    const double n = (double)P * cg;
+    m1 /= n;
+    m2 /= n;
+    cf[0] = (float)(-rstd * rstd * m2);
+    cf[1] = (float)(-rstd * m1 + mu * rstd * rstd * m2);
+  }
+  if (blockIdx.x == 0 && t == 64) {  // (a lane of the second wave: beside thread 0's serial sum)
+    const double ga = gamma ? (double)gamma[ch] : 1.0, be = beta ? (double)beta[ch] : 0.0;
+    if (style) {
+      const double s1 = (double)rows[(size_t)bc * 2], s2 = (double)rows[(size_t)bc * 2 + 1];
+      const double t2 = rstd * (s2 - mu * s1);
+      dstyle[(size_t)b * 2 * c + ch] = (float)(ga * t2 + be * s1);  // d factor
+      dstyle[(size_t)b * 2 * c + c + ch] = (float)s1;               // d bias
+    }
+    if (b == 0 && (dgamma || dbeta)) {
+      double dga = 0.0, dbe = 0.0;
+      for (int bb = 0; bb < nb; ++bb) {
+        const double m = (double)mean_rstd[((size_t)bb * groups + g) * 2], r = (double)mean_rstd[((size_t)bb * groups + g) * 2 + 1];
+        const double s1 = (double)rows[((size_t)bb * c + ch) * 2], s2 = (double)rows[((size_t)bb * c + ch) * 2 + 1];
+        const double f = style ? (double)style[(size_t)bb * style_stride + ch] : 1.0;
+        dga += f * (r * (s2 - m * s1));
+        dbe += f * s1;
+      }
+      if (dgamma) dgamma[ch] = (float)dga;
+      if (dbeta) dbeta[ch] = (float)dbe;
+    }
+  }
+  __syncthreads();
   const float sc = scale[bc], sh = shift[bc];
-  const float c2 = coef[((size_t)b * groups + g) * 2], c3 = coef[((size_t)b * groups + g) * 2 + 1];
+  const float c2 = cf[0], c3 = cf[1];
   const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
   float *dr = dx + (size_t)bc * P;
   if ((P & 3) == 0) {
@@ -176,13 +173,11 @@ extern "C" int p2pb_norm_act_backward(int b, int c, int groups, int npos, const 
       !shift || !mean_rstd || !dx || !ws || (style && (!dstyle || style_stride < 2 * c)))
     return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  float *rows = ws, *coef = ws + (size_t)2 * b * c;
+  float *rows = ws;
   hipLaunchKernelGGL(na_bwd_reduce_kernel, dim3(b * c), dim3(256), 0, s, npos, x, gy, scale, shift, swish, rows);
-  hipLaunchKernelGGL(na_bwd_params_kernel, dim3(groups), dim3(256), 0, s, b, c, groups, (double)npos, rows, mean_rstd,
-                     gamma, beta, style, style_stride, dgamma, dbeta, dstyle, coef);
   const int per = (npos & 3) == 0 ? npos / 4 : npos;
   const unsigned gx = (unsigned)((per + 255) / 256 > 32 ? 32 : (per + 255) / 256);
-  hipLaunchKernelGGL(na_bwd_apply_kernel, dim3(gx, b * c), dim3(256), 0, s, c, groups, npos, x, gy, scale, shift, swish,
-                     coef, dx);
+  hipLaunchKernelGGL(na_bwd_apply_kernel, dim3(gx, b * c), dim3(256), 0, s, b, c, groups, npos, x, gy, scale, shift, swish,
+                     rows, mean_rstd, gamma, beta, style, style_stride, dgamma, dbeta, dstyle, dx);
   return p2pb_launch_status();
 }

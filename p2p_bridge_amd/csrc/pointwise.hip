@@ -536,8 +536,10 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
   if (FX && STATS && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
 }
 
+// w element (co, ci) at w[co * s_co + ci * s_ci]: (cin, 1) for a layer's own weight [cout][cin], (1, cout) for the adjoint
+// (data-gradient) operator of a layer whose weight is [cin][cout] -- no transposed copy of the weight is ever made
 __global__ void pw_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, const float *__restrict__ w,
-                               float *__restrict__ wp) {
+                               float *__restrict__ wp, long s_co, long s_ci) {
   const size_t total = (size_t)cin_pad * cout_pad;
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int kk = (int)(e & 3);
@@ -545,7 +547,7 @@ __global__ void pw_pack_kernel(int cout, int cin, int cin_pad, int cout_pad, con
     const int kh = (int)((e / ((size_t)4 * cout_pad)) & 1);
     const int chunk = (int)(e / ((size_t)8 * cout_pad));
     const int ci = chunk * 8 + 2 * kk + kh;
-    wp[e] = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
+    wp[e] = (co < cout && ci < cin) ? w[(size_t)co * s_co + (size_t)ci * s_ci] : 0.0f;
   }
 }
 
@@ -556,12 +558,19 @@ extern "C" size_t p2pb_pointwise_packed_floats(int cout, int cin) {
   return (size_t)pw_cin_pad(cin) * pw_cout_pad(cout);
 }
 
-extern "C" int p2pb_pointwise_pack_weights(int cout, int cin, const float *w, float *wp, void *stream) {
+static int pw_pack(int cout, int cin, const float *w, float *wp, bool adjoint, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const size_t total = p2pb_pointwise_packed_floats(cout, cin);
   hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256),
-                     0, (hipStream_t)stream, cout, cin, pw_cin_pad(cin), pw_cout_pad(cout), w, wp);
+                     0, (hipStream_t)stream, cout, cin, pw_cin_pad(cin), pw_cout_pad(cout), w, wp, adjoint ? 1L : (long)cin,
+                     adjoint ? (long)cout : 1L);
   return p2pb_launch_status();
+}
+extern "C" int p2pb_pointwise_pack_weights(int cout, int cin, const float *w, float *wp, void *stream) {
+  return pw_pack(cout, cin, w, wp, false, stream);
+}
+extern "C" int p2pb_pointwise_pack_weights_adjoint(int cout, int cin, const float *w_forward, float *wp, void *stream) {
+  return pw_pack(cout, cin, w_forward, wp, true, stream);
 }
 
 extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 // channel = chunk*32 + kstep*16 + khalf*8 + idx
 // mode SPLIT_F16X3: planes 0, 1 hold the fp16 pair of w * S_w (plane 2 unused); trailer = {max|w| bits, 1 / (S_x S_w)}
 __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, const float *__restrict__ w,
-                                     unsigned short *__restrict__ wp, int mode, float *__restrict__ trailer) {
+                                     unsigned short *__restrict__ wp, int mode, float *__restrict__ trailer, long s_co, long s_ci) {
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;  // (chunk, coblk, kstep, khalf, co, idx)
   const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(trailer[0]) : 1.0f;
   if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
@@ -946,7 +955,7 @@ __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, 
     q >>= 1;
     const int cb = (int)(q % ncoblk), chunk = (int)(q / ncoblk);
     const int co = cb * 128 + col, ci = chunk * PWS_CK + ks * 16 + kh * 8 + idx;
-    const float x = (co < cout && ci < cin) ? w[(size_t)co * cin + ci] : 0.0f;
+    const float x = (co < cout && ci < cin) ? w[(size_t)co * s_co + (size_t)ci * s_ci] : 0.0f;
     unsigned p0, p1, p2;
     if (mode == SPLIT_F16X3) {
       split2h(x * sw, 0.0f, p0, p1);
@@ -965,7 +974,7 @@ extern "C" size_t p2pb_pointwise_split_packed_bytes(int cout, int cin) {
   return nchunk * ncoblk * (2 * 3 * 2 * 128) * 16 + 16;  // + trailer {max|w| bits, output scale, -, -} (fp16 mode)
 }
 
-extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w, void *wp, void *stream) {
+static int pw_pack_split(int cout, int cin, const float *w, void *wp, bool adjoint, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;
@@ -979,8 +988,15 @@ extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float 
                        (unsigned *)trailer);
   }
   hipLaunchKernelGGL(pw_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp, mode, trailer);
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp, mode, trailer,
+                     adjoint ? 1L : (long)cin, adjoint ? (long)cout : 1L);
   return p2pb_launch_status();
+}
+extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w, void *wp, void *stream) {
+  return pw_pack_split(cout, cin, w, wp, false, stream);
+}
+extern "C" int p2pb_pointwise_pack_weights_split_adjoint(int cout, int cin, const float *w_forward, void *wp, void *stream) {
+  return pw_pack_split(cout, cin, w_forward, wp, true, stream);
 }
 
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,

@@ -42,23 +42,75 @@ def enabled(x: torch.Tensor) -> bool:
     return USE_HIP and x.is_cuda and x.dtype == F32
 
 
+# ---- weight gradients beside the data-gradient chain ---------------------------------------------------------------------
+# dW of a layer is needed only by the optimiser; dX is what the rest of the backward pass waits for. Inside
+# `wgrad_overlap()` the weight-gradient GEMMs (a quarter of the step's kernel time) are issued on a second stream that forks
+# from the backward stream at each layer and is joined once, after backward (`join_wgrad`): the long chain of small
+# data-gradient / normalisation kernels -- each far too small to fill 256 CUs -- then runs beside them instead of between
+# them. Used by train.GraphedStep (the fork / join is captured into the hipGraph as parallel branches); NOT under DDP,
+# whose hooks read a gradient as soon as its backward returns.
+_overlap = {"stream": None, "pending": []}
+
+
+class wgrad_overlap:
+    def __init__(self, stream: "torch.cuda.Stream"):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev, _overlap["stream"] = _overlap["stream"], self.stream
+        return self
+
+    def __exit__(self, *a):
+        join_wgrad()
+        _overlap["stream"] = self.prev
+
+
+def join_wgrad():
+    """the current stream waits for the weight gradients issued so far; their operands may be freed again"""
+    st = _overlap["stream"]
+    if st is not None and _overlap["pending"]:
+        torch.cuda.current_stream().wait_stream(st)
+    _overlap["pending"].clear()
+
+
+def _on_wgrad_stream(fn, *operands):
+    """fn() on the overlap stream (after everything already queued on the current one), or inline without one. The
+    operands are kept alive until the join: the allocator must not hand their memory to later kernels of the main stream
+    while the side stream still reads them."""
+    st = _overlap["stream"]
+    if st is None:
+        return fn()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out = fn()
+    _overlap["pending"].append(operands)
+    return out
+
+
+_ZEROS = {}
+
+
+def _zero_bias(n, device):
+    """one zero vector per (length, device) for the lifetime of the process (the convolution launcher wants a bias row)"""
+    key = (int(n), str(device))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(int(n), dtype=F32, device=device)
+    return _ZEROS[key]
+
+
 def _dgrad_holder(conv, kind):
-    """conv-like object carrying the weight of the data-gradient pass, cached on the module per weight version"""
+    """conv-like object of the data-gradient pass: the layer's OWN weight tensor flagged `adjoint`, which the pack kernels
+    read transposed (and, for the 3x3x3 convolution, with every tap axis reversed: p2pb_*_pack_weights*_adjoint) -- no
+    flipped / transposed copy of the weight per step. The holder lives on the module; its packs are cached per weight
+    version like the forward ones."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.device)
-    cache = getattr(conv, "_p2pb_dgrad", None)
-    if cache is None or cache[0] != key:
-        with torch.no_grad():
-            if kind == "conv3d":  # [co,ci,3,3,3] -> [ci,co,3,3,3] with every axis reversed
-                wt = w.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
-                h = types.SimpleNamespace(weight=wt, bias=torch.zeros(wt.shape[0], dtype=F32, device=w.device),
-                                          out_channels=wt.shape[0], in_channels=wt.shape[1], padding=(1, 1, 1),
-                                          stride=(1, 1, 1))
-            else:  # [co,ci(,1(,1))] -> [ci,co]
-                wt = w.detach().reshape(w.shape[0], -1).t().contiguous()
-                h = types.SimpleNamespace(weight=wt, bias=None, out_channels=wt.shape[0], in_channels=wt.shape[1])
-        cache = conv._p2pb_dgrad = (key, h)
-    return cache[1]
+    h = getattr(conv, "_p2pb_dgrad", None)
+    if h is None or h.weight is not w:
+        co, ci = w.shape[0], w[0].numel() // (27 if kind == "conv3d" else 1)
+        h = types.SimpleNamespace(weight=w, adjoint=True, out_channels=ci, in_channels=co,
+                                  bias=_zero_bias(ci, w.device) if kind == "conv3d" else None, padding=(1, 1, 1), stride=(1, 1, 1))
+        conv._p2pb_dgrad = h
+    return h
 
 
 def _empty(x):
@@ -88,19 +140,25 @@ class _Conv3dK3(torch.autograd.Function):
         gy = gy.contiguous()
         b, ci, r = x.shape[0], x.shape[1], x.shape[2]
         co = gy.shape[1]
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            want_b = ctx.needs_input_grad[2]
+
+            def wgrad():
+                gw = torch.empty(co, ci, 3, 3, 3, dtype=F32, device=x.device)
+                gb = torch.empty(co, dtype=F32, device=x.device) if want_b else None
+                math = _i(train_math())
+                ws = torch.empty(lib().p2pb_conv3d_k3_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(r), math), dtype=F32,
+                                 device=x.device)
+                call("p2pb_conv3d_k3_wgrad", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
+                     math, stream_ptr())
+                return gw, gb
+
+            gw, gb = _on_wgrad_stream(wgrad, x, gy)
         gx = None
         if ctx.needs_input_grad[0]:
             with fused.split_math("bf16x6"):  # gradients have no scale an fp16-pair split could rely on
                 gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True)
-        gw = gb = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw = torch.empty(co, ci, 3, 3, 3, dtype=F32, device=x.device)
-            gb = torch.empty(co, dtype=F32, device=x.device) if ctx.needs_input_grad[2] else None
-            math = _i(train_math())
-            ws = torch.empty(lib().p2pb_conv3d_k3_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(r), math), dtype=F32,
-                             device=x.device)
-            call("p2pb_conv3d_k3_wgrad", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
-                 math, stream_ptr())
         return gx, gw, gb, None, None
 
 
@@ -127,20 +185,25 @@ class _Pointwise(torch.autograd.Function):
         gy = gy.contiguous()
         b, ci, p = x.shape
         co = gy.shape[1]
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            want_b = ctx.needs_input_grad[2]
+
+            def wgrad():
+                gw = torch.empty(co, ci, dtype=F32, device=x.device)
+                gb = torch.empty(co, dtype=F32, device=x.device) if want_b else None
+                math = _i(train_math())
+                ws = torch.empty(lib().p2pb_pointwise_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(p), math), dtype=F32,
+                                 device=x.device)
+                call("p2pb_pointwise_wgrad", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
+                     math, stream_ptr())
+                return gw.view(conv.weight.shape), gb
+
+            gw, gb = _on_wgrad_stream(wgrad, x, gy)
         gx = None
         if ctx.needs_input_grad[0]:
             with fused.split_math("bf16x6"):
                 gx, _ = fused.pw_conv(gy, _dgrad_holder(conv, "pw"), stats=False, use_bias=False)
-        gw = gb = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw = torch.empty(co, ci, dtype=F32, device=x.device)
-            gb = torch.empty(co, dtype=F32, device=x.device) if ctx.needs_input_grad[2] else None
-            math = _i(train_math())
-            ws = torch.empty(lib().p2pb_pointwise_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(p), math), dtype=F32,
-                             device=x.device)
-            call("p2pb_pointwise_wgrad", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
-                 math, stream_ptr())
-            gw = gw.view(conv.weight.shape)
         return gx, gw, gb, None, None
 
 

@@ -247,12 +247,15 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
     if split:
         split = "f16" if lib().p2pb_get_split_terms() == 16 else "bf16"  # the pack follows the arithmetic selected now
     if split not in packs:
-        co, ci = w.shape[:2]
+        adjoint = bool(getattr(conv, "adjoint", False))  # dense._dgrad_holder: `w` is the forward layer's weight [ci][co]
+        co, ci = (w.shape[1], w.shape[0]) if adjoint else w.shape[:2]
         assert tuple(w.shape[2:]) == (3, 3, 3) and conv.padding == (1, 1, 1) and conv.stride == (1, 1, 1)
+        assert split or not adjoint
         wc = w.detach().contiguous()
         if split:
             wt = torch.empty(lib().p2pb_conv3d_k3_split_packed_bytes(_i(co), _i(ci)), dtype=torch.uint8, device=w.device)
-            call("p2pb_conv3d_k3_pack_weights_split", _i(co), _i(ci), ptr(wc), ptr(wt), stream_ptr())
+            call("p2pb_conv3d_k3_pack_weights_split_adjoint" if adjoint else "p2pb_conv3d_k3_pack_weights_split", _i(co), _i(ci),
+                 ptr(wc), ptr(wt), stream_ptr())
         else:
             wt = torch.empty(lib().p2pb_conv3d_k3_packed_floats(_i(co), _i(ci)), dtype=F32, device=w.device)
             call("p2pb_conv3d_k3_pack_weights", _i(co), _i(ci), ptr(wc), ptr(wt), stream_ptr())
@@ -539,6 +542,10 @@ def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None, split=False) -> torch.Tenso
     slice; fp32 pack or (split) the 16-bit pack of the split-operand kernel in the arithmetic selected now; cached like
     pack_conv3d_weight"""
     w = conv.weight
+    adjoint = bool(getattr(conv, "adjoint", False))  # dense._dgrad_holder: `w` is the forward layer's weight [ci][co(,1(,1))]
+    if adjoint:
+        assert ci_lo == 0 and ci_hi in (None, w.shape[0])
+        ci_hi = w.shape[0]
     ci_hi = w.shape[1] if ci_hi is None else ci_hi
     key = (w.data_ptr(), w._version, w.device)
     cache = getattr(conv, "_p2pb_packed_pw", None)
@@ -549,15 +556,20 @@ def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None, split=False) -> torch.Tenso
         split = "f16" if lib().p2pb_get_split_terms() == 16 else "bf16"
     k = (ci_lo, ci_hi, split)
     if k not in packs:
-        co = w.shape[0]
-        w2 = w.detach().reshape(co, -1)[:, ci_lo:ci_hi].contiguous()
+        if adjoint:
+            w2 = w.detach().reshape(w.shape[0], -1).contiguous()
+            co = w2.shape[1]
+        else:
+            co = w.shape[0]
+            w2 = w.detach().reshape(co, -1)[:, ci_lo:ci_hi].contiguous()
+        sfx = "_adjoint" if adjoint else ""
         if split:
             wp = torch.empty(lib().p2pb_pointwise_split_packed_bytes(_i(co), _i(ci_hi - ci_lo)), dtype=torch.uint8,
                              device=w.device)
-            call("p2pb_pointwise_pack_weights_split", _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
+            call("p2pb_pointwise_pack_weights_split" + sfx, _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
         else:
             wp = torch.empty(lib().p2pb_pointwise_packed_floats(_i(co), _i(ci_hi - ci_lo)), dtype=F32, device=w.device)
-            call("p2pb_pointwise_pack_weights", _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
+            call("p2pb_pointwise_pack_weights" + sfx, _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
         packs[k] = wp
     return packs[k]
 
@@ -591,7 +603,7 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
     point_major (no statistics, rows 16-byte aligned): y f32[B,P,Cout], the layout group_sub / interp_add gather from."""
     check(x, F32, "x")
     b, ci, p = x.shape
-    co = conv.weight.shape[0]
+    co = conv.out_channels if getattr(conv, "adjoint", False) else conv.weight.shape[0]
     split = use_split_pw(ci, co, p, math)
     if in_scale is not None and (co + (127 if split else 63)) // (128 if split else 64) >= int(os.environ.get("P2PB_PREPASS_BLOCKS", "9")):
         # every output-channel block re-applies the folded norm+Swish to its operand: for very wide layers one

@@ -244,11 +244,19 @@ class GraphedStep:
         self.model, self.optimizer, self.sched, self.warmup = model, optimizer, lr_scheduler, int(warmup)
         self.calls, self.graph, self.static = 0, None, None
         self.side = torch.cuda.Stream()
+        self.overlap = os.environ.get("P2PB_WGRAD_OVERLAP", "0") == "1"  # measured: profiles/r03c_wgrad_overlap_ab.txt (slower)
+        self.wgrad_stream = torch.cuda.Stream()
 
     def _step(self, x_gt, x_start, x_cond, steps):
+        from . import dense
+
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.model(x_gt, x_start, x_cond, steps=steps)
-        loss.backward()
+        if self.overlap:  # weight-gradient GEMMs on a second stream beside the data-gradient chain, joined after backward
+            with dense.wgrad_overlap(self.wgrad_stream):
+                loss.backward()
+        else:
+            loss.backward()
         self.optimizer.step()
         return loss.detach()  # (a live loss would keep the AccumulateGrad nodes of this stream alive into the capture)
 
