@@ -119,10 +119,19 @@ __device__ __forceinline__ float f16_weight_scale(float wmax) {
 }
 // max |w| of a tensor into *slot (uint bits of a non-negative float order like the float), slot zeroed before
 static __global__ void absmax_bits_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ slot) {
+  __shared__ float part[4];
   float m = 0.0f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(w[i]));
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(slot, __builtin_bit_cast(unsigned, m));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per workgroup (they serialise on the one line: 256 of them were most of this kernel's 10 us)
+  if (threadIdx.x == 0) atomicMax(slot, __builtin_bit_cast(unsigned, fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+// workgroups for a tensor of n elements: 16 elements per thread, at most 64
+static inline unsigned absmax_blocks(size_t n) {
+  const size_t b = (n + 4095) / 4096;
+  return (unsigned)(b < 1 ? 1 : b > 64 ? 64 : b);
 }
 
 // ---- 32 rows x 32 lanes -> one row total per lane ("reduce-scatter" over the half-wave) ----

@@ -1057,7 +1057,7 @@ static int conv_pack_split(int cout, int cin, const float *w, void *wt_split, bo
   if (mode == SPLIT_F16X3) {
     const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin * 27,
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(absmax_blocks((size_t)cout * cin * 27)), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin * 27,
                        (unsigned *)trailer);
   }
   hipLaunchKernelGGL(conv3d_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),

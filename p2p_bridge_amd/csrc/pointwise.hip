@@ -984,7 +984,7 @@ static int pw_pack_split(int cout, int cin, const float *w, void *wp, bool adjoi
   if (mode == SPLIT_F16X3) {
     const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(absmax_bits_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin,
+    hipLaunchKernelGGL(absmax_bits_kernel, dim3(absmax_blocks((size_t)cout * cin)), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin,
                        (unsigned *)trailer);
   }
   hipLaunchKernelGGL(pw_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),

@@ -19,17 +19,12 @@ for _ in range(3): step()
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step(); torch.cuda.synchronize()
-ev = prof.events()
-want = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add_", "aten::add", "aten::contiguous", "aten::mul", "aten::cat", "aten::sum", "aten::clone")
-cnt = collections.Counter()
-for e in ev:
-    if e.name in want and e.device_type == torch.autograd.DeviceType.CPU:
-        st = [f for f in (e.stack or []) if "p2p_bridge_amd" in f or "autograd" in f][:3]
-        kids = sum(1 for k in e.kernels) if hasattr(e, "kernels") else 0
-        if kids:
-            cnt[(e.name, " <- ".join(s.split("/")[-1] for s in st))] += kids
-tot = collections.Counter()
-for (n, s), v in cnt.items(): tot[n] += v
-print(dict(tot))
-for (n, s), v in cnt.most_common(60):
-    print(f"{v:5d} {n:16s} {s}")
+want = ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::copy_", "aten::contiguous", "aten::add_", "aten::add", "aten::mul", "aten::cat", "aten::sum", "aten::clone")
+rows = []
+for e in prof.key_averages(group_by_stack_n=12):
+    if e.key in want:
+        st = [f for f in e.stack if "p2p_bridge_amd" in f or "torch/autograd" in f or "torch/nn" in f][:4]
+        rows.append((e.count, e.key, " <- ".join(x.strip().split("/")[-1][:70] for x in st)))
+rows.sort(reverse=True)
+for c, k, st in rows[:70]:
+    print(f"{c:5d} {k:18s} {st}")

@@ -1,5 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_optim_gpu.py tests/test_dense_train_gpu.py tests/test_train_gpu.py tests/test_full_size_parity_gpu.py -x -q -m gpu -s > gpurun_out/optim_tests.log 2>&1; echo "tests exit $?"
-tail -n 4 gpurun_out/optim_tests.log; grep -h "7 steps" gpurun_out/optim_tests.log
-for o in 0 1; do python tools/exp_train_step.py 2>&1 | tail -1; done
+timeout 2400 python -m pytest tests -q -m gpu > gpurun_out/r03c_gpu_tests.txt 2>&1; echo "tests exit $?"
+tail -n 3 gpurun_out/r03c_gpu_tests.txt
+bash tools/profile_round.sh r03c > gpurun_out/profile_round.log 2>&1
+tail -n 12 gpurun_out/profile_round.log | cut -c1-700
