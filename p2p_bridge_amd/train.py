@@ -221,33 +221,92 @@ def train_step(model, optimizer, lr_scheduler, batches: Iterator[Dict], cfg, ali
     return loss_accum
 
 
+class GradBuckets:
+    """Bucketed gradient averaging over the process group for steps that do not run under DistributedDataParallel (the
+    captured step): the gradients are copied into a few flat buffers (25 MB like DDP's buckets: a ring all-reduce over
+    xGMI is per-link bound, a handful of large collectives beats hundreds of small ones), all-reduced (SUM) asynchronously
+    one after the other, scaled by 1 / world and copied back -- two multi-tensor copies and one collective per bucket.
+    Gradient tensors may change address between calls (the flat buffers are keyed on the shapes only)."""
+
+    def __init__(self, params, bucket_bytes: int = 25 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):  # (gradients become ready roughly in reverse parameter order)
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [None] * len(self.buckets)
+
+    @torch.no_grad()
+    def allreduce(self, world: Optional[int] = None):
+        world = dist.get_world_size() if world is None else world
+        work = []
+        for k, bucket in enumerate(self.buckets):
+            ps = [p for p in bucket if p.grad is not None]
+            if not ps:
+                continue
+            n = sum(p.numel() for p in ps)
+            if self.flat[k] is None or self.flat[k].numel() != n or self.flat[k].device != ps[0].device:
+                self.flat[k] = torch.empty(n, dtype=ps[0].grad.dtype, device=ps[0].device)
+            views, off = [], 0
+            for p in ps:
+                views.append(self.flat[k][off:off + p.numel()].view_as(p.grad))
+                off += p.numel()
+            torch._foreach_copy_(views, [p.grad for p in ps])
+            work.append((dist.all_reduce(self.flat[k], op=dist.ReduceOp.SUM, async_op=True), k, ps, views))
+        for w, k, ps, views in work:
+            w.wait()
+            self.flat[k].mul_(1.0 / world)
+            torch._foreach_copy_([p.grad for p in ps], views)
+
+
+def broadcast_parameters(module, src: int = 0):
+    """every rank starts from rank `src`'s parameters and buffers (what DistributedDataParallel does when it wraps)"""
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src)
+
+
 class GraphedStep:
     """The optimiser step of train_step() as ONE hipGraph: zero_grad -> loss = model(x_gt, x_start, x_cond) -> backward ->
-    clip + AdamW (optim.ClipAdamW), captured once with static input buffers and replayed per step -- about 1200 kernel
+    clip + AdamW (optim.ClipAdamW), captured once with static input buffers and replayed per step -- about 1100 kernel
     launches a step at BASELINE config 3's shape, which the eager loop cannot issue as fast as the GPU runs them.
     Same order of operations as the reference's loop (train.py:107-143); what stays on the host, outside the graph: the data
     side (get_data_batch and its auction alignment), the draw of the bridge steps (torch.randint on the CPU generator, as
     P2PB.forward draws them: the host random stream is the eager loop's), the LR scheduler (the learning rate is read from
     the optimiser's control block) and the EMA update. The first `warmup` calls run eagerly (they are real steps; the
     capture needs warmed-up allocators and packed weights), the next call captures and replays.
-    Not for DDP (the bucketed all-reduce inside the backward is left to the eager loop), accumulation_steps > 1 or a
-    GradScaler: the loss is fp32 throughout, so the scaler only contributes its skip-the-step-on-overflow,
-    which ClipAdamW(skip_nonfinite=True) does on the device."""
+    distributed=True (one process per GPU, the network NOT wrapped in DistributedDataParallel -- its hooks would put
+    collectives inside the capture): the graph ends after backward, the gradients are averaged over the process group in
+    25 MB buckets (GradBuckets: RCCL ring all-reduces over xGMI, issued back to back), then clip + AdamW run as their three
+    launches; rank 0's parameters are broadcast at construction. The all-reduce is not hidden behind the backward kernels
+    as DDP's is; it costs less than the launch time the capture saves (105.8 MB of gradients at config 3).
+    Not for accumulation_steps > 1 or a GradScaler: the loss is fp32 throughout, so the scaler only
+    contributes its skip-the-step-on-overflow, which ClipAdamW(skip_nonfinite=True) does on the device."""
 
-    def __init__(self, model, optimizer, lr_scheduler=None, warmup: int = 3):
+    def __init__(self, model, optimizer, lr_scheduler=None, warmup: int = 3, distributed: bool = False):
         from .optim import ClipAdamW
 
         if not isinstance(optimizer, ClipAdamW):
             raise TypeError("GraphedStep needs optim.ClipAdamW (load_optim_sched(..., fused=True))")
         if hasattr(model.model, "module"):
-            raise NotImplementedError("GraphedStep: single-process training (DDP steps run eagerly)")
+            raise NotImplementedError("GraphedStep: pass the network unwrapped (distributed=True averages the gradients itself)")
         self.model, self.optimizer, self.sched, self.warmup = model, optimizer, lr_scheduler, int(warmup)
         self.calls, self.graph, self.static = 0, None, None
         self.side = torch.cuda.Stream()
         self.overlap = os.environ.get("P2PB_WGRAD_OVERLAP", "0") == "1"  # measured: profiles/r03c_wgrad_overlap_ab.txt (slower)
         self.wgrad_stream = torch.cuda.Stream()
+        self.distributed = bool(distributed)
+        self.buckets = None
+        if self.distributed:
+            broadcast_parameters(model.model)
+            self.buckets = GradBuckets(model.model.parameters())
 
-    def _step(self, x_gt, x_start, x_cond, steps):
+    def _fwd_bwd(self, x_gt, x_start, x_cond, steps):
         from . import dense
 
         self.optimizer.zero_grad(set_to_none=True)
@@ -257,14 +316,27 @@ class GraphedStep:
                 loss.backward()
         else:
             loss.backward()
-        self.optimizer.step()
         return loss.detach()  # (a live loss would keep the AccumulateGrad nodes of this stream alive into the capture)
 
-    def _after(self):
+    def _step(self, x_gt, x_start, x_cond, steps):
+        """the captured region: everything up to the optimiser (single process), or up to the end of backward"""
+        loss = self._fwd_bwd(x_gt, x_start, x_cond, steps)
+        if not self.distributed:
+            self.optimizer.step()
+        return loss
+
+    def _finish(self, loss):
+        """outside the graph: gradient averaging + optimiser (distributed), scheduler, EMA, loss all-reduce (train.py:143)"""
+        if self.distributed:
+            self.buckets.allreduce()
+            self.optimizer.step()
         if self.sched is not None:
             self.sched.step()
         if self.model.ema is not None:
             self.model.ema.update()
+        if self.distributed:
+            dist.all_reduce(loss)
+        return loss
 
     def __call__(self, x_gt, x_start, x_cond=None) -> torch.Tensor:
         steps = torch.randint(0, self.model.timesteps, (x_gt.shape[0],))
@@ -274,8 +346,7 @@ class GraphedStep:
             with torch.cuda.stream(self.side):
                 loss = self._step(x_gt, x_start, x_cond, steps.to(x_gt.device))
             torch.cuda.current_stream().wait_stream(self.side)
-            self._after()
-            return loss
+            return self._finish(loss)
         if self.graph is None:
             self.static = dict(x_gt=x_gt.clone(), x_start=x_start.clone(), x_cond=None if x_cond is None else x_cond.clone(),
                                steps=steps.to(x_gt.device))
@@ -294,9 +365,9 @@ class GraphedStep:
         st["steps"].copy_(steps, non_blocking=True)
         self.optimizer.sync_lr()
         self.graph.replay()
-        self.optimizer.bump_versions()  # (a replay changes the weights without autograd seeing it: caches keyed on _version)
-        self._after()
-        return st["loss"].clone()
+        if not self.distributed:
+            self.optimizer.bump_versions()  # (a replay changes the weights without autograd seeing it: caches keyed on _version)
+        return self._finish(st["loss"].clone())
 
 
 def save_checkpoint(path, step, model, optimizer):
@@ -311,9 +382,12 @@ def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, 
     """the reference's loop (train.py:107-211) over `steps` optimiser steps. Returns the list of logged mean losses.
     ckpt: a checkpoint dictionary already loaded into `model` (p2pb.load_checkpoint): the optimiser state is restored from
     it and, unless `restart`, training continues at ckpt["step"] + 1 (models/model_loader.py:13-61,114-165).
-    graph: the step as one captured hipGraph (GraphedStep; single process, accumulation_steps 1)."""
+    graph: the step as one captured hipGraph (GraphedStep; accumulation_steps 1; with distributed=True the network must NOT
+    be DDP-wrapped: the gradients are averaged in buckets after the replay)."""
     tr = _get(cfg, "training")
-    graph = bool(graph) and not distributed and int(_get(tr, "accumulation_steps", 1)) == 1 and model.device.type == "cuda"
+    graph = bool(graph) and int(_get(tr, "accumulation_steps", 1)) == 1 and model.device.type == "cuda"
+    if graph and distributed and hasattr(model.model, "module"):
+        raise ValueError("train(graph=True, distributed=True) takes the network unwrapped: GraphedStep averages the gradients itself")
     optimizer, sched = load_optim_sched(cfg, model, ckpt, restart, fused=True if graph else None, skip_nonfinite=graph)
     if ckpt is not None and not restart and "step" in ckpt:
         start_step = int(ckpt["step"]) + 1
@@ -322,7 +396,7 @@ def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, 
     scaler = torch.amp.GradScaler("cuda", enabled=bool(_get(tr, "amp", False))) if on_gpu else None
     model.train()
     history = []
-    stepper = GraphedStep(model, optimizer, sched) if graph else None
+    stepper = GraphedStep(model, optimizer, sched, distributed=distributed) if graph else None
     for step in range(start_step, start_step + steps):
         if stepper is not None:
             data = get_data_batch(next(batches), cfg, align_fn)
@@ -400,7 +474,7 @@ def main(argv=None):
     ap.add_argument("--bs", type=int, default=64, help="GLOBAL batch (divided over the GPUs like train.py:226)")
     ap.add_argument("--npoints", type=int, default=2048)
     ap.add_argument("--no-align", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="the optimiser step as one captured hipGraph (single GPU)")
+    ap.add_argument("--graph", action="store_true", help="forward + backward (+ optimiser on one GPU) as one captured hipGraph per step; with --gpus N the gradients are averaged in 25 MB buckets after the replay instead of by DDP")
     ap.add_argument("--output-dir", default=None)
     ap.add_argument("--resume", default=None, help="checkpoint (step_*.pth) to continue from: weights, EMA, optimiser, step")
     ap.add_argument("--restart", action="store_true", help="with --resume: load the network only, start at step 0")
@@ -432,7 +506,7 @@ def main(argv=None):
     if args.resume:
         ckpt = torch.load(args.resume, map_location="cpu")
         product.load_checkpoint(model, ckpt, use_ema=True, restart=args.restart)
-    if mode == "rank":
+    if mode == "rank" and not args.graph:  # (--graph: train.GraphedStep averages the gradients itself, no DDP hooks)
         ddp_wrap(model, local_rank)
     batches = synthetic_punet_batches(cfg["training"]["bs"], args.npoints, seed=1000 * rank, device=model.device)
     t0 = time.perf_counter()

@@ -186,3 +186,55 @@ def test_get_data_batch_and_align_hook():
           "noisy_features": torch.rand(2, 5, 64), "noisy_colors": torch.rand(2, 64, 3)}
     d2 = T.get_data_batch(b2, cfg)
     assert d2["x_cond"].shape == (2, 8, 64) and d2["x_gt"].shape == (2, 3, 64)
+
+
+def _bucket_worker(rank, world, port, out):
+    from p2p_bridge_amd import train as T
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, model = make()
+    # rank-dependent start: broadcast_parameters must make every rank rank 0's copy (what DDP does when it wraps)
+    with torch.no_grad():
+        for p in model.model.parameters():
+            p.add_(float(rank))
+    T.broadcast_parameters(model.model)
+    full = batch(8, 64, seed=3)
+    steps = torch.arange(8) * 100 + 7
+    lo, hi = rank * 4, rank * 4 + 4
+    data = T.get_data_batch({k: v[lo:hi] for k, v in full.items()}, cfg)
+    loss = model(data["x_gt"], data["x_start"], data["x_cond"], steps=steps[lo:hi])
+    loss.backward()  # local gradients only: no DDP
+    buckets = T.GradBuckets(model.model.parameters(), bucket_bytes=64)  # (tiny buckets: several collectives in flight)
+    assert len(buckets.buckets) >= 3
+    unused = nn.Parameter(torch.zeros(3))  # a parameter without a gradient is left alone
+    buckets.buckets[0].append(unused)
+    buckets.allreduce()
+    assert unused.grad is None
+    first = {k: p.grad.clone() for k, p in model.model.named_parameters()}
+    buckets.allreduce()  # averaging identical gradients changes nothing; the flat buffers are reused
+    for k, p in model.model.named_parameters():
+        assert torch.allclose(p.grad, first[k], rtol=1e-6, atol=1e-9)
+    if rank == 0:
+        torch.save({"grads": first, "params": {k: p.detach().clone() for k, p in model.model.named_parameters()}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_buckets_average_like_ddp(tmp_path):
+    """train.GradBuckets (the captured step's gradient averaging, world_size 2 over gloo): bucketed flat all-reduce ==
+    the 1-rank gradients on the concatenated batch, exactly what the DDP test above establishes for DDP's reducer"""
+    from p2p_bridge_amd import train as T
+    from p2p_bridge_amd.sharding import free_port
+
+    out = str(tmp_path / "b0.pt")
+    mp.spawn(_bucket_worker, args=(2, free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    cfg, model = make()
+    for k, p in model.model.named_parameters():
+        assert torch.equal(got["params"][k], p.detach()), k  # rank 0's start everywhere
+    data = T.get_data_batch(batch(8, 64, seed=3), cfg)
+    loss = model(data["x_gt"], data["x_start"], data["x_cond"], steps=torch.arange(8) * 100 + 7)
+    loss.backward()
+    for k, p in model.model.named_parameters():
+        assert torch.allclose(got["grads"][k], p.grad, rtol=1e-5, atol=1e-7), k
