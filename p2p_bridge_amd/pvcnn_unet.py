@@ -204,16 +204,41 @@ class StyleBank:
         self._refresh()  # (slices only depend on the shapes)
         w = torch.cat([m.emd.weight for m in self.mods], dim=0)
         b = torch.cat([m.emd.bias for m in self.mods], dim=0)
-        return _Styles(cond, F.linear(cond, w, b), self.slices)
+        styles = F.linear(cond, w, b)
+        # one autograd node for all the per-layer slices: 42 separate `styles[:, lo:hi]` cost a zero fill, a copy and an
+        # accumulation of the full [B, 13184] row each in the backward pass (126 launches per step)
+        bounds = tuple(self.slices[id(m)] for m in self.mods)
+        parts = _SplitColumns.apply(styles, bounds)
+        return _Styles(cond, styles, self.slices, {id(m): t for m, t in zip(self.mods, parts)})
+
+
+class _SplitColumns(torch.autograd.Function):
+    """x[B, total] -> the column slices x[:, lo:hi] (views); backward = ONE concatenation of the slices' gradients"""
+
+    @staticmethod
+    def forward(ctx, x, bounds):
+        ctx.bounds, ctx.rows = bounds, x.shape[0]
+        ctx.set_materialize_grads(False)
+        return tuple(x[:, lo:hi] for lo, hi in bounds)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next((g for g in grads if g is not None), None)
+        if ref is None:
+            return None, None
+        parts = [g if g is not None else ref.new_zeros(ctx.rows, hi - lo) for g, (lo, hi) in zip(grads, ctx.bounds)]
+        return torch.cat(parts, dim=1), None
 
 
 class _Styles:
     """the global embedding of this evaluation + the precomputed style of every AdaGN"""
 
-    def __init__(self, vector, styles, slices):
-        self.vector, self.styles, self.slices = vector, styles, slices
+    def __init__(self, vector, styles, slices, parts=None):
+        self.vector, self.styles, self.slices, self.parts = vector, styles, slices, parts
 
     def style(self, adagn):
+        if self.parts is not None:  # training: the slices of ONE autograd node (StyleBank.evaluate_train)
+            return self.parts[id(adagn)]
         lo, hi = self.slices[id(adagn)]
         return self.styles[:, lo:hi]
 
