@@ -547,12 +547,20 @@ int p2pb_pointwise_pack_weights_split_adjoint(int cout, int cin, const float *w_
  *   max_norm <= 0: no clipping (gradients are not rewritten). decoupled: AdamW (p *= 1 - lr wd) / Adam (g += wd p).
  *   skip_nonfinite: a non-finite gradient norm leaves parameters, moments and the step count untouched (what the
  *           GradScaler of the reference's loop does to optimizer.step()).
+ *   amax    NULL, or device u32[ntensors]: bits of max |param| per tensor AFTER this update (0 for an empty / all-zero
+ *           tensor) -- what p2pb_*_pack_weights_split_amax take, so that the next forward's weight packs need no reduction
+ *           launch of their own
  * -> 0 or a hipError_t code */
 size_t p2pb_optim_entry_bytes(void);
 int p2pb_optim_chunk(void);
 int p2pb_optim_clip_adam_step(int nchunks, const void *table, const int *chunks, double *partial, double *ctl, double max_norm,
                               double beta1, double beta2, double eps, double weight_decay, int decoupled, int skip_nonfinite,
-                              void *stream);
+                              unsigned *amax, int ntensors, void *stream);
+/* p2pb_conv3d_k3_pack_weights_split / p2pb_pointwise_pack_weights_split with max |w| (float bits, device) supplied by the
+ * caller instead of reduced in front of the pack: the same pack for the same value. -> 0 or P2PB_EINVAL */
+int p2pb_conv3d_k3_pack_weights_split_amax(int cout, int cin, const float *w, void *wt_split, const unsigned *amax_bits,
+                                           void *stream);
+int p2pb_pointwise_pack_weights_split_amax(int cout, int cin, const float *w, void *wp, const unsigned *amax_bits, void *stream);
 
 #ifdef __cplusplus
 }

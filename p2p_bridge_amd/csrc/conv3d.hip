@@ -396,10 +396,16 @@ static __host__ __device__ size_t conv_split_trailer_bytes(int nchunk, int cout_
 // -- a correlation's adjoint is the correlation with the point-reflected kernel and the channel roles swapped
 static __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, int cout_pad, const float *__restrict__ w,
                                         unsigned short *__restrict__ wt, int mode, float *__restrict__ trailer, long s_co,
-                                        long s_ci, int flip) {
+                                        long s_ci, int flip, const unsigned *__restrict__ amax) {
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;  // one thread per (tap, chunk, khalf, co, idx)
-  const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(trailer[0]) : 1.0f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
+  // max |w| (bits): from the caller's slot (amax: the optimiser keeps it per tensor, csrc/optim.hip) or from the reduction
+  // launched in front of this kernel (trailer[0])
+  const float wmax = amax ? __builtin_bit_cast(float, *amax) : trailer[0];
+  const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(wmax) : 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
+    if (amax) trailer[0] = wmax, trailer[2] = trailer[3] = 0.0f;  // (the whole trailer, as the zero fill of the other path)
+  }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int idx = (int)(e & 7);
     size_t q = e >> 3;
@@ -1047,14 +1053,15 @@ extern "C" size_t p2pb_conv3d_k3_split_packed_bytes(int cout, int cin) {
   return (size_t)27 * nchunk * 3 * 2 * cout_pad * 8 * sizeof(unsigned short) + 16;  // + trailer (fp16 mode's scales)
 }
 
-static int conv_pack_split(int cout, int cin, const float *w, void *wt_split, bool adjoint, void *stream) {
+static int conv_pack_split(int cout, int cin, const float *w, void *wt_split, bool adjoint, void *stream,
+                           const unsigned *amax = nullptr) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;
   // the pack is made for the arithmetic selected NOW (p2pb_set_split_terms); callers re-pack after a switch to / from 16
   float *trailer = (float *)((char *)wt_split + conv_split_trailer_bytes(nchunk, cout_pad));
   const int mode = p2pb_g_split_terms;
-  if (mode == SPLIT_F16X3) {
+  if (mode == SPLIT_F16X3 && !amax) {
     const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
     if (rc) return rc;
     hipLaunchKernelGGL(absmax_bits_kernel, dim3(absmax_blocks((size_t)cout * cin * 27)), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin * 27,
@@ -1062,7 +1069,8 @@ static int conv_pack_split(int cout, int cin, const float *w, void *wt_split, bo
   }
   hipLaunchKernelGGL(conv3d_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
                      dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, (unsigned short *)wt_split, mode,
-                     trailer, adjoint ? 27L : (long)cin * 27, adjoint ? (long)cout * 27 : 27L, adjoint ? 1 : 0);
+                     trailer, adjoint ? 27L : (long)cin * 27, adjoint ? (long)cout * 27 : 27L, adjoint ? 1 : 0,
+                     mode == SPLIT_F16X3 ? amax : nullptr);
   return p2pb_launch_status();
 }
 extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float *w, void *wt_split, void *stream) {
@@ -1070,6 +1078,10 @@ extern "C" int p2pb_conv3d_k3_pack_weights_split(int cout, int cin, const float 
 }
 extern "C" int p2pb_conv3d_k3_pack_weights_split_adjoint(int cout, int cin, const float *w_forward, void *wt_split, void *stream) {
   return conv_pack_split(cout, cin, w_forward, wt_split, true, stream);
+}
+extern "C" int p2pb_conv3d_k3_pack_weights_split_amax(int cout, int cin, const float *w, void *wt_split, const unsigned *amax_bits,
+                                                      void *stream) {
+  return amax_bits ? conv_pack_split(cout, cin, w, wt_split, false, stream, amax_bits) : P2PB_EINVAL;
 }
 #endif
 

@@ -74,8 +74,11 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_sumsq_kernel(const OptEntry
 }
 
 __global__ __launch_bounds__(OPT_THREADS) void optim_finish_kernel(int nchunks, const double *__restrict__ partial, double *__restrict__ ctl,
-                                                                  double max_norm, double beta1, double beta2, int skip_nonfinite) {
+                                                                  double max_norm, double beta1, double beta2, int skip_nonfinite,
+                                                                  unsigned *__restrict__ amax, int ntensors) {
   __shared__ double red[OPT_THREADS / 64];
+  if (amax)  // the update kernel's workgroups add the updated tensors' max |w| to these (atomicMax on the bits)
+    for (int i = threadIdx.x; i < ntensors; i += OPT_THREADS) amax[i] = 0u;
   double s = 0.0;
   for (int i = threadIdx.x; i < nchunks; i += OPT_THREADS) s += partial[i];
   const double t = opt_block_sum(s, red);
@@ -117,7 +120,10 @@ __device__ __forceinline__ void opt_update(float &p, float &g, float &m, float &
 template <bool DECOUPLED>
 __global__ __launch_bounds__(OPT_THREADS) void optim_update_kernel(const OptEntry *__restrict__ tab, const int2 *__restrict__ chunks,
                                                                   const double *__restrict__ ctl, double wd_d, float omb1, float b2, float omb2,
-                                                                  float eps, int clip) {
+                                                                  float eps, int clip, unsigned *__restrict__ amax) {
+  __shared__ float wmax[OPT_THREADS / 64];
+  float pmax = 0.0f;  // max |p| of this chunk after the update: the weight packs of the next forward take their
+                      // per-tensor fp16 scale from it (p2pb_*_pack_weights_split_amax) instead of a reduction launch each
   const int2 c = chunks[blockIdx.x];
   const OptEntry e = tab[c.x];
   const long start = (long)c.y * OPT_CHUNK;
@@ -144,6 +150,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_update_kernel(const OptEntr
         ((float4 *)m)[i] = M;
         ((float4 *)v)[i] = V;
       }
+      pmax = fmaxf(fmaxf(pmax, fmaxf(fabsf(P.x), fabsf(P.y))), fmaxf(fabsf(P.z), fabsf(P.w)));
     }
     done = nq << 2;
   }
@@ -156,6 +163,17 @@ __global__ __launch_bounds__(OPT_THREADS) void optim_update_kernel(const OptEntr
       m[i] = M;
       v[i] = V;
     }
+    pmax = fmaxf(pmax, fabsf(P));
+  }
+  if (amax) {  // (fmaxf drops a NaN operand, as the packs' own reduction does)
+    for (int o = 32; o > 0; o >>= 1) pmax = fmaxf(pmax, __shfl_xor(pmax, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = pmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float w = wmax[0];
+      for (int i = 1; i < OPT_THREADS / 64; ++i) w = fmaxf(w, wmax[i]);
+      atomicMax(amax + c.x, __builtin_bit_cast(unsigned, w));
+    }
   }
 }
 
@@ -166,20 +184,20 @@ int p2pb_optim_chunk(void) { return OPT_CHUNK; }
 
 int p2pb_optim_clip_adam_step(int nchunks, const void *table, const int *chunks, double *partial, double *ctl, double max_norm,
                               double beta1, double beta2, double eps, double weight_decay, int decoupled, int skip_nonfinite,
-                              void *stream_) {
+                              unsigned *amax, int ntensors, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (nchunks <= 0) return 0;
-  if (!table || !chunks || !partial || !ctl) return (int)hipErrorInvalidValue;
+  if (!table || !chunks || !partial || !ctl || (amax && ntensors <= 0)) return (int)hipErrorInvalidValue;
   optim_sumsq_kernel<<<nchunks, OPT_THREADS, 0, stream>>>((const OptEntry *)table, (const int2 *)chunks, partial);
-  optim_finish_kernel<<<1, OPT_THREADS, 0, stream>>>(nchunks, partial, ctl, max_norm, beta1, beta2, skip_nonfinite);
+  optim_finish_kernel<<<1, OPT_THREADS, 0, stream>>>(nchunks, partial, ctl, max_norm, beta1, beta2, skip_nonfinite, amax, ntensors);
   const double wd = weight_decay;
   const float omb1 = (float)(1.0 - beta1), b2 = (float)beta2, omb2 = (float)(1.0 - beta2), e = (float)eps;
   if (decoupled)
     optim_update_kernel<true><<<nchunks, OPT_THREADS, 0, stream>>>((const OptEntry *)table, (const int2 *)chunks, ctl, wd, omb1, b2, omb2, e,
-                                                                    max_norm > 0.0);
+                                                                    max_norm > 0.0, amax);
   else
     optim_update_kernel<false><<<nchunks, OPT_THREADS, 0, stream>>>((const OptEntry *)table, (const int2 *)chunks, ctl, wd, omb1, b2, omb2, e,
-                                                                     max_norm > 0.0);
+                                                                     max_norm > 0.0, amax);
   return p2pb_launch_status();
 }
 }

@@ -940,10 +940,15 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 // channel = chunk*32 + kstep*16 + khalf*8 + idx
 // mode SPLIT_F16X3: planes 0, 1 hold the fp16 pair of w * S_w (plane 2 unused); trailer = {max|w| bits, 1 / (S_x S_w)}
 __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, const float *__restrict__ w,
-                                     unsigned short *__restrict__ wp, int mode, float *__restrict__ trailer, long s_co, long s_ci) {
+                                     unsigned short *__restrict__ wp, int mode, float *__restrict__ trailer, long s_co, long s_ci,
+                                     const unsigned *__restrict__ amax) {
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;  // (chunk, coblk, kstep, khalf, co, idx)
-  const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(trailer[0]) : 1.0f;
-  if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
+  const float wmax = amax ? __builtin_bit_cast(float, *amax) : trailer[0];  // (conv3d_pack_split_kernel: same convention)
+  const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(wmax) : 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    trailer[1] = mode == SPLIT_F16X3 ? 1.0f / (SPLIT_F16_SX * sw) : 1.0f;
+    if (amax) trailer[0] = wmax, trailer[2] = trailer[3] = 0.0f;  // (the whole trailer, as the zero fill of the other path)
+  }
   for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
     const int idx = (int)(e & 7);
     size_t q = e >> 3;
@@ -974,14 +979,14 @@ extern "C" size_t p2pb_pointwise_split_packed_bytes(int cout, int cin) {
   return nchunk * ncoblk * (2 * 3 * 2 * 128) * 16 + 16;  // + trailer {max|w| bits, output scale, -, -} (fp16 mode)
 }
 
-static int pw_pack_split(int cout, int cin, const float *w, void *wp, bool adjoint, void *stream) {
+static int pw_pack_split(int cout, int cin, const float *w, void *wp, bool adjoint, void *stream, const unsigned *amax = nullptr) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + PWS_CK - 1) / PWS_CK, ncoblk = (cout + 127) / 128;
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;
   // the pack is made for the arithmetic selected NOW (p2pb_set_split_terms); callers re-pack after a switch
   float *trailer = (float *)((char *)wp + (size_t)nchunk * ncoblk * PWS_TILE * 16);
   const int mode = p2pb_g_split_terms;
-  if (mode == SPLIT_F16X3) {
+  if (mode == SPLIT_F16X3 && !amax) {
     const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
     if (rc) return rc;
     hipLaunchKernelGGL(absmax_bits_kernel, dim3(absmax_blocks((size_t)cout * cin)), dim3(256), 0, (hipStream_t)stream, w, (size_t)cout * cin,
@@ -989,7 +994,7 @@ static int pw_pack_split(int cout, int cin, const float *w, void *wp, bool adjoi
   }
   hipLaunchKernelGGL(pw_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
                      dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp, mode, trailer,
-                     adjoint ? 1L : (long)cin, adjoint ? (long)cout : 1L);
+                     adjoint ? 1L : (long)cin, adjoint ? (long)cout : 1L, mode == SPLIT_F16X3 ? amax : nullptr);
   return p2pb_launch_status();
 }
 extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float *w, void *wp, void *stream) {
@@ -997,6 +1002,10 @@ extern "C" int p2pb_pointwise_pack_weights_split(int cout, int cin, const float 
 }
 extern "C" int p2pb_pointwise_pack_weights_split_adjoint(int cout, int cin, const float *w_forward, void *wp, void *stream) {
   return pw_pack_split(cout, cin, w_forward, wp, true, stream);
+}
+extern "C" int p2pb_pointwise_pack_weights_split_amax(int cout, int cin, const float *w, void *wp, const unsigned *amax_bits,
+                                                      void *stream) {
+  return amax_bits ? pw_pack_split(cout, cin, w, wp, false, stream, amax_bits) : P2PB_EINVAL;
 }
 
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,

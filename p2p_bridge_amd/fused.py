@@ -234,6 +234,15 @@ def use_split(cout: int, math=None) -> bool:
     return (math or conv_math()) in SPLIT_MATHS
 
 
+def _amax_slot(w):
+    """device slot holding the float bits of max |w|, kept by optim.ClipAdamW's update kernel -- valid only for exactly the
+    version of the parameter that update produced (any other in-place change falls back to the pack's own reduction)"""
+    slot = getattr(w, "_p2pb_amax", None)
+    if slot is None or getattr(w, "_p2pb_amax_version", None) != w._version or slot.device != w.device:
+        return None
+    return slot
+
+
 def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
     """packed copy of a Conv3d weight (fp32 [27][cin_pad][cout_pad], or split=True the 16-bit pack of the split-operand
     kernel), cached on the module and refreshed when the parameter is modified in place (optimizer step /
@@ -254,8 +263,12 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
         wc = w.detach().contiguous()
         if split:
             wt = torch.empty(lib().p2pb_conv3d_k3_split_packed_bytes(_i(co), _i(ci)), dtype=torch.uint8, device=w.device)
-            call("p2pb_conv3d_k3_pack_weights_split_adjoint" if adjoint else "p2pb_conv3d_k3_pack_weights_split", _i(co), _i(ci),
-                 ptr(wc), ptr(wt), stream_ptr())
+            amax = _amax_slot(w) if (split == "f16" and not adjoint) else None
+            if amax is not None:
+                call("p2pb_conv3d_k3_pack_weights_split_amax", _i(co), _i(ci), ptr(wc), ptr(wt), ptr(amax), stream_ptr())
+            else:
+                call("p2pb_conv3d_k3_pack_weights_split_adjoint" if adjoint else "p2pb_conv3d_k3_pack_weights_split", _i(co),
+                     _i(ci), ptr(wc), ptr(wt), stream_ptr())
         else:
             wt = torch.empty(lib().p2pb_conv3d_k3_packed_floats(_i(co), _i(ci)), dtype=F32, device=w.device)
             call("p2pb_conv3d_k3_pack_weights", _i(co), _i(ci), ptr(wc), ptr(wt), stream_ptr())
@@ -566,7 +579,11 @@ def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None, split=False) -> torch.Tenso
         if split:
             wp = torch.empty(lib().p2pb_pointwise_split_packed_bytes(_i(co), _i(ci_hi - ci_lo)), dtype=torch.uint8,
                              device=w.device)
-            call("p2pb_pointwise_pack_weights_split" + sfx, _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
+            amax = _amax_slot(w) if (split == "f16" and not adjoint and ci_lo == 0 and ci_hi == w2.shape[1] == w[0].numel()) else None
+            if amax is not None:
+                call("p2pb_pointwise_pack_weights_split_amax", _i(co), _i(ci_hi), ptr(w2), ptr(wp), ptr(amax), stream_ptr())
+            else:
+                call("p2pb_pointwise_pack_weights_split" + sfx, _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
         else:
             wp = torch.empty(lib().p2pb_pointwise_packed_floats(_i(co), _i(ci_hi - ci_lo)), dtype=F32, device=w.device)
             call("p2pb_pointwise_pack_weights" + sfx, _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())

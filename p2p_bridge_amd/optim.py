@@ -33,7 +33,7 @@ class ClipAdamW(torch.optim.Optimizer):
         self.decoupled, self.skip_nonfinite = bool(decoupled), bool(skip_nonfinite)
         self._ctl = None  # device f64[8]
         self._key = None  # the pointers the device tables were built from
-        self._tab = self._chunks = self._partial = None
+        self._tab = self._chunks = self._partial = self._amax = None
         self._htab = self._copied = None
         self._captured = False  # the tables were recorded into a hipGraph: the staging buffer must not change any more
         self._lr_dev = None
@@ -89,6 +89,12 @@ class ClipAdamW(torch.optim.Optimizer):
             self._tab = torch.empty(tab.shape, dtype=torch.int64, device=dev)    # node re-reads it at every replay
             self._chunks = torch.from_numpy(np.ascontiguousarray(chunks)).to(dev)
             self._partial = torch.empty(len(chunks), dtype=torch.float64, device=dev)
+            # max |p| per tensor after each update (float bits): the weight packs of the next forward take their fp16 scale
+            # from here (fused.pack_*_weight) instead of a zero fill + a reduction launch per layer per step
+            self._amax = torch.zeros(len(ps), dtype=torch.int32, device=dev)
+            for i, p in enumerate(ps):
+                p._p2pb_amax = self._amax[i:i + 1]
+                p._p2pb_amax_version = -1
             self._copied = torch.cuda.Event()
         elif self._captured:
             raise RuntimeError("ClipAdamW: this optimiser's tables belong to a captured step (train.GraphedStep): replay it "
@@ -126,7 +132,7 @@ class ClipAdamW(torch.optim.Optimizer):
         _lib.call("p2pb_optim_clip_adam_step", int(self._partial.numel()), _lib.ptr(self._tab), _lib.ptr(self._chunks),
                   _lib.ptr(self._partial), _lib.ptr(ctl), ctypes.c_double(self.max_norm), ctypes.c_double(b1), ctypes.c_double(b2),
                   ctypes.c_double(group["eps"]), ctypes.c_double(group["weight_decay"]), int(self.decoupled),
-                  int(self.skip_nonfinite), _lib.stream_ptr())
+                  int(self.skip_nonfinite), _lib.ptr(self._amax), int(self._amax.numel()), _lib.stream_ptr())
         self.bump_versions(ps)
         return loss
 
@@ -138,6 +144,9 @@ class ClipAdamW(torch.optim.Optimizer):
         torch.autograd.graph.increment_version(ps)
         if self.max_norm > 0.0:
             torch.autograd.graph.increment_version([p.grad for p in ps])
+        if self._tab is not None and len(ps) == self._tab.shape[0]:  # the slots hold max |p| of exactly this version
+            for p in ps:
+                p._p2pb_amax_version = p._version
 
     # ---- what the host may read back (each is one device -> host copy) ---------------------------------------------------
     def grad_norm(self) -> float:

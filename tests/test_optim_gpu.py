@@ -245,3 +245,31 @@ def test_graphed_step_with_two_ranks_follows_ddp(tmp_path):
     diff = (runs[True]["flat"] - runs[False]["flat"]).norm().item() / moved
     print(f"\ntwo ranks, 6 steps: |parameter change| {moved:.3e}; relative L2 difference graphed / DDP {diff:.3e}")
     assert moved > 1e-3 and diff < 2e-2
+
+
+def test_optimiser_keeps_max_abs_per_tensor_for_the_weight_packs():
+    """the update kernel leaves the float bits of max |p| per tensor (the fp16 scale of the f16x3 weight packs comes from it):
+    equal to a reduction over the updated tensor, and a pack made from the slot is byte-identical to one that reduces itself;
+    any other in-place change of the weight invalidates the slot"""
+    from p2p_bridge_amd import fused
+    from p2p_bridge_amd.optim import ClipAdamW
+
+    torch.manual_seed(3)
+    conv = torch.nn.Conv3d(16, 32, 3, padding=1).cuda()
+    lin = torch.nn.Conv1d(160, 256, 1).cuda()
+    ps = list(conv.parameters()) + list(lin.parameters())
+    opt = ClipAdamW(ps, lr=1e-2, max_norm=1.0)
+    for step in range(3):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        opt.step()
+        for i, p in enumerate(ps):
+            assert opt._amax[i].item() == p.detach().abs().max().view(torch.int32).item()
+            assert fused._amax_slot(p) is not None
+    a = fused.pack_conv3d_weight(conv, True).clone()
+    b = fused.pack_pointwise_weight(lin, 0, None, True).clone()
+    with torch.no_grad():
+        conv.weight.mul_(1.0)  # same values, new version: the slot no longer vouches for them
+        lin.weight.mul_(1.0)
+    assert fused._amax_slot(conv.weight) is None and fused._amax_slot(lin.weight) is None
+    assert torch.equal(fused.pack_conv3d_weight(conv, True), a) and torch.equal(fused.pack_pointwise_weight(lin, 0, None, True), b)
