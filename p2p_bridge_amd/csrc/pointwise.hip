@@ -362,14 +362,20 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
         load_ah(ci0 + 16);
         load_bh(ci0 + 16);
       }
+      // term by term over all the accumulators (a1 b0, a0 b1, a0 b0 per accumulator as before: same bits): the three MFMAs
+      // that update one accumulator are 4 MT instructions apart instead of back to back
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][1], pl0[t], acc[m][t]);
-          acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][0], pl1[t], acc[m][t]);
-          acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][0], pl0[t], acc[m][t]);
-        }
+        for (int t = 0; t < 4; ++t) acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][1], pl0[t], acc[m][t]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][0], pl1[t], acc[m][t]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][0], pl0[t], acc[m][t]);
     }
     const float oscale = ((const float *)(wp4 + (size_t)nchunk32 * ncoblk128 * PWS_TILE_))[1];
 #pragma unroll
