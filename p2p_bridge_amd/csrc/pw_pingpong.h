@@ -354,18 +354,32 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
 #endif
   // ---- epilogue (the arithmetic and the outputs of pws_epilogue; a slot = 64 consecutive positions)
   {
+    // bias (+ per-sample bias) of the tile's 256 channels through an LDS table: fetched by 256 lanes at once. Read per row
+    // straight from memory, the 32 rows of a lane were 32 (64 with bias_b) dependent load -> wait -> use round trips in a
+    // chain of branches -- most of the epilogue's 14.8 k cycles (profiles/r03b_pingpong_timeline.txt). The operand buffers
+    // are free: every wave's DMA has landed (vmcnt(0) above) once all of them are past this barrier.
+    float *btab = (float *)pp_lds;
+    __syncthreads();
+    if (tid < 256) {
+      float v = bias ? bias[co0 + tid] : 0.0f;
+      if (bias_b) v += bias_b[(size_t)b * cout + co0 + tid];
+      btab[tid] = v;
+    }
     const float oscale = ((const float *)(wp + (size_t)nstage * nblk128 * PWS_TILE))[1];  // 1 / (S_x S_w)
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        float bv = bias ? bias[co] : 0.0f;
-        if (bias_b) bv += bias_b[(size_t)b * cout + co];
+        const float bv = btab[wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf];
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n][r] = acc[m][n][r] * oscale + bv;
       }
   }
+  PP_TL(tl3);
+#ifdef PP_TIMELINE
+  unsigned long long tl4 = 0;
+#endif
   const int pw0 = pblk + wn * 128;  // the wave's first position
   if (out) {
     float *ob = out + (size_t)b * cout * P;
@@ -407,6 +421,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
       z[0] = 0.0f;
       z[1] = 0.0f;
     }
+#ifdef PP_TIMELINE
+    tl4 = __builtin_readcyclecounter();
+#endif
     if (POOL && pool_u == 0) {
 #pragma unroll
       for (int m = 0; m < 2; ++m)
@@ -430,8 +447,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
 #ifdef PP_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0 && pp_tl_buf) {
-    unsigned long long *q = pp_tl_buf + (size_t)lin * 4;
-    q[0] = tl0, q[1] = tl1, q[2] = tl2, q[3] = __builtin_readcyclecounter();
+    unsigned long long *q = pp_tl_buf + (size_t)lin * 6;
+    q[0] = tl0, q[1] = tl1, q[2] = tl2, q[3] = __builtin_readcyclecounter(), q[4] = tl3, q[5] = tl4;
   }
 #endif
 }
