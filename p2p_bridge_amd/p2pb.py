@@ -401,15 +401,19 @@ class P2PB(nn.Module):
         the level-0 farthest-point sampling -- a 12500-round dependent chain on ONE workgroup per cloud -- while the dense
         layers behind it wait: samples are independent, so the batch is cut into chains that each replay
         their own captured step on their own stream, started a fraction of a step apart, and one chain's FPS runs under
-        the other chains' dense layers. Same arithmetic per sample, same results. MEASURED (profiles/r03b_pvdl_chains.txt):
-        no gain THERE -- 2 chains 42.2 -> 44.1 / 49.9 -> 49.6 / 63.9 -> 62.9 ms per evaluation at B = 4 / 8 / 16, 4 chains
-        1.5-1.9 x SLOWER: what follows the FPS is a chain of ~300 dependent launches whose length does not shrink with the
-        sub-batch, and four graphs' branches queue behind each other's 26 ms FPS kernels in the hardware queues."""
+        the other chains' dense layers. Same arithmetic per sample, same results. MEASURED: at B = 4 / 8 / 16 no gain
+        (profiles/r03b_pvdl_chains.txt: what follows the FPS is a chain of ~300 dependent launches whose length does not
+        shrink with the sub-batch; 4 chains 1.5-1.9 x slower). The FPS latency is hidden by BATCH: this part holds 128 clouds
+        of 50000 points in 35 GiB of its 288 GB (profiles/r03d_pvdl_large_batches.txt: 420 k points/s at B = 16, 580 k at
+        32, 701 k at 64, 746 k at 96), and from B = 32 on two chains add what one batch leaves (632 k at 32, 741 k at 64,
+        the 745 k plateau from 96 up)."""
         v = self.sample_chains if self.sample_chains is not None else os.environ.get("P2PB_SAMPLE_CHAINS")
         B, N = xt.shape[0], xt.shape[2]
         # automatic: two chains for large batches of small clouds (config 2: +1.4 %, A/B 954-959 -> 968-973 k points/s: the
-        # ~50 small launches of one chain's evaluation run under the other chain's GEMMs), one otherwise
-        k = int(v) if v not in (None, "", "auto") else (2 if (B >= 16 and B % 2 == 0 and N <= 16384) else 1)
+        # ~50 small launches of one chain's evaluation run under the other chain's GEMMs) and for >= 32 large clouds
+        # (configs 4-5: +9 % at 32, +6 % at 64), one otherwise
+        auto = 2 if (B % 2 == 0 and ((B >= 16 and N <= 16384) or (B >= 32 and N > 16384))) else 1
+        k = int(v) if v not in (None, "", "auto") else auto
         return max(1, min(k, B))
 
     def _ddpm_chains(self, net, xt, x_cond, clip, rev, table, log_steps, chains):

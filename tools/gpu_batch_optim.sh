@@ -1,13 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_pw_tile_forms_gpu.py tests/test_fused_gpu.py tests/test_net_parity_gpu.py tests/test_full_size_parity_gpu.py -x -q -m gpu 2>&1 | tail -1
-for i in 1 2 3; do for l in pw_base main; do
-if [ $l = main ]; then unset P2PB_LIB_PATH; else export P2PB_LIB_PATH=$PWD/tools/exp/lib_$l.so; fi
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step > gpurun_out/ab_$l.log 2>&1
-python - <<P
-import json
-for l in open('gpurun_out/ab_$l.log'):
-    if l.startswith('{'):
-        d=json.loads(l); print('$l', d['value'], d['ms_per_step'], d['roofline']['ms_per_launch'], d['roofline']['frac'])
-P
-done; done
+for cfg in "2 32" "2 96" "2 128" "4 128" "3 96"; do set -- $cfg; P2PB_SAMPLE_CHAINS=$1 EXTRA=3 B=$2 T=30 timeout 900 python tools/exp_pvdl.py 2>&1 | grep "PVDL\|Error" | tail -1 | sed "s/^/[$1 chains] /" | cut -c1-200; done
