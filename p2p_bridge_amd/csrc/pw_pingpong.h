@@ -310,18 +310,31 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     load_b(s + 2, set);
   };
   if (grp == 1) head(1, 1);
+#ifdef PP_TIMELINE  // inside one steady-state interval (the even stage 6), both halves: wave 0 and wave 4
+  unsigned long long ts[5] = {0, 0, 0, 0, 0};
+#define PP_TLS(k) do { if (s == 6) ts[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PP_TLS(k)
+#endif
   for (int s = 0; s < nstage; s += 2) {
     // even stage s: its successor s + 1 lives in register set 1
+    PP_TLS(0);
     if (grp == 0) dma_a(s + 2, (s + 2) % 3);
     multiply(s % 3, 0);
+    PP_TLS(1);
     if (grp == 0) {
       PP_VMCNT(16);
+      PP_TLS(2);
       stage_b(s + 1, 1, 1);
       load_b(s + 3, 1);
+      PP_TLS(3);
       PP_BARRIER(20);
+      PP_TLS(4);
     } else {
       PP_BARRIER(20);
+      PP_TLS(2);
       head(s + 2, 0);
+      PP_TLS(3);
     }
     // odd stage s + 1: its successor s + 2 lives in register set 0
     if (grp == 0) dma_a(s + 3, (s + 3) % 3);
@@ -447,8 +460,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
 #ifdef PP_TIMELINE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0 && pp_tl_buf) {
-    unsigned long long *q = pp_tl_buf + (size_t)lin * 6;
+    unsigned long long *q = pp_tl_buf + (size_t)lin * 16;
     q[0] = tl0, q[1] = tl1, q[2] = tl2, q[3] = __builtin_readcyclecounter(), q[4] = tl3, q[5] = tl4;
+    for (int k = 0; k < 5; ++k) q[6 + k] = ts[k];
+  }
+  if (tid == 256 && pp_tl_buf) {
+    unsigned long long *q = pp_tl_buf + (size_t)lin * 16;
+    for (int k = 0; k < 5; ++k) q[11 + k] = ts[k];
   }
 #endif
 }

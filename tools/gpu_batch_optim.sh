@@ -1,2 +1,2 @@
 #!/bin/bash
-timeout 900 python -m pytest tests/test_sampler_features_gpu.py tests/test_conditional_gpu.py -x -q -m gpu 2>&1 | tail -2
+P2PB_LIB_PATH=$PWD/tools/exp/lib_pwtl.so python tools/exp_pp_timeline.py 2>&1 | grep -v Warn | tail -12
