@@ -1525,3 +1525,42 @@ extern "C" int p2pb_affine_act_max(int b, int c, int m, int u, const float *x, c
   hipLaunchKernelGGL(affine_act_max_kernel, dim3(gx, b * c), dim3(256), 0, s, m, u, x, scale, shift, swish, y);
   return p2pb_launch_status();
 }
+
+// ---- pre-split operand form of the ping-pong GEMM (pw_pingpong.h PRE): the operand transform + split as ONE elementwise
+// pass per layer, the GEMM with both operands by LDS-DMA. Same bits as the staged form.
+extern "C" int p2pb_pointwise_presplit_supported(int cin, int cout, int npos) {
+  return cin > 0 && cin % 64 == 0 && cout > 0 && cout % 256 == 0 && npos > 0 && npos % 256 == 0 && p2pb_g_split_terms == SPLIT_F16X3;
+}
+extern "C" int p2pb_pointwise_presplit(int b, int cin, int npos, const float *x, const float *in_scale, const float *in_shift,
+                                       int in_swish, void *out_split, void *stream) {
+  if (b <= 0 || cin <= 0 || cin % PP_CK != 0 || npos <= 0 || npos % 256 != 0 || !x || !out_split || (in_scale && !in_shift))
+    return P2PB_EINVAL;
+  hipLaunchKernelGGL(pw_presplit_kernel, dim3(npos / 256, cin / PP_CK, b), dim3(256), 0, (hipStream_t)stream, cin, npos, x, in_scale,
+                     in_shift, in_swish, (u32x4 *)out_split);
+  return p2pb_launch_status();
+}
+// x_split from p2pb_pointwise_presplit (b * cin * npos * 4 bytes); wp_split / bias / bias_b / out / stats_part / minmax as
+// p2pb_pointwise_conv_pool_forward (pool_u: 0 = global pooling partials in minmax, or < 0: no pooling output)
+extern "C" int p2pb_pointwise_conv_forward_presplit(int b, int cin, int cout, int npos, const void *x_split, const void *wp_split,
+                                                    const float *bias, const float *bias_b, float *out, float *stats_part,
+                                                    float *minmax, void *stream) {
+  if (b <= 0 || !p2pb_pointwise_presplit_supported(cin, cout, npos) || !x_split || !wp_split) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 pgrid(npos / 256, cout / 256, b);
+#define LAUNCHPRE(PL)                                                                                                  \
+  do {                                                                                                                 \
+    static bool once = false;                                                                                          \
+    if (!once) {                                                                                                       \
+      (void)hipFuncSetAttribute((const void *)pw_pingpong_kernel<false, PL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                PP_LDS_BYTES);                                                                         \
+      once = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((pw_pingpong_kernel<false, PL, true>), pgrid, dim3(512), PP_LDS_BYTES, s, cin, cout, npos, npos / 64, \
+                       (const float *)x_split, (const u32x4 *)wp_split, bias, bias_b, (const float *)nullptr,           \
+                       (const float *)nullptr, 0, out, stats_part, minmax, 0);                                          \
+  } while (0)
+  if (minmax) LAUNCHPRE(true);
+  else LAUNCHPRE(false);
+#undef LAUNCHPRE
+  return p2pb_launch_status();
+}

@@ -40,7 +40,7 @@ extern "C" int p2pb_pp_timeline_set(void *p) {  // hand-counted vmcnt waits of t
 #define PP_TILE 2048  // 16-byte groups per operand tile per stage (32 KB)
 #define PP_LDS_BYTES (5 * PP_TILE * 16)  // A x 3, B x 2: all 160 KB of the CU
 
-template <bool XF, bool POOL>
+template <bool XF, bool POOL, bool PRE = false>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void pw_pingpong_kernel(int cin, int cout, int P, int nslots,
                                                              const float *__restrict__ in, const u32x4 *__restrict__ wp,
                                                              const float *__restrict__ bias,
@@ -284,6 +284,37 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   };
 
   PP_TL(tl0);
+  if constexpr (PRE) {
+    // ---- pre-split operand (p2pb_pointwise_presplit: folded norm + Swish + fp16-pair split applied ONCE per element, in the
+    // byte layout of the B tile): both operand tiles arrive by LDS-DMA, nothing is staged through registers, every wave
+    // runs  [DMA B(s+1), DMA A(s+2); multiply(s); barrier]  -- the timeline of the staged form says why: a wave's
+    // staging (2.0-2.9 k cycles: sixteen exp / rcp chains, splits, LDS writes, and once per 256-channel block) takes as long
+    // as its multiply (2.0-2.2 k), so a stage lasts 5.2 k cycles where the matrix pipe needs 3.1 k.
+    // `in` = S[b][P / 256][cin / 32][2048] x 16 B. VMEM queue at a barrier, oldest first: A(s+1) B(s+1) A(s+2) -> vmcnt(4).
+    const u32x4 *bsrc = (const u32x4 *)in + ((size_t)b * gridDim.x + bx) * (size_t)nstage * PP_TILE;
+    auto dma_b = [&](int s, int buf) {
+      const int st = s < nstage ? s : nstage - 1;
+      const u32x4 *src = bsrc + (size_t)st * PP_TILE;
+      u32x4 *dst = pp_lds + (3 + buf) * PP_TILE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = i * 512 + wave * 64;  // wave-uniform; lane l lands at e + l
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + e + lane),
+                                         (__attribute__((address_space(3))) void *)(dst + e), 16, 0, 0);
+      }
+    };
+    dma_b(0, 0);
+    dma_a(0, 0);
+    dma_a(1, 1);
+    PP_BARRIER(4);
+    for (int s = 0; s < nstage; ++s) {
+      dma_b(s + 1, (s + 1) & 1);
+      dma_a(s + 2, (s + 2) % 3);
+      multiply(s % 3, s & 1);
+      PP_BARRIER(4);
+    }
+  }
+  if constexpr (!PRE) {
   if (grp == 1) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every arbitration otherwise (+4..8 %)
   // ---- prologue. VMEM queue, oldest first: loads(0) loads(1) DMA(0) DMA(1) | loads(2)
   load_b(0, 0);
@@ -294,6 +325,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   stage_b(0, 0, 0);
   load_b(2, 0);
   PP_BARRIER(12);  // DMA(0) has landed
+  }
   PP_TL(tl1);
   // Interval s (between barriers s and s + 1): half 0 runs [DMA A(s+2); multiply(s); stage B(s+1); loads(s+3)], half 1
   // [DMA A(s+2); stage B(s+1); loads(s+3); multiply(s)] -- written as ONE loop body with the multiply in common code
@@ -309,13 +341,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     stage_b(s, s & 1, set);
     load_b(s + 2, set);
   };
-  if (grp == 1) head(1, 1);
 #ifdef PP_TIMELINE  // inside one steady-state interval (the even stage 6), both halves: wave 0 and wave 4
   unsigned long long ts[5] = {0, 0, 0, 0, 0};
 #define PP_TLS(k) do { if (s == 6) ts[k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PP_TLS(k)
 #endif
+  if constexpr (!PRE) {
+  if (grp == 1) head(1, 1);
   for (int s = 0; s < nstage; s += 2) {
     // even stage s: its successor s + 1 lives in register set 1
     PP_TLS(0);
@@ -349,6 +382,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
       if (s + 2 < nstage) head(s + 3, 1);
     }
   }
+  }  // !PRE
   PP_VMCNT(0);  // nothing of this workgroup may still be on its way into LDS when the waves retire
   PP_TL(tl2);
 
@@ -469,4 +503,56 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     for (int k = 0; k < 5; ++k) q[11 + k] = ts[k];
   }
 #endif
+}
+
+// ---- the operand of the PRE form: x f32[b, cin, P] -> S[b][P / 256][cin / 32][2048] x 16 B, the bytes stage_b() would put
+// into the B tile of (position block, stage): folded norm + Swish (or the plain fp16 scale) and the fp16-pair split, the SAME
+// instruction sequence per element (bit-identical tiles), done once instead of once per 256-channel block of the layer.
+// One workgroup per (position block, stage, sample): thread t owns position t, walks the four 8-channel groups.
+__global__ __launch_bounds__(256) void pw_presplit_kernel(int cin, int P, const float *__restrict__ in,
+                                                          const float *__restrict__ in_scale, const float *__restrict__ in_shift,
+                                                          int in_swish, u32x4 *__restrict__ out) {
+  const int t = threadIdx.x, pb = blockIdx.x, st = blockIdx.y, b = blockIdx.z;
+  const int nstage = cin / PP_CK;
+  const float *x = in + ((size_t)b * cin + (size_t)st * PP_CK) * P + (size_t)pb * 256 + t;
+  u32x4 *o = out + (((size_t)b * gridDim.x + pb) * nstage + st) * PP_TILE;
+#pragma unroll
+  for (int cg = 0; cg < 4; ++cg) {
+    float y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) y[i] = x[(size_t)(8 * cg + i) * P];
+    if (in_scale) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = st * PP_CK + 8 * cg + i;
+        y[i] = __fmaf_rn(y[i], in_scale[b * cin + c], in_shift[b * cin + c]);
+      }
+      if (in_swish) {
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(y[i] * -1.44269504088896340736f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_rcpf(__fmaf_rn(e[i], 0.25f, 0.25f));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] *= e[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] *= SPLIT_F16_SX;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] *= SPLIT_F16_SX;
+    }
+    u32x4 q0, q1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned p0, p1;
+      split2h(y[2 * i], y[2 * i + 1], p0, p1);
+      q0[i] = p0;
+      q1[i] = p1;
+    }
+    const int kstep = cg >> 1, kh = cg & 1;
+    o[((kstep * 2 + 0) * 2 + kh) * 256 + t] = q0;
+    o[((kstep * 2 + 1) * 2 + kh) * 256 + t] = q1;
+  }
 }

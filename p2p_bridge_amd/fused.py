@@ -597,6 +597,15 @@ def pool_supported(npos: int, pool_u: int) -> bool:
 
 
 PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/exp_pw.py)
+PW_PRE_MIN_COUT = 1024  # pre-split operand for the wide GEMM from four 256-channel blocks up (pw_conv)
+
+
+def pw_pre_enabled() -> bool:
+    """P2PB_PW_PRE=1: the widest 1x1 layers take a pre-split operand (one elementwise pass + the ping-pong GEMM with both
+    operands by LDS-DMA). OFF by default: the GEMM alone runs at 0.46 of the three-product ceiling instead of 0.33 and the
+    pair is 6 % faster than the staged kernel in isolation, but inside the sampler the extra 1.07 GB pass costs what it
+    saves (bench -0.3 .. -0.5 %, profiles/r03d_pw_presplit_ab.txt)"""
+    return os.environ.get("P2PB_PW_PRE", "0") == "1"
 
 
 def use_wide_f16(ci: int, co: int) -> bool:
@@ -652,6 +661,21 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     bias = conv.bias if use_bias else None
+    if (split and acc is None and not point_major and pool_u in (None, 0) and in_scale is not None and not isinstance(in_scale, Fold)
+            and math is None and co >= PW_PRE_MIN_COUT and pw_pre_enabled() and lib().p2pb_pointwise_presplit_supported(_i(ci), _i(co), _i(p))):
+        # pre-split operand (csrc/pw_pingpong.h PRE): folded norm + Swish + fp16-pair split ONCE per element in one elementwise
+        # pass, the GEMM with both operands by LDS-DMA -- bit-identical to the staged kernel, which redoes the transform in
+        # every 256-channel block (4 x for the 512 -> 1024 layer) on the same VALU its matrix instructions issue from
+        xs = torch.empty(b * ci * p, dtype=F32, device=x.device)
+        call("p2pb_pointwise_presplit", _i(b), _i(ci), _i(p), ptr(x), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(xs),
+             stream_ptr())
+        mm = None
+        if pool_u is not None:
+            nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(0), flags)
+            mm = torch.empty(b, nmm // (b * co * 2), co, 2, dtype=F32, device=x.device)
+        call("p2pb_pointwise_conv_forward_presplit", _i(b), _i(ci), _i(co), _i(p), ptr(xs), ptr(wp), ptr(bias), ptr(bias_b), ptr(y),
+             ptr(st), ptr(mm), stream_ptr())
+        return (y, st) if pool_u is None else (y, st, mm)
     fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
     aref = None if acc is None else acc.ref
     if pool_u is None:
