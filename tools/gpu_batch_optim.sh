@@ -1,20 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out
-for i in 1 2 3 4; do for pz in 0 1; do
-P2PB_PW_PRE=$pz timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step > gpurun_out/ab_$pz.log 2>&1
-python - <<P
-import json
-for l in open('gpurun_out/ab_$pz.log'):
-    if l.startswith('{'):
-        d=json.loads(l); print('pre=$pz', d['value'], d['ms_per_step'], d['roofline']['ms_per_launch'])
-P
-done; done
-for i in 1 2; do for pz in 0 1; do
-P2PB_SAMPLE_CHAINS=1 P2PB_PW_PRE=$pz timeout 600 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step > gpurun_out/ab_$pz.log 2>&1
-python - <<P
-import json
-for l in open('gpurun_out/ab_$pz.log'):
-    if l.startswith('{'):
-        d=json.loads(l); print('[1 chain] pre=$pz', d['value'], d['ms_per_step'], d['roofline']['ms_per_launch'])
-P
-done; done
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/r03e; mkdir -p $out; cd /tmp; export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_bench -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step > $out/prof_bench.log 2>&1
+db=$(find $out/prof_bench -name "*.db" | head -1)
+python $R/tools/rocpd_roofline.py $db $out/r03e_roofline_kernel.csv "pw_pingpong_kernel<true, true, false>"
+rm -rf $out/prof_bench
+cat $out/r03e_roofline_kernel.csv

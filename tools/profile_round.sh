@@ -15,7 +15,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_bench -o bench
 db=$(find $out/prof_bench -name "*.db" | head -1)
 python $R/tools/rocpd_window.py $db $out/${tag}_per_eval.csv > /dev/null
 python $R/tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv > /dev/null
-python $R/tools/rocpd_roofline.py $db $out/${tag}_roofline_kernel.csv "pw_pingpong_kernel<true, true>" > /dev/null
+python $R/tools/rocpd_roofline.py $db $out/${tag}_roofline_kernel.csv "pw_pingpong_kernel<true, true, false>" > /dev/null
 python $R/tools/rocpd_roofline.py $db $out/${tag}_roofline_second_kernel.csv "conv3d_k3_compact_kernel<16" > /dev/null
 # 2) PMC passes of the dominant GEMM (separate passes)
 i=0
