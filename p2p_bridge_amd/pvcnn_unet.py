@@ -17,6 +17,8 @@ from dataclasses import dataclass
 from typing import Any, List, Optional
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
