@@ -19,34 +19,43 @@
 typedef unsigned long long u64;
 
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ u64 dpp_max_step(u64 v) {
-  const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-  const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, ROW_MASK, 0xf, false);
-  const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, ROW_MASK, 0xf, false);
-  const u64 o = ((u64)ohi << 32) | olo;
+__device__ __forceinline__ unsigned dpp_umax_step(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);  // (0 = identity of max)
   return o > v ? o : v;
 }
-
-// max over the 64 lanes; result valid in lane 63, returned broadcast to all lanes
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = dpp_umax_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_umax_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_umax_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_umax_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row max
+  v = dpp_umax_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_umax_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave max
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// max of 64-bit keys over the 64 lanes, broadcast to all lanes: the lexicographic maximum as two 32-bit reductions (the high
+// words, then the low words of the lanes that hold the winning high word) -- v_max_u32 steps instead of 64-bit compare +
+// two selects per step (the round of the small-cloud FPS is bound by its VALU instruction count)
 __device__ __forceinline__ u64 wave_max_u64(u64 v) {
-  v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
-  v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
-  v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
-  v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row max
-  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
-  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave max
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
-  return ((u64)hi << 32) | lo;
+  const unsigned hi = (unsigned)(v >> 32);
+  const unsigned H = wave_max_u32(hi);
+  const unsigned L = wave_max_u32(hi == H ? (unsigned)v : 0u);
+  return ((u64)H << 32) | L;
 }
 
-// max over each 16-lane row; valid in lane 15 of the row
+// max over the first 16-lane row of the wave, returned in every lane (the callers' rows all hold the same 16 values): the same
+// two 32-bit reductions
+__device__ __forceinline__ unsigned row_max_u32(unsigned v) {
+  v = dpp_umax_step<0x111, 0xf>(v);
+  v = dpp_umax_step<0x112, 0xf>(v);
+  v = dpp_umax_step<0x114, 0xf>(v);
+  v = dpp_umax_step<0x118, 0xf>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
 __device__ __forceinline__ u64 row_max_u64(u64 v) {
-  v = dpp_max_step<0x111, 0xf>(v);
-  v = dpp_max_step<0x112, 0xf>(v);
-  v = dpp_max_step<0x114, 0xf>(v);
-  v = dpp_max_step<0x118, 0xf>(v);
-  return v;
+  const unsigned hi = (unsigned)(v >> 32);
+  const unsigned H = row_max_u32(hi);
+  const unsigned L = row_max_u32(hi == H ? (unsigned)v : 0u);
+  return ((u64)H << 32) | L;
 }
 
 __device__ __forceinline__ u64 fps_key(float best, int k) {
@@ -120,7 +129,8 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, const float 
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const float d = sqdist3(x[i] - x1, y[i] - y1, z[i] - z1);
-      const float d2 = fminf(d, dist[i]);
+      float d2;  // fminf(d, dist[i]) as the bare instruction (fminf canonicalises an operand with a v_max_f32 x, x first: 17 of the
+      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(dist[i]));  // round's 258 VALU instructions; same value, NaN included)
       dist[i] = d2;
       if (d2 > best) {
         best = d2;
