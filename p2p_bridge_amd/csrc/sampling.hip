@@ -250,7 +250,8 @@ __global__ __launch_bounds__(1024) void fps_coop_kernel(int n, int m, const floa
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       const float d = sqdist3(x[i] - x1, y[i] - y1, z[i] - z1);
-      const float d2 = fminf(d, dist[i]);
+      float d2;  // (bare v_min_f32: see fps_kernel)
+      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(dist[i]));
       dist[i] = d2;
       if (d2 > best) {
         best = d2;
@@ -602,7 +603,8 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
             const int k = i0 + 64 * q + lane;
             if (k < pn) {
               const float d = sqdist3(r[q].x - sx, r[q].y - sy, r[q].z - sz);
-              const float d2 = fminf(d, dold[q]);
+              float d2;  // (bare v_min_f32: see fps_kernel)
+              asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(dold[q]));
               if (d2 != dold[q]) md[p0 + k] = d2;
               const u64 key = fps_key(d2, __float_as_int(r[q].w));
               if (key > best) {
