@@ -155,6 +155,16 @@ struct RowAdd {
 // (the min / max steps as the bare instructions: behind a DPP / permlane move the compiler no longer knows its operand is a
 //  canonical float and puts a canonicalising v_max_f32 x, x in front of every fminf / fmaxf -- 266 of them in the pooling
 //  epilogue of the ping-pong GEMM; v_min_f32 / v_max_f32 return the same value, a quiet NaN only if both operands are NaN)
+__device__ __forceinline__ float vmin_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 struct RowMin {
   __device__ static float f(float a, float b) {
     float r;

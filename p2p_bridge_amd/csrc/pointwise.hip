@@ -196,11 +196,11 @@ __device__ __forceinline__ float dpp_perm(float v) {
 // min and max over aligned groups of g lanes. g = 2..16: every lane of the group ends with the result
 // (xor-1, xor-2 inside quads, then the half-row and row mirrors); g = 32: lanes 31 / 63 hold their half-wave's.
 __device__ __forceinline__ void group_minmax(float &mn, float &mx, int g) {
-  if (g > 1) { mn = fminf(mn, dpp_perm<0xB1, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0xB1, 0xf>(mx)); }    // quad_perm [1,0,3,2]
-  if (g > 2) { mn = fminf(mn, dpp_perm<0x4E, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x4E, 0xf>(mx)); }    // quad_perm [2,3,0,1]
-  if (g > 4) { mn = fminf(mn, dpp_perm<0x141, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x141, 0xf>(mx)); }  // row_half_mirror
-  if (g > 8) { mn = fminf(mn, dpp_perm<0x140, 0xf>(mn)); mx = fmaxf(mx, dpp_perm<0x140, 0xf>(mx)); }  // row_mirror
-  if (g > 16) { mn = fminf(mn, dpp_perm<0x142, 0xa>(mn)); mx = fmaxf(mx, dpp_perm<0x142, 0xa>(mx)); } // row_bcast:15
+  if (g > 1) { mn = vmin_raw(mn, dpp_perm<0xB1, 0xf>(mn)); mx = vmax_raw(mx, dpp_perm<0xB1, 0xf>(mx)); }    // quad_perm [1,0,3,2]
+  if (g > 2) { mn = vmin_raw(mn, dpp_perm<0x4E, 0xf>(mn)); mx = vmax_raw(mx, dpp_perm<0x4E, 0xf>(mx)); }    // quad_perm [2,3,0,1]
+  if (g > 4) { mn = vmin_raw(mn, dpp_perm<0x141, 0xf>(mn)); mx = vmax_raw(mx, dpp_perm<0x141, 0xf>(mx)); }  // row_half_mirror
+  if (g > 8) { mn = vmin_raw(mn, dpp_perm<0x140, 0xf>(mn)); mx = vmax_raw(mx, dpp_perm<0x140, 0xf>(mx)); }  // row_mirror
+  if (g > 16) { mn = vmin_raw(mn, dpp_perm<0x142, 0xa>(mn)); mx = vmax_raw(mx, dpp_perm<0x142, 0xa>(mx)); } // row_bcast:15
 }
 
 // POOL: additionally emit {min, max} of the raw output over groups of pool_g lanes (= 4*pool_g consecutive
