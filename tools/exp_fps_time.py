@@ -12,6 +12,9 @@ def timeit(f, n=10):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+from p2p_bridge_amd.synthetic import synthetic_patches
 for (B, n, m) in [(16, 8192, 2048), (32, 8192, 2048), (16, 2048, 512), (16, 512, 128)]:
     c = torch.rand(B, 3, n, device="cuda")
-    print(f"B={B} n={n} m={m}: {timeit(lambda: L._ext.furthest_point_sampling_forward(c, m)):.1f} us")
+    print(f"B={B} n={n} m={m}: uniform cube {timeit(lambda: L._ext.furthest_point_sampling_forward(c, m)):.1f} us", end="")
+    p = synthetic_patches(B, n, seed=3)[0].cuda().contiguous()  # the bench's noisy surface patches
+    print(f" | bench patches {timeit(lambda: L._ext.furthest_point_sampling_forward(p, m)):.1f} us")

@@ -1,6 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out
-bash tools/profile_round.sh r03f > gpurun_out/profile_round.log 2>&1
-tail -n 7 gpurun_out/profile_round.log | cut -c1-300
-PVDL_BATCHES="4 8 16" bash tools/profile_pvdl.sh r03f > gpurun_out/profile_pvdl.log 2>&1
-tail -n 12 gpurun_out/profile_pvdl.log | cut -c1-200
+python tools/exp_fps_time.py 2>&1 | grep "B=" | head -2
+P2PB_FPS_CELL=0 python tools/exp_fps_time.py 2>&1 | grep "B=" | head -2
