@@ -523,21 +523,6 @@ int p2pb_merge_accumulate(int npatch, int k, const float *pred, const int *idx, 
                           int *counts, void *stream);
 int p2pb_merge_finish(int n, const double *sums, const int *counts, const float *original, float *out, void *stream);
 
-/* ---- pre-split operand of the wide 1x1 GEMM (round 3; csrc/pw_pingpong.h PRE) ----
- * The wide layers (cout a multiple of 256, cin of 64, npos of 256; f16x3 arithmetic: p2pb_pointwise_presplit_supported) can
- * take their operand already transformed (folded norm + Swish: in_scale / in_shift f32[b,cin] or NULL, in_swish) and split
- * into its fp16 pair, in the byte layout of the kernel's LDS tile: S[b][npos / 256][cin / 32][2048] x 16 B =
- * b * cin * npos * 4 bytes. p2pb_pointwise_presplit makes it in one elementwise pass; p2pb_pointwise_conv_forward_presplit is
- * p2pb_pointwise_conv_forward / _pool_forward (global pooling: minmax != NULL) on it: out f32[b,cout,npos] or NULL,
- * stats_part / minmax as there. Bit-identical to the staged form (the transform is applied once per element instead of
- * once per 256-channel block). -> 0 or P2PB_EINVAL */
-int p2pb_pointwise_presplit_supported(int cin, int cout, int npos);
-int p2pb_pointwise_presplit(int b, int cin, int npos, const float *x, const float *in_scale, const float *in_shift,
-                            int in_swish, void *out_split, void *stream);
-int p2pb_pointwise_conv_forward_presplit(int b, int cin, int cout, int npos, const void *x_split, const void *wp_split,
-                                         const float *bias, const float *bias_b, float *out, float *stats_part, float *minmax,
-                                         void *stream);
-
 /* ---- packs of the ADJOINT (data-gradient) operator, read straight from the forward layer's weight ----
  * dX of a layer is the same convolution kernel on dY with the transposed weight (and the taps point-reflected for the
  * 3x3x3 convolution). These pack variants take the FORWARD weight -- w_forward f32[cin][cout][27] resp. f32[cin][cout],

@@ -1526,6 +1526,7 @@ extern "C" int p2pb_affine_act_max(int b, int c, int m, int u, const float *x, c
   return p2pb_launch_status();
 }
 
+#ifdef P2PB_EXP_PW_PRE
 // ---- pre-split operand form of the ping-pong GEMM (pw_pingpong.h PRE): the operand transform + split as ONE elementwise
 // pass per layer, the GEMM with both operands by LDS-DMA. Same bits as the staged form.
 extern "C" int p2pb_pointwise_presplit_supported(int cin, int cout, int npos) {
@@ -1564,3 +1565,4 @@ extern "C" int p2pb_pointwise_conv_forward_presplit(int b, int cin, int cout, in
 #undef LAUNCHPRE
   return p2pb_launch_status();
 }
+#endif  // P2PB_EXP_PW_PRE

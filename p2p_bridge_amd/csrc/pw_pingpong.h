@@ -505,6 +505,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
 #endif
 }
 
+#ifdef P2PB_EXP_PW_PRE  // experiment builds only (tools/build_pw_variant.sh pre "-DP2PB_EXP_PW_PRE"; tools/exp_pw_pre.py): measured
+                       // slower end to end (profiles/r03d_pw_presplit_ab.txt), so not part of the shipped library
 // ---- the operand of the PRE form: x f32[b, cin, P] -> S[b][P / 256][cin / 32][2048] x 16 B, the bytes stage_b() would put
 // into the B tile of (position block, stage): folded norm + Swish (or the plain fp16 scale) and the fp16-pair split, the SAME
 // instruction sequence per element (bit-identical tiles), done once instead of once per 256-channel block of the layer.
@@ -556,3 +558,4 @@ __global__ __launch_bounds__(256) void pw_presplit_kernel(int cin, int P, const 
     o[((kstep * 2 + 1) * 2 + kh) * 256 + t] = q1;
   }
 }
+#endif  // P2PB_EXP_PW_PRE

@@ -601,11 +601,12 @@ PW_PRE_MIN_COUT = 1024  # pre-split operand for the wide GEMM from four 256-chan
 
 
 def pw_pre_enabled() -> bool:
-    """P2PB_PW_PRE=1: the widest 1x1 layers take a pre-split operand (one elementwise pass + the ping-pong GEMM with both
-    operands by LDS-DMA). OFF by default: the GEMM alone runs at 0.46 of the three-product ceiling instead of 0.33 and the
-    pair is 6 % faster than the staged kernel in isolation, but inside the sampler the extra 1.07 GB pass costs what it
-    saves (bench -0.3 .. -0.5 %, profiles/r03d_pw_presplit_ab.txt)"""
-    return os.environ.get("P2PB_PW_PRE", "0") == "1"
+    """EXPERIMENT builds only (tools/build_pw_variant.sh pre "-DP2PB_EXP_PW_PRE" + P2PB_LIB_PATH + P2PB_PW_PRE=1): the widest 1x1
+    layers take a pre-split operand (one elementwise pass + the ping-pong GEMM with both operands by LDS-DMA). Not in the
+    shipped library: the GEMM alone runs at 0.46 of the three-product ceiling instead of 0.33 and the pair is 6 % faster than
+    the staged kernel in isolation, but inside the sampler the extra 1.07 GB pass costs what it saves (bench -0.3 .. -0.5 %,
+    profiles/r03d_pw_presplit_ab.txt)"""
+    return os.environ.get("P2PB_PW_PRE", "0") == "1" and hasattr(lib(), "p2pb_pointwise_presplit_supported")
 
 
 def use_wide_f16(ci: int, co: int) -> bool:

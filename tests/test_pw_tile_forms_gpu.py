@@ -116,47 +116,3 @@ def test_pingpong_kernel_shapes():
     env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP="1")
     r = subprocess.run([sys.executable, "-c", PP_CODE], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PINGPONG-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-
-
-PRE_CODE = r"""
-import os, sys, torch
-sys.path.insert(0, %r)
-from p2p_bridge_amd import _lib, fused
-torch.manual_seed(0)
-lib = _lib.lib()
-assert lib.p2pb_pointwise_presplit_supported(512, 1024, 8192) == 1
-assert lib.p2pb_pointwise_presplit_supported(512, 1000, 8192) == 0 and lib.p2pb_pointwise_presplit_supported(96, 1024, 512) == 0
-assert lib.p2pb_pointwise_conv_forward_presplit(1, 96, 1024, 512, None, None, None, None, None, None, None, None) != 0
-for (B, ci, co, P, sw) in [(2, 512, 1024, 512, True), (1, 192, 1280, 768, False), (3, 64, 1024, 256, True)]:
-    x = torch.randn(B, ci, P, device="cuda") * 3
-    conv = torch.nn.Conv1d(ci, co, 1).cuda()
-    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
-    bias_b = torch.randn(B, co, device="cuda")
-    got = {}
-    for pre in ("0", "1"):
-        os.environ["P2PB_PW_PRE"] = pre
-        with torch.no_grad():
-            y, st = fused.pw_conv(x, conv, sc, sh, swish=sw, bias_b=bias_b)
-            y2, st2, mm = fused.pw_conv(x, conv, sc, sh, swish=sw, pool_u=0, store=False)
-        assert y2 is None
-        got[pre] = (y, st, st2, mm)
-    for k, (a, b_) in enumerate(zip(got["0"], got["1"])):
-        assert torch.equal(a, b_), (B, ci, co, P, k, (a - b_).abs().max().item())
-    with torch.no_grad():
-        act = x.double() * sc[:, :, None].double() + sh[:, :, None].double()
-        act = act * torch.sigmoid(act) if sw else act
-        ref = torch.nn.functional.conv1d(act, conv.weight.double(), conv.bias.double()) + bias_b[:, :, None].double()
-    assert (got["1"][0].double() - ref).abs().max().item() < 1e-5 * ref.abs().max().item()
-print("PRE-OK")
-""" % ROOT
-
-
-def test_presplit_operand_form_is_bit_identical():
-    """the widest layers take their operand pre-split (p2pb_pointwise_presplit + pw_pingpong_kernel<PRE>: transform + fp16-pair
-    split once per element, both operands by LDS-DMA): the same bytes in the B tile, the same products in the same order --
-    outputs, statistics partials and pooling extrema EQUAL the staged ping-pong kernel's (forced on these small shapes by
-    P2PB_PW_WM=4, hence the subprocess), with and without the folded transform's Swish, a per-sample bias, stored /
-    pooled-only outputs; the C entry points refuse what they cannot take"""
-    env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP="1")
-    r = subprocess.run([sys.executable, "-c", PRE_CODE], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "PRE-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
