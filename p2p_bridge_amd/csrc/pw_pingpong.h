@@ -66,6 +66,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   const int pblk = bx * 256, co0 = by * 256;
   const int nstage = cin / PP_CK;
   const int nblk128 = cout / 128;
+  float bpre = 0.0f;  // bias (+ per-sample bias) of channel co0 + tid for the epilogue's table
+  if (tid < 256) {
+    bpre = bias ? bias[co0 + tid] : 0.0f;
+    if (bias_b) bpre += bias_b[(size_t)b * cout + co0 + tid];
+  }
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -407,11 +412,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     // are free: every wave's DMA has landed (vmcnt(0) above) once all of them are past this barrier.
     float *btab = (float *)pp_lds;
     __syncthreads();
-    if (tid < 256) {
-      float v = bias ? bias[co0 + tid] : 0.0f;
-      if (bias_b) v += bias_b[(size_t)b * cout + co0 + tid];
-      btab[tid] = v;
-    }
+    if (tid < 256) btab[tid] = bpre;  // (fetched at the top of the kernel: its latency is under the stage loop)
     const float oscale = ((const float *)(wp + (size_t)nstage * nblk128 * PWS_TILE))[1];  // 1 / (S_x S_w)
     __syncthreads();
 #pragma unroll
