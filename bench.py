@@ -140,36 +140,16 @@ def gemm_roofline(model, B, P, reps=10):
     ci, co = conv.in_channels, conv.out_channels
     x = torch.randn(B, ci, P, device="cuda")
     flops = 2.0 * B * P * ci * co
-    arena = fused.StatsArena()
-    arena.begin(x.device)
-    with torch.no_grad(), fused.use_arena(arena):
-        groups = 8
-        if fused.gn_acc_enabled("pws"):
-            # as in the sampler: the operand's GroupNorm is folded in the kernel's prologue from the accumulators the
-            # previous layer filled (here: x's own statistics, written in the accumulators' fixed-point format), and the
-            # kernel adds its output's statistics to accumulators of its own
-            acc_in = fused.Acc(B, ci, groups, False, x.device)
-            xd = x.double()
-            tot = torch.stack([xd.sum(2).view(B, groups, -1).sum(2), (xd * xd).sum(2).view(B, groups, -1).sum(2)], -1)
-            fl = torch.floor(tot)
-            acc_in.group.view(B, groups, 4, -1)[..., 0] = torch.stack([fl, torch.floor((tot - fl) * 2.0 ** 44)], -1).long().view(B, groups, 4)
-            from p2p_bridge_amd.pvcnn_unet import _group_norm_of
-
-            prev = _group_norm_of(model.model.global_pnet.mlp2.shared_mlp_0.mlp[1])
-            sc, sh = fused.Fold(acc_in, prev.weight, prev.bias, None, prev.eps, float(P)), None
-        else:
-            groups = None
-            sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
-        mark = arena.off
+    with torch.no_grad():
+        # as in the sampler: the previous layer's folded GroupNorm + Swish applied to the operand on load
+        sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
         for _ in range(3):
-            arena.off = mark
-            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False, acc_groups=groups)
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            arena.off = mark
-            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False, acc_groups=groups)
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
         e1.record()
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps

@@ -51,6 +51,11 @@ int p2pb_set_split_terms(int terms);
  * threads' launches and weight packs do not see; p2pb_get_split_terms returns what a launch from this thread would use */
 int p2pb_set_split_terms_thread(int terms);
 int p2pb_get_split_terms(void);
+/* Test / debug hook: the kernel form the most recent p2pb_pointwise_conv* launch with these (cin, cout) took
+ * (0 exact-fp32 unaligned, 1 wide exact-fp32, 2 wide f16x3, 3 split 128-channel, 4 split 256-channel, 5 ping-pong,
+ * 6 gathered wide f16x3), or -1 if none; *launches (may be NULL) = how many such launches since the last reset.
+ * cin < 0 resets the table. Host-side bookkeeping only (under hipGraph capture: recorded at capture time). */
+int p2pb_debug_pointwise_form(int cin, int cout, unsigned long long *launches);
 
 /* Voxelization.forward normalisation (models/pvcnn.py:215-228): centre on the mean, divide by
  * 2*max-norm (+eps), +0.5, *r, clamp [0,r-1]; also the half-to-even rounded int voxel coords.
@@ -277,8 +282,8 @@ int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, const float 
  * (h0 | h1 of 4 x value), 4 bytes per (voxel, channel) with the channels zero-padded to a multiple of 16. The f16x3
  * kernels then stage with LDS-DMA alone. Bit-identical outputs. Producers: p2pb_avg_voxelize_cl_gather_split (a first
  * convolution's operand straight from the voxeliser) and p2pb_conv3d_presplit (y f32[b,nvox,c] voxel-major -> S, applying
- * swish?(y*in_scale + in_shift) - in_sub; in_scale == NULL: the plain split). Consumers: p2pb_conv3d_k3_forward_fx /
- * _sparse_fx with flags bit 4 (16; needs bits 2 and 3, no in_scale / in_sub / in_fold / out_acc) and
+ * swish?(y*in_scale + in_shift) - in_sub; in_scale == NULL: the plain split). Consumers: p2pb_conv3d_k3_forward_ex /
+ * _sparse with flags bit 4 (16; needs bits 2 and 3, no in_scale / in_sub) and
  * p2pb_conv3d_k3_forward_compact_pre. f16x3 arithmetic only (P2PB_EINVAL under bf16x6). */
 int p2pb_conv3d_presplit(int b, int c, long nvox, const float *y, const float *in_scale, const float *in_shift,
                          int in_swish, const float *in_sub, void *out_split, void *stream);
@@ -315,77 +320,6 @@ int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, c
  * aff_a = scale*gate, aff_b = shift*gate. w1 f32[hidden,c], w2 f32[c,hidden] (nn.Linear layouts, no bias). */
 int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,
                         const float *scale, const float *shift, float *aff_a, float *aff_b, void *stream);
-
-/* ---- GroupNorm statistics without a finishing launch (the sampler's fused path; csrc/common.h) -------------------
- * Between a layer and the next the reference runs torch.nn.GroupNorm (+ AdaGN, models/modules.py:341-358). With
- * stats_part / p2pb_gn_affine_params that costs one small launch per layer (48 per network evaluation). The *_fx
- * entry points below remove it: a producer adds its output's {sum, sum of squares} to ONE accumulator per (sample,
- * group) with 64-bit integer atomics on a fixed-point pair (floor(v), frac(v) * 2^44) -- the result is independent of
- * the arrival order of the workgroups, so deterministic -- and a consumer folds scale / shift for its own input
- * channels in its prologue. The caller zeroes the accumulators before the producer runs (one fill of all of an evaluation's accumulators).
- *   p2pb_gn_acc  (producer): group i64[b,groups,4,16] = {sum, sumsq} pairs, every word on a 128-byte line of its own
- *                (same-line atomics serialise); channel i64[b,c,2] = per-channel sum, or NULL
- *   p2pb_gn_fold (consumer): the same accumulators + the norm's parameters: gamma / beta f32[c] or NULL, style rows
- *                (factor[c] | bias[c]) with pitch style_stride or NULL, eps, count = positions per channel
- * Every *_fx function is its namesake with `in_fold` next to in_scale / in_shift (give one or neither) and `out_acc`
- * next to stats_part (give one or neither); NULL for both new arguments is exactly the namesake. */
-typedef struct p2pb_gn_acc {
-  long long *group;
-  long long *channel;
-  int groups;
-} p2pb_gn_acc;
-typedef struct p2pb_gn_fold {
-  const long long *group;
-  const long long *channel;
-  const float *gamma;
-  const float *beta;
-  const float *style;
-  int style_stride;
-  int groups;
-  float eps;
-  double count;
-} p2pb_gn_fold;
-/* stand-alone finisher: scale, shift (, chmean: needs fold->channel) f32[b,c], for consumers that take arrays */
-int p2pb_gn_fold_params(int b, int c, const p2pb_gn_fold *fold, float *scale, float *shift, float *chmean,
-                        void *stream);
-int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
-                              const float *bias, const float *out_class, const p2pb_gn_fold *in_fold,
-                              const float *in_scale, const float *in_shift, int in_swish, const float *in_sub,
-                              int flags /* bit 2 required with in_fold / out_acc */, float *out, float *stats_part,
-                              const p2pb_gn_acc *out_acc, void *stream);
-int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
-                                     const float *bias, const float *out_class, const p2pb_gn_fold *in_fold,
-                                     const float *in_scale, const float *in_shift, int in_swish, const float *in_sub,
-                                     int flags, const int *active_list, const int *active_count,
-                                     const int *inactive_list, const int *inactive_count, float *out,
-                                     float *stats_part, const p2pb_gn_acc *out_acc, void *stream);
-int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r, const float *in, const void *wt_split,
-                                      const float *bias, const float *out_class, const p2pb_gn_fold *in_fold,
-                                      const float *in_scale, const float *in_shift, int in_swish, const float *in_sub,
-                                      const unsigned char *alist, const int *acount, float *out, float *stats_part,
-                                      const p2pb_gn_acc *out_acc, void *stream);
-int p2pb_conv3d_k3_far_field_fx(int b, int cin, int cout, const float *prev_bias, const p2pb_gn_fold *in_fold,
-                                const float *in_scale, const float *in_shift, int in_swish, const float *wt_packed,
-                                const float *bias, float *a, float *k_out, float *tap_ws, void *stream);
-/* SE gate from the accumulators of the grid it squeezes (fold->channel required) */
-int p2pb_se_gate_affine_fx(int b, int c, int hidden, const p2pb_gn_fold *fold, const float *w1, const float *w2,
-                           float *aff_a, float *aff_b, void *stream);
-int p2pb_pointwise_conv_forward_fx(int b, int cin, int cout, int npos, const float *in, const void *wp,
-                                   const float *bias, const float *bias_b, const p2pb_gn_fold *in_fold,
-                                   const float *in_scale, const float *in_shift, int in_swish, int flags, float *out,
-                                   float *stats_part, const p2pb_gn_acc *out_acc, void *stream);
-int p2pb_pointwise_conv_pool_forward_fx(int b, int cin, int cout, int npos, const float *in, const void *wp,
-                                        const float *bias, const float *bias_b, const p2pb_gn_fold *in_fold,
-                                        const float *in_scale, const float *in_shift, int in_swish, int flags,
-                                        float *out, float *stats_part, const p2pb_gn_acc *out_acc, int pool_u,
-                                        float *minmax, void *stream);
-int p2pb_minmax_act_fx(int b, int c, int m, int nslots, const float *minmax, const p2pb_gn_fold *fold, int swish,
-                       float *y, void *stream);
-int p2pb_group_sub_fx(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx, float *out,
-                      float *stats_part, const p2pb_gn_acc *out_acc, float *ws, void *stream);
-int p2pb_three_interpolate_add_fx(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
-                                  const float *add, const float *bias, float *out, float *stats_part,
-                                  const p2pb_gn_acc *out_acc, float *ws, void *stream);
 
 /* Voxel-major forms for the fused branch (grid f32[b,r,r,r,c]; conv flags bit 3): same values as
  * p2pb_avg_voxelize_forward / p2pb_trilinear_devoxelize_affine, coalesced on both sides (voxelize.hip).

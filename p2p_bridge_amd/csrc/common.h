@@ -207,142 +207,17 @@ __device__ __forceinline__ float rowreduce32(float (&v)[32]) {
   return (lane & 1) ? y : x;
 }
 
-// ---- GroupNorm statistics without a finishing launch (round 3 of the normalisation design) ----
-// Producers add their {sum, sum of squares} to ONE accumulator per (sample, group) with 64-bit INTEGER atomics, so the
-// result does not depend on the order the workgroups arrive in (deterministic), nobody waits for anybody, and every
-// consumer folds the norm for its own input channels in its prologue (gn_fold_table) -- no gn_affine launch between a
-// layer and the next. A value v is carried as the pair (floor(v), (v - floor(v)) * 2^44) of int64 sums: exact to
-// 2^-44 absolute per addend, no overflow below |sum| = 2^62 or 2^19 addends.
-// Same-line atomics serialise: measured 12 ns per 64-bit atomic per 128-byte line, 14 G atomics/s when spread over
-// >= 1024 lines (tools/exp/atomic_contention.hip). The GROUP accumulators therefore give every one of their words a
-// 128-byte line of its own (stride GN_LINE int64): with the four words of a group in one line -- the first layout --
-// the gather kernels' epilogues queued 30 000 atomics per line and ran 5x longer. The per-channel sums (two adjacent
-// words per channel) see few adds per line and stay packed.
-#define GN_FX_FRAC 17592186044416.0 /* 2^44 */
-#define GN_LINE 16 /* int64 per 128-byte line */
-template <int STRIDE>
-__device__ __forceinline__ void gn_fx_add(long long *p, double v) {
-  const double fl = floor(v);
-  atomicAdd((unsigned long long *)p, (unsigned long long)(long long)fl);
-  atomicAdd((unsigned long long *)p + STRIDE, (unsigned long long)(long long)((v - fl) * GN_FX_FRAC));
-}
-template <int STRIDE>
-__device__ __forceinline__ double gn_fx_read(const long long *p) {
-  return (double)p[0] + (double)p[STRIDE] * (1.0 / GN_FX_FRAC);
-}
-
-// device view of p2pb_gn_acc (+ the layer's channel count): group i64[b,groups,4,GN_LINE] = {sum, sumsq} as fx pairs,
-// one word per line; channel i64[b,c,2] = per-channel sum (optional: SE3d's squeeze input)
-struct GnAcc {
-  long long *group, *channel;
-  int c, cg;  // channels, channels per group
+// ---- which kernel form a pointwise launch took (debug / test hook: include/p2pb_hip.h p2pb_debug_pointwise_form) ----
+enum {
+  P2PB_FORM_PW_FP32 = 0,      // pw_conv_kernel: exact-fp32 MFMA, unaligned rows
+  P2PB_FORM_PW_WIDE_FP32 = 1, // pw_wide_kernel, exact-fp32 MFMA
+  P2PB_FORM_PW_WIDE_F16 = 2,  // pw_wide_kernel on the split pack (f16x3 products)
+  P2PB_FORM_PW_SPLIT128 = 3,  // pw_split_kernel, 128-channel workgroups
+  P2PB_FORM_PW_SPLIT256 = 4,  // pw_split_kernel, 256-channel workgroups
+  P2PB_FORM_PW_PINGPONG = 5,  // pw_pingpong_kernel
+  P2PB_FORM_PW_GATHER = 6,    // pw_wide_kernel<GATHER> (grouped operand built on the fly)
 };
-__device__ __forceinline__ void gn_acc_group(const GnAcc &a, int b, int g, double s, double q) {
-  long long *p = a.group + ((size_t)b * (a.c / a.cg) + g) * 4 * GN_LINE;
-  gn_fx_add<GN_LINE>(p, s);
-  gn_fx_add<GN_LINE>(p + 2 * GN_LINE, q);
-}
-// one lane, channels visited in ASCENDING order (the convolution epilogues: lanes 31 / 63 hold a channel's totals,
-// sixteen channels one after the other): consecutive channels of a group are summed in registers first
-struct GnRun {
-  int g;
-  double s, q;
-};
-__device__ __forceinline__ void gn_run_flush(GnRun &r, const GnAcc &a, int b) {
-  if (r.g >= 0) gn_acc_group(a, b, r.g, r.s, r.q);
-  r.g = -1;
-}
-__device__ __forceinline__ void gn_run_add(GnRun &r, const GnAcc &a, int b, int co, float s1, float s2) {
-  const int g = co / a.cg;
-  if (g != r.g) {
-    gn_run_flush(r, a, b);
-    r.g = g;
-    r.s = 0.0;
-    r.q = 0.0;
-  }
-  r.s += (double)s1;
-  r.q += (double)s2;
-  if (a.channel) gn_fx_add<1>(a.channel + ((size_t)b * a.c + co) * 2, (double)s1);
-}
-// all 64 lanes, one channel each (co < 0: none): when the group of a lane's channel is a function of a subset of the
-// lane-id bits (power-of-two group sizes with the GEMM epilogues' bit-permuted lane -> channel maps) the butterfly
-// below leaves every group's total in all of its lanes and the group's lowest lane adds it; otherwise every lane adds
-// its own channel. Lane order is fixed, so the sums are deterministic either way.
-__device__ __forceinline__ void gn_wave_add(const GnAcc &a, int b, int co, float s1, float s2) {
-  if (a.channel && co >= 0) gn_fx_add<1>(a.channel + ((size_t)b * a.c + co) * 2, (double)s1);
-  double s = (double)s1, q = (double)s2;
-  if ((a.cg & (a.cg - 1)) != 0) {
-    if (co >= 0) gn_acc_group(a, b, co / a.cg, s, q);
-    return;
-  }
-  const int lane = (int)(threadIdx.x & 63);
-  const int key = co >= 0 ? co / a.cg : -1;
-  bool leader = true;
-#pragma unroll
-  for (int st = 1; st < 64; st <<= 1) {
-    const int kp = __shfl_xor(key, st, 64);
-    const double sp = __shfl_xor(s, st, 64), qp = __shfl_xor(q, st, 64);
-    const bool same = kp == key;
-    s += same ? sp : 0.0;
-    q += same ? qp : 0.0;
-    leader = leader && (!same || !(lane & st));
-  }
-  if (leader && key >= 0) gn_acc_group(a, b, key, s, q);
-}
-
-// what a consumer needs to turn the accumulators of its INPUT into scale / shift: p2pb_gn_fold (include/p2pb_hip.h)
-typedef p2pb_gn_fold GnFold;
-// GroupNorm (biased variance) + AdaGN style folded to x*sc + sh for channel ch of sample b: the arithmetic of
-// gn_affine_kernel (conv3d.hip), every consumer and the stand-alone finisher go through this one function
-__device__ __forceinline__ void gn_fold_channel(const GnFold &f, int b, int c, int ch, float &sc_out, float &sh_out,
-                                                float *chmean = nullptr) {
-  const int cg = c / f.groups, g = ch / cg;
-  const long long *p = f.group + ((size_t)b * f.groups + g) * 4 * GN_LINE;
-  const double n = f.count * cg;
-  const double mean = gn_fx_read<GN_LINE>(p) / n;
-  double var = gn_fx_read<GN_LINE>(p + 2 * GN_LINE) / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double rstd = 1.0 / sqrt(var + (double)f.eps);
-  const double ga = f.gamma ? (double)f.gamma[ch] : 1.0, be = f.beta ? (double)f.beta[ch] : 0.0;
-  const double fa = f.style ? (double)f.style[(size_t)b * f.style_stride + ch] : 1.0;
-  const double bi = f.style ? (double)f.style[(size_t)b * f.style_stride + c + ch] : 0.0;
-  const double sc = rstd * ga * fa, sh = (be - mean * rstd * ga) * fa + bi;
-  sc_out = (float)sc;
-  sh_out = (float)sh;
-  if (chmean) *chmean = (float)(sc * (gn_fx_read<1>(f.channel + ((size_t)b * c + ch) * 2) / f.count) + sh);
-}
-// workgroup prologue of a consumer: tab[0..c) = scale, tab[c..2c) = shift of sample b (LDS), folded here from the
-// producer's accumulators (f.group != NULL) or copied from the caller's arrays; the caller's next barrier publishes it
-#define P2PB_FOLD_MAXC 1024
-__device__ __forceinline__ void xf_table(float *tab, const GnFold &f, const float *scale, const float *shift, int b,
-                                         int c) {
-  if (f.group) {
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) gn_fold_channel(f, b, c, ch, tab[ch], tab[c + ch]);
-  } else {
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-      tab[ch] = scale[(size_t)b * c + ch];
-      tab[c + ch] = shift[(size_t)b * c + ch];
-    }
-  }
-}
-
-// host views (include/p2pb_hip.h) -> kernel arguments; c = the channel count the accumulators / the fold describe
-static inline bool gn_acc_ok(const p2pb_gn_acc *a, int c) { return !a || !a->group || (a->groups > 0 && c % a->groups == 0); }
-static inline GnAcc gn_acc_arg(const p2pb_gn_acc *a, int c) {
-  GnAcc g = GnAcc();
-  if (a && a->group) {
-    g.group = a->group;
-    g.channel = a->channel;
-    g.c = c;
-    g.cg = c / a->groups;
-  }
-  return g;
-}
-static inline bool gn_fold_ok(const p2pb_gn_fold *f, int c) {
-  return !f || !f->group ||
-         (f->groups > 0 && c % f->groups == 0 && f->count > 0.0 && (!f->style || f->style_stride >= 2 * c));
-}
-static inline GnFold gn_fold_arg(const p2pb_gn_fold *f) { return (f && f->group) ? *f : GnFold(); }
+void p2pb_note_pointwise_form(int cin, int cout, int form);
 
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);

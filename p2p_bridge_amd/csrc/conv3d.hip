@@ -657,13 +657,10 @@ __device__ __forceinline__ conv_i32x4 conv_make_rsrc(const void *p, unsigned byt
   return r;
 }
 
-// FX: the sampler path's statistics plumbing (operand norm folded here from accumulators / output statistics added to
-// accumulators, common.h) is compiled in -- a separate instantiation (voxel-major form only), so that the plain form
-// carries neither the two argument structs nor the table
 #ifndef CONV_F16_WAVES
 #define CONV_F16_WAVES 2  // (waves per SIMD the f16x3 forms are compiled for; their two-plane tile would fit three workgroups)
 #endif
-template <int R, bool COMPACT, int MT, bool XF, bool CL, bool FX, int TERMS, bool PRE = false>
+template <int R, bool COMPACT, int MT, bool XF, bool CL, int TERMS, bool PRE = false>
 __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_split_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                              const float *__restrict__ in,
                                                              const unsigned short *__restrict__ wt,
@@ -674,19 +671,15 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
                                                              const float *__restrict__ in_sub, int skip_zero,
                                                              const int *__restrict__ brick_list,
                                                              const int *__restrict__ brick_count,
-                                                             float *__restrict__ out, float *__restrict__ stats_part,
-                                                             GnFold fold, GnAcc gacc) {
+                                                             float *__restrict__ out, float *__restrict__ stats_part) {
   using G = SplitGeom<R>;
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
   constexpr int PLANE = HD * HH * HW;
   constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;
-  // folded norm of the operand, per input channel of this sample: [scale | shift], from the caller's arrays or folded
-  // here from the producer's accumulators (common.h gn_fold_table); published by the first barrier of the stage loop
-  __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];
   constexpr int BH = R / G::TH, BW = R / G::TW;
   constexpr int R3 = R * R * R;
   // tile[split][khalf][voxel] : 8 bf16 (16 bytes) = channels khalf*8 .. khalf*8+7 of the staged chunk (PRE: two buffers)
-  static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF && CL && !FX), "pre-split operands: f16x3, voxel-major, no fold");
+  static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF && CL), "pre-split operands: f16x3, voxel-major, transform applied");
   __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
   // (PRE: the second stage buffer is its OWN object, and the stage loop is unrolled by two with the roles fixed, so that
   //  the compiler can tell the LDS-DMA into one buffer from the fragment reads of the other -- with one array it waits
@@ -858,8 +851,6 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
     }
   };
   stage_load(0);
-  const bool folded = FX && XF && fold.group != nullptr;  // (else: the caller's arrays, through the scalar cache)
-  if (folded) xf_table(xtab, fold, in_scale, in_shift, b, cin);
 
   for (int ci0 = 0; ci0 < cin; ci0 += CONV_SCK) {
     __syncthreads();
@@ -869,8 +860,8 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       float sc = 1.0f, sh = 0.0f, sub = 0.0f;
       const bool cok = ci0 + c < cin;
       if (XF && cok) {
-        sc = folded ? xtab[ci0 + c] : in_scale[b * cin + ci0 + c];
-        sh = folded ? xtab[cin + ci0 + c] : in_shift[b * cin + ci0 + c];
+        sc = in_scale[b * cin + ci0 + c];  // (wave-uniform: through the scalar cache)
+        sh = in_shift[b * cin + ci0 + c];
         if (in_sub) sub = in_sub[b * cin + ci0 + c];
       }
 #pragma unroll
@@ -923,7 +914,6 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   }
 
   float *outb = out + (size_t)b * cout * R3;
-  GnRun grun = {-1, 0.0, 0.0};
   // boundary-class constants of a second convolution: the workgroup's [27][32 MT] slice of K[b] goes through LDS (the
   // operand tile is free now) -- one cooperative fetch instead of a dependent global load per (row, N-tile)
   constexpr int NCW = 32 * MT;
@@ -971,11 +961,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
         s1 += v;
         s2 += v * v;
       }
-      if (FX && gacc.group) {  // order-independent accumulators (sampler path): consecutive channels of a group first
-        s1 = halfwave_sum_to_last(s1);
-        s2 = halfwave_sum_to_last(s2);
-        if (l31 == 31 && cok) gn_run_add(grun, gacc, b, co, s1, s2);
-      } else if (stats_part) {
+      if (stats_part) {
         // the brick's four statistics slots: wave column wn fills slot wn for its channels; with two wave rows
         // only two columns exist and slots 2, 3 are zeroed
         s1 = halfwave_sum_to_last(s1);
@@ -1005,7 +991,6 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       }
     }
   }
-  if (FX && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
 #ifdef CONV_TIMELINE
   if constexpr (PRE) {
     __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -1096,16 +1081,10 @@ extern "C" size_t p2pb_conv3d_k3_stats_floats(int b, int cout, int r) {
 // far-field constants of a folded operand transform: a[b,c] = xf(base[c]) with the SAME device function the
 // staging code uses (bit-identical), i.e. the value of swish(affine(conv0 output)) where conv0 saw only zeros
 static __global__ void far_value_kernel(int c, const float *__restrict__ base, const float *__restrict__ scale,
-                                 const float *__restrict__ shift, int swish, float *__restrict__ a, GnFold fold) {
+                                 const float *__restrict__ shift, int swish, float *__restrict__ a) {
   const int b = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
   if (ch >= c) return;
-  float sc, sh;
-  if (fold.group) gn_fold_channel(fold, b, c, ch, sc, sh);
-  else {
-    sc = scale[(size_t)b * c + ch];
-    sh = shift[(size_t)b * c + ch];
-  }
-  a[(size_t)b * c + ch] = xf_apply(base[ch], sc, sh, swish);
+  a[(size_t)b * c + ch] = xf_apply(base[ch], scale[(size_t)b * c + ch], shift[(size_t)b * c + ch], swish);
 }
 
 // T[b, tap, co] = sum_ci W[tap][ci][co] * a[b,ci]  (one thread per output channel, weights read coalesced)
@@ -1149,19 +1128,11 @@ static __global__ __launch_bounds__(256) void class_bias_kernel(int cout, const 
 extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
                                         const float *in_shift, int in_swish, const float *wt_packed,
                                         const float *bias, float *a, float *k_out, float *tap_ws, void *stream) {
-  return p2pb_conv3d_k3_far_field_fx(b, cin, cout, prev_bias, nullptr, in_scale, in_shift, in_swish, wt_packed, bias, a,
-                                     k_out, tap_ws, stream);
-}
-
-extern "C" int p2pb_conv3d_k3_far_field_fx(int b, int cin, int cout, const float *prev_bias,
-                                           const p2pb_gn_fold *in_fold, const float *in_scale, const float *in_shift,
-                                           int in_swish, const float *wt_packed, const float *bias, float *a,
-                                           float *k_out, float *tap_ws, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || !gn_fold_ok(in_fold, cin)) return P2PB_EINVAL;
+  if (b <= 0 || cin <= 0 || cout <= 0 || !in_scale || !in_shift) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
   hipLaunchKernelGGL(far_value_kernel, dim3(cdiv(cin, 256), b), dim3(256), 0, s, cin, prev_bias, in_scale, in_shift,
-                     in_swish, a, gn_fold_arg(in_fold));
+                     in_swish, a);
   hipLaunchKernelGGL(tap_sum_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cin, cout, nchunk, cout_pad,
                      wt_packed, a, tap_ws);
   hipLaunchKernelGGL(class_bias_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cout, tap_ws, bias, k_out);
@@ -1196,52 +1167,46 @@ static int conv_launch(int b, int cin, int cout, const float *in, const float *w
 int conv3d_tu6_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
                      const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                      const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
-                     float *stats_part, bool cl, hipStream_t s, const GnFold &fold, const GnAcc &gacc);
+                     float *stats_part, bool cl, hipStream_t s);
 template <int R, int MT>
 static int conv_launch_split(int b, int cin, int cout, const float *in, const void *wt, const float *bias,
                              const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                              const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count,
-                             float *out, float *stats_part, bool cl, hipStream_t s, const GnFold &fold = GnFold(),
-                             const GnAcc &gacc = GnAcc(), bool pre = false) {
+                             float *out, float *stats_part, bool cl, hipStream_t s, bool pre = false) {
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
-  if ((in_scale || fold.group) && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
   if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
   const unsigned short *w = (const unsigned short *)wt;
-  const bool fx = fold.group != nullptr || gacc.group != nullptr;
-  if (fx && !cl) return P2PB_EINVAL;  // (the statistics plumbing exists in the voxel-major form only)
 #if CONV_TU != 6
   if (p2pb_g_split_terms == SPLIT_BF16X6) {
     if (pre) return P2PB_EINVAL;  // (the S format is the f16x3 arithmetic's)
     return conv3d_tu6_split(R, MT, b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero,
-                            brick_list, brick_count, out, stats_part, cl, s, fold, gacc);
+                            brick_list, brick_count, out, stats_part, cl, s);
   }
 #endif
-#define LAUNCHT(XF, CL, FXV, TM)                                                                                      \
-  hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk,   \
+#define LAUNCHT(XF, CL, TM)                                                                                           \
+  hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, XF, CL, TM>), grid, dim3(256), 0, s, cin, cout, nchunk,        \
                      cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero, brick_list,     \
-                     brick_count, out, stats_part, fold, gacc)
-#define LAUNCH(XF, CL, FXV) LAUNCHT(XF, CL, FXV, CONV_TERMS)
+                     brick_count, out, stats_part)
+#define LAUNCH(XF, CL) LAUNCHT(XF, CL, CONV_TERMS)
   if (pre) {  // `in` is the pre-split operand grid (S format): f16x3, voxel-major, transform already applied
 #if CONV_TU != 6
     if constexpr (R >= 8) {
-      if (!cl || in_scale || in_sub || fold.group || gacc.group) return P2PB_EINVAL;
-      hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, false, true, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s,
+      if (!cl || in_scale || in_sub) return P2PB_EINVAL;
+      hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, false, true, SPLIT_F16X3, true>), grid, dim3(256), 0, s,
                          cin, cout, nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0,
-                         brick_list, brick_count, out, stats_part, fold, gacc);
+                         brick_list, brick_count, out, stats_part);
       return p2pb_launch_status();
     }
 #endif
     return P2PB_EINVAL;
   }
-  if (in_scale != nullptr || fold.group != nullptr) {
-    if (fx) LAUNCH(true, true, true);
-    else if (cl) LAUNCH(true, true, false);
-    else LAUNCH(true, false, false);
+  if (in_scale != nullptr) {
+    if (cl) LAUNCH(true, true);
+    else LAUNCH(true, false);
   } else {
-    if (fx) LAUNCH(false, true, true);
-    else if (cl) LAUNCH(false, true, false);
-    else LAUNCH(false, false, false);
+    if (cl) LAUNCH(false, true);
+    else LAUNCH(false, false);
   }
 #undef LAUNCH
 #undef LAUNCHT
@@ -1251,12 +1216,12 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
 int conv3d_tu6_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
                      const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                      const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
-                     float *stats_part, bool cl, hipStream_t s, const GnFold &fold, const GnAcc &gacc) {
+                     float *stats_part, bool cl, hipStream_t s) {
 #define GOB(RR)                                                                                                        \
   return mt == 2 ? conv_launch_split<RR, 2>(b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, \
-                                            skip_zero, brick_list, brick_count, out, stats_part, cl, s, fold, gacc)      \
+                                            skip_zero, brick_list, brick_count, out, stats_part, cl, s)      \
                  : conv_launch_split<RR, 1>(b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, \
-                                            skip_zero, brick_list, brick_count, out, stats_part, cl, s, fold, gacc)
+                                            skip_zero, brick_list, brick_count, out, stats_part, cl, s)
   switch (r) {
     case 32: GOB(32);
     case 16: GOB(16);
@@ -1364,7 +1329,7 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
                                                           const float *__restrict__ out_class,
                                                           const int *__restrict__ brick_list,
                                                           const int *__restrict__ brick_count, float *__restrict__ out,
-                                                          float *__restrict__ stats_part, GnAcc gacc) {
+                                                          float *__restrict__ stats_part) {
   constexpr int TD = 4, TH = 8, TW = 8, BH = R / TH, BW = R / TW, NBRICK = (R / TD) * BH * BW, R3 = R * R * R;
   __shared__ int ncls[27];
   if ((int)blockIdx.x >= *brick_count) return;
@@ -1412,26 +1377,7 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
     float *ob = out + (size_t)b * cout * R3 + (d * R + h) * R + w;
     for (int co = 0; co < cout; ++co) ob[(size_t)co * R3] = kb ? kb[cls * cout + co] : bias[co];
   }
-  if (gacc.group) {
-    for (int c0 = 0; c0 < cout; c0 += 256) {  // (whole waves: gn_wave_add reduces across the lanes)
-      const int co = c0 + t;
-      float s1 = 0.0f, s2 = 0.0f;
-      if (co < cout) {
-        if (kb) {
-          for (int c = 0; c < 27; ++c) {
-            const float v = kb[c * cout + co], n = (float)ncls[c];
-            s1 += n * v;
-            s2 += n * v * v;
-          }
-        } else {
-          const float v = bias[co];
-          s1 = 256.0f * v;
-          s2 = 256.0f * v * v;
-        }
-      }
-      if ((c0 + (t & ~63)) < cout) gn_wave_add(gacc, b, co < cout ? co : -1, s1, s2);
-    }
-  } else if (stats_part) {
+  if (stats_part) {
     for (int co = t; co < cout; co += 256) {
       float s1 = 0.0f, s2 = 0.0f;
       if (kb) {
@@ -1474,24 +1420,7 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
                                          const float *bias, const float *out_class, const float *in_scale,
                                          const float *in_shift, int in_swish, const float *in_sub, int flags,
                                          float *out, float *stats_part, void *stream) {
-  return p2pb_conv3d_k3_forward_fx(b, cin, cout, r, in, wt_packed, bias, out_class, nullptr, in_scale, in_shift,
-                                   in_swish, in_sub, flags, out, stats_part, nullptr, stream);
-}
-#endif
-
-// the same with the sampler path's statistics plumbing: in_fold (instead of in_scale / in_shift) = fold the operand's
-// norm here from the producer's accumulators; out_acc (instead of stats_part) = add this output's statistics to
-// accumulators. Split pack only (flags bit 2).
-#if CONV_TU != 6
-extern "C" int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
-                                         const float *bias, const float *out_class, const p2pb_gn_fold *in_fold,
-                                         const float *in_scale, const float *in_shift, int in_swish,
-                                         const float *in_sub, int flags, float *out, float *stats_part,
-                                         const p2pb_gn_acc *out_acc, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout)) return P2PB_EINVAL;
-  const GnFold fold = gn_fold_arg(in_fold);
-  const GnAcc gacc = gn_acc_arg(out_acc, cout);
-  if ((fold.group || gacc.group) && !(flags & 4)) return P2PB_EINVAL;
+  if (b <= 0 || cin <= 0 || cout <= 0) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int skip = flags & 1;
   const bool compact = (flags & 2) != 0;
@@ -1507,9 +1436,9 @@ extern "C" int p2pb_conv3d_k3_forward_fx(int b, int cin, int cout, int r, const 
     const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= wide_min;
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc, pre)         \
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, pre)         \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, fold, gacc, pre)
+                                         in_sub, skip, nullptr, nullptr, out, stats_part, cl, s, pre)
     switch (r) {
       case 32: GOS(32);
       case 16: GOS(16);
@@ -1547,24 +1476,7 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
                                              const int *active_list, const int *active_count,
                                              const int *inactive_list, const int *inactive_count, float *out,
                                              float *stats_part, void *stream) {
-  return p2pb_conv3d_k3_forward_sparse_fx(b, cin, cout, r, in, wt_packed, bias, out_class, nullptr, in_scale, in_shift,
-                                          in_swish, in_sub, flags, active_list, active_count, inactive_list,
-                                          inactive_count, out, stats_part, nullptr, stream);
-}
-
-extern "C" int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
-                                                const float *bias, const float *out_class,
-                                                const p2pb_gn_fold *in_fold, const float *in_scale,
-                                                const float *in_shift, int in_swish, const float *in_sub, int flags,
-                                                const int *active_list, const int *active_count,
-                                                const int *inactive_list, const int *inactive_count, float *out,
-                                                float *stats_part, const p2pb_gn_acc *out_acc, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || (r != 16 && r != 32) || !active_list || !inactive_list ||
-      !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout))
-    return P2PB_EINVAL;
-  const GnFold fold = gn_fold_arg(in_fold);
-  const GnAcc gacc = gn_acc_arg(out_acc, cout);
-  if ((fold.group || gacc.group) && !(flags & 4)) return P2PB_EINVAL;
+  if (b <= 0 || cin <= 0 || cout <= 0 || (r != 16 && r != 32) || !active_list || !inactive_list) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int total = conv_bricks(r) * b;
   const bool cl = (flags & 8) != 0;
@@ -1572,7 +1484,7 @@ extern "C" int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r,
   if (pre && (flags & 12) != 12) return P2PB_EINVAL;
 #define FILL(RR, CL)                                                                                          \
   hipLaunchKernelGGL((conv3d_fill_kernel<RR, CL>), dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list, \
-                     inactive_count, out, stats_part, gacc)
+                     inactive_count, out, stats_part)
   if (r == 32) {
     if (cl) FILL(32, true);
     else FILL(32, false);
@@ -1585,9 +1497,9 @@ extern "C" int p2pb_conv3d_k3_forward_sparse_fx(int b, int cin, int cout, int r,
   if (flags & 4) {
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc, pre)   \
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, pre)   \
               : conv_launch_split<RR, 1>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \
-                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, fold, gacc, pre)
+                                         in_sub, 1, active_list, active_count, out, stats_part, cl, s, pre)
     if (r == 32) { GOS(32); }
     GOS(16);
 #undef GOS
@@ -1712,7 +1624,7 @@ extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned c
 }
 #endif
 
-template <int R, int WM, bool XF, bool FX, int TERMS, bool PRE = false>  // FX, TERMS, PRE: see conv3d_k3_split_kernel
+template <int R, int WM, bool XF, int TERMS, bool PRE = false>  // TERMS, PRE: see conv3d_k3_split_kernel
 __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) void conv3d_k3_compact_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                                 const float *__restrict__ in,
                                                                 const unsigned short *__restrict__ wt,
@@ -1723,21 +1635,19 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
                                                                 const float *__restrict__ in_sub, int skip_zero,
                                                                 const unsigned char *__restrict__ alist,
                                                                 const int *__restrict__ acount,
-                                                                float *__restrict__ out, float *__restrict__ stats_part,
-                                                                GnFold fold, GnAcc gacc) {
+                                                                float *__restrict__ out, float *__restrict__ stats_part) {
   using G = SplitGeom<R>;
   constexpr int HD = G::TD + 2, HH = G::TH + 2, HW = G::TW + 2;
   constexpr int PLANE = HD * HH * HW;
   constexpr int BH = R / G::TH, BW = R / G::TW, BD = R / G::TD, NBRICK = BD * BH * BW;
   constexpr int R3 = R * R * R;
   constexpr int WN = 4 / WM;
-  static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF && !FX), "pre-split operands: f16x3, no fold");
+  static_assert(!PRE || (TERMS == SPLIT_F16X3 && !XF), "pre-split operands: f16x3, transform applied");
   __shared__ u32x4 tile[split_planes(TERMS) * 2 * PLANE];
   __shared__ u32x4 tile2[PRE ? split_planes(TERMS) * 2 * PLANE : 1];  // (its own object: see the split kernel)
   __shared__ unsigned char lst[256];
   __shared__ int ncls[27];
   __shared__ float wstat[4][2][16][2];  // per wave, half-wave, accumulator row: {sum, sumsq} over the active outputs
-  __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];  // folded norm of the operand (see the split kernel)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -1761,8 +1671,6 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   const int count = acount[(size_t)b * NBRICK + brick];
   lst[tid] = alist[((size_t)b * NBRICK + brick) * 256 + tid];
   if (tid < 27) ncls[tid] = 0;
-  const bool folded = FX && XF && fold.group != nullptr;
-  if (folded) xf_table(xtab, fold, in_scale, in_shift, b, cin);
   __syncthreads();
   CONV_TL(tid);  // 1: brick list in LDS
   const int ntiles = (count + 31) >> 5;
@@ -1883,8 +1791,8 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
         float sc = 1.0f, sh = 0.0f, sub = 0.0f;
         const bool cok = ci0 + c < cin;
         if (XF && cok) {
-          sc = folded ? xtab[ci0 + c] : in_scale[b * cin + ci0 + c];
-          sh = folded ? xtab[cin + ci0 + c] : in_shift[b * cin + ci0 + c];
+          sc = in_scale[b * cin + ci0 + c];
+          sh = in_shift[b * cin + ci0 + c];
           if (in_sub) sub = in_sub[b * cin + ci0 + c];
         }
 #pragma unroll
@@ -2047,35 +1955,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
       outb[(size_t)vx * cout + cob + c] = kb ? kb[cls * cout + cob + c] : bias[cob + c];
     }
   }
-  if (FX && gacc.group) {
-    if (l31 == 31) {  // the wave columns' active sums
-      GnRun grun = {-1, 0.0, 0.0};
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-        if (co < cout) gn_run_add(grun, gacc, b, co, wstat[wave][khalf][r][0], wstat[wave][khalf][r][1]);
-      }
-      gn_run_flush(grun, gacc, b);
-    }
-    if ((tid & ~63) < cw) {  // the constants' sums
-      const int co = cob + tid;
-      float s1 = 0.0f, s2 = 0.0f;
-      if (tid < cw) {
-        if (kb) {
-          for (int c = 0; c < 27; ++c) {
-            const float x = kb[c * cout + co], n = (float)ncls[c];
-            s1 += n * x;
-            s2 += n * x * x;
-          }
-        } else {
-          const float x = bias[co];
-          s1 = (float)ninact * x;
-          s2 = (float)ninact * x * x;
-        }
-      }
-      gn_wave_add(gacc, b, tid < cw ? co : -1, s1, s2);
-    }
-  } else if (stats_part) {
+  if (stats_part) {
     // slots of the brick: [0, WN) = the wave columns' active sums, WN = the constants' sums, the rest zero
     float *sp = stats_part + (((size_t)b * NBRICK + brick) * 4) * cout * 2;
     if (l31 == 31) {
@@ -2128,33 +2008,25 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                        const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                        const float *in_sub, const unsigned char *alist, const int *acount, float *out, float *stats_part,
-                       hipStream_t s, const GnFold &fold, const GnAcc &gacc);
+                       hipStream_t s);
 static int conv_launch_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                                const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                                const float *in_sub, const unsigned char *alist, const int *acount, float *out,
-                               float *stats_part, hipStream_t s, const GnFold &fold, const GnAcc &gacc, bool pre = false) {
-  const bool xf = in_scale != nullptr || fold.group != nullptr;
-  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
+                               float *stats_part, hipStream_t s, bool pre = false) {
+  const bool xf = in_scale != nullptr;
 #if CONV_TU != 6
-  if (pre && (p2pb_g_split_terms == SPLIT_BF16X6 || xf || in_sub || gacc.group)) return P2PB_EINVAL;
+  if (pre && (p2pb_g_split_terms == SPLIT_BF16X6 || xf || in_sub)) return P2PB_EINVAL;
   if (p2pb_g_split_terms == SPLIT_BF16X6)
     return conv3d_tu6_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
-                              acount, out, stats_part, s, fold, gacc);
+                              acount, out, stats_part, s);
 #endif
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   const unsigned short *w = (const unsigned short *)wt_split;
   const bool wm1 = cout <= 32;  // one M-tile per workgroup, tiles dealt to four wave columns
   dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
-  const bool fx = fold.group != nullptr || gacc.group != nullptr;
-#define LAUNCHX(RR, WMV, XF, FXV, TM)                                                                                 \
-  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, FXV, TM>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
-                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part,   \
-                     fold, gacc)
-#define LAUNCH(RR, WMV, XF)                          \
-  do {                                               \
-    if (fx) LAUNCHX(RR, WMV, XF, true, CONV_TERMS);   \
-    else LAUNCHX(RR, WMV, XF, false, CONV_TERMS);     \
-  } while (0)
+#define LAUNCH(RR, WMV, XF)                                                                                           \
+  hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, CONV_TERMS>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
+                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part)
 #define GO(RR)                                                   \
   if (wm1) {                                                     \
     if (xf) LAUNCH(RR, 1, true);                                 \
@@ -2167,13 +2039,13 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
 #define GOPRE(RR)                                                                                                          \
   do {                                                                                                                     \
     if (wm1)                                                                                                               \
-      hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 1, false, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
+      hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 1, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
                          nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0, alist, acount, out, \
-                         stats_part, fold, gacc);                                                                          \
+                         stats_part);                                                                                      \
     else                                                                                                                   \
-      hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 2, false, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
+      hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 2, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
                          nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0, alist, acount, out, \
-                         stats_part, fold, gacc);                                                                          \
+                         stats_part);                                                                                      \
   } while (0)
   if (pre) {
     if (r == 32) GOPRE(32); else if (r == 16) GOPRE(16); else GOPRE(8);
@@ -2184,16 +2056,15 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
   if (r == 32) { GO(32) } else if (r == 16) { GO(16) } else { GO(8) }
 #undef GO
 #undef LAUNCH
-#undef LAUNCHX
   return p2pb_launch_status();
 }
 #if CONV_TU == 6
 int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                        const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                        const float *in_sub, const unsigned char *alist, const int *acount, float *out, float *stats_part,
-                       hipStream_t s, const GnFold &fold, const GnAcc &gacc) {
+                       hipStream_t s) {
   return conv_launch_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist, acount,
-                             out, stats_part, s, fold, gacc);
+                             out, stats_part, s);
 }
 #endif
 
@@ -2203,23 +2074,9 @@ extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, c
                                               const float *in_shift, int in_swish, const float *in_sub,
                                               const unsigned char *alist, const int *acount, float *out,
                                               float *stats_part, void *stream) {
-  return p2pb_conv3d_k3_forward_compact_fx(b, cin, cout, r, in, wt_split, bias, out_class, nullptr, in_scale, in_shift,
-                                           in_swish, in_sub, alist, acount, out, stats_part, nullptr, stream);
-}
-
-extern "C" int p2pb_conv3d_k3_forward_compact_fx(int b, int cin, int cout, int r, const float *in, const void *wt_split,
-                                                 const float *bias, const float *out_class,
-                                                 const p2pb_gn_fold *in_fold, const float *in_scale,
-                                                 const float *in_shift, int in_swish, const float *in_sub,
-                                                 const unsigned char *alist, const int *acount, float *out,
-                                                 float *stats_part, const p2pb_gn_acc *out_acc, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || !alist || !acount || (r != 8 && r != 16 && r != 32) ||
-      !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout))
-    return P2PB_EINVAL;
-  const GnFold fold = gn_fold_arg(in_fold);
-  const GnAcc gacc = gn_acc_arg(out_acc, cout);
+  if (b <= 0 || cin <= 0 || cout <= 0 || !alist || !acount || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
   return conv_launch_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
-                             acount, out, stats_part, (hipStream_t)stream, fold, gacc);
+                             acount, out, stats_part, (hipStream_t)stream);
 }
 #endif
 
@@ -2231,7 +2088,7 @@ extern "C" int p2pb_conv3d_k3_forward_compact_pre(int b, int cin, int cout, int 
                                                   float *stats_part, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || !in_split || !alist || !acount || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
   return conv_launch_compact(b, cin, cout, r, (const float *)in_split, wt_split, bias, out_class, nullptr, nullptr, 0,
-                             nullptr, alist, acount, out, stats_part, (hipStream_t)stream, GnFold(), GnAcc(), true);
+                             nullptr, alist, acount, out, stats_part, (hipStream_t)stream, true);
 }
 
 // y f32[b][nvox][c] (voxel-major) -> S format u32x4[b][nvox][ceil(c/16)][2 planes][2 khalf]: the operand transform of
@@ -2453,66 +2310,3 @@ extern "C" int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean
 }
 #endif
 
-// ------------------------------------------------------------------------------------------------
-// The same two steps on the sampler path's accumulators (common.h: fixed-point group / channel sums added by the
-// producers' epilogues). gn_fold_params_kernel is the stand-alone finisher for consumers that take scale / shift
-// arrays; se_gate_affine_fold_kernel folds the norm itself (it is the consumer of the second convolution's statistics).
-// ------------------------------------------------------------------------------------------------
-static __global__ __launch_bounds__(256) void gn_fold_params_kernel(int c, GnFold fold, float *__restrict__ scale,
-                                                             float *__restrict__ shift, float *__restrict__ chmean) {
-  const int b = blockIdx.y, ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
-  float sc, sh, cm;
-  gn_fold_channel(fold, b, c, ch, sc, sh, chmean ? &cm : nullptr);
-  scale[(size_t)b * c + ch] = sc;
-  shift[(size_t)b * c + ch] = sh;
-  if (chmean) chmean[(size_t)b * c + ch] = cm;
-}
-
-#if CONV_TU != 6
-extern "C" int p2pb_gn_fold_params(int b, int c, const p2pb_gn_fold *fold, float *scale, float *shift, float *chmean,
-                                   void *stream) {
-  if (b <= 0 || c <= 0 || !fold || !fold->group || !gn_fold_ok(fold, c) || !scale || !shift ||
-      (chmean && !fold->channel))
-    return P2PB_EINVAL;
-  hipLaunchKernelGGL(gn_fold_params_kernel, dim3(cdiv(c, 256), b), dim3(256), 0, (hipStream_t)stream, c, *fold, scale,
-                     shift, chmean);
-  return p2pb_launch_status();
-}
-#endif
-
-static __global__ __launch_bounds__(256) void se_gate_affine_fold_kernel(int c, int hidden, GnFold fold,
-                                                                  const float *__restrict__ w1,
-                                                                  const float *__restrict__ w2,
-                                                                  float *__restrict__ aff_a, float *__restrict__ aff_b) {
-  extern __shared__ float se_sm[];  // c means + c scales + c shifts + hidden activations
-  float *mean = se_sm, *sc = se_sm + c, *sh = se_sm + 2 * c, *hid = se_sm + 3 * c;
-  const int b = blockIdx.x, t = threadIdx.x;
-  for (int i = t; i < c; i += 256) gn_fold_channel(fold, b, c, i, sc[i], sh[i], &mean[i]);
-  __syncthreads();
-  for (int h = t; h < hidden; h += 256) {
-    float acc = 0.0f;
-    for (int i = 0; i < c; ++i) acc = __fmaf_rn(w1[(size_t)h * c + i], mean[i], acc);
-    hid[h] = fmaxf(acc, 0.0f);
-  }
-  __syncthreads();
-  for (int i = t; i < c; i += 256) {
-    float acc = 0.0f;
-    for (int h = 0; h < hidden; ++h) acc = __fmaf_rn(w2[(size_t)i * hidden + h], hid[h], acc);
-    const float gate = 1.0f / (1.0f + expf(-acc));
-    aff_a[(size_t)b * c + i] = sc[i] * gate;
-    aff_b[(size_t)b * c + i] = sh[i] * gate;
-  }
-}
-
-// fold (group + channel accumulators of the grid the gate squeezes) -> aff_a, aff_b f32[b,c]
-#if CONV_TU != 6
-extern "C" int p2pb_se_gate_affine_fx(int b, int c, int hidden, const p2pb_gn_fold *fold, const float *w1,
-                                      const float *w2, float *aff_a, float *aff_b, void *stream) {
-  if (b <= 0 || c <= 0 || hidden <= 0 || !fold || !fold->group || !fold->channel || !gn_fold_ok(fold, c))
-    return P2PB_EINVAL;
-  hipLaunchKernelGGL(se_gate_affine_fold_kernel, dim3(b), dim3(256), (size_t)(3 * c + hidden) * sizeof(float),
-                     (hipStream_t)stream, c, hidden, *fold, w1, w2, aff_a, aff_b);
-  return p2pb_launch_status();
-}
-#endif

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void nb_transpose_kernel(int c, int n, const f
 __global__ __launch_bounds__(256) void group_sub_kernel(int c, int n, int m, int u, int nslots,
                                                         const float *__restrict__ zt, const float *__restrict__ cxt,
                                                         const int *__restrict__ idx, float *__restrict__ out,
-                                                        float *__restrict__ stats, GnAcc gacc) {
+                                                        float *__restrict__ stats) {
   __shared__ float tile[64][65];  // [channel][position]
   const int b = blockIdx.z, p0 = blockIdx.x * 64, t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -256,28 +256,23 @@ __global__ __launch_bounds__(256) void group_sub_kernel(int c, int n, int m, int
     }
     __syncthreads();
     const int pt = lane;
-    GnRun grun = {-1, 0.0, 0.0};
-    // accumulators: a wave owns `per` CONSECUTIVE channel rows (whole GroupNorm groups: fewer atomics); partials: rows
-    // wave, wave + 4, ... as before (four waves then write four adjacent output rows at a time: measured 15 % faster)
+    // a wave owns rows wave, wave + 4, ... (four waves write four adjacent output rows at a time: measured 15 % faster
+    // than consecutive rows per wave)
     const int per = cpl / 4;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int cr = gacc.group ? wave * per + k : wave + 4 * k;
+      const int cr = wave + 4 * k;
       const float v = tile[cr & 63][pt];  // zero outside the tensor: statistics unaffected
       if (k < per && c0 + cr < c) {
         if (out && p0 + pt < mu) out[((size_t)b * c + c0 + cr) * mu + p0 + pt] = v;  // (out == NULL: statistics only)
         const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
         if ((lane & 31) == 31) {
-          if (gacc.group) gn_run_add(grun, gacc, b, c0 + cr, s1, s2);
-          else {
-            float *p = stats + (((size_t)b * nslots + blockIdx.x * 2 + (lane >> 5)) * c + c0 + cr) * 2;
-            p[0] = s1;
-            p[1] = s2;
-          }
+          float *p = stats + (((size_t)b * nslots + blockIdx.x * 2 + (lane >> 5)) * c + c0 + cr) * 2;
+          p[0] = s1;
+          p[1] = s2;
         }
       }
     }
-    if (gacc.group && (lane & 31) == 31) gn_run_flush(grun, gacc, b);
     __syncthreads();
   }
 }
@@ -289,15 +284,7 @@ extern "C" size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u) {
 // ws: f32[b*(n+m)*c] scratch for the point-major copies
 extern "C" int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx,
                               float *out, float *stats_part, float *ws, void *stream) {
-  return p2pb_group_sub_fx(b, c, n, m, u, z, cx, idx, out, stats_part, nullptr, ws, stream);
-}
-
-// out_acc instead of stats_part: the statistics go to order-independent accumulators (include/p2pb_hip.h)
-extern "C" int p2pb_group_sub_fx(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx,
-                                 float *out, float *stats_part, const p2pb_gn_acc *out_acc, float *ws, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !gn_acc_ok(out_acc, c)) return P2PB_EINVAL;
-  const GnAcc gacc = gn_acc_arg(out_acc, c);
-  if (!stats_part && !gacc.group) return P2PB_EINVAL;
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !stats_part) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const float *zt = z, *cxt = cx;  // ws == NULL: z f32[b,n,c] and cx f32[b,m,c] are point-major already
   if (ws) {
@@ -309,7 +296,7 @@ extern "C" int p2pb_group_sub_fx(int b, int c, int n, int m, int u, const float 
   }
   const int nblk = (int)(((long)m * u + 63) / 64);
   hipLaunchKernelGGL(group_sub_kernel, dim3(nblk, cdiv(c, c <= 32 ? 32 : 64), b), dim3(256), 0, s, c, n, m, u, nblk * 2,
-                     zt, cxt, idx, out, stats_part, gacc);
+                     zt, cxt, idx, out, stats_part);
   return p2pb_launch_status();
 }
 
@@ -781,7 +768,7 @@ __global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int
                                                                const float *__restrict__ weights,
                                                                const float *__restrict__ add,
                                                                const float *__restrict__ bias, float *__restrict__ out,
-                                                               float *__restrict__ stats, GnAcc gacc) {
+                                                               float *__restrict__ stats) {
   __shared__ float tile[64][65];  // [channel][position]
   __shared__ int sid[64][3];
   __shared__ float sw[64][3];
@@ -809,10 +796,9 @@ __global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int
     __syncthreads();
     const int pt = lane;
     const bool pok = p0 + pt < n;
-    GnRun grun = {-1, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const int cr = gacc.group ? wave * 16 + k : wave + 4 * k;  // (see group_sub_kernel)
+      const int cr = wave + 4 * k;  // (see group_sub_kernel)
       if (c0 + cr < c) {
         float v = 0.0f;
         if (pok) {
@@ -824,16 +810,12 @@ __global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int
         }
         const float s1 = halfwave_sum_to_last(v), s2 = halfwave_sum_to_last(v * v);
         if ((lane & 31) == 31) {
-          if (gacc.group) gn_run_add(grun, gacc, b, c0 + cr, s1, s2);
-          else {
-            float *p = stats + (((size_t)b * nslots + blockIdx.x * 2 + (lane >> 5)) * c + c0 + cr) * 2;
-            p[0] = s1;
-            p[1] = s2;
-          }
+          float *p = stats + (((size_t)b * nslots + blockIdx.x * 2 + (lane >> 5)) * c + c0 + cr) * 2;
+          p[0] = s1;
+          p[1] = s2;
         }
       }
     }
-    if (gacc.group && (lane & 31) == 31) gn_run_flush(grun, gacc, b);
     __syncthreads();
   }
 }
@@ -842,15 +824,7 @@ __global__ __launch_bounds__(256) void three_interp_add_kernel(int c, int m, int
 extern "C" int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
                                           const float *add, const float *bias, float *out, float *stats_part,
                                           float *ws, void *stream) {
-  return p2pb_three_interpolate_add_fx(b, c, m, n, cz, idx, w, add, bias, out, stats_part, nullptr, ws, stream);
-}
-
-extern "C" int p2pb_three_interpolate_add_fx(int b, int c, int m, int n, const float *cz, const int *idx, const float *w,
-                                             const float *add, const float *bias, float *out, float *stats_part,
-                                             const p2pb_gn_acc *out_acc, float *ws, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || !gn_acc_ok(out_acc, c)) return P2PB_EINVAL;
-  const GnAcc gacc = gn_acc_arg(out_acc, c);
-  if (!stats_part && !gacc.group) return P2PB_EINVAL;
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || !stats_part) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const float *czt = cz;  // ws == NULL: cz f32[b,m,c] is point-major already
   if (ws) {
@@ -859,7 +833,7 @@ extern "C" int p2pb_three_interpolate_add_fx(int b, int c, int m, int n, const f
   }
   const int nblk = (n + 63) / 64;
   hipLaunchKernelGGL(three_interp_add_kernel, dim3(nblk, cdiv(c, 64), b), dim3(256), 0, s, c, m, n, nblk * 2, czt, idx, w,
-                     add, bias, out, stats_part, gacc);
+                     add, bias, out, stats_part);
   return p2pb_launch_status();
 }
 

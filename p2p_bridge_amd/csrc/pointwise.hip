@@ -224,7 +224,7 @@ struct PwGather {
   const int *idx;    // i32[b, P]
   int gn, gu;        // points per cloud, neighbours per centre
 };
-template <int MT, bool XF, bool STATS, bool POOL, bool FX, int TERMS = 0, bool GATHER = false>  // FX: see pw_split_kernel
+template <int MT, bool XF, bool STATS, bool POOL, int TERMS = 0, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int cout_pad, int P, int nslots,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias,
@@ -232,12 +232,9 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
                                                       const float *__restrict__ in_scale,
                                                       const float *__restrict__ in_shift, int in_swish,
                                                       float *__restrict__ out, float *__restrict__ stats_part,
-                                                      float *__restrict__ mm_out, int pool_g, int out_pm, GnFold fold,
-                                                      GnAcc gacc, PwGather gat = PwGather()) {
+                                                      float *__restrict__ mm_out, int pool_g, int out_pm,
+                                                      PwGather gat = PwGather()) {
   static_assert(!GATHER || TERMS == SPLIT_F16X3, "the gathered operand exists in the f16x3 form");
-  // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
-  // producer's accumulators (common.h) -- the one barrier of this kernel
-  __shared__ float xtab[(XF && FX) ? 2 * P2PB_FOLD_MAXC : 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
   const int co0 = blockIdx.y * (32 * MT), b = blockIdx.z;
@@ -408,11 +405,6 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
     load_b(0, bnxt);
     load_a(0, a_nxt);
   }
-  const bool folded = FX && XF && fold.group != nullptr;  // (the caller's arrays: scalar loads, no LDS, no barrier)
-  if (folded) {
-    xf_table(xtab, fold, in_scale, in_shift, b, cin);
-    __syncthreads();
-  }
 
   for (int ci0 = 0; TERMS == 0 && ci0 < cin; ci0 += PWW_CK) {
     // rotate (the vmcnt wait lands here), request the next chunk, then multiply the current one
@@ -427,17 +419,10 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
     if (XF) {
 #pragma unroll
       for (int kk = 0; kk < PWW_CK / 2; ++kk) {
-        float sc, sh;
-        if (folded) {
-          const int cx = min(ci0 + 2 * kk + khalf, cin - 1);  // (uniform per half-wave: two LDS broadcasts)
-          sc = xtab[cx];
-          sh = xtab[cin + cx];
-        } else {  // wave-uniform indices: the folded norm parameters travel through the scalar cache
-          const int ca = b * cin + min(ci0 + 2 * kk, cin - 1), cb = b * cin + min(ci0 + 2 * kk + 1, cin - 1);
-          const float sca = in_scale[ca], scb = in_scale[cb], sha = in_shift[ca], shb = in_shift[cb];
-          sc = khalf ? scb : sca;
-          sh = khalf ? shb : sha;
-        }
+        // wave-uniform indices: the folded norm parameters travel through the scalar cache
+        const int ca = b * cin + min(ci0 + 2 * kk, cin - 1), cb = b * cin + min(ci0 + 2 * kk + 1, cin - 1);
+        const float sca = in_scale[ca], scb = in_scale[cb], sha = in_shift[ca], shb = in_shift[cb];
+        const float sc = khalf ? scb : sca, sh = khalf ? shb : sha;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           float v = bcur[kk][s] * sc + sh;
@@ -484,7 +469,6 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
   // statistics slots keep the 64-position granularity of the narrow kernel: this wave fills slot `slot`
   // with its 128-position sums and zeroes slot + 1
   const int slot = (blockIdx.x * 4 + wave) * 2;
-  GnRun grun = {-1, 0.0, 0.0};
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -522,9 +506,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       if (STATS) {
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
-        if (FX && gacc.group) {
-          if (l31 == 31 && co < cout) gn_run_add(grun, gacc, b, co, s1, s2);
-        } else if (l31 == 31 && co < cout) {
+        if (l31 == 31 && co < cout) {
           if (slot < nslots) {
             float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
             q[0] = s1;
@@ -539,7 +521,6 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       }
     }
   }
-  if (FX && STATS && gacc.group && l31 == 31) gn_run_flush(grun, gacc, b);
 }
 
 // w element (co, ci) at w[co * s_co + ci * s_ci]: (cin, 1) for a layer's own weight [cout][cin], (1, cout) for the adjoint
@@ -613,8 +594,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
                                              int wm, int wn, int l31, int khalf, int cout, int P, int nslots,
                                              const float *__restrict__ bias, const float *__restrict__ bias_b,
                                              float *__restrict__ out, float *__restrict__ stats_part,
-                                             float *__restrict__ mm_out, int pool_u, int out_pm, const GnAcc &gacc,
-                                             const float *sb) {
+                                             float *__restrict__ mm_out, int pool_u, int out_pm, const float *sb) {
   // sb: the workgroup's bias (+ per-sample bias) values [64 WM], staged in LDS by the kernel's prologue. Fetched from
   // global memory inside the row loops below they were one L2 round trip each, serialised by the loops' branches (the
   // same finding as in the convolutions' epilogue, conv3d.hip / tools/exp_conv_timeline.py).
@@ -693,14 +673,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
                                     : (pok ? fmaxf(v0, v1) : -INFINITY);
       }
   };
-  if (gacc.group) {  // order-independent accumulators: one add per (wave, group) -- common.h gn_wave_add
-    float tv[32];
-    rowvals(0, tv);
-    const float s1 = rowreduce32<RowAdd>(tv);
-    rowvals(1, tv);
-    const float s2 = rowreduce32<RowAdd>(tv);
-    gn_wave_add(gacc, b, rco < cout ? rco : -1, s1, s2);
-  } else if (stats_part) {
+  if (stats_part) {
     float tv[32];
     rowvals(0, tv);
     const float s1 = rowreduce32<RowAdd>(tv);
@@ -741,12 +714,9 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // tiles), every A fragment feeds four MFMAs instead of two and the weight tile is streamed from L2 once per 256
 // positions -- the 128 x 128 tiling moves 10.7 GB through L2 for the 512 -> 1024 x 262144 GEMM (6.4 GB of it the
 // pre-split weights, re-read by 2048 position blocks), 256 x 256 moves 5.3 GB.
-// FX: the statistics plumbing of the sampler path (operand norm folded here from accumulators / output statistics added
-// to accumulators) is compiled in. A separate instantiation, because merely carrying the two argument structs through
-// the stage loop costs the plain form 5 % (scalar registers: the row descriptors already fill the SGPR file).
 // TERMS: the arithmetic (common.h, p2pb_set_split_terms) -- SPLIT_F16X3 (default: fp16-pair split, three products, two
 // operand planes: the third is neither fetched, written nor read) or SPLIT_BF16X6 (three bf16 terms, six products)
-template <bool XF, bool POOL, int WM, int NB, bool FX, int TERMS>
+template <bool XF, bool POOL, int WM, int NB, int TERMS>
 #ifndef PWS_WM4_WAVES
 #define PWS_WM4_WAVES 4
 #endif
@@ -757,8 +727,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
                                                        const float *__restrict__ in_scale,
                                                        const float *__restrict__ in_shift, int in_swish,
                                                        float *__restrict__ out, float *__restrict__ stats_part,
-                                                       float *__restrict__ mm_out, int pool_u, int out_pm, GnFold fold,
-                                                       GnAcc gacc) {
+                                                       float *__restrict__ mm_out, int pool_u, int out_pm) {
   extern __shared__ u32x4 pws_lds[];  // [A: WM/2 blocks of 128 channels][B: NB blocks of 128 positions][XF: 2 cin floats]
   constexpr int NT = 128 * WM;
   constexpr int BS = 128 * NB;  // 16-byte groups per (kstep, split, khalf) row of the B tile
@@ -845,13 +814,8 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
                                          (__attribute__((address_space(3))) void *)(dst + i * NT + wave * 64), 16, 0, 0);
   };
   load_b(0);
-  // folded norm of the operand per input channel [scale | shift]: the caller's arrays, or folded here from the
-  // producer's accumulators (common.h); published by the barrier at the top of the first stage
-  // (the caller's arrays keep travelling through the scalar cache: an LDS broadcast at the top of the transform phase
-  //  costs this kernel 1.2 % -- measured)
-  float *xtab = (float *)(pws_lds + (WM / 2 + NB) * PWS_TILE);
-  const bool folded = FX && XF && fold.group != nullptr;
-  if (folded) xf_table(xtab, fold, in_scale, in_shift, b, cin);
+  // (the folded norm parameters of the operand travel through the scalar cache: an LDS broadcast at the top of the transform
+  //  phase costs this kernel 1.2 % -- measured)
 
   for (int ci0 = 0; ci0 < cin; ci0 += PWS_CK) {
     __syncthreads();  // everyone is done reading the previous stage
@@ -863,7 +827,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int c = min(ci0 + 8 * bgrp + i, cin - 1);
-          const float sc = folded ? xtab[c] : in_scale[b * cin + c], sh = folded ? xtab[cin + c] : in_shift[b * cin + c];
+          const float sc = in_scale[b * cin + c], sh = in_shift[b * cin + c];
 #pragma unroll
           for (int q = 0; q < NBW; ++q)
 #pragma unroll
@@ -939,7 +903,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
         for (int r = 0; r < 16; ++r) acc[m][n][r] *= oscale;
   }
   pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
-                             stats_part, mm_out, pool_u, out_pm, FX ? gacc : GnAcc(), pws_bias);
+                             stats_part, mm_out, pool_u, out_pm, pws_bias);
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
@@ -1016,10 +980,8 @@ extern "C" int p2pb_pointwise_pack_weights_split_amax(int cout, int cin, const f
 
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
-                           float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s,
-                           const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc()) {
-  const bool xf = in_scale != nullptr || fold.group != nullptr;
-  const bool fx = fold.group != nullptr || gacc.group != nullptr;
+                           float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
+  const bool xf = in_scale != nullptr;
   const int mode = p2pb_g_split_terms;
   // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
   static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
@@ -1031,40 +993,34 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
   // 72 KB of dynamic LDS (above the 64 KB default): opt in once per instantiation
-#define LAUNCHW(XF, PL, WM, NB, FXV, TM)                                                                                  \
+#define LAUNCHW(XF, PL, WM, NB, TM)                                                                                  \
   do {                                                                                                               \
     static bool once = false;                                                                                        \
-    const int lds = (WM / 2 + NB) * PWS_TILE * 16 + (fold.group ? 2 * cin * 4 : 0);                                   \
+    const int lds = (WM / 2 + NB) * PWS_TILE * 16;                                                                   \
     if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, FXV, TM>,                                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize,                                          \
-                                (WM / 2 + NB) * PWS_TILE * 16 + 2 * P2PB_FOLD_MAXC * 4);                               \
+      (void)hipFuncSetAttribute((const void *)pw_split_kernel<XF, PL, WM, NB, TM>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                    \
       once = true;                                                                                                   \
     }                                                                                                                \
-    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, FXV, TM>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in,  \
-                       w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fold,  \
-                       gacc);                                                                                        \
+    hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, TM>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
+                       w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm);       \
   } while (0)
-#define LAUNCHF(XF, PL, WM, NB)                          \
-  do {                                                   \
-    if (fx) {                                             \
-      if (mode == SPLIT_F16X3) LAUNCHW(XF, PL, WM, NB, true, SPLIT_F16X3); \
-      else LAUNCHW(XF, PL, WM, NB, true, 6);              \
-    } else if (mode == SPLIT_F16X3) LAUNCHW(XF, PL, WM, NB, false, SPLIT_F16X3); \
-    else LAUNCHW(XF, PL, WM, NB, false, 6);               \
+#define LAUNCHF(XF, PL, WM, NB)                                       \
+  do {                                                                \
+    if (mode == SPLIT_F16X3) LAUNCHW(XF, PL, WM, NB, SPLIT_F16X3);     \
+    else LAUNCHW(XF, PL, WM, NB, 6);                                   \
   } while (0)
 #define LAUNCH(XF, PL)                    \
   do {                                    \
     if (wm4) LAUNCHF(XF, PL, 4, 1);        \
     else LAUNCHF(XF, PL, 2, 1);            \
   } while (0)
-  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
   // Round 3: the layers that qualified for 256-channel workgroups AND come in whole 256 x 256 tiles with an even number
   // of 32-channel stages run the ping-pong kernel (pw_pingpong.h: one 8-wave workgroup per CU, 160 KB of LDS, weight
   // DMA two stages ahead, the two waves of a SIMD in opposite phase): 512 -> 1024 x 8192 x 32 in 0.88 ms against 1.04-1.15
   // (tools/exp/pp). P2PB_PW_PP=0 keeps pw_split_kernel (A/B timing).
   static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 1;
-  if (pp_env && wm4 && !fx && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 256 == 0 && P % 256 == 0 &&
+  if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 256 == 0 && P % 256 == 0 &&
       (!minmax || pool_u == 0)) {
     dim3 pgrid(P / 256, cout / 256, b);
 #define LAUNCHPP(XF, PL)                                                                                             \
@@ -1083,8 +1039,10 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     else if (minmax) LAUNCHPP(false, true);
     else LAUNCHPP(false, false);
 #undef LAUNCHPP
+    p2pb_note_pointwise_form(cin, cout, P2PB_FORM_PW_PINGPONG);
     return p2pb_launch_status();
   }
+  p2pb_note_pointwise_form(cin, cout, wm4 ? P2PB_FORM_PW_SPLIT256 : P2PB_FORM_PW_SPLIT128);
   if (xf && minmax) LAUNCH(true, true);
   else if (xf) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
@@ -1103,26 +1061,22 @@ static bool pw_wide_ok(int P, const float *in, const float *out) {
 template <int MT>
 static int pw_launch(int b, int cin, int cout, int P, const float *in, const float *wp, const float *bias,
                      const float *bias_b, const float *in_scale, const float *in_shift, int in_swish, float *out,
-                     float *stats_part, float *minmax, int pool_g, int out_pm, hipStream_t s,
-                     const GnFold &fold = GnFold(), const GnAcc &gacc = GnAcc(), bool split_pack = false) {
-  const bool xf = in_scale != nullptr || fold.group != nullptr, st = stats_part != nullptr || gacc.group != nullptr;
-  if (xf && cin > P2PB_FOLD_MAXC) return P2PB_EINVAL;
-  const bool fx = fold.group != nullptr || gacc.group != nullptr;
+                     float *stats_part, float *minmax, int pool_g, int out_pm, hipStream_t s, bool split_pack = false) {
+  const bool xf = in_scale != nullptr, st = stats_part != nullptr;
   // split_pack: wp is the f16x3 split pack (flags bits 2 + 7): plain statistics form, 16-byte rows, f16x3 selected
-  if (split_pack && (fx || !pw_wide_ok(P, in, out) || p2pb_g_split_terms != SPLIT_F16X3)) return P2PB_EINVAL;
+  if (split_pack && (!pw_wide_ok(P, in, out) || p2pb_g_split_terms != SPLIT_F16X3)) return P2PB_EINVAL;
   if (pw_wide_ok(P, in, out)) {
     dim3 grid((P + 511) / 512, (cout + 32 * MT - 1) / (32 * MT), b);
     const int nslots = (P + 255) / 256 * 4;
-#define LAUNCHX(XF, ST, PL, FXV, TM)                                                                                  \
-  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL, FXV, TM>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P,  \
-                     nslots, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm, \
-                     fold, gacc)
-#define LAUNCH(XF, ST, PL)                                        \
-  do {                                                            \
-    if (split_pack) LAUNCHX(XF, ST, PL, false, SPLIT_F16X3);       \
-    else if (fx) LAUNCHX(XF, ST, PL, true, 0);                     \
-    else LAUNCHX(XF, ST, PL, false, 0);                            \
+#define LAUNCHX(XF, ST, PL, TM)                                                                                       \
+  hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL, TM>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P,       \
+                     nslots, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm)
+#define LAUNCH(XF, ST, PL)                                 \
+  do {                                                     \
+    if (split_pack) LAUNCHX(XF, ST, PL, SPLIT_F16X3);       \
+    else LAUNCHX(XF, ST, PL, 0);                            \
   } while (0)
+    p2pb_note_pointwise_form(cin, cout, split_pack ? P2PB_FORM_PW_WIDE_F16 : P2PB_FORM_PW_WIDE_FP32);
     if (minmax) {
       if (xf) LAUNCH(true, true, true);
       else LAUNCH(false, true, true);
@@ -1134,7 +1088,8 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
 #undef LAUNCHX
     return p2pb_launch_status();
   }
-  if (minmax || out_pm || fold.group || gacc.group) return P2PB_EINVAL;  // (the unaligned fallback: arrays / partials only)
+  if (minmax || out_pm) return P2PB_EINVAL;  // (the unaligned fallback: plain form only)
+  p2pb_note_pointwise_form(cin, cout, P2PB_FORM_PW_FP32);
   dim3 grid((P + 255) / 256, (cout + 32 * MT - 1) / (32 * MT), b);
 #define LAUNCH(XF, ST)                                                                                            \
   hipLaunchKernelGGL((pw_conv_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, in, wp, bias, \
@@ -1151,42 +1106,28 @@ extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, c
                                            const float *bias, const float *bias_b, const float *in_scale,
                                            const float *in_shift, int in_swish, int flags, float *out,
                                            float *stats_part, void *stream) {
-  return p2pb_pointwise_conv_forward_fx(b, cin, cout, npos, in, wp_any, bias, bias_b, nullptr, in_scale, in_shift,
-                                        in_swish, flags, out, stats_part, nullptr, stream);
-}
-
-// in_fold / out_acc: the sampler path's statistics plumbing (include/p2pb_hip.h "GroupNorm statistics without a
-// finishing launch"); 16-byte rows required with either
-extern "C" int p2pb_pointwise_conv_forward_fx(int b, int cin, int cout, int npos, const float *in, const void *wp_any,
-                                              const float *bias, const float *bias_b, const p2pb_gn_fold *in_fold,
-                                              const float *in_scale, const float *in_shift, int in_swish, int flags,
-                                              float *out, float *stats_part, const p2pb_gn_acc *out_acc,
-                                              void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out || !gn_fold_ok(in_fold, cin) || !gn_acc_ok(out_acc, cout))
-    return P2PB_EINVAL;
-  const GnFold fold = gn_fold_arg(in_fold);
-  const GnAcc gacc = gn_acc_arg(out_acc, cout);
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !out) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int out_pm = (flags & 32) != 0;  // point-major output f32[b, npos, cout]
-  if (out_pm && (stats_part || gacc.group)) return P2PB_EINVAL;
+  if (out_pm && stats_part) return P2PB_EINVAL;
   if ((flags & 4) && (flags & 128)) {  // narrow layer on the split pack: the wide tiling with f16x3 products
     const float *wsp = (const float *)wp_any;
     return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                    stats_part, nullptr, 0, out_pm, s, fold, gacc, true)
+                                    stats_part, nullptr, 0, out_pm, s, true)
                      : pw_launch<1>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                    stats_part, nullptr, 0, out_pm, s, fold, gacc, true);
+                                    stats_part, nullptr, 0, out_pm, s, true);
   }
   if (flags & 4) {  // wp is the split pack
     if (!pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           nullptr, 0, out_pm, s, fold, gacc);
+                           nullptr, 0, out_pm, s);
   }
   const float *wp = (const float *)wp_any;
   // 64 output channels per wave (128 measured slower: the accumulators alone would take 256 registers)
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, nullptr, 0, out_pm, s, fold, gacc)
+                                  stats_part, nullptr, 0, out_pm, s)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, nullptr, 0, out_pm, s, fold, gacc);
+                                  stats_part, nullptr, 0, out_pm, s);
 }
 
 // pool_u = neighbourhood size (4, 8, 16, 32 or 64 consecutive positions) or 0 for the global pool
@@ -1208,41 +1149,26 @@ extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int np
                                                 const float *in_scale, const float *in_shift, int in_swish, int flags,
                                                 float *out, float *stats_part, int pool_u, float *minmax,
                                                 void *stream) {
-  return p2pb_pointwise_conv_pool_forward_fx(b, cin, cout, npos, in, wp_any, bias, bias_b, nullptr, in_scale, in_shift,
-                                             in_swish, flags, out, stats_part, nullptr, pool_u, minmax, stream);
-}
-
-extern "C" int p2pb_pointwise_conv_pool_forward_fx(int b, int cin, int cout, int npos, const float *in,
-                                                   const void *wp_any, const float *bias, const float *bias_b,
-                                                   const p2pb_gn_fold *in_fold, const float *in_scale,
-                                                   const float *in_shift, int in_swish, int flags, float *out,
-                                                   float *stats_part, const p2pb_gn_acc *out_acc, int pool_u,
-                                                   float *minmax, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !minmax || !gn_fold_ok(in_fold, cin) ||
-      !gn_acc_ok(out_acc, cout))
-    return P2PB_EINVAL;
-  const GnFold fold = gn_fold_arg(in_fold);
-  const GnAcc gacc = gn_acc_arg(out_acc, cout);
-  if (!stats_part && !gacc.group) return P2PB_EINVAL;
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !minmax || !stats_part) return P2PB_EINVAL;
   if (!p2pb_pointwise_pool_supported(npos, pool_u) || !pw_wide_ok(npos, in, out)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if ((flags & 4) && (flags & 128)) {
     const float *wsp = (const float *)wp_any;
     const int gl = pool_lanes(pool_u);
     return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                    stats_part, minmax, gl, 0, s, fold, gacc, true)
+                                    stats_part, minmax, gl, 0, s, true)
                      : pw_launch<1>(b, cin, cout, npos, in, wsp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                    stats_part, minmax, gl, 0, s, fold, gacc, true);
+                                    stats_part, minmax, gl, 0, s, true);
   }
   if (flags & 4)
     return pw_launch_split(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part,
-                           minmax, pool_u, 0, s, fold, gacc);
+                           minmax, pool_u, 0, s);
   const float *wp = (const float *)wp_any;
   const int g = pool_lanes(pool_u);
   return cout > 32 ? pw_launch<2>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, minmax, g, 0, s, fold, gacc)
+                                  stats_part, minmax, g, 0, s)
                    : pw_launch<1>(b, cin, cout, npos, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out,
-                                  stats_part, minmax, g, 0, s, fold, gacc);
+                                  stats_part, minmax, g, 0, s);
 }
 
 // The last layer of a set abstraction's MLP on the GROUPED tensor without building it (pw_wide_kernel<GATHER>):
@@ -1257,20 +1183,21 @@ extern "C" int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, 
   const long npos = (long)m * u;
   if (b <= 0 || cin <= 0 || cout <= 0 || n <= 0 || m <= 0 || !zt || !idx || !wp_split || !in_scale || !in_shift ||
       !stats_part || !minmax || (cin & 7) || npos > 0x7fffffffL || !p2pb_pointwise_pool_supported((int)npos, u) || u == 0 ||
-      cin > P2PB_FOLD_MAXC || p2pb_g_split_terms != SPLIT_F16X3 || (((uintptr_t)zt | (uintptr_t)cxt) & 15))
+      p2pb_g_split_terms != SPLIT_F16X3 || (((uintptr_t)zt | (uintptr_t)cxt) & 15))
     return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int P = (int)npos, nslots = (P + 255) / 256 * 4, gl = pool_lanes(u);
   const PwGather gat = {cxt, idx, n, u};
   const float *wsp = (const float *)wp_split;
 #define LAUNCHG(MTV)                                                                                                      \
-  hipLaunchKernelGGL((pw_wide_kernel<MTV, true, true, true, false, SPLIT_F16X3, true>),                                   \
+  hipLaunchKernelGGL((pw_wide_kernel<MTV, true, true, true, SPLIT_F16X3, true>),                                   \
                      dim3((P + 511) / 512, (cout + 32 * MTV - 1) / (32 * MTV), b), dim3(256), 0, s, cin, cout,             \
                      pw_cout_pad(cout), P, nslots, zt, wsp, bias, (const float *)nullptr, in_scale, in_shift, in_swish,    \
-                     (float *)nullptr, stats_part, minmax, gl, 0, GnFold(), GnAcc(), gat)
+                     (float *)nullptr, stats_part, minmax, gl, 0, gat)
   if (cout > 32) LAUNCHG(2);
   else LAUNCHG(1);
 #undef LAUNCHG
+  p2pb_note_pointwise_form(cin, cout, P2PB_FORM_PW_GATHER);
   return p2pb_launch_status();
 }
 
@@ -1357,53 +1284,6 @@ extern "C" int p2pb_minmax_act(int b, int c, int m, int nslots, const float *min
   const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(minmax_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, m, nslots, minmax, scale,
                      shift, swish, y, total);
-  return p2pb_launch_status();
-}
-
-// the same with the norm folded here from the producer's accumulators: one (sample, channel) row per workgroup row
-// (neighbour max) or one thread per (sample, channel) (global pool)
-__global__ __launch_bounds__(256) void minmax_act_fold_kernel(int c, int m, int nslots, const float *__restrict__ mm,
-                                                              GnFold fold, int swish, float *__restrict__ y, int bc_n) {
-  int bc;
-  if (nslots == 0) bc = blockIdx.y;
-  else {
-    bc = blockIdx.x * 256 + threadIdx.x;
-    if (bc >= bc_n) return;
-  }
-  const int b = bc / c, ch = bc % c;
-  float sc, sh;
-  gn_fold_channel(fold, b, c, ch, sc, sh);
-  auto act_max = [&](float mn, float mx) {
-    float lo = mn * sc + sh, hi = mx * sc + sh;
-    if (swish) {
-      lo = swishf(lo);
-      hi = swishf(hi);
-    }
-    return fmaxf(lo, hi);
-  };
-  if (nslots == 0) {
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
-      const float2 v = *(const float2 *)(mm + ((size_t)bc * m + j) * 2);
-      y[(size_t)bc * m + j] = act_max(v.x, v.y);
-    }
-  } else {
-    float mn = INFINITY, mx = -INFINITY;
-    for (int sl = 0; sl < nslots; ++sl) {
-      const float2 v = *(const float2 *)(mm + (((size_t)b * nslots + sl) * c + ch) * 2);
-      mn = fminf(mn, v.x);
-      mx = fmaxf(mx, v.y);
-    }
-    y[bc] = act_max(mn, mx);
-  }
-}
-
-extern "C" int p2pb_minmax_act_fx(int b, int c, int m, int nslots, const float *minmax, const p2pb_gn_fold *fold,
-                                  int swish, float *y, void *stream) {
-  if (b <= 0 || c <= 0 || m <= 0 || nslots < 0 || !fold || !fold->group || !gn_fold_ok(fold, c)) return P2PB_EINVAL;
-  // (one fold per wave: a workgroup takes up to 4096 elements of its row)
-  const dim3 grid = nslots == 0 ? dim3(cdiv(m, 4096), b * c) : dim3(cdiv((long)b * c, 256));
-  hipLaunchKernelGGL(minmax_act_fold_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, m, nslots, minmax, *fold, swish,
-                     y, b * c);
   return p2pb_launch_status();
 }
 
@@ -1526,43 +1406,3 @@ extern "C" int p2pb_affine_act_max(int b, int c, int m, int u, const float *x, c
   return p2pb_launch_status();
 }
 
-#ifdef P2PB_EXP_PW_PRE
-// ---- pre-split operand form of the ping-pong GEMM (pw_pingpong.h PRE): the operand transform + split as ONE elementwise
-// pass per layer, the GEMM with both operands by LDS-DMA. Same bits as the staged form.
-extern "C" int p2pb_pointwise_presplit_supported(int cin, int cout, int npos) {
-  return cin > 0 && cin % 64 == 0 && cout > 0 && cout % 256 == 0 && npos > 0 && npos % 256 == 0 && p2pb_g_split_terms == SPLIT_F16X3;
-}
-extern "C" int p2pb_pointwise_presplit(int b, int cin, int npos, const float *x, const float *in_scale, const float *in_shift,
-                                       int in_swish, void *out_split, void *stream) {
-  if (b <= 0 || cin <= 0 || cin % PP_CK != 0 || npos <= 0 || npos % 256 != 0 || !x || !out_split || (in_scale && !in_shift))
-    return P2PB_EINVAL;
-  hipLaunchKernelGGL(pw_presplit_kernel, dim3(npos / 256, cin / PP_CK, b), dim3(256), 0, (hipStream_t)stream, cin, npos, x, in_scale,
-                     in_shift, in_swish, (u32x4 *)out_split);
-  return p2pb_launch_status();
-}
-// x_split from p2pb_pointwise_presplit (b * cin * npos * 4 bytes); wp_split / bias / bias_b / out / stats_part / minmax as
-// p2pb_pointwise_conv_pool_forward (pool_u: 0 = global pooling partials in minmax, or < 0: no pooling output)
-extern "C" int p2pb_pointwise_conv_forward_presplit(int b, int cin, int cout, int npos, const void *x_split, const void *wp_split,
-                                                    const float *bias, const float *bias_b, float *out, float *stats_part,
-                                                    float *minmax, void *stream) {
-  if (b <= 0 || !p2pb_pointwise_presplit_supported(cin, cout, npos) || !x_split || !wp_split) return P2PB_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  dim3 pgrid(npos / 256, cout / 256, b);
-#define LAUNCHPRE(PL)                                                                                                  \
-  do {                                                                                                                 \
-    static bool once = false;                                                                                          \
-    if (!once) {                                                                                                       \
-      (void)hipFuncSetAttribute((const void *)pw_pingpong_kernel<false, PL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                PP_LDS_BYTES);                                                                         \
-      once = true;                                                                                                     \
-    }                                                                                                                  \
-    hipLaunchKernelGGL((pw_pingpong_kernel<false, PL, true>), pgrid, dim3(512), PP_LDS_BYTES, s, cin, cout, npos, npos / 64, \
-                       (const float *)x_split, (const u32x4 *)wp_split, bias, bias_b, (const float *)nullptr,           \
-                       (const float *)nullptr, 0, out, stats_part, minmax, 0);                                          \
-  } while (0)
-  if (minmax) LAUNCHPRE(true);
-  else LAUNCHPRE(false);
-#undef LAUNCHPRE
-  return p2pb_launch_status();
-}
-#endif  // P2PB_EXP_PW_PRE

@@ -146,29 +146,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   auto take_b = [&](int set, float (&r)[8][2]) {
     if (set == 0) { PP_TAKE8(0, r); } else { PP_TAKE8(1, r); }
   };
-#ifdef PP_SAFE
-#define PP_N(n) "0"
-#else
 #define PP_N(n) #n
-#endif
 #define PP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" PP_N(n) ")" ::: "memory")
 // the stage barrier: the DMA of the next stage has landed (vmcnt), this wave's LDS writes and reads are done (lgkmcnt),
 // then a RAW s_barrier -- __syncthreads() carries a vmcnt(0) while an LDS-DMA is in flight, which would drain the
 // two-stage-deep prefetch at every barrier
-#ifdef PP_DBG_SYNC
-#define PP_BARRIER(n) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
-#else
 #define PP_BARRIER(n) asm volatile("s_waitcnt vmcnt(" PP_N(n) ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
-#ifdef PP_DBG_SYNC
-#define PP_BARRIER(n) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
-#else
 #define PP_BARRIER(n) asm volatile("s_waitcnt vmcnt(" PP_N(n) ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
   auto dma_a = [&](int s, int buf) {
-#ifdef PP_EXP_NODMA
-    return;
-#endif
     const int st = s < nstage ? s : nstage - 1;
     const u32x4 *src = wp + ((size_t)st * nblk128 + by * 2) * PWS_TILE;
     u32x4 *dst = pp_lds + buf * PP_TILE;
@@ -182,9 +167,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
     }
   };
   auto stage_b = [&](int s, int buf, int set) {  // braw (raw activations of stage s) -> transformed, split, into buffer buf
-#ifdef PP_EXP_NOSTAGE
-    return;
-#endif
     // Written element-parallel (every step over all 16 values before the next step) so that the sixteen dependent
     // chains fma -> exp -> rcp -> mul -> cvt -> sub -> cvt overlap: issued two at a time (the compiler's choice for the
     // nested form) the phase was latency-bound at ~11 cycles per instruction.
@@ -267,12 +249,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int s = 0; s < 2; ++s) bf[n][s] = lb[((kstep * 2 + s) * 2 + khalf) * 256 + n * 32];
-#ifdef PP_EXP_NOMFMA
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-        acc[0][n][0] += __builtin_bit_cast(float, bf[n][0][0] ^ bf[n][1][1] ^ af[0][0][0] ^ af[1][1][1] ^ af[0][1][2] ^ af[1][0][3]);
-      continue;
-#endif
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -391,19 +367,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
   PP_VMCNT(0);  // nothing of this workgroup may still be on its way into LDS when the waves retire
   PP_TL(tl2);
 
-#ifdef PP_EXP_NOEPI
-  {
-    float t = 0.0f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) t += acc[m][n][r];
-    if (t == 12345.0f) mm_out[tid] = 1.0f;
-    return;
-  }
-#endif
   // ---- epilogue (the arithmetic and the outputs of pws_epilogue; a slot = 64 consecutive positions)
   {
     // bias (+ per-sample bias) of the tile's 256 channels through an LDS table: fetched by 256 lanes at once. Read per row
@@ -506,57 +469,3 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(224))) void 
 #endif
 }
 
-#ifdef P2PB_EXP_PW_PRE  // experiment builds only (tools/build_pw_variant.sh pre "-DP2PB_EXP_PW_PRE"; tools/exp_pw_pre.py): measured
-                       // slower end to end (profiles/r03d_pw_presplit_ab.txt), so not part of the shipped library
-// ---- the operand of the PRE form: x f32[b, cin, P] -> S[b][P / 256][cin / 32][2048] x 16 B, the bytes stage_b() would put
-// into the B tile of (position block, stage): folded norm + Swish (or the plain fp16 scale) and the fp16-pair split, the SAME
-// instruction sequence per element (bit-identical tiles), done once instead of once per 256-channel block of the layer.
-// One workgroup per (position block, stage, sample): thread t owns position t, walks the four 8-channel groups.
-__global__ __launch_bounds__(256) void pw_presplit_kernel(int cin, int P, const float *__restrict__ in,
-                                                          const float *__restrict__ in_scale, const float *__restrict__ in_shift,
-                                                          int in_swish, u32x4 *__restrict__ out) {
-  const int t = threadIdx.x, pb = blockIdx.x, st = blockIdx.y, b = blockIdx.z;
-  const int nstage = cin / PP_CK;
-  const float *x = in + ((size_t)b * cin + (size_t)st * PP_CK) * P + (size_t)pb * 256 + t;
-  u32x4 *o = out + (((size_t)b * gridDim.x + pb) * nstage + st) * PP_TILE;
-#pragma unroll
-  for (int cg = 0; cg < 4; ++cg) {
-    float y[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) y[i] = x[(size_t)(8 * cg + i) * P];
-    if (in_scale) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = st * PP_CK + 8 * cg + i;
-        y[i] = __fmaf_rn(y[i], in_scale[b * cin + c], in_shift[b * cin + c]);
-      }
-      if (in_swish) {
-        float e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_exp2f(y[i] * -1.44269504088896340736f);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = __builtin_amdgcn_rcpf(__fmaf_rn(e[i], 0.25f, 0.25f));
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] *= e[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] *= SPLIT_F16_SX;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) y[i] *= SPLIT_F16_SX;
-    }
-    u32x4 q0, q1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned p0, p1;
-      split2h(y[2 * i], y[2 * i + 1], p0, p1);
-      q0[i] = p0;
-      q1[i] = p1;
-    }
-    const int kstep = cg >> 1, kh = cg & 1;
-    o[((kstep * 2 + 0) * 2 + kh) * 256 + t] = q0;
-    o[((kstep * 2 + 1) * 2 + kh) * 256 + t] = q1;
-  }
-}
-#endif  // P2PB_EXP_PW_PRE

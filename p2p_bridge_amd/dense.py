@@ -158,7 +158,9 @@ class _Conv3dK3(torch.autograd.Function):
         gx = None
         if ctx.needs_input_grad[0]:
             with fused.split_math("bf16x6"):  # gradients have no scale an fp16-pair split could rely on
-                gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True)
+                # force_split: the adjoint pack exists only in the split form (the kernel reads the forward weight transposed
+                # and tap-reflected), so the data gradient runs bf16x6 under P2PB_CONV_MATH=fp32 too
+                gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True, force_split=True)
         return gx, gw, gb, None, None
 
 

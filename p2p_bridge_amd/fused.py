@@ -19,152 +19,6 @@ _i, _f, _d = ctypes.c_int, ctypes.c_float, ctypes.c_double
 F32 = torch.float32
 
 
-# ------------------------------------------------------------------ GroupNorm statistics without a finishing launch
-# (include/p2pb_hip.h "p2pb_gn_acc / p2pb_gn_fold", csrc/common.h). A producer called with acc_groups=G adds its output's
-# {sum, sum of squares} to fixed-point accumulators taken from the evaluation's arena and returns an `Acc`; norm_affine
-# turns that into a `Fold`, which the consumers' in_scale argument accepts in place of the (scale, shift) arrays -- they
-# fold the norm in their prologue. Consumers that only take arrays call Fold.arrays() (one small launch, as before).
-
-
-class _GnAccStruct(ctypes.Structure):
-    _fields_ = [("group", ctypes.c_void_p), ("channel", ctypes.c_void_p), ("groups", ctypes.c_int)]
-
-
-class _GnFoldStruct(ctypes.Structure):
-    _fields_ = [("group", ctypes.c_void_p), ("channel", ctypes.c_void_p), ("gamma", ctypes.c_void_p),
-                ("beta", ctypes.c_void_p), ("style", ctypes.c_void_p), ("style_stride", ctypes.c_int),
-                ("groups", ctypes.c_int), ("eps", ctypes.c_float), ("count", ctypes.c_double)]
-
-
-def _addr(t):
-    return None if t is None else t.data_ptr()
-
-
-class StatsArena:
-    """all accumulators of one network evaluation in one int64 buffer, zeroed by ONE fill at the top of the evaluation
-    (begin). Owned by the network module; grown buffers are kept (a captured graph may still point into an old one)."""
-
-    def __init__(self):
-        self.buf, self.off, self.need, self._kept = None, 0, 0, []
-
-    def begin(self, device):
-        if self.buf is None or self.buf.device != device or self.need > self.buf.numel():
-            if self.buf is not None:
-                self._kept.append(self.buf)
-            self.buf = torch.empty(max(self.need, 1 << 18), dtype=torch.int64, device=device)
-        self.off = self.need = 0
-        self.buf.zero_()
-
-    def take(self, n, device):
-        self.need += n
-        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
-            return torch.zeros(n, dtype=torch.int64, device=device)  # first evaluation of a larger shape: begin() regrows
-        out = self.buf[self.off:self.off + n]
-        self.off += n
-        return out
-
-
-_arena = None  # the evaluation in progress (set by use_arena)
-
-
-class use_arena:
-    def __init__(self, arena):
-        self.arena = arena
-
-    def __enter__(self):
-        global _arena
-        self.prev, _arena = _arena, self.arena
-        return self.arena
-
-    def __exit__(self, *a):
-        global _arena
-        _arena = self.prev
-
-
-GN_ACC_DEFAULT = "0"
-
-
-def gn_acc_enabled(kind=None) -> bool:
-    """which producers add their statistics to accumulators; the others write per-slot partials, finished by one
-    gn_affine launch per layer (the round-2 path). OFF by default -- built, verified and measured in round 2, it does not
-    pay on this chip: the 48 finishing launches of an evaluation cost ~0.2 ms under hipGraph replay (not the 0.6 ms the
-    profiler's per-launch overhead suggested), while the chip retires only ~14 G 64-bit atomics/s (12 ns each on one
-    128-byte line: tools/exp/atomic_contention.hip, profiles/r02_atomic_contention.txt) and the folded prologue + the
-    extra kernel arguments cost the dominant GEMM 5 %. Best measured subset `pws,conv8,conv16` (LDS-tiled GEMM + coarse
-    grids: 27 of 48 launches gone): -2.5 % end to end; all producers (`1`): -5 %.
-    P2PB_GN_ACC: comma list of kinds out of pws, pww, conv8, conv16, conv32, gsub, interp; `1` = all; `0` = none."""
-    v = os.environ.get("P2PB_GN_ACC", GN_ACC_DEFAULT)
-    if v == "0":
-        return False
-    if v == "1" or kind is None:
-        return True
-    return kind in v.split(",")
-
-
-GN_LINE = 16  # int64 per 128-byte line: every word of the group accumulators sits on its own line (csrc/common.h)
-
-
-class Acc:
-    """the accumulators one producer adds to: group i64[b,groups,4,GN_LINE] (word 0 of each line), channel i64[b,c,2] | None"""
-
-    def __init__(self, b, c, groups, want_channel, device):
-        ng = b * groups * 4 * GN_LINE
-        n = ng + (b * c * 2 if want_channel else 0)
-        buf = _arena.take(n, device) if _arena is not None else torch.zeros(n, dtype=torch.int64, device=device)
-        self.b, self.c, self.groups = b, c, groups
-        self.group = buf[:ng]
-        self.channel = buf[ng:] if want_channel else None
-        self.struct = _GnAccStruct(_addr(self.group), _addr(self.channel), groups)
-
-    @property
-    def ref(self):
-        return ctypes.byref(self.struct)
-
-
-class Fold:
-    """GroupNorm (+ AdaGN style) of a tensor whose statistics sit in `acc`, to be folded by the consumer"""
-
-    def __init__(self, acc, gamma, beta, style, eps, count):
-        stride = 0
-        if style is not None:
-            if style.stride(1) != 1 or style.shape[1] != 2 * acc.c:
-                style = style.contiguous()
-            stride = style.stride(0)
-        self.acc, self.gamma, self.beta, self.style = acc, gamma, beta, style  # (keeps the tensors alive)
-        self.b, self.c = acc.b, acc.c
-        self.struct = _GnFoldStruct(_addr(acc.group), _addr(acc.channel), _addr(gamma), _addr(beta), _addr(style), stride,
-                                    acc.groups, float(eps), float(count))
-        self._arrays = None
-
-    @property
-    def ref(self):
-        return ctypes.byref(self.struct)
-
-    def arrays(self, want_mean=False):
-        """scale, shift (, chmean) f32[b,c] through the stand-alone finisher, for consumers that take arrays"""
-        if self._arrays is None or (want_mean and self._arrays[2] is None):
-            dev = self.acc.group.device
-            scale = torch.empty(self.b, self.c, dtype=F32, device=dev)
-            shift = torch.empty_like(scale)
-            chmean = torch.empty_like(scale) if want_mean else None
-            call("p2pb_gn_fold_params", _i(self.b), _i(self.c), self.ref, ptr(scale), ptr(shift), ptr(chmean), stream_ptr())
-            self._arrays = (scale, shift, chmean)
-        return self._arrays if want_mean else self._arrays[:2]
-
-
-def _split_fold(in_scale, in_shift):
-    """consumer argument -> (fold ref | None, scale, shift)"""
-    if isinstance(in_scale, Fold):
-        return in_scale.ref, None, None
-    return None, in_scale, in_shift
-
-
-def _arrays_of(in_scale, in_shift):
-    if isinstance(in_scale, Fold):
-        return in_scale.arrays()
-    return in_scale, in_shift
-
-
 CONV_MATHS = ("f16x3", "bf16x6", "fp32")
 SPLIT_MATHS = ("f16x3", "bf16x6")
 CONV_MATH_DEFAULT = "f16x3"
@@ -281,7 +135,7 @@ def conv_pre_plan(r: int):
     grid (S format, include/p2pb_hip.h: the voxeliser / one elementwise pass apply the operand transform and the
     fp16-pair split ONCE per element, the convolution stages with LDS-DMA alone; bit-identical outputs)?
     P2PB_CONV_PRE="<first>:<second>" lists resolutions, default below; f16x3 arithmetic only."""
-    if conv_math() != "f16x3" or lib().p2pb_get_split_terms() != 16 or gn_acc_enabled():
+    if conv_math() != "f16x3" or lib().p2pb_get_split_terms() != 16:
         return False, False
     spec = os.environ.get("P2PB_CONV_PRE", CONV_PRE_DEFAULT)
     parts = (spec.split(":") + [""])[:2]
@@ -298,15 +152,13 @@ def conv3d_presplit(y, in_scale=None, in_shift=None, swish=False, in_sub=None):
     check(y, F32, "y")
     b, r, c = y.shape[0], y.shape[1], y.shape[4]
     out = torch.empty(b, r, r, r, (c + 15) // 16 * 16, dtype=F32, device=y.device)
-    in_scale, in_shift = _arrays_of(in_scale, in_shift)
     call("p2pb_conv3d_presplit", _i(b), _i(c), ctypes.c_long(r * r * r), ptr(y), ptr(in_scale), ptr(in_shift), _i(int(swish)),
          ptr(in_sub), ptr(out), stream_ptr())
     return out
 
 
 def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
-              skip_zero=False, compact=False, math=None, force_split=False, channels_last=False, acc_groups=None,
-              acc_channel=False, pre=False):
+              skip_zero=False, compact=False, math=None, force_split=False, channels_last=False, pre=False):
     """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None); with
     channels_last the grids are voxel-major, x f32[B,r,r,r,Cin] -> y f32[B,r,r,r,Cout] (the layout of the fused
     voxel branch: contiguous channels for the staging loads, the stores, voxelize and devoxelize).
@@ -320,20 +172,14 @@ def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in
         ci = conv.in_channels
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
-    st = acc = None
-    if not split:
-        in_scale, in_shift = _arrays_of(in_scale, in_shift)  # (the exact-fp32 kernels take arrays / write partials)
-    if stats and split and acc_groups and gn_acc_enabled(f"conv{r}"):
-        acc = Acc(b, co, acc_groups, acc_channel, x.device)
-    elif stats:
+    st = None
+    if stats:
         nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     flags = (1 if skip_zero else 0) | (2 if compact else 0) | (4 if split else 0) | (8 if channels_last else 0) | (16 if pre else 0)
-    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
-    call("p2pb_conv3d_k3_forward_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class), fold,
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st),
-         None if acc is None else acc.ref, stream_ptr())
-    return y, (acc if acc is not None else st)
+    call("p2pb_conv3d_k3_forward_ex", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias), ptr(out_class),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(y), ptr(st), stream_ptr())
+    return y, st
 
 
 def brick_lists(cnt, r):
@@ -349,7 +195,7 @@ def brick_lists(cnt, r):
 
 
 def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                     out_class=None, math=None, channels_last=False, acc_groups=None, acc_channel=False, pre=False):
+                     out_class=None, math=None, channels_last=False, pre=False):
     """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second;
     pre: x is the pre-split operand grid (conv3d_presplit / voxelize_cl_gather(split=True))"""
     check(x, F32, "x")
@@ -361,22 +207,15 @@ def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None
         ci = conv.in_channels
     wt = pack_conv3d_weight(conv, split)
     y = torch.empty((b, r, r, r, co) if channels_last else (b, co, r, r, r), dtype=F32, device=x.device)
-    st = acc = None
-    if not split:
-        in_scale, in_shift = _arrays_of(in_scale, in_shift)
-    if split and acc_groups and gn_acc_enabled(f"conv{r}"):
-        acc = Acc(b, co, acc_groups, acc_channel, x.device)
-    else:
-        nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
-        st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
+    st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     act, ina = lists[2 * which], lists[2 * which + 1]
     ca, ci_ = counts[2 * which:], counts[2 * which + 1:]
     flags = (4 if split else 0) | (8 if channels_last else 0) | (16 if pre else 0)
-    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
-    call("p2pb_conv3d_k3_forward_sparse_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
-         ptr(out_class), fold, ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(act), ptr(ca),
-         ptr(ina), ptr(ci_), ptr(y), ptr(st), None if acc is None else acc.ref, stream_ptr())
-    return y, (acc if acc is not None else st)
+    call("p2pb_conv3d_k3_forward_sparse", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
+         ptr(out_class), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(act), ptr(ca),
+         ptr(ina), ptr(ci_), ptr(y), ptr(st), stream_ptr())
+    return y, st
 
 
 def active_lists(cnt, r):
@@ -392,7 +231,7 @@ def active_lists(cnt, r):
 
 
 def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                      out_class=None, acc_groups=None, acc_channel=False, pre=False):
+                      out_class=None, pre=False):
     """compact sparse conv on voxel-major grids (csrc/conv3d.hip): only the listed outputs of every brick are computed,
     the others get their constant. which = 0: first convolution of a PVConv (set D1); which = 1: second one in
     far-field form (set D2; in_sub / out_class from conv3d_far_field). x f32[B,r,r,r,Cin] -> (y f32[B,r,r,r,Cout], stats)"""
@@ -401,38 +240,32 @@ def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=Non
     co = conv.out_channels
     wt = pack_conv3d_weight(conv, True)
     y = torch.empty(b, r, r, r, co, dtype=F32, device=x.device)
-    st = acc = None
-    if acc_groups and gn_acc_enabled(f"conv{r}"):
-        acc = Acc(b, co, acc_groups, acc_channel, x.device)
-    else:
-        nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
-        st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
+    nfl = lib().p2pb_conv3d_k3_stats_floats(_i(b), _i(co), _i(r))
+    st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     al, ac = lists[which], counts[which]
     if pre:  # x is the pre-split operand grid
-        assert in_scale is None and in_sub is None and acc is None and x.shape[4] == (conv.in_channels + 15) // 16 * 16
+        assert in_scale is None and in_sub is None and x.shape[4] == (conv.in_channels + 15) // 16 * 16
         call("p2pb_conv3d_k3_forward_compact_pre", _i(b), _i(conv.in_channels), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
              ptr(out_class), ptr(al), ptr(ac), ptr(y), ptr(st), stream_ptr())
         return y, st
-    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
-    call("p2pb_conv3d_k3_forward_compact_fx", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
-         ptr(out_class), fold, ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(al), ptr(ac), ptr(y), ptr(st),
-         None if acc is None else acc.ref, stream_ptr())
-    return y, (acc if acc is not None else st)
+    call("p2pb_conv3d_k3_forward_compact", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
+         ptr(out_class), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(al), ptr(ac), ptr(y), ptr(st),
+         stream_ptr())
+    return y, st
 
 
 def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
     """far-field constants for the sparse form of `conv` applied to swish(affine(prev conv output)):
     a f32[B,Cin] (operand value where the previous conv saw only zeros, i.e. where its output == prev_bias) and
     K f32[B,27,Cout] (conv(a)+bias per boundary class)"""
-    b, ci = (in_scale.b, in_scale.c) if isinstance(in_scale, Fold) else in_scale.shape
+    b, ci = in_scale.shape
     co = conv.out_channels
     wt = pack_conv3d_weight(conv)
     dev = prev_bias.device
     a = torch.empty(b, ci, dtype=F32, device=dev)
     k = torch.empty(b, 27, co, dtype=F32, device=dev)
     ws = torch.empty(b, 27, co, dtype=F32, device=dev)
-    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
-    call("p2pb_conv3d_k3_far_field_fx", _i(b), _i(ci), _i(co), ptr(prev_bias), fold, ptr(in_scale), ptr(in_shift),
+    call("p2pb_conv3d_k3_far_field", _i(b), _i(ci), _i(co), ptr(prev_bias), ptr(in_scale), ptr(in_shift),
          _i(int(swish)), ptr(wt), ptr(conv.bias), ptr(a), ptr(k), ptr(ws), stream_ptr())
     return a, k
 
@@ -454,16 +287,6 @@ def gn_affine_params(part, count_per_channel, groups, gamma, beta, style=None, e
     return scale, shift, chmean
 
 
-def se_gate_affine_fold(fold, fc1_weight, fc2_weight):
-    """the same from a Fold whose accumulators include the per-channel sums: the gate kernel folds the norm itself"""
-    dev = fc1_weight.device
-    a = torch.empty(fold.b, fold.c, dtype=F32, device=dev)
-    bb = torch.empty_like(a)
-    call("p2pb_se_gate_affine_fx", _i(fold.b), _i(fold.c), _i(fc1_weight.shape[0]), fold.ref, ptr(fc1_weight),
-         ptr(fc2_weight), ptr(a), ptr(bb), stream_ptr())
-    return a, bb
-
-
 def se_gate_affine(chmean, fc1_weight, fc2_weight, scale, shift):
     """SE3d gate folded into the devoxelisation affine: (scale, shift) * sigmoid(W2 relu(W1 chmean))"""
     b, c = chmean.shape
@@ -480,11 +303,9 @@ def devoxelize_affine(grid, vcoords, r, aff_a, aff_b, channels_last=False, add=N
     b, c = (grid.shape[0], grid.shape[4]) if channels_last else grid.shape[:2]
     n = vcoords.shape[2]
     out = torch.empty(b, c, n, dtype=F32, device=grid.device)
-    aff_a, aff_b = _arrays_of(aff_a, aff_b)
     aff_a, aff_b = aff_a.contiguous(), aff_b.contiguous()  # (named: temporaries inside the argument list could be freed
     if channels_last:                                      #  and their blocks reused before the launch)
         h, hs, hb = add if add is not None else (None, None, None)
-        hs, hb = _arrays_of(hs, hb)
         call("p2pb_trilinear_devoxelize_cl_affine", _i(b), _i(c), _i(n), _i(int(r)), ptr(vcoords), ptr(grid),
              ptr(aff_a), ptr(aff_b), ptr(h), ptr(hs), ptr(hb), ptr(out), stream_ptr())
     else:
@@ -597,16 +418,6 @@ def pool_supported(npos: int, pool_u: int) -> bool:
 
 
 PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/exp_pw.py)
-PW_PRE_MIN_COUT = 1024  # pre-split operand for the wide GEMM from four 256-channel blocks up (pw_conv)
-
-
-def pw_pre_enabled() -> bool:
-    """EXPERIMENT builds only (tools/build_pw_variant.sh pre "-DP2PB_EXP_PW_PRE" + P2PB_LIB_PATH + P2PB_PW_PRE=1): the widest 1x1
-    layers take a pre-split operand (one elementwise pass + the ping-pong GEMM with both operands by LDS-DMA). Not in the
-    shipped library: the GEMM alone runs at 0.46 of the three-product ceiling instead of 0.33 and the pair is 6 % faster than
-    the staged kernel in isolation, but inside the sampler the extra 1.07 GB pass costs what it saves (bench -0.3 .. -0.5 %,
-    profiles/r03d_pw_presplit_ab.txt)"""
-    return os.environ.get("P2PB_PW_PRE", "0") == "1" and hasattr(lib(), "p2pb_pointwise_presplit_supported")
 
 
 def use_wide_f16(ci: int, co: int) -> bool:
@@ -623,7 +434,7 @@ def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
 
 
 def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
-            use_bias=True, pool_u=None, store=True, math=None, point_major=False, acc_groups=None):
+            use_bias=True, pool_u=None, store=True, math=None, point_major=False):
     """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None).
     pool_u (0 = all positions, or the neighbourhood size): also returns the {min, max} tensor minmax_act()
     pools from -> (y | None, stats, minmax); store=False skips writing y altogether.
@@ -637,14 +448,13 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         # elementwise pre-pass (1 read + 1 write of the input) is cheaper than the recomputations. With the
         # XCD-aware workgroup order the blocks of one activation tile run side by side and up to 8 recomputations
         # measure faster than the extra pass (+0.9 % end to end), so the pass starts at 9 blocks (> 1024 channels)
-        x = affine_act(x, *_arrays_of(in_scale, in_shift), swish)
+        x = affine_act(x, in_scale, in_shift, swish)
         in_scale = in_shift = None
         swish = False
     point_major = point_major and not stats and pool_u is None and p % 4 == 0
     # narrow layers in the f16x3 arithmetic: the wide (register-tiled) kernel on the split pack (flags 4 | 128)
     wide_h = (not split and math is None and conv_math() == "f16x3" and lib().p2pb_get_split_terms() == 16 and p % 4 == 0
-              and x.data_ptr() % 16 == 0 and use_wide_f16(ci, co) and not (acc_groups and gn_acc_enabled("pww"))
-              and not isinstance(in_scale, Fold))
+              and x.data_ptr() % 16 == 0 and use_wide_f16(ci, co))
     wp = pack_pointwise_weight(conv, ci_lo, ci_hi, split or wide_h)
     pre = 128 if wide_h else 0
     flags = _i((4 if (split or wide_h) else 0) | (32 if point_major else 0) | pre)
@@ -652,43 +462,21 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         y = torch.empty(b, p, co, dtype=F32, device=x.device)
     else:
         y = torch.empty(b, co, p, dtype=F32, device=x.device) if (store or pool_u is None) else None
-    st = acc = None
-    aligned = p % 4 == 0 and x.data_ptr() % 16 == 0  # (the unaligned fallback kernel takes arrays / writes partials)
-    if not aligned:
-        in_scale, in_shift = _arrays_of(in_scale, in_shift)
-    if (stats or pool_u is not None) and aligned and acc_groups and gn_acc_enabled("pws" if split else "pww"):
-        acc = Acc(b, co, acc_groups, False, x.device)
-    elif stats or pool_u is not None:
+    st = None
+    if stats or pool_u is not None:
         nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     bias = conv.bias if use_bias else None
-    if (split and acc is None and not point_major and pool_u in (None, 0) and in_scale is not None and not isinstance(in_scale, Fold)
-            and math is None and co >= PW_PRE_MIN_COUT and pw_pre_enabled() and lib().p2pb_pointwise_presplit_supported(_i(ci), _i(co), _i(p))):
-        # pre-split operand (csrc/pw_pingpong.h PRE): folded norm + Swish + fp16-pair split ONCE per element in one elementwise
-        # pass, the GEMM with both operands by LDS-DMA -- bit-identical to the staged kernel, which redoes the transform in
-        # every 256-channel block (4 x for the 512 -> 1024 layer) on the same VALU its matrix instructions issue from
-        xs = torch.empty(b * ci * p, dtype=F32, device=x.device)
-        call("p2pb_pointwise_presplit", _i(b), _i(ci), _i(p), ptr(x), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(xs),
-             stream_ptr())
-        mm = None
-        if pool_u is not None:
-            nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(0), flags)
-            mm = torch.empty(b, nmm // (b * co * 2), co, 2, dtype=F32, device=x.device)
-        call("p2pb_pointwise_conv_forward_presplit", _i(b), _i(ci), _i(co), _i(p), ptr(xs), ptr(wp), ptr(bias), ptr(bias_b), ptr(y),
-             ptr(st), ptr(mm), stream_ptr())
-        return (y, st) if pool_u is None else (y, st, mm)
-    fold, in_scale, in_shift = _split_fold(in_scale, in_shift)
-    aref = None if acc is None else acc.ref
     if pool_u is None:
-        call("p2pb_pointwise_conv_forward_fx", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b), fold,
-             ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), aref, stream_ptr())
-        return y, (acc if acc is not None else st)
+        call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
+             ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), stream_ptr())
+        return y, st
     nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(pool_u), flags)
     mm = torch.empty((b, nmm // (b * co * 2), co, 2) if pool_u == 0 else (b, co, p // pool_u, 2), dtype=F32,
                      device=x.device)
-    call("p2pb_pointwise_conv_pool_forward_fx", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b), fold,
-         ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), aref, _i(pool_u), ptr(mm), stream_ptr())
-    return y, (acc if acc is not None else st), mm
+    call("p2pb_pointwise_conv_pool_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
+         ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), _i(pool_u), ptr(mm), stream_ptr())
+    return y, st, mm
 
 
 def minmax_act(mm, scale, shift, swish=True, global_pool=False):
@@ -702,18 +490,15 @@ def minmax_act(mm, scale, shift, swish=True, global_pool=False):
         b, c, m, _ = mm.shape
         nslots = 0
         y = torch.empty(b, c, m, dtype=F32, device=mm.device)
-    if isinstance(scale, Fold):
-        call("p2pb_minmax_act_fx", _i(b), _i(c), _i(m), _i(nslots), ptr(mm), scale.ref, _i(int(swish)), ptr(y), stream_ptr())
-    else:
-        call("p2pb_minmax_act", _i(b), _i(c), _i(m), _i(nslots), ptr(mm), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
-             stream_ptr())
+    call("p2pb_minmax_act", _i(b), _i(c), _i(m), _i(nslots), ptr(mm), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
+         stream_ptr())
     return y
 
 
 def gather_pool_supported(ci: int, co: int, m: int, u: int) -> bool:
     """can pw_conv_pool_gather run the last set-abstraction layer ci -> co over (m centres x u neighbours) on the gathered
     operand? (the narrow-layer f16x3 kernel: not the LDS-tiled GEMM's shapes; 32-byte row pieces; a supported pool)"""
-    return (conv_math() == "f16x3" and lib().p2pb_get_split_terms() == 16 and not gn_acc_enabled() and ci % 8 == 0
+    return (conv_math() == "f16x3" and lib().p2pb_get_split_terms() == 16 and ci % 8 == 0
             and not use_split_pw(ci, co, m * u) and use_wide_f16(ci, co) and pool_supported(m * u, u) and u > 0
             and os.environ.get("P2PB_SA_GATHER", "1") != "0")
 
@@ -729,7 +514,6 @@ def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True):
     co = conv.weight.shape[0]
     p = m * u
     wp = pack_pointwise_weight(conv, 0, None, True)
-    in_scale, in_shift = _arrays_of(in_scale, in_shift)
     nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
     st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=zt.device)
     mm = torch.empty(b, co, m, 2, dtype=F32, device=zt.device)
@@ -738,7 +522,7 @@ def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True):
     return st, mm
 
 
-def group_sub(z, cx, idx, point_major=False, acc_groups=None, stats_only=False):
+def group_sub(z, cx, idx, point_major=False, stats_only=False):
     """z f32[B,C,N], cx f32[B,C,M] | None, idx i32[B,M,U] -> (y f32[B,C,M*U] = z[:, :, idx] - cx[:, :, :, None],
     GroupNorm partials f32[B,nslots,C,2]): the grouped output of a set abstraction's first layer when that layer
     was applied to the ungrouped points (csrc/neighbors.hip group_sub_kernel). point_major: z f32[B,N,C] and
@@ -751,19 +535,15 @@ def group_sub(z, cx, idx, point_major=False, acc_groups=None, stats_only=False):
     m, u = idx.shape[1], idx.shape[2]
     # stats_only: only the GroupNorm partials of the grouped tensor (the consumer gathers it itself: pw_conv_pool_gather)
     y = None if stats_only else torch.empty(b, c, m * u, dtype=F32, device=z.device)
-    st = acc = None
-    if acc_groups and gn_acc_enabled("gsub"):
-        acc = Acc(b, c, acc_groups, False, z.device)
-    else:
-        nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
-        st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
+    nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
+    st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
     ws = None if point_major else torch.empty(b * (n + m) * c, dtype=F32, device=z.device)
-    call("p2pb_group_sub_fx", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st),
-         None if acc is None else acc.ref, ptr(ws), stream_ptr())
-    return y, (acc if acc is not None else st)
+    call("p2pb_group_sub", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(y), ptr(st), ptr(ws),
+         stream_ptr())
+    return y, st
 
 
-def interp_add(cz, idx, w, add=None, bias=None, point_major=False, acc_groups=None):
+def interp_add(cz, idx, w, add=None, bias=None, point_major=False):
     """cz f32[B,C,M] (point_major: f32[B,M,C]), idx i32[B,3,N], w f32[B,3,N], add f32[B,C,N] | None, bias f32[C] | None
     -> (y f32[B,C,N] = sum_k w_k cz[:, :, idx_k] + add (+ bias), GroupNorm partials f32[B,nslots,C,2])"""
     check(cz, F32, "cz")
@@ -773,22 +553,17 @@ def interp_add(cz, idx, w, add=None, bias=None, point_major=False, acc_groups=No
         b, c, m = cz.shape
     n = idx.shape[2]
     y = torch.empty(b, c, n, dtype=F32, device=cz.device)
-    st = acc = None
-    if acc_groups and gn_acc_enabled("interp"):
-        acc = Acc(b, c, acc_groups, False, cz.device)
-    else:
-        nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(n), _i(1))
-        st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=cz.device)
+    nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(n), _i(1))
+    st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=cz.device)
     ws = None if point_major else torch.empty(b * m * c, dtype=F32, device=cz.device)
-    call("p2pb_three_interpolate_add_fx", _i(b), _i(c), _i(m), _i(n), ptr(cz), ptr(idx), ptr(w), ptr(add), ptr(bias),
-         ptr(y), ptr(st), None if acc is None else acc.ref, ptr(ws), stream_ptr())
-    return y, (acc if acc is not None else st)
+    call("p2pb_three_interpolate_add", _i(b), _i(c), _i(m), _i(n), ptr(cz), ptr(idx), ptr(w), ptr(add), ptr(bias),
+         ptr(y), ptr(st), ptr(ws), stream_ptr())
+    return y, st
 
 
 def affine_act(x, scale, shift, swish=True, residual=None):
     """swish(x*scale[b,c]+shift[b,c]) (+ residual), x f32[B,C,P]"""
     b, c, p = x.shape
-    scale, shift = _arrays_of(scale, shift)
     y = torch.empty_like(x)
     if residual is not None:
         residual = residual.contiguous()
@@ -801,7 +576,6 @@ def affine_act_max(x, scale, shift, m, u, swish=True):
     """max over the last (neighbour) axis of swish(x*scale+shift): x f32[B,C,m*u] -> f32[B,C,m];
     u == 0: max over the whole row -> f32[B,C]"""
     b, c = x.shape[:2]
-    scale, shift = _arrays_of(scale, shift)
     y = torch.empty((b, c, m) if u else (b, c), dtype=F32, device=x.device)
     call("p2pb_affine_act_max", _i(b), _i(c), _i(m), _i(u), ptr(x), ptr(scale), ptr(shift), _i(int(swish)), ptr(y),
          stream_ptr())
@@ -834,7 +608,7 @@ class operand_audit:
                 for n, v in zip(names[kind], a):
                     if n:
                         kw[n] = v
-                sc, sh = _arrays_of(kw.get("in_scale"), kw.get("in_shift"))
+                sc, sh = kw.get("in_scale"), kw.get("in_shift")
                 cl = kw.get("channels_last", kind == "conv3d_k3_compact")
                 v = x
                 if sc is not None:

@@ -397,11 +397,16 @@ class P2PB(nn.Module):
 
     def _sampler_chains(self, xt) -> int:
         """how many independent sub-batches the graph sampler runs side by side (`self.sample_chains` / P2PB_SAMPLE_CHAINS;
-        default 1). Built for the large clouds of BASELINE configs 4-5 (50000 points), which spend half of an evaluation in
+        default "auto": TWO chains for an even batch of >= 16 clouds of <= 16384 points or >= 32 larger clouds, one otherwise).
+        A chain evaluates HALF the batch, and the GEMM dispatch is keyed on the batch a launch sees (csrc/pointwise.hip: the
+        256-channel / ping-pong forms need >= 1024 workgroups), so a two-chain run is the same arithmetic per sample only up to
+        the kernel form -- results agree with the one-chain run to fp32 rounding (1e-6 level), not bit for bit
+        (tests/test_full_size_parity_gpu.py::test_c2_bench_dispatch_*: both against the oracle). Each chain owns a captured
+        graph and its static buffers. Built for the large clouds of BASELINE configs 4-5 (50000 points), which spend half of an evaluation in
         the level-0 farthest-point sampling -- a 12500-round dependent chain on ONE workgroup per cloud -- while the dense
         layers behind it wait: samples are independent, so the batch is cut into chains that each replay
         their own captured step on their own stream, started a fraction of a step apart, and one chain's FPS runs under
-        the other chains' dense layers. Same arithmetic per sample, same results. MEASURED: at B = 4 / 8 / 16 no gain
+        the other chains' dense layers. MEASURED: at B = 4 / 8 / 16 no gain
         (profiles/r03b_pvdl_chains.txt: what follows the FPS is a chain of ~300 dependent launches whose length does not
         shrink with the sub-batch; 4 chains 1.5-1.9 x slower). The FPS latency is hidden by BATCH: this part holds 128 clouds
         of 50000 points in 35 GiB of its 288 GB (profiles/r03d_pvdl_large_batches.txt: 420 k points/s at B = 16, 580 k at

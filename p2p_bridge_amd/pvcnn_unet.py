@@ -249,17 +249,9 @@ def _group_norm_of(norm):
     return norm.norm if isinstance(norm, AdaGN) else (norm.group_norm if isinstance(norm, MyGroupNorm) else norm)
 
 
-def norm_groups(norm) -> int:
-    """group count of an AdaGN / GroupNorm / MyGroupNorm: what a producing kernel needs to accumulate its output's
-    statistics for that norm (fused.Acc)"""
-    return _group_norm_of(norm).num_groups
-
-
 def norm_affine(norm, part, count, cond, want_mean=False):
     """AdaGN / GroupNorm / MyGroupNorm folded to per-(sample, channel) (scale, shift[, channel mean]) from the
-    producing kernel's statistics: {sum, sumsq} partials -> arrays through fused.gn_affine_params (one launch), or
-    accumulators (fused.Acc) -> (fused.Fold, None[, None]): the consumers' in_scale argument takes the Fold and folds
-    the norm in its own prologue -- no launch here"""
+    producing kernel's statistics: {sum, sumsq} partials -> arrays through fused.gn_affine_params (one launch)"""
     from . import fused
 
     style = None
@@ -268,9 +260,6 @@ def norm_affine(norm, part, count, cond, want_mean=False):
             raise RuntimeError("AdaGN needs the global embedding")
         style = cond.style(norm) if isinstance(cond, _Styles) else norm.emd(cond)
     gn = _group_norm_of(norm)
-    if isinstance(part, fused.Acc):
-        fold = fused.Fold(part, gn.weight, gn.bias, style, gn.eps, count)
-        return (fold, None, None) if want_mean else (fold, None)
     out = fused.gn_affine_params(part, count, gn.num_groups, gn.weight, gn.bias, style, gn.eps, want_mean)
     return out if want_mean else out[:2]
 
@@ -333,13 +322,11 @@ class SharedMLP(nn.Module):
         pool = reduce_max and fused.pool_supported(P, shape[-1])
         for i in range(1 if first is not None else 0, nl):
             conv, norm = self.layers[3 * i], self.layers[3 * i + 1]
-            ng = norm_groups(norm)
             if pool and i == nl - 1:
-                _, st, mm = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, pool_u=shape[-1], store=False,
-                                          acc_groups=ng)
+                _, st, mm = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, pool_u=shape[-1], store=False)
                 sc, sh = norm_affine(norm, st, P, cond)
                 return fused.minmax_act(mm, sc, sh).view(B, conv.weight.shape[0], *shape[2:-1])
-            h, st = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, acc_groups=ng)
+            h, st = fused.pw_conv(h, conv, sc, sh, swish=sc is not None)
             sc, sh = norm_affine(norm, st, P, cond)
         C = h.shape[1]
         if reduce_max:
@@ -411,7 +398,6 @@ class PVConv(nn.Module):
                                           self.voxelization.eps)
             v, cnt = fused.voxelize_cl(features.contiguous(), vox, r)
         r3 = float(r ** 3)
-        g1, g2 = norm_groups(vl[1]), norm_groups(vl[5])  # the statistics each convolution accumulates for its norm
         c1, c2 = compact_plan()
         if self.sparse_conv and (r in c1 or r in c2):
             # voxel-level sparsity: only the outputs within one (first conv) / two (second conv, far-field form) voxels
@@ -419,51 +405,43 @@ class PVConv(nn.Module):
             if lists is None:
                 lists, counts = fused.active_lists(cnt, r)
             if r in c1:
-                y1, st1 = fused.conv3d_k3_compact(v, vl[0], lists, counts, 0, acc_groups=g1, pre=pre1)
+                y1, st1 = fused.conv3d_k3_compact(v, vl[0], lists, counts, 0, pre=pre1)
             else:
-                y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, acc_groups=g1, pre=pre1)
+                y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
             if r in c2:
                 a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
                 if pre2:
                     y2, st2 = fused.conv3d_k3_compact(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
-                                                      out_class=k, acc_groups=g2, acc_channel=True, pre=True)
+                                                      out_class=k, pre=True)
                 else:
-                    y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
-                                                      acc_groups=g2, acc_channel=True)
+                    y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k)
             elif pre2:
-                y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True,
-                                          acc_groups=g2, acc_channel=True, pre=True)
+                y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True, pre=True)
             else:
-                y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True,
-                                          acc_groups=g2, acc_channel=True)
+                y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True)
         elif r >= 32 and self.sparse_conv:  # at r = 16 every 4x8x8 brick touches the surface: dense is faster
             if lists is None:
                 lists, counts = fused.brick_lists(cnt, r)
-            y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0, channels_last=True, acc_groups=g1, pre=pre1)
+            y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0, channels_last=True, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
             a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
             if pre2:
                 y2, st2 = fused.conv3d_k3_sparse(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
-                                                 out_class=k, channels_last=True, acc_groups=g2, acc_channel=True, pre=True)
+                                                 out_class=k, channels_last=True, pre=True)
             else:
                 y2, st2 = fused.conv3d_k3_sparse(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
-                                                 channels_last=True, acc_groups=g2, acc_channel=True)
+                                                 channels_last=True)
         else:
-            y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, acc_groups=g1, pre=pre1)
+            y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
             if pre2:
-                y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True,
-                                          acc_groups=g2, acc_channel=True, pre=True)
+                y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True, pre=True)
             else:
-                y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True,
-                                          acc_groups=g2, acc_channel=True)
+                y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True)
         se = vl[6] if len(vl) > 6 else None
         sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
-        if isinstance(sc2, fused.Fold):  # accumulators: the gate kernel folds the norm itself
-            if se is not None:
-                sc2, sh2 = fused.se_gate_affine_fold(sc2, se.fc[0].weight, se.fc[2].weight)
-        elif se is not None:
+        if se is not None:
             sc2, sh2 = fused.se_gate_affine(mean2, se.fc[0].weight, se.fc[2].weight, sc2, sh2)
         # point = (h, scale, shift): the point branch's raw conv output and folded norm; its Swish and the sum of
         # the two branches happen in the devoxelisation pass
@@ -478,7 +456,7 @@ class PVConv(nn.Module):
                 from . import fused as F_
 
                 feats = features.contiguous()
-                h, st = F_.pw_conv(feats, pf[0], acc_groups=norm_groups(pf[1]))
+                h, st = F_.pw_conv(feats, pf[0])
                 scp, shp = norm_affine(pf[1], st, feats.shape[2], cond)
                 data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, scp, shp), geo=data.geo)
                 if self.attn is not None:
@@ -575,7 +553,7 @@ class PointNetSAModule(nn.Module):
                     sc2, sh2 = norm_affine(mlp.layers[4], st2, M * U, data.cond)
                     data.features = fused.minmax_act(mm, sc2, sh2)
                 else:
-                    y, st = fused.group_sub(z, cx, nidx, point_major=pm, acc_groups=norm_groups(mlp.layers[1]))
+                    y, st = fused.group_sub(z, cx, nidx, point_major=pm)
                     data.features = mlp._run_fused(y.view(y.shape[0], y.shape[1], M, U), data.cond, True, None, first=st)
             else:
                 grouped = L._ext.group_concat(coords.contiguous(), centers, data.features.contiguous(), nidx)
@@ -615,10 +593,9 @@ class PointNetFPModule(nn.Module):
                 skip = data.features
                 if skip is not None:
                     ys, _ = fused.pw_conv(skip.contiguous(), conv0, stats=False, ci_lo=cg, ci_hi=cg + skip.shape[1])
-                    y, st = fused.interp_add(cz, idx, w, add=ys, point_major=pm, acc_groups=norm_groups(self.mlp.layers[1]))
+                    y, st = fused.interp_add(cz, idx, w, add=ys, point_major=pm)
                 else:
-                    y, st = fused.interp_add(cz, idx, w, bias=conv0.bias, point_major=pm,
-                                             acc_groups=norm_groups(self.mlp.layers[1]))
+                    y, st = fused.interp_add(cz, idx, w, bias=conv0.bias, point_major=pm)
                 if data.time_emb is not None:
                     data.time_emb = data.time_emb[:, :, 0:1].expand(-1, -1, data.coords.shape[-1])
                 data.features = self.mlp._run_fused(y, data.cond, False, None, first=st)
@@ -711,28 +688,27 @@ class Pnet2Stage(nn.Module):
         N = coords.shape[2]
         a0, a1 = self.mlp1.shared_mlp_0.mlp, self.mlp1.shared_mlp_1.mlp
         b0, b1 = self.mlp2.shared_mlp_0.mlp, self.mlp2.shared_mlp_1.mlp
-        ng = norm_groups
-        h, st = fused.pw_conv(coords.contiguous(), a0[0], acc_groups=ng(a0[1]))
+        h, st = fused.pw_conv(coords.contiguous(), a0[0])
         sc, sh = norm_affine(a0[1], st, N, None)
         pool = fused.pool_supported(N, 0)  # the max-pools ride in the GEMM epilogues as {min, max} partials
         if pool:
-            h, st, mm = fused.pw_conv(h, a1[0], sc, sh, swish=True, pool_u=0, acc_groups=ng(a1[1]))
+            h, st, mm = fused.pw_conv(h, a1[0], sc, sh, swish=True, pool_u=0)
             sc, sh = norm_affine(a1[1], st, N, None)
             g = fused.minmax_act(mm, sc, sh, global_pool=True)
         else:
-            h, st = fused.pw_conv(h, a1[0], sc, sh, swish=True, acc_groups=ng(a1[1]))
+            h, st = fused.pw_conv(h, a1[0], sc, sh, swish=True)
             sc, sh = norm_affine(a1[1], st, N, None)
             g = fused.affine_act_max(h, sc, sh, N, 0)
         c1 = h.shape[1]
         w = b0[0].weight.reshape(b0[0].out_channels, -1)
         bias_b = (g @ w[:, c1:].t()).contiguous()
-        h, st = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1, acc_groups=ng(b0[1]))
+        h, st = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1)
         sc, sh = norm_affine(b0[1], st, N, None)
         if pool:  # the 1024-channel output is never written: only its statistics and extrema are needed
-            _, st, mm = fused.pw_conv(h, b1[0], sc, sh, swish=True, pool_u=0, store=False, acc_groups=ng(b1[1]))
+            _, st, mm = fused.pw_conv(h, b1[0], sc, sh, swish=True, pool_u=0, store=False)
             sc, sh = norm_affine(b1[1], st, N, None)
             return fused.minmax_act(mm, sc, sh, global_pool=True)
-        h, st = fused.pw_conv(h, b1[0], sc, sh, swish=True, acc_groups=ng(b1[1]))
+        h, st = fused.pw_conv(h, b1[0], sc, sh, swish=True)
         sc, sh = norm_affine(b1[1], st, N, None)
         return fused.affine_act_max(h, sc, sh, N, 0)
 
@@ -950,7 +926,6 @@ class PVCNN2Unet(nn.Module):
         self.plan["voxel"] = sorted({(m.level, m.resolution, bool(m.voxelization.normalize), float(m.voxelization.eps))
                                      for m in self.modules() if isinstance(m, PVConv)})
         self._side_streams = {}
-        self._stats_arenas = {}  # per device: fused.StatsArena (GroupNorm accumulators of one evaluation)
         out_mlp = _get(pvd, "out_mlp", 128)
         self.classifier = nn.ModuleList([SharedMLP(plan["out"], out_mlp, cond_dim=0), nn.Dropout(dropout),
                                          nn.Conv1d(out_mlp, out_dim, 1)])
@@ -973,19 +948,6 @@ class PVCNN2Unet(nn.Module):
         return e
 
     def forward(self, x, t, x_cond=None):
-        from . import fused
-
-        if fused.enabled(self, x) and fused.gn_acc_enabled():
-            # inference: every GroupNorm's statistics of this evaluation accumulate in one arena, zeroed by one fill
-            arena = self._stats_arenas.get(x.device)
-            if arena is None:
-                arena = self._stats_arenas[x.device] = fused.StatsArena()
-            arena.begin(x.device)
-            with fused.use_arena(arena):
-                return self._forward_impl(x, t, x_cond)
-        return self._forward_impl(x, t, x_cond)
-
-    def _forward_impl(self, x, t, x_cond=None):
         if x_cond is not None:
             x = torch.cat([x, x_cond], dim=1)
         B, C, N = x.shape
@@ -1006,7 +968,7 @@ class PVCNN2Unet(nn.Module):
         if self.embed_feats is not None:
             src = coords if self.extra_feature_channels == 0 else feats
             if use_fused:
-                h, st = fused.pw_conv(src, self.embed_feats[0], acc_groups=norm_groups(self.embed_feats[1]))
+                h, st = fused.pw_conv(src, self.embed_feats[0])
                 sc, sh = norm_affine(self.embed_feats[1], st, N, None)
                 feats, _ = fused.pw_conv(h, self.embed_feats[3], sc, sh, swish=True, stats=False)
             else:
@@ -1047,7 +1009,7 @@ class PVCNN2Unet(nn.Module):
 
         if use_fused:  # classifier: SharedMLP(GroupNorm) -> Dropout(eval: identity) -> Conv1d, two fused GEMMs
             c0 = self.classifier[0]
-            h, st = fused.pw_conv(data.features.contiguous(), c0.layers[0], acc_groups=norm_groups(c0.layers[1]))
+            h, st = fused.pw_conv(data.features.contiguous(), c0.layers[0])
             sc, sh = norm_affine(c0.layers[1], st, h.shape[2], None)
             return fused.pw_conv(h, self.classifier[2], sc, sh, swish=True, stats=False)[0]
         from . import dense

@@ -352,7 +352,9 @@ class GraphedStep:
                                steps=steps.to(x_gt.device))
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            # thread_local: with a live RCCL process group the watchdog thread polls its events during the capture; calls from
+            # OTHER threads must not invalidate it (P2PB._graph_runner does the same)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.static["loss"] = self._step(self.static["x_gt"], self.static["x_start"], self.static["x_cond"],
                                                  self.static["steps"])
         st = self.static
@@ -385,10 +387,17 @@ def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, 
     graph: the step as one captured hipGraph (GraphedStep; accumulation_steps 1; with distributed=True the network must NOT
     be DDP-wrapped: the gradients are averaged in buckets after the replay)."""
     tr = _get(cfg, "training")
-    graph = bool(graph) and int(_get(tr, "accumulation_steps", 1)) == 1 and model.device.type == "cuda"
+    if graph and (int(_get(tr, "accumulation_steps", 1)) != 1 or model.device.type != "cuda"):
+        # (no silent fall-back to the eager step: the caller has left the network unwrapped for the captured step, and an
+        #  eager step on an unwrapped network would train every rank on its own shard with no gradient averaging)
+        raise ValueError("train(graph=True) needs training.accumulation_steps == 1 and a model on a HIP device")
+    graph = bool(graph)
     if graph and distributed and hasattr(model.model, "module"):
         raise ValueError("train(graph=True, distributed=True) takes the network unwrapped: GraphedStep averages the gradients itself")
-    optimizer, sched = load_optim_sched(cfg, model, ckpt, restart, fused=True if graph else None, skip_nonfinite=graph)
+    # skip_nonfinite whenever the fused optimiser runs: an f16x3 range overflow (|activation| >= 16380, csrc/common.h split2h)
+    # makes one step's gradients non-finite; the step is skipped on the device (what GradScaler's skip does), instead of a
+    # NaN clip coefficient poisoning every parameter and Adam moment for good
+    optimizer, sched = load_optim_sched(cfg, model, ckpt, restart, fused=True if graph else None, skip_nonfinite=True)
     if ckpt is not None and not restart and "step" in ckpt:
         start_step = int(ckpt["step"]) + 1
     align_fn = make_align_fn() if (align and _get(_get(cfg, "data"), "dataset") == "PUNet") else None

@@ -69,6 +69,31 @@ def test_pointwise_forward_backward(b, ci, co, shape, math, monkeypatch):
     assert _rel(conv.bias.grad, b64.grad) < 5e-6
 
 
+@pytest.mark.parametrize("conv_math", ["fp32", "bf16x6", "f16x3"])
+def test_conv3d_backward_under_every_conv_math(conv_math):
+    """the data-gradient pass reads the forward weight through the ADJOINT pack, which exists only in the split
+    form -- under P2PB_CONV_MATH=fp32 the backward used to raise. Forward + both gradients vs fp64 under each arithmetic."""
+    from p2p_bridge_amd import dense, fused
+
+    prev = fused.set_conv_math(conv_math)
+    try:
+        torch.manual_seed(5)
+        conv = nn.Conv3d(64, 32, 3, padding=1).cuda()
+        x = torch.randn(2, 64, 16, 16, 16, device="cuda", requires_grad=True)
+        gy = torch.randn(2, 32, 16, 16, 16, device="cuda")
+        y = dense.conv3d_k3(x, conv)
+        y.backward(gy)
+    finally:
+        fused.set_conv_math(prev)
+    x64 = x.detach().double().cpu().requires_grad_(True)
+    w64 = conv.weight.detach().double().cpu().requires_grad_(True)
+    y64 = F.conv3d(x64, w64, conv.bias.detach().double().cpu(), padding=1)
+    y64.backward(gy.double().cpu())
+    assert _rel(y.detach(), y64.detach()) < 5e-6
+    assert _rel(x.grad, x64.grad) < 5e-6
+    assert _rel(conv.weight.grad, w64.grad) < 1e-4
+
+
 def test_no_bias_and_no_input_grad():
     from p2p_bridge_amd import dense
 
