@@ -97,17 +97,13 @@ def conv_roofline(model, x_start, reps=10):
     listed = int(counts[which].sum().item())
     flops = 2.0 * 27 * conv.in_channels * conv.out_channels * listed
     dense = 2.0 * 27 * conv.in_channels * conv.out_channels * B * r ** 3
-    arena = fused.StatsArena()  # the launch adds its statistics to accumulators, as inside an evaluation
-    arena.begin(x.device)
-    with torch.no_grad(), fused.use_arena(arena):
+    with torch.no_grad():
         for _ in range(3):
-            arena.off = 0
             orig(*args, **kw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            arena.off = 0
             orig(*args, **kw)
         e1.record()
         torch.cuda.synchronize()

@@ -437,7 +437,7 @@ def test_c2_t30_gate_on_a_briefly_trained_denoiser():
     torch.manual_seed(0)
     trainee = product.P2PB(tcfg, PVCNN2Unet(tcfg))
     batches = T.synthetic_punet_batches(8, 2048, seed=77, device=trainee.device)
-    hist = T.train(tcfg, trainee, batches, 300, align=False, graph=True)
+    hist = T.train(tcfg, trainee, batches, 300, align=True, graph=True)
     torch.cuda.synchronize()
     assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
     sd = {k: v.detach().cpu().clone() for k, v in trainee.model.state_dict().items()}

@@ -46,10 +46,8 @@ for k, o in origs.items():
 SPLIT_PEAK_TFLOPS = split_peak_tflops()
 print(f"# voxel convolutions of one evaluation, B = {B}, {N} points; peak = {SPLIT_PEAK_TFLOPS:.1f} TFLOP/s ({fused.conv_math()})")
 print("layer,form,r,cin,cout,operand,ms,work_fraction,TFLOPs_dense_equivalent,TFLOPs_on_work,frac_of_peak_on_work")
-arena = fused.StatsArena()
-arena.begin(x_start.device)
 total = 0.0
-with torch.no_grad(), fused.use_arena(arena):
+with torch.no_grad():
     for kind, orig, a, k in calls:
         if kind == "conv3d_presplit":  # the elementwise pass that writes a second convolution's operand pre-split
             for _ in range(2):
@@ -83,13 +81,11 @@ with torch.no_grad(), fused.use_arena(arena):
         pre = bool(k.get("pre"))
         xf = len(a) > 5 and a[5] is not None or k.get("in_scale") is not None or (kind == "conv3d_k3" and len(a) > 2 and a[2] is not None)
         for _ in range(2):
-            arena.off = 0
             orig(*a, **k)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10):
-            arena.off = 0
             orig(*a, **k)
         e1.record()
         torch.cuda.synchronize()

@@ -33,7 +33,7 @@ for gain in (1.0, 4.0):
             for n, v in zip(names, a):
                 if n:
                     kw[n] = v
-            sc, sh = fused._arrays_of(kw.get("in_scale"), kw.get("in_shift"))
+            sc, sh = kw.get("in_scale"), kw.get("in_shift")
             cl = kw.get("channels_last", kind == "conv3d_k3_compact")
             v = x
             if sc is not None:
