@@ -51,11 +51,11 @@ int p2pb_set_split_terms(int terms);
  * threads' launches and weight packs do not see; p2pb_get_split_terms returns what a launch from this thread would use */
 int p2pb_set_split_terms_thread(int terms);
 int p2pb_get_split_terms(void);
-/* Test / debug hook: the kernel form the most recent p2pb_pointwise_conv* launch with these (cin, cout) took
+/* Test / debug hook: the kernel form the most recent p2pb_pointwise_conv* launch with these (cin, cout, npos) took
  * (0 exact-fp32 unaligned, 1 wide exact-fp32, 2 wide f16x3, 3 split 128-channel, 4 split 256-channel, 5 ping-pong,
  * 6 gathered wide f16x3), or -1 if none; *launches (may be NULL) = how many such launches since the last reset.
  * cin < 0 resets the table. Host-side bookkeeping only (under hipGraph capture: recorded at capture time). */
-int p2pb_debug_pointwise_form(int cin, int cout, unsigned long long *launches);
+int p2pb_debug_pointwise_form(int cin, int cout, int npos, unsigned long long *launches);
 
 /* Voxelization.forward normalisation (models/pvcnn.py:215-228): centre on the mean, divide by
  * 2*max-norm (+eps), +0.5, *r, clamp [0,r-1]; also the half-to-even rounded int voxel coords.

@@ -24,29 +24,29 @@ extern "C" int p2pb_set_split_terms_thread(int terms) {  // 0 clears the calling
 }
 extern "C" int p2pb_get_split_terms(void) { return p2pb_split_terms_now(); }  // what a launch from THIS thread would use
 
-// which form a pointwise launch took, per (cin, cout): a small host-side table behind p2pb_debug_pointwise_form (tests assert
+// which form a pointwise launch took, per (cin, cout, positions): a small host-side table behind p2pb_debug_pointwise_form (tests assert
 // that the layers of the bench's configuration run the kernels the roofline is quoted on)
 #include <mutex>
 namespace {
 struct FormRow {
-  int cin, cout, form;
+  int cin, cout, npos, form;
   unsigned long long n;
 };
 std::mutex g_form_mu;
 FormRow g_forms[128];
 int g_nforms = 0;
 }  // namespace
-void p2pb_note_pointwise_form(int cin, int cout, int form) {
+void p2pb_note_pointwise_form(int cin, int cout, int npos, int form) {
   std::lock_guard<std::mutex> lk(g_form_mu);
   for (int i = 0; i < g_nforms; ++i)
-    if (g_forms[i].cin == cin && g_forms[i].cout == cout) {
+    if (g_forms[i].cin == cin && g_forms[i].cout == cout && g_forms[i].npos == npos) {
       g_forms[i].form = form;
       ++g_forms[i].n;
       return;
     }
-  if (g_nforms < 128) g_forms[g_nforms++] = {cin, cout, form, 1ull};
+  if (g_nforms < 128) g_forms[g_nforms++] = {cin, cout, npos, form, 1ull};
 }
-extern "C" int p2pb_debug_pointwise_form(int cin, int cout, unsigned long long *launches) {
+extern "C" int p2pb_debug_pointwise_form(int cin, int cout, int npos, unsigned long long *launches) {
   std::lock_guard<std::mutex> lk(g_form_mu);
   if (launches) *launches = 0;
   if (cin < 0) {
@@ -54,7 +54,7 @@ extern "C" int p2pb_debug_pointwise_form(int cin, int cout, unsigned long long *
     return -1;
   }
   for (int i = 0; i < g_nforms; ++i)
-    if (g_forms[i].cin == cin && g_forms[i].cout == cout) {
+    if (g_forms[i].cin == cin && g_forms[i].cout == cout && g_forms[i].npos == npos) {
       if (launches) *launches = g_forms[i].n;
       return g_forms[i].form;
     }

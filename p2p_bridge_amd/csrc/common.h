@@ -217,7 +217,7 @@ enum {
   P2PB_FORM_PW_PINGPONG = 5,  // pw_pingpong_kernel
   P2PB_FORM_PW_GATHER = 6,    // pw_wide_kernel<GATHER> (grouped operand built on the fly)
 };
-void p2pb_note_pointwise_form(int cin, int cout, int form);
+void p2pb_note_pointwise_form(int cin, int cout, int npos, int form);
 
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);

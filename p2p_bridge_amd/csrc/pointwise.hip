@@ -586,6 +586,7 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
 #define PWS_TILE (2 * 3 * 2 * 128)                     // 16-byte groups per operand tile (24 KB)
 #define PWS_LDS_BYTES (2 * PWS_TILE * 16)               // A + B
 #include "pw_pingpong.h"  // the >= 256-channel / 256-position-block form of the f16x3 arithmetic (round 3)
+#include "pw_pp512.h"     // the 512-channel x 128-position re-tiling of it (round 4)
 
 // Epilogue of the split-operand GEMM kernels for one wave's 64 channels x NB x 64 positions: bias, stores (channel- or
 // point-major), GroupNorm partials per 64-position slot, optional {min, max} for the pooling that follows.
@@ -1019,7 +1020,30 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   // of 32-channel stages run the ping-pong kernel (pw_pingpong.h: one 8-wave workgroup per CU, 160 KB of LDS, weight
   // DMA two stages ahead, the two waves of a SIMD in opposite phase): 512 -> 1024 x 8192 x 32 in 0.88 ms against 1.04-1.15
   // (tools/exp/pp). P2PB_PW_PP=0 keeps pw_split_kernel (A/B timing).
-  static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 1;
+  static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 2;
+  // Round 4: 512 channels x 128 positions per workgroup (pw_pp512.h): half the staging work per MFMA, conflict-free staging
+  // stores, ragged position counts. P2PB_PW_PP=1 keeps the 256 x 256 form of round 3, 0 pw_split_kernel (A/B timing).
+  if (pp_env >= 2 && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0)) {
+    dim3 pgrid((P + 127) / 128, cout / 512, b);
+#define LAUNCHP5(XF, PL)                                                                                              \
+  do {                                                                                                                \
+    static bool once = false;                                                                                         \
+    if (!once) {                                                                                                      \
+      (void)hipFuncSetAttribute((const void *)pw_pp512_kernel<XF, PL>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                P5_LDS_BYTES);                                                                        \
+      once = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((pw_pp512_kernel<XF, PL>), pgrid, dim3(512), P5_LDS_BYTES, s, cin, cout, P, nslots, in, w, bias, \
+                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                        \
+  } while (0)
+    if (xf && minmax) LAUNCHP5(true, true);
+    else if (xf) LAUNCHP5(true, false);
+    else if (minmax) LAUNCHP5(false, true);
+    else LAUNCHP5(false, false);
+#undef LAUNCHP5
+    p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_PINGPONG);
+    return p2pb_launch_status();
+  }
   if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 256 == 0 && P % 256 == 0 &&
       (!minmax || pool_u == 0)) {
     dim3 pgrid(P / 256, cout / 256, b);
@@ -1039,10 +1063,10 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     else if (minmax) LAUNCHPP(false, true);
     else LAUNCHPP(false, false);
 #undef LAUNCHPP
-    p2pb_note_pointwise_form(cin, cout, P2PB_FORM_PW_PINGPONG);
+    p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_PINGPONG);
     return p2pb_launch_status();
   }
-  p2pb_note_pointwise_form(cin, cout, wm4 ? P2PB_FORM_PW_SPLIT256 : P2PB_FORM_PW_SPLIT128);
+  p2pb_note_pointwise_form(cin, cout, P, wm4 ? P2PB_FORM_PW_SPLIT256 : P2PB_FORM_PW_SPLIT128);
   if (xf && minmax) LAUNCH(true, true);
   else if (xf) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
@@ -1076,7 +1100,7 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
     if (split_pack) LAUNCHX(XF, ST, PL, SPLIT_F16X3);       \
     else LAUNCHX(XF, ST, PL, 0);                            \
   } while (0)
-    p2pb_note_pointwise_form(cin, cout, split_pack ? P2PB_FORM_PW_WIDE_F16 : P2PB_FORM_PW_WIDE_FP32);
+    p2pb_note_pointwise_form(cin, cout, P, split_pack ? P2PB_FORM_PW_WIDE_F16 : P2PB_FORM_PW_WIDE_FP32);
     if (minmax) {
       if (xf) LAUNCH(true, true, true);
       else LAUNCH(false, true, true);
@@ -1089,7 +1113,7 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
     return p2pb_launch_status();
   }
   if (minmax || out_pm) return P2PB_EINVAL;  // (the unaligned fallback: plain form only)
-  p2pb_note_pointwise_form(cin, cout, P2PB_FORM_PW_FP32);
+  p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_FP32);
   dim3 grid((P + 255) / 256, (cout + 32 * MT - 1) / (32 * MT), b);
 #define LAUNCH(XF, ST)                                                                                            \
   hipLaunchKernelGGL((pw_conv_kernel<MT, XF, ST>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P, in, wp, bias, \
@@ -1197,7 +1221,7 @@ extern "C" int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, 
   if (cout > 32) LAUNCHG(2);
   else LAUNCHG(1);
 #undef LAUNCHG
-  p2pb_note_pointwise_form(cin, cout, P2PB_FORM_PW_GATHER);
+  p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_GATHER);
   return p2pb_launch_status();
 }
 

@@ -319,19 +319,19 @@ def test_c4_full_width_pvdl_50000():
 PW_PINGPONG = 5
 
 
-def _pw_form(cin, cout):
+def _pw_form(cin, cout, npos=8192):
     import ctypes
 
     from p2p_bridge_amd import _lib
 
     n = ctypes.c_ulonglong(0)
-    return _lib.lib().p2pb_debug_pointwise_form(cin, cout, ctypes.byref(n)), n.value
+    return _lib.lib().p2pb_debug_pointwise_form(cin, cout, npos, ctypes.byref(n)), n.value
 
 
 def _pw_forms_reset():
     from p2p_bridge_amd import _lib
 
-    _lib.lib().p2pb_debug_pointwise_form(-1, 0, None)
+    _lib.lib().p2pb_debug_pointwise_form(-1, 0, 0, None)
 
 
 def test_c2_bench_dispatch_one_evaluation_b8(c2):

@@ -50,10 +50,11 @@ print("TILE-FORMS-OK")
 """ % ROOT
 
 
-@pytest.mark.parametrize("pp", ["1", "0"])
+@pytest.mark.parametrize("pp", ["2", "1", "0"])
 def test_256_channel_forms(pp):
-    """pp = 1: shapes in whole 256 x 256 tiles with an even stage count take the ping-pong kernel (pw_pingpong.h), the
-    others pw_split_kernel<WM = 4>; pp = 0: pw_split_kernel for all"""
+    """pp = 2 (default): shapes with whole 512-channel blocks and an even stage count take the 512 x 128 ping-pong kernel
+    (pw_pp512.h), whole 256 x 256 tiles the round-3 form (pw_pingpong.h), the others pw_split_kernel<WM = 4>; pp = 1: without
+    the 512 x 128 form; pp = 0: pw_split_kernel for all"""
     env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP=pp)
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TILE-FORMS-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
@@ -116,3 +117,78 @@ def test_pingpong_kernel_shapes():
     env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP="1")
     r = subprocess.run([sys.executable, "-c", PP_CODE], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PINGPONG-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+P5_CODE = r"""
+import sys, ctypes, torch
+sys.path.insert(0, %r)
+from p2p_bridge_amd import fused, _lib
+torch.manual_seed(2)
+def swish(x): return x * torch.sigmoid(x)
+def form(ci, co, P):
+    return _lib.lib().p2pb_debug_pointwise_form(ci, co, P, None)
+# (B, cin, cout, P, transform): 4 .. 16 stages, 1 .. 3 channel blocks of 512, whole and RAGGED position tiles (P %% 128 != 0, down to
+# a single partial tile), odd grid sizes
+for (B, ci, co, P, xf) in [(1, 128, 512, 128, "swish"), (3, 128, 512, 768, "affine"), (2, 512, 1024, 2048, "swish"),
+                           (5, 192, 1536, 256, "none"), (2, 256, 512, 1284, "swish"), (1, 128, 1024, 60, "affine"),
+                           (2, 512, 1024, 12500, "swish"), (1, 320, 512, 1000, "none")]:
+    x = torch.randn(B, ci, P, device="cuda") * 3
+    conv = torch.nn.Conv1d(ci, co, 1).cuda()
+    sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
+    bias_b = torch.randn(B, co, device="cuda")
+    with torch.no_grad():
+        xin = x.double()
+        if xf != "none":
+            xin = xin * sc[:, :, None].double() + sh[:, :, None].double()
+        if xf == "swish":
+            xin = swish(xin)
+        ref = torch.nn.functional.conv1d(xin, conv.weight.double(), conv.bias.double()) + bias_b[:, :, None].double()
+        mag = torch.nn.functional.conv1d(xin.abs(), conv.weight.double().abs()) + conv.bias.double().abs()[None, :, None] + bias_b[:, :, None].double().abs()
+        args = (x, conv) if xf == "none" else (x, conv, sc, sh)
+        kw = dict(bias_b=bias_b, swish=(xf == "swish")) if xf != "none" else dict(bias_b=bias_b)
+        y, st = fused.pw_conv(*args, **kw)
+        assert form(ci, co, P) == 5, ("the ping-pong form did not run", ci, co, P, form(ci, co, P))
+        assert ((y.double() - ref).abs() / mag).max().item() < 2e-6, ("output", B, ci, co, P)
+        nslots = (P + 255) // 256 * 4
+        assert st.shape[1] == nslots
+        # statistics per 128 positions = a pair of 64-position slots (sums in the even slot, zero in the odd one; extrema in
+        # both); slots past the last tile are zero. The tail tile's columns >= P contribute nothing.
+        T = nslots // 2
+        pad = T * 128 - P
+        rp = torch.nn.functional.pad(ref, (0, pad)).view(B, co, T, 128)
+        mp = torch.nn.functional.pad(mag, (0, pad)).view(B, co, T, 128) + 1e-30
+        s = st.double().view(B, T, 2, co, 2).sum(2)
+        assert ((s[..., 0] - rp.sum(3).transpose(1, 2)).abs() / (mp.sum(3).transpose(1, 2) + 1e-30)).max().item() < 2e-6, "slot sums"
+        q = (rp * rp).sum(3).transpose(1, 2)
+        assert ((s[..., 1] - q).abs() / (q + 1e-30)).max().item() < 1e-5, "slot sumsq"
+        _, st2, mm = fused.pw_conv(*args, pool_u=0, store=False, **kw)
+        assert torch.equal(st2, st), "statistics with / without the stored output"
+        T2 = (P + 127) // 128
+        assert mm.shape[1] == 2 * T2
+        mm = mm.view(B, T2, 2, co, 2)
+        assert torch.equal(mm[:, :, 0], mm[:, :, 1])
+        pad2 = T2 * 128 - P
+        rmin = torch.nn.functional.pad(ref, (0, pad2), value=float("inf")).view(B, co, T2, 128).min(3).values.transpose(1, 2)
+        rmax = torch.nn.functional.pad(ref, (0, pad2), value=float("-inf")).view(B, co, T2, 128).max(3).values.transpose(1, 2)
+        mmax = torch.nn.functional.pad(mag, (0, pad2)).view(B, co, T2, 128).max(3).values.transpose(1, 2)
+        assert ((mm[:, :, 0, :, 0].double() - rmin).abs() / mmax).max().item() < 2e-6
+        assert ((mm[:, :, 0, :, 1].double() - rmax).abs() / mmax).max().item() < 2e-6
+        for _ in range(3):  # deterministic: the hand-counted waits and the raw barriers leave no race
+            y2, st3 = fused.pw_conv(*args, **kw)
+            assert torch.equal(y2, y) and torch.equal(st3, st)
+        # out of range is loud here too, and stays inside its column
+        if P > 6:
+            xb = x.clone(); xb[0, 3, 5] = float("nan")
+            yb, _ = fused.pw_conv(*((xb,) + args[1:]), **kw)
+            assert not torch.isfinite(yb[0, :, 5]).any() and torch.equal(yb[:, :, :5], y[:, :, :5]) and torch.equal(yb[0, :, 6:], y[0, :, 6:])
+print("PP512-OK")
+""" % ROOT
+
+
+def test_pp512_kernel_shapes():
+    """pw_pp512_kernel (round 4: 512 channels x 128 positions per workgroup) on its own shape family, ragged position counts
+    included (PVDL's 12500-point level): every output against float64 with per-element bounds, per-slot statistics and
+    extrema, zeroed / masked tails, run-to-run identical; the form table confirms the kernel ran"""
+    env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP="2")
+    r = subprocess.run([sys.executable, "-c", P5_CODE], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "PP512-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
