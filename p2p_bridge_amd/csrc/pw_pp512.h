@@ -39,24 +39,16 @@
 
 #define P5_STR2(x) #x
 #define P5_STR(x) P5_STR2(x)
-// the pinned registers: raw activations of even stages in v[240:247], of odd stages in v[248:255] (the kernel is compiled
-// for 240 VGPRs; these 16 are touched by inline asm only)
-#define P5_R00 240
-#define P5_R01 241
-#define P5_R02 242
-#define P5_R03 243
-#define P5_R04 244
-#define P5_R05 245
-#define P5_R06 246
-#define P5_R07 247
-#define P5_R10 248
-#define P5_R11 249
-#define P5_R12 250
-#define P5_R13 251
-#define P5_R14 252
-#define P5_R15 253
-#define P5_R16 254
-#define P5_R17 255
+// the pinned registers: the raw activations of the next stage in v[248:255] (the kernel is compiled for 248 VGPRs; these 8 are
+// touched by inline asm only -- loads write them, a hand-placed s_waitcnt retires them, v_mov copies hand them to the compiler)
+#define P5_R00 248
+#define P5_R01 249
+#define P5_R02 250
+#define P5_R03 251
+#define P5_R04 252
+#define P5_R05 253
+#define P5_R06 254
+#define P5_R07 255
 // (s_nop 4: an SGPR written by the SALU needs wait states before a VMEM instruction reads it as its scalar offset; the
 //  hazard recogniser does not look inside inline asm)
 #define P5_LOAD1(set, i)                                                                                     \
@@ -72,7 +64,7 @@
 #define P5_BARRIER(n) asm volatile("s_waitcnt vmcnt(" #n ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <bool XF, bool POOL>
-__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(240))) void pw_pp512_kernel(
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void pw_pp512_kernel(
     int cin, int cout, int P, int nslots, const float *__restrict__ in, const u32x4 *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ bias_b, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, int in_swish, float *__restrict__ out, float *__restrict__ stats_part,
@@ -98,6 +90,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(240))) void 
   float bpre = bias ? bias[co0 + tid] : 0.0f;
   if (bias_b) bpre += bias_b[(size_t)b * cout + co0 + tid];
 
+#ifdef PP_TIMELINE
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool tl_on = false;
+  const unsigned long long tl0 = __builtin_readcyclecounter();
+#define P5_TLS(k) do { if (tl_on) ts[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define P5_TLS(k)
+#endif
   f32x16 acc[2][4];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -112,14 +112,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(240))) void 
                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(inb >> 32)),
                     (unsigned)__builtin_amdgcn_readfirstlane(cin * P * 4), 0x00020000u};
   const unsigned voff = (unsigned)(pblk + 64 * half + lane) * 4u;
-  auto load_b = [&](int s, int set) {
+  auto load_b = [&](int s) {
     const int st = s < nstage ? s : nstage - 1;  // past the end: a valid row, never used
-    if (set == 0) { P5_LOAD8(0); } else { P5_LOAD8(1); }
+    P5_LOAD8(0);
   };
-  auto take_b = [&](int set, float (&r)[8]) {
-    if (set == 0) { P5_TAKE8(0, r); } else { P5_TAKE8(1, r); }
-  };
+  auto take_b = [&](float (&r)[8]) { P5_TAKE8(0, r); };
+  // the weight tile of a stage: 8 LDS-DMA instructions per wave. A wave BLOCKS at issue while the texture path accepts them
+  // (60-170 cycles per 1 KB instruction, tools/exp_p5_timeline.py), so each half issues its share in its own non-matrix
+  // window: half 1 at the top of the interval (beside half 0's MFMA block), half 0 right after its MFMA block
   auto dma_a = [&](int s, int buf) {
+#ifdef P5_EXP_NODMA
+    return;
+#endif
     const int st = s < nstage ? s : nstage - 1;
     const u32x4 *src = wp + ((size_t)st * nblk128 + by * 4) * PWS_TILE;
     u32x4 *dst = p5_lds + buf * P5_A_SLOTS;
@@ -132,20 +136,35 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(240))) void 
                                        (__attribute__((address_space(3))) void *)(dst + e), 16, 0, 0);
     }
   };
-  auto stage_b = [&](int s, int buf, int set) {  // raw activations of stage s -> transformed, split, into B[buf]
-    // element-parallel (every step over all 8 values before the next step): the dependent chains fma -> exp -> rcp -> mul
-    // -> cvt -> sub -> cvt overlap. 4 swish(v) = v * rcp(0.25 + 0.25 e^-v): the activation scale of the fp16 split
-    // (SPLIT_F16_SX = 4, a power of two: exact) rides in the reciprocal's argument
-    float braw[8], y[8];
-    take_b(set, braw);
+  // The non-matrix window of a wave, stage s -> B[buf]: fetch the stage's folded-norm parameters (scalar loads: their latency
+  // runs under what follows), take the raw activations out of the pinned registers, REQUEST what the next windows need -- the
+  // raw activations of stage s + 1 into the registers just freed, then (dma >= 0) this wave's share of weight stage `dma` --
+  // and only then do the VALU work (transform, split) and the two LDS stores: the texture path accepts a stage's bytes at 64
+  // B/clk and a wave blocks at issue meanwhile, so everything is issued FIRST and the arithmetic runs in its shadow
+  // (issued last, the eight loads alone waited ~1 k cycles behind the DMA: tools/exp_p5_timeline.py).
+  // element-parallel arithmetic (every step over all 8 values before the next): the dependent chains fma -> exp -> rcp -> mul
+  // -> cvt -> sub -> cvt overlap. 4 swish(v) = v * rcp(0.25 + 0.25 e^-v): the activation scale of the fp16 split
+  // (SPLIT_F16_SX = 4, a power of two: exact) rides in the reciprocal's argument
+  auto stage = [&](int s, int buf, int dma, int dbuf) {
+#ifdef P5_EXP_NOSTAGE
+    return;
+#endif
+    float braw[8], y[8], sc[8], sh[8];
     if (XF) {
-      float sc[8], sh[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int c = (s < nstage ? s : nstage - 1) * P5_CK + 8 * cg + i;
         sc[i] = in_scale[b * cin + c];
         sh[i] = in_shift[b * cin + c];
       }
+    }
+    P5_VMCNT(0);  // the raw activations of stage s (requested a whole interval ago)
+    P5_TLS(2);
+    take_b(braw);
+    load_b(s + 1);
+    if (dma >= 0) dma_a(dma, dbuf);
+    P5_TLS(1);
+    if (XF) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) y[i] = __fmaf_rn(braw[i], sc[i], sh[i]);
       if (in_swish) {
@@ -176,6 +195,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(240))) void 
     const int kstep = cg >> 1, kh = cg & 1, slot = 64 * half + lane;
     lb[((kstep * 2 + 0) * 2 + kh) * 128 + slot] = q0;
     lb[((kstep * 2 + 1) * 2 + kh) * 128 + slot] = q1;
+    P5_TLS(3);
   };
   auto multiply = [&](int buf) {  // stage tiles A[buf], B[buf]
     const u32x4 *la = p5_lds + buf * P5_A_SLOTS + (wm >> 1) * 1024 + (wm & 1) * 64 + l31;
@@ -210,50 +230,41 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(240))) void 
   };
 
   if (grp == 1) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses every arbitration otherwise
-  // ---- prologue. VMEM queue, oldest first: L(0) L(1) D(0) | L(2)      (L = 8 activation loads, D = 8 weight DMAs)
-  load_b(0, 0);
-  load_b(1, 1);
+  // ---- prologue: L(0), D(0) requested; stage 0 staged (which requests L(1)); barrier: D(0) has landed.
+  // (L(s) = the 8 activation loads of stage s into the one pinned register set, D(s) = this wave's 8 weight DMAs)
+  load_b(0);
   dma_a(0, 0);
-  P5_VMCNT(16);  // L(0)
-  stage_b(0, 0, 0);
-  load_b(2, 0);
-  P5_BARRIER(8);  // D(0) has landed
-  // Interval s (between barriers s and s + 1), every wave: D(s+1) at the top; half 0 then multiplies stage s and stages s + 1,
-  // half 1 stages s + 1 and multiplies s. VMEM issue order per wave: ... D(s) L(s+2) | D(s+1) [wait] L(s+3):
-  //   staging s + 1 needs L(s+1); younger than it: D(s) L(s+2) D(s+1) = 24 -> vmcnt(24)
-  //   the barrier needs D(s+1);   younger: L(s+3) = 8                     -> vmcnt(8)
-  // Past the last stage the indices clamp (valid addresses, buffers nobody reads again), so the counts never change.
-  for (int s = 0; s < nstage; s += 2) {
-    // even stage s: its successor lives in register set 1
-    dma_a(s + 1, 1);
-    if (grp == 1) {
-      P5_VMCNT(24);
-      stage_b(s + 1, 1, 1);
-      load_b(s + 3, 1);
-    }
-    multiply(0);
-    if (grp == 0) {
-      P5_VMCNT(24);
-      stage_b(s + 1, 1, 1);
-      load_b(s + 3, 1);
-    }
-    P5_BARRIER(8);
-    // odd stage s + 1: its successor lives in register set 0
-    dma_a(s + 2, 0);
-    if (grp == 1) {
-      P5_VMCNT(24);
-      stage_b(s + 2, 0, 0);
-      load_b(s + 4, 0);
-    }
-    multiply(1);
-    if (grp == 0) {
-      P5_VMCNT(24);
-      stage_b(s + 2, 0, 0);
-      load_b(s + 4, 0);
-    }
-    P5_BARRIER(8);
+  stage(0, 0, -1, 0);
+  P5_BARRIER(8);  // D(0) (older than L(1)) has landed
+#ifdef PP_TIMELINE
+  const unsigned long long tl1 = __builtin_readcyclecounter();
+#endif
+  // Interval s (between barriers s and s + 1), W = the window above for stage s + 1 (requests L(s+2), D(s+1)):
+  //   half 0: multiply(s) | W     -- its matrix block starts at the barrier
+  //   half 1: W | multiply(s)     -- issue + VALU beside half 0's MFMAs, then its own block beside half 0's window
+  // The barrier waits for everything this wave requested in the interval (vmcnt(0)): D(s+1) must have landed for all waves'
+  // reads of A[(s+1) & 1], and L(s+2), older than it, has had the whole interval. Past the last stage the indices clamp
+  // (valid addresses, buffers nobody reads again).
+  for (int s = 0; s < nstage; ++s) {
+#ifdef PP_TIMELINE
+    tl_on = s == 6;
+#endif
+    const int cur = s & 1, nxt = cur ^ 1;
+    P5_TLS(0);
+    if (grp == 1) stage(s + 1, nxt, s + 1, nxt);
+    multiply(cur);
+    P5_TLS(4);
+    if (grp == 0) stage(s + 1, nxt, s + 1, nxt);
+    P5_TLS(5);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    P5_TLS(6);
+    P5_BARRIER(0);
+    P5_TLS(7);
   }
   P5_VMCNT(0);  // nothing of this workgroup may still be on its way into LDS when the waves retire
+#ifdef PP_TIMELINE
+  const unsigned long long tl2 = __builtin_readcyclecounter();
+#endif
 
   // ---- epilogue (the arithmetic and the outputs of pws_epilogue; a slot = 64 consecutive positions)
   {
@@ -365,4 +376,12 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(240))) void 
       q[(size_t)cout * 2 + 1] = mx;
     }
   }
+#ifdef PP_TIMELINE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((tid == 0 || tid == 256) && pp_tl_buf) {
+    unsigned long long *q = pp_tl_buf + (size_t)lin * 32 + (tid ? 16 : 0);
+    q[0] = tl0, q[1] = tl1, q[2] = tl2, q[3] = __builtin_readcyclecounter();
+    for (int k = 0; k < 8; ++k) q[4 + k] = ts[k];
+  }
+#endif
 }

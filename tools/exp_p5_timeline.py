@@ -1,0 +1,24 @@
+"""Phases of a workgroup of pw_pp512_kernel (512 -> 1024, P = 8192, B = 32 as the sampler launches it) from a -DPP_TIMELINE
+build of pointwise.hip (tools/build_pw_variant.sh tl "-DPP_TIMELINE"; P2PB_LIB_PATH=tools/exp/lib_pwtl.so, P2PB_PW_PP=2):
+s_memtime stamps of wave 0 (half 0: multiply, then stage) and wave 4 (half 1: stage, then multiply), stored last."""
+import ctypes, os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from p2p_bridge_amd import _lib
+buf = torch.zeros(32 * 8192, dtype=torch.int64, device="cuda")
+assert _lib.lib().p2pb_pp_timeline_set(ctypes.c_void_p(buf.data_ptr())) == 0
+import runpy
+runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_pw.py"))
+torch.cuda.synchronize()
+t = buf.cpu().numpy().reshape(-1, 32).astype(np.float64)
+t = t[t[:, 0] != 0]
+q = lambda a: f"{np.mean(a):.0f} (p10 {np.percentile(a, 10):.0f}, p90 {np.percentile(a, 90):.0f})"
+print(f"{len(t)} workgroups ({len(t) / 256:.0f} in sequence per CU); shader cycles")
+print("life", q(t[:, 3] - t[:, 0]), "| prologue", q(t[:, 1] - t[:, 0]), "| stage loop", q(t[:, 2] - t[:, 1]), f"-> per stage {np.mean(t[:, 2] - t[:, 1]) / 16:.0f} (matrix pipe alone: 3072)",
+      "| epilogue", q(t[:, 3] - t[:, 2]))
+a, c = t[:, 4:12], t[:, 20:28]
+print("even stage 6, half 0 (wave 0): multiply", q(a[:, 4] - a[:, 0]), "| scalars + wait raw", q(a[:, 2] - a[:, 4]), "| take + loads + DMA issue", q(a[:, 1] - a[:, 2]),
+      "| transform + split + LDS stores", q(a[:, 3] - a[:, 1]), "| wait everything landed", q(a[:, 6] - a[:, 5]), "| barrier", q(a[:, 7] - a[:, 6]), "| total", q(a[:, 7] - a[:, 0]))
+print("              half 1 (wave 4): scalars + wait raw", q(c[:, 2] - c[:, 0]), "| take + loads + DMA issue", q(c[:, 1] - c[:, 2]), "| transform + split + LDS stores", q(c[:, 3] - c[:, 1]),
+      "| multiply", q(c[:, 4] - c[:, 3]), "| wait everything landed", q(c[:, 6] - c[:, 5]), "| barrier", q(c[:, 7] - c[:, 6]), "| total", q(c[:, 7] - c[:, 0]))

@@ -8,7 +8,8 @@ import torch
 
 from p2p_bridge_amd import fused
 
-B, ci, co, P, G = 32, 512, 1024, 8192, 8
+import os
+B, ci, co, P, G = int(os.environ.get("PW_B", 32)), 512, 1024, int(os.environ.get("PW_P", 8192)), 8
 x = torch.randn(B, ci, P, device="cuda")
 conv = torch.nn.Conv1d(ci, co, 1).cuda()
 with torch.no_grad():
