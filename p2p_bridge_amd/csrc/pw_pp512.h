@@ -358,15 +358,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          tv[m * 16 + r] = fminf(fminf(cok[0] ? acc[m][0][r] : INFINITY, cok[1] ? acc[m][1][r] : INFINITY),
-                                 fminf(cok[2] ? acc[m][2][r] : INFINITY, cok[3] ? acc[m][3][r] : INFINITY));
+          tv[m * 16 + r] = full ? fminf(fminf(acc[m][0][r], acc[m][1][r]), fminf(acc[m][2][r], acc[m][3][r]))
+                                : fminf(fminf(cok[0] ? acc[m][0][r] : INFINITY, cok[1] ? acc[m][1][r] : INFINITY),
+                                        fminf(cok[2] ? acc[m][2][r] : INFINITY, cok[3] ? acc[m][3][r] : INFINITY));
       const float mn = rowreduce32<RowMin>(tv);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          tv[m * 16 + r] = fmaxf(fmaxf(cok[0] ? acc[m][0][r] : -INFINITY, cok[1] ? acc[m][1][r] : -INFINITY),
-                                 fmaxf(cok[2] ? acc[m][2][r] : -INFINITY, cok[3] ? acc[m][3][r] : -INFINITY));
+          tv[m * 16 + r] = full ? fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]))
+                                : fmaxf(fmaxf(cok[0] ? acc[m][0][r] : -INFINITY, cok[1] ? acc[m][1][r] : -INFINITY),
+                                        fmaxf(cok[2] ? acc[m][2][r] : -INFINITY, cok[3] ? acc[m][3][r] : -INFINITY));
       const float mx = rowreduce32<RowMax>(tv);
       // minmax f32[b, 2 * ceil(P / 128), cout, 2] (p2pb_pointwise_minmax_floats, split tiling): both slots of the tile
       float *q = mm_out + (((size_t)b * nmine + slot) * cout + rco) * 2;

@@ -18,7 +18,6 @@ print(f"{len(t)} workgroups ({len(t) / 256:.0f} in sequence per CU); shader cycl
 print("life", q(t[:, 3] - t[:, 0]), "| prologue", q(t[:, 1] - t[:, 0]), "| stage loop", q(t[:, 2] - t[:, 1]), f"-> per stage {np.mean(t[:, 2] - t[:, 1]) / 16:.0f} (matrix pipe alone: 3072)",
       "| epilogue", q(t[:, 3] - t[:, 2]))
 a, c = t[:, 4:12], t[:, 20:28]
-print("even stage 6, half 0 (wave 0): multiply", q(a[:, 4] - a[:, 0]), "| scalars + wait raw", q(a[:, 2] - a[:, 4]), "| take + loads + DMA issue", q(a[:, 1] - a[:, 2]),
-      "| transform + split + LDS stores", q(a[:, 3] - a[:, 1]), "| wait everything landed", q(a[:, 6] - a[:, 5]), "| barrier", q(a[:, 7] - a[:, 6]), "| total", q(a[:, 7] - a[:, 0]))
-print("              half 1 (wave 4): scalars + wait raw", q(c[:, 2] - c[:, 0]), "| take + loads + DMA issue", q(c[:, 1] - c[:, 2]), "| transform + split + LDS stores", q(c[:, 3] - c[:, 1]),
-      "| multiply", q(c[:, 4] - c[:, 3]), "| wait everything landed", q(c[:, 6] - c[:, 5]), "| barrier", q(c[:, 7] - c[:, 6]), "| total", q(c[:, 7] - c[:, 0]))
+for name, w in (("wave 0", a), ("wave 4", c)):
+    print(f"stage 6, {name}: scalars + take + loads + fragments + 48 MFMAs with the window interleaved", q(w[:, 5] - w[:, 0]),
+          "| wait everything landed", q(w[:, 6] - w[:, 5]), "| barrier", q(w[:, 7] - w[:, 6]), "| total", q(w[:, 7] - w[:, 0]))
