@@ -123,13 +123,13 @@ def conv_roofline(model, x_start, reps=10):
 def gemm_roofline(model, B, P, reps=10):
     """Dominant kernel of the sampler (largest share of the critical stream in profiles/r0N*_per_eval.csv): the global
     embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels over all P points of every patch;
-    models/pvcnn.py:905-932) -- since round 3 pw_pingpong_kernel<XF=true, POOL=true> (csrc/pw_pingpong.h; pw_split_kernel
-    under P2PB_PW_PP=0 or for shapes outside whole 256 x 256 tiles): split-operand GEMM in the arithmetic fused.conv_math()
+    models/pvcnn.py:905-932) -- pw_pp512_kernel<XF=true, POOL=true> (csrc/pw_pp512.h: the ping-pong GEMM on 512-channel x
+    128-position tiles; pw_split_kernel under P2PB_PW_PP=0 or for layers without whole 512-channel blocks): split-operand GEMM in the arithmetic fused.conv_math()
     selects (f16x3 by default) that applies the previous layer's folded GroupNorm + Swish to its operand on load and whose
     epilogue emits the GroupNorm statistics and the per-channel {min, max} the max-pool is formed from -- the
     1024-channel output is never written. Timed live with HIP events on torch's current stream, launched exactly as
     the sampler launches it, right after the timed sampler runs (a warm chip: 10-15 % slower than the same launch from
-    a cold start, tools/exp/pp). `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
+    a cold start). `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
     from p2p_bridge_amd import fused
 
     conv = model.model.global_pnet.mlp2.shared_mlp_1.mlp[0]
@@ -155,27 +155,28 @@ def gemm_roofline(model, B, P, reps=10):
     traffic = None
     try:
         vals = {}
-        pingpong = split and fused.conv_math() == "f16x3" and os.environ.get("P2PB_PW_PP", "1") != "0" and P % 256 == 0 and B * (P // 128) * (co // 256) >= 1024
+        pingpong = split and fused.conv_math() == "f16x3" and os.environ.get("P2PB_PW_PP", "1") != "0" and co % 512 == 0 and ci % 64 == 0 and B * ((P + 127) // 128) * (co // 256) >= 1024
         import glob
 
-        cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_pw_pingpong_512_1024_pool.csv")), reverse=True) if pingpong else [])
-        cands += [os.path.join(ROOT, "profiles", f"{t}_pmc_pw_split_512_1024_pool.csv") for t in ("r02f", "r02", "r01")]
+        cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_pw_pp512_512_1024_pool.csv")), reverse=True) if pingpong else [])
+        if not pingpong:
+            cands = [os.path.join(ROOT, "profiles", f"{t}_pmc_pw_split_512_1024_pool.csv") for t in ("r02f", "r02", "r01")]
         pmc = next(q for q in cands if os.path.exists(q))  # (newest round's PMC passes of the kernel this launch runs)
         for line in open(pmc):
             k, v = line.split(",")[:2]
             if k in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[k] = float(v)
         traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0) if split else None
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         pass
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_basis": f"profiles/{os.path.basename(pmc) if traffic is not None else 'r0N_pmc_pw_*_512_1024_pool.csv'}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch "
                              "(FETCH_SIZE counts half of 8- and 16-byte-per-lane streaming reads on gfx950: calibrated on a "
                              f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 4 * ci * co} B: "
-                             "the activation tile is staged once per 256-channel block (4 x for this layer), the blocks of one "
+                             "the activation tile is staged once per 512-channel block (2 x for this layer), the blocks of one "
                              "tile run side by side on one XCD and share it in that XCD's L2",
-            "kernel": (f"pw_pingpong_kernel<XF=true,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)" if traffic is not None and "pingpong" in pmc
+            "kernel": (f"pw_pp512_kernel<XF=true,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)" if pingpong
                        else f"pw_split_kernel<XF=true,POOL=true,WM=4> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)"),
             "peak_basis": split_peak_basis() if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
             "frac_of_six_product_ceiling": round(achieved / SPLIT_PEAK_TFLOPS, 4) if split else None,

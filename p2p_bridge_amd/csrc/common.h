@@ -214,7 +214,7 @@ enum {
   P2PB_FORM_PW_WIDE_F16 = 2,  // pw_wide_kernel on the split pack (f16x3 products)
   P2PB_FORM_PW_SPLIT128 = 3,  // pw_split_kernel, 128-channel workgroups
   P2PB_FORM_PW_SPLIT256 = 4,  // pw_split_kernel, 256-channel workgroups
-  P2PB_FORM_PW_PINGPONG = 5,  // pw_pingpong_kernel
+  P2PB_FORM_PW_PINGPONG = 5,  // pw_pp512_kernel
   P2PB_FORM_PW_GATHER = 6,    // pw_wide_kernel<GATHER> (grouped operand built on the fly)
 };
 void p2pb_note_pointwise_form(int cin, int cout, int npos, int form);

@@ -585,8 +585,7 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
 
 #define PWS_TILE (2 * 3 * 2 * 128)                     // 16-byte groups per operand tile (24 KB)
 #define PWS_LDS_BYTES (2 * PWS_TILE * 16)               // A + B
-#include "pw_pingpong.h"  // the >= 256-channel / 256-position-block form of the f16x3 arithmetic (round 3)
-#include "pw_pp512.h"     // the 512-channel x 128-position re-tiling of it (round 4)
+#include "pw_pp512.h"  // the ping-pong form of the f16x3 arithmetic for >= 512-channel layers (rounds 3-4)
 
 // Epilogue of the split-operand GEMM kernels for one wave's 64 channels x NB x 64 positions: bias, stores (channel- or
 // point-major), GroupNorm partials per 64-position slot, optional {min, max} for the pooling that follows.
@@ -989,7 +988,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
                                        : (cout >= 512 && (long)((P + 127) / 128) * ((cout + 255) / 256) * b >= 1024));
   // (256-position workgroups of THIS kernel -- half the weight traffic through L2 at one wave per SIMD less -- measured
-  //  4 % / 7 % slower and are not instantiated; the 256 x 256 tile lives in pw_pingpong.h, with the pipeline it needs)
+  //  4 % / 7 % slower and are not instantiated; the wide tile lives in pw_pp512.h, with the pipeline it needs)
   dim3 grid((P + 127) / 128, wm4 ? (cout + 255) / 256 : (cout + 127) / 128, b);
   const int nslots = (P + 255) / 256 * 4;
   const u32x4 *w = (const u32x4 *)wp;
@@ -1016,14 +1015,12 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     if (wm4) LAUNCHF(XF, PL, 4, 1);        \
     else LAUNCHF(XF, PL, 2, 1);            \
   } while (0)
-  // Round 3: the layers that qualified for 256-channel workgroups AND come in whole 256 x 256 tiles with an even number
-  // of 32-channel stages run the ping-pong kernel (pw_pingpong.h: one 8-wave workgroup per CU, 160 KB of LDS, weight
-  // DMA two stages ahead, the two waves of a SIMD in opposite phase): 512 -> 1024 x 8192 x 32 in 0.88 ms against 1.04-1.15
-  // (tools/exp/pp). P2PB_PW_PP=0 keeps pw_split_kernel (A/B timing).
-  static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 2;
-  // Round 4: 512 channels x 128 positions per workgroup (pw_pp512.h): half the staging work per MFMA, conflict-free staging
-  // stores, ragged position counts. P2PB_PW_PP=1 keeps the 256 x 256 form of round 3, 0 pw_split_kernel (A/B timing).
-  if (pp_env >= 2 && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0)) {
+  // The layers that qualify for 256-channel workgroups AND come in whole 512-channel blocks with an even number of
+  // 32-channel stages run the ping-pong kernel (pw_pp512.h: one 8-wave workgroup per CU on 512 channels x 128 positions, all
+  // 160 KB of LDS, weight tiles by LDS-DMA, the two waves of a SIMD in opposite phase; any position count).
+  // P2PB_PW_PP=0 keeps pw_split_kernel (A/B timing).
+  static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 1;
+  if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0)) {
     dim3 pgrid((P + 127) / 128, cout / 512, b);
 #define LAUNCHP5(XF, PL)                                                                                              \
   do {                                                                                                                \
@@ -1041,28 +1038,6 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     else if (minmax) LAUNCHP5(false, true);
     else LAUNCHP5(false, false);
 #undef LAUNCHP5
-    p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_PINGPONG);
-    return p2pb_launch_status();
-  }
-  if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 256 == 0 && P % 256 == 0 &&
-      (!minmax || pool_u == 0)) {
-    dim3 pgrid(P / 256, cout / 256, b);
-#define LAUNCHPP(XF, PL)                                                                                             \
-  do {                                                                                                               \
-    static bool once = false;                                                                                        \
-    if (!once) {                                                                                                     \
-      (void)hipFuncSetAttribute((const void *)pw_pingpong_kernel<XF, PL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                PP_LDS_BYTES);                                                                       \
-      once = true;                                                                                                   \
-    }                                                                                                                \
-    hipLaunchKernelGGL((pw_pingpong_kernel<XF, PL>), pgrid, dim3(512), PP_LDS_BYTES, s, cin, cout, P, P / 64, in, w,  \
-                       bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                  \
-  } while (0)
-    if (xf && minmax) LAUNCHPP(true, true);
-    else if (xf) LAUNCHPP(true, false);
-    else if (minmax) LAUNCHPP(false, true);
-    else LAUNCHPP(false, false);
-#undef LAUNCHPP
     p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_PINGPONG);
     return p2pb_launch_status();
   }

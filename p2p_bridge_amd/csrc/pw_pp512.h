@@ -1,5 +1,5 @@
 // pw_pp512.h -- the wide 1x1-convolution GEMM of the f16x3 arithmetic (>= 512 output channels in whole 512-blocks, an even
-// number of 32-channel stages), round 4: the ping-pong kernel of round 3 re-tiled to 512 channels x 128 positions.
+// number of 32-channel stages), round 4: the ping-pong kernel of round 3 (256 x 256 tile: git history, csrc/pw_pingpong.h) re-tiled to 512 channels x 128 positions.
 // Included by pointwise.hip.
 //
 // Why (round-3 evidence, profiles/r03f_pmc_pw_pingpong_*, r03b_pingpong_timeline.txt, r03d_pw_presplit_ab.txt): on the
@@ -32,6 +32,10 @@
 // for the global pooling (pool_u == 0), optional channel-major stores.
 #pragma once
 
+#ifdef PP_TIMELINE  // experiment builds (tools/exp_p5_timeline.py): s_memtime stamps of waves 0 and 4, stored at the very end
+__device__ unsigned long long *pp_tl_buf;
+extern "C" int p2pb_pp_timeline_set(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(pp_tl_buf), &p, sizeof(p)); }
+#endif
 #define P5_CK 32
 #define P5_A_SLOTS 4096  // 16-byte slots of one weight stage tile (64 KB)
 #define P5_B_SLOTS 1024  // ... of one activation stage tile (16 KB)

@@ -15,7 +15,7 @@ timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_bench -o bench
 db=$(find $out/prof_bench -name "*.db" | head -1)
 python $R/tools/rocpd_window.py $db $out/${tag}_per_eval.csv > /dev/null
 python $R/tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv > /dev/null
-python $R/tools/rocpd_roofline.py $db $out/${tag}_roofline_kernel.csv "pw_pingpong_kernel<true, true, false>" > /dev/null
+python $R/tools/rocpd_roofline.py $db $out/${tag}_roofline_kernel.csv "pw_pp512_kernel<true, true>" > /dev/null
 python $R/tools/rocpd_roofline.py $db $out/${tag}_roofline_second_kernel.csv "conv3d_k3_compact_kernel<16" > /dev/null
 # 2) PMC passes of the dominant GEMM (separate passes)
 i=0
@@ -23,7 +23,7 @@ for ctrs in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out/pmc/p$i -o pmc -- python $R/tools/pmc_pw.py > $out/pmc_p$i.log 2>&1
 done
-python $R/tools/pmc_summary.py $out/pmc pw_pingpong $out/${tag}_pmc_pw_pingpong_512_1024_pool.csv > /dev/null
+python $R/tools/pmc_summary.py $out/pmc pw_pp512 $out/${tag}_pmc_pw_pp512_512_1024_pool.csv > /dev/null
 # 3) metric kernels
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_metrics -o m -- python $R/tools/exp_metrics.py > $out/${tag}_metrics_timing.txt 2>&1
 db=$(find $out/prof_metrics -name "*.db" | head -1)
