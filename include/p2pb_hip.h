@@ -402,6 +402,13 @@ int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const f
 int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, int m, int u, const float *zt, const float *cxt,
                                     const int *idx, const void *wp_split, const float *bias, const float *in_scale,
                                     const float *in_shift, int in_swish, float *stats_part, float *minmax, void *stream);
+/* nn.Linear on a handful of rows (the per-evaluation Linears: AdaGN styles models/modules.py:337-345, time embedding
+ * models/unet_pvc.py:108-112, the global embedding's per-sample bias models/pvcnn.py:926): out[b,co] = bias[co] + sum_ci
+ * w[co,ci] x[b,ci]. x f32[b,cin] with row pitch x_stride (floats), w f32[cout,cin] with row pitch w_stride (a column slice of
+ * a wider matrix is fine), bias f32[cout] or NULL, out f32[b,cout] with row pitch out_stride. cin % 4 == 0, 16-byte aligned
+ * rows. No scratch memory (safe in concurrently replayed hipGraphs, unlike a BLAS call with a per-stream workspace). */
+int p2pb_linear_rows(int b, int cin, int cout, const float *x, long x_stride, const float *w, long w_stride,
+                     const float *bias, float *out, long out_stride, void *stream);
 /* y = max(act(scale*min+shift), act(scale*max+shift)); nslots == 0: minmax f32[b,c,m,2] -> y f32[b,c,m];
  * nslots > 0: minmax f32[b,nslots,c,2] (reduced over nslots first) -> y f32[b,c] */
 int p2pb_minmax_act(int b, int c, int m, int nslots, const float *minmax, const float *scale, const float *shift,

@@ -1287,6 +1287,73 @@ extern "C" int p2pb_minmax_act(int b, int c, int m, int nslots, const float *min
 }
 
 // ------------------------------------------------------------------------------------------------
+// nn.Linear on a handful of rows: out[b, co] = bias[co] + sum_ci w[co, ci] x[b, ci]   (b <= a few dozen)
+// The per-evaluation Linears of the network -- every AdaGN's style Linear on the global embedding (concatenated: 1024 ->
+// 13184 for PVDS, models/modules.py:337-345), the time embedding's two (models/unet_pvc.py:108-112), the global embedding's
+// per-sample bias (models/pvcnn.py:926) -- are weight-streaming GEMVs (54 MB of weights for the styles). They used to go
+// through torch's BLAS, whose per-stream WORKSPACE a captured graph bakes in: two sampler chains replaying their graphs side
+// by side then shared one workspace and corrupted each other's GEMMs (round 4, tests/test_full_size_parity_gpu.py::
+// test_c2_bench_dispatch_two_chains_b32). This kernel needs no scratch: x in LDS (batch chunks of <= 16 rows), one wave per
+// output row streaming its weights once as 16-byte loads, fp32 FMA chains, a butterfly per batch row.
+// ------------------------------------------------------------------------------------------------
+#define LR_BC 16
+__global__ __launch_bounds__(256) void linear_rows_kernel(int B, int cin, int cout, const float *__restrict__ x, long xs,
+                                                          const float *__restrict__ w, long ws,
+                                                          const float *__restrict__ bias, float *__restrict__ out, long os,
+                                                          int bc) {
+  extern __shared__ float lr_x[];  // [bc][cin]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * 32, row1 = min(cout, row0 + 32);
+  for (int b0 = 0; b0 < B; b0 += bc) {
+    const int nb = min(bc, B - b0);
+    __syncthreads();
+    for (int e = tid * 4; e < nb * cin; e += 1024) {
+      const int bb = e / cin, c = e - bb * cin;
+      *(f32x4 *)(lr_x + e) = *(const f32x4 *)(x + (size_t)(b0 + bb) * xs + c);
+    }
+    __syncthreads();
+    for (int row = row0 + wave; row < row1; row += 4) {
+      float acc[LR_BC];
+#pragma unroll
+      for (int i = 0; i < LR_BC; ++i) acc[i] = 0.0f;
+      for (int c = lane * 4; c < cin; c += 256) {
+        const f32x4 wv = *(const f32x4 *)(w + (size_t)row * ws + c);
+#pragma unroll
+        for (int i = 0; i < LR_BC; ++i)
+          if (i < nb) {
+            const f32x4 xv = *(const f32x4 *)(lr_x + i * cin + c);
+            acc[i] = __fmaf_rn(wv[3], xv[3], __fmaf_rn(wv[2], xv[2], __fmaf_rn(wv[1], xv[1], __fmaf_rn(wv[0], xv[0], acc[i]))));
+          }
+      }
+      float mine = 0.0f;
+#pragma unroll
+      for (int i = 0; i < LR_BC; ++i) {
+        float v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == i) mine = v;
+      }
+      if (lane < nb) out[(size_t)(b0 + lane) * os + row] = mine + (bias ? bias[row] : 0.0f);
+    }
+  }
+}
+
+// x f32[b, cin] (row pitch x_stride floats), w f32[cout, cin] (row pitch w_stride: a column slice of a wider matrix is fine),
+// bias f32[cout] or NULL -> out f32[b, cout] (row pitch out_stride). cin % 4 == 0, 16-byte aligned rows.
+extern "C" int p2pb_linear_rows(int b, int cin, int cout, const float *x, long x_stride, const float *w, long w_stride,
+                                const float *bias, float *out, long out_stride, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !x || !w || !out || (cin & 3) || (x_stride & 3) || (w_stride & 3) ||
+      (((uintptr_t)x | (uintptr_t)w) & 15) || x_stride < cin || w_stride < cin || out_stride < cout)
+    return P2PB_EINVAL;
+  int bc = (int)(65536 / ((long)cin * 4));  // batch rows per LDS chunk (64 KB: two workgroups per CU)
+  if (bc < 1) return P2PB_EINVAL;           // (cin > 16384)
+  if (bc > LR_BC) bc = LR_BC;
+  if (bc > b) bc = b;
+  hipLaunchKernelGGL(linear_rows_kernel, dim3(cdiv(cout, 32)), dim3(256), (size_t)bc * cin * 4, (hipStream_t)stream, b, cin,
+                     cout, x, x_stride, w, w_stride, bias, out, out_stride, bc);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // y = act(x*scale[b,c] + shift[b,c]) (+ residual)   over [b, c, P]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void affine_act_kernel(int c, int P, const float *__restrict__ x,

@@ -529,12 +529,13 @@ __device__ __forceinline__ int fg_cell(int wave, int row) {
   return ((wave - 3 * cy - 9 * cz) & 15) + 16 * cy + 256 * cz;
 }
 
+typedef float fg_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const float *__restrict__ coords,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ rec, const float *__restrict__ cbox,
                                                         float *__restrict__ mind, int *__restrict__ indices) {
   __shared__ u64 slots[2][16];      // per-wave maxima (double-buffered by round parity: one barrier per round)
-  __shared__ float sxyz[2][16][4];  // ... and the coordinates of those points
+  __shared__ __attribute__((aligned(16))) float sxyz[2][16][4];  // ... and the coordinates of those points
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, b = blockIdx.x;
   const float *c = coords + (size_t)b * 3 * n;
   const int *cs = cell_start + (size_t)b * (FG_CELLS + 1);
@@ -638,9 +639,9 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
     const u64 wkey = wave_max_u64(key);
     if (key == wkey && (wkey != 0 ? true : lane == 0)) {  // (an all-empty wave: lane 0 writes the zero key)
       slots[j & 1][wave] = wkey;
-      sxyz[j & 1][wave][0] = kx;
-      sxyz[j & 1][wave][1] = ky;
-      sxyz[j & 1][wave][2] = kz;
+      // (one 16-byte store: three adjacent floats become a ds_write_b96, which misbehaved beside another stream's matrix
+      //  kernels -- voxelize.hip devox_cl_kernel, round 4)
+      *(volatile fg_f32x4 *)&sxyz[j & 1][wave][0] = fg_f32x4{kx, ky, kz, 0.0f};
     }
     __syncthreads();
     const u64 mine = slots[j & 1][t & 15];
@@ -649,9 +650,10 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 15);
     const u64 fin = ((u64)hi << 32) | lo;
     const int ws = __builtin_ctzll(__ballot(lane < 16 && mine == fin));
-    sx = sxyz[j & 1][ws][0];
-    sy = sxyz[j & 1][ws][1];
-    sz = sxyz[j & 1][ws][2];
+    const fg_f32x4 sq = *(volatile fg_f32x4 *)&sxyz[j & 1][ws][0];
+    sx = sq[0];
+    sy = sq[1];
+    sz = sq[2];
     if (t == 0) out[j] = fps_key_index(fin);
   }
 }

@@ -650,20 +650,28 @@ __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, cons
                                                        const float *__restrict__ add_scale,
                                                        const float *__restrict__ add_shift, float *__restrict__ outs) {
   __shared__ float tile[64][65];  // [channel][point]
-  __shared__ int sidx[64][8];
-  __shared__ float sw[64][8];
+  __shared__ __attribute__((aligned(16))) int sidx[64][8];
+  __shared__ __attribute__((aligned(16))) float sw[64][8];
   const int b = blockIdx.z, p0 = blockIdx.x * 64, t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int r3 = r * r * r;
-  if (t < 64) {
-    const int i = min(p0 + t, n - 1);
+  // Every wave stages the trilinear corners of ITS OWN 16 points (lanes 0..15), with 16-byte LDS stores only.
+  // Round 4: the first form -- wave 0 staged all 64 points and the compiler merged a row's eight stores into ds_write_b96 +
+  // ds_write2_b32 + ds_write_b32 -- returned wrong values for wave 3's points when a matrix kernel of ANOTHER stream shared the CU
+  // (the two-chain sampler: 10-15 % of such launches had one wave's 16 points x 64 channels off by O(1); alone, or beside
+  // element-wise kernels, never; tools/dbg/devox_conc.py). Either change alone removes it (own points: 0 of 90 launches
+  // wrong; 16-byte stores: 0 of 90); ds_write_b96 is not used anywhere in this library any more.
+  if (lane < 16) {
+    const int tt = wave * 16 + lane;
+    const int i = min(p0 + tt, n - 1);
     const float *co = coords + (size_t)b * 3 * n;
     const Corners k = devox_corners(co[i], co[i + n], co[i + 2 * n], r);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      sidx[t][q] = k.idx[q];
-      sw[t][q] = k.w[q];
-    }
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    *(volatile i32x4 *)&sidx[tt][0] = i32x4{k.idx[0], k.idx[1], k.idx[2], k.idx[3]};
+    *(volatile i32x4 *)&sidx[tt][4] = i32x4{k.idx[4], k.idx[5], k.idx[6], k.idx[7]};
+    *(volatile f32x4 *)&sw[tt][0] = f32x4{k.w[0], k.w[1], k.w[2], k.w[3]};
+    *(volatile f32x4 *)&sw[tt][4] = f32x4{k.w[4], k.w[5], k.w[6], k.w[7]};
   }
   __syncthreads();
   const float *g = grid + (size_t)b * r3 * c;

@@ -479,6 +479,23 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
     return y, st, mm
 
 
+def linear_rows(x, weight, bias=None):
+    """nn.Linear on a few rows without BLAS: x f32[B,Cin] (rows may be strided), weight f32[Cout,Cin] (may be a column slice of
+    a wider matrix), bias f32[Cout] | None -> f32[B,Cout]. csrc/pointwise.hip linear_rows_kernel: no scratch memory, so two
+    sampler chains can replay graphs holding it side by side (a torch matmul bakes a per-stream BLAS workspace into the graph)"""
+    if x.stride(-1) != 1 or x.data_ptr() % 16 or x.stride(0) % 4:
+        x = x.contiguous()
+    if weight.stride(-1) != 1 or weight.data_ptr() % 16 or weight.stride(0) % 4:
+        weight = weight.contiguous()
+    b, ci = x.shape
+    co = weight.shape[0]
+    assert weight.shape[1] == ci and x.dtype == F32 and weight.dtype == F32 and x.is_cuda
+    out = torch.empty(b, co, dtype=F32, device=x.device)
+    call("p2pb_linear_rows", _i(b), _i(ci), _i(co), ptr(x), ctypes.c_long(x.stride(0)), ptr(weight), ctypes.c_long(weight.stride(0)),
+         ptr(bias), ptr(out), ctypes.c_long(co), stream_ptr())
+    return out
+
+
 def minmax_act(mm, scale, shift, swish=True, global_pool=False):
     """max(act(scale*min+shift), act(scale*max+shift)): mm f32[B,C,M,2] -> f32[B,C,M], or (global_pool)
     per-wave partials f32[B,nslots,C,2] -> f32[B,C]"""

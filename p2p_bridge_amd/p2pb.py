@@ -433,6 +433,9 @@ class P2PB(nn.Module):
         streams = self._chain_streams = (getattr(self, "_chain_streams", None) or [])
         while len(streams) < chains:
             streams.append(torch.cuda.Stream(device=xt.device))
+        if getattr(self, "_chains_serial", False):  # (test hook: the chains' graphs one after the other on the calling stream --
+            # the reference tests/test_concurrency_gpu.py compares the side-by-side replay with, bit for bit)
+            streams = [main] * chains
         x_c = [xt[p] for p in parts]
         logs = [([], []) for _ in parts]
         nsteps = len(rev) - 1

@@ -198,7 +198,9 @@ class StyleBank:
 
     def evaluate(self, cond):
         self._refresh()
-        return _Styles(cond, F.linear(cond, self.weight, self.bias), self.slices)
+        from . import fused
+
+        return _Styles(cond, fused.linear_rows(cond, self.weight, self.bias), self.slices)
 
     def evaluate_train(self, cond):
         """the same ONE GEMM under autograd (training): the concatenation is part of the graph, so its backward hands
@@ -701,7 +703,7 @@ class Pnet2Stage(nn.Module):
             g = fused.affine_act_max(h, sc, sh, N, 0)
         c1 = h.shape[1]
         w = b0[0].weight.reshape(b0[0].out_channels, -1)
-        bias_b = (g @ w[:, c1:].t()).contiguous()
+        bias_b = fused.linear_rows(g, w[:, c1:])  # (no BLAS in the captured step: fused.linear_rows)
         h, st = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1)
         sc, sh = norm_affine(b0[1], st, N, None)
         if pool:  # the 1024-channel output is never written: only its statistics and extrema are needed
@@ -986,7 +988,13 @@ class PVCNN2Unet(nn.Module):
         if t is not None:
             if t.dim() == 0:
                 t = t.view(1).expand(B)
-            time_emb = self.embedf(self.get_timestep_embedding(t))[:, :, None].expand(-1, -1, N)
+            te = self.get_timestep_embedding(t)
+            if use_fused:  # the two Linears without BLAS (fused.linear_rows: nothing with a workspace inside a captured step)
+                te = fused.linear_rows(te, self.embedf[0].weight, self.embedf[0].bias)
+                te = fused.linear_rows(F.leaky_relu(te, self.embedf[1].negative_slope), self.embedf[2].weight, self.embedf[2].bias)
+            else:
+                te = self.embedf(te)
+            time_emb = te[:, :, None].expand(-1, -1, N)
         data = PVCData(features=feats, coords=coords, time_emb=time_emb, cond=cond, geo=geo)
 
         skips, level_coords = [feats], []

@@ -451,3 +451,24 @@ def test_set_abstraction_last_layer_on_the_gathered_operand(fused, B, N, M, U, C
         h = swish(ref.double() * sc[:, :, None, None] + sh[:, :, None, None])
         out = torch.einsum("oc,bcmu->bomu", conv.weight.view(C2, C1).double(), h) + conv.bias.double()[None, :, None, None]
         assert rel_err(mm_b[..., 1], out.amax(-1)) < TOL and rel_err(mm_b[..., 0], out.amin(-1)) < TOL
+
+
+@pytest.mark.parametrize("b,ci,co,wide", [(16, 1024, 13184, 0), (32, 1024, 2048, 0), (2, 64, 64, 0), (5, 256, 512, 128), (1, 1024, 96, 0),
+                                          (33, 128, 77, 0)])
+def test_linear_rows_matches_fp64(b, ci, co, wide):
+    """fused.linear_rows (csrc/pointwise.hip linear_rows_kernel: the per-evaluation nn.Linear layers without BLAS) vs float64:
+    batch chunks (b > 16), a column slice of a wider weight (the global embedding's per-sample bias reads w[:, c1:]), ragged
+    channel counts, with and without bias"""
+    from p2p_bridge_amd import fused
+
+    torch.manual_seed(b + ci + co)
+    x = torch.randn(b, ci, device="cuda")
+    wfull = torch.randn(co, wide + ci, device="cuda") / ci ** 0.5
+    w = wfull[:, wide:]
+    bias = torch.randn(co, device="cuda") if co % 2 == 0 else None
+    y = fused.linear_rows(x, w, bias)
+    ref = x.double() @ w.double().t() + (bias.double() if bias is not None else 0.0)
+    mag = x.double().abs() @ w.double().abs().t() + 1.0
+    assert y.shape == (b, co)
+    assert ((y.double() - ref).abs() / mag).max().item() < 2e-6
+    assert torch.equal(fused.linear_rows(x, w, bias), y)  # deterministic
