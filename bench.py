@@ -183,6 +183,63 @@ def gemm_roofline(model, B, P, reps=10):
             "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
 
 
+HBM_PEAK_TBPS = 8.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# algorithmic bytes of the custom (index / gather / scatter) ops, MB per sample per network evaluation, PVDS @ N = 8192
+HBM_GROUPS = [
+    ("voxelize (a9-a10: coordinates, counting sort, gather into the voxel-major / pre-split grid)", 28.43,
+     ("voxel_coords_kernel", "vox_count_kernel", "vox_scan_kernel", "vox_fill_kernel", "vox_sort_kernel", "vox_gather_cl", "transpose_cn_kernel"),
+     "8 small launches per level on 16 clouds: the coordinate half (voxel_coords, count / scan / fill / sort: one workgroup per cloud "
+     "for the deterministic reductions and the scan) is latency-bound and runs on the geometry stream beside the dense layers; the "
+     "gathers move 60 % of the bytes at ~2 TB/s"),
+    ("devoxelize (a12)", 26.11, ("devox_cl_kernel",),
+     "8-corner gather of voxel-major rows (256 B per corner and point at C = 64): L2-resident grid, the point-major -> channel-major "
+     "transpose through LDS"),
+    ("grouping (a17: group_sub, the set abstraction's gathered first layer)", 19.86, ("group_sub_kernel",),
+     "row gathers of the ungrouped tensor (L2-resident: 1 MB per sample) + an LDS transpose; writes 32 x what it reads"),
+    ("3-NN interpolation (a19: cell grid build, search, interpolate + add)", 12.49,
+     ("three_nn_kernel", "three_nn_cells_kernel", "nn_cells_build_kernel", "three_interp_add_kernel"),
+     "search-bound, not byte-bound: 53.7 M pair distances per sample are the work (cell-grid search for m >= 512 centres, brute force "
+     "below); the bytes are what the reference's O(N M) scan would stream"),
+    ("ball query (a16)", 0.51, ("ball_query",), "compute-bound distance tests from LDS-resident clouds; 0.5 MB of output per sample"),
+    ("FPS (a14)", 0.14, ("fps_kernel", "fps_grid", "fps_coop"),
+     "a dependent chain of M - 1 argmax rounds per cloud (one workgroup each): latency-bound by construction, hidden on the geometry stream"),
+    ("gather (a15)", 0.08, ("gather_kernel",), "three coordinates per centre: launch-bound"),
+]
+
+
+def hbm_kernels(patches_per_chain):
+    """The HBM side of the roofline (SURVEY 8d 'per-kernel HBM fractions from rocprof alongside'): per custom-op group the
+    algorithmic bytes of one chain-evaluation (SURVEY's per-sample figure x the patches a sampler chain evaluates), the kernel
+    time per evaluation from the newest committed rocprofv3 kernel trace of this bench (profiles/r*_per_eval.csv, produced by
+    tools/profile_round.sh from the same command), and the fraction of the 8 TB/s HBM peak. Not measured live: it is a table
+    of profile data, the file it came from is named."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_per_eval.csv")), key=os.path.getmtime)
+    files = [f for f in files if "_c4_" not in f and "_c5_" not in f and "accumul" not in f and "partials" not in f]
+    if not files:
+        return None
+    src = files[-1]
+    rows = []
+    for line in open(src):
+        if line.startswith("#") or line.startswith("pct,"):
+            continue
+        parts = line.rstrip("\n").split(",", 4)
+        if len(parts) == 5:
+            rows.append((float(parts[3]), parts[4].strip('"')))
+    out = []
+    for name, mb, keys, why in HBM_GROUPS:
+        ms = sum(t for t, k in rows if any(key in k for key in keys))
+        if ms <= 0:
+            continue
+        nbytes = mb * 1e6 * patches_per_chain
+        tbps = nbytes / (ms * 1e-3) / 1e12
+        out.append({"group": name, "algorithmic_bytes": int(nbytes), "ms_per_eval": round(ms, 4), "TB_per_s": round(tbps, 3),
+                    "frac_of_8TBps": round(tbps / HBM_PEAK_TBPS, 4), "note": why})
+    return {"source": f"profiles/{os.path.basename(src)} (rocprofv3 --kernel-trace of bench.py, one {patches_per_chain}-patch chain-evaluation)",
+            "kernels": out}
+
+
 def conv_math_note():
     from p2p_bridge_amd import fused
 
@@ -324,6 +381,8 @@ def main():
         evals = args.T
         res["roofline"]["sampler_dense_tflops"] = round(
             61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval
+        chains = model._sampler_chains(x_start)
+        res["roofline"]["hbm_kernels"] = hbm_kernels(args.batch // chains)
         if world == 1 and "P2PB_CONV_MATH" not in os.environ and not args.no_alt_math:
             res["alt_math"] = alt_math_leg(cfg, sd, x_start, args)
         if world == 1 and not args.no_train_step:

@@ -288,10 +288,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
         for (int n = 0; n < 4; ++n) acc[m][n][r] = acc[m][n][r] * oscale + bv;
       }
   }
-  const bool full = pblk + 128 <= P;  // (ragged last tile: columns >= P are masked below)
-  bool cok[4];
-#pragma unroll
-  for (int n = 0; n < 4; ++n) cok[n] = pblk + n * 32 + l31 < P;
+  const bool full = pblk + 128 <= P;  // (wave-uniform; a ragged last tile masks its columns >= P in place below)
   if (out) {
     float *ob = out + (size_t)b * cout * P;
 #pragma unroll
@@ -301,7 +298,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
         const int co = co0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          if (cok[n]) ob[(size_t)co * P + pblk + n * 32 + l31] = acc[m][n][r];
+          if (pblk + n * 32 + l31 < P) ob[(size_t)co * P + pblk + n * 32 + l31] = acc[m][n][r];
       }
   }
   const int rm = l31 >> 4, rr = l31 & 15;
@@ -309,40 +306,34 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
   // ONE reduction set per wave (its 128 positions = two 64-position slots of the partials' layout): the four tiles of a row
   // are combined per lane first, then one reduce-scatter per statistic. The sums go to the wave's even slot and zero to the
   // odd one; the extrema (whose consumer takes a min / max over slots) go to both.
+  // Ragged tile (once per sample at most): columns >= P are set to ZERO in the accumulators before the sums, and to a copy of
+  // the row's first column (always valid) before the extrema -- the statistics code itself has one form and no masks.
   {
     const int slot = pblk >> 6;  // even
     const int nmine = 2 * (int)gridDim.x;  // slots the tiles of this launch own; [nmine, nslots) are zeroed by the last tile
     float tv[32];
+    if (!full) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const bool ok = pblk + n * 32 + l31 < P;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = ok ? acc[m][n][r] : 0.0f;
+      }
+    }
     if (stats_part) {
-      if (full) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) tv[m * 16 + r] = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
-      } else {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            tv[m * 16 + r] = ((cok[0] ? acc[m][0][r] : 0.0f) + (cok[1] ? acc[m][1][r] : 0.0f)) +
-                             ((cok[2] ? acc[m][2][r] : 0.0f) + (cok[3] ? acc[m][3][r] : 0.0f));
-      }
+        for (int r = 0; r < 16; ++r) tv[m * 16 + r] = (acc[m][0][r] + acc[m][1][r]) + (acc[m][2][r] + acc[m][3][r]);
       const float s1 = rowreduce32<RowAdd>(tv);
-      if (full) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            tv[m * 16 + r] = (acc[m][0][r] * acc[m][0][r] + acc[m][1][r] * acc[m][1][r]) +
-                             (acc[m][2][r] * acc[m][2][r] + acc[m][3][r] * acc[m][3][r]);
-      } else {
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            tv[m * 16 + r] = ((cok[0] ? acc[m][0][r] * acc[m][0][r] : 0.0f) + (cok[1] ? acc[m][1][r] * acc[m][1][r] : 0.0f)) +
-                             ((cok[2] ? acc[m][2][r] * acc[m][2][r] : 0.0f) + (cok[3] ? acc[m][3][r] * acc[m][3][r] : 0.0f));
-      }
+        for (int r = 0; r < 16; ++r)
+          tv[m * 16 + r] = (acc[m][0][r] * acc[m][0][r] + acc[m][1][r] * acc[m][1][r]) +
+                           (acc[m][2][r] * acc[m][2][r] + acc[m][3][r] * acc[m][3][r]);
       const float s2 = rowreduce32<RowAdd>(tv);
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
       q[0] = s1;
@@ -358,21 +349,27 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
         }
     }
     if (POOL && pool_u == 0) {
+      if (!full) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float first = __shfl(acc[m][0][r], khalf * 32);  // column pblk of this row (pblk < P)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n][r] = pblk + n * 32 + l31 < P ? acc[m][n][r] : first;
+          }
+      }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          tv[m * 16 + r] = full ? fminf(fminf(acc[m][0][r], acc[m][1][r]), fminf(acc[m][2][r], acc[m][3][r]))
-                                : fminf(fminf(cok[0] ? acc[m][0][r] : INFINITY, cok[1] ? acc[m][1][r] : INFINITY),
-                                        fminf(cok[2] ? acc[m][2][r] : INFINITY, cok[3] ? acc[m][3][r] : INFINITY));
+          tv[m * 16 + r] = fminf(fminf(acc[m][0][r], acc[m][1][r]), fminf(acc[m][2][r], acc[m][3][r]));
       const float mn = rowreduce32<RowMin>(tv);
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          tv[m * 16 + r] = full ? fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]))
-                                : fmaxf(fmaxf(cok[0] ? acc[m][0][r] : -INFINITY, cok[1] ? acc[m][1][r] : -INFINITY),
-                                        fmaxf(cok[2] ? acc[m][2][r] : -INFINITY, cok[3] ? acc[m][3][r] : -INFINITY));
+          tv[m * 16 + r] = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
       const float mx = rowreduce32<RowMax>(tv);
       // minmax f32[b, 2 * ceil(P / 128), cout, 2] (p2pb_pointwise_minmax_floats, split tiling): both slots of the tile
       float *q = mm_out + (((size_t)b * nmine + slot) * cout + rco) * 2;
