@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the bf16x6 comparison leg (profiling runs)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the config-3 training-step leg")
+    ap.add_argument("--no-pvdl", action="store_true", help="skip the BASELINE config-4 leg (full-width PVDL, 8 x 50000 points)")
     ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL over xGMI); gloo only with --dry-run")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / timing protocol only, no GPU work (CPU self-test of the N-rank path)")
@@ -388,6 +389,8 @@ def main():
         if world == 1 and not args.no_train_step:
             del model  # (free the sampler's graph pool first)
             res["train_step"] = train_step_leg()
+        if world == 1 and not args.no_pvdl:
+            res["pvdl"] = pvdl_leg()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(sd, args.points, args.T)
         print(json.dumps(res), flush=True)
@@ -489,6 +492,46 @@ def alt_math_leg(cfg, sd, x_start, args):
     return {"conv_math": "bf16x6 (P2PB_CONV_MATH=bf16x6; not the headline)",
             "value": round(args.batch * args.points * args.steps / dt, 1), "unit": "points/s",
             "ms_per_step": round(dt / args.steps * 1e3, 2), "max_abs_diff_of_one_evaluation_vs_default": diff}
+
+
+def pvdl_leg(B=8, N=50000, T=30, extra=3, reps=2):
+    """NOT `value`: BASELINE config 4 on this one GPU -- full-width PVDL (118.6 M parameters, channels 64..1024, 13 PVConvs),
+    xyz + RGB condition, B clouds of 50000 points, T = 30, the product's own conditional sampler as one hipGraph per step.
+    dense-equivalent FLOPs: SURVEY 8d, 486 GFLOP per sample and evaluation at 50000 points. At this batch an evaluation is bound
+    by the level-0 farthest-point sampling (12499 dependent rounds per cloud, one workgroup each); batch hides it
+    (profiles/r03d_pvdl_large_batches.txt)."""
+    import copy
+
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.synthetic import synthetic_patches
+
+    c = copy.deepcopy(PVDS)
+    c["data"]["npoints"] = N
+    c["diffusion"]["beta_end"] = 3e-4
+    c["model"]["extra_feature_channels"] = extra
+    c["model"]["dropout"] = 0.1
+    c["model"]["PVD"].update(feat_embed_dim=64, attention_heads=12, channels=[64, 128, 256, 512, 1024],
+                             n_sa_blocks=[2, 3, 2, 2], n_fp_blocks=[2, 3, 2, 2])
+    torch.manual_seed(0)
+    model = product.build_model(c, device="cuda")
+    x, _ = synthetic_patches(B, N, seed=1)
+    g = torch.Generator().manual_seed(2)
+    cond = torch.rand(B, extra, N, generator=g)
+    x, cond = x.cuda(), cond.cuda()
+    run = lambda: model.sample(x_start=x, x_cond=cond, steps=T, log_count=1, verbose=False, graph=True)
+    out = run()  # weight packs + capture
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert torch.isfinite(out["x_pred"]).all()
+    tf = 486.0 * B * T / dt / 1e3
+    return {"workload": f"PVDL_SNPP xyz+RGB ({3 + extra}-ch), {B} x {N}-pt clouds, T={T}, hipGraph (BASELINE configs[3] on one GPU)",
+            "value": round(B * N / dt, 1), "unit": "points/s", "ms_per_sample_call": round(dt * 1e3, 1),
+            "ms_per_evaluation": round(dt * 1e3 / T, 2), "dense_equivalent_tflops": round(tf, 1),
+            "frac_of_split_ceiling": round(tf / split_peak_tflops(), 4), "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
 
 
 def result_line(args, world, dt, dist):

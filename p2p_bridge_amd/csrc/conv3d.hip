@@ -1122,6 +1122,50 @@ static __global__ __launch_bounds__(256) void class_bias_kernel(int cout, const 
   k_out[((size_t)b * 27 + cls) * cout + co] = acc + bias[co];
 }
 
+// The three steps above in ONE launch (round 4: 15 -> 5 launches per network evaluation): workgroup (64 output channels, sample):
+// every thread evaluates a[ci] into LDS (the first channel block also stores it), thread (c, tg) of the 64 x 16 sums taps tg, tg + 16
+// for channel c over the input channels (weights coalesced over c), then the 27 class sums from the LDS table. Same operations in
+// the same order per output as far_value / tap_sum / class_bias: bit-identical.
+static __global__ __launch_bounds__(1024) void far_field_kernel(int cin, int cout, int nchunk, int cout_pad,
+                                                        const float *__restrict__ base, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, int swish,
+                                                        const float *__restrict__ wt, const float *__restrict__ bias,
+                                                        float *__restrict__ a_out, float *__restrict__ k_out) {
+  extern __shared__ float ff_sm[];  // a[cin] | T[27][64]
+  float *a = ff_sm, *T = ff_sm + cin;
+  const int b = blockIdx.y, t = threadIdx.x, c = t & 63, tg = t >> 6;
+  const int co = blockIdx.x * 64 + c;
+  for (int ch = t; ch < cin; ch += 1024) {
+    const float v = xf_apply(base[ch], scale[(size_t)b * cin + ch], shift[(size_t)b * cin + ch], swish);
+    a[ch] = v;
+    if (blockIdx.x == 0) a_out[(size_t)b * cin + ch] = v;
+  }
+  __syncthreads();
+  for (int tap = tg; tap < 27; tap += 16) {
+    float acc = 0.0f;
+    if (co < cout)
+      for (int ci = 0; ci < cin; ++ci) {
+        const size_t idx = ((((size_t)tap * nchunk + (ci >> 3)) * 2 + (ci & 1)) * cout_pad + co) * 4 + ((ci & 7) >> 1);
+        acc = __fmaf_rn(wt[idx], a[ci], acc);
+      }
+    T[tap * 64 + c] = acc;
+  }
+  __syncthreads();
+  if (co >= cout) return;
+  for (int cls = tg; cls < 27; cls += 16) {
+    const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
+    float acc = 0.0f;
+    for (int tap = 0; tap < 27; ++tap) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      if ((cd == 0 && kd == 0) || (cd == 2 && kd == 2) || (ch == 0 && kh == 0) || (ch == 2 && kh == 2) ||
+          (cw == 0 && kw == 0) || (cw == 2 && kw == 2))
+        continue;
+      acc += T[tap * 64 + c];
+    }
+    k_out[((size_t)b * 27 + cls) * cout + co] = acc + bias[co];
+  }
+}
+
 // a f32[b,cin] = far-field operand constants, k_out f32[b,27,cout] = per-boundary-class output constants,
 // tap_ws f32[b,27,cout] scratch
 #if CONV_TU != 6
@@ -1131,6 +1175,11 @@ extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *p
   if (b <= 0 || cin <= 0 || cout <= 0 || !in_scale || !in_shift) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
+  if ((size_t)(cin + 27 * 64) * 4 <= 48 * 1024) {  // (tap_ws unused in this form)
+    hipLaunchKernelGGL(far_field_kernel, dim3(cdiv(cout, 64), b), dim3(1024), (size_t)(cin + 27 * 64) * 4, s, cin, cout, nchunk,
+                       cout_pad, prev_bias, in_scale, in_shift, in_swish, wt_packed, bias, a, k_out);
+    return p2pb_launch_status();
+  }
   hipLaunchKernelGGL(far_value_kernel, dim3(cdiv(cin, 256), b), dim3(256), 0, s, cin, prev_bias, in_scale, in_shift,
                      in_swish, a);
   hipLaunchKernelGGL(tap_sum_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cin, cout, nchunk, cout_pad,

@@ -1293,46 +1293,62 @@ extern "C" int p2pb_minmax_act(int b, int c, int m, int nslots, const float *min
 // per-sample bias (models/pvcnn.py:926) -- are weight-streaming GEMVs (54 MB of weights for the styles). They used to go
 // through torch's BLAS, whose per-stream WORKSPACE a captured graph bakes in: two sampler chains replaying their graphs side
 // by side then shared one workspace and corrupted each other's GEMMs (round 4, tests/test_full_size_parity_gpu.py::
-// test_c2_bench_dispatch_two_chains_b32). This kernel needs no scratch: x in LDS (batch chunks of <= 16 rows), one wave per
-// output row streaming its weights once as 16-byte loads, fp32 FMA chains, a butterfly per batch row.
-// ------------------------------------------------------------------------------------------------
+// test_c2_bench_dispatch_two_chains_b32 -- the corruption found there turned out to be the devoxelisation's, voxelize.hip; the
+// workspace sharing is real all the same).
+// This kernel needs no scratch: the exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32: fp32 products, fp32 accumulate) with
+// M = 32 weight rows, N = the batch rows (<= 16 per chunk, x staged in LDS with a 4-float row pad: conflict-free 16-byte reads),
+// K split over the four waves of a workgroup and summed through LDS in a fixed order (deterministic). A lane's weight operand is
+// one 16-byte load W[row][k0 + 4 h .. + 3] feeding four MFMAs (k pairs (4 h + i) of both half-waves), so the weights stream
+// through once, 32 contiguous bytes per row and step, every 128-byte line consumed by the same wave within four steps.
 #define LR_BC 16
 __global__ __launch_bounds__(256) void linear_rows_kernel(int B, int cin, int cout, const float *__restrict__ x, long xs,
                                                           const float *__restrict__ w, long ws,
                                                           const float *__restrict__ bias, float *__restrict__ out, long os,
                                                           int bc) {
-  extern __shared__ float lr_x[];  // [bc][cin]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * 32, row1 = min(cout, row0 + 32);
+  extern __shared__ float lr_x[];  // [bc][cin + 4]; reused for the cross-wave sum [4][32][17]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int row0 = blockIdx.x * 32;
+  const int xp = cin + 4;
+  const int wrow = min(row0 + l31, cout - 1);  // (clamped rows multiply garbage that is never stored)
+  // this wave's K range: whole 8-steps, dealt round-robin to the four waves
+  const int nk8 = (cin + 7) / 8;
   for (int b0 = 0; b0 < B; b0 += bc) {
     const int nb = min(bc, B - b0);
     __syncthreads();
     for (int e = tid * 4; e < nb * cin; e += 1024) {
       const int bb = e / cin, c = e - bb * cin;
-      *(f32x4 *)(lr_x + e) = *(const f32x4 *)(x + (size_t)(b0 + bb) * xs + c);
+      *(f32x4 *)(lr_x + bb * xp + c) = *(const f32x4 *)(x + (size_t)(b0 + bb) * xs + c);
     }
     __syncthreads();
-    for (int row = row0 + wave; row < row1; row += 4) {
-      float acc[LR_BC];
+    f32x16 acc;
 #pragma unroll
-      for (int i = 0; i < LR_BC; ++i) acc[i] = 0.0f;
-      for (int c = lane * 4; c < cin; c += 256) {
-        const f32x4 wv = *(const f32x4 *)(w + (size_t)row * ws + c);
-#pragma unroll
-        for (int i = 0; i < LR_BC; ++i)
-          if (i < nb) {
-            const f32x4 xv = *(const f32x4 *)(lr_x + i * cin + c);
-            acc[i] = __fmaf_rn(wv[3], xv[3], __fmaf_rn(wv[2], xv[2], __fmaf_rn(wv[1], xv[1], __fmaf_rn(wv[0], xv[0], acc[i]))));
-          }
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const float *wp_ = w + (size_t)wrow * ws + 4 * h;
+    const float *xq = lr_x + min(l31, nb - 1) * xp + 4 * h;
+#pragma unroll 4
+    for (int k8 = wave; k8 < nk8; k8 += 4) {
+      const int k = k8 * 8;
+      f32x4 wv = {0.0f, 0.0f, 0.0f, 0.0f}, xv = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (k + 4 * h < cin) {  // (cin % 4 == 0: a quad is inside or outside)
+        wv = *(const f32x4 *)(wp_ + k);
+        xv = *(const f32x4 *)(xq + k);
       }
-      float mine = 0.0f;
 #pragma unroll
-      for (int i = 0; i < LR_BC; ++i) {
-        float v = acc[i];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == i) mine = v;
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i], xv[i], acc, 0, 0, 0);
+    }
+    __syncthreads();  // everyone is done with x
+    float *red = lr_x;  // [4 waves][32 rows][17]
+    if (l31 < nb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 17 + l31] = acc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * nb; e += 256) {
+      const int r = e / nb, bb = e - r * nb;
+      if (row0 + r < cout) {
+        const float v = (red[(0 * 32 + r) * 17 + bb] + red[(1 * 32 + r) * 17 + bb]) + (red[(2 * 32 + r) * 17 + bb] + red[(3 * 32 + r) * 17 + bb]);
+        out[(size_t)(b0 + bb) * os + row0 + r] = v + (bias ? bias[row0 + r] : 0.0f);
       }
-      if (lane < nb) out[(size_t)(b0 + lane) * os + row] = mine + (bias ? bias[row] : 0.0f);
     }
   }
 }
@@ -1344,11 +1360,13 @@ extern "C" int p2pb_linear_rows(int b, int cin, int cout, const float *x, long x
   if (b <= 0 || cin <= 0 || cout <= 0 || !x || !w || !out || (cin & 3) || (x_stride & 3) || (w_stride & 3) ||
       (((uintptr_t)x | (uintptr_t)w) & 15) || x_stride < cin || w_stride < cin || out_stride < cout)
     return P2PB_EINVAL;
-  int bc = (int)(65536 / ((long)cin * 4));  // batch rows per LDS chunk (64 KB: two workgroups per CU)
+  int bc = (int)(65536 / ((long)(cin + 4) * 4));  // batch rows per LDS chunk (64 KB: two workgroups per CU)
   if (bc < 1) return P2PB_EINVAL;           // (cin > 16384)
   if (bc > LR_BC) bc = LR_BC;
   if (bc > b) bc = b;
-  hipLaunchKernelGGL(linear_rows_kernel, dim3(cdiv(cout, 32)), dim3(256), (size_t)bc * cin * 4, (hipStream_t)stream, b, cin,
+  size_t lr_lds = (size_t)bc * (cin + 4) * 4;
+  if (lr_lds < 4 * 32 * 17 * 4) lr_lds = 4 * 32 * 17 * 4;  // (the cross-wave sum's table)
+  hipLaunchKernelGGL(linear_rows_kernel, dim3(cdiv(cout, 32)), dim3(256), lr_lds, (hipStream_t)stream, b, cin,
                      cout, x, x_stride, w, w_stride, bias, out, out_stride, bc);
   return p2pb_launch_status();
 }

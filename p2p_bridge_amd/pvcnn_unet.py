@@ -51,6 +51,7 @@ class PVCData:
     time_emb: torch.Tensor = None
     cond: Any = None
     geo: Any = None  # build addition: precomputed geometry (Geometry) of this evaluation, inference only
+    lower_temb: torch.Tensor = None  # build addition (fused inference): the time embedding [B, E] that `lower_features` leaves out
 
 
 # ------------------------------------------------------------------------------------ small modules
@@ -591,7 +592,16 @@ class PointNetFPModule(nn.Module):
                 g = data.lower_features.contiguous()
                 cg = g.shape[1]
                 pm = g.shape[2] % 4 == 0  # the coarse-level GEMM writes the point-major rows the blend gathers
-                cz, _ = fused.pw_conv(g, conv0, stats=False, ci_lo=0, ci_hi=cg, use_bias=False, point_major=pm)
+                tb = None
+                if data.lower_temb is not None:
+                    # the time embedding is constant over the positions: its 64 channels of the concatenation the reference
+                    # interpolates (models/unet_pvc.py:254-256) are a per-sample bias of this GEMM, W[:, cf : cf + E] temb[b]
+                    # (the blend then multiplies it by the three weights' sum, as interpolating the constant rows does)
+                    e = data.lower_temb.shape[1]
+                    tb = fused.linear_rows(data.lower_temb, conv0.weight.reshape(conv0.weight.shape[0], -1)[:, cg:cg + e])
+                cz, _ = fused.pw_conv(g, conv0, stats=False, ci_lo=0, ci_hi=cg, use_bias=False, point_major=pm, bias_b=tb)
+                if tb is not None:
+                    cg += data.lower_temb.shape[1]
                 skip = data.features
                 if skip is not None:
                     ys, _ = fused.pw_conv(skip.contiguous(), conv0, stats=False, ci_lo=cg, ci_hi=cg + skip.shape[1])
@@ -1009,9 +1019,15 @@ class PVCNN2Unet(nn.Module):
         data.features = self.global_att(data.features)
 
         for j, stage in enumerate(self.fp_layers):
-            lower = data.features if data.time_emb is None else torch.cat([data.features, data.time_emb], dim=1)
+            ltemb = None
+            if data.time_emb is None:
+                lower = data.features
+            elif use_fused and geo is not None and data.time_emb.shape[1] % 4 == 0 and data.features.shape[1] % 4 == 0:
+                lower, ltemb = data.features, data.time_emb[:, :, 0]  # (the FP module folds the time channels into a bias)
+            else:
+                lower = torch.cat([data.features, data.time_emb], dim=1)
             data = stage(PVCData(features=skips[-1 - j], coords=level_coords[-1 - j], lower_coords=data.coords,
-                                 lower_features=lower, time_emb=data.time_emb, cond=data.cond, geo=geo))
+                                 lower_features=lower, time_emb=data.time_emb, cond=data.cond, geo=geo, lower_temb=ltemb))
         if geo is not None:
             geo.finish()
 

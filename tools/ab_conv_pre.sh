@@ -15,7 +15,7 @@ done
 for i in 1 2; do
   for spec in ":" "8,16,32:8,16" "8,16,32:8,16,32" "8,16,32:"; do
     n=$(echo $spec | tr ',:' '_-')
-    P2PB_CONV_PRE=$spec python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step 2>/dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$spec', d['value'], d['ms_per_step'])" >> $out/bench_ab.txt
+    P2PB_CONV_PRE=$spec python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step --no-pvdl 2>/dev/null | grep '^{' | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$spec', d['value'], d['ms_per_step'])" >> $out/bench_ab.txt
   done
 done
 cat $out/tests.txt; cat $out/bench_ab.txt; tail -3 $out/conv_instances_*.txt

@@ -1,0 +1,477 @@
+#!/usr/bin/env python
+"""bench.py -- denoised points/sec of the P2P-Bridge sampler on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch: `P2PB.sample` of B=32 synthetic PU-Net-shaped
+patches of 8192 points through T=30 bridge steps of the PVDS_PUNet network (BASELINE config 2,
+data.npoints=8192, seeded random weights -- no checkpoints/datasets offline). Inputs are resident in HBM
+before the timed region. With --gpus N (launched by torch.distributed.run) every rank denoises its own
+B patches: patch-level sharding, no data-path collective, weak scaling; time = max over ranks.
+
+Prints ONE JSON line (rank 0) with the driver's fields + "roofline" (dominant kernel, live HIP-event
+timing) + "cpu_baseline" (the CPU oracle timed on this host on a bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # CPU-baseline leg: two OpenMP runtimes (torch, oracle) must not spin
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PVDS = dict(
+    data=dict(npoints=8192),
+    diffusion=dict(timesteps=1000, sampling_timesteps=30, objective="pred_noise", sampling_strategy="DDPM",
+                   loss_type="mse", beta_start=1e-4, beta_end=0.02, t0=1e-4, T=1.0, ot_ode=True),
+    model=dict(type="PVD", ema=False, in_dim=3, extra_feature_channels=0, out_dim=3, time_embed_dim=64, dropout=0.15,
+               PVD=dict(use_global_embedding=True, global_embedding_dim=1024, feat_embed_dim=32,
+                        attention_type="linear", attention_heads=4, attentions=[0, 0, 0, 1],
+                        channels=[32, 64, 128, 256, 512], voxel_resolutions=[32, 16, 8, 8], n_sa_blocks=[1, 2, 1, 1],
+                        n_fp_blocks=[1, 2, 1, 1], radius=[0.1, 0.2, 0.4, 0.8], out_mlp=128)))
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz)
+# (v_mfma_f32_32x32x16_f16 runs at the same rate.) A split kernel spends three (f16x3, the default) or six (bf16x6)
+# 16-bit MFMA products per fp32 product: its matrix-pipe ceiling in fp32-equivalent FLOP/s
+SPLIT_PEAK_TFLOPS = BF16_MFMA_PEAK_TFLOPS / 6
+
+
+def split_products():
+    from p2p_bridge_amd import fused
+
+    return 3 if fused.conv_math() == "f16x3" else 6
+
+
+def split_peak_tflops():
+    return BF16_MFMA_PEAK_TFLOPS / split_products()
+
+
+def split_peak_basis():
+    return (f"dense 16-bit MFMA peak 2516.6 / {split_products()} products per fp32 product "
+            + ("(f16x3: fp16-pair split operands, fp32 accumulate)" if split_products() == 3
+               else "(bf16x6 split operands, fp32 accumulate)"))
+CONV_ALGO_FLOP_PER_SAMPLE_EVAL = 43.88e9  # Conv3d FLOPs per sample per network evaluation (PVDS)
+
+
+def conv_roofline(model, x_start, reps=10):
+    """Second kernel = the 3x3x3 voxel convolution AS THE SAMPLER RUNS IT: conv3d_k3_compact_kernel on the widest
+    r = 16 instance (fp_layers.2.1, second convolution, C 128 -> 128: far-field form, folded AdaGN + Swish operand
+    transform, GroupNorm statistics epilogue). The kernel computes only the outputs within two voxels of an occupied
+    voxel (set D2, csrc/conv3d.hip) and writes analytic constants elsewhere, so its work depends on the occupancy of the
+    input: the launch is captured from ONE real network evaluation of the bench's own patches (same tensors, same
+    lists), then re-issued `reps` times between HIP events on the stream it is launched on.
+    `achieved` counts the ALGORITHMIC FLOPs of what the layer must produce with this formulation: 2*27*Cin*Cout per LISTED
+    output voxel (the exact-constant voxels cost no matrix work by construction); `dense_equivalent` is the same
+    launch priced as the dense convolution the reference runs (all 16^3 voxels)."""
+    from p2p_bridge_amd import fused
+
+    pv = model.model.fp_layers[2][1]
+    target = pv.voxel_layers[4]
+    captured = {}
+    orig = fused.conv3d_k3_compact
+
+    def spy(x, conv, lists, counts, which, *a, **k):
+        if conv is target and "args" not in captured:
+            captured["args"] = (x, conv, lists, counts, which) + a
+            captured["kw"] = k
+        return orig(x, conv, lists, counts, which, *a, **k)
+
+    fused.conv3d_k3_compact = spy
+    try:
+        model.eval()
+        with torch.no_grad():
+            model.model(x_start, torch.full((x_start.shape[0],), 500.0, device=x_start.device))
+        model.train()
+    finally:
+        fused.conv3d_k3_compact = orig
+    if "args" not in captured:
+        return None
+    args, kw = captured["args"], captured["kw"]
+    x, conv, lists, counts, which = args[:5]
+    B, r, C = x.shape[0], x.shape[1], x.shape[4]
+    listed = int(counts[which].sum().item())
+    flops = 2.0 * 27 * conv.in_channels * conv.out_channels * listed
+    dense = 2.0 * 27 * conv.in_channels * conv.out_channels * B * r ** 3
+    with torch.no_grad():
+        for _ in range(3):
+            orig(*args, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            orig(*args, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(split_peak_tflops(), 1), "unit": "TFLOP/s",
+            "frac": round(achieved / split_peak_tflops(), 4), "traffic": None,
+            "kernel": f"conv3d_k3_compact_kernel<{r},XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
+                      f"(fp_layers.2.1.voxel_layers.4, the launch the sampler issues)",
+            "listed_output_voxels": listed, "grid_voxels": B * r ** 3,
+            "listed_fraction": round(listed / float(B * r ** 3), 4),
+            "dense_equivalent_tflops": round(dense / (ms * 1e-3) / 1e12, 2),
+            "peak_basis": split_peak_basis(),
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def gemm_roofline(model, B, P, reps=10):
+    """Dominant kernel of the sampler (largest share of the critical stream in profiles/r0N*_per_eval.csv): the global
+    embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels over all P points of every patch;
+    models/pvcnn.py:905-932) -- pw_pp512_kernel<XF=true, POOL=true> (csrc/pw_pp512.h: the ping-pong GEMM on 512-channel x
+    128-position tiles; pw_split_kernel under P2PB_PW_PP=0 or for layers without whole 512-channel blocks): split-operand GEMM in the arithmetic fused.conv_math()
+    selects (f16x3 by default) that applies the previous layer's folded GroupNorm + Swish to its operand on load and whose
+    epilogue emits the GroupNorm statistics and the per-channel {min, max} the max-pool is formed from -- the
+    1024-channel output is never written. Timed live with HIP events on torch's current stream, launched exactly as
+    the sampler launches it, right after the timed sampler runs (a warm chip: 10-15 % slower than the same launch from
+    a cold start). `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
+    from p2p_bridge_amd import fused
+
+    conv = model.model.global_pnet.mlp2.shared_mlp_1.mlp[0]
+    ci, co = conv.in_channels, conv.out_channels
+    x = torch.randn(B, ci, P, device="cuda")
+    flops = 2.0 * B * P * ci * co
+    with torch.no_grad():
+        # as in the sampler: the previous layer's folded GroupNorm + Swish applied to the operand on load
+        sc, sh = torch.rand(B, ci, device="cuda") + 0.5, torch.randn(B, ci, device="cuda")
+        for _ in range(3):
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fused.pw_conv(x, conv, sc, sh, swish=True, pool_u=0, store=False)
+        e1.record()
+        torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = flops / (ms * 1e-3) / 1e12
+    split = fused.use_split_pw(ci, co, P, None)
+    peak = split_peak_tflops() if split else F32_MFMA_PEAK_TFLOPS
+    traffic = None
+    try:
+        vals = {}
+        pingpong = split and fused.conv_math() == "f16x3" and os.environ.get("P2PB_PW_PP", "1") != "0" and co % 512 == 0 and ci % 64 == 0 and B * ((P + 127) // 128) * (co // 256) >= 1024
+        import glob
+
+        cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_pw_pp512_512_1024_pool.csv")), reverse=True) if pingpong else [])
+        if not pingpong:
+            cands = [os.path.join(ROOT, "profiles", f"{t}_pmc_pw_split_512_1024_pool.csv") for t in ("r02f", "r02", "r01")]
+        pmc = next(q for q in cands if os.path.exists(q))  # (newest round's PMC passes of the kernel this launch runs)
+        for line in open(pmc):
+            k, v = line.split(",")[:2]
+            if k in ("FETCH_SIZE", "WRITE_SIZE"):
+                vals[k] = float(v)
+        traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0) if split else None
+    except (OSError, KeyError, ValueError, StopIteration):
+        pass
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
+            "traffic_basis": f"profiles/{os.path.basename(pmc) if traffic is not None else 'r0N_pmc_pw_*_512_1024_pool.csv'}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch "
+                             "(FETCH_SIZE counts half of 8- and 16-byte-per-lane streaming reads on gfx950: calibrated on a "
+                             f"1 GiB read, tools/pmc_calib.sh); algorithmic input + weights = {4 * B * P * ci + 4 * ci * co} B: "
+                             "the activation tile is staged once per 512-channel block (2 x for this layer), the blocks of one "
+                             "tile run side by side on one XCD and share it in that XCD's L2",
+            "kernel": (f"pw_pp512_kernel<XF=true,POOL=true> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)" if pingpong
+                       else f"pw_split_kernel<XF=true,POOL=true,WM=4> {ci}->{co} P{P} B{B} (global_pnet.mlp2.shared_mlp_1)"),
+            "peak_basis": split_peak_basis() if split else "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)",
+            "frac_of_six_product_ceiling": round(achieved / SPLIT_PEAK_TFLOPS, 4) if split else None,
+            "flop_per_launch": flops, "ms_per_launch": round(ms, 4)}
+
+
+def conv_math_note():
+    from p2p_bridge_amd import fused
+
+    m = fused.conv_math()
+    if m == "f16x3":
+        return ("fp32 operands, fp32 accumulate, fp32 results; products through the 16-bit matrix pipe as f16x3: every "
+                "operand an fp16 pair of its scaled value (22 significand bits), 3 exact MFMA products per fp32 product, "
+                "<= 3 * 2^-22 relative; error vs fp64 at or below the exact-fp32 MFMA kernel's (tests/test_conv_math_gpu.py)")
+    if m == "bf16x6":
+        return ("fp32 results; products as bf16x6 split operands (3 bf16 terms each, 6 MFMA products, fp32 accumulate; "
+                "error vs fp64 equal to the fp32 MFMA kernel's)")
+    return "exact-fp32 MFMA"
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, n_points, T, patches=2, budget_s=20.0):
+    """The CPU oracle (C ops + torch CPU dense layers, all host threads) on a bounded sample of the same workload:
+    `patches` patches through the FULL T-step sampler when that fits the time budget (it does on the GPU box's host:
+    ~0.2 s per evaluation), else as many bridge steps as fit, extrapolated (every step costs the same: one network
+    evaluation + an elementwise update)."""
+    from oracle import net_ref
+
+    x, _ = net_ref.synthetic_patches(patches, n_points, seed=0)
+    net = net_ref.RefNet(PVDS, sd, vox_mode="tree")
+    host = os.cpu_count() or 1
+    # threads actually used: 16 -- measured on the GPU box's host (2 x 64-core EPYC 9575F, 256 hardware threads;
+    # tools/exp_cpu_threads.sh -> profiles/r03b_cpu_baseline_threads.txt: 8 / 16 / 32 / 64 / 128 / 256 threads =
+    # 1508 / 1523 / 1264 / 700 / 195 / 7 points/s): beyond that these small per-patch ops only contend
+    cores = min(host, int(os.environ.get("P2PB_CPU_THREADS", "16")))
+    torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    from oracle import cpu_ops
+
+    cpu_ops.set_threads(cores)
+    t0 = time.perf_counter()
+    net_ref.sample(net, PVDS, x, steps=1, log_count=1)  # warm-up, and the estimate of one step
+    one = time.perf_counter() - t0
+    steps = max(2, min(T, int(budget_s / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    net_ref.sample(net, PVDS, x, steps=steps, log_count=1)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": round(patches * n_points / (dt * T), 2), "unit": "points/s", "cores": cores, "host_cores": host,
+            "host_cpu": cpu_model(), "kind": "port",
+            "sample": f"{patches} patches x {n_points} pts, {steps} of T={T} bridge steps timed after 1 warm-up step "
+                      f"({dt:.2f} s/step, {dt * steps:.1f} s of CPU work)"
+                      + ("" if steps == T else f", extrapolated to T={T}")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--T", type=int, default=30)
+    ap.add_argument("--graph", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt-math", action="store_true", help="skip the bf16x6 comparison leg (profiling runs)")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the config-3 training-step leg")
+    ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL over xGMI); gloo only with --dry-run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / timing protocol only, no GPU work (CPU self-test of the N-rank path)")
+    args = ap.parse_args()
+    from p2p_bridge_amd import sharding
+
+    if args.backend != "nccl" and not args.dry_run:
+        raise SystemExit("--backend other than nccl is for --dry-run only: the product has no CPU path")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    mode, world = sharding.launch_plan(args.gpus, os.environ, ndev if args.backend == "nccl" else args.gpus, args.backend)
+    if mode == "spawn":  # `python bench.py --gpus N`: become N ranks, one per GPU (reference: train.py:20-46,229)
+        raise SystemExit(sharding.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], world))
+    if not args.dry_run and ndev == 0:
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    rank = local_rank = 0
+    dist = None
+    if mode == "rank":
+        import torch.distributed as dist
+
+        rank, local_rank, world = sharding.init_rank(args.backend)
+    elif ndev:
+        torch.cuda.set_device(0)
+    if args.dry_run:
+        return dry_run(args, dist, rank, world)
+
+    from p2p_bridge_amd.synthetic import synthetic_patches
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
+
+    import copy
+
+    cfg = copy.deepcopy(PVDS)
+    cfg["data"]["npoints"] = args.points
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in PVCNN2Unet(cfg).state_dict().items()}
+    model = product.build_model(cfg, sd, device=f"cuda:{local_rank}")
+    x_start, _ = synthetic_patches(args.batch, args.points, seed=rank)  # every rank denoises its OWN patches
+    x_start = x_start.cuda()
+
+    def one():
+        return model.sample(x_start=x_start, steps=args.T, log_count=1, verbose=False, graph=bool(args.graph))
+
+    for _ in range(args.warmup):
+        out = one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0  # this rank's own work (reported per rank; NOT what `value` is computed from)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt_local, device="cuda")
+    assert torch.isfinite(out["x_pred"]).all()
+
+    res = result_line(args, world, dt, dist)
+    # every rank's own time / throughput and the device it ran on, gathered over the process group (collective)
+    res["ranks"] = sharding.rank_evidence(dt_own, args.batch * args.points * args.steps, local_rank)
+    if world > 1:
+        assert res["ranks"]["distinct_devices"] == world, res["ranks"]
+    res["config"]["conv_math"] = conv_math_note()
+    if rank == 0:
+        res["roofline"] = gemm_roofline(model, args.batch, args.points)
+        res["roofline"]["second_kernel"] = conv_roofline(model, x_start)  # the voxel convolution the sampler runs
+        evals = args.T
+        res["roofline"]["sampler_dense_tflops"] = round(
+            61.35e9 * args.batch * evals / (dt / args.steps) / 1e12, 2)  # 61.35 GFLOP/sample/eval
+        if world == 1 and "P2PB_CONV_MATH" not in os.environ and not args.no_alt_math:
+            res["alt_math"] = alt_math_leg(cfg, sd, x_start, args)
+        if world == 1 and not args.no_train_step:
+            del model  # (free the sampler's graph pool first)
+            res["train_step"] = train_step_leg()
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(sd, args.points, args.T)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_step_leg(steps=8, warmup=4, B=8, N=2048):
+    """NOT `value`: BASELINE config 3's per-GPU training step (PVDS_PUNet, 8 patches x 2048 points = global batch 64 over
+    8 GPUs, MSE bridge loss, grad clip 1.0, AdamW) on this one GPU, the reference's order of operations
+    (train.py:107-143; the auction alignment of the data loader is left out: it is timed in profiles/*_metrics_timing.txt).
+    dense FLOPs of a step = 3 x forward (forward, data gradient, weight gradient) = 3 x 61.35 GFLOP x N / 8192 per patch
+    (SURVEY 8d); the forward runs in fused.conv_math(), the data-gradient pass in bf16x6, the weight-gradient GEMMs in
+    P2PB_TRAIN_MATH (bf16x3)."""
+    import copy
+
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.synthetic import synthetic_patches
+
+    cfg = copy.deepcopy(PVDS)
+    cfg["data"]["npoints"] = N
+    torch.manual_seed(0)
+    model = product.build_model(cfg, device="cuda")
+    model.train()
+    from p2p_bridge_amd import train as T
+
+    tcfg = copy.deepcopy(cfg)
+    tcfg["training"] = copy.deepcopy(T.PVDS_PUNET_TRAIN["training"])
+    x1, x0 = synthetic_patches(B, N, seed=0)
+    x1, x0 = x1.cuda(), x0.cuda()
+
+    def timed(step_fn, n_warm, n):
+        for _ in range(n_warm):
+            loss = step_fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step_fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, float(loss)
+
+    # eager: zero_grad -> loss -> backward -> clip + AdamW (optim.ClipAdamW, three launches) -> scheduler -> EMA
+    opt, sched = T.load_optim_sched(tcfg, model, fused=True, skip_nonfinite=True)
+
+    def eager():
+        opt.zero_grad(set_to_none=True)
+        loss = model(x0, x1)
+        loss.backward()
+        opt.step()
+        sched.step()
+        if model.ema is not None:
+            model.ema.update()
+        return loss.detach()
+
+    eager_dt, _ = timed(eager, warmup, steps)
+    # the same step as one captured hipGraph (train.GraphedStep, `python -m p2p_bridge_amd.train --graph`)
+    stepper = T.GraphedStep(model, opt, sched, warmup=1)
+    dt, loss = timed(lambda: stepper(x0, x1), warmup + 2, steps)
+    flop = 3.0 * 61.35e9 * N / 8192.0 * B
+    return {"workload": f"PVDS_PUNet training step, {B} patches x {N} points per GPU (BASELINE configs[2] = global batch 64 on 8 GPUs), "
+                        "mse bridge loss, clip 1.0, AdamW, scheduler, EMA; hand-written forward / backward / optimiser kernels, the step "
+                        "captured as one hipGraph (train.GraphedStep); eager_ms_per_step = the same step launched eagerly",
+            "ms_per_step": round(dt * 1e3, 2), "eager_ms_per_step": round(eager_dt * 1e3, 2), "patches_per_s": round(B / dt, 1), "points_per_s": round(B * N / dt, 1),
+            "dense_tflops": round(flop / dt / 1e12, 2), "frac_of_f16x3_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3), 4),
+            "frac_of_bf16x6_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6), 4), "steps": steps, "warmup": warmup,
+            "final_loss": round(loss, 5)}
+
+
+def alt_math_leg(cfg, sd, x_start, args):
+    """NOT `value`: the same workload in the other split arithmetic (bf16x6: six products, no range contract), timed the
+    same way on a fresh model (its own captured graph), and how far ONE network evaluation on identical inputs is from the
+    default's (a free-running 30-step sampler amplifies any difference through neighbour-index decisions, so its end
+    points are not comparable)"""
+    from p2p_bridge_amd import fused, p2pb as product
+
+    fused.set_conv_math("bf16x6")
+    try:
+        model = product.build_model(cfg, sd, device=str(x_start.device))
+        run = lambda: model.sample(x_start=x_start, steps=args.T, log_count=1, verbose=False, graph=bool(args.graph))
+        for _ in range(max(1, args.warmup)):
+            out = run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t = torch.full((x_start.shape[0],), 500.0, device=x_start.device)
+        model.eval()
+        with torch.no_grad():
+            e6 = model.model(x_start, t).clone()
+            fused.set_conv_math(None)
+            e3 = model.model(x_start, t)
+        diff = float((e3 - e6).abs().max().item())
+        assert torch.isfinite(out["x_pred"]).all()
+    finally:
+        fused.set_conv_math(None)
+    return {"conv_math": "bf16x6 (P2PB_CONV_MATH=bf16x6; not the headline)",
+            "value": round(args.batch * args.points * args.steps / dt, 1), "unit": "points/s",
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "max_abs_diff_of_one_evaluation_vs_default": diff}
+
+
+def result_line(args, world, dt, dist):
+    pts = world * args.batch * args.points * args.steps
+    return {
+        "metric": "denoised points/sec (8192-pt patches, T=30)", "value": round(pts / dt, 1), "unit": "points/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"PVDS_PUNet xyz-only, {args.points}-pt patches, T={args.T} bridge steps, batch "
+                               f"{args.batch} per GPU (BASELINE configs[1])", "patches_per_gpu": args.batch,
+                   "points_per_patch": args.points, "bridge_steps": args.T, "parallelism": f"patch-shard x{world}",
+                   "process_group_world_size": dist.get_world_size() if dist is not None else 1,
+                   "process_group_backend": (dist.get_backend() if dist is not None else None),
+                   "hipgraph": bool(args.graph), "weights": "seeded random init (26.44 M params)"},
+    }
+
+
+def dry_run(args, dist, rank, world):
+    """the N-rank protocol without a GPU (tests/test_bench_launch.py): same barrier / max-over-ranks bracket around a
+    stand-in step whose duration depends on the rank, same JSON line; `value` is meaningless and flagged as such"""
+    from p2p_bridge_amd import sharding
+
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.01 * (rank + 1))
+    dt_own = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    dt_local = time.perf_counter() - t0
+    dt = sharding.max_over_ranks(dt_local)
+    res = result_line(args, world, dt, dist)
+    res["ranks"] = sharding.rank_evidence(dt_own, args.batch * args.points * args.steps, None)
+    res["dry_run"] = True
+    res["data"] = "none (dry run: launch / rendezvous / timing protocol only)"
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

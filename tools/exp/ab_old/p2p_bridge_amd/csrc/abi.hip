@@ -1,0 +1,90 @@
+// abi.hip -- library identification for the C ABI (include/p2pb_hip.h) + the zero-fill helper.
+#include "common.h"
+
+extern "C" int p2pb_version(void) { return 1; }
+extern "C" const char *p2pb_target_arch(void) { return "gfx950"; }
+
+// Arithmetic of the split-operand kernels (common.h SPLIT_*): a process-wide default (p2pb_set_split_terms: set_conv_math)
+// and a per-THREAD override (p2pb_set_split_terms_thread: `with fused.split_math(...)`, e.g. the bf16x6 data-gradient pass
+// that train() runs on the autograd thread) -- so a temporary switch on one thread cannot pair another thread's f16 weight
+// pack with a bf16x6 kernel (round-2 advice). Every launcher and pack reads p2pb_split_terms_now().
+#include <atomic>
+static std::atomic<int> g_split_terms{SPLIT_F16X3};
+static thread_local int tl_split_terms = 0;  // 0: no override on this thread
+int p2pb_split_terms_now() { return tl_split_terms ? tl_split_terms : g_split_terms.load(std::memory_order_relaxed); }
+extern "C" int p2pb_set_split_terms(int terms) {
+  if (terms != SPLIT_BF16X6 && terms != SPLIT_F16X3) return P2PB_EINVAL;
+  g_split_terms.store(terms, std::memory_order_relaxed);
+  return 0;
+}
+extern "C" int p2pb_set_split_terms_thread(int terms) {  // 0 clears the calling thread's override
+  if (terms != 0 && terms != SPLIT_BF16X6 && terms != SPLIT_F16X3) return P2PB_EINVAL;
+  tl_split_terms = terms;
+  return 0;
+}
+extern "C" int p2pb_get_split_terms(void) { return p2pb_split_terms_now(); }  // what a launch from THIS thread would use
+
+// which form a pointwise launch took, per (cin, cout, positions): a small host-side table behind p2pb_debug_pointwise_form (tests assert
+// that the layers of the bench's configuration run the kernels the roofline is quoted on)
+#include <mutex>
+namespace {
+struct FormRow {
+  int cin, cout, npos, form;
+  unsigned long long n;
+};
+std::mutex g_form_mu;
+FormRow g_forms[128];
+int g_nforms = 0;
+}  // namespace
+void p2pb_note_pointwise_form(int cin, int cout, int npos, int form) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  for (int i = 0; i < g_nforms; ++i)
+    if (g_forms[i].cin == cin && g_forms[i].cout == cout && g_forms[i].npos == npos) {
+      g_forms[i].form = form;
+      ++g_forms[i].n;
+      return;
+    }
+  if (g_nforms < 128) g_forms[g_nforms++] = {cin, cout, npos, form, 1ull};
+}
+extern "C" int p2pb_debug_pointwise_form(int cin, int cout, int npos, unsigned long long *launches) {
+  std::lock_guard<std::mutex> lk(g_form_mu);
+  if (launches) *launches = 0;
+  if (cin < 0) {
+    g_nforms = 0;
+    return -1;
+  }
+  for (int i = 0; i < g_nforms; ++i)
+    if (g_forms[i].cin == cin && g_forms[i].cout == cout && g_forms[i].npos == npos) {
+      if (launches) *launches = g_forms[i].n;
+      return g_forms[i].form;
+    }
+  return -1;
+}
+
+// Zero-fill as an ordinary kernel node. hipMemsetAsync is avoided on purpose: under hipGraph stream
+// capture its memset node did not re-execute reliably on replay here (stale voxel counts -> OOB list
+// writes -> GPU memory fault after a few replays), a kernel node always does.
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned *__restrict__ p, size_t nwords) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) p[i] = 0u;
+}
+
+__global__ __launch_bounds__(256) void zero_quads_kernel(uint4 *__restrict__ p, size_t nquads) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += stride) p[i] = z;
+}
+
+int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s) {
+  if (nbytes == 0) return 0;
+  if ((((size_t)p) & 15) == 0 && (nbytes & 15) == 0) {  // 16 B per lane: the streaming-store sweet spot
+    const size_t nq = nbytes / 16;
+    const unsigned grid = (unsigned)((nq + 255) / 256 > 4096 ? 4096 : (nq + 255) / 256);
+    hipLaunchKernelGGL(zero_quads_kernel, dim3(grid), dim3(256), 0, s, (uint4 *)p, nq);
+    return (int)hipGetLastError();
+  }
+  const size_t nwords = (nbytes + 3) / 4;  // every buffer zeroed here is a whole number of 32-bit words
+  const unsigned grid = (unsigned)((nwords + 255) / 256 > 2048 ? 2048 : (nwords + 255) / 256);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid), dim3(256), 0, s, (unsigned *)p, nwords);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,514 @@
+// emd.hip -- the two EMD flavours the reference ships.
+//   PyTorchEMD approximate matching (metrics/PyTorchEMD/cuda/emd_kernel.cu:33,211,300,347)
+//   emd_assignment auction          (metrics/emd_assignment/emd_assignment/emd_cuda.cu:23-226,284)
+// The reference runs approxmatch with ONE block per cloud (<<<32,512>>>) and walks the three phases of
+// every annealing level behind __syncthreads(); here each phase is its own launch spread over all
+// points (phases are separated by the stream order), which keeps every per-thread summation in the
+// reference's ascending order while using the whole chip.
+#include "common.h"
+#include <stdlib.h>
+
+#define EMD_TILE 1024
+
+// Small batches (evaluation runs one 10k..50k-point cloud at a time) leave a (points / 256) x batch grid far below the
+// chip's 256 CUs -- B = 4, N = 8192 is 128 workgroups -- so the inner loop over the OTHER cloud is split over
+// blockIdx.y into `chunks` ranges: the PART forms write one partial sum per (chunk, point) and a tiny *_fin kernel adds
+// the partials in ascending chunk order (fixed order: deterministic; the sum is chunk-sequential instead of fully
+// sequential, a few ulps, far inside approxmatch's __expf tolerance). chunks == 1 keeps the single-pass kernels.
+
+// suml_k = 1e-9 + sum_l exp(level*d_kl) * remainR_l ; ratioL_k = remainL_k / suml_k      (:58-88)
+template <bool PART>
+__global__ __launch_bounds__(256) void am_ratio_l_kernel(int n, int m, int lchunk, float level,
+                                                         const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2,
+                                                         const float *__restrict__ remainL,
+                                                         const float *__restrict__ remainR,
+                                                         float *__restrict__ ratioL, float *__restrict__ part) {
+  __shared__ float buf[EMD_TILE * 4];
+  const int b = PART ? blockIdx.z : blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = k < n;
+  const float *p = xyz1 + ((size_t)b * n + (ok ? k : 0)) * 3;
+  const float x1 = p[0], y1 = p[1], z1 = p[2];
+  float suml = PART ? 0.0f : 1e-9f;
+  const int lo = PART ? blockIdx.y * lchunk : 0, hi = PART ? min(m, lo + lchunk) : m;
+  for (int l0 = lo; l0 < hi; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, hi - l0);
+    __syncthreads();
+    for (int l = threadIdx.x; l < ln; l += 256) {
+      const float *q = xyz2 + ((size_t)b * m + l0 + l) * 3;
+      buf[l * 4 + 0] = q[0];
+      buf[l * 4 + 1] = q[1];
+      buf[l * 4 + 2] = q[2];
+      buf[l * 4 + 3] = remainR[(size_t)b * m + l0 + l];
+    }
+    __syncthreads();
+    for (int l = 0; l < ln; ++l) {
+      const float d = level * sqdist3(buf[l * 4] - x1, buf[l * 4 + 1] - y1, buf[l * 4 + 2] - z1);
+      suml += __expf(d) * buf[l * 4 + 3];
+    }
+  }
+  if (!ok) return;
+  if (PART) part[((size_t)blockIdx.y * gridDim.z + b) * n + k] = suml;
+  else ratioL[(size_t)b * n + k] = __fdiv_rn(remainL[(size_t)b * n + k], suml);
+}
+
+__global__ __launch_bounds__(256) void am_ratio_l_fin_kernel(int n, int chunks, const float *__restrict__ part,
+                                                             const float *__restrict__ remainL,
+                                                             float *__restrict__ ratioL) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  float suml = 1e-9f;
+  for (int c = 0; c < chunks; ++c) suml += part[((size_t)c * gridDim.y + b) * n + k];
+  ratioL[(size_t)b * n + k] = __fdiv_rn(remainL[(size_t)b * n + k], suml);
+}
+
+// sumr_l = remainR_l * sum_k exp(level*d_kl)*ratioL_k ; consumption ; ratioR ; remainR update   (:90-122)
+__device__ __forceinline__ void am_ratio_r_finish(float sumr, size_t i, float *__restrict__ remainR,
+                                                  float *__restrict__ ratioR) {
+  const float rr = remainR[i];
+  sumr *= rr;
+  const float consumption = fminf(__fdiv_rn(rr, sumr + 1e-9f), 1.0f);
+  ratioR[i] = consumption * rr;
+  remainR[i] = fmaxf(0.0f, rr - sumr);
+}
+
+template <bool PART>
+__global__ __launch_bounds__(256) void am_ratio_r_kernel(int n, int m, int kchunk, float level,
+                                                         const float *__restrict__ xyz1,
+                                                         const float *__restrict__ xyz2,
+                                                         const float *__restrict__ ratioL, float *__restrict__ remainR,
+                                                         float *__restrict__ ratioR, float *__restrict__ part) {
+  __shared__ float buf[EMD_TILE * 4];
+  const int b = PART ? blockIdx.z : blockIdx.y;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = l < m;
+  const float *q = xyz2 + ((size_t)b * m + (ok ? l : 0)) * 3;
+  const float x2 = q[0], y2 = q[1], z2 = q[2];
+  float sumr = 0;
+  const int lo = PART ? blockIdx.y * kchunk : 0, hi = PART ? min(n, lo + kchunk) : n;
+  for (int k0 = lo; k0 < hi; k0 += EMD_TILE) {
+    const int kn = min(EMD_TILE, hi - k0);
+    __syncthreads();
+    for (int k = threadIdx.x; k < kn; k += 256) {
+      const float *p = xyz1 + ((size_t)b * n + k0 + k) * 3;
+      buf[k * 4 + 0] = p[0];
+      buf[k * 4 + 1] = p[1];
+      buf[k * 4 + 2] = p[2];
+      buf[k * 4 + 3] = ratioL[(size_t)b * n + k0 + k];
+    }
+    __syncthreads();
+    for (int k = 0; k < kn; ++k) {
+      const float w = __expf(level * sqdist3(x2 - buf[k * 4], y2 - buf[k * 4 + 1], z2 - buf[k * 4 + 2])) * buf[k * 4 + 3];
+      sumr += w;
+    }
+  }
+  if (!ok) return;
+  if (PART) part[((size_t)blockIdx.y * gridDim.z + b) * m + l] = sumr;
+  else am_ratio_r_finish(sumr, (size_t)b * m + l, remainR, ratioR);
+}
+
+__global__ __launch_bounds__(256) void am_ratio_r_fin_kernel(int m, int chunks, const float *__restrict__ part,
+                                                             float *__restrict__ remainR, float *__restrict__ ratioR) {
+  const int b = blockIdx.y, l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= m) return;
+  float sumr = 0.0f;
+  for (int c = 0; c < chunks; ++c) sumr += part[((size_t)c * gridDim.y + b) * m + l];
+  am_ratio_r_finish(sumr, (size_t)b * m + l, remainR, ratioR);
+}
+
+// match[l,k] += exp(level*d)*ratioL_k*ratioR_l ; remainL_k -= sum_l (...)                          (:124-160)
+template <bool PART>
+__global__ __launch_bounds__(256) void am_match_kernel(int n, int m, int lchunk, float level,
+                                                       const float *__restrict__ xyz1,
+                                                       const float *__restrict__ xyz2,
+                                                       const float *__restrict__ ratioL,
+                                                       const float *__restrict__ ratioR, float *__restrict__ remainL,
+                                                       float *__restrict__ match, float *__restrict__ part) {
+  __shared__ float buf[EMD_TILE * 4];
+  const int b = PART ? blockIdx.z : blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = k < n;
+  const float *p = xyz1 + ((size_t)b * n + (ok ? k : 0)) * 3;
+  const float x1 = p[0], y1 = p[1], z1 = p[2];
+  const float rl = ok ? ratioL[(size_t)b * n + k] : 0.0f;
+  float *mt = match + (size_t)b * n * m;
+  float suml = 0;
+  const int lo = PART ? blockIdx.y * lchunk : 0, hi = PART ? min(m, lo + lchunk) : m;
+  for (int l0 = lo; l0 < hi; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, hi - l0);
+    __syncthreads();
+    for (int l = threadIdx.x; l < ln; l += 256) {
+      const float *q = xyz2 + ((size_t)b * m + l0 + l) * 3;
+      buf[l * 4 + 0] = q[0];
+      buf[l * 4 + 1] = q[1];
+      buf[l * 4 + 2] = q[2];
+      buf[l * 4 + 3] = ratioR[(size_t)b * m + l0 + l];
+    }
+    __syncthreads();
+    if (ok) {
+      for (int l = 0; l < ln; ++l) {
+        const float w =
+            __expf(level * sqdist3(buf[l * 4] - x1, buf[l * 4 + 1] - y1, buf[l * 4 + 2] - z1)) * rl * buf[l * 4 + 3];
+        mt[(size_t)(l0 + l) * n + k] += w;
+        suml += w;
+      }
+    }
+  }
+  if (!ok) return;
+  if (PART) part[((size_t)blockIdx.y * gridDim.z + b) * n + k] = suml;
+  else remainL[(size_t)b * n + k] = fmaxf(0.0f, remainL[(size_t)b * n + k] - suml);
+}
+
+__global__ __launch_bounds__(256) void am_match_fin_kernel(int n, int chunks, const float *__restrict__ part,
+                                                           float *__restrict__ remainL) {
+  const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  float suml = 0.0f;
+  for (int c = 0; c < chunks; ++c) suml += part[((size_t)c * gridDim.y + b) * n + k];
+  remainL[(size_t)b * n + k] = fmaxf(0.0f, remainL[(size_t)b * n + k] - suml);
+}
+
+__global__ void am_init_kernel(int n, int m, float multiL, float multiR, float *__restrict__ remainL,
+                               float *__restrict__ remainR) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) remainL[(size_t)b * n + i] = multiL;
+  if (i < m) remainR[(size_t)b * m + i] = multiR;
+}
+
+// chunks of the inner cloud per launch: enough workgroups for ~4 per CU, chunks of whole LDS tiles
+static int am_chunks(int b, int n, int m) {
+  static const char *force = getenv("P2PB_AM_CHUNKS");  // "1": single-pass kernels (A/B and parity experiments)
+  if (force && atoi(force) == 1) return 1;
+  const long base = (long)cdiv(n < m ? n : m, 256) * b;
+  const int inner = n > m ? n : m;
+  int c = 1;
+  while (base * c < 1024 && inner / (c * 2) >= EMD_TILE) c *= 2;
+  return c;
+}
+
+extern "C" size_t p2pb_approxmatch_temp_floats(int b, int n, int m) {
+  const int c = am_chunks(b, n, m);
+  return (size_t)b * (n + m) * 2 + (c > 1 ? (size_t)c * b * (n > m ? n : m) : 0);
+}
+
+static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                            int chunks, void *stream);
+// The reference's contract (metrics/PyTorchEMD/cuda/emd_kernel.cu:34): temp = 2 (n + m) b floats. Single-pass kernels, no
+// scratch beyond that -- a caller that sizes temp like the reference is always in bounds.
+extern "C" int p2pb_approxmatch_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                                        float *temp, void *stream) {
+  return approxmatch_impl(b, n, m, xyz1, xyz2, match, temp, 1, stream);
+}
+// The same with an explicit scratch size: temp_floats >= p2pb_approxmatch_temp_floats(b, n, m) lets small batches of large
+// clouds split the inner cloud into chunks (partials behind the reference's four arrays: 4 x faster at b = 4, 8192^2);
+// a smaller scratch (>= 2 (n + m) b) runs the single-pass kernels; below that P2PB_EINVAL.
+extern "C" int p2pb_approxmatch_forward_ws(int b, int n, int m, const float *xyz1, const float *xyz2, float *match,
+                                           float *temp, size_t temp_floats, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0 || temp_floats < (size_t)b * (n + m) * 2) return P2PB_EINVAL;
+  const int c = am_chunks(b, n, m);
+  return approxmatch_impl(b, n, m, xyz1, xyz2, match, temp, temp_floats >= p2pb_approxmatch_temp_floats(b, n, m) ? c : 1, stream);
+}
+static int approxmatch_impl(int b, int n, int m, const float *xyz1, const float *xyz2, float *match, float *temp,
+                            int chunks, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0 || !temp) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int e = p2pb_zero_async(match, sizeof(float) * (size_t)b * n * m, s);
+  if (e != 0) return e;
+  const float multiL = n >= m ? 1.0f : (float)(m / n), multiR = n >= m ? (float)(n / m) : 1.0f;
+  // temp holds the same four work arrays as the reference (emd_kernel.cu:34), laid out array-major:
+  //   temp = remainL[b][n] | remainR[b][m] | ratioL[b][n] | ratioR[b][m] | partials[chunks][b][max(n,m)]
+  float *remainL = temp, *remainR = remainL + (size_t)b * n, *ratioL = remainR + (size_t)b * m,
+        *ratioR = ratioL + (size_t)b * n, *part = ratioR + (size_t)b * m;
+  const int lch = (cdiv(m, chunks) + EMD_TILE - 1) / EMD_TILE * EMD_TILE, kch = (cdiv(n, chunks) + EMD_TILE - 1) / EMD_TILE * EMD_TILE;
+  const int lc = cdiv(m, lch), kc = cdiv(n, kch);
+  hipLaunchKernelGGL(am_init_kernel, dim3(cdiv(n > m ? n : m, 256), b), dim3(256), 0, s, n, m, multiL, multiR,
+                     remainL, remainR);
+  for (int j = 7; j >= -2; --j) {
+    float level = -powf(4.0f, (float)j);
+    if (j == -2) level = 0;
+    if (chunks == 1) {
+      hipLaunchKernelGGL(am_ratio_l_kernel<false>, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, m, level, xyz1, xyz2,
+                         remainL, remainR, ratioL, (float *)nullptr);
+      hipLaunchKernelGGL(am_ratio_r_kernel<false>, dim3(cdiv(m, 256), b), dim3(256), 0, s, n, m, n, level, xyz1, xyz2,
+                         ratioL, remainR, ratioR, (float *)nullptr);
+      hipLaunchKernelGGL(am_match_kernel<false>, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, m, level, xyz1, xyz2,
+                         ratioL, ratioR, remainL, match, (float *)nullptr);
+    } else {
+      hipLaunchKernelGGL(am_ratio_l_kernel<true>, dim3(cdiv(n, 256), lc, b), dim3(256), 0, s, n, m, lch, level, xyz1,
+                         xyz2, remainL, remainR, ratioL, part);
+      hipLaunchKernelGGL(am_ratio_l_fin_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, lc, part, remainL, ratioL);
+      hipLaunchKernelGGL(am_ratio_r_kernel<true>, dim3(cdiv(m, 256), kc, b), dim3(256), 0, s, n, m, kch, level, xyz1,
+                         xyz2, ratioL, remainR, ratioR, part);
+      hipLaunchKernelGGL(am_ratio_r_fin_kernel, dim3(cdiv(m, 256), b), dim3(256), 0, s, m, kc, part, remainR, ratioR);
+      hipLaunchKernelGGL(am_match_kernel<true>, dim3(cdiv(n, 256), lc, b), dim3(256), 0, s, n, m, lch, level, xyz1, xyz2,
+                         ratioL, ratioR, remainL, match, part);
+      hipLaunchKernelGGL(am_match_fin_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, lc, part, remainL);
+    }
+  }
+  return p2pb_launch_status();
+}
+
+// cost_i = sum_{k,l} d_kl * match[l,k]                                                            (:211-262)
+__global__ __launch_bounds__(256) void matchcost_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                        const float *__restrict__ xyz2,
+                                                        const float *__restrict__ match, float *__restrict__ out) {
+  __shared__ float buf[EMD_TILE * 3];
+  __shared__ float red[256];
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = k < n;
+  const float *p = xyz1 + ((size_t)b * n + (ok ? k : 0)) * 3;
+  const float x1 = p[0], y1 = p[1], z1 = p[2];
+  const float *mt = match + (size_t)b * n * m;
+  float sub = 0;
+  for (int l0 = 0; l0 < m; l0 += EMD_TILE) {
+    const int ln = min(EMD_TILE, m - l0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < ln * 3; e += 256) buf[e] = xyz2[((size_t)b * m + l0) * 3 + e];
+    __syncthreads();
+    if (ok)
+      for (int l = 0; l < ln; ++l) {
+        const float d = sqdist3(buf[l * 3] - x1, buf[l * 3 + 1] - y1, buf[l * 3 + 2] - z1);
+        sub += d * mt[(size_t)(l0 + l) * n + k];
+      }
+  }
+  red[threadIdx.x] = sub;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out + b, red[0]);
+}
+
+extern "C" int p2pb_matchcost_forward(int b, int n, int m, const float *xyz1, const float *xyz2, const float *match,
+                                      float *cost, void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int e = p2pb_zero_async(cost, sizeof(float) * b, s);
+  if (e != 0) return e;
+  hipLaunchKernelGGL(matchcost_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, xyz1, xyz2, match, cost);
+  return p2pb_launch_status();
+}
+
+// grad1_l = grad_cost * sum_k 2*match[k,l]*(x1_l - x2_k)                                           (:347-375)
+__global__ __launch_bounds__(256) void matchcost_grad1_kernel(int n, int m, const float *__restrict__ grad_cost,
+                                                              const float *__restrict__ xyz1,
+                                                              const float *__restrict__ xyz2,
+                                                              const float *__restrict__ match,
+                                                              float *__restrict__ grad1) {
+  const int b = blockIdx.y;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= n) return;
+  const float *p = xyz1 + ((size_t)b * n + l) * 3;
+  const float x1 = p[0], y1 = p[1], z1 = p[2];
+  const float *mt = match + (size_t)b * n * m;
+  float dx = 0, dy = 0, dz = 0;
+  for (int k = 0; k < m; ++k) {
+    const float *q = xyz2 + ((size_t)b * m + k) * 3;
+    const float d = mt[(size_t)k * n + l] * 2;
+    dx += (x1 - q[0]) * d;
+    dy += (y1 - q[1]) * d;
+    dz += (z1 - q[2]) * d;
+  }
+  const float gc = grad_cost[b];
+  float *g = grad1 + ((size_t)b * n + l) * 3;
+  g[0] = dx * gc;
+  g[1] = dy * gc;
+  g[2] = dz * gc;
+}
+
+// grad2_k = grad_cost * sum_j 2*match[k,j]*(x2_k - x1_j) : one workgroup per target point          (:300-345)
+__global__ __launch_bounds__(256) void matchcost_grad2_kernel(int n, int m, const float *__restrict__ grad_cost,
+                                                              const float *__restrict__ xyz1,
+                                                              const float *__restrict__ xyz2,
+                                                              const float *__restrict__ match,
+                                                              float *__restrict__ grad2) {
+  __shared__ float red[3][256];
+  const int b = blockIdx.y, k = blockIdx.x;
+  const float *q = xyz2 + ((size_t)b * m + k) * 3;
+  const float x2 = q[0], y2 = q[1], z2 = q[2];
+  const float *row = match + (size_t)b * n * m + (size_t)k * n;
+  float sx = 0, sy = 0, sz = 0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float *p = xyz1 + ((size_t)b * n + j) * 3;
+    const float d = row[j] * 2;
+    sx += (x2 - p[0]) * d;
+    sy += (y2 - p[1]) * d;
+    sz += (z2 - p[2]) * d;
+  }
+  red[0][threadIdx.x] = sx;
+  red[1][threadIdx.x] = sy;
+  red[2][threadIdx.x] = sz;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+      red[2][threadIdx.x] += red[2][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) grad2[((size_t)b * m + k) * 3 + threadIdx.x] = red[threadIdx.x][0] * grad_cost[b];
+}
+
+extern "C" int p2pb_matchcost_backward(int b, int n, int m, const float *grad_cost, const float *xyz1,
+                                       const float *xyz2, const float *match, float *grad1, float *grad2,
+                                       void *stream) {
+  if (b <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(matchcost_grad1_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, m, grad_cost, xyz1, xyz2, match,
+                     grad1);
+  hipLaunchKernelGGL(matchcost_grad2_kernel, dim3(m, b), dim3(256), 0, s, n, m, grad_cost, xyz1, xyz2, match, grad2);
+  return p2pb_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Auction assignment. The reference spends 7 launches per round (clear / count / scan / compact /
+// Bid / GetMax / Assign); here a round is 3 launches: one WAVE per bidder (assigned bidders exit at
+// once, so no compaction pass is needed), then GetMax and Assign as in the reference.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float atomic_max_f32(float *address, float val) {  // emd_cuda.cu:10-20
+  int ret = __float_as_int(*address);
+  while (val > __int_as_float(ret)) {
+    int old = ret;
+    if ((ret = atomicCAS((int *)address, old, __float_as_int(val))) == old) break;
+  }
+  return __int_as_float(ret);
+}
+
+__global__ __launch_bounds__(256) void auction_bid_kernel(int n, const float *__restrict__ xyz1,
+                                                          const float *__restrict__ xyz2, float eps,
+                                                          const int *__restrict__ assignment,
+                                                          const float *__restrict__ price, int *__restrict__ bid,
+                                                          float *__restrict__ bid_increments, float *max_increments) {
+  const int b = blockIdx.y;
+  const int lane = lane_id();
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n || assignment[(size_t)b * n + j] != -1) return;
+  const float *p = xyz1 + ((size_t)b * n + j) * 3;
+  const float x1 = p[0], y1 = p[1], z1 = p[2];
+  float best = -1e9f, better = -1e9f;
+  int best_i = -1;
+  for (int k = lane; k < n; k += 64) {
+    const float *q = xyz2 + ((size_t)b * n + k) * 3;
+    // emd_cuda.cu:146 : `3.0 - sqrtf(..) - price` is evaluated in double (3.0 is a double literal)
+    const float d = (float)((3.0 - (double)sqrtf(sqdist3(q[0] - x1, q[1] - y1, q[2] - z1))) -
+                            (double)price[(size_t)b * n + k]);
+    if (d > best) {
+      better = best;
+      best = d;
+      best_i = k;
+    } else if (d > better) {
+      better = d;
+    }
+  }
+  // merge (best, better, best_i) across lanes: lowest k wins value ties, `better` is the runner-up
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off), obt = __shfl_xor(better, off);
+    const int oi = __shfl_xor(best_i, off);
+    const bool take = (ob > best) || (ob == best && oi >= 0 && (best_i < 0 || oi < best_i));
+    if (take) {
+      better = fmaxf(best, obt);
+      best = ob;
+      best_i = oi;
+    } else {
+      better = fmaxf(better, ob);
+    }
+  }
+  if (lane == 0) {
+    const float inc = best - better + eps;
+    bid[(size_t)b * n + j] = best_i;
+    bid_increments[(size_t)b * n + j] = inc;
+    atomic_max_f32(max_increments + (size_t)b * n + best_i, inc);
+  }
+}
+
+__global__ __launch_bounds__(256) void auction_getmax_kernel(int n, const int *__restrict__ assignment,
+                                                             const int *__restrict__ bid,
+                                                             const float *__restrict__ bid_increments,
+                                                             const float *__restrict__ max_increments, int *max_idx) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || assignment[(size_t)b * n + j] != -1) return;
+  const int bid_id = bid[(size_t)b * n + j];
+  const float bid_inc = bid_increments[(size_t)b * n + j];
+  const float max_inc = max_increments[(size_t)b * n + bid_id];
+  if ((double)bid_inc - 1e-6 <= (double)max_inc && (double)max_inc <= (double)bid_inc + 1e-6)
+    max_idx[(size_t)b * n + bid_id] = j;
+}
+
+__global__ __launch_bounds__(256) void auction_assign_kernel(int n, int *assignment, int *assignment_inv, float *price,
+                                                             const int *__restrict__ bid,
+                                                             const float *__restrict__ bid_increments,
+                                                             float *max_increments, const int *max_idx, int last) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n || assignment[(size_t)b * n + j] != -1) return;
+  const int bid_id = bid[(size_t)b * n + j];
+  if (last || max_idx[(size_t)b * n + bid_id] == j) {
+    const float bid_inc = bid_increments[(size_t)b * n + j];
+    const int ass_inv = assignment_inv[(size_t)b * n + bid_id];
+    if (!last && ass_inv != -1) assignment[(size_t)b * n + ass_inv] = -1;
+    assignment_inv[(size_t)b * n + bid_id] = j;
+    assignment[(size_t)b * n + j] = bid_id;
+    price[(size_t)b * n + bid_id] += bid_inc;
+    max_increments[(size_t)b * n + bid_id] = -1e9f;
+  }
+}
+
+__global__ __launch_bounds__(256) void auction_dist_kernel(int n, const float *__restrict__ xyz1,
+                                                           const float *__restrict__ xyz2, float *__restrict__ dist,
+                                                           const int *__restrict__ assignment) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int k = assignment[(size_t)b * n + j];
+  const float *p = xyz1 + ((size_t)b * n + j) * 3, *q = xyz2 + ((size_t)b * n + k) * 3;
+  dist[(size_t)b * n + j] = sqdist3(p[0] - q[0], p[1] - q[1], p[2] - q[2]);
+}
+
+extern "C" int p2pb_auction_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
+                                    int *assignment, float *price, int *assignment_inv, int *bid,
+                                    float *bid_increments, float *max_increments, int *unass_idx, int *unass_cnt,
+                                    int *unass_cnt_sum, int *cnt_tmp, int *max_idx, float eps, int iters,
+                                    void *stream) {
+  (void)unass_idx, (void)unass_cnt, (void)unass_cnt_sum, (void)cnt_tmp;  // the compaction pass is not needed here
+  if (n != m || b > 512 || n % 128 != 0 || b <= 0 || n <= 0) return -1;  // emd_cuda.cu:236-249
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < iters; ++i) {
+    hipLaunchKernelGGL(auction_bid_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, s, n, xyz1, xyz2, eps, assignment, price,
+                       bid, bid_increments, max_increments);
+    hipLaunchKernelGGL(auction_getmax_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, assignment, bid,
+                       bid_increments, max_increments, max_idx);
+    hipLaunchKernelGGL(auction_assign_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, assignment, assignment_inv,
+                       price, bid, bid_increments, max_increments, max_idx, (int)(i == iters - 1));
+  }
+  hipLaunchKernelGGL(auction_dist_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, xyz1, xyz2, dist, assignment);
+  return p2pb_launch_status() == 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void auction_grad_kernel(int n, const float *__restrict__ xyz1,
+                                                           const float *__restrict__ xyz2,
+                                                           const float *__restrict__ grad_dist,
+                                                           const int *__restrict__ idx, float *grad_xyz) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int j2 = idx[(size_t)b * n + j];
+  const float *p = xyz1 + ((size_t)b * n + j) * 3, *q = xyz2 + ((size_t)b * n + j2) * 3;
+  const float g = grad_dist[(size_t)b * n + j] * 2;
+  float *o = grad_xyz + ((size_t)b * n + j) * 3;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) atomicAdd(o + a, g * (p[a] - q[a]));
+}
+
+extern "C" int p2pb_auction_backward(int b, int n, const float *xyz1, const float *xyz2, float *gradxyz,
+                                     const float *graddist, const int *idx, void *stream) {
+  if (b <= 0 || n <= 0) return P2PB_EINVAL;
+  hipLaunchKernelGGL(auction_grad_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, (hipStream_t)stream, n, xyz1, xyz2,
+                     graddist, idx, gradxyz);
+  return p2pb_launch_status() == 0 ? 1 : 0;
+}

@@ -1,0 +1,183 @@
+// normact.hip -- GroupNorm (+ AdaGN style) (+ Swish) for TRAINING: the backward pass of
+//     y = act( GN_groups(x) * gamma_c + beta_c ) * factor_bc + bias_bc )           act = Swish or identity
+// (models/modules.py:341-358 AdaGN.forward, torch.nn.GroupNorm, Swish :14-19; SharedMLP's conv -> norm -> Swish triple,
+// models/pvcnn.py:162-205) in two launches instead of the ~20 elementwise / reduction kernels the eager autograd graph
+// runs per layer. The forward pass is the inference machinery: the producing convolution emits {sum, sum of squares}
+// partials, gn_affine_kernel folds the norm to a per-(sample, channel) affine  u = A x + B  (p2pb_gn_affine_params_ex
+// additionally returns the group mean / rstd this file needs), p2pb_affine_act applies it.
+//
+// Backward, with n = (x - mu_g) rstd_g the normalised value and gu = gy * act'(u):
+//     per row (b,c):   S1 = sum_p gu ,  S2 = sum_p gu x      -> T1 = S1 , T2 = sum_p gu n = rstd (S2 - mu S1)
+//     d bias_bc = T1 ,  d factor_bc = gamma_c T2 + beta_c T1 ,  d gamma_c = sum_b factor T2 ,  d beta_c = sum_b factor T1
+//     m1_bg = sum_{c in g} gamma factor T1 / (cg P) ,  m2_bg = sum_{c in g} gamma factor T2 / (cg P)
+//     dx = rstd (gu gamma factor - m1 - n m2)  =  gu A + x c2_bg + c3_bg ,  c2 = -rstd^2 m2 ,  c3 = -rstd m1 + mu rstd^2 m2
+// All reductions run in a fixed order (deterministic), row sums in fp32 per thread + fp64 across threads.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// gu = gy * d act(u) / du
+__device__ __forceinline__ float act_grad(float u, float gy, int swish) {
+  if (!swish) return gy;
+  const float s = sigmoid_exact(u);
+  return gy * (s * (1.0f + u * (1.0f - s)));
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double *sm) {
+  const int t = threadIdx.x;
+  sm[t] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s) sm[t] += sm[t + s];
+    __syncthreads();
+  }
+  const double r = sm[0];
+  __syncthreads();
+  return r;
+}
+
+// one workgroup per row (b,c): rows[bc] = {S1, S2}
+__global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *__restrict__ x,
+                                                            const float *__restrict__ gy,
+                                                            const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, int swish,
+                                                            float *__restrict__ rows) {
+  __shared__ double sm[256];
+  const int bc = blockIdx.x, t = threadIdx.x;
+  const float sc = scale[bc], sh = shift[bc];
+  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
+  float s1 = 0.0f, s2 = 0.0f;
+  if ((P & 3) == 0) {
+    const f32x4 *x4 = (const f32x4 *)xr, *g4 = (const f32x4 *)gr;
+    for (int p = t; p < P / 4; p += 256) {
+      const f32x4 xv = x4[p], gv = g4[p];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float gu = act_grad(xv[i] * sc + sh, gv[i], swish);
+        s1 += gu;
+        s2 += gu * xv[i];
+      }
+    }
+  } else {
+    for (int p = t; p < P; p += 256) {
+      const float xv = xr[p];
+      const float gu = act_grad(xv * sc + sh, gr[p], swish);
+      s1 += gu;
+      s2 += gu * xv;
+    }
+  }
+  const double a = block_sum_256((double)s1, sm), b2 = block_sum_256((double)s2, sm);
+  if (t == 0) {
+    rows[(size_t)bc * 2] = (float)a;
+    rows[(size_t)bc * 2 + 1] = (float)b2;
+  }
+}
+
+// dx = gu * A + x * c2 + c3, with the parameter pass folded into the prologue (it used to be a launch of its own: eight
+// workgroups of serial fp64 arithmetic, 8 us of latency per layer on the step's critical path). Every workgroup of row
+// (b, ch) forms the two group coefficients of (b, g) itself -- thread k < cg evaluates channel g*cg + k's terms in fp64,
+// thread 0 adds them in ascending channel order (the order of the old kernel: same bits) -- and the first workgroup of the
+// row also writes the row's parameter gradients: dstyle[b, ch], and for b == 0 dgamma / dbeta summed over the samples in
+// ascending order.
+__global__ __launch_bounds__(256) void na_bwd_apply_kernel(int nb, int c, int groups, int P, const float *__restrict__ x,
+                                                           const float *__restrict__ gy,
+                                                           const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, int swish,
+                                                           const float *__restrict__ rows,
+                                                           const float *__restrict__ mean_rstd,
+                                                           const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta,
+                                                           const float *__restrict__ style, int style_stride,
+                                                           float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                           float *__restrict__ dstyle, float *__restrict__ dx) {
+  __shared__ double w1[256], w2[256];
+  __shared__ float cf[2];
+  const int bc = blockIdx.y, b = bc / c, ch = bc % c, cg = c / groups, g = ch / cg, t = threadIdx.x;
+  const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
+  if (t < cg) {
+    const int k = g * cg + t;
+    const double ga = gamma ? (double)gamma[k] : 1.0;
+    const double s1 = (double)rows[((size_t)b * c + k) * 2], s2 = (double)rows[((size_t)b * c + k) * 2 + 1];
+    const double f = style ? (double)style[(size_t)b * style_stride + k] : 1.0;
+    w1[t] = ga * f * s1;
+    w2[t] = ga * f * (rstd * (s2 - mu * s1));
+  }
+  __syncthreads();
+  if (t == 0) {
+    double m1 = 0.0, m2 = 0.0;
+    for (int k = 0; k < cg; ++k) {
+      m1 += w1[k];
+      m2 += w2[k];
+    }
+    const double n = (double)P * cg;
+    m1 /= n;
+    m2 /= n;
+    cf[0] = (float)(-rstd * rstd * m2);
+    cf[1] = (float)(-rstd * m1 + mu * rstd * rstd * m2);
+  }
+  if (blockIdx.x == 0 && t == 64) {  // (a lane of the second wave: beside thread 0's serial sum)
+    const double ga = gamma ? (double)gamma[ch] : 1.0, be = beta ? (double)beta[ch] : 0.0;
+    if (style) {
+      const double s1 = (double)rows[(size_t)bc * 2], s2 = (double)rows[(size_t)bc * 2 + 1];
+      const double t2 = rstd * (s2 - mu * s1);
+      dstyle[(size_t)b * 2 * c + ch] = (float)(ga * t2 + be * s1);  // d factor
+      dstyle[(size_t)b * 2 * c + c + ch] = (float)s1;               // d bias
+    }
+    if (b == 0 && (dgamma || dbeta)) {
+      double dga = 0.0, dbe = 0.0;
+      for (int bb = 0; bb < nb; ++bb) {
+        const double m = (double)mean_rstd[((size_t)bb * groups + g) * 2], r = (double)mean_rstd[((size_t)bb * groups + g) * 2 + 1];
+        const double s1 = (double)rows[((size_t)bb * c + ch) * 2], s2 = (double)rows[((size_t)bb * c + ch) * 2 + 1];
+        const double f = style ? (double)style[(size_t)bb * style_stride + ch] : 1.0;
+        dga += f * (r * (s2 - m * s1));
+        dbe += f * s1;
+      }
+      if (dgamma) dgamma[ch] = (float)dga;
+      if (dbeta) dbeta[ch] = (float)dbe;
+    }
+  }
+  __syncthreads();
+  const float sc = scale[bc], sh = shift[bc];
+  const float c2 = cf[0], c3 = cf[1];
+  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
+  float *dr = dx + (size_t)bc * P;
+  if ((P & 3) == 0) {
+    const f32x4 *x4 = (const f32x4 *)xr, *g4 = (const f32x4 *)gr;
+    f32x4 *d4 = (f32x4 *)dr;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P / 4; p += gridDim.x * 256) {
+      const f32x4 xv = x4[p], gv = g4[p];
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = act_grad(xv[i] * sc + sh, gv[i], swish) * sc + xv[i] * c2 + c3;
+      d4[p] = o;
+    }
+  } else {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+      const float xv = xr[p];
+      dr[p] = act_grad(xv * sc + sh, gr[p], swish) * sc + xv * c2 + c3;
+    }
+  }
+}
+
+// x, gy f32[b,c,npos]; scale, shift f32[b,c] and mean_rstd f32[b,groups,2] from p2pb_gn_affine_params_ex; gamma, beta
+// f32[c] or NULL; style rows (factor[c] | bias[c]) with pitch style_stride, or NULL. Outputs: dx f32[b,c,npos],
+// dgamma / dbeta f32[c] (may be NULL), dstyle f32[b,2c] (required iff style). ws: 2*b*c + 2*b*groups floats.
+extern "C" int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, const float *gy,
+                                      const float *scale, const float *shift, const float *mean_rstd,
+                                      const float *gamma, const float *beta, const float *style, int style_stride,
+                                      int swish, float *dx, float *dgamma, float *dbeta, float *dstyle, float *ws,
+                                      void *stream) {
+  if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || c / groups > 256 || npos <= 0 || !x || !gy || !scale ||
+      !shift || !mean_rstd || !dx || !ws || (style && (!dstyle || style_stride < 2 * c)))
+    return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float *rows = ws;
+  hipLaunchKernelGGL(na_bwd_reduce_kernel, dim3(b * c), dim3(256), 0, s, npos, x, gy, scale, shift, swish, rows);
+  const int per = (npos & 3) == 0 ? npos / 4 : npos;
+  const unsigned gx = (unsigned)((per + 255) / 256 > 32 ? 32 : (per + 255) / 256);
+  hipLaunchKernelGGL(na_bwd_apply_kernel, dim3(gx, b * c), dim3(256), 0, s, b, c, groups, npos, x, gy, scale, shift, swish,
+                     rows, mean_rstd, gamma, beta, style, style_stride, dgamma, dbeta, dstyle, dx);
+  return p2pb_launch_status();
+}

@@ -1,0 +1,561 @@
+// wgrad.hip -- weight gradients of the dense layers for training (BASELINE config 3), exact fp32 on the gfx950
+// matrix cores (v_mfma_f32_32x32x2_f32). Replaces what cuDNN / cuBLAS compute for the reference's
+// nn.Conv3d (models/pvcnn.py:265-282) and k=1 Conv1d / Conv2d (models/pvcnn.py:162-205, 803-823) in backward:
+//
+//   3x3x3 convolution:   dW[co][ci][tap] = sum_{b, v} dY[b, co, v] * X[b, ci, v + off(tap)]     (zero padding)
+//   1x1 convolution:     dW[co][ci]      = sum_{b, p} dY[b, co, p] * X[b, ci, p]
+//   both:                db[co]          = sum_{b, p} dY[b, co, p]
+//
+// (The data gradients need no kernel of their own: dX of the 3x3x3 convolution is the forward kernel of conv3d.hip
+// run on dY with the taps flipped and the channel roles swapped, dX of a 1x1 layer is the forward GEMM of
+// pointwise.hip with the transposed weight -- p2p_bridge_amd/dense.py.)
+//
+// Formulation: a GEMM whose reduction dimension is the VOXEL / POSITION index: M = output channels (A operand = dY
+// rows), N = input channels (B operand = X rows, shifted by the tap offset), K = B * r^3. The output is tiny and K is
+// huge, so the launch is split over K: every workgroup owns one (co tile, ci tile) and walks a strided subset of
+// the K units (4x8x8 voxel bricks / 256-position chunks), keeping the accumulators in registers all the way, and
+// writes ONE partial [co tile][ci tile][taps]; wgrad_reduce_kernel adds the partials in a fixed order
+// (deterministic: no float atomics). Per unit the workgroup stages the dY brick [64][256] and the zero-padded halo
+// brick of X [32][6*10*10] in LDS (odd row pitches: the 32 lanes of a fragment read hit 32 distinct banks), then every
+// k-pair (two voxels) is one ds_read_b32 per fragment. The 27 taps are dealt to the four waves (7/7/7/6): a wave keeps
+// 2 x 7 accumulator tiles (224 VGPRs) and spends 9 LDS reads per 14 MFMAs (896 matrix cycles) -- the kernel is
+// matrix-bound by construction, staging is ~2 % of a unit.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define WG_COT 64  // output channels per workgroup (2 M-tiles)
+#define WG_CIT 32  // input channels per workgroup (1 N-tile), conv
+#define WG_TPW 7   // taps per wave
+
+template <int TD, int TH, int TW>
+struct WBrick {
+  static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+  static constexpr int NV = TD * TH * TW, PLANE = HD * HH * HW;
+  static constexpr int PA = NV + 1, PB = PLANE | 1;  // odd LDS row pitches
+};
+
+template <int R, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad_kernel(int nb, int cin, int cout, int nsplit,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ dy,
+                                                              float *__restrict__ part, float *__restrict__ bpart) {
+  using G = WBrick<TD, TH, TW>;
+  constexpr int R3 = R * R * R;
+  constexpr int BD = R / TD, BH = R / TH, BW = R / TW, NBRICK = BD * BH * BW;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *dys = smem;                    // [WG_COT][PA]
+  float *xs = smem + WG_COT * G::PA;    // [WG_CIT][PB]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int split = blockIdx.x, co0 = blockIdx.y * WG_COT, ci0 = blockIdx.z * WG_CIT;
+  const int tap0 = wave * WG_TPW;
+  const int ntap = min(WG_TPW, 27 - tap0);
+
+  f32x16 acc[2][WG_TPW];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < WG_TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+  float bsum = 0.0f;  // thread tid < WG_COT: running sum of dY row tid (only the ci-tile-0 workgroups write it)
+
+  const int units = nb * NBRICK;
+  for (int u = split; u < units; u += nsplit) {
+    const int b = u / NBRICK, bk = u % NBRICK;
+    const int d0 = (bk / (BH * BW)) * TD, h0 = ((bk / BW) % BH) * TH, w0 = (bk % BW) * TW;
+    __syncthreads();  // everyone is done with the previous unit's tiles
+    // ---- stage dY brick: thread -> voxel(s) j, all rows
+    for (int j = tid; j < G::NV; j += 256) {
+      const int jd = j / (TH * TW), jh = (j / TW) % TH, jw = j % TW;
+      const size_t gv = ((size_t)(d0 + jd) * R + (h0 + jh)) * R + (w0 + jw);
+      const float *src = dy + ((size_t)b * cout + co0) * R3 + gv;
+#pragma unroll 8
+      for (int c = 0; c < WG_COT; ++c) dys[c * G::PA + j] = (co0 + c < cout) ? src[(size_t)c * R3] : 0.0f;
+    }
+    // ---- stage the zero-padded halo brick of X
+    for (int e = tid; e < G::PLANE; e += 256) {
+      const int dz = e / (G::HH * G::HW), hy = (e / G::HW) % G::HH, wx = e % G::HW;
+      const int d = d0 - 1 + dz, h = h0 - 1 + hy, w = w0 - 1 + wx;
+      const bool ok = (unsigned)d < (unsigned)R && (unsigned)h < (unsigned)R && (unsigned)w < (unsigned)R;
+      const float *src = x + ((size_t)b * cin + ci0) * R3 + ((size_t)d * R + h) * R + w;
+#pragma unroll 8
+      for (int c = 0; c < WG_CIT; ++c) xs[c * G::PB + e] = (ok && ci0 + c < cin) ? src[(size_t)c * R3] : 0.0f;
+    }
+    __syncthreads();
+    if (bpart && blockIdx.z == 0 && tid < WG_COT) {
+      float s = 0.0f;
+      for (int j = 0; j < G::NV; ++j) s += dys[tid * G::PA + j];
+      bsum += s;
+    }
+    // ---- K loop over voxel pairs: voxel v = 2*kk + khalf
+    const float *arow = dys + l31 * G::PA;
+    const float *brow = xs + l31 * G::PB;
+#pragma unroll 2
+    for (int kk = 0; kk < G::NV / 2; ++kk) {
+      const int v = 2 * kk + khalf;
+      const int jd = v / (TH * TW), jh = (v / TW) % TH, jw = v % TW;
+      const int hb = (jd * G::HH + jh) * G::HW + jw;
+      const float a0 = arow[v], a1 = arow[32 * G::PA + v];
+#pragma unroll
+      for (int t = 0; t < WG_TPW; ++t) {
+        if (t < ntap) {
+          const int tap = tap0 + t;
+          const int toff = ((tap / 9) * G::HH + (tap / 3) % 3) * G::HW + tap % 3;
+          const float bv = brow[hb + toff];
+          acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- partial out: part[split][tap][co][ci] (lanes = consecutive ci: coalesced rows), bias sums behind it
+  float *po = part + (size_t)split * ((size_t)cout * cin * 27 + cout);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < WG_TPW; ++t) {
+      if (t >= ntap) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf, ci = ci0 + l31;
+        if (co < cout && ci < cin) po[((size_t)(tap0 + t) * cout + co) * cin + ci] = acc[m][t][r];
+      }
+    }
+  if (bpart && blockIdx.z == 0 && tid < WG_COT && co0 + tid < cout) po[(size_t)cout * cin * 27 + co0 + tid] = bsum;
+}
+
+// 1x1 layers: units = 256-position chunks of one sample; workgroup tile 64 x 64, wave (w & 1, w >> 1) owns one
+// 32 x 32 tile
+#define PW_CH 256
+__global__ __launch_bounds__(256) void pointwise_wgrad_kernel(int nb, int cin, int cout, int npos, int nsplit,
+                                                              const float *__restrict__ x,
+                                                              const float *__restrict__ dy,
+                                                              float *__restrict__ part, float *__restrict__ bpart) {
+  constexpr int PA = PW_CH + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *dys = smem;            // [64][PA]
+  float *xs = smem + 64 * PA;   // [64][PA]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int split = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float bsum = 0.0f;
+  const int nchunk = (npos + PW_CH - 1) / PW_CH;
+  const int units = nb * nchunk;
+  for (int u = split; u < units; u += nsplit) {
+    const int b = u / nchunk, p0 = (u % nchunk) * PW_CH;
+    const int np = min(PW_CH, npos - p0);
+    __syncthreads();
+    {  // thread -> position tid (coalesced rows)
+      const bool ok = tid < np;
+      const float *sd = dy + ((size_t)b * cout + co0) * npos + p0 + tid;
+      const float *sx = x + ((size_t)b * cin + ci0) * npos + p0 + tid;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) {
+        dys[c * PA + tid] = (ok && co0 + c < cout) ? sd[(size_t)c * npos] : 0.0f;
+        xs[c * PA + tid] = (ok && ci0 + c < cin) ? sx[(size_t)c * npos] : 0.0f;
+      }
+    }
+    __syncthreads();
+    if (bpart && blockIdx.z == 0 && tid < 64) {
+      float s = 0.0f;
+      for (int j = 0; j < np; ++j) s += dys[tid * PA + j];
+      bsum += s;
+    }
+    const float *arow = dys + ((wave & 1) * 32 + l31) * PA;
+    const float *brow = xs + ((wave >> 1) * 32 + l31) * PA;
+#pragma unroll 4
+    for (int kk = 0; kk < PW_CH / 2; ++kk) {
+      const int v = 2 * kk + khalf;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[v], brow[v], acc, 0, 0, 0);
+    }
+  }
+  float *po = part + (size_t)split * ((size_t)cout * cin + cout);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf, ci = ci0 + (wave >> 1) * 32 + l31;
+    if (co < cout && ci < cin) po[(size_t)co * cin + ci] = acc[r];
+  }
+  if (bpart && blockIdx.z == 0 && tid < 64 && co0 + tid < cout) po[(size_t)cout * cin + co0 + tid] = bsum;
+}
+
+// ================================================================================================
+// Split-operand (bf16) forms of the same two GEMMs -- the default. torch.set_float32_matmul_precision("high")
+// (the reference's choice, train.py:221) means exactly this arithmetic: every fp32 operand is the sum of bf16
+// terms and the product is accumulated in fp32 on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16 K-values per
+// 32-cycle instruction against 2 per 64 cycles for the exact-fp32 MFMA above). NTERM = 2 ("bf16x3": x0y0 + x0y1 +
+// x1y0, 16 significand bits, the precision class of the reference's TF32 cuDNN / cuBLAS kernels, 3 MFMAs per 16
+// K-values) or NTERM = 3 ("bf16x6", fp32-faithful like the forward kernels, 6 MFMAs).
+//
+// K = voxels, and an MFMA lane carries 8 CONSECUTIVE K-values of its row: 8 voxels along w. Both operands are
+// activations that live in HBM as fp32 rows [channel][voxel], so a fragment is one 32-byte run of a row -- loaded
+// straight from L1 / L2 (no LDS: every element is used by one lane only; the reuse is across waves and taps, which
+// the caches serve) and split into its bf16 terms in registers. The tap shift is along the SAME axis as the
+// fragment for kw != 1; per (kd, kh) row the lane loads the aligned run f[0..7] plus its two neighbours and forms
+// the three kw fragments (l,f0..f6) / (f0..f7) / (f1..f7,r) from them: one load + one split per 3 taps.
+// Workgroup = 64 co x 64 ci x ONE kd plane (9 taps): wave (m, n) owns the 32 x 32 tile (m, n) for those 9 taps =
+// 144 accumulator registers -> two waves per SIMD hide the load latency. Split over K as above.
+// ================================================================================================
+template <int NTERM>
+__device__ __forceinline__ void split_pair(float a, float b, unsigned (&t)[NTERM]) {
+  unsigned p0, p1, p2;
+  split3(a, b, p0, p1, p2);
+  t[0] = p0;
+  if (NTERM > 1) t[1] = p1;
+  if (NTERM > 2) t[2] = p2;
+}
+
+template <int NTERM>
+__device__ __forceinline__ void mfma_products(f32x16 &acc, const u32x4 (&a)[NTERM], const u32x4 (&b)[NTERM]) {
+  // small terms first; (i, j) with i + j < NTERM
+#pragma unroll
+  for (int s = NTERM - 1; s >= 0; --s)
+#pragma unroll
+    for (int i = 0; i <= s; ++i)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]),
+                                                    __builtin_bit_cast(bf16x8, b[s - i]), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void load8(const float *p, bool vec, float (&f)[8]) {
+  if (vec) {
+    const float4 v0 = *(const float4 *)p, v1 = *(const float4 *)(p + 4);
+    f[0] = v0.x, f[1] = v0.y, f[2] = v0.z, f[3] = v0.w, f[4] = v1.x, f[5] = v1.y, f[6] = v1.z, f[7] = v1.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = p[i];
+  }
+}
+
+template <int R, int NTERM>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16_kernel(int nb, int cin, int cout, int nsplit,
+                                                                      const float *__restrict__ x,
+                                                                      const float *__restrict__ dy,
+                                                                      float *__restrict__ part,
+                                                                      float *__restrict__ bpart) {
+  constexpr int R3 = R * R * R, KG = R3 / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int split = blockIdx.x, kd = blockIdx.z;
+  const int ncit = (cin + 63) / 64;
+  const int co_t = (blockIdx.y / ncit) * 64 + (wave & 1) * 32, ci_t = (blockIdx.y % ncit) * 64 + (wave >> 1) * 32;
+  const int co = co_t + l31, ci = ci_t + l31;
+  const bool cok = co < cout, cik = ci < cin;
+  const bool want_bias = bpart && kd == 0 && (blockIdx.y % ncit) == 0 && (wave >> 1) == 0;
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bsum = 0.0f;
+  const int total = nb * KG;
+  for (int g = split; g < total; g += nsplit) {
+    const int b = g / KG, q = (g % KG) * 16 + 8 * khalf;
+    float fa[8];
+    if (cok) load8(dy + ((size_t)b * cout + co) * R3 + q, true, fa);
+    else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = 0.0f;
+    }
+    u32x4 a[NTERM];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned t[NTERM];
+      split_pair<NTERM>(fa[2 * i], fa[2 * i + 1], t);
+#pragma unroll
+      for (int s = 0; s < NTERM; ++s) a[s][i] = t[s];
+    }
+    if (want_bias) bsum += ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fa[4] + fa[5]) + (fa[6] + fa[7]));
+    const float *xrow = x + ((size_t)b * cin + (cik ? ci : 0)) * R3;
+    if (R >= 8) {
+      const int d = q / (R * R), h = (q / R) % R, w = q % R;  // w is a multiple of 8
+      const int nd = d + kd - 1;
+      const bool dok = (unsigned)nd < (unsigned)R && cik;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int nh = h + kh - 1;
+        const bool rok = dok && (unsigned)nh < (unsigned)R;
+        float f[8], left = 0.0f, right = 0.0f;
+        if (rok) {
+          const float *src = xrow + ((size_t)nd * R + nh) * R + w;
+          load8(src, true, f);
+          if (w > 0) left = src[-1];
+          if (w + 8 < R) right = src[8];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) f[i] = 0.0f;
+        }
+        u32x4 fm[NTERM], fz[NTERM], fp[NTERM];  // kw = 0 (dw = -1), 1, 2
+        unsigned t[NTERM];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          split_pair<NTERM>(f[2 * i], f[2 * i + 1], t);
+#pragma unroll
+          for (int s = 0; s < NTERM; ++s) fz[s][i] = t[s];
+        }
+        split_pair<NTERM>(left, f[0], t);
+#pragma unroll
+        for (int s = 0; s < NTERM; ++s) fm[s][0] = t[s];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+          split_pair<NTERM>(f[2 * i - 1], f[2 * i], t);
+#pragma unroll
+          for (int s = 0; s < NTERM; ++s) fm[s][i] = t[s], fp[s][i - 1] = t[s];
+        }
+        split_pair<NTERM>(f[7], right, t);
+#pragma unroll
+        for (int s = 0; s < NTERM; ++s) fp[s][3] = t[s];
+        mfma_products<NTERM>(acc[kh * 3 + 0], a, fm);
+        mfma_products<NTERM>(acc[kh * 3 + 1], a, fz);
+        mfma_products<NTERM>(acc[kh * 3 + 2], a, fp);
+      }
+    } else {  // R == 4: a fragment spans two h-rows of four voxels; gathered element-wise (64-voxel grids only)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float f[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int v = q + i;
+            const int nd = v / (R * R) + kd - 1, nh = (v / R) % R + kh - 1, nw = v % R + kw - 1;
+            const bool ok = cik && (unsigned)nd < (unsigned)R && (unsigned)nh < (unsigned)R && (unsigned)nw < (unsigned)R;
+            f[i] = ok ? xrow[((size_t)nd * R + nh) * R + nw] : 0.0f;
+          }
+          u32x4 fb[NTERM];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            unsigned t[NTERM];
+            split_pair<NTERM>(f[2 * i], f[2 * i + 1], t);
+#pragma unroll
+            for (int s = 0; s < NTERM; ++s) fb[s][i] = t[s];
+          }
+          mfma_products<NTERM>(acc[kh * 3 + kw], a, fb);
+        }
+    }
+  }
+  float *po = part + (size_t)split * ((size_t)cout * cin * 27 + cout);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = co_t + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (oc < cout && cik) po[((size_t)(kd * 9 + t) * cout + oc) * cin + ci] = acc[t][r];
+    }
+  if (want_bias) {
+    bsum += __shfl_xor(bsum, 32);
+    if (khalf == 0 && cok) po[(size_t)cout * cin * 27 + co] = bsum;
+  }
+}
+
+template <int NTERM>
+__global__ __launch_bounds__(256, 2) void pointwise_wgrad_bf16_kernel(int nb, int cin, int cout, int npos, int nsplit,
+                                                                      const float *__restrict__ x,
+                                                                      const float *__restrict__ dy,
+                                                                      float *__restrict__ part,
+                                                                      float *__restrict__ bpart) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int split = blockIdx.x;
+  const int ncit = (cin + 63) / 64;
+  const int co_t = (blockIdx.y / ncit) * 64 + (wave & 1) * 32, ci_t = (blockIdx.y % ncit) * 64 + (wave >> 1) * 32;
+  const int co = co_t + l31, ci = ci_t + l31;
+  const bool cok = co < cout, cik = ci < cin;
+  const bool want_bias = bpart && (blockIdx.y % ncit) == 0 && (wave >> 1) == 0;
+  const bool vec = (npos & 3) == 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float bsum = 0.0f;
+  const int KG = (npos + 15) / 16;
+  const int total = nb * KG;
+  for (int g = split; g < total; g += nsplit) {
+    const int b = g / KG, p = (g % KG) * 16 + 8 * khalf;
+    float fa[8], fb[8];
+    const float *sa = dy + ((size_t)b * cout + (cok ? co : 0)) * npos + p;
+    const float *sb = x + ((size_t)b * cin + (cik ? ci : 0)) * npos + p;
+    if (p + 8 <= npos) {
+      load8(sa, vec, fa);
+      load8(sb, vec, fb);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        fa[i] = p + i < npos ? sa[i] : 0.0f;
+        fb[i] = p + i < npos ? sb[i] : 0.0f;
+      }
+    }
+    if (!cok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = 0.0f;
+    }
+    if (!cik) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fb[i] = 0.0f;
+    }
+    if (want_bias) bsum += ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fa[4] + fa[5]) + (fa[6] + fa[7]));
+    u32x4 a[NTERM], bq[NTERM];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned t[NTERM];
+      split_pair<NTERM>(fa[2 * i], fa[2 * i + 1], t);
+#pragma unroll
+      for (int s = 0; s < NTERM; ++s) a[s][i] = t[s];
+      split_pair<NTERM>(fb[2 * i], fb[2 * i + 1], t);
+#pragma unroll
+      for (int s = 0; s < NTERM; ++s) bq[s][i] = t[s];
+    }
+    mfma_products<NTERM>(acc, a, bq);
+  }
+  float *po = part + (size_t)split * ((size_t)cout * cin + cout);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int oc = co_t + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (oc < cout && cik) po[(size_t)oc * cin + ci] = acc[r];
+  }
+  if (want_bias) {
+    bsum += __shfl_xor(bsum, 32);
+    if (khalf == 0 && cok) po[(size_t)cout * cin + co] = bsum;
+  }
+}
+
+// out = sum_s part[s], s ascending (deterministic). A partial row is [ntap][cout*cin] weights | cout bias sums; the
+// weights leave in the parameter's layout dw[co][ci][ntap] (coalesced reads of the partials, one scattered write).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int nsplit, int ntap, size_t cc, size_t nbias,
+                                                           const float *__restrict__ part, float *__restrict__ dw,
+                                                           float *__restrict__ db) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = cc * ntap, row = n + nbias;
+  if (i >= (db ? row : n)) return;
+  // same ascending order (same bits); eight partials in flight per thread -- the plain loop was one L2 round trip per
+  // addend (23 us per launch, 52 launches per training step)
+  float s = 0.0f;
+  int k = 0;
+  for (; k + 8 <= nsplit; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + j) * row + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < nsplit; ++k) s += part[(size_t)k * row + i];
+  if (i < n) dw[(i % cc) * ntap + i / cc] = s;
+  else db[i - n] = s;
+}
+
+// math: 0 = bf16x3 (default; "high" matmul precision, train.py:221), 1 = bf16x6 (fp32-faithful), 2 = exact fp32 MFMA
+static int conv_wgrad_units(int r, int math) { return math == 2 ? (r >= 8 ? (r / 4) * (r / 8) * (r / 8) : 1) : r * r * r / 16; }
+static int conv_wgrad_wgs_per_split(int cin, int cout, int math) {
+  return math == 2 ? ((cout + WG_COT - 1) / WG_COT) * ((cin + WG_CIT - 1) / WG_CIT)
+                   : ((cout + 63) / 64) * ((cin + 63) / 64) * 3;
+}
+// K-splits of a launch: enough workgroups to fill the chip (`target`), but the partials (written once, read once by
+// the reduction) stay below ~48 MB -- wide layers on small grids have few K units and large outputs
+static int wgrad_nsplit(long units, int wgs_per_split, int target, size_t out_floats) {
+  long s = (target + wgs_per_split - 1) / wgs_per_split;
+  const long cap = (long)((48u << 20) / (out_floats * sizeof(float)));
+  if (s > cap) s = cap;
+  if (s > units) s = units;
+  if (s > 192) s = 192;
+  return s < 1 ? 1 : (int)s;
+}
+
+extern "C" size_t p2pb_conv3d_k3_wgrad_ws_floats(int b, int cin, int cout, int r, int math) {
+  const int ns = wgrad_nsplit((long)b * conv_wgrad_units(r, math), conv_wgrad_wgs_per_split(cin, cout, math),
+                              math == 2 ? 512 : 384, (size_t)cout * cin * 27);
+  return (size_t)ns * ((size_t)cout * cin * 27 + cout);
+}
+
+template <int R, int TD, int TH, int TW>
+static void conv_wgrad_launch_fp32(int b, int cin, int cout, int ns, const float *x, const float *dy, float *ws,
+                                   bool bias, hipStream_t s) {
+  using G = WBrick<TD, TH, TW>;
+  const int cot = (cout + WG_COT - 1) / WG_COT, cit = (cin + WG_CIT - 1) / WG_CIT;
+  const size_t lds = (size_t)(WG_COT * G::PA + WG_CIT * G::PB) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void *)conv3d_k3_wgrad_kernel<R, TD, TH, TW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((conv3d_k3_wgrad_kernel<R, TD, TH, TW>), dim3(ns, cot, cit), dim3(256), lds, s, b, cin, cout, ns,
+                     x, dy, ws, bias ? ws : nullptr);
+}
+
+template <int R>
+static void conv_wgrad_launch_bf16(int b, int cin, int cout, int ns, int math, const float *x, const float *dy,
+                                   float *ws, bool bias, hipStream_t s) {
+  const dim3 grid(ns, ((cout + 63) / 64) * ((cin + 63) / 64), 3);
+  if (math == 1)
+    hipLaunchKernelGGL((conv3d_k3_wgrad_bf16_kernel<R, 3>), grid, dim3(256), 0, s, b, cin, cout, ns, x, dy, ws,
+                       bias ? ws : nullptr);
+  else
+    hipLaunchKernelGGL((conv3d_k3_wgrad_bf16_kernel<R, 2>), grid, dim3(256), 0, s, b, cin, cout, ns, x, dy, ws,
+                       bias ? ws : nullptr);
+}
+
+extern "C" int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float *x, const float *dy, float *dw,
+                                    float *db, float *ws, int math, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !x || !dy || !dw || !ws || math < 0 || math > 2) return P2PB_EINVAL;
+  if (r != 4 && r != 8 && r != 16 && r != 32) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int ns = wgrad_nsplit((long)b * conv_wgrad_units(r, math), conv_wgrad_wgs_per_split(cin, cout, math),
+                              math == 2 ? 512 : 384, (size_t)cout * cin * 27);
+  const bool bias = db != nullptr;
+  if (math == 2) {
+    switch (r) {
+      case 32: conv_wgrad_launch_fp32<32, 4, 8, 8>(b, cin, cout, ns, x, dy, ws, bias, s); break;
+      case 16: conv_wgrad_launch_fp32<16, 4, 8, 8>(b, cin, cout, ns, x, dy, ws, bias, s); break;
+      case 8: conv_wgrad_launch_fp32<8, 4, 8, 8>(b, cin, cout, ns, x, dy, ws, bias, s); break;
+      default: conv_wgrad_launch_fp32<4, 4, 4, 4>(b, cin, cout, ns, x, dy, ws, bias, s); break;
+    }
+  } else {
+    switch (r) {
+      case 32: conv_wgrad_launch_bf16<32>(b, cin, cout, ns, math, x, dy, ws, bias, s); break;
+      case 16: conv_wgrad_launch_bf16<16>(b, cin, cout, ns, math, x, dy, ws, bias, s); break;
+      case 8: conv_wgrad_launch_bf16<8>(b, cin, cout, ns, math, x, dy, ws, bias, s); break;
+      default: conv_wgrad_launch_bf16<4>(b, cin, cout, ns, math, x, dy, ws, bias, s); break;
+    }
+  }
+  const size_t n = (size_t)cout * cin * 27;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(n + cout), 256)), dim3(256), 0, s, ns, 27,
+                     (size_t)cout * cin, (size_t)cout, ws, dw, db);
+  return p2pb_launch_status();
+}
+
+static int pw_wgrad_units(int npos, int math) { return math == 2 ? (npos + PW_CH - 1) / PW_CH : (npos + 15) / 16; }
+
+extern "C" size_t p2pb_pointwise_wgrad_ws_floats(int b, int cin, int cout, int npos, int math) {
+  const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64);
+  const int ns = wgrad_nsplit((long)b * pw_wgrad_units(npos, math), tiles, 512, (size_t)cout * cin);
+  return (size_t)ns * ((size_t)cout * cin + cout);
+}
+
+extern "C" int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const float *x, const float *dy, float *dw,
+                                    float *db, float *ws, int math, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || npos <= 0 || !x || !dy || !dw || !ws || math < 0 || math > 2)
+    return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int cot = (cout + 63) / 64, cit = (cin + 63) / 64;
+  const int ns = wgrad_nsplit((long)b * pw_wgrad_units(npos, math), cot * cit, 512, (size_t)cout * cin);
+  const bool bias = db != nullptr;
+  if (math == 2) {
+    const size_t lds = (size_t)(2 * 64 * (PW_CH + 1)) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)pointwise_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(ns, cot, cit), dim3(256), lds, s, b, cin, cout, npos, ns, x, dy,
+                       ws, bias ? ws : nullptr);
+  } else if (math == 1) {
+    hipLaunchKernelGGL(pointwise_wgrad_bf16_kernel<3>, dim3(ns, cot * cit), dim3(256), 0, s, b, cin, cout, npos, ns, x,
+                       dy, ws, bias ? ws : nullptr);
+  } else {
+    hipLaunchKernelGGL(pointwise_wgrad_bf16_kernel<2>, dim3(ns, cot * cit), dim3(256), 0, s, b, cin, cout, npos, ns, x,
+                       dy, ws, bias ? ws : nullptr);
+  }
+  const size_t n = (size_t)cout * cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(n + cout), 256)), dim3(256), 0, s, ns, 1, n, (size_t)cout,
+                     ws, dw, db);
+  return p2pb_launch_status();
+}

@@ -1,0 +1,299 @@
+"""Training-time dense layers on the hand-written gfx950 kernels: forward AND backward of the 3x3x3 voxel
+convolution (nn.Conv3d in PVConv, models/pvcnn.py:265-282) and of the k=1 convolutions (SharedMLP / Pnet2Stage /
+embed_feats / classifier / LinearAttention, models/pvcnn.py:162-205,803-823, unet_pvc.py:76-83,147-154,
+modules.py:173-174) as autograd Functions. The reference gets these from cuDNN / cuBLAS (TF32); round 1 of this build
+left them on torch / MIOpen in training.
+
+    forward   the inference kernels (csrc/conv3d.hip split-operand implicit GEMM, csrc/pointwise.hip GEMMs), plain mode
+    dX        the SAME forward kernels on dY with a transformed weight: taps flipped + channel roles swapped for the
+              convolution (a correlation's adjoint is the correlation with the point-reflected kernel), W^T for 1x1
+    dW, db    csrc/wgrad.hip: split-K exact-fp32 MFMA GEMMs over the voxel / position index, deterministic reduction
+
+The parameters stay ordinary nn.Conv3d / nn.Conv1d / nn.Conv2d modules (reference checkpoint names); only the
+function applied to them changes. Transformed / packed weights are cached per parameter version.
+"""
+import ctypes
+import types
+
+import torch
+
+from . import fused
+from ._lib import call, lib, ptr, stream_ptr
+
+_i = ctypes.c_int
+F32 = torch.float32
+USE_HIP = True  # tools/exp_train_step.py flips this to time the torch / MIOpen dense layers on the same graph
+_MATH = {"bf16x3": 0, "bf16x6": 1, "fp32": 2}
+
+
+def train_math() -> int:
+    """arithmetic of the weight-gradient GEMMs (csrc/wgrad.hip), P2PB_TRAIN_MATH: "bf16x3" (default) = torch's "high"
+    float32 matmul precision, which the reference's train.py:221 selects (its cuDNN / cuBLAS kernels then run TF32);
+    "bf16x6" = fp32-faithful split operands like the forward kernels; "fp32" = the exact-fp32 MFMA kernels"""
+    import os
+
+    m = os.environ.get("P2PB_TRAIN_MATH", "bf16x3")
+    if m not in _MATH:
+        raise ValueError(f"P2PB_TRAIN_MATH must be one of {sorted(_MATH)}, got {m!r}")
+    return _MATH[m]
+
+
+def enabled(x: torch.Tensor) -> bool:
+    return USE_HIP and x.is_cuda and x.dtype == F32
+
+
+# ---- weight gradients beside the data-gradient chain ---------------------------------------------------------------------
+# dW of a layer is needed only by the optimiser; dX is what the rest of the backward pass waits for. Inside
+# `wgrad_overlap()` the weight-gradient GEMMs (a quarter of the step's kernel time) are issued on a second stream that forks
+# from the backward stream at each layer and is joined once, after backward (`join_wgrad`): the long chain of small
+# data-gradient / normalisation kernels -- each far too small to fill 256 CUs -- then runs beside them instead of between
+# them. Used by train.GraphedStep (the fork / join is captured into the hipGraph as parallel branches); NOT under DDP,
+# whose hooks read a gradient as soon as its backward returns.
+_overlap = {"stream": None, "pending": []}
+
+
+class wgrad_overlap:
+    def __init__(self, stream: "torch.cuda.Stream"):
+        self.stream = stream
+
+    def __enter__(self):
+        self.prev, _overlap["stream"] = _overlap["stream"], self.stream
+        return self
+
+    def __exit__(self, *a):
+        join_wgrad()
+        _overlap["stream"] = self.prev
+
+
+def join_wgrad():
+    """the current stream waits for the weight gradients issued so far; their operands may be freed again"""
+    st = _overlap["stream"]
+    if st is not None and _overlap["pending"]:
+        torch.cuda.current_stream().wait_stream(st)
+    _overlap["pending"].clear()
+
+
+def _on_wgrad_stream(fn, *operands):
+    """fn() on the overlap stream (after everything already queued on the current one), or inline without one. The
+    operands are kept alive until the join: the allocator must not hand their memory to later kernels of the main stream
+    while the side stream still reads them."""
+    st = _overlap["stream"]
+    if st is None:
+        return fn()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        out = fn()
+    _overlap["pending"].append(operands)
+    return out
+
+
+_ZEROS = {}
+
+
+def _zero_bias(n, device):
+    """one zero vector per (length, device) for the lifetime of the process (the convolution launcher wants a bias row)"""
+    key = (int(n), str(device))
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(int(n), dtype=F32, device=device)
+    return _ZEROS[key]
+
+
+def _dgrad_holder(conv, kind):
+    """conv-like object of the data-gradient pass: the layer's OWN weight tensor flagged `adjoint`, which the pack kernels
+    read transposed (and, for the 3x3x3 convolution, with every tap axis reversed: p2pb_*_pack_weights*_adjoint) -- no
+    flipped / transposed copy of the weight per step. The holder lives on the module; its packs are cached per weight
+    version like the forward ones."""
+    w = conv.weight
+    h = getattr(conv, "_p2pb_dgrad", None)
+    if h is None or h.weight is not w:
+        co, ci = w.shape[0], w[0].numel() // (27 if kind == "conv3d" else 1)
+        h = types.SimpleNamespace(weight=w, adjoint=True, out_channels=ci, in_channels=co,
+                                  bias=_zero_bias(ci, w.device) if kind == "conv3d" else None, padding=(1, 1, 1), stride=(1, 1, 1))
+        conv._p2pb_dgrad = h
+    return h
+
+
+def _empty(x):
+    return torch.empty(0, dtype=F32, device=x.device)
+
+
+class _Conv3dK3(torch.autograd.Function):
+    """-> (y, GroupNorm partials of y [B,nslots,Cout,2] or an empty tensor)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv, want_stats=False):
+        x = x.contiguous()
+        y, st = fused.conv3d_k3(x, conv, stats=want_stats, compact=True)
+        ctx.save_for_backward(x)
+        ctx.conv = conv
+        st = st if st is not None else _empty(x)
+        ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output's gradient: a fill launch per layer)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, gy, _gst=None):
+        if gy is None:
+            return None, None, None, None, None
+        (x,) = ctx.saved_tensors
+        conv = ctx.conv
+        gy = gy.contiguous()
+        b, ci, r = x.shape[0], x.shape[1], x.shape[2]
+        co = gy.shape[1]
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            want_b = ctx.needs_input_grad[2]
+
+            def wgrad():
+                gw = torch.empty(co, ci, 3, 3, 3, dtype=F32, device=x.device)
+                gb = torch.empty(co, dtype=F32, device=x.device) if want_b else None
+                math = _i(train_math())
+                ws = torch.empty(lib().p2pb_conv3d_k3_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(r), math), dtype=F32,
+                                 device=x.device)
+                call("p2pb_conv3d_k3_wgrad", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
+                     math, stream_ptr())
+                return gw, gb
+
+            gw, gb = _on_wgrad_stream(wgrad, x, gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            with fused.split_math("bf16x6"):  # gradients have no scale an fp16-pair split could rely on
+                # force_split: the adjoint pack exists only in the split form (the kernel reads the forward weight transposed
+                # and tap-reflected), so the data gradient runs bf16x6 under P2PB_CONV_MATH=fp32 too
+                gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True, force_split=True)
+        return gx, gw, gb, None, None
+
+
+class _Pointwise(torch.autograd.Function):
+    """-> (y, GroupNorm partials of y or an empty tensor)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, conv, want_stats=False):
+        x = x.contiguous()
+        y, st = fused.pw_conv(x, conv, stats=want_stats, use_bias=bias is not None)
+        ctx.save_for_backward(x)
+        ctx.conv = conv
+        st = st if st is not None else _empty(x)
+        ctx.mark_non_differentiable(st)
+        ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output's gradient: a fill launch per layer)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, gy, _gst=None):
+        if gy is None:
+            return None, None, None, None, None
+        (x,) = ctx.saved_tensors
+        conv = ctx.conv
+        gy = gy.contiguous()
+        b, ci, p = x.shape
+        co = gy.shape[1]
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            want_b = ctx.needs_input_grad[2]
+
+            def wgrad():
+                gw = torch.empty(co, ci, dtype=F32, device=x.device)
+                gb = torch.empty(co, dtype=F32, device=x.device) if want_b else None
+                math = _i(train_math())
+                ws = torch.empty(lib().p2pb_pointwise_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(p), math), dtype=F32,
+                                 device=x.device)
+                call("p2pb_pointwise_wgrad", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
+                     math, stream_ptr())
+                return gw.view(conv.weight.shape), gb
+
+            gw, gb = _on_wgrad_stream(wgrad, x, gy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            with fused.split_math("bf16x6"):
+                gx, _ = fused.pw_conv(gy, _dgrad_holder(conv, "pw"), stats=False, use_bias=False)
+        return gx, gw, gb, None, None
+
+
+class _NormAct(torch.autograd.Function):
+    """y = act(GroupNorm(x) * gamma + beta [* factor + bias]) with the statistics the producing convolution emitted:
+    forward = gn_affine (fold to a per-(sample, channel) affine) + affine_act, backward = csrc/normact.hip (3 launches)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, style, stats, groups, eps, swish):
+        b, c = x.shape[:2]
+        p = x.numel() // (b * c)
+        x3 = x.reshape(b, c, p)
+        if style is not None and (style.stride(1) != 1 or style.shape[1] != 2 * c):
+            style = style.contiguous()
+        scale = torch.empty(b, c, dtype=F32, device=x.device)
+        shift = torch.empty_like(scale)
+        mr = torch.empty(b, groups, 2, dtype=F32, device=x.device)
+        call("p2pb_gn_affine_params_ex", _i(b), _i(c), _i(groups), _i(stats.shape[1]), ctypes.c_double(float(p)),
+             ptr(stats), ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0),
+             ctypes.c_float(eps), ptr(scale), ptr(shift), ptr(None), ptr(mr), stream_ptr())
+        y = fused.affine_act(x3, scale, shift, bool(swish), None)
+        ctx.save_for_backward(x3, scale, shift, mr, gamma, beta, style)
+        ctx.groups, ctx.swish = groups, bool(swish)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, scale, shift, mr, gamma, beta, style = ctx.saved_tensors
+        b, c, p = x3.shape
+        groups = ctx.groups
+        gy = gy.contiguous()
+        dx = torch.empty_like(x3)
+        dgamma = torch.empty_like(gamma) if gamma is not None else None
+        dbeta = torch.empty_like(beta) if beta is not None else None
+        dstyle = torch.empty(b, 2 * c, dtype=F32, device=x3.device) if style is not None else None
+        ws = torch.empty(2 * b * c + 2 * b * groups, dtype=F32, device=x3.device)
+        call("p2pb_norm_act_backward", _i(b), _i(c), _i(groups), _i(p), ptr(x3), ptr(gy), ptr(scale), ptr(shift), ptr(mr),
+             ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0), _i(int(ctx.swish)),
+             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dstyle), ptr(ws), stream_ptr())
+        return dx.view(gy.shape), dgamma, dbeta, dstyle, None, None, None, None
+
+
+def conv3d_k3(x, conv: torch.nn.Conv3d, want_stats=False):
+    """nn.Conv3d(kernel 3, stride 1, padding 1) applied to x f32[B,Cin,r,r,r], r in {4, 8, 16, 32}"""
+    if not enabled(x) or x.shape[2] not in (4, 8, 16, 32):
+        return (conv(x), None) if want_stats else conv(x)
+    y, st = _Conv3dK3.apply(x, conv.weight, conv.bias, conv, want_stats)
+    return (y, st) if want_stats else y
+
+
+def pointwise(x, conv, want_stats=False):
+    """a k=1 nn.Conv1d / nn.Conv2d applied to x f32[B,Cin,...]"""
+    if not enabled(x):
+        return (conv(x), None) if want_stats else conv(x)
+    shape = x.shape
+    y, st = _Pointwise.apply(x.reshape(shape[0], shape[1], -1), conv.weight, conv.bias, conv, want_stats)
+    y = y.view(shape[0], y.shape[1], *shape[2:])
+    return (y, st) if want_stats else y
+
+
+def _group_norm_of(norm):
+    """(nn.GroupNorm, emd Linear | None) of AdaGN / MyGroupNorm / GroupNorm, or None when the module is not foldable"""
+    gn = getattr(norm, "norm", None)
+    if gn is not None and hasattr(norm, "emd"):
+        return gn, norm.emd
+    gn = getattr(norm, "group_norm", None)
+    if gn is not None:
+        return gn, None
+    return (norm, None) if isinstance(norm, torch.nn.GroupNorm) else None
+
+
+def conv_norm_act(x, conv, norm, cond=None, swish=True):
+    """the reference's conv -> GroupNorm | AdaGN(cond) -> [Swish] triple (models/pvcnn.py:162-205, 265-283) for training:
+    HIP convolution (emitting the norm's statistics) + folded norm / activation with a 3-launch backward.
+    cond: the global embedding [B, ctx_dim] for AdaGN (its Linear `emd` stays a torch op: a plain [B, ctx] GEMM)."""
+    gn_emd = _group_norm_of(norm)
+    is3d = isinstance(conv, torch.nn.Conv3d)
+    ok = (enabled(x) and gn_emd is not None and gn_emd[0].num_channels == conv.out_channels
+          and gn_emd[0].num_channels // gn_emd[0].num_groups <= 256 and (not is3d or x.shape[2] in (4, 8, 16, 32)))
+    if not ok:
+        y = conv3d_k3(x, conv) if is3d else pointwise(x, conv)
+        y = norm(y, cond) if (gn_emd is not None and gn_emd[1] is not None and cond is not None) else norm(y)
+        return y * torch.sigmoid(y) if swish else y
+    gn, emd = gn_emd
+    y, st = conv3d_k3(x, conv, True) if is3d else pointwise(x, conv, True)
+    style = None
+    if emd is not None:
+        if cond is None:
+            raise RuntimeError("AdaGN needs the global embedding")
+        style = cond.style(norm) if hasattr(cond, "style") else emd(cond)
+    return _NormAct.apply(y, gn.weight, gn.bias, style, st, gn.num_groups, gn.eps, swish)

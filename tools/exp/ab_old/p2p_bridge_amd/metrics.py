@@ -1,0 +1,259 @@
+"""Chamfer / EMD metric-and-loss wrappers on the gfx950 kernels: the autograd Functions, nn.Modules and
+helper functions the reference exposes around its three metric extensions, with the same names and
+argument meaning:
+
+  chamfer_3DFunction / chamfer_3DDist / chamfer_3DFunction_noGrad / chamfer_dist_nograd
+                                              (metrics/chamfer3D/dist_chamfer_3D.py:44-157)
+  EarthMoverDistanceFunction / earth_mover_distance / earth_mover_distance_nograd
+                                              (metrics/PyTorchEMD/emd.py:5-49, emd_nograd.py:7-45)
+  emdFunction / emdModule                     (metrics/emd_assignment/emd_module.py:30-96)
+  calculate_cd_cuda / calculate_emd_cuda      (metrics/metrics.py:56-108, chunked evaluation)
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .metric_modules import chamfer_3D, emd_assignment, emd_cuda
+
+
+class chamfer_3DFunction(Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1, xyz2 = xyz1.float().contiguous(), xyz2.float().contiguous()
+        b, n, d = xyz1.shape
+        assert d == 3, "Wrong last dimension for the chamfer distance 's input! Check with .size()"
+        _, m, d = xyz2.shape
+        assert d == 3, "Wrong last dimension for the chamfer distance 's input! Check with .size()"
+        dev = xyz1.device
+        dist1 = torch.empty(b, n, device=dev)
+        dist2 = torch.empty(b, m, device=dev)
+        idx1 = torch.empty(b, n, dtype=torch.int32, device=dev)
+        idx2 = torch.empty(b, m, dtype=torch.int32, device=dev)
+        chamfer_3D.forward(xyz1, xyz2, dist1, dist2, idx1, idx2)
+        ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
+        ctx.mark_non_differentiable(idx1, idx2)
+        return dist1, dist2, idx1, idx2
+
+    @staticmethod
+    def backward(ctx, graddist1, graddist2, gradidx1, gradidx2):
+        xyz1, xyz2, idx1, idx2 = ctx.saved_tensors
+        g1, g2 = torch.zeros_like(xyz1), torch.zeros_like(xyz2)
+        chamfer_3D.backward(xyz1, xyz2, g1, g2, graddist1.contiguous(), graddist2.contiguous(), idx1, idx2)
+        return g1, g2
+
+
+class chamfer_3DDist(nn.Module):
+    def forward(self, input1, input2):
+        return chamfer_3DFunction.apply(input1.contiguous(), input2.contiguous())
+
+
+class chamfer_3DFunction_noGrad(Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        with torch.no_grad():
+            return chamfer_3DFunction.forward(ctx, xyz1, xyz2)
+
+
+class chamfer_3DDist_nograd(nn.Module):
+    def forward(self, input1, input2):
+        with torch.no_grad():
+            return chamfer_3DFunction.apply(input1.contiguous(), input2.contiguous())
+
+
+def chamfer_dist_nograd(x, y):
+    d1, d2, _, _ = chamfer_3DDist_nograd()(x, y)
+    return d1, d2
+
+
+class EarthMoverDistanceFunction(Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2):
+        xyz1, xyz2 = xyz1.contiguous(), xyz2.contiguous()
+        assert xyz1.is_cuda and xyz2.is_cuda, "Only support cuda currently."
+        match = emd_cuda.approxmatch_forward(xyz1, xyz2)
+        cost = emd_cuda.matchcost_forward(xyz1, xyz2, match)
+        ctx.save_for_backward(xyz1, xyz2, match)
+        return cost
+
+    @staticmethod
+    def backward(ctx, grad_cost):
+        xyz1, xyz2, match = ctx.saved_tensors
+        g1, g2 = emd_cuda.matchcost_backward(grad_cost.contiguous(), xyz1, xyz2, match)
+        return g1, g2
+
+
+def _bn3(x, transpose):
+    if x.dim() == 2:
+        x = x.unsqueeze(0)
+    return x.transpose(1, 2) if transpose else x
+
+
+def earth_mover_distance(xyz1, xyz2, transpose=True):
+    """approximate EMD cost per cloud, inputs (b,3,n) when transpose else (b,n,3) -> (b)"""
+    return EarthMoverDistanceFunction.apply(_bn3(xyz1, transpose), _bn3(xyz2, transpose))
+
+
+def earth_mover_distance_nograd(xyz1, xyz2, transpose=True):
+    xyz1, xyz2 = _bn3(xyz1, transpose), _bn3(xyz2, transpose)
+    assert xyz1.shape[-1] == 3, f"require it to be B,N,3; get: {xyz1.shape}"
+    with torch.no_grad():
+        return EarthMoverDistanceFunction.apply(xyz1, xyz2) / float(xyz1.shape[1])
+
+
+class emdFunction(Function):
+    @staticmethod
+    def forward(ctx, xyz1, xyz2, eps=0.005, iters=50):
+        b, n, _ = xyz1.size()
+        _, m, _ = xyz2.size()
+        assert n == m and xyz1.size(0) == xyz2.size(0) and n % 128 == 0 and b <= 512
+        xyz1, xyz2 = xyz1.contiguous().float().cuda(), xyz2.contiguous().float().cuda()
+        dev = xyz1.device
+        f = lambda *s: torch.zeros(*s, device=dev)
+        i = lambda *s: torch.zeros(*s, device=dev, dtype=torch.int32)
+        dist, assignment, assignment_inv = f(b, n), i(b, n) - 1, i(b, m) - 1
+        emd_assignment.forward(xyz1, xyz2, dist, assignment, f(b, m), assignment_inv, i(b, n), f(b, n), f(b, m),
+                               i(b * n), i(512), i(512), i(512), i(b * m), eps, iters)
+        ctx.save_for_backward(xyz1, xyz2, assignment)
+        ctx.mark_non_differentiable(assignment)
+        return dist, assignment
+
+    @staticmethod
+    def backward(ctx, graddist, gradidx):
+        xyz1, xyz2, assignment = ctx.saved_tensors
+        g1 = torch.zeros_like(xyz1)
+        emd_assignment.backward(xyz1, xyz2, g1, graddist.contiguous(), assignment)
+        return g1, torch.zeros_like(xyz2), None, None
+
+
+class emdModule(nn.Module):
+    def forward(self, input1, input2, eps, iters):
+        return emdFunction.apply(input1, input2, eps, iters)
+
+
+@torch.no_grad()
+def calculate_cd_cuda(pred, gt, batch_size=4):
+    """CD-L2 = mean_i min_j + mean_j min_i, evaluated in chunks (metrics/metrics.py:56-83). pred/gt [B,N,3]"""
+    out = []
+    for s in range(0, pred.shape[0], batch_size):
+        d1, d2 = chamfer_dist_nograd(pred[s:s + batch_size].contiguous(), gt[s:s + batch_size].contiguous())
+        out.append(d1.mean(dim=1) + d2.mean(dim=1))
+    return torch.cat(out)
+
+
+@torch.no_grad()
+def calculate_emd_cuda(pred, gt, batch_size=4):
+    """approximate EMD / N in chunks (metrics/metrics.py:86-108). pred/gt [B,N,3]"""
+    out = []
+    for s in range(0, pred.shape[0], batch_size):
+        out.append(earth_mover_distance_nograd(pred[s:s + batch_size], gt[s:s + batch_size], transpose=False))
+    return torch.cat(out)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Evaluation metrics on the unit sphere: metrics/metrics.py:139-226, models/evaluation.py:314-353.
+# chamfer_dist_nograd is this package's HIP Chamfer; the point-to-mesh distances replace pytorch3d._C.point_face_dist_*
+# (csrc/p2m.hip). pytorch3d is a pip dependency of the reference: its published definitions are restated in oracle/.
+# ------------------------------------------------------------------------------------------------------------------
+def normalize_sphere(pc, radius=1.0):
+    """pc [B,N,3] -> (pc centred on the bounding-box centre and scaled to `radius`, center [B,1,3], scale [B,1,1])
+    (metrics/metrics.py:139-157)"""
+    p_max = pc.max(dim=-2, keepdim=True)[0]
+    p_min = pc.min(dim=-2, keepdim=True)[0]
+    center = (p_max + p_min) / 2
+    pc = pc - center
+    scale = (pc ** 2).sum(dim=-1, keepdim=True).sqrt().max(dim=-2, keepdim=True)[0] / radius
+    return pc / scale, center, scale
+
+
+def normalize_pcl(pc, center, scale):
+    return (pc - center) / scale
+
+
+def denormalize_pcl(pc, center, scale):
+    return pc * scale + center
+
+
+@torch.no_grad()
+def cd_unit_sphere(gen, ref, normalize=True):
+    """(mean_i min_j, mean_j min_i) squared distances, gen/ref [B,N,3] (metrics/metrics.py:177-195)"""
+    if normalize:
+        ref, center, scale = normalize_sphere(ref)
+        gen = normalize_pcl(gen, center, scale)
+    cd1, cd2 = chamfer_dist_nograd(gen.contiguous(), ref.contiguous())
+    return cd1.mean().item(), cd2.mean().item()
+
+
+def chamfer_distance_unit_sphere(gen, ref, batch_reduction="mean", point_reduction="mean"):
+    """pytorch3d.loss.chamfer_distance(gen, ref) after normalising both with ref's sphere (models/evaluation.py:291-294):
+    -> (loss, None); mean / sum reductions over points and batch, None batch reduction -> [B]"""
+    ref, center, scale = normalize_sphere(ref)
+    gen = normalize_pcl(gen, center, scale)
+    d1, d2, _, _ = chamfer_3DDist()(gen.contiguous(), ref.contiguous())
+    red = (lambda d: d.mean(dim=1)) if point_reduction == "mean" else (lambda d: d.sum(dim=1))
+    if point_reduction not in ("mean", "sum"):
+        raise ValueError("point_reduction must be 'mean' or 'sum'")
+    loss = red(d1) + red(d2)
+    if batch_reduction == "mean":
+        loss = loss.mean()
+    elif batch_reduction == "sum":
+        loss = loss.sum()
+    elif batch_reduction is not None:
+        raise ValueError("batch_reduction must be 'mean', 'sum' or None")
+    return loss, None
+
+
+_DEFAULT_MIN_TRIANGLE_AREA = 5e-3  # pytorch3d.loss.point_mesh_distance
+
+
+def _p2m(fn, points, tris, n_out, min_triangle_area):
+    from ._lib import call, check, ptr, stream_ptr
+    import ctypes
+
+    check(points, torch.float32, "points"), check(tris, torch.float32, "tris")
+    d = torch.empty(n_out, dtype=torch.float32, device=points.device)
+    idx = torch.empty(n_out, dtype=torch.int32, device=points.device)
+    call(fn, ctypes.c_int(points.shape[0]), ctypes.c_int(tris.shape[0]), ptr(points), ptr(tris),
+         ctypes.c_float(min_triangle_area), ptr(d), ptr(idx), stream_ptr())
+    return d, idx.long()
+
+
+def point_face_distance(points, tris, min_triangle_area=_DEFAULT_MIN_TRIANGLE_AREA):
+    """points f32[P,3], tris f32[T,3,3] -> (squared distance of every point to its closest triangle [P], its index)"""
+    return _p2m("p2pb_point_face_dist", points.contiguous(), tris.contiguous(), points.shape[0], min_triangle_area)
+
+
+def face_point_distance(points, tris, min_triangle_area=_DEFAULT_MIN_TRIANGLE_AREA):
+    """-> (squared distance of every triangle to its closest point [T], its index)"""
+    return _p2m("p2pb_face_point_dist", points.contiguous(), tris.contiguous(), tris.shape[0], min_triangle_area)
+
+
+@torch.no_grad()
+def point_mesh_face_distance(pcl, verts, faces, min_triangle_area=_DEFAULT_MIN_TRIANGLE_AREA):
+    """(point_dist, face_dist) of metrics/p2m.py:307-375 for one (mesh, cloud) pair: mean squared distance of the
+    points to the mesh and of the faces to the cloud"""
+    tris = verts[faces.long()].contiguous()
+    return (point_face_distance(pcl, tris, min_triangle_area)[0].mean(),
+            face_point_distance(pcl, tris, min_triangle_area)[0].mean())
+
+
+@torch.no_grad()
+def point_face_dist(pcl, verts, faces, normalize=True):
+    """metrics/metrics.py:198-226 -> (point_dist, face_dist) floats; pcl [N,3], verts [M,3], faces i64[T,3]"""
+    assert pcl.dim() == 2 and verts.dim() == 2 and faces.dim() == 2, "Batch is not supported."
+    if normalize:
+        verts, center, scale = normalize_sphere(verts.unsqueeze(0))
+        verts = verts[0]
+        pcl = normalize_pcl(pcl.unsqueeze(0), center=center, scale=scale)[0]
+    pd, fd = point_mesh_face_distance(pcl.cuda(), verts.cuda(), faces.cuda())
+    return pd.item(), fd.item()
+
+
+@torch.no_grad()
+def point_mesh_bidir_distance_single_unit_sphere(pcl, verts, faces):
+    """models/evaluation.py:329-353: pytorch3d.loss.point_mesh_face_distance(min_triangle_area=0.0) on the mesh's
+    unit sphere = point_dist + face_dist"""
+    assert pcl.dim() == 2 and verts.dim() == 2 and faces.dim() == 2, "Batch is not supported."
+    verts, center, scale = normalize_sphere(verts.unsqueeze(0))
+    pcl = normalize_pcl(pcl.unsqueeze(0), center=center, scale=scale)[0]
+    pd, fd = point_mesh_face_distance(pcl, verts[0], faces, min_triangle_area=0.0)
+    return pd + fd

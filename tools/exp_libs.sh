@@ -4,5 +4,5 @@ for v in "$@"; do
   export P2PB_LIB_PATH=$GRAFT_REPO_ROOT/tools/exp/lib_$v.so
   echo "== $v (rep $rep)"
   timeout 600 python tools/exp_conv_instances.py 2>&1 | grep -v amdgpu.ids | tail -1
-  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step 2>&1 | tail -1 | cut -c1-140
+  timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step --no-pvdl 2>&1 | tail -1 | cut -c1-140
 done; done

@@ -11,7 +11,7 @@ python bench.py --steps 5 --warmup 2 > $out/bench.out 2> $out/bench.err
 grep '^{' $out/bench.out | tail -1 > $out/${tag}_bench_line.json
 cd /tmp && export TMPDIR=/tmp
 # 1) kernel trace of bench.py (hipGraph replay, as the bench runs)
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_bench -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step > $out/prof_bench.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof_bench -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step --no-pvdl > $out/prof_bench.log 2>&1
 db=$(find $out/prof_bench -name "*.db" | head -1)
 python $R/tools/rocpd_window.py $db $out/${tag}_per_eval.csv > /dev/null
 python $R/tools/rocpd_stats.py $db $out/${tag}_kernel_stats.csv > /dev/null

@@ -1,6 +1,6 @@
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/tl; rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step > $out/prof.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/prof -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-math --no-train-step --no-pvdl > $out/prof.log 2>&1
 db=$(find $out/prof -name "*.db" | head -1)
 python $R/tools/rocpd_timeline.py $db > $out/timeline.txt
 rm -rf $out/prof
