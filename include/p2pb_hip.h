@@ -165,7 +165,8 @@ int p2pb_three_nn(int b, int m, int n, const float *points, const float *centers
 int p2pb_three_interpolate(int b, int c, int m, int n, const float *cfeat, const int *idx, const float *w,
                            float *out, void *stream);
 /* p2pb_three_nn through a uniform 16^3 grid over the centres (exact: same idx / w, ties by ascending index);
- * 3 <= m <= 8192, ws: p2pb_three_nn_cells_ws_bytes(b, m) bytes of scratch (16-byte aligned) */
+ * m >= 3 (the centre records sit in LDS up to 8192 centres and stay in global memory / L2 above), ws:
+ * p2pb_three_nn_cells_ws_bytes(b, m) bytes of scratch (16-byte aligned) */
 size_t p2pb_three_nn_cells_ws_bytes(int b, int m);
 int p2pb_three_nn_cells(int b, int m, int n, const float *points, const float *centers, int *idx, float *w, void *ws,
                         void *stream);

@@ -588,6 +588,8 @@ __global__ __launch_bounds__(1024) void nn_cells_build_kernel(int m, const float
   }
 }
 
+template <bool LDS_REC>  // false (m > NNC_MAX_M, PVDL's 12500-centre level): the records stay in global memory (L2-resident:
+                         // 16 m bytes per cloud), only the cell table goes to LDS -- many workgroups per CU hide the L2 trips
 __global__ __launch_bounds__(256) void three_nn_cells_kernel(int n, int m, const float *__restrict__ points,
                                                              const int *__restrict__ cell_start,
                                                              const float4 *__restrict__ cell_rec,
@@ -596,10 +598,11 @@ __global__ __launch_bounds__(256) void three_nn_cells_kernel(int n, int m, const
   // the cloud's cell table and sorted centre records, shared by the workgroup's 256 points (all of one cloud):
   // every candidate is then one 16-byte LDS read at an address known up front (no dependent global loads)
   extern __shared__ float4 nnc_lds[];
-  float4 *rec = nnc_lds;
-  int *cs = (int *)(nnc_lds + m);
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < m; i += 256) rec[i] = cell_rec[(size_t)b * m + i];
+  const float4 *rec = LDS_REC ? (const float4 *)nnc_lds : cell_rec + (size_t)b * m;
+  int *cs = (int *)(nnc_lds + (LDS_REC ? m : 0));
+  if (LDS_REC)
+    for (int i = threadIdx.x; i < m; i += 256) nnc_lds[i] = cell_rec[(size_t)b * m + i];
   for (int i = threadIdx.x; i <= NNC_CELLS; i += 256) cs[i] = cell_start[(size_t)b * (NNC_CELLS + 1) + i];
   __syncthreads();
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -685,25 +688,30 @@ extern "C" size_t p2pb_three_nn_cells_ws_bytes(int b, int m) {
   return (size_t)b * m * 16 + ((size_t)b * (NNC_CELLS + 1) + (size_t)b * m) * sizeof(int) + (size_t)b * 4 * sizeof(float);
 }
 
-// p2pb_three_nn through a uniform grid over the centres: same idx / w. 3 <= m <= 8192;
+// p2pb_three_nn through a uniform grid over the centres: same idx / w. m >= 3 (records in LDS up to 8192 centres, in L2 above);
 // ws: p2pb_three_nn_cells_ws_bytes(b, m) bytes, 16-byte aligned
 extern "C" int p2pb_three_nn_cells(int b, int m, int n, const float *points, const float *centers, int *idx, float *w,
                                    void *ws, void *stream) {
-  if (b <= 0 || n <= 0 || m < 3 || m > NNC_MAX_M || !ws || ((uintptr_t)ws & 15)) return P2PB_EINVAL;
+  if (b <= 0 || n <= 0 || m < 3 || m > (1 << 24) || !ws || ((uintptr_t)ws & 15)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   float4 *cell_rec = (float4 *)ws;
   int *cell_start = (int *)(cell_rec + (size_t)b * m);
   int *cell_ids = cell_start + (size_t)b * (NNC_CELLS + 1);
   float *box = (float *)(cell_ids + (size_t)b * m);
-  const size_t lds = (size_t)m * 16 + (NNC_CELLS + 1) * sizeof(int);
+  const bool in_lds = m <= NNC_MAX_M;
+  const size_t lds = (in_lds ? (size_t)m * 16 : 0) + (NNC_CELLS + 1) * sizeof(int) + 16;
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute((const void *)three_nn_cells_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)three_nn_cells_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
   hipLaunchKernelGGL(nn_cells_build_kernel, dim3(b), dim3(1024), 0, s, m, centers, cell_start, cell_ids, cell_rec, box);
-  hipLaunchKernelGGL(three_nn_cells_kernel, dim3(cdiv(n, 256), b), dim3(256), lds, s, n, m, points, cell_start, cell_rec,
-                     box, w, idx);
+  if (in_lds)
+    hipLaunchKernelGGL(three_nn_cells_kernel<true>, dim3(cdiv(n, 256), b), dim3(256), lds, s, n, m, points, cell_start, cell_rec,
+                       box, w, idx);
+  else
+    hipLaunchKernelGGL(three_nn_cells_kernel<false>, dim3(cdiv(n, 256), b), dim3(256), lds, s, n, m, points, cell_start, cell_rec,
+                       box, w, idx);
   return p2pb_launch_status();
 }
 

@@ -220,7 +220,8 @@ def three_nn(points_coords, centers_coords):
     m = centers_coords.shape[2]
     idx = torch.empty(b, 3, n, dtype=I32, device=points_coords.device)
     w = torch.empty(b, 3, n, dtype=F32, device=points_coords.device)
-    if 256 <= m <= 8192 and os.environ.get("P2PB_NN_CELLS", "1") != "0":  # grid search (exact) once brute force is the slower one
+    if 256 <= m and os.environ.get("P2PB_NN_CELLS", "1") != "0":  # grid search (exact) once brute force is the slower one
+        # (records in LDS up to 8192 centres, L2-resident above: PVDL's 12500-centre level)
         ws = _ws(lib().p2pb_three_nn_cells_ws_bytes(_i(b), _i(m)), points_coords.device)
         call("p2pb_three_nn_cells", _i(b), _i(m), _i(n), ptr(points_coords), ptr(centers_coords), ptr(idx), ptr(w),
              ptr(ws), stream_ptr())
