@@ -62,6 +62,19 @@ extern "C" int p2pb_pp_timeline_set(void *p) { return (int)hipMemcpyToSymbol(HIP
 #define P5_LOAD8(set) P5_LOAD1(set, 0); P5_LOAD1(set, 1); P5_LOAD1(set, 2); P5_LOAD1(set, 3); P5_LOAD1(set, 4); P5_LOAD1(set, 5); P5_LOAD1(set, 6); P5_LOAD1(set, 7)
 #define P5_TAKE1(set, i, r) asm volatile("v_mov_b32 %0, v" P5_STR(P5_R##set##i) : "=v"(r[i]))
 #define P5_TAKE8(set, r) P5_TAKE1(set, 0, r); P5_TAKE1(set, 1, r); P5_TAKE1(set, 2, r); P5_TAKE1(set, 3, r); P5_TAKE1(set, 4, r); P5_TAKE1(set, 5, r); P5_TAKE1(set, 6, r); P5_TAKE1(set, 7, r)
+// y[i0], y[i0 + 1] = raw[i0 .. i0 + 1] * sc + sh with the raw pair read from the pinned registers v[248 + i0 : 249 + i0]
+#define P5_TAKE_FMA(j, i0)                                                                                          \
+  do {                                                                                                              \
+    const f32x2 scp = {sc[i0], sc[i0 + 1]}, shp = {sh[i0], sh[i0 + 1]};                                             \
+    f32x2 yp;                                                                                                       \
+    asm volatile("v_pk_fma_f32 %0, v[" P5_STR(P5_R0##i0) ":" P5_STR(P5_R0##i0##H) "], %1, %2" : "=v"(yp) : "s"(scp), "v"(shp)); \
+    y[i0] = yp[0];                                                                                                  \
+    y[i0 + 1] = yp[1];                                                                                              \
+  } while (0)
+#define P5_R00H 249
+#define P5_R02H 251
+#define P5_R04H 253
+#define P5_R06H 255
 #define P5_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // the stage barrier: the weight DMA of the next stage has landed (vmcnt), this wave's LDS traffic is done (lgkmcnt), then a
 // RAW s_barrier (__syncthreads() would carry a vmcnt(0) and drain the prefetch)
@@ -164,13 +177,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
     }
     P5_VMCNT(0);  // the raw activations of stage s (requested a whole interval ago)
     P5_TLS(2);
-    take_b(braw);
+    if (dma >= 0) dma_a(dma, dbuf);  // (first: the scalar loads above land while the texture path accepts the DMA)
+    // the folded norm straight out of the pinned registers (packed fma, two channels per instruction; no copies), THEN the
+    // request for the next stage's activations into the same registers
+    if (XF) {
+      P5_TAKE_FMA(0, 0); P5_TAKE_FMA(1, 2); P5_TAKE_FMA(2, 4); P5_TAKE_FMA(3, 6);
+    } else {
+      take_b(braw);
+    }
     load_b(s + 1);
-    if (dma >= 0) dma_a(dma, dbuf);
     P5_TLS(1);
     if (XF) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) y[i] = __fmaf_rn(braw[i], sc[i], sh[i]);
       if (in_swish) {
         float t[8];
 #pragma unroll

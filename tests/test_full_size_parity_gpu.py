@@ -328,6 +328,16 @@ def _pw_form(cin, cout, npos=8192):
     return _lib.lib().p2pb_debug_pointwise_form(cin, cout, npos, ctypes.byref(n)), n.value
 
 
+def _expect_pingpong(*layers):
+    """the wide GEMMs took the ping-pong form -- in the default arithmetic; under P2PB_CONV_MATH=bf16x6 (the kernel exists in f16x3
+    only) they must have taken pw_split_kernel's 256-channel form"""
+    from p2p_bridge_amd import fused
+
+    want = (PW_PINGPONG,) if fused.conv_math() == "f16x3" else (3, 4)
+    for cin, cout in layers:
+        assert _pw_form(cin, cout)[0] in want, (cin, cout, _pw_form(cin, cout), fused.conv_math())
+
+
 def _pw_forms_reset():
     from p2p_bridge_amd import _lib
 
@@ -346,7 +356,7 @@ def test_c2_bench_dispatch_one_evaluation_b8(c2):
         out = model.model(x.cuda(), t.cuda()).cpu()
         ref = orc(x, t)
     model.train()
-    assert _pw_form(512, 1024)[0] == PW_PINGPONG and _pw_form(256, 512)[0] == PW_PINGPONG, (_pw_form(512, 1024), _pw_form(256, 512))
+    _expect_pingpong((512, 1024), (256, 512))
     err = (out - ref).abs().max().item()
     print(f"\nC2 one evaluation (B=8, N=8192, ping-pong GEMMs): max|hip - oracle| = {err:.3e}, |ref|max = {ref.abs().max().item():.3f}")
     assert err < TOL
@@ -387,7 +397,7 @@ def test_c2_bench_dispatch_graph_sampler_b8(c2):
     model.clear_graphs()
     out = model.sample(x_start=x.cuda(), steps=3, log_count=3, verbose=False, graph=True)
     assert model._sampler_chains(x.cuda()) == 1
-    assert _pw_form(512, 1024)[0] == PW_PINGPONG and _pw_form(256, 512)[0] == PW_PINGPONG
+    _expect_pingpong((512, 1024), (256, 512))
     errs = _teacher_forced_errors(orc, cfg, x, out["x_chain"].cpu(), 3)
     print(f"\nC2 sample(graph=True), B=8, 3 steps: max|hip - oracle| per step (teacher-forced) = {[f'{e:.2e}' for e in errs]}")
     assert max(errs) < TOL
@@ -406,7 +416,7 @@ def test_c2_bench_dispatch_two_chains_b32(c2):
     model.clear_graphs()
     assert model._sampler_chains(x.cuda()) == 2
     out = model.sample(x_start=x.cuda(), steps=2, log_count=2, verbose=False, graph=True)["x_chain"].cpu()
-    assert _pw_form(512, 1024)[0] == PW_PINGPONG and _pw_form(256, 512)[0] == PW_PINGPONG
+    _expect_pingpong((512, 1024), (256, 512))
     assert torch.isfinite(out).all()
     errs = _teacher_forced_errors(orc, cfg, x, out, 2)
     model.clear_graphs()

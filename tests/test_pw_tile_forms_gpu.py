@@ -129,6 +129,8 @@ def test_pp512_kernel_shapes():
     """pw_pp512_kernel (round 4: 512 channels x 128 positions per workgroup) on its own shape family, ragged position counts
     included (PVDL's 12500-point level): every output against float64 with per-element bounds, per-slot statistics and
     extrema, zeroed / masked tails, run-to-run identical; the form table confirms the kernel ran"""
+    if os.environ.get("P2PB_CONV_MATH", "f16x3") != "f16x3":
+        pytest.skip("pw_pp512_kernel exists in the f16x3 arithmetic only")
     env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP="1")
     r = subprocess.run([sys.executable, "-c", P5_CODE], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PP512-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
