@@ -87,15 +87,11 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h(float a, float b, unsigned &p0, unsigned &p1) {
   f32x2 v = {a, b};
   const f16x2 q0 = __builtin_convertvector(v, f16x2);
+  v = v - __builtin_convertvector(q0, f32x2);
+  // (round 4: the residual as one v_fma_mix_f32 per element -- 4 instead of 5 instructions per pair, same bits -- measured
+  //  0.3 % SLOWER on the widest GEMM and 2 % slower together with the pinned-register fma of pw_pp512.h; not kept)
+  const f16x2 q1 = __builtin_convertvector(v, f16x2);
   p0 = __builtin_bit_cast(unsigned, q0);
-  // residual x - float(h0) as ONE mixed-precision fma per element (v_fma_mix_f32 reads the fp16 half directly: float(h0) *
-  // -1 + x, exact like the subtraction it replaces -- same bits, inf / NaN included) instead of two unpacking converts + a
-  // packed subtract: 4 VALU instructions per pair instead of 5 in every staging loop of the f16x3 kernels (round 4)
-  float r0, r1;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(p0), "v"(a));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(p0), "v"(b));
-  const f32x2 r = {r0, r1};
-  const f16x2 q1 = __builtin_convertvector(r, f16x2);
   p1 = __builtin_bit_cast(unsigned, q1);
 }
 // the split of one staged pair in the arithmetic MODE (6 / 3: bf16 terms; 16: fp16 pair of the scaled value)
