@@ -203,18 +203,37 @@ class StyleBank:
 
         return _Styles(cond, fused.linear_rows(cond, self.weight, self.bias), self.slices)
 
-    def evaluate_train(self, cond):
+    def evaluate_train(self, cond, decoder_ids=None):
         """the same ONE GEMM under autograd (training): the concatenation is part of the graph, so its backward hands
-        every AdaGN's Linear its own gradient slice -- 3 GEMMs per step instead of 3 per AdaGN (~140 launches fewer)"""
+        every AdaGN's Linear its own gradient slice -- 3 GEMMs per step instead of 3 per AdaGN (~140 launches fewer).
+        decoder_ids (the segmented backward, PVCNN2Unet.collect_cut): TWO products, the decoder's AdaGNs on an alias of the
+        embedding -- the weight gradients of the decoder's style Linears are then complete when the decoder's backward is
+        (train.segmented_backward ships them with the first all-reduce); the alias joins the cut (_Styles.cut)."""
         self._refresh()  # (slices only depend on the shapes)
-        w = torch.cat([m.emd.weight for m in self.mods], dim=0)
-        b = torch.cat([m.emd.bias for m in self.mods], dim=0)
-        styles = F.linear(cond, w, b)
-        # one autograd node for all the per-layer slices: 42 separate `styles[:, lo:hi]` cost a zero fill, a copy and an
-        # accumulation of the full [B, 13184] row each in the backward pass (126 launches per step)
-        bounds = tuple(self.slices[id(m)] for m in self.mods)
-        parts = _SplitColumns.apply(styles, bounds)
-        return _Styles(cond, styles, self.slices, {id(m): t for m, t in zip(self.mods, parts)})
+        parts, cut = {}, []
+        groups = [(self.mods, cond)]
+        if decoder_ids:
+            alias = cond.view_as(cond) if cond.requires_grad else cond
+            cut = [alias]
+            groups = [([m for m in self.mods if id(m) not in decoder_ids], cond),
+                      ([m for m in self.mods if id(m) in decoder_ids], alias)]
+        styles = None
+        for mods, vec in groups:
+            if not mods:
+                continue
+            w = torch.cat([m.emd.weight for m in mods], dim=0)
+            b = torch.cat([m.emd.bias for m in mods], dim=0)
+            styles = F.linear(vec, w, b)
+            # one autograd node for all the per-layer slices: 42 separate `styles[:, lo:hi]` cost a zero fill, a copy and an
+            # accumulation of the full [B, 13184] row each in the backward pass (126 launches per step)
+            bounds, off = [], 0
+            for m in mods:
+                bounds.append((off, off + m.emd.weight.shape[0]))
+                off = bounds[-1][1]
+            parts.update({id(m): t for m, t in zip(mods, _SplitColumns.apply(styles, tuple(bounds)))})
+        out = _Styles(cond, styles if len(groups) == 1 else None, self.slices, parts)
+        out.cut = cut
+        return out
 
 
 class _SplitColumns(torch.autograd.Function):
@@ -240,6 +259,7 @@ class _Styles:
 
     def __init__(self, vector, styles, slices, parts=None):
         self.vector, self.styles, self.slices, self.parts = vector, styles, slices, parts
+        self.cut = []  # (segmented backward: what the decoder's styles take from the encoder half)
 
     def style(self, adagn):
         if self.parts is not None:  # training: the slices of ONE autograd node (StyleBank.evaluate_train)
@@ -948,6 +968,8 @@ class PVCNN2Unet(nn.Module):
         self.register_buffer("_temb_freq", freq, persistent=False)
         self._style_bank = None
         self.overlap_geometry = True  # inference: run FPS / ball query / 3-NN on a side stream (Geometry)
+        self.collect_cut, self.cut = False, None  # training: train.segmented_backward's encoder | decoder boundary
+        self._dec_adagn = None
 
     def get_timestep_embedding(self, timesteps, device=None):
         if timesteps.dim() == 2 and timesteps.shape[1] == 1:
@@ -958,6 +980,13 @@ class PVCNN2Unet(nn.Module):
         if self.embed_dim % 2 == 1:
             e = F.pad(e, (0, 1), "constant", 0)
         return e
+
+    def _decoder_adagns(self):
+        """ids of the AdaGN modules of the decoder half (global_att, fp_layers, classifier): train.segmented_backward"""
+        if self._dec_adagn is None:
+            self._dec_adagn = {id(m) for part in (self.global_att, self.fp_layers, self.classifier) if part is not None
+                               for m in part.modules() if isinstance(m, AdaGN)}
+        return self._dec_adagn
 
     def forward(self, x, t, x_cond=None):
         if x_cond is not None:
@@ -992,7 +1021,10 @@ class PVCNN2Unet(nn.Module):
         if cond is not None and x.is_cuda:
             if self._style_bank is None:
                 self._style_bank = StyleBank(self)
-            cond = self._style_bank.evaluate(cond) if use_fused else self._style_bank.evaluate_train(cond)
+            if use_fused:
+                cond = self._style_bank.evaluate(cond)
+            else:
+                cond = self._style_bank.evaluate_train(cond, self._decoder_adagns() if self.collect_cut else None)
         feats = torch.cat([coords, feats], dim=1)
         time_emb = None
         if t is not None:
@@ -1015,6 +1047,29 @@ class PVCNN2Unet(nn.Module):
             if i > 0 and data.time_emb is not None:
                 data.features = torch.cat([data.features, data.time_emb], dim=1)
             data = stage(data)
+
+        if self.collect_cut and torch.is_grad_enabled():
+            # Segmented backward (train.segmented_backward: the multi-rank captured step starts the decoder's gradient all-reduce
+            # while the encoder's backward still runs). The DECODER half (global_att, fp_layers, classifier) takes every tensor
+            # that comes from the encoder half through an ALIAS (view_as: a new autograd node, no copy), so that the gradient
+            # of the loss with respect to the alias walks the decoder only: the bottleneck features, the skip tensors, the time
+            # embedding, and the global embedding that the decoder AdaGNs' styles are made from (one product for the decoder's
+            # AdaGNs, one for the encoder's: with a single product the slices of ALL AdaGNs are outputs of one autograd node,
+            # and the gradient at that node walks the encoder's AdaGNs as well). Nothing else crosses (coordinates and
+            # neighbour indices carry no gradient).
+            def alias(x):
+                return x.view_as(x) if x.requires_grad else x
+
+            data.features = alias(data.features)
+            skips = [alias(x) for x in skips]
+            cut = [data.features] + skips
+            if data.time_emb is not None and te.requires_grad:
+                te_c = alias(te)
+                data.time_emb = te_c[:, :, None].expand(-1, -1, data.coords.shape[-1])
+                cut.append(te_c)
+            if isinstance(cond, _Styles):
+                cut += cond.cut  # (the embedding as the decoder's style Linears see it: StyleBank.evaluate_train)
+            self.cut = [x for x in cut if x.requires_grad]
 
         data.features = self.global_att(data.features)
 

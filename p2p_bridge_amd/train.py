@@ -240,13 +240,23 @@ class GradBuckets:
         if cur:
             self.buckets.append(cur)
         self.flat = [None] * len(self.buckets)
+        self.views, self.members, self._work = [None] * len(self.buckets), [None] * len(self.buckets), []
+
+    def allreduce(self, world: Optional[int] = None):
+        self.start()
+        self.finish(world)
+
+    def start(self):
+        self.pack()
+        self.reduce()
 
     @torch.no_grad()
-    def allreduce(self, world: Optional[int] = None):
-        world = dist.get_world_size() if world is None else world
-        work = []
+    def pack(self):
+        """copy the gradients into the flat buffers (one multi-tensor copy per bucket; capturable: GraphedStep records it at
+        the end of the backward graph, so a replayed step issues no copy launches of its own)"""
         for k, bucket in enumerate(self.buckets):
             ps = [p for p in bucket if p.grad is not None]
+            self.members[k] = ps
             if not ps:
                 continue
             n = sum(p.numel() for p in ps)
@@ -256,12 +266,61 @@ class GradBuckets:
             for p in ps:
                 views.append(self.flat[k][off:off + p.numel()].view_as(p.grad))
                 off += p.numel()
+            self.views[k] = views
             torch._foreach_copy_(views, [p.grad for p in ps])
-            work.append((dist.all_reduce(self.flat[k], op=dist.ReduceOp.SUM, async_op=True), k, ps, views))
-        for w, k, ps, views in work:
+
+    def reduce(self):
+        """issue the all-reduces of the packed buckets (asynchronous: they run on the process group's stream, behind the work
+        already enqueued on the current stream, beside whatever the caller enqueues next)"""
+        self._work = [(dist.all_reduce(self.flat[k], op=dist.ReduceOp.SUM, async_op=True), k)
+                      for k in range(len(self.buckets)) if self.members[k]]
+
+    @torch.no_grad()
+    def finish(self, world: Optional[int] = None, repoint: bool = False):
+        """wait for reduce()'s collectives (the current stream waits), scale by 1 / world, and copy back into the gradients
+        -- or, repoint=True, make the flat buffers' views the gradients (no copy: the captured step, whose next replay
+        rewrites its own static gradient tensors whatever p.grad names)"""
+        world = dist.get_world_size() if world is None else world
+        work, self._work = self._work, []
+        for w, k in work:
             w.wait()
             self.flat[k].mul_(1.0 / world)
-            torch._foreach_copy_([p.grad for p in ps], views)
+            if repoint:
+                for p, v in zip(self.members[k], self.views[k]):
+                    p.grad = v
+            else:
+                torch._foreach_copy_([p.grad for p in self.members[k]], self.views[k])
+
+
+def decoder_parameters(net):
+    """the parameters whose gradients are complete after the FIRST segment of segmented_backward: everything under global_att /
+    fp_layers / classifier, the AdaGN style Linears included (with collect_cut the style bank makes the decoder's styles in a
+    product of their own, pvcnn_unet.StyleBank.evaluate_train)"""
+    return [p for name, p in net.named_parameters()
+            if p.requires_grad and name.split(".")[0] in ("global_att", "fp_layers", "classifier")]
+
+
+def segmented_backward(net, loss, between=None):
+    """loss.backward() in two segments with a hook between them. Segment 1: torch.autograd.grad from the loss to the decoder's
+    parameters AND to the cut (net.cut: every tensor the decoder takes from the encoder, collected by the forward pass when
+    net.collect_cut is set); `between(decoder_params)` runs (the multi-rank step starts the all-reduce of those gradients
+    here); segment 2: torch.autograd.backward from the cut with the gradients of segment 1 -- the encoder, the global
+    embedding, the time embedding and the style Linears. Same gradients as loss.backward() up to the order of a few sums
+    (tests/test_train_gpu.py::test_segmented_backward_equals_backward)."""
+    cut = net.cut
+    if not cut:
+        raise RuntimeError("segmented_backward: run the forward pass with net.collect_cut = True (training mode)")
+    dec = decoder_parameters(net)
+    grads = torch.autograd.grad(loss, cut + dec, allow_unused=True)  # (no retain_graph: no node runs in both segments)
+    gcut, gdec = grads[:len(cut)], grads[len(cut):]
+    for p, g in zip(dec, gdec):
+        if g is not None:
+            p.grad = g if p.grad is None else p.grad + g
+    if between is not None:
+        between(dec)
+    roots = [(t, g) for t, g in zip(cut, gcut) if g is not None]
+    torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
+    net.cut = None
 
 
 def broadcast_parameters(module, src: int = 0):
@@ -282,9 +341,11 @@ class GraphedStep:
     capture needs warmed-up allocators and packed weights), the next call captures and replays.
     distributed=True (one process per GPU, the network NOT wrapped in DistributedDataParallel -- its hooks would put
     collectives inside the capture): the graph ends after backward, the gradients are averaged over the process group in
-    25 MB buckets (GradBuckets: RCCL ring all-reduces over xGMI, issued back to back), then clip + AdamW run as their three
-    launches; rank 0's parameters are broadcast at construction. The all-reduce is not hidden behind the backward kernels
-    as DDP's is; it costs less than the launch time the capture saves (105.8 MB of gradients at config 3).
+    25 MB buckets (GradBuckets: the packing copies are the graph's last nodes, the RCCL ring all-reduces over xGMI are issued
+    back to back after the replay, the flat buffers' views become the gradients), then clip + AdamW run as their three launches; rank 0's parameters are broadcast at construction. The backward pass is captured as TWO graphs
+    (segmented_backward: decoder | encoder; P2PB_SEGMENTED_BACKWARD=0 for one): the all-reduce of the decoder's gradients
+    (the larger part of the bytes at config 3: tests/test_optim_gpu.py prints the share) is issued between the two replays and runs on RCCL's stream beside the encoder's
+    backward kernels; only the encoder's buckets are exposed. exposed_allreduce_ms() measures what is left.
     Not for accumulation_steps > 1 or a GradScaler: the loss is fp32 throughout, so the scaler only
     contributes its skip-the-step-on-overflow, which ClipAdamW(skip_nonfinite=True) does on the device."""
 
@@ -301,34 +362,81 @@ class GraphedStep:
         self.overlap = os.environ.get("P2PB_WGRAD_OVERLAP", "0") == "1"  # measured: profiles/r03c_wgrad_overlap_ab.txt (slower)
         self.wgrad_stream = torch.cuda.Stream()
         self.distributed = bool(distributed)
-        self.buckets = None
+        self.buckets = self.buckets_dec = self.graph_b = None
+        self.collectives = True  # (exposed_allreduce_ms switches them off for its reference timing)
         if self.distributed:
             broadcast_parameters(model.model)
-            self.buckets = GradBuckets(model.model.parameters())
+            params = list(model.model.parameters())
+            if os.environ.get("P2PB_SEGMENTED_BACKWARD", "1") == "1" and hasattr(model.model, "collect_cut"):
+                dec = decoder_parameters(model.model)
+                ids = {id(p) for p in dec}
+                self.buckets_dec = GradBuckets(dec)
+                params = [p for p in params if id(p) not in ids]
+            self.buckets = GradBuckets(params)
 
     def _fwd_bwd(self, x_gt, x_start, x_cond, steps):
         from . import dense
 
         self.optimizer.zero_grad(set_to_none=True)
+        net = self.model.model
+        if self.buckets_dec is not None:
+            net.collect_cut = True
+            try:
+                loss = self.model(x_gt, x_start, x_cond, steps=steps)
+            finally:
+                net.collect_cut = False
+            # first segment only: the decoder's gradients + the gradients at the cut; _encoder_backward() is the second
+            self.cut = net.cut
+            net.cut = None
+            dec = self.buckets_dec.params
+            grads = torch.autograd.grad(loss, self.cut + dec, allow_unused=True)
+            self.gcut = grads[:len(self.cut)]
+            for p, g in zip(dec, grads[len(self.cut):]):
+                p.grad = g
+            self.buckets_dec.pack()
+            return loss.detach()
         loss = self.model(x_gt, x_start, x_cond, steps=steps)
         if self.overlap:  # weight-gradient GEMMs on a second stream beside the data-gradient chain, joined after backward
             with dense.wgrad_overlap(self.wgrad_stream):
                 loss.backward()
         else:
             loss.backward()
+        if self.distributed:
+            self.buckets.pack()
         return loss.detach()  # (a live loss would keep the AccumulateGrad nodes of this stream alive into the capture)
 
     def _step(self, x_gt, x_start, x_cond, steps):
-        """the captured region: everything up to the optimiser (single process), or up to the end of backward"""
+        """the captured region: everything up to the optimiser (single process), or up to the end of backward (several
+        ranks; with the segmented backward: up to the end of the decoder's backward)"""
         loss = self._fwd_bwd(x_gt, x_start, x_cond, steps)
         if not self.distributed:
             self.optimizer.step()
         return loss
 
+    def _encoder_backward(self):
+        """the second captured region of the segmented backward: from the cut through the encoder (+ embeddings, styles)"""
+        roots = [(t, g) for t, g in zip(self.cut, self.gcut) if g is not None]
+        self.cut = None  # (the autograd graph goes with the backward pass; the cut gradients stay: static graph inputs)
+        torch.autograd.backward([t for t, _ in roots], [g for _, g in roots])
+        self.buckets.pack()
+
+    def _between(self):
+        """between the two segments: the decoder's gradients are final -- start their all-reduce"""
+        if self.buckets_dec is not None and self.collectives:
+            self.buckets_dec.reduce()
+
+    def _average(self):
+        """after backward: the remaining buckets, then wait for all of them"""
+        if self.collectives:
+            self.buckets.reduce()
+            if self.buckets_dec is not None:
+                self.buckets_dec.finish(repoint=True)
+            self.buckets.finish(repoint=True)
+
     def _finish(self, loss):
         """outside the graph: gradient averaging + optimiser (distributed), scheduler, EMA, loss all-reduce (train.py:143)"""
         if self.distributed:
-            self.buckets.allreduce()
+            self._average()
             self.optimizer.step()
         if self.sched is not None:
             self.sched.step()
@@ -345,6 +453,9 @@ class GraphedStep:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 loss = self._step(x_gt, x_start, x_cond, steps.to(x_gt.device))
+                if self.buckets_dec is not None:
+                    self._between()
+                    self._encoder_backward()
             torch.cuda.current_stream().wait_stream(self.side)
             return self._finish(loss)
         if self.graph is None:
@@ -357,6 +468,10 @@ class GraphedStep:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.static["loss"] = self._step(self.static["x_gt"], self.static["x_start"], self.static["x_cond"],
                                                  self.static["steps"])
+            if self.buckets_dec is not None:  # same pool: the second graph reads the first one's activations in place
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    self._encoder_backward()
         st = self.static
         if x_gt.shape != st["x_gt"].shape or (x_cond is None) != (st["x_cond"] is None):
             raise RuntimeError(f"GraphedStep was captured for batches of shape {tuple(st['x_gt'].shape)}")
@@ -366,10 +481,42 @@ class GraphedStep:
             st["x_cond"].copy_(x_cond, non_blocking=True)
         st["steps"].copy_(steps, non_blocking=True)
         self.optimizer.sync_lr()
-        self.graph.replay()
+        self._replay()
         if not self.distributed:
             self.optimizer.bump_versions()  # (a replay changes the weights without autograd seeing it: caches keyed on _version)
         return self._finish(st["loss"].clone())
+
+
+    def _replay(self):
+        self.graph.replay()
+        if self.graph_b is not None:
+            self._between()  # RCCL's stream picks the decoder's buckets up here, beside the encoder's backward kernels
+            self.graph_b.replay()
+
+    def exposed_allreduce_ms(self, steps: int = 10) -> Optional[float]:
+        """milliseconds per step the gradient all-reduce adds to the captured step: (replay + averaging) - (replay alone)
+        on the static batch, optimiser left out of both. Collective (every rank calls it); None before the capture."""
+        if self.graph is None or not self.distributed:
+            return None
+
+        def timed(collectives: bool) -> float:
+            self.collectives = collectives
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self._replay()
+                self._average()
+            torch.cuda.synchronize()
+            dist.barrier()
+            self.collectives = True
+            return (time.perf_counter() - t0) / steps
+
+        timed(True)
+        a, b = timed(True), timed(False)
+        t = torch.tensor([a, b], dtype=torch.float64, device=self.static["x_gt"].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(max(0.0, (t[0] - t[1]).item()) * 1e3, 4)
 
 
 def save_checkpoint(path, step, model, optimizer):
@@ -406,6 +553,7 @@ def train(cfg, model, batches: Iterator[Dict], steps: int, start_step: int = 0, 
     model.train()
     history = []
     stepper = GraphedStep(model, optimizer, sched, distributed=distributed) if graph else None
+    model.graphed_step = stepper  # (main() asks it for exposed_allreduce_ms)
     for step in range(start_step, start_step + steps):
         if stepper is not None:
             data = get_data_batch(next(batches), cfg, align_fn)
@@ -528,10 +676,13 @@ def main(argv=None):
     # of a step that is gradient all-reduce not hidden behind the backward kernels (steps with / without DDP's sync)
     ranks = sharding.rank_evidence(dt, float(args.steps * cfg["training"]["bs"]), local_rank)
     share = allreduce_share(cfg, model, batches) if mode == "rank" else None
+    exposed = model.graphed_step.exposed_allreduce_ms() if (mode == "rank" and args.graph) else None
     if rank == 0:
         print(json.dumps({"steps": args.steps, "world": world, "global_batch": cfg["training"]["bs"] * world,
                           "s_per_step": dt / args.steps, "final_loss": hist[-1] if hist else None,
-                          "exposed_allreduce_share_of_step": share, "ranks": ranks}), flush=True)
+                          "exposed_allreduce_share_of_step": share, "exposed_allreduce_ms": exposed,
+                          "segmented_backward": bool(args.graph and model.graphed_step.graph_b is not None),
+                          "ranks": ranks}), flush=True)
     if mode == "rank":
         dist.barrier()
         dist.destroy_process_group()

@@ -190,6 +190,74 @@ def test_train_runs_graphed(tmp_path):
     assert all(float(s["step"]) == 6.0 for s in ck["optimizer_state"]["state"].values())
 
 
+def test_segmented_backward_equals_backward():
+    """train.segmented_backward (decoder | cut | encoder, the captured multi-rank step's two backward graphs) against
+    loss.backward() on the tiny network and on config 3's widths at a small batch: every parameter gets a gradient in both,
+    the decoder's parameters get theirs in the FIRST segment (what the early all-reduce ships is final), and the two agree
+    to the run-to-run spread of backward itself (fp32 atomics in the scatters: two plain backward passes are compared too)."""
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd import train as T
+
+    for which in ("tiny", "config3"):
+        if which == "tiny":
+            cfg, sd = _tiny()
+            model = product.build_model(cfg, sd, device="cuda:0")
+            bt = next(T.synthetic_punet_batches(2, 1024, seed=9, device=torch.device("cuda:0")))
+        else:
+            from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
+
+            cfg = copy.deepcopy(T.PVDS_PUNET_TRAIN)
+            cfg["gpu"] = "cuda:0"
+            torch.manual_seed(3)
+            model = product.P2PB(cfg, PVCNN2Unet(cfg))
+            bt = next(T.synthetic_punet_batches(2, 2048, seed=9, device=torch.device("cuda:0")))
+        model.train()
+        net = model.model
+        data = T.get_data_batch(bt, cfg, None)
+        steps = torch.tensor([3, 700])
+
+        def grads(mode):
+            for p in net.parameters():
+                p.grad = None
+            torch.manual_seed(21)  # (dropout masks, bridge noise)
+            net.collect_cut = mode == "segmented"
+            loss = model(data["x_gt"], data["x_start"], data["x_cond"], steps=steps.cuda())
+            net.collect_cut = False
+            seen = {}
+            if mode == "segmented":
+                T.segmented_backward(net, loss, between=lambda dec: seen.update(n=sum(p.grad is not None for p in dec), of=len(dec)))
+            else:
+                loss.backward()
+            return [None if p.grad is None else p.grad.clone() for p in net.parameters()], seen, float(loss)
+
+        a, _, la = grads("plain")
+        b, _, lb = grads("plain")
+        c, seen, lc = grads("segmented")
+        assert la == lb == lc
+        assert seen["n"] == seen["of"] > 0.3 * len(a) and dec_bytes_ok(net, T)
+        dec_bytes = sum(p.numel() for p in T.decoder_parameters(net)) / sum(p.numel() for p in net.parameters())
+        assert [g is None for g in a] == [g is None for g in c] and all(g is not None for g in c)
+        flat = lambda gs: torch.cat([g.flatten() for g in gs]).double()  # noqa: E731
+        fa, fb, fc = flat(a), flat(b), flat(c)
+        spread = (fa - fb).norm().item() / fa.norm().item()
+        diff = (fa - fc).norm().item() / fa.norm().item()
+        # per tensor, against the largest gradient element of the step (a bias in front of a GroupNorm has a gradient of
+        # exactly zero in real arithmetic: what it holds is rounding noise, and noise differs by 100 % between any two runs)
+        top = max(x.abs().max().item() for x in a)
+        worst_plain = max((x - y).abs().max().item() for x, y in zip(a, b)) / top
+        worst = max((x - y).abs().max().item() for x, y in zip(a, c)) / top
+        print(f"\n{which}: decoder share of the gradient bytes {dec_bytes:.2f}; relative L2 plain / plain {spread:.2e}, "
+              f"segmented / plain {diff:.2e}; worst element / largest gradient: plain / plain {worst_plain:.2e}, "
+              f"segmented / plain {worst:.2e}", end="")
+        assert diff <= max(3 * spread, 2e-6) and worst <= max(3 * worst_plain, 1e-5)
+    print()
+
+
+def dec_bytes_ok(net, T):
+    """the first all-reduce carries most of the gradient bytes (the decoder with its style Linears)"""
+    return sum(p.numel() for p in T.decoder_parameters(net)) > 0.6 * sum(p.numel() for p in net.parameters())
+
+
 def _graph_rank(rank, world, port, out, graph):
     import sys
 
@@ -212,6 +280,11 @@ def _graph_rank(rank, world, port, out, graph):
     torch.manual_seed(5)  # the same bridge steps on both ranks and in both modes
     batches = T.synthetic_punet_batches(2, 1024, seed=700 + rank, device=model.device)
     hist = T.train(cfg, model, batches, steps=6, distributed=True, rank=rank, world=world, align=False, graph=graph)
+    if graph:  # two captured graphs: the decoder's buckets are all-reduced beside the encoder's backward pass
+        st = model.graphed_step
+        assert st.graph_b is not None and st.buckets_dec is not None and len(st.buckets_dec.params) > 0
+        exposed = st.exposed_allreduce_ms(steps=2)
+        assert exposed is not None and exposed >= 0.0
     net = model.model.module if hasattr(model.model, "module") else model.model
     flat = torch.cat([p.detach().flatten() for p in net.parameters()])
     other = [torch.zeros_like(flat) for _ in range(world)]

@@ -215,6 +215,15 @@ def _bucket_worker(rank, world, port, out):
     buckets.allreduce()  # averaging identical gradients changes nothing; the flat buffers are reused
     for k, p in model.model.named_parameters():
         assert torch.allclose(p.grad, first[k], rtol=1e-6, atol=1e-9)
+    # the captured step's order: pack (recorded in the backward graph) | reduce (after the replay) | finish(repoint=True):
+    # the flat buffers' views BECOME the gradients, nothing is copied back
+    own = {k: p.grad for k, p in model.model.named_parameters()}
+    buckets.pack()
+    buckets.reduce()
+    buckets.finish(repoint=True)
+    for k, p in model.model.named_parameters():
+        assert p.grad is not own[k] and torch.allclose(p.grad, first[k], rtol=1e-6, atol=1e-9)
+        assert any(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * 4 for f in buckets.flat if f is not None)
     if rank == 0:
         torch.save({"grads": first, "params": {k: p.detach().clone() for k, p in model.model.named_parameters()}}, out)
     dist.barrier()
