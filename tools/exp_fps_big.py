@@ -37,11 +37,12 @@ def run(mode, x, m, reps=2):
     return idx, (time.perf_counter() - t0) / reps * 1e3
 
 
-for kind, b, n, m in [("room", 4, 50000, 12500), ("room", 1, 50000, 12500), ("volume", 4, 50000, 12500),
-                      ("sphere", 2, 150000, 50000), ("room", 2, 20000, 5000), ("room", 8, 50000, 12500)]:
-    x = clouds(kind, b, n)
-    res = {mode: run(mode, x, m) for mode in ("grid", "coop") + (("single",) if n <= 50000 and b <= 4 else ())}
-    ref = res["coop"][0]
-    ok = all(torch.equal(v[0], ref) for v in res.values())
-    print(f"{kind:7s} b={b} n={n} m={m}: " + ", ".join(f"{k} {v[1]:8.2f} ms" for k, v in res.items()) + f"   identical: {ok}",
-          flush=True)
+if __name__ == "__main__":
+  for kind, b, n, m in [("room", 4, 50000, 12500), ("room", 1, 50000, 12500), ("volume", 4, 50000, 12500),
+                        ("sphere", 2, 150000, 50000), ("room", 2, 20000, 5000), ("room", 8, 50000, 12500)]:
+      x = clouds(kind, b, n)
+      res = {mode: run(mode, x, m) for mode in ("grid", "coop") + (("single",) if n <= 50000 and b <= 4 else ())}
+      ref = res["coop"][0]
+      ok = all(torch.equal(v[0], ref) for v in res.values())
+      print(f"{kind:7s} b={b} n={n} m={m}: " + ", ".join(f"{k} {v[1]:8.2f} ms" for k, v in res.items()) + f"   identical: {ok}",
+            flush=True)
