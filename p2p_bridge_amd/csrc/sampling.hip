@@ -561,7 +561,12 @@ __device__ __forceinline__ int fg_key_index(u64 key) {
 // (the wave id in the key's low bits names the winner: no slot array, no 16-lane reduction after the barrier); a wave none
 // of whose cells changed keeps its maximum; the wave that updates a cell finds ITS new maximum in the same reduction as the
 // cell's (the lanes' other cells join the candidates) and brings the cell's own record up to date after the barrier.
-__global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const float *__restrict__ coords,
+#ifndef FG_NW
+#define FG_NW 16  // waves per cloud, 64 / FG_NW cells per lane. 8 waves x 8 cells (-DFG_NW=8) measured 32.3 ms against 23.5 at
+#endif            // 50000 -> 12500: the cell-select chains double and two updates per wave and round become common
+
+constexpr int FG_NS = 64 / FG_NW;  // cells per lane
+__global__ __launch_bounds__(64 * FG_NW) void fps_grid_kernel(int n, int m, const float *__restrict__ coords,
                                                         const int *__restrict__ cell_start,
                                                         const float4 *__restrict__ rec, const float *__restrict__ cbox,
                                                         float *__restrict__ mind, int *__restrict__ indices) {
@@ -577,12 +582,12 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
 
   // this lane's four cells: record range, tight box, key of the farthest point (distance bits | tie-key: the
   // reference's total order) and that point's coordinates -- all in registers
-  int s0[4], cn[4];
-  float blo[4][3], bhi[4][3], cmax[4], cx[4], cy[4], cz[4];
-  u64 ckey[4];
+  int s0[FG_NS], cn[FG_NS];
+  float blo[FG_NS][3], bhi[FG_NS][3], cmax[FG_NS], cx[FG_NS], cy[FG_NS], cz[FG_NS];
+  u64 ckey[FG_NS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int cell = fg_cell(wave, lane + 64 * i);
+  for (int i = 0; i < FG_NS; ++i) {
+    const int cell = fg_cell(wave + FG_NW * (i >> 2), lane + 64 * (i & 3));
     s0[i] = cs[cell];
     cn[i] = cs[cell + 1] - s0[i];
 #pragma unroll
@@ -594,8 +599,9 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
     ckey[i] = 0;
     cx[i] = cy[i] = cz[i] = 0.0f;
   }
-  for (int k = t; k < n; k += 1024) md[k] = 1e38f;
+  for (int k = t; k < n; k += 64 * FG_NW) md[k] = 1e38f;
   if (t < 3) gmax[t] = 0;
+  if (t < 128) ((float *)sxyz)[t] = 0.0f;
   int jm3 = 1;  // j mod 3
   if (t == 0) out[0] = 0;
   float sx = c[0], sy = c[n], sz = c[(size_t)2 * n];  // sample 0 = point 0
@@ -614,7 +620,7 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
     const float wy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, byv), from));
     const float wz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bzv), from));
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FG_NS; ++i)
       if (lane == src && ii == i) {
         ckey[i] = wbest;
         cmax[i] = __uint_as_float((unsigned)(wbest >> 32) - 1u);
@@ -642,13 +648,16 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
       const float dz = fmaxf(fmaxf(blo[i][2] - sz, sz - bhi[i][2]), 0.0f);
       return __ballot(cn[i] > 0 && (j == 1 || !(sqdist3(dx, dy, dz) >= cmax[i])));
     };
-    unsigned long long todo0 = hits(0), todo1 = hits(1), todo2 = hits(2), todo3 = hits(3);  // (four scalars: an array went to scratch)
+    unsigned long long todo0 = hits(0), todo1 = hits(1), todo2 = hits(2), todo3 = hits(3);  // (scalars: an array went to scratch)
+    unsigned long long todo4 = 0, todo5 = 0, todo6 = 0, todo7 = 0;
+    if constexpr (FG_NS == 8) todo4 = hits(4), todo5 = hits(5), todo6 = hits(6), todo7 = hits(7);
 #if defined(FG_ABL) && FG_ABL == 2  // box tests, no cell updates after round 1
     if (j > 1) {
-      asm volatile("" ::"s"(todo0), "s"(todo1), "s"(todo2), "s"(todo3));
-      todo0 = todo1 = todo2 = todo3 = 0;
+      asm volatile("" ::"s"(todo0), "s"(todo1), "s"(todo2), "s"(todo3), "s"(todo4), "s"(todo5), "s"(todo6), "s"(todo7));
+      todo0 = todo1 = todo2 = todo3 = todo4 = todo5 = todo6 = todo7 = 0;
     }
 #endif
+#define FG_ANY (todo0 | todo1 | todo2 | todo3 | todo4 | todo5 | todo6 | todo7)
     auto pick = [&](int &ii, int &src) {  // (wave-uniform) the next cell to update: (slot, owning lane); false when none is left
 #define FG_PICK(I, T)          \
   if (T) {                     \
@@ -661,20 +670,29 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
       FG_PICK(1, todo1)
       FG_PICK(2, todo2)
       FG_PICK(3, todo3)
+      FG_PICK(4, todo4)
+      FG_PICK(5, todo5)
+      FG_PICK(6, todo6)
+      FG_PICK(7, todo7)
 #undef FG_PICK
       return false;
     };
     int ia, la;
 #ifdef FG_TIMELINE
-    one = __builtin_popcountll(todo0) + __builtin_popcountll(todo1) + __builtin_popcountll(todo2) + __builtin_popcountll(todo3);
+    one = __builtin_popcountll(todo0) + __builtin_popcountll(todo1) + __builtin_popcountll(todo2) + __builtin_popcountll(todo3) +
+          __builtin_popcountll(todo4) + __builtin_popcountll(todo5) + __builtin_popcountll(todo6) + __builtin_popcountll(todo7);
     FG_STAMP(1, one);
 #endif
-    if ((todo0 | todo1 | todo2 | todo3) != 0) {  // (round 1: every cell with a point)
+    if (FG_ANY != 0) {  // (round 1: every cell with a point)
       __builtin_amdgcn_s_setprio(3);             // the round waits for these waves
       while (pick(ia, la)) {  // all 64 lanes recompute the cell with exactly fps_kernel's arithmetic
-        const bool last = (todo0 | todo1 | todo2 | todo3) == 0;
-        const int a = ia == 0 ? s0[0] : ia == 1 ? s0[1] : ia == 2 ? s0[2] : s0[3];
-        const int c2 = ia == 0 ? cn[0] : ia == 1 ? cn[1] : ia == 2 ? cn[2] : cn[3];
+        const bool last = FG_ANY == 0;
+        int a = s0[0], c2 = cn[0];
+#pragma unroll
+        for (int i = 1; i < FG_NS; ++i) {
+          a = ia == i ? s0[i] : a;
+          c2 = ia == i ? cn[i] : c2;
+        }
         const int p0 = __builtin_amdgcn_readlane(a, la), pn = __builtin_amdgcn_readlane(c2, la);
         float4 r;
         float dold;
@@ -693,7 +711,7 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
         float ox = 0.0f, oy = 0.0f, oz = 0.0f;
         if (last) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < FG_NS; ++i)
             if (ckey[i] > okey && !(lane == la && ia == i)) {
               okey = ckey[i];
               ox = cx[i], oy = cy[i], oz = cz[i];
@@ -773,6 +791,7 @@ __global__ __launch_bounds__(1024) void fps_grid_kernel(int n, int m, const floa
     sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq[1]), ws));
     sz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq[2]), ws));
     if (t == 0) out[j] = fg_key_index(fin);
+#undef FG_ANY
 #ifdef FG_TIMELINE
     FG_STAMP(7, __float_as_int(sz));
     if (j > 1 && one == 1) {
@@ -814,6 +833,6 @@ extern "C" int p2pb_furthest_point_sampling_grid(int b, int n, int m, const floa
   w += (size_t)b * n * 16;
   float *mind = (float *)w;
   hipLaunchKernelGGL(fps_grid_build_kernel, dim3(b), dim3(1024), 0, s, n, coords, cell_start, rec, cbox);
-  hipLaunchKernelGGL(fps_grid_kernel, dim3(b), dim3(1024), 0, s, n, m, coords, cell_start, rec, cbox, mind, idx);
+  hipLaunchKernelGGL(fps_grid_kernel, dim3(b), dim3(64 * FG_NW), 0, s, n, m, coords, cell_start, rec, cbox, mind, idx);
   return p2pb_launch_status();
 }
