@@ -660,7 +660,8 @@ __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, cons
   // ds_write2_b32 + ds_write_b32 -- returned wrong values for wave 3's points when a matrix kernel of ANOTHER stream shared the CU
   // (the two-chain sampler: 10-15 % of such launches had one wave's 16 points x 64 channels off by O(1); alone, or beside
   // element-wise kernels, never; tools/dbg/devox_conc.py). Either change alone removes it (own points: 0 of 90 launches
-  // wrong; 16-byte stores: 0 of 90); ds_write_b96 is not used anywhere in this library any more.
+  // wrong; 16-byte stores: 0 of 90 as flat_store_dwordx4 -- what a volatile store through a generic pointer compiles to -- and
+  // 0 of 270 as the ds_write_b128 below); ds_write_b96 is not used anywhere in this library any more.
   if (lane < 16) {
     const int tt = wave * 16 + lane;
     const int i = min(p0 + tt, n - 1);
@@ -668,10 +669,13 @@ __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, cons
     const Corners k = devox_corners(co[i], co[i + n], co[i + 2 * n], r);
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    *(volatile i32x4 *)&sidx[tt][0] = i32x4{k.idx[0], k.idx[1], k.idx[2], k.idx[3]};
-    *(volatile i32x4 *)&sidx[tt][4] = i32x4{k.idx[4], k.idx[5], k.idx[6], k.idx[7]};
-    *(volatile f32x4 *)&sw[tt][0] = f32x4{k.w[0], k.w[1], k.w[2], k.w[3]};
-    *(volatile f32x4 *)&sw[tt][4] = f32x4{k.w[4], k.w[5], k.w[6], k.w[7]};
+    // (address_space(3): a volatile store through a generic pointer is a flat_store_dwordx4)
+#define DV_LDS __attribute__((address_space(3)))
+    *(volatile DV_LDS i32x4 *)&sidx[tt][0] = i32x4{k.idx[0], k.idx[1], k.idx[2], k.idx[3]};
+    *(volatile DV_LDS i32x4 *)&sidx[tt][4] = i32x4{k.idx[4], k.idx[5], k.idx[6], k.idx[7]};
+    *(volatile DV_LDS f32x4 *)&sw[tt][0] = f32x4{k.w[0], k.w[1], k.w[2], k.w[3]};
+    *(volatile DV_LDS f32x4 *)&sw[tt][4] = f32x4{k.w[4], k.w[5], k.w[6], k.w[7]};
+#undef DV_LDS
   }
   __syncthreads();
   const float *g = grid + (size_t)b * r3 * c;
