@@ -138,9 +138,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
   // (60-170 cycles per 1 KB instruction, tools/exp_p5_timeline.py), so each half issues its share in its own non-matrix
   // window: half 1 at the top of the interval (beside half 0's MFMA block), half 0 right after its MFMA block
   auto dma_a = [&](int s, int buf) {
-#ifdef P5_EXP_NODMA
-    return;
-#endif
     const int st = s < nstage ? s : nstage - 1;
     const u32x4 *src = wp + ((size_t)st * nblk128 + by * 4) * PWS_TILE;
     u32x4 *dst = p5_lds + buf * P5_A_SLOTS;
@@ -163,9 +160,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
   // -> cvt -> sub -> cvt overlap. 4 swish(v) = v * rcp(0.25 + 0.25 e^-v): the activation scale of the fp16 split
   // (SPLIT_F16_SX = 4, a power of two: exact) rides in the reciprocal's argument
   auto stage = [&](int s, int buf, int dma, int dbuf) {
-#ifdef P5_EXP_NOSTAGE
-    return;
-#endif
     float braw[8], y[8], sc[8], sh[8];
     if (XF) {
 #pragma unroll

@@ -554,7 +554,8 @@ __device__ __forceinline__ int fg_key_index(u64 key) {
   const unsigned sec = ~((unsigned)key >> 4) & 0x0FFFFFFFu;
   return (int)(((sec & 0x7FFFFu) << 9) | (sec >> 19));
 }
-// What bounds a round (round 4, tools/dbg/fg_abl.py on timing-only builds, 50000 -> 12500, cycles at 2.4 GHz): 1944 with
+// What bounds a round (round 4, tools/dbg/fg_abl.py on timing-only builds -- tools/exp/patches/sampling_fg_ablations.patch --,
+// 50000 -> 12500, cycles at 2.4 GHz): 1944 with
 // neither box tests nor updates (slot write, barrier, reading the winner -- sixteen waves, four to a SIMD, each issuing the
 // same instructions), 2461 with the box tests, 4908 in all: the wave that updates a cell is the critical path (one trip to
 // L2, then reductions), everything else is instruction count x 16 waves. Hence: the waves' maxima meet in ONE LDS atomic
@@ -640,9 +641,6 @@ __global__ __launch_bounds__(64 * FG_NW) void fps_grid_kernel(int n, int m, cons
     //  20 % SLOWER than taking them one after the other with all 64 lanes; taking them two at a time with both cells'
     //  loads in flight changed nothing, round 4: 0.2 cells per wave and round, two or more in 1 % of them.)
     auto hits = [&](int i) {
-#if defined(FG_ABL) && FG_ABL == 1  // timing experiments (wrong results): no box tests after round 1
-      if (j > 1) return 0ull;
-#endif
       const float dx = fmaxf(fmaxf(blo[i][0] - sx, sx - bhi[i][0]), 0.0f);
       const float dy = fmaxf(fmaxf(blo[i][1] - sy, sy - bhi[i][1]), 0.0f);
       const float dz = fmaxf(fmaxf(blo[i][2] - sz, sz - bhi[i][2]), 0.0f);
@@ -651,12 +649,6 @@ __global__ __launch_bounds__(64 * FG_NW) void fps_grid_kernel(int n, int m, cons
     unsigned long long todo0 = hits(0), todo1 = hits(1), todo2 = hits(2), todo3 = hits(3);  // (scalars: an array went to scratch)
     unsigned long long todo4 = 0, todo5 = 0, todo6 = 0, todo7 = 0;
     if constexpr (FG_NS == 8) todo4 = hits(4), todo5 = hits(5), todo6 = hits(6), todo7 = hits(7);
-#if defined(FG_ABL) && FG_ABL == 2  // box tests, no cell updates after round 1
-    if (j > 1) {
-      asm volatile("" ::"s"(todo0), "s"(todo1), "s"(todo2), "s"(todo3), "s"(todo4), "s"(todo5), "s"(todo6), "s"(todo7));
-      todo0 = todo1 = todo2 = todo3 = todo4 = todo5 = todo6 = todo7 = 0;
-    }
-#endif
 #define FG_ANY (todo0 | todo1 | todo2 | todo3 | todo4 | todo5 | todo6 | todo7)
     auto pick = [&](int &ii, int &src) {  // (wave-uniform) the next cell to update: (slot, owning lane); false when none is left
 #define FG_PICK(I, T)          \
@@ -697,11 +689,6 @@ __global__ __launch_bounds__(64 * FG_NW) void fps_grid_kernel(int n, int m, cons
         float4 r;
         float dold;
         FG_STAMP(2, p0 + pn);
-#if defined(FG_ABL) && FG_ABL == 3  // timing experiment: no trip to L2 (made-up records)
-        r = make_float4(sx + lane, sy, sz, __int_as_float(p0 + lane));
-        dold = 1.0f + lane;
-        if (j == 1)
-#endif
         if (lane < pn) {  // (a cell holds 12 points on average at 50000: one pass)
           r = rc[p0 + lane];
           dold = md[p0 + lane];
@@ -729,9 +716,6 @@ __global__ __launch_bounds__(64 * FG_NW) void fps_grid_kernel(int n, int m, cons
             const float d = sqdist3(r.x - sx, r.y - sy, r.z - sz);
             float d2;  // (bare v_min_f32: see fps_kernel)
             asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(dold));
-#if defined(FG_ABL) && FG_ABL == 3
-            if (j == 1)
-#endif
             if (d2 != dold) md[p0 + k] = d2;
             const u64 key = fg_key(d2, __float_as_int(r.w));
             if (key > best) {
@@ -756,12 +740,8 @@ __global__ __launch_bounds__(64 * FG_NW) void fps_grid_kernel(int n, int m, cons
             best = okey;
             bx = ox, by = oy, bz = oz;
           }
-#if defined(FG_ABL) && FG_ABL == 4  // timing experiment: no reduction (lane 0's candidate)
-          wkey = j == 1 ? wave_max_u64(best) : (u64)__builtin_amdgcn_readfirstlane((int)(best >> 32)) << 32;
-#else
           wkey = wave_max_u64(best);
-#endif
-          const int from = __builtin_ctzll(__ballot(best == wkey) | (1ull << 63));  // (an all-empty wave: the zero key, lane 0)
+          const int from = __builtin_ctzll(__ballot(best == wkey));  // (an all-empty wave: the zero key, lane 0)
           wkx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), from));
           wky = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), from));
           wkz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), from));
