@@ -136,6 +136,133 @@ static inline unsigned absmax_blocks(size_t n) {
   return (unsigned)(b < 1 ? 1 : b > 64 ? 64 : b);
 }
 
+// ---- GroupNorm(+AdaGN) finisher: the {sum, sum of squares} partials of a producing kernel -> per-(sample, channel) scale / shift ----
+// (the arithmetic of gn_affine_kernel, conv3d.hip, which calls this too: one workgroup, >= 256 threads of it, per (sample, group);
+//  fixed summation order, double accumulation: the same bits whichever kernel runs it.) A producing kernel given a GnFinish runs
+// it itself: the workgroup that completes a (sample, group) -- a ticket counted after a device-scope release of every
+// contributor's partials -- computes the group's affine, and the separate gn_affine launch between producer and consumer (a
+// dependent launch costs ~13 us of the chain on this part, 48 of them per evaluation) is gone.
+struct GnFinish {
+  const float *gamma, *beta, *style;  // [c] | NULL, [c] | NULL, rows of (factor[c] | bias[c]) | NULL
+  float *scale, *shift, *chmean;      // f32[b, c] outputs (chmean may be NULL); scale == NULL: no finisher
+  unsigned *tickets;                  // one counter per (sample, group), zero before the launch and zero again after it
+  double count_per_channel;
+  int style_stride, groups, expected;  // expected: contributing workgroups per (sample, group)
+  float eps;
+};
+typedef float gnf_f32x2 __attribute__((ext_vector_type(2)));
+// Partials that a finisher in ANOTHER workgroup of the same launch will read travel as device-scope (write-through / cache-
+// bypassing) accesses: the XCDs' L2s are not coherent with each other for plain accesses, and the alternative -- a device-scope
+// release fence (buffer_wbl2) at the end of every producing workgroup -- cost +20 % of the sampler when it was tried.
+__device__ __forceinline__ void gnf_store(float *p, float v, bool coherent) {
+  if (coherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+__device__ __forceinline__ float gnf_load(const float *p, bool coherent) {
+  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+// lds: 4 x 256 doubles. Call with all threads of the workgroup (threads >= 256 idle through the barriers).
+__device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int g,
+                                                double *lds, float *mean_rstd = nullptr, bool coherent = false) {
+  double *rs = lds, *rq = lds + 256, *chs = lds + 512, *chq = lds + 768;
+  const int t = threadIdx.x;
+  const int cg = c / f.groups, g0 = g * cg;
+  const int nt = 256 / cg;  // partial accumulators per channel
+  const int k = t % cg, j = t / cg;
+  double s = 0.0, q = 0.0;
+  if (t < 256 && j < nt) {  // (same order, four slots' loads in flight: the plain loop was one L2 round trip per slot)
+    const float *p0 = part + ((size_t)b * nslots * c + g0 + k) * 2;
+    const size_t pitch = (size_t)c * 2;
+    int sl = j;
+    for (; sl + 3 * nt < nslots; sl += 4 * nt) {
+      gnf_f32x2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *pp = p0 + (size_t)(sl + u * nt) * pitch;
+        if (coherent) v[u] = gnf_f32x2{gnf_load(pp, true), gnf_load(pp + 1, true)};
+        else v[u] = *(const gnf_f32x2 *)pp;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s += (double)v[u][0];
+        q += (double)v[u][1];
+      }
+    }
+    for (; sl < nslots; sl += nt) {
+      const float *p = p0 + (size_t)sl * pitch;
+      s += (double)gnf_load(p, coherent);
+      q += (double)gnf_load(p + 1, coherent);
+    }
+  }
+  if (t < 256) {
+    rs[t] = s;
+    rq[t] = q;
+  }
+  __syncthreads();
+  if (t < cg) {
+    double ts = 0.0, tq = 0.0;
+    for (int jj = 0; jj < nt; ++jj) {
+      ts += rs[jj * cg + t];
+      tq += rq[jj * cg + t];
+    }
+    chs[t] = ts;
+    chq[t] = tq;
+  }
+  __syncthreads();
+  if (t < cg) {
+    double gs = 0.0, gq = 0.0;
+    for (int kk = 0; kk < cg; ++kk) {
+      gs += chs[kk];
+      gq += chq[kk];
+    }
+    const int ch = g0 + t;
+    const double n = f.count_per_channel * cg;
+    const double mean = gs / n;
+    double var = gq / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)f.eps);
+    const double ga = f.gamma ? (double)f.gamma[ch] : 1.0, be = f.beta ? (double)f.beta[ch] : 0.0;
+    const double fa = f.style ? (double)f.style[(size_t)b * f.style_stride + ch] : 1.0;
+    const double bi = f.style ? (double)f.style[(size_t)b * f.style_stride + c + ch] : 0.0;
+    const double sc = rstd * ga * fa;
+    const double sh = (be - mean * rstd * ga) * fa + bi;
+    f.scale[(size_t)b * c + ch] = (float)sc;
+    f.shift[(size_t)b * c + ch] = (float)sh;
+    if (f.chmean) f.chmean[(size_t)b * c + ch] = (float)(sc * (chs[t] / f.count_per_channel) + sh);
+    if (mean_rstd && t == 0) {  // training: the backward pass of the norm needs the group moments (normact.hip)
+      mean_rstd[((size_t)b * f.groups + g) * 2] = (float)mean;
+      mean_rstd[((size_t)b * f.groups + g) * 2 + 1] = (float)rstd;
+    }
+  }
+  __syncthreads();  // (lds may be reused by the caller, or by the next group)
+}
+// End of a producing workgroup whose channel tile [c0, c0 + cw) of sample b is written: count it on the groups it covers and
+// finish those it completes. Every thread calls it; `lds` as above (the kernel's operand tiles are free by now).
+// The caller has made sure that tile and group boundaries nest (cw % cg == 0 or cg % cw == 0, c0 % min(cw, cg) == 0).
+__device__ __forceinline__ void gn_finish_arrive(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int c0, int cw,
+                                                 double *lds) {
+  __shared__ int gnf_last;
+  const int cg = c / f.groups;
+  // this thread's partials (device-scope stores: gnf_store) have reached memory before the workgroup is counted
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int gfirst = c0 / cg, glast = (min(c0 + cw, c) - 1) / cg;
+  for (int g = gfirst; g <= glast; ++g) {
+    if (threadIdx.x == 0) {
+      const unsigned old = atomicAdd(&f.tickets[(size_t)b * f.groups + g], 1u);
+      gnf_last = old == (unsigned)f.expected - 1u;
+    }
+    __syncthreads();
+    const bool last = gnf_last != 0;
+    __syncthreads();
+    if (last) {  // (the other contributors' partials: device-scope loads)
+      gn_finish_group(c, nslots, part, f, b, g, lds, nullptr, true);
+      if (threadIdx.x == 0)  // ready for the next launch that is handed this counter
+        __hip_atomic_store(&f.tickets[(size_t)b * f.groups + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- 32 rows x 32 lanes -> one row total per lane ("reduce-scatter" over the half-wave) ----
 // A GEMM epilogue holds, per lane, one value of each of 32 output-channel rows and needs every row's reduction
 // over the 32 lanes of its half-wave. Reducing the rows one by one costs 5 DPP steps per row (160 per statistic);
@@ -220,6 +347,11 @@ enum {
   P2PB_FORM_PW_GATHER = 6,    // pw_wide_kernel<GATHER> (grouped operand built on the fly)
 };
 void p2pb_note_pointwise_form(int cin, int cout, int npos, int form);
+// the GroupNorm finisher armed for this thread's next statistics-producing launch (abi.hip), its ticket counters, and the
+// separate launch for producers that do not run it themselves (conv3d.hip)
+bool p2pb_gn_finisher_take(GnFinish *out);
+unsigned *p2pb_gn_tickets(size_t n, hipStream_t s);
+int p2pb_gn_affine_launch(int b, int c, int nslots, const float *part, const GnFinish &f, hipStream_t s);
 
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);

@@ -2230,75 +2230,22 @@ static __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups
                                                         int style_stride, float eps, float *__restrict__ scale,
                                                         float *__restrict__ shift, float *__restrict__ chmean,
                                                         float *__restrict__ mean_rstd) {
-  __shared__ double rs[256], rq[256];
-  __shared__ double chs[256], chq[256];  // per-channel totals of this group (cg <= 256)
-  const int b = blockIdx.y, g = blockIdx.x, t = threadIdx.x;
-  const int cg = c / groups, g0 = g * cg;
-  const int nt = 256 / cg;  // partial accumulators per channel
-  const int k = t % cg, j = t / cg;
-  double s = 0.0, q = 0.0;
-  if (j < nt) {  // (same order, four slots' loads in flight: the plain loop was one L2 round trip per slot)
-    const float *p0 = part + ((size_t)b * nslots * c + g0 + k) * 2;
-    const size_t pitch = (size_t)c * 2;
-    int sl = j;
-    for (; sl + 3 * nt < nslots; sl += 4 * nt) {
-      f32x2 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const f32x2 *)(p0 + (size_t)(sl + u * nt) * pitch);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        s += (double)v[u][0];
-        q += (double)v[u][1];
-      }
-    }
-    for (; sl < nslots; sl += nt) {
-      const float *p = p0 + (size_t)sl * pitch;
-      s += (double)p[0];
-      q += (double)p[1];
-    }
-  }
-  rs[t] = s;
-  rq[t] = q;
-  __syncthreads();
-  if (t < cg) {
-    double ts = 0.0, tq = 0.0;
-    for (int jj = 0; jj < nt; ++jj) {
-      ts += rs[jj * cg + t];
-      tq += rq[jj * cg + t];
-    }
-    chs[t] = ts;
-    chq[t] = tq;
-  }
-  __syncthreads();
-  if (t >= cg) return;
-  double gs = 0.0, gq = 0.0;
-  for (int kk = 0; kk < cg; ++kk) {
-    gs += chs[kk];
-    gq += chq[kk];
-  }
-  const int ch = g0 + t;
-  const double n = count_per_channel * cg;
-  const double mean = gs / n;
-  double var = gq / n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double rstd = 1.0 / sqrt(var + (double)eps);
-  const double ga = gamma ? (double)gamma[ch] : 1.0, be = beta ? (double)beta[ch] : 0.0;
-  const double f = style ? (double)style[(size_t)b * style_stride + ch] : 1.0;
-  const double bi = style ? (double)style[(size_t)b * style_stride + c + ch] : 0.0;
-  const double sc = rstd * ga * f;
-  const double sh = (be - mean * rstd * ga) * f + bi;
-  scale[(size_t)b * c + ch] = (float)sc;
-  shift[(size_t)b * c + ch] = (float)sh;
-  if (chmean) chmean[(size_t)b * c + ch] = (float)(sc * (chs[t] / count_per_channel) + sh);
-  if (mean_rstd && t == 0) {  // training: the backward pass of the norm needs the group moments (normact.hip)
-    mean_rstd[((size_t)b * groups + g) * 2] = (float)mean;
-    mean_rstd[((size_t)b * groups + g) * 2 + 1] = (float)rstd;
-  }
+  __shared__ double lds[4 * 256];
+  GnFinish f;  // (the arithmetic lives in common.h: producing kernels handed a GnFinish run it themselves)
+  f.gamma = gamma, f.beta = beta, f.style = style, f.scale = scale, f.shift = shift, f.chmean = chmean, f.tickets = nullptr;
+  f.count_per_channel = count_per_channel, f.style_stride = style_stride, f.groups = groups, f.expected = 0, f.eps = eps;
+  gn_finish_group(c, nslots, part, f, blockIdx.y, blockIdx.x, lds, mean_rstd);
 }
 
 // part: f32[b, nslots, c, 2]; gamma/beta f32[c] or NULL; style = rows of (factor[c] | bias[c]) with a row pitch of
 // style_stride floats (a column slice of the one style GEMM of the evaluation), or NULL -> scale/shift/chmean f32[b,c]
 #if CONV_TU != 6
+// (for the producers of other translation units that were handed a finisher they cannot run themselves)
+int p2pb_gn_affine_launch(int b, int c, int nslots, const float *part, const GnFinish &f, hipStream_t s) {
+  hipLaunchKernelGGL(gn_affine_kernel, dim3(f.groups, b), dim3(256), 0, s, c, f.groups, nslots, f.count_per_channel, part, f.gamma,
+                     f.beta, f.style, f.style_stride, f.eps, f.scale, f.shift, f.chmean, (float *)nullptr);
+  return p2pb_launch_status();
+}
 extern "C" int p2pb_gn_affine_params_ex(int b, int c, int groups, int nslots, double count_per_channel,
                                         const float *part, const float *gamma, const float *beta, const float *style,
                                         int style_stride, float eps, float *scale, float *shift, float *chmean,

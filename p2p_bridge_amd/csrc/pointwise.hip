@@ -14,6 +14,7 @@
 // (so stores are lane-consecutive), K = input channels. Small-C layers are HBM-bound (8 FLOP/B at
 // C=32..64), the wide ones (Pnet2Stage 512->1024) MFMA-bound.
 #include "common.h"
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -594,7 +595,8 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
                                              int wm, int wn, int l31, int khalf, int cout, int P, int nslots,
                                              const float *__restrict__ bias, const float *__restrict__ bias_b,
                                              float *__restrict__ out, float *__restrict__ stats_part,
-                                             float *__restrict__ mm_out, int pool_u, int out_pm, const float *sb) {
+                                             float *__restrict__ mm_out, int pool_u, int out_pm, const float *sb,
+                                             bool coherent = false) {
   // sb: the workgroup's bias (+ per-sample bias) values [64 WM], staged in LDS by the kernel's prologue. Fetched from
   // global memory inside the row loops below they were one L2 round trip each, serialised by the loops' branches (the
   // same finding as in the convolutions' epilogue, conv3d.hip / tools/exp_conv_timeline.py).
@@ -681,13 +683,14 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
     const float s2 = rowreduce32<RowAdd>(tv);
     if (rco < cout) {
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
-      q[0] = s1;
-      q[1] = s2;
+      // coherent: a finisher in another workgroup of this launch reads them (common.h GnFinish): device-scope stores
+      gnf_store(q, s1, coherent);
+      gnf_store(q + 1, s2, coherent);
       if (bx == gx - 1 && pb == NB - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
         for (int sl = slot + 1; sl < nslots; ++sl) {
           float *z = stats_part + (((size_t)b * nslots + sl) * cout + rco) * 2;
-          z[0] = 0.0f;
-          z[1] = 0.0f;
+          gnf_store(z, 0.0f, coherent);
+          gnf_store(z + 1, 0.0f, coherent);
         }
     }
   }
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
                                                        const float *__restrict__ in_scale,
                                                        const float *__restrict__ in_shift, int in_swish,
                                                        float *__restrict__ out, float *__restrict__ stats_part,
-                                                       float *__restrict__ mm_out, int pool_u, int out_pm) {
+                                                       float *__restrict__ mm_out, int pool_u, int out_pm, GnFinish fin) {
   extern __shared__ u32x4 pws_lds[];  // [A: WM/2 blocks of 128 channels][B: NB blocks of 128 positions][XF: 2 cin floats]
   constexpr int NT = 128 * WM;
   constexpr int BS = 128 * NB;  // 16-byte groups per (kstep, split, khalf) row of the B tile
@@ -891,19 +894,23 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
       }
     }
   }
-  if (!mact) return;
-  if constexpr (TERMS == SPLIT_F16X3) {  // 1 / (S_x S_w), a power of two, stored behind the pack
-    const int nblk128 = WM == 2 ? ncoblk : (cout + 127) / 128;
-    const float oscale = ((const float *)(wp + (size_t)((cin + PWS_CK - 1) / PWS_CK) * nblk128 * PWS_TILE))[1];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2 * NB; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][n][r] *= oscale;
-  }
+  if (!mact && !fin.scale) return;
+  if (mact) {
+    if constexpr (TERMS == SPLIT_F16X3) {  // 1 / (S_x S_w), a power of two, stored behind the pack
+      const int nblk128 = WM == 2 ? ncoblk : (cout + 127) / 128;
+      const float oscale = ((const float *)(wp + (size_t)((cin + PWS_CK - 1) / PWS_CK) * nblk128 * PWS_TILE))[1];
+  #pragma unroll
+      for (int m = 0; m < 2; ++m)
+  #pragma unroll
+        for (int n = 0; n < 2 * NB; ++n)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] *= oscale;
+    }
   pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
-                             stats_part, mm_out, pool_u, out_pm, pws_bias);
+                             stats_part, mm_out, pool_u, out_pm, pws_bias, fin.scale != nullptr);
+  }
+  // the GroupNorm that follows this layer, finished here by the workgroup that completes a (sample, group) (common.h)
+  if (fin.scale) gn_finish_arrive(cout, nslots, stats_part, fin, b, co0, 64 * WM, (double *)pws_lds);
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
@@ -978,6 +985,25 @@ extern "C" int p2pb_pointwise_pack_weights_split_amax(int cout, int cin, const f
   return amax_bits ? pw_pack_split(cout, cin, w, wp, false, stream, amax_bits) : P2PB_EINVAL;
 }
 
+// the finisher the entry point took for this launch (abi.hip p2pb_gn_finisher_arm); a launcher that hands it to its kernel
+// clears `pending`, otherwise the entry point launches gn_affine_kernel behind the producer
+static thread_local GnFinish tl_pw_fin;
+static thread_local bool tl_pw_fin_pending = false;
+static std::atomic<unsigned long long> g_fin_fused{0}, g_fin_behind{0};
+// how many armed finishers ran inside their producer / as a launch behind it (tests assert the fused form is the one running)
+extern "C" void p2pb_debug_gn_finisher(unsigned long long *fused, unsigned long long *behind) {
+  if (fused) *fused = g_fin_fused.load();
+  if (behind) *behind = g_fin_behind.load();
+}
+static int pw_finish_behind(int rc, int b, int cout, int P, const float *stats_part, hipStream_t s) {
+  if (!tl_pw_fin_pending) return rc;
+  tl_pw_fin_pending = false;
+  if (rc != 0) return rc;
+  if (!stats_part) return P2PB_EINVAL;  // (a finisher armed for a launch without statistics)
+  ++g_fin_behind;
+  return p2pb_gn_affine_launch(b, cout, (P + 255) / 256 * 4, stats_part, tl_pw_fin, s);
+}
+
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
@@ -1003,7 +1029,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
       once = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, TM>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
-                       w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm);       \
+                       w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fin);  \
   } while (0)
 #define LAUNCHF(XF, PL, WM, NB)                                       \
   do {                                                                \
@@ -1042,6 +1068,23 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     return p2pb_launch_status();
   }
   p2pb_note_pointwise_form(cin, cout, P, wm4 ? P2PB_FORM_PW_SPLIT256 : P2PB_FORM_PW_SPLIT128);
+  GnFinish fin = {};
+  static const int fin_env = getenv("P2PB_GN_FINISH") ? atoi(getenv("P2PB_GN_FINISH")) : 1;
+  if (tl_pw_fin_pending && fin_env && stats_part && !out_pm && cout % tl_pw_fin.groups == 0) {
+    // tile and group boundaries must nest; the contributors of a (sample, group) are the position blocks of the channel
+    // tiles it spans
+    const int cw = wm4 ? 256 : 128, cg = cout / tl_pw_fin.groups;
+    if ((cw % cg == 0 || cg % cw == 0) && cg <= 256) {
+      unsigned *tk = p2pb_gn_tickets((size_t)b * tl_pw_fin.groups, s);
+      if (tk) {
+        fin = tl_pw_fin;
+        fin.tickets = tk;
+        fin.expected = (int)grid.x * (cg > cw ? cg / cw : 1);
+        tl_pw_fin_pending = false;
+        ++g_fin_fused;
+      }
+    }
+  }
   if (xf && minmax) LAUNCH(true, true);
   else if (xf) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
@@ -1101,7 +1144,7 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
   return p2pb_launch_status();
 }
 
-extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const void *wp_any,
+static int pw_conv_forward_impl(int b, int cin, int cout, int npos, const float *in, const void *wp_any,
                                            const float *bias, const float *bias_b, const float *in_scale,
                                            const float *in_shift, int in_swish, int flags, float *out,
                                            float *stats_part, void *stream) {
@@ -1129,6 +1172,16 @@ extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, c
                                   stats_part, nullptr, 0, out_pm, s);
 }
 
+extern "C" int p2pb_pointwise_conv_forward(int b, int cin, int cout, int npos, const float *in, const void *wp_any,
+                                           const float *bias, const float *bias_b, const float *in_scale,
+                                           const float *in_shift, int in_swish, int flags, float *out,
+                                           float *stats_part, void *stream) {
+  tl_pw_fin_pending = p2pb_gn_finisher_take(&tl_pw_fin);  // (a finisher armed for this launch: abi.hip)
+  const int rc = pw_conv_forward_impl(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, flags, out,
+                                      stats_part, stream);
+  return pw_finish_behind(rc, b, cout, npos, stats_part, (hipStream_t)stream);
+}
+
 // pool_u = neighbourhood size (4, 8, 16, 32 or 64 consecutive positions) or 0 for the global pool
 static int pool_lanes(int pool_u) { return pool_u == 0 ? 32 : pool_u / 4; }
 
@@ -1143,7 +1196,7 @@ extern "C" size_t p2pb_pointwise_minmax_floats(int b, int cout, int npos, int po
   return (size_t)b * cout * (npos / pool_u) * 2;
 }
 
-extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in,
+static int pw_conv_pool_forward_impl(int b, int cin, int cout, int npos, const float *in,
                                                 const void *wp_any, const float *bias, const float *bias_b,
                                                 const float *in_scale, const float *in_shift, int in_swish, int flags,
                                                 float *out, float *stats_part, int pool_u, float *minmax,
@@ -1170,12 +1223,23 @@ extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int np
                                   stats_part, minmax, g, 0, s);
 }
 
+extern "C" int p2pb_pointwise_conv_pool_forward(int b, int cin, int cout, int npos, const float *in,
+                                                const void *wp_any, const float *bias, const float *bias_b,
+                                                const float *in_scale, const float *in_shift, int in_swish, int flags,
+                                                float *out, float *stats_part, int pool_u, float *minmax,
+                                                void *stream) {
+  tl_pw_fin_pending = p2pb_gn_finisher_take(&tl_pw_fin);
+  const int rc = pw_conv_pool_forward_impl(b, cin, cout, npos, in, wp_any, bias, bias_b, in_scale, in_shift, in_swish, flags, out,
+                                           stats_part, pool_u, minmax, stream);
+  return pw_finish_behind(rc, b, cout, npos, stats_part, (hipStream_t)stream);
+}
+
 // The last layer of a set abstraction's MLP on the GROUPED tensor without building it (pw_wide_kernel<GATHER>):
 //   operand[ci, (mi, ui)] = zt[b, idx[b, mi, ui], ci] - cxt[b, mi, ci]   (zt f32[b,n,cin], cxt f32[b,m,cin] point-major,
 //   idx i32[b,m,u]: what p2pb_group_sub writes out as f32[b,cin,m*u]), folded norm + Swish applied on load, then the
 //   1x1 convolution with the statistics + neighbourhood {min, max} epilogue of p2pb_pointwise_conv_pool_forward (output
 //   never stored). wp_split = the split pack; f16x3 arithmetic; cin % 8 == 0, u in {4, 8, 16, 32, 64}.
-extern "C" int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, int m, int u, const float *zt,
+static int pw_conv_pool_gather_impl(int b, int cin, int cout, int n, int m, int u, const float *zt,
                                                const float *cxt, const int *idx, const void *wp_split, const float *bias,
                                                const float *in_scale, const float *in_shift, int in_swish,
                                                float *stats_part, float *minmax, void *stream) {
@@ -1198,6 +1262,16 @@ extern "C" int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, 
 #undef LAUNCHG
   p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_GATHER);
   return p2pb_launch_status();
+}
+
+extern "C" int p2pb_pointwise_conv_pool_gather(int b, int cin, int cout, int n, int m, int u, const float *zt,
+                                               const float *cxt, const int *idx, const void *wp_split, const float *bias,
+                                               const float *in_scale, const float *in_shift, int in_swish,
+                                               float *stats_part, float *minmax, void *stream) {
+  tl_pw_fin_pending = p2pb_gn_finisher_take(&tl_pw_fin);
+  const int rc = pw_conv_pool_gather_impl(b, cin, cout, n, m, u, zt, cxt, idx, wp_split, bias, in_scale, in_shift, in_swish,
+                                          stats_part, minmax, stream);
+  return pw_finish_behind(rc, b, cout, (int)((long)m * u), stats_part, (hipStream_t)stream);
 }
 
 

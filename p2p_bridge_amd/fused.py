@@ -433,8 +433,27 @@ def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
             and npos % 4 == 0)
 
 
+def arm_finisher(fin, b, c, device):
+    """hand the GroupNorm that follows a layer to the layer's own launch (csrc/common.h GnFinish): fin = (count_per_channel,
+    groups, gamma, beta, style | None, eps, want_mean) -> (scale, shift, chmean | None) f32[B,C], filled in stream order by the
+    NEXT statistics-producing launch of this thread -- by its last workgroup per (sample, group) where the kernel can, by a
+    gn_affine launch right behind it otherwise (same values, same bits: one device function)"""
+    count, groups, gamma, beta, style, eps, want_mean = fin
+    scale = torch.empty(b, c, dtype=F32, device=device)
+    shift = torch.empty_like(scale)
+    chmean = torch.empty_like(scale) if want_mean else None
+    stride = 0
+    if style is not None:
+        if style.stride(1) != 1 or style.shape[1] != 2 * c:
+            style = style.contiguous()
+        stride = style.stride(0)
+    call("p2pb_gn_finisher_arm", _i(int(groups)), _d(float(count)), ptr(gamma), ptr(beta), ptr(style), _i(stride), _f(eps),
+         ptr(scale), ptr(shift), ptr(chmean))
+    return (scale, shift, chmean), style  # (style: kept alive by the caller until the launch is enqueued)
+
+
 def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
-            use_bias=True, pool_u=None, store=True, math=None, point_major=False):
+            use_bias=True, pool_u=None, store=True, math=None, point_major=False, fin=None):
     """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None).
     pool_u (0 = all positions, or the neighbourhood size): also returns the {min, max} tensor minmax_act()
     pools from -> (y | None, stats, minmax); store=False skips writing y altogether.
@@ -467,16 +486,20 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
         nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
         st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     bias = conv.bias if use_bias else None
+    aff = keep = None
+    if fin is not None:  # fin: the norm that follows (arm_finisher) -> the result carries (scale, shift, chmean) as well
+        assert st is not None
+        aff, keep = arm_finisher(fin, b, co, x.device)
     if pool_u is None:
         call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
              ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), stream_ptr())
-        return y, st
+        return (y, st) if fin is None else (y, st, aff)
     nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(pool_u), flags)
     mm = torch.empty((b, nmm // (b * co * 2), co, 2) if pool_u == 0 else (b, co, p // pool_u, 2), dtype=F32,
                      device=x.device)
     call("p2pb_pointwise_conv_pool_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
          ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), _i(pool_u), ptr(mm), stream_ptr())
-    return y, st, mm
+    return (y, st, mm) if fin is None else (y, st, mm, aff)
 
 
 def linear_rows(x, weight, bias=None):
@@ -520,7 +543,7 @@ def gather_pool_supported(ci: int, co: int, m: int, u: int) -> bool:
             and os.environ.get("P2PB_SA_GATHER", "1") != "0")
 
 
-def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True):
+def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True, fin=None):
     """the last 1x1 layer of a set abstraction on the grouped tensor WITHOUT building it: operand[ci, (m, u)] =
     zt[b, idx[b,m,u], ci] - cxt[b, m, ci] gathered on load (zt f32[B,N,Ci], cxt f32[B,M,Ci] point-major, idx i32[B,M,U]:
     what group_sub would write as f32[B,Ci,M*U]), folded norm + Swish on load, statistics + neighbourhood {min, max}
@@ -534,9 +557,12 @@ def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True):
     nfl = lib().p2pb_pointwise_stats_floats(_i(b), _i(co), _i(p))
     st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=zt.device)
     mm = torch.empty(b, co, m, 2, dtype=F32, device=zt.device)
+    aff = keep = None
+    if fin is not None:
+        aff, keep = arm_finisher(fin, b, co, zt.device)
     call("p2pb_pointwise_conv_pool_gather", _i(b), _i(ci), _i(co), _i(n), _i(m), _i(u), ptr(zt), ptr(cxt), ptr(idx), ptr(wp),
          ptr(conv.bias), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(st), ptr(mm), stream_ptr())
-    return st, mm
+    return (st, mm) if fin is None else (st, mm, aff)
 
 
 def group_sub(z, cx, idx, point_major=False, stats_only=False):

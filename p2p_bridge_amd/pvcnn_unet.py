@@ -287,6 +287,18 @@ def norm_affine(norm, part, count, cond, want_mean=False):
     return out if want_mean else out[:2]
 
 
+def norm_fin(norm, count, cond, want_mean=False):
+    """the same norm as a finisher descriptor for the PRODUCING launch (fused.pw_conv(..., fin=...): csrc/common.h GnFinish): the
+    scale / shift arrays come back with the producer's outputs, no gn_affine launch between producer and consumer"""
+    style = None
+    if isinstance(norm, AdaGN):
+        if cond is None:
+            raise RuntimeError("AdaGN needs the global embedding")
+        style = cond.style(norm) if isinstance(cond, _Styles) else norm.emd(cond)
+    gn = _group_norm_of(norm)
+    return (count, gn.num_groups, gn.weight, gn.bias, style, gn.eps, want_mean)
+
+
 class SharedMLP(nn.Module):
     """(1x1 conv -> AdaGN|GroupNorm(8) -> Swish) repeated; parameters live in `layers` at indices
     3i / 3i+1 like the reference (models/pvcnn.py:162-205)."""
@@ -346,11 +358,10 @@ class SharedMLP(nn.Module):
         for i in range(1 if first is not None else 0, nl):
             conv, norm = self.layers[3 * i], self.layers[3 * i + 1]
             if pool and i == nl - 1:
-                _, st, mm = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, pool_u=shape[-1], store=False)
-                sc, sh = norm_affine(norm, st, P, cond)
+                _, st, mm, (sc, sh, _) = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, pool_u=shape[-1], store=False,
+                                                       fin=norm_fin(norm, P, cond))
                 return fused.minmax_act(mm, sc, sh).view(B, conv.weight.shape[0], *shape[2:-1])
-            h, st = fused.pw_conv(h, conv, sc, sh, swish=sc is not None)
-            sc, sh = norm_affine(norm, st, P, cond)
+            h, st, (sc, sh, _) = fused.pw_conv(h, conv, sc, sh, swish=sc is not None, fin=norm_fin(norm, P, cond))
         C = h.shape[1]
         if reduce_max:
             return fused.affine_act_max(h, sc, sh, int(np.prod(shape[2:-1])), shape[-1]).view(B, C, *shape[2:-1])
@@ -479,8 +490,7 @@ class PVConv(nn.Module):
                 from . import fused as F_
 
                 feats = features.contiguous()
-                h, st = F_.pw_conv(feats, pf[0])
-                scp, shp = norm_affine(pf[1], st, feats.shape[2], cond)
+                h, st, (scp, shp, _) = F_.pw_conv(feats, pf[0], fin=norm_fin(pf[1], feats.shape[2], cond))
                 data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, scp, shp), geo=data.geo)
                 if self.attn is not None:
                     data.features = self.attn(data.features)
@@ -572,8 +582,8 @@ class PointNetSAModule(nn.Module):
                     # its operand itself and emits the statistics + {min, max} the max-pool is formed from
                     _, st = fused.group_sub(z, cx, nidx, point_major=True, stats_only=True)
                     sc, sh = norm_affine(mlp.layers[1], st, M * U, data.cond)
-                    st2, mm = fused.pw_conv_pool_gather(z, cx, nidx, mlp.layers[3], sc, sh, True)
-                    sc2, sh2 = norm_affine(mlp.layers[4], st2, M * U, data.cond)
+                    st2, mm, (sc2, sh2, _) = fused.pw_conv_pool_gather(z, cx, nidx, mlp.layers[3], sc, sh, True,
+                                                                       fin=norm_fin(mlp.layers[4], M * U, data.cond))
                     data.features = fused.minmax_act(mm, sc2, sh2)
                 else:
                     y, st = fused.group_sub(z, cx, nidx, point_major=pm)
@@ -720,28 +730,22 @@ class Pnet2Stage(nn.Module):
         N = coords.shape[2]
         a0, a1 = self.mlp1.shared_mlp_0.mlp, self.mlp1.shared_mlp_1.mlp
         b0, b1 = self.mlp2.shared_mlp_0.mlp, self.mlp2.shared_mlp_1.mlp
-        h, st = fused.pw_conv(coords.contiguous(), a0[0])
-        sc, sh = norm_affine(a0[1], st, N, None)
+        h, st, (sc, sh, _) = fused.pw_conv(coords.contiguous(), a0[0], fin=norm_fin(a0[1], N, None))
         pool = fused.pool_supported(N, 0)  # the max-pools ride in the GEMM epilogues as {min, max} partials
         if pool:
-            h, st, mm = fused.pw_conv(h, a1[0], sc, sh, swish=True, pool_u=0)
-            sc, sh = norm_affine(a1[1], st, N, None)
+            h, st, mm, (sc, sh, _) = fused.pw_conv(h, a1[0], sc, sh, swish=True, pool_u=0, fin=norm_fin(a1[1], N, None))
             g = fused.minmax_act(mm, sc, sh, global_pool=True)
         else:
-            h, st = fused.pw_conv(h, a1[0], sc, sh, swish=True)
-            sc, sh = norm_affine(a1[1], st, N, None)
+            h, st, (sc, sh, _) = fused.pw_conv(h, a1[0], sc, sh, swish=True, fin=norm_fin(a1[1], N, None))
             g = fused.affine_act_max(h, sc, sh, N, 0)
         c1 = h.shape[1]
         w = b0[0].weight.reshape(b0[0].out_channels, -1)
         bias_b = fused.linear_rows(g, w[:, c1:])  # (no BLAS in the captured step: fused.linear_rows)
-        h, st = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1)
-        sc, sh = norm_affine(b0[1], st, N, None)
+        h, st, (sc, sh, _) = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1, fin=norm_fin(b0[1], N, None))
         if pool:  # the 1024-channel output is never written: only its statistics and extrema are needed
-            _, st, mm = fused.pw_conv(h, b1[0], sc, sh, swish=True, pool_u=0, store=False)
-            sc, sh = norm_affine(b1[1], st, N, None)
+            _, st, mm, (sc, sh, _) = fused.pw_conv(h, b1[0], sc, sh, swish=True, pool_u=0, store=False, fin=norm_fin(b1[1], N, None))
             return fused.minmax_act(mm, sc, sh, global_pool=True)
-        h, st = fused.pw_conv(h, b1[0], sc, sh, swish=True)
-        sc, sh = norm_affine(b1[1], st, N, None)
+        h, st, (sc, sh, _) = fused.pw_conv(h, b1[0], sc, sh, swish=True, fin=norm_fin(b1[1], N, None))
         return fused.affine_act_max(h, sc, sh, N, 0)
 
 
@@ -1009,8 +1013,7 @@ class PVCNN2Unet(nn.Module):
         if self.embed_feats is not None:
             src = coords if self.extra_feature_channels == 0 else feats
             if use_fused:
-                h, st = fused.pw_conv(src, self.embed_feats[0])
-                sc, sh = norm_affine(self.embed_feats[1], st, N, None)
+                h, st, (sc, sh, _) = fused.pw_conv(src, self.embed_feats[0], fin=norm_fin(self.embed_feats[1], N, None))
                 feats, _ = fused.pw_conv(h, self.embed_feats[3], sc, sh, swish=True, stats=False)
             else:
                 from . import dense
@@ -1088,8 +1091,8 @@ class PVCNN2Unet(nn.Module):
 
         if use_fused:  # classifier: SharedMLP(GroupNorm) -> Dropout(eval: identity) -> Conv1d, two fused GEMMs
             c0 = self.classifier[0]
-            h, st = fused.pw_conv(data.features.contiguous(), c0.layers[0])
-            sc, sh = norm_affine(c0.layers[1], st, h.shape[2], None)
+            xin = data.features.contiguous()
+            h, st, (sc, sh, _) = fused.pw_conv(xin, c0.layers[0], fin=norm_fin(c0.layers[1], xin.shape[2], None))
             return fused.pw_conv(h, self.classifier[2], sc, sh, swish=True, stats=False)[0]
         from . import dense
 
