@@ -139,9 +139,9 @@ static inline unsigned absmax_blocks(size_t n) {
 // ---- GroupNorm(+AdaGN) finisher: the {sum, sum of squares} partials of a producing kernel -> per-(sample, channel) scale / shift ----
 // (the arithmetic of gn_affine_kernel, conv3d.hip, which calls this too: one workgroup, >= 256 threads of it, per (sample, group);
 //  fixed summation order, double accumulation: the same bits whichever kernel runs it.) A producing kernel given a GnFinish runs
-// it itself: the workgroup that completes a (sample, group) -- a ticket counted after a device-scope release of every
-// contributor's partials -- computes the group's affine, and the separate gn_affine launch between producer and consumer (a
-// dependent launch costs ~13 us of the chain on this part, 48 of them per evaluation) is gone.
+// it itself when P2PB_GN_FINISH asks for it (pointwise.hip: measured SLOWER than the launch behind the producer, which is the
+// default): the workgroup that completes a (sample, group) -- a ticket counted after every contributor's device-scope partial
+// stores have reached memory -- computes the group's affine.
 struct GnFinish {
   const float *gamma, *beta, *style;  // [c] | NULL, [c] | NULL, rows of (factor[c] | bias[c]) | NULL
   float *scale, *shift, *chmean;      // f32[b, c] outputs (chmean may be NULL); scale == NULL: no finisher
@@ -237,11 +237,11 @@ __device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *
   __syncthreads();  // (lds may be reused by the caller, or by the next group)
 }
 // End of a producing workgroup whose channel tile [c0, c0 + cw) of sample b is written: count it on the groups it covers and
-// finish those it completes. Every thread calls it; `lds` as above (the kernel's operand tiles are free by now).
+// finish those it completes. Every thread calls it; `lds`: 4 x 256 + 1 doubles (the kernel's operand tiles are free by now).
 // The caller has made sure that tile and group boundaries nest (cw % cg == 0 or cg % cw == 0, c0 % min(cw, cg) == 0).
 __device__ __forceinline__ void gn_finish_arrive(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int c0, int cw,
                                                  double *lds) {
-  __shared__ int gnf_last;
+  int &gnf_last = *(int *)(lds + 4 * 256);  // (in the caller's LDS: the ping-pong GEMM has no static byte left)
   const int cg = c / f.groups;
   // this thread's partials (device-scope stores: gnf_store) have reached memory before the workgroup is counted
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
                                                       const float *__restrict__ in_shift, int in_swish,
                                                       float *__restrict__ out, float *__restrict__ stats_part,
                                                       float *__restrict__ mm_out, int pool_g, int out_pm,
-                                                      PwGather gat = PwGather()) {
+                                                      PwGather gat = PwGather(), GnFinish fin = GnFinish()) {
   static_assert(!GATHER || TERMS == SPLIT_F16X3, "the gathered operand exists in the f16x3 form");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -508,19 +508,24 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
         s1 = halfwave_sum_to_last(s1);
         s2 = halfwave_sum_to_last(s2);
         if (l31 == 31 && co < cout) {
+          const bool coherent = fin.scale != nullptr;  // (read by the finisher of another workgroup: common.h GnFinish)
           if (slot < nslots) {
             float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
-            q[0] = s1;
-            q[1] = s2;
+            gnf_store(q, s1, coherent);
+            gnf_store(q + 1, s2, coherent);
           }
           if (slot + 1 < nslots) {
             float *q = stats_part + (((size_t)b * nslots + slot + 1) * cout + co) * 2;
-            q[0] = 0.0f;
-            q[1] = 0.0f;
+            gnf_store(q, 0.0f, coherent);
+            gnf_store(q + 1, 0.0f, coherent);
           }
         }
       }
     }
+  }
+  if (STATS && fin.scale) {  // the GroupNorm that follows, finished by the workgroup that completes a (sample, group)
+    __shared__ double pww_fin[4 * 256 + 1];
+    gn_finish_arrive(cout, nslots, stats_part, fin, b, co0, 32 * MT, pww_fin);
   }
 }
 
@@ -1004,6 +1009,32 @@ static int pw_finish_behind(int rc, int b, int cout, int P, const float *stats_p
   return p2pb_gn_affine_launch(b, cout, (P + 255) / 256 * 4, stats_part, tl_pw_fin, s);
 }
 
+// the pending finisher as a kernel argument, if this launch can run it: channel tiles of `cw`, `pblocks` workgroups per tile and
+// sample; tile and group boundaries must nest (the contributors of a (sample, group) are the position blocks of the channel tiles
+// it spans). Otherwise an empty descriptor, and the finisher stays pending for the launch behind the producer.
+// P2PB_GN_FINISH (default 0: every armed finisher is the gn_affine launch behind its producer): bit 0 lets the split-operand
+// kernel run it in its last workgroup per (sample, group), bit 1 the wide kernel, bit 2 the ping-pong kernel. MEASURED, one box,
+// bench.py ms per sample call (30 evaluations x 2 chains): 0 -> 248.5, 1 -> 255.0 (13 layers per evaluation), 5 -> 260.0 (15),
+// 3 -> 257 against 243 on another box (22 layers). Removing the 48 finishing launches altogether (timing-only experiment, constants
+// in their place) is worth 8 % -- but the ticketed form costs more than the launch it replaces: the workgroup that arrives last
+// wins ALL the groups of its channel tile and finishes them one after the other from memory-side reads, and every producing
+// workgroup waits for its own stores before it is counted. Same bits in every form (tests/test_gn_finisher_gpu.py).
+static GnFinish pw_take_finisher(int b, int cout, int cw, int pblocks, bool has_stats, hipStream_t s, int kind = 1) {
+  GnFinish fin = {};
+  static const int fin_env = getenv("P2PB_GN_FINISH") ? atoi(getenv("P2PB_GN_FINISH")) : 0;
+  if (!tl_pw_fin_pending || !(fin_env & kind) || !has_stats || cout % tl_pw_fin.groups != 0) return fin;
+  const int cg = cout / tl_pw_fin.groups;
+  if (!(cw % cg == 0 || cg % cw == 0) || cg > 256) return fin;
+  unsigned *tk = p2pb_gn_tickets((size_t)b * tl_pw_fin.groups, s);
+  if (!tk) return fin;
+  fin = tl_pw_fin;
+  fin.tickets = tk;
+  fin.expected = pblocks * (cg > cw ? cg / cw : 1);
+  tl_pw_fin_pending = false;
+  ++g_fin_fused;
+  return fin;
+}
+
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
                            const float *bias_b, const float *in_scale, const float *in_shift, int in_swish,
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
@@ -1048,6 +1079,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 1;
   if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0)) {
     dim3 pgrid((P + 127) / 128, cout / 512, b);
+    const GnFinish fin5 = pw_take_finisher(b, cout, 512, (int)pgrid.x, stats_part != nullptr, s, 4);
 #define LAUNCHP5(XF, PL)                                                                                              \
   do {                                                                                                                \
     static bool once = false;                                                                                         \
@@ -1057,7 +1089,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
       once = true;                                                                                                    \
     }                                                                                                                 \
     hipLaunchKernelGGL((pw_pp512_kernel<XF, PL>), pgrid, dim3(512), P5_LDS_BYTES, s, cin, cout, P, nslots, in, w, bias, \
-                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                        \
+                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, fin5);                  \
   } while (0)
     if (xf && minmax) LAUNCHP5(true, true);
     else if (xf) LAUNCHP5(true, false);
@@ -1068,23 +1100,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     return p2pb_launch_status();
   }
   p2pb_note_pointwise_form(cin, cout, P, wm4 ? P2PB_FORM_PW_SPLIT256 : P2PB_FORM_PW_SPLIT128);
-  GnFinish fin = {};
-  static const int fin_env = getenv("P2PB_GN_FINISH") ? atoi(getenv("P2PB_GN_FINISH")) : 1;
-  if (tl_pw_fin_pending && fin_env && stats_part && !out_pm && cout % tl_pw_fin.groups == 0) {
-    // tile and group boundaries must nest; the contributors of a (sample, group) are the position blocks of the channel
-    // tiles it spans
-    const int cw = wm4 ? 256 : 128, cg = cout / tl_pw_fin.groups;
-    if ((cw % cg == 0 || cg % cw == 0) && cg <= 256) {
-      unsigned *tk = p2pb_gn_tickets((size_t)b * tl_pw_fin.groups, s);
-      if (tk) {
-        fin = tl_pw_fin;
-        fin.tickets = tk;
-        fin.expected = (int)grid.x * (cg > cw ? cg / cw : 1);
-        tl_pw_fin_pending = false;
-        ++g_fin_fused;
-      }
-    }
-  }
+  const GnFinish fin = pw_take_finisher(b, cout, wm4 ? 256 : 128, (int)grid.x, stats_part != nullptr && !out_pm, s);
   if (xf && minmax) LAUNCH(true, true);
   else if (xf) LAUNCH(true, false);
   else if (minmax) LAUNCH(false, true);
@@ -1112,13 +1128,15 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
     const int nslots = (P + 255) / 256 * 4;
 #define LAUNCHX(XF, ST, PL, TM)                                                                                       \
   hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL, TM>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P,       \
-                     nslots, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm)
+                     nslots, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm,  \
+                     PwGather(), fin)
 #define LAUNCH(XF, ST, PL)                                 \
   do {                                                     \
     if (split_pack) LAUNCHX(XF, ST, PL, SPLIT_F16X3);       \
     else LAUNCHX(XF, ST, PL, 0);                            \
   } while (0)
     p2pb_note_pointwise_form(cin, cout, P, split_pack ? P2PB_FORM_PW_WIDE_F16 : P2PB_FORM_PW_WIDE_FP32);
+    const GnFinish fin = pw_take_finisher(b, cout, 32 * MT, (int)grid.x, st && !out_pm, s, 2);
     if (minmax) {
       if (xf) LAUNCH(true, true, true);
       else LAUNCH(false, true, true);
@@ -1256,7 +1274,8 @@ static int pw_conv_pool_gather_impl(int b, int cin, int cout, int n, int m, int 
   hipLaunchKernelGGL((pw_wide_kernel<MTV, true, true, true, SPLIT_F16X3, true>),                                   \
                      dim3((P + 511) / 512, (cout + 32 * MTV - 1) / (32 * MTV), b), dim3(256), 0, s, cin, cout,             \
                      pw_cout_pad(cout), P, nslots, zt, wsp, bias, (const float *)nullptr, in_scale, in_shift, in_swish,    \
-                     (float *)nullptr, stats_part, minmax, gl, 0, gat)
+                     (float *)nullptr, stats_part, minmax, gl, 0, gat, fin)
+  const GnFinish fin = pw_take_finisher(b, cout, cout > 32 ? 64 : 32, (P + 511) / 512, true, s, 2);
   if (cout > 32) LAUNCHG(2);
   else LAUNCHG(1);
 #undef LAUNCHG

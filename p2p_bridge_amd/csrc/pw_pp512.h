@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
     int cin, int cout, int P, int nslots, const float *__restrict__ in, const u32x4 *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ bias_b, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, int in_swish, float *__restrict__ out, float *__restrict__ stats_part,
-    float *__restrict__ mm_out, int pool_u) {
+    float *__restrict__ mm_out, int pool_u, GnFinish fin) {
   extern __shared__ u32x4 p5_lds[];  // [A0 | A1 | B0 | B1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -346,17 +346,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
           tv[m * 16 + r] = (acc[m][0][r] * acc[m][0][r] + acc[m][1][r] * acc[m][1][r]) +
                            (acc[m][2][r] * acc[m][2][r] + acc[m][3][r] * acc[m][3][r]);
       const float s2 = rowreduce32<RowAdd>(tv);
+      const bool coherent = fin.scale != nullptr;  // (read by the finisher of another workgroup: common.h GnFinish)
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
-      q[0] = s1;
-      q[1] = s2;
+      gnf_store(q, s1, coherent);
+      gnf_store(q + 1, s2, coherent);
       float *z = q + (size_t)cout * 2;  // slot + 1
-      z[0] = 0.0f;
-      z[1] = 0.0f;
+      gnf_store(z, 0.0f, coherent);
+      gnf_store(z + 1, 0.0f, coherent);
       if (bx == (int)gridDim.x - 1)
         for (int sl = nmine; sl < nslots; ++sl) {
           float *zz = stats_part + (((size_t)b * nslots + sl) * cout + rco) * 2;
-          zz[0] = 0.0f;
-          zz[1] = 0.0f;
+          gnf_store(zz, 0.0f, coherent);
+          gnf_store(zz + 1, 0.0f, coherent);
         }
     }
     if (POOL && pool_u == 0) {
@@ -398,4 +399,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
     for (int k = 0; k < 8; ++k) q[4 + k] = ts[k];
   }
 #endif
+  // the GroupNorm that follows this layer, finished by the workgroup that completes a (sample, group) (common.h)
+  if (fin.scale) gn_finish_arrive(cout, nslots, stats_part, fin, b, co0, 512, (double *)p5_lds);
 }
