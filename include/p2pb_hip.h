@@ -68,6 +68,7 @@ int p2pb_debug_pointwise_form(int cin, int cout, int npos, unsigned long long *l
 int p2pb_gn_finisher_arm(int groups, double count_per_channel, const float *gamma, const float *beta, const float *style,
                          int style_stride, float eps, float *scale, float *shift, float *chmean);
 int p2pb_gn_finisher_armed(void);
+void p2pb_gn_finisher_disarm(void); /* drop an armed finisher whose producing launch did not happen (error paths) */
 /* test hook: armed finishers that ran inside their producing kernel / as a launch behind it, since the library was loaded */
 void p2pb_debug_gn_finisher(unsigned long long *fused, unsigned long long *behind);
 

@@ -114,6 +114,7 @@ extern "C" int p2pb_gn_finisher_arm(int groups, double count_per_channel, const 
   return 0;
 }
 extern "C" int p2pb_gn_finisher_armed(void) { return tl_fin_armed ? 1 : 0; }
+extern "C" void p2pb_gn_finisher_disarm(void) { tl_fin_armed = false; }  // (a caller whose producing launch never happened)
 bool p2pb_gn_finisher_take(GnFinish *out) {
   if (!tl_fin_armed) return false;
   *out = tl_fin;

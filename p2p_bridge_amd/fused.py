@@ -490,10 +490,18 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
     if fin is not None:  # fin: the norm that follows (arm_finisher) -> the result carries (scale, shift, chmean) as well
         assert st is not None
         aff, keep = arm_finisher(fin, b, co, x.device)
-    if pool_u is None:
-        call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
-             ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), stream_ptr())
-        return (y, st) if fin is None else (y, st, aff)
+    try:
+        if pool_u is None:
+            call("p2pb_pointwise_conv_forward", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(wp), ptr(bias), ptr(bias_b),
+                 ptr(in_scale), ptr(in_shift), _i(int(swish)), flags, ptr(y), ptr(st), stream_ptr())
+            return (y, st) if fin is None else (y, st, aff)
+        return _pw_conv_pool(x, wp, bias, bias_b, in_scale, in_shift, swish, flags, y, st, pool_u, b, ci, co, p, fin, aff)
+    finally:
+        if fin is not None:
+            lib().p2pb_gn_finisher_disarm()  # (no-op after a launch that took it; an error path must not leave it armed)
+
+
+def _pw_conv_pool(x, wp, bias, bias_b, in_scale, in_shift, swish, flags, y, st, pool_u, b, ci, co, p, fin, aff):
     nmm = lib().p2pb_pointwise_minmax_floats(_i(b), _i(co), _i(p), _i(pool_u), flags)
     mm = torch.empty((b, nmm // (b * co * 2), co, 2) if pool_u == 0 else (b, co, p // pool_u, 2), dtype=F32,
                      device=x.device)
@@ -560,8 +568,12 @@ def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True, fin=
     aff = keep = None
     if fin is not None:
         aff, keep = arm_finisher(fin, b, co, zt.device)
-    call("p2pb_pointwise_conv_pool_gather", _i(b), _i(ci), _i(co), _i(n), _i(m), _i(u), ptr(zt), ptr(cxt), ptr(idx), ptr(wp),
-         ptr(conv.bias), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(st), ptr(mm), stream_ptr())
+    try:
+        call("p2pb_pointwise_conv_pool_gather", _i(b), _i(ci), _i(co), _i(n), _i(m), _i(u), ptr(zt), ptr(cxt), ptr(idx), ptr(wp),
+             ptr(conv.bias), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(st), ptr(mm), stream_ptr())
+    finally:
+        if fin is not None:
+            lib().p2pb_gn_finisher_disarm()
     return (st, mm) if fin is None else (st, mm, aff)
 
 
