@@ -51,6 +51,13 @@ int p2pb_set_split_terms(int terms);
  * threads' launches and weight packs do not see; p2pb_get_split_terms returns what a launch from this thread would use */
 int p2pb_set_split_terms_thread(int terms);
 int p2pb_get_split_terms(void);
+/* Deterministic mode (process-wide, default off): the scatter-add backward passes (p2pb_trilinear_devoxelize_backward,
+ * p2pb_grouping_backward, p2pb_three_nn_interpolate_backward -- the adjoints of PN2/trilinear_devox_gpu.cu:111,
+ * pvcnn_grouping_gpu.cu:51, pvcnn_neighbor_interpolate_gpu.cu:101, whose float atomicAdd order is arbitrary in the reference
+ * too) accumulate in a fixed order -- one wave per workgroup over rows held in LDS -- so that a training run is bit-reproducible;
+ * slower. A row that does not fit 128 KB of LDS is refused (P2PB_EINVAL) instead of falling back to global atomics. */
+int p2pb_set_deterministic(int on);
+int p2pb_get_deterministic(void);
 /* Test / debug hook: the kernel form the most recent p2pb_pointwise_conv* launch with these (cin, cout, npos) took
  * (0 exact-fp32 unaligned, 1 wide exact-fp32, 2 wide f16x3, 3 split 128-channel, 4 split 256-channel, 5 ping-pong,
  * 6 gathered wide f16x3), or -1 if none; *launches (may be NULL) = how many such launches since the last reset.
@@ -311,6 +318,15 @@ int p2pb_conv3d_k3_forward_compact_pre(int b, int cin, int cout, int r, const vo
 int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
                              const float *in_shift, int in_swish, const float *wt_packed, const float *bias,
                              float *a, float *k_out, float *tap_ws /* f32[b,27,cout] scratch */, void *stream);
+/* The same with the GroupNorm(+AdaGN) BETWEEN the two convolutions of a PVConv (models/pvcnn.py:267-268, modules.py:341-358)
+ * folded into the launch: part f32[b,nslots,cin,2] = the first convolution's statistics partials and the norm's parameters as
+ * in p2pb_gn_affine_params; scale / shift f32[b,cin] are OUTPUTS (the values and bits p2pb_gn_affine_params writes) for the
+ * kernels that stage the second convolution's operand. One launch instead of two on the sampler's dependent chain. */
+int p2pb_conv3d_k3_far_field_gn(int b, int cin, int cout, const float *prev_bias, const float *part, int nslots,
+                                double count_per_channel, int groups, const float *gamma, const float *beta,
+                                const float *style, int style_stride, float eps, int in_swish, const float *wt_packed,
+                                const float *bias, float *scale, float *shift, float *a, float *k_out, float *tap_ws,
+                                void *stream);
 
 /* GroupNorm (+AdaGN style, models/modules.py:341-358) folded into a per-(sample, channel) affine:
  * AdaGN(GN(x)) == x*scale + shift. part f32[b,nslots,c,2] partial {sum,sumsq}; gamma/beta f32[c] or
@@ -336,6 +352,16 @@ int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, c
  * aff_a = scale*gate, aff_b = shift*gate. w1 f32[hidden,c], w2 f32[c,hidden] (nn.Linear layouts, no bias). */
 int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,
                         const float *scale, const float *shift, float *aff_a, float *aff_b, void *stream);
+/* The tail of a PVConv's voxel branch in one launch (models/pvcnn.py:283-286 AdaGN + SE3d behind the second Conv3d, and the
+ * norm of the point branch's SharedMLP, :162-205): part2 f32[b,nslots2,c,2] + its norm (as p2pb_gn_affine_params) ->
+ * aff_a, aff_b f32[b,c] = (scale, shift) x the SE3d gate (hidden == 0: no gate) -- what p2pb_gn_affine_params(..., chmean)
+ * followed by p2pb_se_gate_affine returns, same bits; partp f32[b,nslotsp,cp,2] (NULL: none) + its norm -> scale_p, shift_p
+ * f32[b,cp]. Three launches of the dependent chain become one. */
+int p2pb_pvconv_tail(int b, int c, int hidden, const float *part2, int nslots2, double count2, int groups2,
+                     const float *gamma2, const float *beta2, const float *style2, int style_stride2, float eps2,
+                     const float *w1, const float *w2, float *aff_a, float *aff_b, int cp, const float *partp, int nslotsp,
+                     double countp, int groupsp, const float *gammap, const float *betap, const float *stylep,
+                     int style_stridep, float epsp, float *scale_p, float *shift_p, void *stream);
 
 /* Voxel-major forms for the fused branch (grid f32[b,r,r,r,c]; conv flags bit 3): same values as
  * p2pb_avg_voxelize_forward / p2pb_trilinear_devoxelize_affine, coalesced on both sides (voxelize.hip).
@@ -429,6 +455,13 @@ int p2pb_linear_rows(int b, int cin, int cout, const float *x, long x_stride, co
  * nslots > 0: minmax f32[b,nslots,c,2] (reduced over nslots first) -> y f32[b,c] */
 int p2pb_minmax_act(int b, int c, int m, int nslots, const float *minmax, const float *scale, const float *shift,
                     int swish, float *y, void *stream);
+/* the global max-pool form (minmax f32[b,nslots,c,2], nslots >= 1 -> y f32[b,c]) with the GroupNorm in front of the activation
+ * folded in (Pnet2Stage, models/pvcnn.py:905-932: MyGroupNorm -> Swish -> max over the points): part f32[b,nslots_st,c,2] = the
+ * producing GEMM's statistics partials + the norm's parameters; scale / shift f32[b,c] are OUTPUTS (p2pb_gn_affine_params'
+ * values and bits: the next GEMM applies them to the same tensor on load). c <= 4096. */
+int p2pb_minmax_act_pool_gn(int b, int c, int nslots, const float *minmax, const float *part, int nslots_st,
+                            double count_per_channel, int groups, const float *gamma, const float *beta, const float *style,
+                            int style_stride, float eps, int swish, float *scale, float *shift, float *y, void *stream);
 /* y[b,c,p] = act(x*scale[b,c] + shift[b,c]) (+ residual[b,c,p]); act = Swish when swish != 0 */
 int p2pb_affine_act(int b, int c, int npos, const float *x, const float *scale, const float *shift, int swish,
                     const float *residual, float *y, void *stream);

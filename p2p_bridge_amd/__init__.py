@@ -12,7 +12,36 @@ built (python -m p2p_bridge_amd.build); anything else raises.
 """
 import sys
 
-__all__ = ["install_dropin"]
+__all__ = ["install_dropin", "deterministic"]
+
+
+class deterministic:
+    """`with p2p_bridge_amd.deterministic():` (or `deterministic(True)` / `(False)` as a call) -- bit-reproducible training:
+    the scatter-add backward passes accumulate in a fixed order (include/p2pb_hip.h p2pb_set_deterministic) and torch's
+    own kernels run under torch.use_deterministic_algorithms(warn_only=True). Slower; off by default, as in the reference
+    (whose CUDA backward kernels are float-atomic scatters as well)."""
+
+    def __init__(self, on: bool = True):
+        import torch
+
+        from ._lib import lib
+
+        self.prev = (bool(lib().p2pb_get_deterministic()), torch.are_deterministic_algorithms_enabled(),
+                     torch.is_deterministic_algorithms_warn_only_enabled())
+        lib().p2pb_set_deterministic(int(on))
+        torch.use_deterministic_algorithms(bool(on), warn_only=True)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+
+        from ._lib import lib
+
+        lib().p2pb_set_deterministic(int(self.prev[0]))
+        torch.use_deterministic_algorithms(self.prev[1], warn_only=self.prev[2])
+        return False
 
 
 def install_dropin():

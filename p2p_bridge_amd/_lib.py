@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("P2PB_LIB_PATH") or os.path.join(_HERE, "libp2pb_hip.s
 
 # every symbol include/p2pb_hip.h declares (tests/test_abi.py checks the two lists agree)
 SYMBOLS = [
-    "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_set_split_terms_thread", "p2pb_get_split_terms", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
+    "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_set_split_terms_thread", "p2pb_get_split_terms", "p2pb_set_deterministic", "p2pb_get_deterministic", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
     "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_avg_voxelize_cl_gather_split", "p2pb_conv3d_presplit",
     "p2pb_conv3d_k3_forward_compact_pre", "p2pb_trilinear_devoxelize_forward",
     "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats",
@@ -24,7 +24,7 @@ SYMBOLS = [
     "p2pb_auction_forward", "p2pb_auction_backward", "p2pb_conv3d_k3_packed_floats", "p2pb_conv3d_k3_pack_weights",
     "p2pb_conv3d_k3_split_packed_bytes", "p2pb_conv3d_k3_pack_weights_split",
     "p2pb_conv3d_k3_stats_floats", "p2pb_conv3d_k3_forward", "p2pb_conv3d_k3_forward_ex",
-    "p2pb_conv3d_k3_far_field", "p2pb_conv3d_active_lists", "p2pb_conv3d_k3_forward_compact", "p2pb_conv3d_brick_lists", "p2pb_conv3d_k3_forward_sparse", "p2pb_gn_affine_params", "p2pb_se_gate_affine",
+    "p2pb_conv3d_k3_far_field", "p2pb_conv3d_k3_far_field_gn", "p2pb_pvconv_tail", "p2pb_minmax_act_pool_gn", "p2pb_conv3d_active_lists", "p2pb_conv3d_k3_forward_compact", "p2pb_conv3d_brick_lists", "p2pb_conv3d_k3_forward_sparse", "p2pb_gn_affine_params", "p2pb_se_gate_affine",
     "p2pb_trilinear_devoxelize_affine", "p2pb_avg_voxelize_cl_forward", "p2pb_voxel_sort", "p2pb_avg_voxelize_cl_gather", "p2pb_trilinear_devoxelize_cl_affine", "p2pb_pointwise_packed_floats", "p2pb_pointwise_pack_weights",
     "p2pb_pointwise_stats_floats", "p2pb_pointwise_conv_forward", "p2pb_affine_act", "p2pb_affine_act_max",
     "p2pb_pointwise_split_packed_bytes", "p2pb_pointwise_pack_weights_split", "p2pb_pointwise_pool_supported", "p2pb_pointwise_minmax_floats", "p2pb_pointwise_conv_pool_forward",

@@ -24,6 +24,19 @@ extern "C" int p2pb_set_split_terms_thread(int terms) {  // 0 clears the calling
 }
 extern "C" int p2pb_get_split_terms(void) { return p2pb_split_terms_now(); }  // what a launch from THIS thread would use
 
+// Deterministic mode (process-wide): the scatter-add backward passes (devoxelise, grouping, three-NN interpolation) accumulate
+// their LDS rows with ONE wave per workgroup, so every destination receives its contributions in program order (ascending source
+// index; the lanes of one ds_add_f32 are served in lane order) instead of in the arrival order of 8 waves. Slower (those passes
+// 0.6 -> ~4 ms per config-3 step), bit-reproducible from run to run; rows that do not fit the LDS are refused (P2PB_EINVAL)
+// rather than sent to the global-atomic kernels.
+static std::atomic<int> g_deterministic{0};
+bool p2pb_deterministic() { return g_deterministic.load(std::memory_order_relaxed) != 0; }
+extern "C" int p2pb_set_deterministic(int on) {
+  g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+extern "C" int p2pb_get_deterministic(void) { return p2pb_deterministic() ? 1 : 0; }
+
 // which form a pointwise launch took, per (cin, cout, positions): a small host-side table behind p2pb_debug_pointwise_form (tests assert
 // that the layers of the bench's configuration run the kernels the roofline is quoted on)
 #include <mutex>

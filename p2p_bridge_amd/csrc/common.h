@@ -161,16 +161,20 @@ __device__ __forceinline__ void gnf_store(float *p, float v, bool coherent) {
 __device__ __forceinline__ float gnf_load(const float *p, bool coherent) {
   return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
 }
-// lds: 4 x 256 doubles. Call with all threads of the workgroup (threads >= 256 idle through the barriers).
-__device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int g,
-                                                double *lds, float *mean_rstd = nullptr, bool coherent = false) {
+// lds: 4 x 256 doubles per 256-thread SLICE. Every thread of the workgroup calls it (same barriers); a slice is 256 consecutive
+// threads with vt = the thread's index inside it, `live` = the slice has a group to finish (a 1024-thread workgroup finishes four
+// groups at once: far_field_kernel, pvconv_tail_kernel). Outputs: f.scale / f.shift / f.chmean (global, each may be NULL) and the
+// optional tables tab_* (f32[c] of THIS sample, e.g. in LDS, for a kernel that goes on to use the values itself).
+__device__ __forceinline__ void gn_finish_group_v(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int g,
+                                                  double *lds, int vt, bool live, float *mean_rstd = nullptr, bool coherent = false,
+                                                  float *tab_scale = nullptr, float *tab_shift = nullptr, float *tab_mean = nullptr) {
   double *rs = lds, *rq = lds + 256, *chs = lds + 512, *chq = lds + 768;
-  const int t = threadIdx.x;
+  const int t = vt;
   const int cg = c / f.groups, g0 = g * cg;
   const int nt = 256 / cg;  // partial accumulators per channel
   const int k = t % cg, j = t / cg;
   double s = 0.0, q = 0.0;
-  if (t < 256 && j < nt) {  // (same order, four slots' loads in flight: the plain loop was one L2 round trip per slot)
+  if (live && j < nt) {  // (same order, four slots' loads in flight: the plain loop was one L2 round trip per slot)
     const float *p0 = part + ((size_t)b * nslots * c + g0 + k) * 2;
     const size_t pitch = (size_t)c * 2;
     int sl = j;
@@ -194,12 +198,12 @@ __device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *
       q += (double)gnf_load(p + 1, coherent);
     }
   }
-  if (t < 256) {
+  if (live) {
     rs[t] = s;
     rq[t] = q;
   }
   __syncthreads();
-  if (t < cg) {
+  if (live && t < cg) {
     double ts = 0.0, tq = 0.0;
     for (int jj = 0; jj < nt; ++jj) {
       ts += rs[jj * cg + t];
@@ -209,7 +213,7 @@ __device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *
     chq[t] = tq;
   }
   __syncthreads();
-  if (t < cg) {
+  if (live && t < cg) {
     double gs = 0.0, gq = 0.0;
     for (int kk = 0; kk < cg; ++kk) {
       gs += chs[kk];
@@ -226,15 +230,36 @@ __device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *
     const double bi = f.style ? (double)f.style[(size_t)b * f.style_stride + c + ch] : 0.0;
     const double sc = rstd * ga * fa;
     const double sh = (be - mean * rstd * ga) * fa + bi;
-    f.scale[(size_t)b * c + ch] = (float)sc;
-    f.shift[(size_t)b * c + ch] = (float)sh;
-    if (f.chmean) f.chmean[(size_t)b * c + ch] = (float)(sc * (chs[t] / f.count_per_channel) + sh);
+    const float cm = (float)(sc * (chs[t] / f.count_per_channel) + sh);
+    if (f.scale) f.scale[(size_t)b * c + ch] = (float)sc;
+    if (f.shift) f.shift[(size_t)b * c + ch] = (float)sh;
+    if (f.chmean) f.chmean[(size_t)b * c + ch] = cm;
+    if (tab_scale) tab_scale[ch] = (float)sc;
+    if (tab_shift) tab_shift[ch] = (float)sh;
+    if (tab_mean) tab_mean[ch] = cm;
     if (mean_rstd && t == 0) {  // training: the backward pass of the norm needs the group moments (normact.hip)
       mean_rstd[((size_t)b * f.groups + g) * 2] = (float)mean;
       mean_rstd[((size_t)b * f.groups + g) * 2 + 1] = (float)rstd;
     }
   }
   __syncthreads();  // (lds may be reused by the caller, or by the next group)
+}
+// one group by the first 256 threads of the workgroup (threads >= 256 idle through the barriers); lds: 4 x 256 doubles
+__device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int g,
+                                                double *lds, float *mean_rstd = nullptr, bool coherent = false) {
+  gn_finish_group_v(c, nslots, part, f, b, g, lds, (int)threadIdx.x, threadIdx.x < 256, mean_rstd, coherent);
+}
+// ALL groups of sample b by a workgroup of 256 * NS threads, NS groups at a time (lds: NS x 1024 doubles); the same bits as one
+// gn_affine launch. The tables (if given) are complete after it returns (it ends on a barrier).
+template <int NS>
+__device__ __forceinline__ void gn_finish_sample(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, double *lds,
+                                                 float *tab_scale = nullptr, float *tab_shift = nullptr, float *tab_mean = nullptr) {
+  const int slice = (int)threadIdx.x >> 8, vt = (int)threadIdx.x & 255;
+  for (int g0 = 0; g0 < f.groups; g0 += NS) {
+    const int g = g0 + slice;
+    gn_finish_group_v(c, nslots, part, f, b, g < f.groups ? g : 0, lds + slice * 1024, vt, slice < NS && g < f.groups, nullptr, false,
+                      tab_scale, tab_shift, tab_mean);
+  }
 }
 // End of a producing workgroup whose channel tile [c0, c0 + cw) of sample b is written: count it on the groups it covers and
 // finish those it completes. Every thread calls it; `lds`: 4 x 256 + 1 doubles (the kernel's operand tiles are free by now).
@@ -364,6 +389,9 @@ int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);
 // and the output is written exactly once. Rows longer than the LDS take the global-atomic kernels.
 #define SCAT_THREADS 512
 #define SCAT_LDS_MAX (128 * 1024)
+bool p2pb_deterministic();  // abi.hip: p2pb_set_deterministic
+// threads per workgroup of the LDS-row kernels: one wave in deterministic mode (adds in program order), 8 waves otherwise
+static inline int scat_threads() { return p2pb_deterministic() ? 64 : SCAT_THREADS; }
 // channels per workgroup: as many rows as fit 64 KB (two workgroups per CU), at most `cap`; one row up to 128 KB; 0 = no fit
 static inline int scat_rows(long L, int c, int cap) {
   if (L * 4 > SCAT_LDS_MAX) return 0;
@@ -374,12 +402,12 @@ static inline int scat_rows(long L, int c, int cap) {
   return ch;
 }
 __device__ __forceinline__ void scat_zero(float *rows, int count) {
-  for (int i = threadIdx.x * 4; i < count; i += SCAT_THREADS * 4) *(float4 *)(rows + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x * 4; i < count; i += blockDim.x * 4) *(float4 *)(rows + i) = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();
 }
 // rows[j][0..L) -> gx[(b * c + c0 + j)][0..L) for the nch rows of this workgroup; L * 4 bytes need not be 16-aligned
 __device__ __forceinline__ void scat_store(const float *rows, int L, int Lp, int nch, float *gx_rows) {
   __syncthreads();
   for (int j = 0; j < nch; ++j)
-    for (int i = threadIdx.x; i < L; i += SCAT_THREADS) gx_rows[(size_t)j * L + i] = rows[j * Lp + i];
+    for (int i = threadIdx.x; i < L; i += blockDim.x) gx_rows[(size_t)j * L + i] = rows[j * Lp + i];
 }

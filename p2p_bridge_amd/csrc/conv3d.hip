@@ -1126,19 +1126,39 @@ static __global__ __launch_bounds__(256) void class_bias_kernel(int cout, const 
 // every thread evaluates a[ci] into LDS (the first channel block also stores it), thread (c, tg) of the 64 x 16 sums taps tg, tg + 16
 // for channel c over the input channels (weights coalesced over c), then the 27 class sums from the LDS table. Same operations in
 // the same order per output as far_value / tap_sum / class_bias: bit-identical.
+// part != NULL: the GroupNorm(+AdaGN) between the two convolutions is folded HERE as well -- `scale` / `shift` are then OUTPUTS
+// (fin.scale / fin.shift, f32[b, cin], written by the first channel block for the kernels that stage the operand) and the
+// gn_affine launch between the first convolution and this kernel is gone (round 5; gn_finish_sample: the same bits).
 static __global__ __launch_bounds__(1024) void far_field_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                         const float *__restrict__ base, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, int swish,
                                                         const float *__restrict__ wt, const float *__restrict__ bias,
-                                                        float *__restrict__ a_out, float *__restrict__ k_out) {
-  extern __shared__ float ff_sm[];  // a[cin] | T[27][64]
-  float *a = ff_sm, *T = ff_sm + cin;
+                                                        float *__restrict__ a_out, float *__restrict__ k_out,
+                                                        const float *__restrict__ part, int nslots, GnFinish fin) {
+  extern __shared__ double ff_sm_d[];  // [scale[cin] | shift[cin]] (folded form) | union { 4 x 1024 doubles, a[cin] | T[27][64] }
+  float *ff_sm = (float *)ff_sm_d;
   const int b = blockIdx.y, t = threadIdx.x, c = t & 63, tg = t >> 6;
   const int co = blockIdx.x * 64 + c;
-  for (int ch = t; ch < cin; ch += 1024) {
-    const float v = xf_apply(base[ch], scale[(size_t)b * cin + ch], shift[(size_t)b * cin + ch], swish);
-    a[ch] = v;
-    if (blockIdx.x == 0) a_out[(size_t)b * cin + ch] = v;
+  float *a, *T;
+  if (part != nullptr) {
+    float *tsc = ff_sm, *tsh = ff_sm + cin;
+    double *gl = ff_sm_d + (2 * cin + 1) / 2;
+    GnFinish f = fin;
+    if (blockIdx.x != 0) f.scale = f.shift = nullptr;  // (every channel block computes the values, one writes them)
+    gn_finish_sample<4>(cin, nslots, part, f, b, gl, tsc, tsh);
+    a = (float *)gl, T = a + cin;
+    for (int ch = t; ch < cin; ch += 1024) {
+      const float v = xf_apply(base[ch], tsc[ch], tsh[ch], swish);
+      a[ch] = v;
+      if (blockIdx.x == 0) a_out[(size_t)b * cin + ch] = v;
+    }
+  } else {
+    a = ff_sm, T = ff_sm + cin;
+    for (int ch = t; ch < cin; ch += 1024) {
+      const float v = xf_apply(base[ch], scale[(size_t)b * cin + ch], shift[(size_t)b * cin + ch], swish);
+      a[ch] = v;
+      if (blockIdx.x == 0) a_out[(size_t)b * cin + ch] = v;
+    }
   }
   __syncthreads();
   for (int tap = tg; tap < 27; tap += 16) {
@@ -1169,16 +1189,24 @@ static __global__ __launch_bounds__(1024) void far_field_kernel(int cin, int cou
 // a f32[b,cin] = far-field operand constants, k_out f32[b,27,cout] = per-boundary-class output constants,
 // tap_ws f32[b,27,cout] scratch
 #if CONV_TU != 6
-extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
-                                        const float *in_shift, int in_swish, const float *wt_packed,
-                                        const float *bias, float *a, float *k_out, float *tap_ws, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || !in_scale || !in_shift) return P2PB_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
+static bool gn_shape_ok(int c, int groups, const float *style, int style_stride) {
+  return groups > 0 && c % groups == 0 && c / groups <= 256 && !(style && style_stride < 2 * c);
+}
+static int far_field_launch(int b, int cin, int cout, const float *prev_bias, const float *in_scale, const float *in_shift,
+                            int in_swish, const float *wt_packed, const float *bias, float *a, float *k_out, float *tap_ws,
+                            const float *part, int nslots, const GnFinish &fin, hipStream_t s) {
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
-  if ((size_t)(cin + 27 * 64) * 4 <= 48 * 1024) {  // (tap_ws unused in this form)
-    hipLaunchKernelGGL(far_field_kernel, dim3(cdiv(cout, 64), b), dim3(1024), (size_t)(cin + 27 * 64) * 4, s, cin, cout, nchunk,
-                       cout_pad, prev_bias, in_scale, in_shift, in_swish, wt_packed, bias, a, k_out);
+  const size_t body = (size_t)(cin + 27 * 64) * 4;
+  const size_t lds = part ? (size_t)((2 * cin + 1) / 2) * 8 + (body > 32768 ? body : 32768) : body;
+  if (lds <= 48 * 1024) {  // (tap_ws unused in this form)
+    hipLaunchKernelGGL(far_field_kernel, dim3(cdiv(cout, 64), b), dim3(1024), lds, s, cin, cout, nchunk, cout_pad, prev_bias,
+                       in_scale, in_shift, in_swish, wt_packed, bias, a, k_out, part, nslots, fin);
     return p2pb_launch_status();
+  }
+  if (part) {  // (very wide layers: the norm as its own launch)
+    const int e = p2pb_gn_affine_launch(b, cin, nslots, part, fin, s);
+    if (e != 0) return e;
+    in_scale = fin.scale, in_shift = fin.shift;
   }
   hipLaunchKernelGGL(far_value_kernel, dim3(cdiv(cin, 256), b), dim3(256), 0, s, cin, prev_bias, in_scale, in_shift,
                      in_swish, a);
@@ -1186,6 +1214,28 @@ extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *p
                      wt_packed, a, tap_ws);
   hipLaunchKernelGGL(class_bias_kernel, dim3(cdiv(cout, 256), 27, b), dim3(256), 0, s, cout, tap_ws, bias, k_out);
   return p2pb_launch_status();
+}
+extern "C" int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,
+                                        const float *in_shift, int in_swish, const float *wt_packed,
+                                        const float *bias, float *a, float *k_out, float *tap_ws, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !in_scale || !in_shift) return P2PB_EINVAL;
+  return far_field_launch(b, cin, cout, prev_bias, in_scale, in_shift, in_swish, wt_packed, bias, a, k_out, tap_ws, nullptr, 0,
+                          GnFinish(), (hipStream_t)stream);
+}
+// the same with the GroupNorm(+AdaGN) of the operand folded in: part f32[b, nslots, cin, 2] = the first convolution's statistics
+// partials; scale / shift f32[b, cin] are OUTPUTS (what p2pb_gn_affine_params would have written, same bits)
+extern "C" int p2pb_conv3d_k3_far_field_gn(int b, int cin, int cout, const float *prev_bias, const float *part, int nslots,
+                                           double count_per_channel, int groups, const float *gamma, const float *beta,
+                                           const float *style, int style_stride, float eps, int in_swish,
+                                           const float *wt_packed, const float *bias, float *scale, float *shift, float *a,
+                                           float *k_out, float *tap_ws, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !part || nslots <= 0 || !scale || !shift || !gn_shape_ok(cin, groups, style, style_stride))
+    return P2PB_EINVAL;
+  GnFinish f = {};
+  f.gamma = gamma, f.beta = beta, f.style = style, f.scale = scale, f.shift = shift, f.chmean = nullptr, f.tickets = nullptr;
+  f.count_per_channel = count_per_channel, f.style_stride = style_stride, f.groups = groups, f.expected = 0, f.eps = eps;
+  return far_field_launch(b, cin, cout, prev_bias, nullptr, nullptr, in_swish, wt_packed, bias, a, k_out, tap_ws, part, nslots, f,
+                          (hipStream_t)stream);
 }
 #endif
 
@@ -2295,6 +2345,75 @@ static __global__ __launch_bounds__(256) void se_gate_affine_kernel(int c, int h
     aff_b[(size_t)b * c + i] = shift[(size_t)b * c + i] * gate;
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The tail of a PVConv's voxel branch in ONE launch (round 5: three GroupNorm-folding launches + the gate -> one):
+//   workgroup (0, b): GroupNorm(+AdaGN) of the SECOND convolution's output from its statistics partials (gn_finish_sample: the
+//     arithmetic and bits of gn_affine_kernel) -> scale, shift, channel mean in LDS -> SE3d gate (se_gate_affine_kernel's
+//     arithmetic) -> aff_a = scale * gate, aff_b = shift * gate (hidden == 0: no SE3d, aff = scale, shift);
+//   workgroup (1, b): the GroupNorm(+AdaGN) of the POINT branch's 1x1 convolution (its partials have been waiting since
+//     before the voxel branch started) -> scale_p, shift_p for the devoxelisation pass that adds swish(h * scale_p + shift_p).
+// 1024 threads: four groups at a time. Replaces models/pvcnn.py:283-286 (AdaGN, SE3d) + models/pvcnn.py:162-205's norm.
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(1024) void pvconv_tail_kernel(int c, int hidden, const float *__restrict__ part2, int nslots2,
+                                                           GnFinish f2, const float *__restrict__ w1, const float *__restrict__ w2,
+                                                           float *__restrict__ aff_a, float *__restrict__ aff_b,
+                                                           int cp, const float *__restrict__ partp, int nslotsp, GnFinish fp) {
+  extern __shared__ double pt_sm[];  // 4 x 1024 doubles | scale[c] | shift[c] | mean[c] | hid[hidden]
+  const int b = blockIdx.y, t = threadIdx.x;
+  if (blockIdx.x == 1) {
+    gn_finish_sample<4>(cp, nslotsp, partp, fp, b, pt_sm);
+    return;
+  }
+  float *sc = (float *)(pt_sm + 4096), *sh = sc + c, *mean = sh + c, *hid = mean + c;
+  gn_finish_sample<4>(c, nslots2, part2, f2, b, pt_sm, sc, sh, mean);
+  if (hidden <= 0) {
+    for (int i = t; i < c; i += 1024) {
+      aff_a[(size_t)b * c + i] = sc[i];
+      aff_b[(size_t)b * c + i] = sh[i];
+    }
+    return;
+  }
+  for (int h = t; h < hidden; h += 1024) {
+    float acc = 0.0f;
+    for (int i = 0; i < c; ++i) acc = __fmaf_rn(w1[(size_t)h * c + i], mean[i], acc);
+    hid[h] = fmaxf(acc, 0.0f);
+  }
+  __syncthreads();
+  for (int i = t; i < c; i += 1024) {
+    float acc = 0.0f;
+    for (int h = 0; h < hidden; ++h) acc = __fmaf_rn(w2[(size_t)i * hidden + h], hid[h], acc);
+    const float gate = 1.0f / (1.0f + expf(-acc));
+    aff_a[(size_t)b * c + i] = sc[i] * gate;
+    aff_b[(size_t)b * c + i] = sh[i] * gate;
+  }
+}
+
+#if CONV_TU != 6
+// part2 f32[b, nslots2, c, 2] + its norm (count2 = positions per channel, groups2, gamma2, beta2, style2 rows of 2c floats or NULL)
+// -> aff_a, aff_b f32[b, c] (SE3d gate from w1 f32[hidden, c], w2 f32[c, hidden]; hidden == 0: none); partp (may be NULL)
+// f32[b, nslotsp, cp, 2] + its norm -> scale_p, shift_p f32[b, cp]
+extern "C" int p2pb_pvconv_tail(int b, int c, int hidden, const float *part2, int nslots2, double count2, int groups2,
+                                const float *gamma2, const float *beta2, const float *style2, int style_stride2, float eps2,
+                                const float *w1, const float *w2, float *aff_a, float *aff_b, int cp, const float *partp,
+                                int nslotsp, double countp, int groupsp, const float *gammap, const float *betap,
+                                const float *stylep, int style_stridep, float epsp, float *scale_p, float *shift_p, void *stream) {
+  if (b <= 0 || c <= 0 || hidden < 0 || !part2 || nslots2 <= 0 || !aff_a || !aff_b || (hidden > 0 && (!w1 || !w2)) ||
+      !gn_shape_ok(c, groups2, style2, style_stride2))
+    return P2PB_EINVAL;
+  if (partp && (cp <= 0 || nslotsp <= 0 || !scale_p || !shift_p || !gn_shape_ok(cp, groupsp, stylep, style_stridep))) return P2PB_EINVAL;
+  GnFinish f2 = {}, fp = {};
+  f2.gamma = gamma2, f2.beta = beta2, f2.style = style2, f2.style_stride = style_stride2, f2.groups = groups2, f2.eps = eps2;
+  f2.count_per_channel = count2;  // (scale / shift / chmean stay in the kernel's LDS tables)
+  fp.gamma = gammap, fp.beta = betap, fp.style = stylep, fp.style_stride = style_stridep, fp.groups = groupsp, fp.eps = epsp;
+  fp.count_per_channel = countp, fp.scale = scale_p, fp.shift = shift_p;
+  const size_t lds = 4096 * 8 + (size_t)(3 * c + hidden) * 4;
+  if (lds > 64 * 1024) return P2PB_EINVAL;
+  hipLaunchKernelGGL(pvconv_tail_kernel, dim3(partp ? 2 : 1, b), dim3(1024), lds, (hipStream_t)stream, c, hidden, part2, nslots2, f2,
+                     w1, w2, aff_a, aff_b, cp, partp, nslotsp, fp);
+  return p2pb_launch_status();
+}
+#endif
 
 #if CONV_TU != 6
 extern "C" int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,

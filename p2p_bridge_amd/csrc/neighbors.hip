@@ -320,7 +320,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void grouping_grad_lds_kernel(int c, 
   scat_zero(rows, CH * Lp);
   const int *ib = idx + (size_t)b * mu;
   const float *g0 = gy + ((size_t)b * c + c0) * mu;
-  for (int q = threadIdx.x; q < mu; q += SCAT_THREADS) {
+  for (int q = threadIdx.x; q < mu; q += blockDim.x) {
     const int id = ib[q];
 #pragma unroll
     for (int j = 0; j < CH; ++j)
@@ -337,7 +337,7 @@ static int grouping_grad_lds_launch(int b, int c, int n, int mu, const float *gy
     (void)hipFuncSetAttribute((const void *)grouping_grad_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_LDS_MAX);
     once = true;
   }
-  hipLaunchKernelGGL(grouping_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(SCAT_THREADS), sizeof(float) * (size_t)CH * Lp, s, c, n,
+  hipLaunchKernelGGL(grouping_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(scat_threads()), sizeof(float) * (size_t)CH * Lp, s, c, n,
                      Lp, mu, gy, idx, gx);
   return p2pb_launch_status();
 }
@@ -353,6 +353,7 @@ extern "C" int p2pb_grouping_backward(int b, int c, int n, int m, int u, const f
     case 8: return grouping_grad_lds_launch<8>(b, c, n, m * u, grad_y, idx, grad_x, s);
     default: return grouping_grad_lds_launch<4>(b, c, n, m * u, grad_y, idx, grad_x, s);
   }
+  if (p2pb_deterministic()) return P2PB_EINVAL;  // (rows beyond the LDS: only the global-atomic kernel is left)
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * n, s);
   if (e != 0) return e;
   constexpr int CC = 8;
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void three_interp_grad_lds_kernel(int
   const int *id = indices + (size_t)b * 3 * n;
   const float *w = weights + (size_t)b * 3 * n;
   const float *g0 = gy + ((size_t)b * c + c0) * n;
-  for (int j = threadIdx.x; j < n; j += SCAT_THREADS) {
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
     const int a0 = id[j], a1 = id[j + n], a2 = id[j + 2 * n];
     const float w0 = w[j], w1 = w[j + n], w2 = w[j + 2 * n];
 #pragma unroll
@@ -904,7 +905,7 @@ static int three_interp_grad_lds_launch(int b, int c, int n, int m, const float 
                               SCAT_LDS_MAX);
     once = true;
   }
-  hipLaunchKernelGGL(three_interp_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(SCAT_THREADS), sizeof(float) * (size_t)CH * Lp, s, c,
+  hipLaunchKernelGGL(three_interp_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(scat_threads()), sizeof(float) * (size_t)CH * Lp, s, c,
                      n, m, Lp, gy, idx, w, gx);
   return p2pb_launch_status();
 }
@@ -920,6 +921,7 @@ extern "C" int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, co
     case 8: return three_interp_grad_lds_launch<8>(b, c, n, m, grad_y, idx, w, grad_x, s);
     default: return three_interp_grad_lds_launch<4>(b, c, n, m, grad_y, idx, w, grad_x, s);
   }
+  if (p2pb_deterministic()) return P2PB_EINVAL;  // (rows beyond the LDS: only the global-atomic kernel is left)
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * m, s);
   if (e != 0) return e;
   constexpr int CC = 16;

@@ -1005,6 +1005,10 @@ static int pw_finish_behind(int rc, int b, int cout, int P, const float *stats_p
   tl_pw_fin_pending = false;
   if (rc != 0) return rc;
   if (!stats_part) return P2PB_EINVAL;  // (a finisher armed for a launch without statistics)
+  // the checks of p2pb_gn_affine_params_ex (a MyGroupNorm(32, cout) with cout % 32 != 0, or cout / groups > 256, ran
+  // gn_finish_group with a truncated group / past its 256-entry LDS table and read gamma out of bounds)
+  const GnFinish &f = tl_pw_fin;
+  if (f.groups <= 0 || cout % f.groups != 0 || cout / f.groups > 256 || (f.style && f.style_stride < 2 * cout)) return P2PB_EINVAL;
   ++g_fin_behind;
   return p2pb_gn_affine_launch(b, cout, (P + 255) / 256 * 4, stats_part, tl_pw_fin, s);
 }
@@ -1022,7 +1026,9 @@ static int pw_finish_behind(int rc, int b, int cout, int P, const float *stats_p
 static GnFinish pw_take_finisher(int b, int cout, int cw, int pblocks, bool has_stats, hipStream_t s, int kind = 1) {
   GnFinish fin = {};
   static const int fin_env = getenv("P2PB_GN_FINISH") ? atoi(getenv("P2PB_GN_FINISH")) : 0;
-  if (!tl_pw_fin_pending || !(fin_env & kind) || !has_stats || cout % tl_pw_fin.groups != 0) return fin;
+  if (!tl_pw_fin_pending || !(fin_env & kind) || !has_stats || tl_pw_fin.groups <= 0 || cout % tl_pw_fin.groups != 0 ||
+      (tl_pw_fin.style && tl_pw_fin.style_stride < 2 * cout))
+    return fin;  // (left pending: pw_finish_behind rejects the shapes gn_finish_group cannot take)
   const int cg = cout / tl_pw_fin.groups;
   if (!(cw % cg == 0 || cg % cw == 0) || cg > 256) return fin;
   unsigned *tk = p2pb_gn_tickets((size_t)b * tl_pw_fin.groups, s);
@@ -1333,29 +1339,41 @@ __global__ __launch_bounds__(256) void minmax_act_kernel(int c, int m, int nslot
 // global pool (nslots > 0) with the slot loop spread over 8 waves: 32 channels x 8 slot classes per workgroup, min / max
 // combined through LDS (exact, order-free) -- one thread per (sample, channel) walked 128+ slots serially: 69 us for the
 // 1024-channel embedding of the bench
+// part != NULL (round 5): the GroupNorm that precedes the activation is folded here too -- the workgroup finishes the groups its
+// 32 channels belong to from the producing GEMM's statistics partials (gn_finish_group: gn_affine_kernel's bits), WRITES
+// scale / shift (fin.scale / fin.shift: the next GEMM applies them to the same tensor on load) and pools with them; the
+// gn_affine launch between the GEMM and this kernel is gone.
 __global__ __launch_bounds__(256) void minmax_act_pool_kernel(int c, int nslots, const float *__restrict__ mm,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift, int swish,
-                                                              float *__restrict__ y) {
+                                                              float *__restrict__ y, const float *__restrict__ part, int nslots_st,
+                                                              GnFinish fin) {
   __shared__ float smn[8][32], smx[8][32];
-  const int b = blockIdx.y, ch = blockIdx.x * 32 + (threadIdx.x & 31), part = threadIdx.x >> 5;
+  __shared__ double gl[4 * 256];
+  extern __shared__ float mmp_tab[];  // folded form: scale[c] | shift[c] of this sample
+  const int b = blockIdx.y, ch = blockIdx.x * 32 + (threadIdx.x & 31), part_i = threadIdx.x >> 5;
   float mn = INFINITY, mx = -INFINITY;
   if (ch < c)
-    for (int sl = part; sl < nslots; sl += 8) {
+    for (int sl = part_i; sl < nslots; sl += 8) {
       const float2 v = *(const float2 *)(mm + (((size_t)b * nslots + sl) * c + ch) * 2);
       mn = fminf(mn, v.x);
       mx = fmaxf(mx, v.y);
     }
-  smn[part][threadIdx.x & 31] = mn;
-  smx[part][threadIdx.x & 31] = mx;
+  smn[part_i][threadIdx.x & 31] = mn;
+  smx[part_i][threadIdx.x & 31] = mx;
+  if (part != nullptr) {
+    const int cg = c / fin.groups, c0 = blockIdx.x * 32, c1 = min(c0 + 32, c) - 1;
+    for (int g = c0 / cg; g <= c1 / cg; ++g)
+      gn_finish_group_v(c, nslots_st, part, fin, b, g, gl, (int)threadIdx.x, true, nullptr, false, mmp_tab, mmp_tab + c);
+  }
   __syncthreads();
-  if (part != 0 || ch >= c) return;
+  if (part_i != 0 || ch >= c) return;
 #pragma unroll
   for (int p = 1; p < 8; ++p) {
     mn = fminf(mn, smn[p][threadIdx.x]);
     mx = fmaxf(mx, smx[p][threadIdx.x]);
   }
-  const float sc = scale[(size_t)b * c + ch], sh = shift[(size_t)b * c + ch];
+  const float sc = part ? mmp_tab[ch] : scale[(size_t)b * c + ch], sh = part ? mmp_tab[c + ch] : shift[(size_t)b * c + ch];
   float lo = mn * sc + sh, hi = mx * sc + sh;
   if (swish) {
     lo = swishf(lo);
@@ -1369,13 +1387,30 @@ extern "C" int p2pb_minmax_act(int b, int c, int m, int nslots, const float *min
   if (b <= 0 || c <= 0 || m <= 0 || nslots < 0) return P2PB_EINVAL;
   if (nslots >= 16) {
     hipLaunchKernelGGL(minmax_act_pool_kernel, dim3((c + 31) / 32, b), dim3(256), 0, (hipStream_t)stream, c, nslots, minmax,
-                       scale, shift, swish, y);
+                       scale, shift, swish, y, (const float *)nullptr, 0, GnFinish());
     return p2pb_launch_status();
   }
   const size_t total = nslots == 0 ? (size_t)b * c * m : (size_t)b * c;
   const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipLaunchKernelGGL(minmax_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c, m, nslots, minmax, scale,
                      shift, swish, y, total);
+  return p2pb_launch_status();
+}
+// the global max-pool (minmax f32[b, nslots, c, 2] -> y f32[b, c]) with the GroupNorm in front of the activation folded in: part
+// f32[b, nslots_st, c, 2] = the producing GEMM's statistics partials; scale / shift f32[b, c] are OUTPUTS (p2pb_gn_affine_params'
+// values, same bits). Replaces MyGroupNorm + Swish + the max-pool of models/pvcnn.py:905-932 behind a Pnet2Stage GEMM.
+extern "C" int p2pb_minmax_act_pool_gn(int b, int c, int nslots, const float *minmax, const float *part, int nslots_st,
+                                       double count_per_channel, int groups, const float *gamma, const float *beta,
+                                       const float *style, int style_stride, float eps, int swish, float *scale, float *shift,
+                                       float *y, void *stream) {
+  if (b <= 0 || c <= 0 || nslots <= 0 || !minmax || !part || nslots_st <= 0 || !scale || !shift || !y || groups <= 0 ||
+      c % groups != 0 || c / groups > 256 || (style && style_stride < 2 * c) || (size_t)c * 8 > 32 * 1024)
+    return P2PB_EINVAL;
+  GnFinish f = {};
+  f.gamma = gamma, f.beta = beta, f.style = style, f.scale = scale, f.shift = shift, f.style_stride = style_stride, f.groups = groups;
+  f.eps = eps, f.count_per_channel = count_per_channel;
+  hipLaunchKernelGGL(minmax_act_pool_kernel, dim3((c + 31) / 32, b), dim3(256), (size_t)c * 8, (hipStream_t)stream, c, nslots, minmax,
+                     (const float *)nullptr, (const float *)nullptr, swish, y, part, nslots_st, f);
   return p2pb_launch_status();
 }
 

@@ -765,7 +765,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void devox_grad_lds_kernel(int c, int
   const int *ib = inds + (size_t)b * 8 * n;
   const float *wb = wgts + (size_t)b * 8 * n;
   const float *g0 = gy + ((size_t)b * c + c0) * n;
-  for (int i = threadIdx.x; i < n; i += SCAT_THREADS) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int idx[8];
     float w[8];
 #pragma unroll
@@ -795,7 +795,7 @@ static int devox_grad_lds_launch(int b, int c, int n, int r3, const int *inds, c
     (void)hipFuncSetAttribute((const void *)devox_grad_lds_kernel<CH>, hipFuncAttributeMaxDynamicSharedMemorySize, SCAT_LDS_MAX);
     once = true;
   }
-  hipLaunchKernelGGL(devox_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(SCAT_THREADS), lds, s, c, n, r3, Lp, inds, wgts, gy, gx);
+  hipLaunchKernelGGL(devox_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(scat_threads()), lds, s, c, n, r3, Lp, inds, wgts, gy, gx);
   return p2pb_launch_status();
 }
 
@@ -811,6 +811,7 @@ extern "C" int p2pb_trilinear_devoxelize_backward(int b, int c, int n, int r3, c
     case 16: return devox_grad_lds_launch<16>(b, c, n, r3, inds, wgts, grad_y, grad_x, s);
     default: return devox_grad_lds_launch<8>(b, c, n, r3, inds, wgts, grad_y, grad_x, s);
   }
+  if (p2pb_deterministic()) return P2PB_EINVAL;  // (rows beyond the LDS: only the global-atomic kernel is left)
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * r3, s);
   if (e != 0) return e;
   constexpr int CC = 16;

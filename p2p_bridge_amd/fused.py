@@ -270,6 +270,78 @@ def conv3d_far_field(prev_bias, conv, in_scale, in_shift, swish=True):
     return a, k
 
 
+def _style_arg(style, c):
+    """style rows (factor | bias) f32[B, 2c], possibly a column slice of the evaluation's one style matrix -> (tensor, row stride)"""
+    if style is None:
+        return None, 0
+    if style.stride(1) != 1 or style.shape[1] != 2 * c:
+        style = style.contiguous()
+    return style, style.stride(0)
+
+
+def conv3d_far_field_gn(prev_bias, conv, part, fin, swish=True):
+    """conv3d_far_field with the GroupNorm(+AdaGN) of the operand folded into the launch: part f32[B,nslots,Cin,2] = the first
+    convolution's statistics partials, fin = pvcnn_unet.norm_fin(...) -> (scale, shift f32[B,Cin], a f32[B,Cin], K f32[B,27,Cout]):
+    the values gn_affine_params + conv3d_far_field return, one launch instead of two on the dependent chain"""
+    count, groups, gamma, beta, style, eps, _ = fin
+    b, nslots, ci, _ = part.shape
+    co = conv.out_channels
+    wt = pack_conv3d_weight(conv)
+    dev = part.device
+    scale = torch.empty(b, ci, dtype=F32, device=dev)
+    shift, a = torch.empty_like(scale), torch.empty_like(scale)
+    k = torch.empty(b, 27, co, dtype=F32, device=dev)
+    ws = torch.empty(b, 27, co, dtype=F32, device=dev)
+    style, stride = _style_arg(style, ci)
+    call("p2pb_conv3d_k3_far_field_gn", _i(b), _i(ci), _i(co), ptr(prev_bias), ptr(part), _i(nslots), _d(float(count)), _i(int(groups)),
+         ptr(gamma), ptr(beta), ptr(style), _i(stride), _f(eps), _i(int(swish)), ptr(wt), ptr(conv.bias), ptr(scale), ptr(shift),
+         ptr(a), ptr(k), ptr(ws), stream_ptr())
+    return scale, shift, a, k
+
+
+def pvconv_tail(part2, fin2, se=None, point=None):
+    """the tail of a PVConv's voxel branch in one launch (csrc/conv3d.hip pvconv_tail_kernel): part2 = the second convolution's
+    statistics partials f32[B,nslots,C,2], fin2 its norm (norm_fin), se = (fc1 weight [hidden, C], fc2 weight [C, hidden]) | None,
+    point = (partials of the point branch's 1x1 convolution, its norm_fin) | None ->
+    (aff_a, aff_b f32[B,C] = the folded norm x the SE3d gate, scale_p, shift_p f32[B,Cp] | None, None)"""
+    count2, groups2, gamma2, beta2, style2, eps2, _ = fin2
+    b, ns2, c, _ = part2.shape
+    dev = part2.device
+    aff_a = torch.empty(b, c, dtype=F32, device=dev)
+    aff_b = torch.empty_like(aff_a)
+    style2, stride2 = _style_arg(style2, c)
+    w1, w2 = se if se is not None else (None, None)
+    hidden = 0 if se is None else w1.shape[0]
+    scp = shp = partp = gammap = betap = stylep = None
+    cp = nsp = groupsp = stridep = 0
+    countp, epsp = 1.0, 1e-5
+    if point is not None:
+        partp, (countp, groupsp, gammap, betap, stylep, epsp, _) = point
+        nsp, cp = partp.shape[1], partp.shape[2]
+        stylep, stridep = _style_arg(stylep, cp)
+        scp = torch.empty(b, cp, dtype=F32, device=dev)
+        shp = torch.empty_like(scp)
+    call("p2pb_pvconv_tail", _i(b), _i(c), _i(hidden), ptr(part2), _i(ns2), _d(float(count2)), _i(int(groups2)), ptr(gamma2), ptr(beta2),
+         ptr(style2), _i(stride2), _f(eps2), ptr(w1), ptr(w2), ptr(aff_a), ptr(aff_b), _i(cp), ptr(partp), _i(nsp), _d(float(countp)),
+         _i(int(groupsp)), ptr(gammap), ptr(betap), ptr(stylep), _i(stridep), _f(epsp), ptr(scp), ptr(shp), stream_ptr())
+    return aff_a, aff_b, scp, shp
+
+
+def minmax_act_pool_gn(mm, part, fin, swish=True):
+    """global max-pool of act(norm(x)) from the producing GEMM's {min, max} partials mm f32[B,nslots,C,2] with the norm folded in:
+    part = the GEMM's statistics partials, fin = norm_fin(...) -> (y f32[B,C], scale, shift f32[B,C]); one launch instead of
+    gn_affine_params + minmax_act(global_pool=True), same values"""
+    count, groups, gamma, beta, style, eps, _ = fin
+    b, nslots, c, _ = mm.shape
+    dev = mm.device
+    y = torch.empty(b, c, dtype=F32, device=dev)
+    scale, shift = torch.empty_like(y), torch.empty_like(y)
+    style, stride = _style_arg(style, c)
+    call("p2pb_minmax_act_pool_gn", _i(b), _i(c), _i(nslots), ptr(mm), ptr(part), _i(part.shape[1]), _d(float(count)), _i(int(groups)),
+         ptr(gamma), ptr(beta), ptr(style), _i(stride), _f(eps), _i(int(swish)), ptr(scale), ptr(shift), ptr(y), stream_ptr())
+    return y, scale, shift
+
+
 def gn_affine_params(part, count_per_channel, groups, gamma, beta, style=None, eps=1e-5, want_mean=False):
     """partials f32[B,nslots,C,2] -> scale, shift (, chmean) f32[B,C]. style: f32[B,2C] rows (factor | bias), may
     be a column slice of a wider matrix (row stride passed through, no copy)"""

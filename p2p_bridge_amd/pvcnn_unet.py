@@ -442,24 +442,24 @@ class PVConv(nn.Module):
                 y1, st1 = fused.conv3d_k3_compact(v, vl[0], lists, counts, 0, pre=pre1)
             else:
                 y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, pre=pre1)
-            sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
-            if r in c2:
-                a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
+            if r in c2:  # (the norm between the convolutions is folded inside the far-field launch)
+                sc1, sh1, a, k = fused.conv3d_far_field_gn(vl[0].bias, vl[4], st1, norm_fin(vl[1], r3, cond), True)
                 if pre2:
                     y2, st2 = fused.conv3d_k3_compact(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
                                                       out_class=k, pre=True)
                 else:
                     y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k)
-            elif pre2:
-                y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True, pre=True)
             else:
-                y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True)
+                sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
+                if pre2:
+                    y2, st2 = fused.conv3d_k3(fused.conv3d_presplit(y1, sc1, sh1, True), vl[4], compact=True, channels_last=True, pre=True)
+                else:
+                    y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True)
         elif r >= 32 and self.sparse_conv:  # at r = 16 every 4x8x8 brick touches the surface: dense is faster
             if lists is None:
                 lists, counts = fused.brick_lists(cnt, r)
             y1, st1 = fused.conv3d_k3_sparse(v, vl[0], lists, counts, 0, channels_last=True, pre=pre1)
-            sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
-            a, k = fused.conv3d_far_field(vl[0].bias, vl[4], sc1, sh1, True)
+            sc1, sh1, a, k = fused.conv3d_far_field_gn(vl[0].bias, vl[4], st1, norm_fin(vl[1], r3, cond), True)
             if pre2:
                 y2, st2 = fused.conv3d_k3_sparse(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
                                                  out_class=k, channels_last=True, pre=True)
@@ -474,12 +474,13 @@ class PVConv(nn.Module):
             else:
                 y2, st2 = fused.conv3d_k3(y1, vl[4], sc1, sh1, swish=True, compact=True, channels_last=True)
         se = vl[6] if len(vl) > 6 else None
-        sc2, sh2, mean2 = norm_affine(vl[5], st2, r3, cond, want_mean=True)
-        if se is not None:
-            sc2, sh2 = fused.se_gate_affine(mean2, se.fc[0].weight, se.fc[2].weight, sc2, sh2)
-        # point = (h, scale, shift): the point branch's raw conv output and folded norm; its Swish and the sum of
-        # the two branches happen in the devoxelisation pass
-        return fused.devoxelize_affine(y2, vcoords, r, sc2, sh2, channels_last=True, add=point)
+        # the second norm (+ channel means), the SE3d gate and the point branch's norm in ONE launch (fused.pvconv_tail);
+        # point = (h, partials, norm): the point branch's raw conv output, its statistics and the norm that follows; its Swish
+        # and the sum of the two branches happen in the devoxelisation pass
+        aff_a, aff_b, scp, shp = fused.pvconv_tail(st2, norm_fin(vl[5], r3, cond), None if se is None else (se.fc[0].weight, se.fc[2].weight),
+                                                   None if point is None else (point[1], point[2]))
+        return fused.devoxelize_affine(y2, vcoords, r, aff_a, aff_b, channels_last=True,
+                                       add=None if point is None else (point[0], scp, shp))
 
     def forward(self, data: PVCData) -> PVCData:
         coords, features, cond = data.coords, data.features, data.cond
@@ -490,8 +491,9 @@ class PVConv(nn.Module):
                 from . import fused as F_
 
                 feats = features.contiguous()
-                h, st, (scp, shp, _) = F_.pw_conv(feats, pf[0], fin=norm_fin(pf[1], feats.shape[2], cond))
-                data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, scp, shp), geo=data.geo)
+                h, st = F_.pw_conv(feats, pf[0])
+                data.features = self._voxel_branch_fused(feats, coords, cond, point=(h, st, norm_fin(pf[1], feats.shape[2], cond)),
+                                                         geo=data.geo)
                 if self.attn is not None:
                     data.features = self.attn(data.features)
                 return data
@@ -732,9 +734,9 @@ class Pnet2Stage(nn.Module):
         b0, b1 = self.mlp2.shared_mlp_0.mlp, self.mlp2.shared_mlp_1.mlp
         h, st, (sc, sh, _) = fused.pw_conv(coords.contiguous(), a0[0], fin=norm_fin(a0[1], N, None))
         pool = fused.pool_supported(N, 0)  # the max-pools ride in the GEMM epilogues as {min, max} partials
-        if pool:
-            h, st, mm, (sc, sh, _) = fused.pw_conv(h, a1[0], sc, sh, swish=True, pool_u=0, fin=norm_fin(a1[1], N, None))
-            g = fused.minmax_act(mm, sc, sh, global_pool=True)
+        if pool:  # (the norm behind a pooled GEMM is folded into the pooling launch: fused.minmax_act_pool_gn)
+            h, st, mm = fused.pw_conv(h, a1[0], sc, sh, swish=True, pool_u=0)
+            g, sc, sh = fused.minmax_act_pool_gn(mm, st, norm_fin(a1[1], N, None))
         else:
             h, st, (sc, sh, _) = fused.pw_conv(h, a1[0], sc, sh, swish=True, fin=norm_fin(a1[1], N, None))
             g = fused.affine_act_max(h, sc, sh, N, 0)
@@ -743,8 +745,8 @@ class Pnet2Stage(nn.Module):
         bias_b = fused.linear_rows(g, w[:, c1:])  # (no BLAS in the captured step: fused.linear_rows)
         h, st, (sc, sh, _) = fused.pw_conv(h, b0[0], sc, sh, swish=True, bias_b=bias_b, ci_lo=0, ci_hi=c1, fin=norm_fin(b0[1], N, None))
         if pool:  # the 1024-channel output is never written: only its statistics and extrema are needed
-            _, st, mm, (sc, sh, _) = fused.pw_conv(h, b1[0], sc, sh, swish=True, pool_u=0, store=False, fin=norm_fin(b1[1], N, None))
-            return fused.minmax_act(mm, sc, sh, global_pool=True)
+            _, st, mm = fused.pw_conv(h, b1[0], sc, sh, swish=True, pool_u=0, store=False)
+            return fused.minmax_act_pool_gn(mm, st, norm_fin(b1[1], N, None))[0]
         h, st, (sc, sh, _) = fused.pw_conv(h, b1[0], sc, sh, swish=True, fin=norm_fin(b1[1], N, None))
         return fused.affine_act_max(h, sc, sh, N, 0)
 

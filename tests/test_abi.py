@@ -36,6 +36,35 @@ def test_library_contains_gfx950_code_object():
     assert "gfx950" in out
 
 
+def test_no_kernel_issues_ds_write_b96():
+    """Round 4's cross-stream corruption sat in a kernel whose LDS staging the compiler had merged into
+    ds_write_b96 + ds_write2_b32; the mechanism is unexplained (barrier and s_waitcnt were in order in the ISA), so the invariant
+    that protects the library is enforced here: the disassembly of every translation unit of libp2pb_hip.so holds no 12-byte LDS
+    store. (tests/test_concurrency_gpu.py is the dynamic half of the net.)"""
+    import glob
+    import tempfile
+
+    from p2p_bridge_amd import build
+
+    build.build()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objs = sorted(glob.glob(os.path.join(build.OBJ, "*.o")))
+    assert len(objs) >= 16
+    seen_b128 = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            fat, co = os.path.join(tmp, "x.fat"), os.path.join(tmp, "x.co")
+            subprocess.run([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", o], check=True)
+            subprocess.run([f"{llvm}/clang-offload-bundler", "--type=o", "--unbundle", f"--input={fat}",
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+            isa = subprocess.run([f"{llvm}/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+            assert "s_endpgm" in isa, o
+            seen_b128 += isa.count("ds_write_b128")
+            for bad in ("ds_write_b96", "ds_store_b96"):
+                assert bad not in isa, (bad, os.path.basename(o))
+    assert seen_b128 > 100  # (the grep sees LDS stores at all)
+
+
 def test_no_cpu_fallback():
     """product ops refuse CPU tensors (the oracle is never a fallback)."""
     import torch

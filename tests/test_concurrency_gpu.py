@@ -67,3 +67,121 @@ def test_two_chain_sampler_equals_its_serial_replay():
         c = run()
         d = (c - ref).abs().amax(dim=(2, 3))
         assert torch.equal(c, ref), (rep, [(int(b), int(k), float(d[b, k])) for b, k in (d > 0).nonzero().tolist()][:8])
+
+
+def _record_evaluation(net, mods, names, xin, t):
+    """every top-level fused.* / pointnet2_batch_cuda.* call of one network evaluation: (name, function, args, kwargs)"""
+    calls, orig, depth = [], {}, [0]
+    for mname, k in names:
+        f = getattr(mods[mname], k)
+        orig[(mname, k)] = f
+
+        def wrap(f=f, mname=mname, k=k):
+            def g(*a, **kw):
+                depth[0] += 1
+                try:
+                    out = f(*a, **kw)
+                finally:
+                    depth[0] -= 1
+                if depth[0] == 0:
+                    calls.append((f"{mname}.{k}", f, a, kw))
+                return out
+            return g
+        setattr(mods[mname], k, wrap())
+    try:
+        with torch.no_grad():
+            net(xin, t)
+    finally:
+        for (mname, k), f in orig.items():
+            setattr(mods[mname], k, f)
+    torch.cuda.synchronize()
+    return calls
+
+
+def _flat(o):
+    if isinstance(o, torch.Tensor):
+        return [o]
+    if isinstance(o, (tuple, list)):
+        return [t for e in o for t in _flat(e)]
+    return []
+
+
+def test_every_op_of_an_evaluation_beside_matrix_kernels_is_bitwise_stable():
+    """The standing net behind round 4's cross-stream finding (the devoxelisation returned wrong values for one wave's
+    points when a matrix kernel of another stream shared its CU; the cause inside the hardware / compiler is NOT explained -- the
+    barrier and s_waitcnt in the ISA were in order -- so the library is protected by two invariants instead: no ds_write_b96 in
+    any kernel (tests/test_abi.py greps the disassembly) and THIS test). Every product call of one network evaluation at the
+    bench's chain shape (stock PVDS, 16 x 8192 points: ~200 launches of ~45 kernels, recorded with its own tensors) is replayed
+    on one stream while another stream runs (a) the ping-pong GEMM pw_pp512_kernel (512 -> 1024 with the pooling epilogue) and
+    (b) the compact voxel convolution (r = 16, C128, set D2) of ANOTHER evaluation -- the two kernel families that fill every
+    CU's LDS and matrix pipe -- and every output is compared BITWISE with the serial result. (tools/dbg/conc_ops.py was the
+    all-pairs form of this that found the devoxelisation; all pairs take minutes, the two matrix partners are the ones that
+    ever produced a difference.)"""
+    import copy
+    import types
+
+    from oracle import net_ref
+    from p2p_bridge_amd import fused, pointnet2_batch_cuda as ext
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
+    from test_host_logic import PVDS
+
+    cfg = copy.deepcopy(PVDS)
+    cfg["data"]["npoints"] = 8192
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in PVCNN2Unet(cfg).state_dict().items()}
+    model = product.build_model(cfg, sd, device="cuda")
+    model.eval()
+    net = model.model
+    x, _ = net_ref.synthetic_patches(32, 8192, seed=5)
+    x = x.cuda()
+    t = torch.full((16,), 500.0, device="cuda")
+    mods = {"fused": fused, "ext": ext}
+    not_ops = {"conv_math", "set_conv_math", "use_split", "use_split_pw", "use_wide_f16", "pool_supported", "gather_pool_supported",
+               "conv_pre_plan", "enabled", "pack_conv3d_weight", "pack_pointwise_weight", "lib", "call", "check", "ptr", "stream_ptr",
+               "fps_coop_fallbacks", "arm_finisher"}
+    names = [(mname, k) for mname, m in mods.items() for k, v in vars(m).items()
+             if isinstance(v, types.FunctionType) and v.__module__ == m.__name__ and not k.startswith("_") and k not in not_ops]
+    ca = _record_evaluation(net, mods, names, x[:16].contiguous(), t)
+    cb = _record_evaluation(net, mods, names, x[16:].contiguous(), t)
+    assert len(ca) == len(cb) > 150, (len(ca), len(cb))
+    kinds = {n for n, *_ in ca}
+    for must in ("fused.pw_conv", "fused.conv3d_k3_compact", "fused.conv3d_k3_sparse", "fused.conv3d_k3", "fused.devoxelize_affine",
+                 "fused.voxelize_cl_gather", "fused.group_sub", "fused.interp_add", "fused.minmax_act", "fused.gn_affine_params",
+                 "fused.conv3d_far_field", "fused.se_gate_affine", "fused.linear_rows", "fused.voxel_sort",
+                 "ext.furthest_point_sampling_forward", "ext.ball_query", "ext.three_nn"):
+        assert must in kinds, (must, sorted(kinds))
+
+    def is_pp512(c):
+        n, f, a, kw = c
+        return n == "fused.pw_conv" and tuple(a[0].shape[1:]) == (512, 8192) and a[1].weight.shape[0] == 1024
+
+    def is_compact_c128(c):
+        n, f, a, kw = c
+        return n == "fused.conv3d_k3_compact" and a[1].in_channels == 128 and a[1].out_channels == 128 and a[4] == 1
+    partners = [next(c for c in cb if is_pp512(c)), next(c for c in cb if is_compact_c128(c))]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    bad, unstable = [], set()
+    with torch.no_grad():
+        refs = [[o.clone() for o in _flat(f(*a, **kw))] for (_, f, a, kw) in ca]
+        torch.cuda.synchronize()
+        for i, (name, f, a, kw) in enumerate(ca):
+            again = _flat(f(*a, **kw))  # an op whose serial re-run differs (list compaction by atomics) cannot be compared
+            torch.cuda.synchronize()
+            if not all(torch.equal(u, v) for u, v in zip(again, refs[i])):
+                unstable.add(name)
+                continue
+            for (pn, pf, pa, pkw) in partners:
+                outs = []
+                for _ in range(2):
+                    for _ in range(2):
+                        with torch.cuda.stream(sa):
+                            pf(*pa, **pkw)
+                        with torch.cuda.stream(sb):
+                            outs.append(_flat(f(*a, **kw)))
+                    torch.cuda.synchronize()
+                nbad = sum(not torch.equal(u, v) for o in outs for u, v in zip(o, refs[i]))
+                if nbad:
+                    bad.append((i, name, pn, nbad))
+    assert unstable <= {"fused.brick_lists", "fused.voxel_sort"}, unstable
+    assert not bad, bad[:10]

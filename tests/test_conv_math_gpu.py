@@ -22,7 +22,10 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 @pytest.fixture()
 def fused():
     from p2p_bridge_amd import fused as f
-    assert f.conv_math() == "f16x3" and f.lib().p2pb_get_split_terms() == 16  # the suite runs on the default
+    if not (f.conv_math() == "f16x3" and f.lib().p2pb_get_split_terms() == 16):
+        # this file tests the DEFAULT arithmetic and switches away from it and back; a suite run under P2PB_CONV_MATH=bf16x6 /
+        # fp32 (the fallback arithmetics: every other file runs on them unchanged) has nothing to test here
+        pytest.skip("tests of the default arithmetic (f16x3); the suite runs under P2PB_CONV_MATH=" + f.conv_math())
     yield f
     f.set_conv_math(None)
     assert f.lib().p2pb_get_split_terms() == 16

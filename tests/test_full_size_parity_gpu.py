@@ -362,7 +362,7 @@ def test_c2_bench_dispatch_one_evaluation_b8(c2):
     assert err < TOL
 
 
-def _teacher_forced_errors(orc, cfg, x_start, chain, steps):
+def _teacher_forced_errors(orc, cfg, x_start, chain, steps, x_cond=None):
     """per-step max|hip - oracle| of a sampler run whose EVERY state was logged (log_count = steps), the oracle's step fed with
     the HIP chain's own previous state: the captured step (network evaluation + posterior update, models/p2pb.py:190-262) is
     compared at every step without the chain's sensitivity to index decisions compounding -- with seeded random weights at
@@ -378,7 +378,7 @@ def _teacher_forced_errors(orc, cfg, x_start, chain, steps):
     for i, (prev, step) in enumerate(zip(rev[1:], rev[:-1])):
         xt = states[i]
         nl = sch["noise_levels"][torch.full((xt.shape[0],), step, dtype=torch.long)]
-        x0 = xt - sch["std_fwd"][step] * orc(xt, nl, None)
+        x0 = xt - sch["std_fwd"][step] * orc(xt, nl, x_cond)
         std_n, std_p = sch["std_fwd"][step], sch["std_fwd"][prev]
         std_d = (std_n ** 2 - std_p ** 2).sqrt()
         den = std_p ** 2 + std_d ** 2
@@ -453,14 +453,19 @@ def test_c5_full_width_pvdl_50000():
     assert err < TOL
 
 
-def test_c2_t30_gate_on_a_briefly_trained_denoiser():
-    """the literal north_star gate -- predicted xyz within 1e-4 and Chamfer-L2 within 1e-4, T = 30, free-running, FULL output
-    scale -- on a network that behaves like a denoiser instead of a random map: stock PVDS is trained here for 300 captured
-    optimiser steps (8 x 2048 synthetic PU-Net-shaped pairs per step, the C3 step of bench.py, ~5 s) with the product's own
-    train(), then the trained weights go to both sides: HIP sample(graph=True) vs the oracle's sampler at 8192 points, B = 2.
-    A trained bridge moves a point by about the noise level per chain, so a 1-ulp difference does not get amplified to
-    O(1) as it does with random weights (test_c2_t30_free_running_chamfer above)."""
-    _threads()
+def _aligned_punet_batches(bs, npoints, seed, device):
+    """endless PU-Net-shaped (clean, noisy) pairs in MATCHING point order: the training below needs no auction alignment (the
+    auction is racy by the reference's own definition, metrics/emd_assignment/emd_cuda.cu), so every run sees the same pairs"""
+    k = 0
+    while True:
+        noisy, clean = net_ref.synthetic_patches(bs, npoints, seed=seed + k)
+        yield {"clean_points": clean.transpose(1, 2).contiguous().to(device),
+               "noisy_points": noisy.transpose(1, 2).contiguous().to(device)}
+        k += 1
+
+
+def _train_300_steps_deterministically():
+    import p2p_bridge_amd
     from p2p_bridge_amd import p2pb as product
     from p2p_bridge_amd import train as T
     from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
@@ -471,12 +476,29 @@ def test_c2_t30_gate_on_a_briefly_trained_denoiser():
     tcfg["gpu"] = "cuda"
     torch.manual_seed(0)
     trainee = product.P2PB(tcfg, PVCNN2Unet(tcfg))
-    batches = T.synthetic_punet_batches(8, 2048, seed=77, device=trainee.device)
-    hist = T.train(tcfg, trainee, batches, 300, align=True, graph=True)
-    torch.cuda.synchronize()
+    with p2p_bridge_amd.deterministic():  # scatter-add gradients in a fixed order: the SAME network in every run
+        hist = T.train(tcfg, trainee, _aligned_punet_batches(8, 2048, 77, trainee.device), 300, align=False, graph=True)
+        torch.cuda.synchronize()
     assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
     sd = {k: v.detach().cpu().clone() for k, v in trainee.model.state_dict().items()}
     del trainee
+    return sd, hist
+
+
+def test_c2_t30_gate_on_a_briefly_trained_denoiser():
+    """the literal north_star gate -- predicted xyz within 1e-4 and Chamfer-L2 within 1e-4, T = 30, free-running, FULL output
+    scale -- on a network that behaves like a denoiser instead of a random map: stock PVDS is trained here for 300 captured
+    optimiser steps (8 x 2048 synthetic PU-Net-shaped pairs per step, the C3 step of bench.py) with the product's own train()
+    in DETERMINISTIC mode (p2p_bridge_amd.deterministic: fixed-order scatter gradients, no auction; round 4 trained with
+    float atomics, so every run gated a slightly different network and 1 run in 3 had a handful of points behind a flipped
+    index decision), then the trained weights go to both sides: HIP sample(graph=True) vs the oracle's sampler at 8192
+    points, B = 2. A trained bridge moves a point by about the noise level per chain, so a 1-ulp difference does not get
+    amplified to O(1) as it does with random weights (test_c2_t30_free_running_chamfer above)."""
+    _threads()
+    from p2p_bridge_amd import p2pb as product
+
+    sd, hist = _train_300_steps_deterministically()
+    digest = float(sum(v.double().abs().sum() for v in sd.values()))
     cfg = pvds_8192()
     model = product.build_model(cfg, sd, device="cuda")
     orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
@@ -491,17 +513,51 @@ def test_c2_t30_gate_on_a_briefly_trained_denoiser():
     ok_steps = int((per_entry < TOL).long().cumprod(0).sum().item())
     moved = (b - x).abs().max().item()
     cd_clean_in, cd_clean_out = chamfer_l2(x, clean).mean().item(), chamfer_l2(b, clean).mean().item()
-    self_ref = net_ref.sample(orc, cfg, _perturb_one_ulp(x), steps=30, log_count=1)["x_pred"]
-    d_self = (self_ref - b).abs().amax(dim=1)
-    print(f"\nC2 T=30 on a 300-step-trained PVDS (loss {hist[0]:.3f} -> {hist[-1]:.3f}; the chain moves the cloud by {moved:.3f}; "
-          f"Chamfer-L2 to the clean cloud {cd_clean_in:.2e} -> {cd_clean_out:.2e}):\n"
-          f"  hip vs oracle          : Chamfer-L2 = {cd.max().item():.3e}, max|dxyz| = {d.max().item():.3e}, points >= 1e-4: "
-          f"{(d >= TOL).sum().item()} of {d.numel()}, steps within 1e-4: {ok_steps} of 30\n"
-          f"  oracle vs oracle(1 ulp): max|dxyz| = {d_self.max().item():.3e}, points >= 1e-4: {(d_self >= TOL).sum().item()}")
+    print(f"\nC2 T=30 on a 300-step-trained PVDS (deterministic training, sum|w| = {digest!r}; loss {hist[0]:.3f} -> {hist[-1]:.3f}; the "
+          f"chain moves the cloud by {moved:.3f}; Chamfer-L2 to the clean cloud {cd_clean_in:.2e} -> {cd_clean_out:.2e}):\n"
+          f"  hip vs oracle: Chamfer-L2 = {cd.max().item():.3e}, max|dxyz| = {d.max().item():.3e}, points >= 1e-4: "
+          f"{(d >= TOL).sum().item()} of {d.numel()}, steps within 1e-4: {ok_steps} of 30")
     assert cd.max().item() <= TOL
-    # xyz: the gate itself is the Chamfer-L2 above. Point by point every coordinate is within 1e-4 in most runs (the network is
-    # trained inside the test with atomics in its backward pass, so every run gates a slightly different network); when one
-    # of the ~10^6 index decisions of the chain sits on a boundary, a handful of points move with it -- in the oracle's own
-    # 1-ulp probe as well -- so: no more than 16 points (0.1 %), or twice what the oracle's probe moves
-    assert (d >= TOL).sum().item() <= max(16, 2 * (d_self >= TOL).sum().item())
-    assert ok_steps == 30 or d.max().item() >= TOL
+    assert d.max().item() < TOL, (d >= TOL).sum().item()  # ALL 16384 points within 1e-4 (the literal clause)
+    assert ok_steps == 30
+
+
+def test_pvdl_bench_leg_dispatch_vs_oracle():
+    """BASELINE config 4 at the dispatch bench.py's `pvdl` leg runs (B = 8): by csrc/pointwise.hip's rule (>= 1024 workgroups of
+    128 positions x 256 channels) the 256 -> 512 and 512 -> 1024 layers of the global embedding at P = 50000 and the 128 -> 512
+    skip GEMM of the 12500-point feature-propagation stage (a RAGGED last tile: 12500 = 97 x 128 + 84) take the ping-pong kernel
+    from B = 6 up, and pw_split_kernel at the B = 1 of test_c4_full_width_pvdl_50000. Here B = 6 (the smallest batch with the
+    leg's dispatch, asserted): one evaluation vs the oracle, then 2 steps of the conditional hipGraph sampler, every captured
+    step against the oracle's step from the same state (teacher-forced)."""
+    _threads()
+    B, N = 6, 50000
+    cfg = pvdl(3, N)
+    model, sd = seeded_model(cfg)
+    orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
+    xyz, _ = net_ref.synthetic_patches(B, N, seed=14)
+    g = torch.Generator().manual_seed(15)
+    rgb = torch.rand(B, 3, N, generator=g)
+    t = torch.tensor([990.0, 777.0, 420.0, 200.0, 50.0, 1.5])
+    _pw_forms_reset()
+    model.eval()
+    with torch.no_grad():
+        out = model.model(torch.cat([xyz, rgb], dim=1).cuda(), t.cuda()).cpu()
+        ref = orc(torch.cat([xyz, rgb], dim=1), t)
+    model.train()
+    from p2p_bridge_amd import fused
+
+    want = (PW_PINGPONG,) if fused.conv_math() == "f16x3" else (3, 4)
+    for cin, cout, npos in ((256, 512, N), (512, 1024, N), (128, 512, 12500)):
+        assert _pw_form(cin, cout, npos)[0] in want, (cin, cout, npos, _pw_form(cin, cout, npos))
+    err = (out - ref).abs().max().item()
+    print(f"\nPVDL extra=3, B={B}, N={N} (the pvdl leg's dispatch): one evaluation max|hip - oracle| = {err:.3e}")
+    assert err < TOL
+    _pw_forms_reset()
+    model.clear_graphs()
+    chain = model.sample(x_start=xyz.cuda(), x_cond=rgb.cuda(), steps=2, log_count=2, verbose=False, graph=True)["x_chain"].cpu()
+    for cin, cout, npos in ((256, 512, N), (512, 1024, N), (128, 512, 12500)):
+        assert _pw_form(cin, cout, npos)[0] in want, (cin, cout, npos, _pw_form(cin, cout, npos))
+    errs = _teacher_forced_errors(orc, cfg, xyz, chain, 2, x_cond=rgb)
+    model.clear_graphs()
+    print(f"PVDL sample(x_cond, graph=True), B={B}, 2 steps: max|hip - oracle| per step (teacher-forced) = {[f'{e:.2e}' for e in errs]}")
+    assert max(errs) < TOL

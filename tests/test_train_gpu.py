@@ -178,3 +178,47 @@ def test_punet_paired_patches_on_device(tmp_path):
              "noisy_points": torch.stack([it["noisy_points"] for it in items])}
     out = T.get_data_batch(batch, T.PVDS_PUNET_TRAIN, T.make_align_fn())
     assert out["x_gt"].shape == (4, 3, 1024) and out["x_start"].shape == (4, 3, 1024)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_deterministic_mode_makes_training_bit_reproducible(graph):
+    """`with p2p_bridge_amd.deterministic():` -- two training runs of stock PVDS (8 x 2048 points, 6 optimiser steps, eager and
+    as the captured step) from the same seed end in BITWISE equal weights: the scatter-add backward passes (devoxelise, grouping,
+    three-NN interpolation) accumulate in a fixed order (include/p2pb_hip.h p2pb_set_deterministic); everything else on the
+    training path already reduces in a fixed order. The reference has no such mode (its backward kernels are float atomicAdd
+    scatters); tests/test_full_size_parity_gpu.py trains its gated denoiser under it."""
+    import p2p_bridge_amd
+    from p2p_bridge_amd import _lib
+    from p2p_bridge_amd import p2pb as product
+    from p2p_bridge_amd import train as T
+    from p2p_bridge_amd.pvcnn_unet import PVCNN2Unet
+    from p2p_bridge_amd.synthetic import synthetic_patches
+
+    def batches(device):
+        k = 0
+        while True:
+            noisy, clean = synthetic_patches(8, 2048, seed=31 + k)
+            yield {"clean_points": clean.transpose(1, 2).contiguous().to(device),
+                   "noisy_points": noisy.transpose(1, 2).contiguous().to(device)}
+            k += 1
+
+    def run():
+        cfg = copy.deepcopy(T.PVDS_PUNET_TRAIN)
+        cfg["model"]["ema"] = False
+        cfg["training"].update(bs=8, log_interval=50, amp=False)
+        cfg["gpu"] = "cuda"
+        torch.manual_seed(3)
+        m = product.P2PB(cfg, PVCNN2Unet(cfg))
+        hist = T.train(cfg, m, batches(m.device), 6, align=False, graph=graph)
+        torch.cuda.synchronize()
+        return hist, {k: v.detach().clone() for k, v in m.model.state_dict().items()}
+
+    assert _lib.lib().p2pb_get_deterministic() == 0
+    with p2p_bridge_amd.deterministic():
+        assert _lib.lib().p2pb_get_deterministic() == 1
+        h1, w1 = run()
+        h2, w2 = run()
+    assert _lib.lib().p2pb_get_deterministic() == 0 and not torch.are_deterministic_algorithms_enabled()
+    assert h1 == h2, (h1, h2)
+    diff = [k for k in w1 if not torch.equal(w1[k], w2[k])]
+    assert not diff, (len(diff), diff[:5])
