@@ -1122,23 +1122,29 @@ static __global__ __launch_bounds__(256) void class_bias_kernel(int cout, const 
   k_out[((size_t)b * 27 + cls) * cout + co] = acc + bias[co];
 }
 
-// The three steps above in ONE launch (round 4: 15 -> 5 launches per network evaluation): workgroup (64 output channels, sample):
-// every thread evaluates a[ci] into LDS (the first channel block also stores it), thread (c, tg) of the 64 x 16 sums taps tg, tg + 16
-// for channel c over the input channels (weights coalesced over c), then the 27 class sums from the LDS table. Same operations in
-// the same order per output as far_value / tap_sum / class_bias: bit-identical.
+// The three steps above in ONE launch (round 4: 15 -> 5 launches per network evaluation): workgroup (FF_CO output channels, sample):
+// every thread evaluates a[ci] into LDS (the first channel block also stores it), thread (c, tap) sums ITS tap for channel c over the
+// input channels, then the 27 class sums from the LDS table. Same operations in the same order per output as far_value / tap_sum /
+// class_bias: bit-identical.
+// Round 5 (profiles/r05_overlap.txt: 52-79 us per launch on 32-64 workgroups, 290 us of every chain-evaluation): 32 channels x 27
+// taps per workgroup instead of 64 channels x 16 tap groups of two (twice the workgroups, half the serial length per thread), and
+// the weights as the 16-byte groups the pack holds -- [tap][ci / 8][ci & 1][co][(ci & 7) >> 1]: one float4 = input channels
+// h, h + 2, h + 4, h + 6 of a chunk -- so a chunk of 8 input channels is two coalesced 16-byte loads (512 contiguous bytes per 32
+// lanes) instead of eight 4-byte loads at a 16-byte stride; the fused multiply-adds stay in ascending input-channel order.
 // part != NULL: the GroupNorm(+AdaGN) between the two convolutions is folded HERE as well -- `scale` / `shift` are then OUTPUTS
 // (fin.scale / fin.shift, f32[b, cin], written by the first channel block for the kernels that stage the operand) and the
 // gn_affine launch between the first convolution and this kernel is gone (round 5; gn_finish_sample: the same bits).
+constexpr int FF_CO = 32;
 static __global__ __launch_bounds__(1024) void far_field_kernel(int cin, int cout, int nchunk, int cout_pad,
                                                         const float *__restrict__ base, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, int swish,
                                                         const float *__restrict__ wt, const float *__restrict__ bias,
                                                         float *__restrict__ a_out, float *__restrict__ k_out,
                                                         const float *__restrict__ part, int nslots, GnFinish fin) {
-  extern __shared__ double ff_sm_d[];  // [scale[cin] | shift[cin]] (folded form) | union { 4 x 1024 doubles, a[cin] | T[27][64] }
+  extern __shared__ double ff_sm_d[];  // [scale[cin] | shift[cin]] (folded form) | union { 4 x 1024 doubles, a[cin] | T[27][FF_CO] }
   float *ff_sm = (float *)ff_sm_d;
-  const int b = blockIdx.y, t = threadIdx.x, c = t & 63, tg = t >> 6;
-  const int co = blockIdx.x * 64 + c;
+  const int b = blockIdx.y, t = threadIdx.x, c = t & (FF_CO - 1), tap = t / FF_CO;
+  const int co = blockIdx.x * FF_CO + c;
   float *a, *T;
   if (part != nullptr) {
     float *tsc = ff_sm, *tsh = ff_sm + cin;
@@ -1146,14 +1152,14 @@ static __global__ __launch_bounds__(1024) void far_field_kernel(int cin, int cou
     GnFinish f = fin;
     if (blockIdx.x != 0) f.scale = f.shift = nullptr;  // (every channel block computes the values, one writes them)
     gn_finish_sample<4>(cin, nslots, part, f, b, gl, tsc, tsh);
-    a = (float *)gl, T = a + cin;
+    a = (float *)gl, T = a + nchunk * 8;
     for (int ch = t; ch < cin; ch += 1024) {
       const float v = xf_apply(base[ch], tsc[ch], tsh[ch], swish);
       a[ch] = v;
       if (blockIdx.x == 0) a_out[(size_t)b * cin + ch] = v;
     }
   } else {
-    a = ff_sm, T = ff_sm + cin;
+    a = ff_sm, T = ff_sm + nchunk * 8;
     for (int ch = t; ch < cin; ch += 1024) {
       const float v = xf_apply(base[ch], scale[(size_t)b * cin + ch], shift[(size_t)b * cin + ch], swish);
       a[ch] = v;
@@ -1161,26 +1167,39 @@ static __global__ __launch_bounds__(1024) void far_field_kernel(int cin, int cou
     }
   }
   __syncthreads();
-  for (int tap = tg; tap < 27; tap += 16) {
+  if (tap < 27) {
     float acc = 0.0f;
-    if (co < cout)
-      for (int ci = 0; ci < cin; ++ci) {
-        const size_t idx = ((((size_t)tap * nchunk + (ci >> 3)) * 2 + (ci & 1)) * cout_pad + co) * 4 + ((ci & 7) >> 1);
-        acc = __fmaf_rn(wt[idx], a[ci], acc);
+    if (co < cout) {
+      const float4 *w4 = (const float4 *)wt + ((size_t)tap * nchunk * 2) * cout_pad + co;
+#pragma unroll 4
+      for (int k8 = 0; k8 < nchunk; ++k8) {
+        const float4 h0 = w4[(size_t)(2 * k8) * cout_pad], h1 = w4[(size_t)(2 * k8 + 1) * cout_pad];
+        const float *av = a + k8 * 8;
+        const int left = cin - k8 * 8;  // (a ragged last chunk: the channels that exist, in order)
+        if (left > 0) acc = __fmaf_rn(h0.x, av[0], acc);
+        if (left > 1) acc = __fmaf_rn(h1.x, av[1], acc);
+        if (left > 2) acc = __fmaf_rn(h0.y, av[2], acc);
+        if (left > 3) acc = __fmaf_rn(h1.y, av[3], acc);
+        if (left > 4) acc = __fmaf_rn(h0.z, av[4], acc);
+        if (left > 5) acc = __fmaf_rn(h1.z, av[5], acc);
+        if (left > 6) acc = __fmaf_rn(h0.w, av[6], acc);
+        if (left > 7) acc = __fmaf_rn(h1.w, av[7], acc);
       }
-    T[tap * 64 + c] = acc;
+    }
+    T[tap * FF_CO + c] = acc;
   }
   __syncthreads();
-  if (co >= cout) return;
-  for (int cls = tg; cls < 27; cls += 16) {
+  if (co >= cout || tap >= 27) return;
+  {
+    const int cls = tap;
     const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
     float acc = 0.0f;
-    for (int tap = 0; tap < 27; ++tap) {
-      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    for (int tp = 0; tp < 27; ++tp) {
+      const int kd = tp / 9, kh = (tp / 3) % 3, kw = tp % 3;
       if ((cd == 0 && kd == 0) || (cd == 2 && kd == 2) || (ch == 0 && kh == 0) || (ch == 2 && kh == 2) ||
           (cw == 0 && kw == 0) || (cw == 2 && kw == 2))
         continue;
-      acc += T[tap * 64 + c];
+      acc += T[tp * FF_CO + c];
     }
     k_out[((size_t)b * 27 + cls) * cout + co] = acc + bias[co];
   }
@@ -1196,10 +1215,10 @@ static int far_field_launch(int b, int cin, int cout, const float *prev_bias, co
                             int in_swish, const float *wt_packed, const float *bias, float *a, float *k_out, float *tap_ws,
                             const float *part, int nslots, const GnFinish &fin, hipStream_t s) {
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
-  const size_t body = (size_t)(cin + 27 * 64) * 4;
+  const size_t body = (size_t)(nchunk * 8 + 27 * FF_CO) * 4;
   const size_t lds = part ? (size_t)((2 * cin + 1) / 2) * 8 + (body > 32768 ? body : 32768) : body;
   if (lds <= 48 * 1024) {  // (tap_ws unused in this form)
-    hipLaunchKernelGGL(far_field_kernel, dim3(cdiv(cout, 64), b), dim3(1024), lds, s, cin, cout, nchunk, cout_pad, prev_bias,
+    hipLaunchKernelGGL(far_field_kernel, dim3(cdiv(cout, FF_CO), b), dim3(1024), lds, s, cin, cout, nchunk, cout_pad, prev_bias,
                        in_scale, in_shift, in_swish, wt_packed, bias, a, k_out, part, nslots, fin);
     return p2pb_launch_status();
   }

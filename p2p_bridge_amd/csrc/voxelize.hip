@@ -384,8 +384,13 @@ __global__ __launch_bounds__(256) void vox_gather_cl_split_kernel(int c, int nch
 }
 
 // Occupied voxels only, after a streaming zero-fill of the split grid (the fp16 pair of 0 is all-zero bits): the form for
-// channel counts that are not a multiple of 4 (the 3 + 32 channels of the first PVConv: scalar point-row loads, and at
-// r = 32 at most a quarter of the voxels is occupied -- the one-pass kernel above took 159 us per 16 patches there)
+// channel counts that are not a multiple of 4 (the 3 + 32 channels of the first PVConv: scalar point-row loads) and, since round 5,
+// for every r = 32 grid (at most a quarter of the voxels is occupied: the one-pass kernel above wrote the 268 MB of the 64-channel
+// level-0 grid at 1.2 TB/s, 226 us per 32 patches; the zero-fill streams at ~7 TB/s). The kernel is LATENCY-bound by its fullest
+// voxel -- a thread adds its voxel's points one after the other (ascending index: the reference's mean, bit for bit), and each
+// point used to be two dependent L2 round trips (list entry -> row): 150-170 us whatever the batch. Now the list entries and rows
+// of FOUR points are in flight before the first is added; the additions keep their order.
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void vox_gather_cl_occ_split_kernel(int c, int nchunk, int n, int r3,
                                                                       const int *__restrict__ cnt, const int *__restrict__ cur,
                                                                       const int *__restrict__ occ, const int *__restrict__ nocc,
@@ -401,11 +406,33 @@ __global__ __launch_bounds__(256) void vox_gather_cl_occ_split_kernel(int c, int
     const float div = (float)(1.0 / (double)(float)cn);  // PN2/vox_gpu.cu:70 divides a double literal
     const float *f = feat_t + (size_t)b * n * c + ch;
     float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    for (int q = 0; q < cn; ++q) {
-      const float *fq = f + (size_t)seg[q] * c;
+    for (int q0 = 0; q0 < cn; q0 += 4) {
+      int id[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (ch + i < c) acc[i] += fq[i] * div;
+      for (int u = 0; u < 4; ++u) id[u] = seg[min(q0 + u, cn - 1)];
+      float x[4][8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *fq = f + (size_t)id[u] * c;
+        if (ALIGNED) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            vox_f32x4 y = vox_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (ch + 4 * h < c) y = *(const vox_f32x4 *)(fq + 4 * h);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x[u][4 * h + i] = y[i];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[u][i] = ch + i < c ? fq[i] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (q0 + u < cn) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += x[u][i] * div;
+        }
     }
     u32x4 p0, p1;
 #pragma unroll
@@ -488,15 +515,22 @@ extern "C" int p2pb_avg_voxelize_cl_gather_split(int b, int c, int n, int r, con
   const int *slist = cur + (size_t)b * r3 + (size_t)b * n;
   hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, feat, feat_t);
   static const int onepass = getenv("P2PB_VOX_ONEPASS") ? atoi(getenv("P2PB_VOX_ONEPASS")) : -1;  // (A/B switch: 0 / 1 force)
-  if (onepass == 0 || (onepass < 0 && (c & 3) != 0)) {  // zero-fill + occupied voxels only (the rule of p2pb_avg_voxelize_cl_gather)
+  // zero-fill + occupied voxels only: ragged rows (the rule of p2pb_avg_voxelize_cl_gather) and every grid with at least four
+  // voxels per point (r = 32 at 8192 points: <= 25 % occupied)
+  if (onepass == 0 || (onepass < 0 && ((c & 3) != 0 || (size_t)r3 >= 4 * (size_t)n))) {
     const int *occ = slist + (size_t)b * n;
     const int *nocc = occ + (size_t)b * n;
     const int maxocc = n < r3 ? n : r3;
     const int e = p2pb_zero_async(out_split, (size_t)b * r3 * nchunk * 64, s);
     if (e != 0) return e;
     const size_t nwg = cdiv((size_t)maxocc * nchunk * 2, 256);
-    hipLaunchKernelGGL(vox_gather_cl_occ_split_kernel, dim3((unsigned)(nwg > 65536 ? 65536 : nwg), b), dim3(256), 0, s, c,
-                       nchunk, n, r3, cnt, cur, occ, nocc, slist, feat_t, (u32x4 *)out_split);
+    const dim3 g((unsigned)(nwg > 65536 ? 65536 : nwg), b);
+    if ((c & 3) == 0)
+      hipLaunchKernelGGL(vox_gather_cl_occ_split_kernel<true>, g, dim3(256), 0, s, c, nchunk, n, r3, cnt, cur, occ, nocc, slist, feat_t,
+                         (u32x4 *)out_split);
+    else
+      hipLaunchKernelGGL(vox_gather_cl_occ_split_kernel<false>, g, dim3(256), 0, s, c, nchunk, n, r3, cnt, cur, occ, nocc, slist, feat_t,
+                         (u32x4 *)out_split);
     return p2pb_launch_status();
   }
   const dim3 grid((unsigned)cdiv((size_t)r3 * nchunk * 2, 256), b);
