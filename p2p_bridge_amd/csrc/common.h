@@ -361,6 +361,30 @@ __device__ __forceinline__ float rowreduce32(float (&v)[32]) {
   return (lane & 1) ? y : x;
 }
 
+// min / max (any associative, commutative Op) over ALIGNED GROUPS OF 8 LANES for 32 rows at once: the last three levels of the
+// network above started from 32 values -- lanes L, 7 - L (row_half_mirror), L ^ 2, L ^ 1 -- leave rows i + 4 j (i = 0..3,
+// j = lane & 7) of the lane's group in v[0..3]: 84 instructions instead of 6 per row and statistic (a set-abstraction
+// neighbourhood of 32 positions at four positions per lane).
+template <class Op>
+__device__ __forceinline__ void groupreduce8(float (&v)[32]) {
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float x = Op::f(v[i], dpp_full<0x141>(v[i])), y = Op::f(v[i + 16], dpp_full<0x141>(v[i + 16]));
+    v[i] = (lane & 4) ? y : x;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = Op::f(v[i], dpp_full<0x4E>(v[i])), y = Op::f(v[i + 8], dpp_full<0x4E>(v[i + 8]));
+    v[i] = (lane & 2) ? y : x;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x = Op::f(v[i], dpp_full<0xB1>(v[i])), y = Op::f(v[i + 4], dpp_full<0xB1>(v[i + 4]));
+    v[i] = (lane & 1) ? y : x;
+  }
+}
+
 // ---- which kernel form a pointwise launch took (debug / test hook: include/p2pb_hip.h p2pb_debug_pointwise_form) ----
 enum {
   P2PB_FORM_PW_FP32 = 0,      // pw_conv_kernel: exact-fp32 MFMA, unaligned rows

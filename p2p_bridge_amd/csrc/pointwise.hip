@@ -225,7 +225,8 @@ struct PwGather {
   const int *idx;    // i32[b, P]
   int gn, gu;        // points per cloud, neighbours per centre
 };
-template <int MT, bool XF, bool STATS, bool POOL, int TERMS = 0, bool GATHER = false>
+// PG (pooling form, compile time): 0 none, 32 global-pool partials, 8 neighbourhoods of 8 lanes, 1 any other width (pool_g)
+template <int MT, bool XF, bool STATS, int PG, int TERMS = 0, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int cout_pad, int P, int nslots,
                                                       const float *__restrict__ in, const float *__restrict__ wp,
                                                       const float *__restrict__ bias,
@@ -466,66 +467,137 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
       }
     return;
   }
-  float *outb = out + (size_t)b * cout * P;
-  // statistics slots keep the 64-position granularity of the narrow kernel: this wave fills slot `slot`
-  // with its 128-position sums and zeroes slot + 1
-  const int slot = (blockIdx.x * 4 + wave) * 2;
+  // ---- epilogue (round 5). The first form reduced every one of the 32 MT rows on its own -- five DPP steps per statistic, a
+  // runtime-width min / max ladder, and a predicated store with its own 64-bit address for every row: ~9000 of the POOL kernel's
+  // 11900 instructions ran ONCE per wave, and with two 16-channel steps per wave (the 32 -> 64 set-abstraction layer) the launch
+  // was bound by issuing them (271 us for 8.6 GFLOP; profiles/r05_overlap.txt). Now: bias in place + stores, then the rows'
+  // reductions as reduce-scatter networks (common.h rowreduce32: lane l31 ends with the total of row l31; groupreduce8 below:
+  // neighbourhoods of 8 lanes) and ONE store per lane. Sums: the lane's four positions (v0 + v1) + (v2 + v3) as before, then the
+  // network's fixed tree instead of the 5-step ladder (the partials change in their last bit, deterministically).
+  float *outb = out ? out + (size_t)b * cout * P : nullptr;
+  const int slot = (blockIdx.x * 4 + wave) * 2;  // this wave fills slot `slot` with its 128-position sums and zeroes slot + 1
+  constexpr int NR = 16 * MT;                    // rows (output channels) per half-wave
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
+  for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
       const float bv = pww_bias[co - co0];
-      const f32x4 v = {acc[m][0][r] + bv, acc[m][1][r] + bv, acc[m][2][r] + bv, acc[m][3][r] + bv};
-      float s1 = 0.0f, s2 = 0.0f;
-      if (co < cout && pok) {
-        if (!POOL || out) *(f32x4 *)(outb + (size_t)co * P + p) = v;
-        if (STATS) {
-          s1 = (v[0] + v[1]) + (v[2] + v[3]);
-          s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[m][t][r] += bv;
+      if (co < cout && pok && outb)
+        *(f32x4 *)(outb + (size_t)co * P + p) = f32x4{acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+    }
+  // the row whose total this lane holds after rowreduce32 (MT == 1: rows 0..15 twice, two statistics packed into one network)
+  const int rrow = MT == 2 ? l31 : (l31 & 15);
+  const int rco = co0 + (rrow >> 4) * 32 + (rrow & 3) + 8 * ((rrow & 15) >> 2) + 4 * khalf;
+  auto rowval = [&](int kind, int m, int r) -> float {  // 0: sum, 1: sum of squares, 2: min, 3: -max over the lane's 4 positions
+    const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    const float v0 = acc[m][0][r], v1 = acc[m][1][r], v2 = acc[m][2][r], v3 = acc[m][3][r];
+    const bool ok = co < cout && pok;
+    if (kind == 0) return ok ? (v0 + v1) + (v2 + v3) : 0.0f;
+    if (kind == 1) return ok ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.0f;
+    if (kind == 2) return pok ? vmin_raw(vmin_raw(v0, v1), vmin_raw(v2, v3)) : INFINITY;
+    return pok ? -vmax_raw(vmax_raw(v0, v1), vmax_raw(v2, v3)) : INFINITY;
+  };
+  if (STATS) {
+    float s1, s2;
+    float tv[32];
+    if constexpr (MT == 2) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) tv[i] = rowval(0, i >> 4, i & 15);
+      s1 = rowreduce32<RowAdd>(tv);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) tv[i] = rowval(1, i >> 4, i & 15);
+      s2 = rowreduce32<RowAdd>(tv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) tv[i] = rowval(i >> 4, 0, i & 15);
+      s1 = s2 = rowreduce32<RowAdd>(tv);  // lanes 0..15: sums, lanes 16..31: sums of squares, of rows l31 & 15
+    }
+    if (rco < cout) {
+      if (slot < nslots) {
+        float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
+        if constexpr (MT == 2) *(f32x2 *)q = f32x2{s1, s2};
+        else q[l31 >> 4] = s1;
+      }
+      if (slot + 1 < nslots) {
+        float *q = stats_part + (((size_t)b * nslots + slot + 1) * cout + rco) * 2;
+        if constexpr (MT == 2) *(f32x2 *)q = f32x2{0.0f, 0.0f};
+        else q[l31 >> 4] = 0.0f;
+      }
+    }
+  }
+  if constexpr (PG != 0) {
+    float tv[32];
+    if constexpr (PG == 32) {  // global max-pool partials: {min, max} over the wave's 128 positions
+      float mn, mx;
+      if constexpr (MT == 2) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) tv[i] = rowval(2, i >> 4, i & 15);
+        mn = rowreduce32<RowMin>(tv);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) tv[i] = rowval(3, i >> 4, i & 15);
+        mx = -rowreduce32<RowMin>(tv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) tv[i] = rowval(2 + (i >> 4), 0, i & 15);
+        mn = rowreduce32<RowMin>(tv);  // lanes 0..15: min, lanes 16..31: -max, of rows l31 & 15
+        mx = -mn;
+      }
+      if (rco < cout) {
+        float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * cout + rco) * 2;
+        if constexpr (MT == 2) *(f32x2 *)q = f32x2{mn, mx};
+        else q[l31 >> 4] = (l31 >> 4) ? mx : mn;
+      }
+    } else if constexpr (PG == 8) {  // neighbourhoods of 32 positions = aligned groups of 8 lanes (the bench's set abstractions)
+      // groupreduce8 leaves rows i + 4 j (i = 0..3, j = lane & 7) of the lane's group in v[i]
+      const int j = l31 & 7;
+      const size_t ngrp = (size_t)(P / 32);
+      if constexpr (MT == 2) {
+        float tx[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          tv[i] = rowval(2, i >> 4, i & 15);
+          tx[i] = rowval(3, i >> 4, i & 15);
+        }
+        groupreduce8<RowMin>(tv);
+        groupreduce8<RowMin>(tx);
+        const int cb = co0 + 32 * (j >> 2) + 8 * (j & 3) + 4 * khalf;  // rows i + 4 j: channels cb + i
+        if (pok) {
+          float *q = mm_out + (((size_t)b * cout + cb) * ngrp + p / 32) * 2;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (cb + i < cout) *(f32x2 *)(q + (size_t)i * ngrp * 2) = f32x2{tv[i], -tx[i]};
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) tv[i] = rowval(2 + (i >> 4), 0, i & 15);
+        groupreduce8<RowMin>(tv);  // j < 4: min of rows i + 4 j, j >= 4: -max of rows i + 4 (j - 4)
+        const int cb = co0 + 8 * (j & 3) + 4 * khalf;
+        if (pok) {
+          float *q = mm_out + (((size_t)b * cout + cb) * ngrp + p / 32) * 2 + (j >> 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (cb + i < cout) q[(size_t)i * ngrp * 2] = (j >> 2) ? -tv[i] : tv[i];
         }
       }
-      if (POOL) {
-        float mn = pok ? fminf(fminf(v[0], v[1]), fminf(v[2], v[3])) : INFINITY;
-        float mx = pok ? fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) : -INFINITY;
-        group_minmax(mn, mx, pool_g);
-        if (co < cout) {
-          if (pool_g == 32) {
-            if (l31 == 31) {
-              float *q = mm_out + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + wave) * cout + co) * 2;
-              q[0] = mn;
-              q[1] = mx;
-            }
-          } else if ((l31 & (pool_g - 1)) == 0 && pok) {
+    } else {  // other neighbourhood sizes: the per-row ladder
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+          float mn = rowval(2, m, r), mx = -rowval(3, m, r);
+          group_minmax(mn, mx, pool_g);
+          if (co < cout && (l31 & (pool_g - 1)) == 0 && pok) {
             const int u = 4 * pool_g;
             float *q = mm_out + (((size_t)b * cout + co) * (P / u) + p / u) * 2;
             q[0] = mn;
             q[1] = mx;
           }
         }
-      }
-      if (STATS) {
-        s1 = halfwave_sum_to_last(s1);
-        s2 = halfwave_sum_to_last(s2);
-        if (l31 == 31 && co < cout) {
-          const bool coherent = fin.scale != nullptr;  // (read by the finisher of another workgroup: common.h GnFinish)
-          if (slot < nslots) {
-            float *q = stats_part + (((size_t)b * nslots + slot) * cout + co) * 2;
-            gnf_store(q, s1, coherent);
-            gnf_store(q + 1, s2, coherent);
-          }
-          if (slot + 1 < nslots) {
-            float *q = stats_part + (((size_t)b * nslots + slot + 1) * cout + co) * 2;
-            gnf_store(q, 0.0f, coherent);
-            gnf_store(q + 1, 0.0f, coherent);
-          }
-        }
-      }
     }
-  }
-  if (STATS && fin.scale) {  // the GroupNorm that follows, finished by the workgroup that completes a (sample, group)
-    __shared__ double pww_fin[4 * 256 + 1];
-    gn_finish_arrive(cout, nslots, stats_part, fin, b, co0, 32 * MT, pww_fin);
   }
 }
 
@@ -1142,14 +1214,22 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
     else LAUNCHX(XF, ST, PL, 0);                            \
   } while (0)
     p2pb_note_pointwise_form(cin, cout, P, split_pack ? P2PB_FORM_PW_WIDE_F16 : P2PB_FORM_PW_WIDE_FP32);
-    const GnFinish fin = pw_take_finisher(b, cout, 32 * MT, (int)grid.x, st && !out_pm, s, 2);
+    const GnFinish fin = GnFinish();  // (the norm that follows: the launch behind this one, pw_finish_behind)
     if (minmax) {
-      if (xf) LAUNCH(true, true, true);
-      else LAUNCH(false, true, true);
-    } else if (xf && st) LAUNCH(true, true, false);
-    else if (xf) LAUNCH(true, false, false);
-    else if (st) LAUNCH(false, true, false);
-    else LAUNCH(false, false, false);
+      const int pg = pool_g == 8 || pool_g == 32 ? pool_g : 1;
+      if (xf) {
+        if (pg == 8) LAUNCH(true, true, 8);
+        else if (pg == 32) LAUNCH(true, true, 32);
+        else LAUNCH(true, true, 1);
+      } else {
+        if (pg == 8) LAUNCH(false, true, 8);
+        else if (pg == 32) LAUNCH(false, true, 32);
+        else LAUNCH(false, true, 1);
+      }
+    } else if (xf && st) LAUNCH(true, true, 0);
+    else if (xf) LAUNCH(true, false, 0);
+    else if (st) LAUNCH(false, true, 0);
+    else LAUNCH(false, false, 0);
 #undef LAUNCH
 #undef LAUNCHX
     return p2pb_launch_status();
@@ -1276,14 +1356,19 @@ static int pw_conv_pool_gather_impl(int b, int cin, int cout, int n, int m, int 
   const int P = (int)npos, nslots = (P + 255) / 256 * 4, gl = pool_lanes(u);
   const PwGather gat = {cxt, idx, n, u};
   const float *wsp = (const float *)wp_split;
-#define LAUNCHG(MTV)                                                                                                      \
-  hipLaunchKernelGGL((pw_wide_kernel<MTV, true, true, true, SPLIT_F16X3, true>),                                   \
+#define LAUNCHG(MTV, PGV)                                                                                                 \
+  hipLaunchKernelGGL((pw_wide_kernel<MTV, true, true, PGV, SPLIT_F16X3, true>),                                    \
                      dim3((P + 511) / 512, (cout + 32 * MTV - 1) / (32 * MTV), b), dim3(256), 0, s, cin, cout,             \
                      pw_cout_pad(cout), P, nslots, zt, wsp, bias, (const float *)nullptr, in_scale, in_shift, in_swish,    \
                      (float *)nullptr, stats_part, minmax, gl, 0, gat, fin)
-  const GnFinish fin = pw_take_finisher(b, cout, cout > 32 ? 64 : 32, (P + 511) / 512, true, s, 2);
-  if (cout > 32) LAUNCHG(2);
-  else LAUNCHG(1);
+  const GnFinish fin = GnFinish();
+  if (gl == 8) {
+    if (cout > 32) LAUNCHG(2, 8);
+    else LAUNCHG(1, 8);
+  } else {
+    if (cout > 32) LAUNCHG(2, 1);
+    else LAUNCHG(1, 1);
+  }
 #undef LAUNCHG
   p2pb_note_pointwise_form(cin, cout, P, P2PB_FORM_PW_GATHER);
   return p2pb_launch_status();
