@@ -279,12 +279,14 @@ int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const float *in, 
  * (halo 1) and second (halo 2) convolution of a PVConv: lists i32[4][b*NBRICK] = {active0, inactive0,
  * active1, inactive1}, counts i32[4]; flags_ws = b*NBRICK*2 bytes scratch; NBRICK = 128 (r=32) / 16 (r=16).
  * p2pb_conv3d_k3_forward_sparse runs the MFMA kernel on the active pairs only and writes the (exactly
- * known) constants + statistics of the inactive bricks. */
+ * known) constants + statistics of the inactive bricks. flags bit 5 (32): the inactive bricks' STATISTICS only -- their
+ * outputs are left unwritten, for a caller that reads `out` inside the active bricks alone (a PVConv's second
+ * convolution: the devoxelisation's corners lie within one voxel of an occupied voxel). */
 int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned char *flags_ws, int *lists, int *counts,
                             void *stream);
 int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                   const float *bias, const float *out_class, const float *in_scale,
-                                  const float *in_shift, int in_swish, const float *in_sub, int flags /* bits 2, 3 */,
+                                  const float *in_shift, int in_swish, const float *in_sub, int flags /* bits 2, 3, 4, 5 */,
                                   const int *active_list, const int *active_count, const int *inactive_list,
                                   const int *inactive_count, float *out, float *stats_part, void *stream);
 /* Compact form (voxel-level sparsity inside the bricks; conv3d.hip). p2pb_conv3d_active_lists derives, from the voxel

@@ -1464,7 +1464,8 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
   atomicAdd(&ncls[cls], 1);
   __syncthreads();
   const float *kb = out_class ? out_class + (size_t)b * 27 * cout : nullptr;
-  if (CL) {  // voxel-major: the brick's voxels x channels, channels fastest (coalesced)
+  if (!out) {  // statistics only (p2pb_conv3d_k3_forward_sparse flags bit 5: nobody reads the inactive bricks' outputs)
+  } else if (CL) {  // voxel-major: the brick's voxels x channels, channels fastest (coalesced)
     __shared__ unsigned char vcls[256];
     vcls[t] = (unsigned char)cls;
     __syncthreads();
@@ -1595,6 +1596,7 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
                                              const int *inactive_list, const int *inactive_count, float *out,
                                              float *stats_part, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || (r != 16 && r != 32) || !active_list || !inactive_list) return P2PB_EINVAL;
+  if ((flags & 32) && !stats_part) return P2PB_EINVAL;  // (bit 5: the inactive bricks' statistics only -- there must be statistics)
   hipStream_t s = (hipStream_t)stream;
   const int total = conv_bricks(r) * b;
   const bool cl = (flags & 8) != 0;
@@ -1602,7 +1604,7 @@ extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, co
   if (pre && (flags & 12) != 12) return P2PB_EINVAL;
 #define FILL(RR, CL)                                                                                          \
   hipLaunchKernelGGL((conv3d_fill_kernel<RR, CL>), dim3(total), dim3(256), 0, s, cout, bias, out_class, inactive_list, \
-                     inactive_count, out, stats_part)
+                     inactive_count, (flags & 32) ? (float *)nullptr : out, stats_part)
   if (r == 32) {
     if (cl) FILL(32, true);
     else FILL(32, false);

@@ -1538,16 +1538,27 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(int B, int cin, int co
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const float *wp_ = w + (size_t)wrow * ws + 4 * h;
     const float *xq = lr_x + min(l31, nb - 1) * xp + 4 * h;
-#pragma unroll 4
-    for (int k8 = wave; k8 < nk8; k8 += 4) {
-      const int k = k8 * 8;
-      f32x4 wv = {0.0f, 0.0f, 0.0f, 0.0f}, xv = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (k + 4 * h < cin) {  // (cin % 4 == 0: a quad is inside or outside)
-        wv = *(const f32x4 *)(wp_ + k);
-        xv = *(const f32x4 *)(xq + k);
+    // weights: EIGHT 16-byte loads per lane in flight (round 5: with four the 54 MB of style weights streamed at 0.7-0.9 TB/s --
+    // 8 waves x 4 KB per CU in flight against an HBM latency of microseconds; the multiply is 16 us of matrix time at most)
+    const int nit = (nk8 - wave + 3) / 4;
+    for (int it0 = 0; it0 < nit; it0 += 8) {
+      f32x4 wv[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = (wave + 4 * (it0 + u)) * 8;
+        wv[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (it0 + u < nit && k + 4 * h < cin) wv[u] = *(const f32x4 *)(wp_ + k);  // (cin % 4 == 0: a quad is inside or outside)
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i], xv[i], acc, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) {
+        const int k = (wave + 4 * (it0 + u)) * 8;
+        xv[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (it0 + u < nit && k + 4 * h < cin) xv[u] = *(const f32x4 *)(xq + k);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[u][i], xv[u][i], acc, 0, 0, 0);
     }
     __syncthreads();  // everyone is done with x
     float *red = lr_x;  // [4 waves][32 rows][17]

@@ -195,9 +195,11 @@ def brick_lists(cnt, r):
 
 
 def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                     out_class=None, math=None, channels_last=False, pre=False):
+                     out_class=None, math=None, channels_last=False, pre=False, active_only=False):
     """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second;
-    pre: x is the pre-split operand grid (conv3d_presplit / voxelize_cl_gather(split=True))"""
+    pre: x is the pre-split operand grid (conv3d_presplit / voxelize_cl_gather(split=True));
+    active_only: the outputs of the inactive bricks are left UNWRITTEN (their statistics are still exact) -- for a caller
+    that reads y inside the active bricks only, e.g. the devoxelisation behind a PVConv's second convolution"""
     check(x, F32, "x")
     b, ci, r = (x.shape[0], x.shape[4], x.shape[1]) if channels_last else (x.shape[0], x.shape[1], x.shape[2])
     co = conv.out_channels
@@ -211,7 +213,7 @@ def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None
     st = torch.empty(b, nfl // (b * co * 2), co, 2, dtype=F32, device=x.device)
     act, ina = lists[2 * which], lists[2 * which + 1]
     ca, ci_ = counts[2 * which:], counts[2 * which + 1:]
-    flags = (4 if split else 0) | (8 if channels_last else 0) | (16 if pre else 0)
+    flags = (4 if split else 0) | (8 if channels_last else 0) | (16 if pre else 0) | (32 if active_only else 0)
     call("p2pb_conv3d_k3_forward_sparse", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
          ptr(out_class), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), _i(flags), ptr(act), ptr(ca),
          ptr(ina), ptr(ci_), ptr(y), ptr(st), stream_ptr())
