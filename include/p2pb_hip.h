@@ -68,16 +68,14 @@ int p2pb_debug_pointwise_form(int cin, int cout, int npos, unsigned long long *l
  * entry point (p2pb_pointwise_conv_forward / _conv_pool_forward / _conv_pool_gather with stats_part != NULL) from the same
  * thread. scale / shift / chmean (f32[b, cout]; chmean may be NULL) are then filled in stream order exactly as
  * p2pb_gn_affine_params(b, cout, groups, nslots, count_per_channel, stats_part, gamma, beta, style, style_stride, eps, ...)
- * called right after that launch would fill them (same bits): by the producing kernel's last workgroup per (sample, group)
- * where the kernel form supports it, by a gn_affine launch behind the producer otherwise. Replaces the reference's separate
+ * called right after that launch would fill them (same bits): the entry point puts the gn_affine launch behind the producer
+ * (the forms that ran it in the producing kernel's last workgroup measured slower and left in round 5). Replaces the reference's separate
  * nn.GroupNorm / AdaGN pass after each 1x1 convolution (models/pvcnn.py:162-205, models/modules.py:341-358).
  * Arming twice without a consuming launch in between is an error (P2PB_EINVAL); p2pb_gn_finisher_armed(): 1 while one waits. */
 int p2pb_gn_finisher_arm(int groups, double count_per_channel, const float *gamma, const float *beta, const float *style,
                          int style_stride, float eps, float *scale, float *shift, float *chmean);
 int p2pb_gn_finisher_armed(void);
 void p2pb_gn_finisher_disarm(void); /* drop an armed finisher whose producing launch did not happen (error paths) */
-/* test hook: armed finishers that ran inside their producing kernel / as a launch behind it, since the library was loaded */
-void p2pb_debug_gn_finisher(unsigned long long *fused, unsigned long long *behind);
 
 /* Voxelization.forward normalisation (models/pvcnn.py:215-228): centre on the mean, divide by
  * 2*max-norm (+eps), +0.5, *r, clamp [0,r-1]; also the half-to-even rounded int voxel coords.

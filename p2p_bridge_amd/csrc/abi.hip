@@ -103,26 +103,18 @@ int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s) {
 }
 
 // ---- the GroupNorm finisher handed to the NEXT statistics-producing launch of this thread (common.h GnFinish) ----
-// p2pb_gn_finisher_arm stores the descriptor; the producer's launcher takes it (p2pb_gn_finisher_take), and either passes it
-// to a kernel that runs the finisher in its last workgroup per (sample, group), or launches gn_affine_kernel right behind the
-// producer -- the same values in the same arrays, in stream order, either way.
+// p2pb_gn_finisher_arm stores the descriptor; the producer's launcher takes it (p2pb_gn_finisher_take) and launches
+// gn_affine_kernel right behind the producer, in stream order (pointwise.hip pw_finish_behind).
 namespace {
 thread_local bool tl_fin_armed = false;
 thread_local GnFinish tl_fin;
-// ticket counters: zero-initialised device words, every counter is left at zero by the kernel that used it. Launches that are
-// being CAPTURED get counters nobody else will ever be handed (a graph is replayed beside whatever runs later); others cycle
-// through a ring (stream order, or at worst 16 K launches of distance, separates two users of a counter).
-unsigned *g_tickets = nullptr;
-constexpr size_t TK_TOTAL = 1u << 20, TK_RING = 1u << 18;  // words: 4 MB in all, 1 MB of it the ring
-std::atomic<size_t> g_tk_ring{0}, g_tk_perm{TK_RING};
-std::mutex g_tk_mu;
 }  // namespace
 extern "C" int p2pb_gn_finisher_arm(int groups, double count_per_channel, const float *gamma, const float *beta, const float *style,
                                     int style_stride, float eps, float *scale, float *shift, float *chmean) {
   if (groups <= 0 || !scale || !shift || !(count_per_channel > 0.0) || tl_fin_armed) return P2PB_EINVAL;
   tl_fin.gamma = gamma, tl_fin.beta = beta, tl_fin.style = style, tl_fin.scale = scale, tl_fin.shift = shift, tl_fin.chmean = chmean;
-  tl_fin.tickets = nullptr, tl_fin.count_per_channel = count_per_channel, tl_fin.style_stride = style_stride;
-  tl_fin.groups = groups, tl_fin.expected = 0, tl_fin.eps = eps;
+  tl_fin.count_per_channel = count_per_channel, tl_fin.style_stride = style_stride;
+  tl_fin.groups = groups, tl_fin.eps = eps;
   tl_fin_armed = true;
   return 0;
 }
@@ -133,26 +125,4 @@ bool p2pb_gn_finisher_take(GnFinish *out) {
   *out = tl_fin;
   tl_fin_armed = false;
   return true;
-}
-// n zero counters for a launch on stream s, or nullptr (then the caller launches the finisher separately)
-unsigned *p2pb_gn_tickets(size_t n, hipStream_t s) {
-  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
-  if (!g_tickets) {
-    if (capturing) return nullptr;  // (no allocation inside a capture; every sampler warms up eagerly first)
-    std::lock_guard<std::mutex> lk(g_tk_mu);
-    if (!g_tickets) {
-      unsigned *p = nullptr;
-      if (hipMalloc(&p, TK_TOTAL * sizeof(unsigned)) != hipSuccess) return nullptr;
-      if (hipMemset(p, 0, TK_TOTAL * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-      g_tickets = p;
-    }
-  }
-  if (n == 0 || n > 4096) return nullptr;
-  if (capturing) {
-    const size_t at = g_tk_perm.fetch_add(n);
-    return at + n <= TK_TOTAL ? g_tickets + at : nullptr;
-  }
-  const size_t at = g_tk_ring.fetch_add(n) % (TK_RING - 4096);
-  return g_tickets + at;
 }

@@ -138,35 +138,25 @@ static inline unsigned absmax_blocks(size_t n) {
 
 // ---- GroupNorm(+AdaGN) finisher: the {sum, sum of squares} partials of a producing kernel -> per-(sample, channel) scale / shift ----
 // (the arithmetic of gn_affine_kernel, conv3d.hip, which calls this too: one workgroup, >= 256 threads of it, per (sample, group);
-//  fixed summation order, double accumulation: the same bits whichever kernel runs it.) A producing kernel given a GnFinish runs
-// it itself when P2PB_GN_FINISH asks for it (pointwise.hip: measured SLOWER than the launch behind the producer, which is the
-// default): the workgroup that completes a (sample, group) -- a ticket counted after every contributor's device-scope partial
-// stores have reached memory -- computes the group's affine.
+//  fixed summation order, double accumulation: the same bits whichever kernel runs it.) Callers: gn_affine_kernel -- also the launch
+// that pointwise.hip puts behind a producer whose caller armed a finisher (p2pb_gn_finisher_arm) -- and the small kernels that fold
+// the norm into their own prologue (far_field_kernel, pvconv_tail_kernel, minmax_act_pool_kernel). Round 4's forms that ran it in
+// the LAST workgroup of the producing GEMM (tickets, device-scope partials) measured slower than the launch they replaced
+// (248.5 -> 255-260 ms per sample call) and left the library in round 5.
 struct GnFinish {
   const float *gamma, *beta, *style;  // [c] | NULL, [c] | NULL, rows of (factor[c] | bias[c]) | NULL
   float *scale, *shift, *chmean;      // f32[b, c] outputs (chmean may be NULL); scale == NULL: no finisher
-  unsigned *tickets;                  // one counter per (sample, group), zero before the launch and zero again after it
   double count_per_channel;
-  int style_stride, groups, expected;  // expected: contributing workgroups per (sample, group)
+  int style_stride, groups;
   float eps;
 };
 typedef float gnf_f32x2 __attribute__((ext_vector_type(2)));
-// Partials that a finisher in ANOTHER workgroup of the same launch will read travel as device-scope (write-through / cache-
-// bypassing) accesses: the XCDs' L2s are not coherent with each other for plain accesses, and the alternative -- a device-scope
-// release fence (buffer_wbl2) at the end of every producing workgroup -- cost +20 % of the sampler when it was tried.
-__device__ __forceinline__ void gnf_store(float *p, float v, bool coherent) {
-  if (coherent) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-__device__ __forceinline__ float gnf_load(const float *p, bool coherent) {
-  return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
 // lds: 4 x 256 doubles per 256-thread SLICE. Every thread of the workgroup calls it (same barriers); a slice is 256 consecutive
 // threads with vt = the thread's index inside it, `live` = the slice has a group to finish (a 1024-thread workgroup finishes four
 // groups at once: far_field_kernel, pvconv_tail_kernel). Outputs: f.scale / f.shift / f.chmean (global, each may be NULL) and the
 // optional tables tab_* (f32[c] of THIS sample, e.g. in LDS, for a kernel that goes on to use the values itself).
 __device__ __forceinline__ void gn_finish_group_v(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int g,
-                                                  double *lds, int vt, bool live, float *mean_rstd = nullptr, bool coherent = false,
+                                                  double *lds, int vt, bool live, float *mean_rstd = nullptr,
                                                   float *tab_scale = nullptr, float *tab_shift = nullptr, float *tab_mean = nullptr) {
   double *rs = lds, *rq = lds + 256, *chs = lds + 512, *chq = lds + 768;
   const int t = vt;
@@ -183,8 +173,7 @@ __device__ __forceinline__ void gn_finish_group_v(int c, int nslots, const float
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float *pp = p0 + (size_t)(sl + u * nt) * pitch;
-        if (coherent) v[u] = gnf_f32x2{gnf_load(pp, true), gnf_load(pp + 1, true)};
-        else v[u] = *(const gnf_f32x2 *)pp;
+        v[u] = *(const gnf_f32x2 *)pp;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -194,8 +183,8 @@ __device__ __forceinline__ void gn_finish_group_v(int c, int nslots, const float
     }
     for (; sl < nslots; sl += nt) {
       const float *p = p0 + (size_t)sl * pitch;
-      s += (double)gnf_load(p, coherent);
-      q += (double)gnf_load(p + 1, coherent);
+      s += (double)p[0];
+      q += (double)p[1];
     }
   }
   if (live) {
@@ -246,8 +235,8 @@ __device__ __forceinline__ void gn_finish_group_v(int c, int nslots, const float
 }
 // one group by the first 256 threads of the workgroup (threads >= 256 idle through the barriers); lds: 4 x 256 doubles
 __device__ __forceinline__ void gn_finish_group(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int g,
-                                                double *lds, float *mean_rstd = nullptr, bool coherent = false) {
-  gn_finish_group_v(c, nslots, part, f, b, g, lds, (int)threadIdx.x, threadIdx.x < 256, mean_rstd, coherent);
+                                                double *lds, float *mean_rstd = nullptr) {
+  gn_finish_group_v(c, nslots, part, f, b, g, lds, (int)threadIdx.x, threadIdx.x < 256, mean_rstd);
 }
 // ALL groups of sample b by a workgroup of 256 * NS threads, NS groups at a time (lds: NS x 1024 doubles); the same bits as one
 // gn_affine launch. The tables (if given) are complete after it returns (it ends on a barrier).
@@ -257,37 +246,10 @@ __device__ __forceinline__ void gn_finish_sample(int c, int nslots, const float 
   const int slice = (int)threadIdx.x >> 8, vt = (int)threadIdx.x & 255;
   for (int g0 = 0; g0 < f.groups; g0 += NS) {
     const int g = g0 + slice;
-    gn_finish_group_v(c, nslots, part, f, b, g < f.groups ? g : 0, lds + slice * 1024, vt, slice < NS && g < f.groups, nullptr, false,
+    gn_finish_group_v(c, nslots, part, f, b, g < f.groups ? g : 0, lds + slice * 1024, vt, slice < NS && g < f.groups, nullptr,
                       tab_scale, tab_shift, tab_mean);
   }
 }
-// End of a producing workgroup whose channel tile [c0, c0 + cw) of sample b is written: count it on the groups it covers and
-// finish those it completes. Every thread calls it; `lds`: 4 x 256 + 1 doubles (the kernel's operand tiles are free by now).
-// The caller has made sure that tile and group boundaries nest (cw % cg == 0 or cg % cw == 0, c0 % min(cw, cg) == 0).
-__device__ __forceinline__ void gn_finish_arrive(int c, int nslots, const float *__restrict__ part, const GnFinish &f, int b, int c0, int cw,
-                                                 double *lds) {
-  int &gnf_last = *(int *)(lds + 4 * 256);  // (in the caller's LDS: the ping-pong GEMM has no static byte left)
-  const int cg = c / f.groups;
-  // this thread's partials (device-scope stores: gnf_store) have reached memory before the workgroup is counted
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int gfirst = c0 / cg, glast = (min(c0 + cw, c) - 1) / cg;
-  for (int g = gfirst; g <= glast; ++g) {
-    if (threadIdx.x == 0) {
-      const unsigned old = atomicAdd(&f.tickets[(size_t)b * f.groups + g], 1u);
-      gnf_last = old == (unsigned)f.expected - 1u;
-    }
-    __syncthreads();
-    const bool last = gnf_last != 0;
-    __syncthreads();
-    if (last) {  // (the other contributors' partials: device-scope loads)
-      gn_finish_group(c, nslots, part, f, b, g, lds, nullptr, true);
-      if (threadIdx.x == 0)  // ready for the next launch that is handed this counter
-        __hip_atomic_store(&f.tickets[(size_t)b * f.groups + g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 // ---- 32 rows x 32 lanes -> one row total per lane ("reduce-scatter" over the half-wave) ----
 // A GEMM epilogue holds, per lane, one value of each of 32 output-channel rows and needs every row's reduction
 // over the 32 lanes of its half-wave. Reducing the rows one by one costs 5 DPP steps per row (160 per statistic);
@@ -385,6 +347,32 @@ __device__ __forceinline__ void groupreduce8(float (&v)[32]) {
   }
 }
 
+// the same over aligned groups of 16 lanes (first lanes L, 15 - L: row_mirror): rows i + 2 j (i = 0, 1; j = lane & 15) end in v[0..1]
+template <class Op>
+__device__ __forceinline__ void groupreduce16(float (&v)[32]) {
+  const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float x = Op::f(v[i], dpp_full<0x140>(v[i])), y = Op::f(v[i + 16], dpp_full<0x140>(v[i + 16]));
+    v[i] = (lane & 8) ? y : x;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = Op::f(v[i], dpp_full<0x141>(v[i])), y = Op::f(v[i + 8], dpp_full<0x141>(v[i + 8]));
+    v[i] = (lane & 4) ? y : x;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x = Op::f(v[i], dpp_full<0x4E>(v[i])), y = Op::f(v[i + 4], dpp_full<0x4E>(v[i + 4]));
+    v[i] = (lane & 2) ? y : x;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float x = Op::f(v[i], dpp_full<0xB1>(v[i])), y = Op::f(v[i + 2], dpp_full<0xB1>(v[i + 2]));
+    v[i] = (lane & 1) ? y : x;
+  }
+}
+
 // ---- which kernel form a pointwise launch took (debug / test hook: include/p2pb_hip.h p2pb_debug_pointwise_form) ----
 enum {
   P2PB_FORM_PW_FP32 = 0,      // pw_conv_kernel: exact-fp32 MFMA, unaligned rows
@@ -396,10 +384,9 @@ enum {
   P2PB_FORM_PW_GATHER = 6,    // pw_wide_kernel<GATHER> (grouped operand built on the fly)
 };
 void p2pb_note_pointwise_form(int cin, int cout, int npos, int form);
-// the GroupNorm finisher armed for this thread's next statistics-producing launch (abi.hip), its ticket counters, and the
-// separate launch for producers that do not run it themselves (conv3d.hip)
+// the GroupNorm finisher armed for this thread's next statistics-producing launch (abi.hip) and the launch that runs it behind
+// the producer (conv3d.hip)
 bool p2pb_gn_finisher_take(GnFinish *out);
-unsigned *p2pb_gn_tickets(size_t n, hipStream_t s);
 int p2pb_gn_affine_launch(int b, int c, int nslots, const float *part, const GnFinish &f, hipStream_t s);
 
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)

@@ -1251,8 +1251,8 @@ extern "C" int p2pb_conv3d_k3_far_field_gn(int b, int cin, int cout, const float
   if (b <= 0 || cin <= 0 || cout <= 0 || !part || nslots <= 0 || !scale || !shift || !gn_shape_ok(cin, groups, style, style_stride))
     return P2PB_EINVAL;
   GnFinish f = {};
-  f.gamma = gamma, f.beta = beta, f.style = style, f.scale = scale, f.shift = shift, f.chmean = nullptr, f.tickets = nullptr;
-  f.count_per_channel = count_per_channel, f.style_stride = style_stride, f.groups = groups, f.expected = 0, f.eps = eps;
+  f.gamma = gamma, f.beta = beta, f.style = style, f.scale = scale, f.shift = shift, f.chmean = nullptr;
+  f.count_per_channel = count_per_channel, f.style_stride = style_stride, f.groups = groups, f.eps = eps;
   return far_field_launch(b, cin, cout, prev_bias, nullptr, nullptr, in_swish, wt_packed, bias, a, k_out, tap_ws, part, nslots, f,
                           (hipStream_t)stream);
 }
@@ -2303,8 +2303,8 @@ static __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups
                                                         float *__restrict__ mean_rstd) {
   __shared__ double lds[4 * 256];
   GnFinish f;  // (the arithmetic lives in common.h: producing kernels handed a GnFinish run it themselves)
-  f.gamma = gamma, f.beta = beta, f.style = style, f.scale = scale, f.shift = shift, f.chmean = chmean, f.tickets = nullptr;
-  f.count_per_channel = count_per_channel, f.style_stride = style_stride, f.groups = groups, f.expected = 0, f.eps = eps;
+  f.gamma = gamma, f.beta = beta, f.style = style, f.scale = scale, f.shift = shift, f.chmean = chmean;
+  f.count_per_channel = count_per_channel, f.style_stride = style_stride, f.groups = groups, f.eps = eps;
   gn_finish_group(c, nslots, part, f, blockIdx.y, blockIdx.x, lds, mean_rstd);
 }
 

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
                                                       const float *__restrict__ in_shift, int in_swish,
                                                       float *__restrict__ out, float *__restrict__ stats_part,
                                                       float *__restrict__ mm_out, int pool_g, int out_pm,
-                                                      PwGather gat = PwGather(), GnFinish fin = GnFinish()) {
+                                                      PwGather gat = PwGather()) {
   static_assert(!GATHER || TERMS == SPLIT_F16X3, "the gathered operand exists in the f16x3 form");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, khalf = lane >> 5;
@@ -667,13 +667,14 @@ extern "C" size_t p2pb_pointwise_stats_floats(int b, int cout, int npos) {
 
 // Epilogue of the split-operand GEMM kernels for one wave's 64 channels x NB x 64 positions: bias, stores (channel- or
 // point-major), GroupNorm partials per 64-position slot, optional {min, max} for the pooling that follows.
-template <bool POOL, int WM, int NB>
+// PL (pooling form, compile time): 0 none, 1 global-pool partials (pool_u == 0), 32 neighbourhoods of 32 positions, 2 any other
+// neighbourhood size (the per-row ladder)
+template <int PL, int WM, int NB>
 __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, int bx, int gx, int pblk, int co0,
                                              int wm, int wn, int l31, int khalf, int cout, int P, int nslots,
                                              const float *__restrict__ bias, const float *__restrict__ bias_b,
                                              float *__restrict__ out, float *__restrict__ stats_part,
-                                             float *__restrict__ mm_out, int pool_u, int out_pm, const float *sb,
-                                             bool coherent = false) {
+                                             float *__restrict__ mm_out, int pool_u, int out_pm, const float *sb) {
   // sb: the workgroup's bias (+ per-sample bias) values [64 WM], staged in LDS by the kernel's prologue. Fetched from
   // global memory inside the row loops below they were one L2 round trip each, serialised by the loops' branches (the
   // same finding as in the convolutions' epilogue, conv3d.hip / tools/exp_conv_timeline.py).
@@ -723,7 +724,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
       acc[m][2 * pb + 1][r] += bv;
       const f32x2 v = {acc[m][2 * pb][r], acc[m][2 * pb + 1][r]};
       if (cok && pok && outb) *(f32x2 *)(outb + (size_t)co * P + p) = v;
-      if (POOL && pool_u != 0) {
+      if constexpr (PL == 2) {
         float mn = pok ? fminf(v[0], v[1]) : INFINITY, mx = pok ? fmaxf(v[0], v[1]) : -INFINITY;
         group_minmax(mn, mx, pool_g);
         if (cok && pok && (pool_g == 32 ? l31 == 31 : (l31 & (pool_g - 1)) == 0)) {
@@ -732,6 +733,30 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
           q[1] = mx;
         }
       }
+    }
+  }
+  if constexpr (PL == 32) {
+    // 32 neighbours = 16 lanes of two positions: the rows' {min, max} through a reduce-scatter network (common.h groupreduce16:
+    // rows i + 2 j end in lane j of the group; round 5 -- the per-row ladder above was 12 instructions per row and statistic)
+    float tn[32], tx[32];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v0 = acc[m][2 * pb][r], v1 = acc[m][2 * pb + 1][r];
+        tn[m * 16 + r] = pok ? vmin_raw(v0, v1) : INFINITY;
+        tx[m * 16 + r] = pok ? -vmax_raw(v0, v1) : INFINITY;
+      }
+    groupreduce16<RowMin>(tn);
+    groupreduce16<RowMin>(tx);
+    const int j = l31 & 15;  // rows 2 j, 2 j + 1: m = j >> 3, r = 2 (j & 7) + i
+    const int cb = co0 + wm * 64 + 32 * (j >> 3) + 2 * (j & 1) + 8 * ((j & 7) >> 1) + 4 * khalf;
+    if (pok) {
+      const size_t ngrp = (size_t)(P / 32);
+      float *q = mm_out + (((size_t)b * cout + cb) * ngrp + p / 32) * 2;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (cb + i < cout) *(f32x2 *)(q + (size_t)i * ngrp * 2) = f32x2{tn[i], -tx[i]};
     }
   }
   // this lane's row after the reductions; one 32-value array live at a time (register pressure: the other position
@@ -760,18 +785,17 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
     const float s2 = rowreduce32<RowAdd>(tv);
     if (rco < cout) {
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
-      // coherent: a finisher in another workgroup of this launch reads them (common.h GnFinish): device-scope stores
-      gnf_store(q, s1, coherent);
-      gnf_store(q + 1, s2, coherent);
+      q[0] = s1;
+      q[1] = s2;
       if (bx == gx - 1 && pb == NB - 1 && wn == 1)  // slots past the last position block (nslots is a multiple of 4)
         for (int sl = slot + 1; sl < nslots; ++sl) {
           float *z = stats_part + (((size_t)b * nslots + sl) * cout + rco) * 2;
-          gnf_store(z, 0.0f, coherent);
-          gnf_store(z + 1, 0.0f, coherent);
+          z[0] = 0.0f;
+          z[1] = 0.0f;
         }
     }
   }
-  if (POOL && pool_u == 0) {
+  if constexpr (PL == 1) {
     float tv[32];
     rowvals(2, tv);
     const float mn = rowreduce32<RowMin>(tv);
@@ -796,7 +820,7 @@ __device__ __forceinline__ void pws_epilogue(f32x16 (&acc)[2][2 * NB], int b, in
 // pre-split weights, re-read by 2048 position blocks), 256 x 256 moves 5.3 GB.
 // TERMS: the arithmetic (common.h, p2pb_set_split_terms) -- SPLIT_F16X3 (default: fp16-pair split, three products, two
 // operand planes: the third is neither fetched, written nor read) or SPLIT_BF16X6 (three bf16 terms, six products)
-template <bool XF, bool POOL, int WM, int NB, int TERMS>
+template <bool XF, int PL, int WM, int NB, int TERMS>
 #ifndef PWS_WM4_WAVES
 #define PWS_WM4_WAVES 4
 #endif
@@ -807,7 +831,7 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
                                                        const float *__restrict__ in_scale,
                                                        const float *__restrict__ in_shift, int in_swish,
                                                        float *__restrict__ out, float *__restrict__ stats_part,
-                                                       float *__restrict__ mm_out, int pool_u, int out_pm, GnFinish fin) {
+                                                       float *__restrict__ mm_out, int pool_u, int out_pm) {
   extern __shared__ u32x4 pws_lds[];  // [A: WM/2 blocks of 128 channels][B: NB blocks of 128 positions][XF: 2 cin floats]
   constexpr int NT = 128 * WM;
   constexpr int BS = 128 * NB;  // 16-byte groups per (kstep, split, khalf) row of the B tile
@@ -971,8 +995,8 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
       }
     }
   }
-  if (!mact && !fin.scale) return;
-  if (mact) {
+  if (!mact) return;
+  {
     if constexpr (TERMS == SPLIT_F16X3) {  // 1 / (S_x S_w), a power of two, stored behind the pack
       const int nblk128 = WM == 2 ? ncoblk : (cout + 127) / 128;
       const float oscale = ((const float *)(wp + (size_t)((cin + PWS_CK - 1) / PWS_CK) * nblk128 * PWS_TILE))[1];
@@ -983,11 +1007,9 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
   #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][n][r] *= oscale;
     }
-  pws_epilogue<POOL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
-                             stats_part, mm_out, pool_u, out_pm, pws_bias, fin.scale != nullptr);
+  pws_epilogue<PL, WM, NB>(acc, b, bx, (int)gridDim.x, pblk, co0, wm, wn, l31, khalf, cout, P, nslots, bias, bias_b, out,
+                             stats_part, mm_out, pool_u, out_pm, pws_bias);
   }
-  // the GroupNorm that follows this layer, finished here by the workgroup that completes a (sample, group) (common.h)
-  if (fin.scale) gn_finish_arrive(cout, nslots, stats_part, fin, b, co0, 64 * WM, (double *)pws_lds);
 }
 
 // split pack: wp[chunk32][cout block of 128][kstep 2][split 3][khalf 2][128 co][8 bf16],
@@ -1066,12 +1088,6 @@ extern "C" int p2pb_pointwise_pack_weights_split_amax(int cout, int cin, const f
 // clears `pending`, otherwise the entry point launches gn_affine_kernel behind the producer
 static thread_local GnFinish tl_pw_fin;
 static thread_local bool tl_pw_fin_pending = false;
-static std::atomic<unsigned long long> g_fin_fused{0}, g_fin_behind{0};
-// how many armed finishers ran inside their producer / as a launch behind it (tests assert the fused form is the one running)
-extern "C" void p2pb_debug_gn_finisher(unsigned long long *fused, unsigned long long *behind) {
-  if (fused) *fused = g_fin_fused.load();
-  if (behind) *behind = g_fin_behind.load();
-}
 static int pw_finish_behind(int rc, int b, int cout, int P, const float *stats_part, hipStream_t s) {
   if (!tl_pw_fin_pending) return rc;
   tl_pw_fin_pending = false;
@@ -1081,36 +1097,7 @@ static int pw_finish_behind(int rc, int b, int cout, int P, const float *stats_p
   // gn_finish_group with a truncated group / past its 256-entry LDS table and read gamma out of bounds)
   const GnFinish &f = tl_pw_fin;
   if (f.groups <= 0 || cout % f.groups != 0 || cout / f.groups > 256 || (f.style && f.style_stride < 2 * cout)) return P2PB_EINVAL;
-  ++g_fin_behind;
   return p2pb_gn_affine_launch(b, cout, (P + 255) / 256 * 4, stats_part, tl_pw_fin, s);
-}
-
-// the pending finisher as a kernel argument, if this launch can run it: channel tiles of `cw`, `pblocks` workgroups per tile and
-// sample; tile and group boundaries must nest (the contributors of a (sample, group) are the position blocks of the channel tiles
-// it spans). Otherwise an empty descriptor, and the finisher stays pending for the launch behind the producer.
-// P2PB_GN_FINISH (default 0: every armed finisher is the gn_affine launch behind its producer): bit 0 lets the split-operand
-// kernel run it in its last workgroup per (sample, group), bit 1 the wide kernel, bit 2 the ping-pong kernel. MEASURED, one box,
-// bench.py ms per sample call (30 evaluations x 2 chains): 0 -> 248.5, 1 -> 255.0 (13 layers per evaluation), 5 -> 260.0 (15),
-// 3 -> 257 against 243 on another box (22 layers). Removing the 48 finishing launches altogether (timing-only experiment, constants
-// in their place) is worth 8 % -- but the ticketed form costs more than the launch it replaces: the workgroup that arrives last
-// wins ALL the groups of its channel tile and finishes them one after the other from memory-side reads, and every producing
-// workgroup waits for its own stores before it is counted. Same bits in every form (tests/test_gn_finisher_gpu.py).
-static GnFinish pw_take_finisher(int b, int cout, int cw, int pblocks, bool has_stats, hipStream_t s, int kind = 1) {
-  GnFinish fin = {};
-  static const int fin_env = getenv("P2PB_GN_FINISH") ? atoi(getenv("P2PB_GN_FINISH")) : 0;
-  if (!tl_pw_fin_pending || !(fin_env & kind) || !has_stats || tl_pw_fin.groups <= 0 || cout % tl_pw_fin.groups != 0 ||
-      (tl_pw_fin.style && tl_pw_fin.style_stride < 2 * cout))
-    return fin;  // (left pending: pw_finish_behind rejects the shapes gn_finish_group cannot take)
-  const int cg = cout / tl_pw_fin.groups;
-  if (!(cw % cg == 0 || cg % cw == 0) || cg > 256) return fin;
-  unsigned *tk = p2pb_gn_tickets((size_t)b * tl_pw_fin.groups, s);
-  if (!tk) return fin;
-  fin = tl_pw_fin;
-  fin.tickets = tk;
-  fin.expected = pblocks * (cg > cw ? cg / cw : 1);
-  tl_pw_fin_pending = false;
-  ++g_fin_fused;
-  return fin;
 }
 
 static int pw_launch_split(int b, int cin, int cout, int P, const float *in, const void *wp, const float *bias,
@@ -1138,7 +1125,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
       once = true;                                                                                                   \
     }                                                                                                                \
     hipLaunchKernelGGL((pw_split_kernel<XF, PL, WM, NB, TM>), grid, dim3(128 * WM), lds, s, cin, cout, P, nslots, in, \
-                       w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm, fin);  \
+                       w, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, out_pm);       \
   } while (0)
 #define LAUNCHF(XF, PL, WM, NB)                                       \
   do {                                                                \
@@ -1157,7 +1144,6 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 1;
   if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0)) {
     dim3 pgrid((P + 127) / 128, cout / 512, b);
-    const GnFinish fin5 = pw_take_finisher(b, cout, 512, (int)pgrid.x, stats_part != nullptr, s, 4);
 #define LAUNCHP5(XF, PL)                                                                                              \
   do {                                                                                                                \
     static bool once = false;                                                                                         \
@@ -1167,7 +1153,7 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
       once = true;                                                                                                    \
     }                                                                                                                 \
     hipLaunchKernelGGL((pw_pp512_kernel<XF, PL>), pgrid, dim3(512), P5_LDS_BYTES, s, cin, cout, P, nslots, in, w, bias, \
-                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u, fin5);                  \
+                       bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_u);                        \
   } while (0)
     if (xf && minmax) LAUNCHP5(true, true);
     else if (xf) LAUNCHP5(true, false);
@@ -1178,11 +1164,18 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     return p2pb_launch_status();
   }
   p2pb_note_pointwise_form(cin, cout, P, wm4 ? P2PB_FORM_PW_SPLIT256 : P2PB_FORM_PW_SPLIT128);
-  const GnFinish fin = pw_take_finisher(b, cout, wm4 ? 256 : 128, (int)grid.x, stats_part != nullptr && !out_pm, s);
-  if (xf && minmax) LAUNCH(true, true);
-  else if (xf) LAUNCH(true, false);
-  else if (minmax) LAUNCH(false, true);
-  else LAUNCH(false, false);
+  const int pl = !minmax ? 0 : pool_u == 0 ? 1 : pool_u == 32 ? 32 : 2;
+  if (xf) {
+    if (pl == 0) LAUNCH(true, 0);
+    else if (pl == 1) LAUNCH(true, 1);
+    else if (pl == 32) LAUNCH(true, 32);
+    else LAUNCH(true, 2);
+  } else {
+    if (pl == 0) LAUNCH(false, 0);
+    else if (pl == 1) LAUNCH(false, 1);
+    else if (pl == 32) LAUNCH(false, 32);
+    else LAUNCH(false, 2);
+  }
 #undef LAUNCH
 #undef LAUNCHF
 #undef LAUNCHW
@@ -1207,14 +1200,13 @@ static int pw_launch(int b, int cin, int cout, int P, const float *in, const flo
 #define LAUNCHX(XF, ST, PL, TM)                                                                                       \
   hipLaunchKernelGGL((pw_wide_kernel<MT, XF, ST, PL, TM>), grid, dim3(256), 0, s, cin, cout, pw_cout_pad(cout), P,       \
                      nslots, in, wp, bias, bias_b, in_scale, in_shift, in_swish, out, stats_part, minmax, pool_g, out_pm,  \
-                     PwGather(), fin)
+                     PwGather())
 #define LAUNCH(XF, ST, PL)                                 \
   do {                                                     \
     if (split_pack) LAUNCHX(XF, ST, PL, SPLIT_F16X3);       \
     else LAUNCHX(XF, ST, PL, 0);                            \
   } while (0)
     p2pb_note_pointwise_form(cin, cout, P, split_pack ? P2PB_FORM_PW_WIDE_F16 : P2PB_FORM_PW_WIDE_FP32);
-    const GnFinish fin = GnFinish();  // (the norm that follows: the launch behind this one, pw_finish_behind)
     if (minmax) {
       const int pg = pool_g == 8 || pool_g == 32 ? pool_g : 1;
       if (xf) {
@@ -1360,8 +1352,7 @@ static int pw_conv_pool_gather_impl(int b, int cin, int cout, int n, int m, int 
   hipLaunchKernelGGL((pw_wide_kernel<MTV, true, true, PGV, SPLIT_F16X3, true>),                                    \
                      dim3((P + 511) / 512, (cout + 32 * MTV - 1) / (32 * MTV), b), dim3(256), 0, s, cin, cout,             \
                      pw_cout_pad(cout), P, nslots, zt, wsp, bias, (const float *)nullptr, in_scale, in_shift, in_swish,    \
-                     (float *)nullptr, stats_part, minmax, gl, 0, gat, fin)
-  const GnFinish fin = GnFinish();
+                     (float *)nullptr, stats_part, minmax, gl, 0, gat)
   if (gl == 8) {
     if (cout > 32) LAUNCHG(2, 8);
     else LAUNCHG(1, 8);
@@ -1449,7 +1440,7 @@ __global__ __launch_bounds__(256) void minmax_act_pool_kernel(int c, int nslots,
   if (part != nullptr) {
     const int cg = c / fin.groups, c0 = blockIdx.x * 32, c1 = min(c0 + 32, c) - 1;
     for (int g = c0 / cg; g <= c1 / cg; ++g)
-      gn_finish_group_v(c, nslots_st, part, fin, b, g, gl, (int)threadIdx.x, true, nullptr, false, mmp_tab, mmp_tab + c);
+      gn_finish_group_v(c, nslots_st, part, fin, b, g, gl, (int)threadIdx.x, true, nullptr, mmp_tab, mmp_tab + c);
   }
   __syncthreads();
   if (part_i != 0 || ch >= c) return;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
     int cin, int cout, int P, int nslots, const float *__restrict__ in, const u32x4 *__restrict__ wp,
     const float *__restrict__ bias, const float *__restrict__ bias_b, const float *__restrict__ in_scale,
     const float *__restrict__ in_shift, int in_swish, float *__restrict__ out, float *__restrict__ stats_part,
-    float *__restrict__ mm_out, int pool_u, GnFinish fin) {
+    float *__restrict__ mm_out, int pool_u) {
   extern __shared__ u32x4 p5_lds[];  // [A0 | A1 | B0 | B1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -361,18 +361,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
           tv[m * 16 + r] = (acc[m][0][r] * acc[m][0][r] + acc[m][1][r] * acc[m][1][r]) +
                            (acc[m][2][r] * acc[m][2][r] + acc[m][3][r] * acc[m][3][r]);
       const float s2 = rowreduce32<RowAdd>(tv);
-      const bool coherent = fin.scale != nullptr;  // (read by the finisher of another workgroup: common.h GnFinish)
       float *q = stats_part + (((size_t)b * nslots + slot) * cout + rco) * 2;
-      gnf_store(q, s1, coherent);
-      gnf_store(q + 1, s2, coherent);
+      q[0] = s1;
+      q[1] = s2;
       float *z = q + (size_t)cout * 2;  // slot + 1
-      gnf_store(z, 0.0f, coherent);
-      gnf_store(z + 1, 0.0f, coherent);
+      z[0] = 0.0f;
+      z[1] = 0.0f;
       if (bx == (int)gridDim.x - 1)
         for (int sl = nmine; sl < nslots; ++sl) {
           float *zz = stats_part + (((size_t)b * nslots + sl) * cout + rco) * 2;
-          gnf_store(zz, 0.0f, coherent);
-          gnf_store(zz + 1, 0.0f, coherent);
+          zz[0] = 0.0f;
+          zz[1] = 0.0f;
         }
     }
     if (POOL && pool_u == 0) {
@@ -414,6 +413,4 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
     for (int k = 0; k < 8; ++k) q[4 + k] = ts[k];
   }
 #endif
-  // the GroupNorm that follows this layer, finished by the workgroup that completes a (sample, group) (common.h)
-  if (fin.scale) gn_finish_arrive(cout, nslots, stats_part, fin, b, co0, 512, (double *)p5_lds);
 }

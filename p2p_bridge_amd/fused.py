@@ -510,8 +510,8 @@ def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
 def arm_finisher(fin, b, c, device):
     """hand the GroupNorm that follows a layer to the layer's own launch (csrc/common.h GnFinish): fin = (count_per_channel,
     groups, gamma, beta, style | None, eps, want_mean) -> (scale, shift, chmean | None) f32[B,C], filled in stream order by the
-    NEXT statistics-producing launch of this thread -- by its last workgroup per (sample, group) where the kernel can, by a
-    gn_affine launch right behind it otherwise (same values, same bits: one device function)"""
+    NEXT statistics-producing launch of this thread: its entry point puts the gn_affine launch right behind the producer (one
+    Python call and one ctypes call fewer per layer; the values and bits of a separate gn_affine_params call)"""
     count, groups, gamma, beta, style, eps, want_mean = fin
     scale = torch.empty(b, c, dtype=F32, device=device)
     shift = torch.empty_like(scale)
