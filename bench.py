@@ -264,40 +264,76 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(sd, n_points, T, patches=2, budget_s=20.0):
-    """The CPU oracle (C ops + torch CPU dense layers, all host threads) on a bounded sample of the same workload:
-    `patches` patches through the FULL T-step sampler when that fits the time budget (it does on the GPU box's host:
-    ~0.2 s per evaluation), else as many bridge steps as fit, extrapolated (every step costs the same: one network
-    evaluation + an elementwise update)."""
-    from oracle import net_ref
+def cpu_worker(sd_path, n_points, T, patches, budget_s, threads, cpu0):
+    """one process of the CPU baseline (`bench.py --cpu-worker ...`): `threads` threads pinned to the logical CPUs cpu0 .. cpu0 +
+    threads - 1, its own `patches` patches through the oracle's sampler; prints one JSON line {dt_step, steps, one}"""
+    try:
+        os.sched_setaffinity(0, set(range(cpu0, cpu0 + threads)))
+    except (AttributeError, OSError):
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    torch.set_num_threads(threads)
+    from oracle import cpu_ops, net_ref
 
-    x, _ = net_ref.synthetic_patches(patches, n_points, seed=0)
-    net = net_ref.RefNet(PVDS, sd, vox_mode="tree")
-    host = os.cpu_count() or 1
-    # threads actually used: 16 -- measured on the GPU box's host (2 x 64-core EPYC 9575F, 256 hardware threads;
-    # tools/exp_cpu_threads.sh -> profiles/r03b_cpu_baseline_threads.txt: 8 / 16 / 32 / 64 / 128 / 256 threads =
-    # 1508 / 1523 / 1264 / 700 / 195 / 7 points/s): beyond that these small per-patch ops only contend
-    cores = min(host, int(os.environ.get("P2PB_CPU_THREADS", "16")))
-    torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    from oracle import cpu_ops
+    cpu_ops.set_threads(threads)
+    import copy
 
-    cpu_ops.set_threads(cores)
+    sd = torch.load(sd_path)
+    cfg = copy.deepcopy(PVDS)
+    cfg["data"]["npoints"] = n_points
+    x, _ = net_ref.synthetic_patches(patches, n_points, seed=cpu0)
+    net = net_ref.RefNet(cfg, sd, vox_mode="tree")
     t0 = time.perf_counter()
-    net_ref.sample(net, PVDS, x, steps=1, log_count=1)  # warm-up, and the estimate of one step
+    net_ref.sample(net, cfg, x, steps=1, log_count=1)  # warm-up, and the estimate of one step
     one = time.perf_counter() - t0
     steps = max(2, min(T, int(budget_s / max(one, 1e-3))))
     t0 = time.perf_counter()
-    net_ref.sample(net, PVDS, x, steps=steps, log_count=1)
+    net_ref.sample(net, cfg, x, steps=steps, log_count=1)
     dt = (time.perf_counter() - t0) / steps
-    return {"value": round(patches * n_points / (dt * T), 2), "unit": "points/s", "cores": cores, "host_cores": host,
-            "host_cpu": cpu_model(), "kind": "port",
-            "sample": f"{patches} patches x {n_points} pts, {steps} of T={T} bridge steps timed after 1 warm-up step "
-                      f"({dt:.2f} s/step, {dt * steps:.1f} s of CPU work)"
+    print(json.dumps({"dt_step": dt, "steps": steps, "one": one}), flush=True)
+
+
+def cpu_baseline(sd, n_points, T, patches=2, budget_s=20.0):
+    """The CPU oracle (C ops + torch CPU dense layers) on a bounded sample of the same workload, USING THE HOST: P worker
+    processes x 16 threads, each pinned to its own 16 logical CPUs and denoising its own `patches` patches (patches are independent:
+    the same patch-parallelism the GPU ranks use), P = physical cores / 16 (review r4 item 8: one 16-thread process left 7/8 of the
+    host idle, and more threads in ONE process only contend -- profiles/r03b_cpu_baseline_threads.txt). Every worker runs the FULL
+    T-step sampler when that fits the time budget, else as many bridge steps as fit, extrapolated (every step costs the same: one
+    network evaluation + an elementwise update). value = sum over workers of patches x points / (T x its seconds per step), all
+    workers running at the same time. P2PB_CPU_THREADS / P2PB_CPU_PROCS override."""
+    import subprocess
+    import tempfile
+
+    host = os.cpu_count() or 1
+    threads = min(host, int(os.environ.get("P2PB_CPU_THREADS", "16")))
+    physical = max(1, host // 2)  # (2 hardware threads per core on the GPU boxes' EPYCs; the first `physical` logical CPUs are distinct cores)
+    procs = int(os.environ.get("P2PB_CPU_PROCS", str(max(1, physical // threads))))
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "sd.pt")
+        torch.save({k: v.detach().cpu() for k, v in sd.items()}, path)
+        cmd = lambda i: [sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(n_points), str(T), str(patches),
+                         str(budget_s), str(threads), str(i * threads)]
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen(cmd(i), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
+        outs = [p.communicate()[0] for p in ps]
+        wall = time.perf_counter() - t0
+    rs = [json.loads(o.strip().splitlines()[-1]) for o in outs if o.strip()]
+    if not rs:
+        raise RuntimeError("cpu_baseline: no worker finished")
+    value = sum(patches * n_points / (r["dt_step"] * T) for r in rs)
+    steps = min(r["steps"] for r in rs)
+    dt = max(r["dt_step"] for r in rs)
+    return {"value": round(value, 2), "unit": "points/s", "cores": threads * len(rs), "processes": len(rs), "threads_per_process": threads,
+            "host_cores": host, "host_cpu": cpu_model(), "kind": "port",
+            "sample": f"{len(rs)} processes x {patches} patches x {n_points} pts, {steps} of T={T} bridge steps timed after 1 warm-up step "
+                      f"in every process, all at once (slowest {dt:.2f} s/step; {wall:.1f} s of wall time in all)"
                       + ("" if steps == T else f", extrapolated to T={T}")}
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":  # (a process of cpu_baseline)
+        a = sys.argv[2:]
+        return cpu_worker(a[0], int(a[1]), int(a[2]), int(a[3]), float(a[4]), int(a[5]), int(a[6]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -494,7 +530,7 @@ def alt_math_leg(cfg, sd, x_start, args):
             "ms_per_step": round(dt / args.steps * 1e3, 2), "max_abs_diff_of_one_evaluation_vs_default": diff}
 
 
-def pvdl_leg(B=8, N=50000, T=30, extra=3, reps=2):
+def pvdl_leg(B=8, N=50000, T=30, extra=3, reps=2, fit_batch=64):
     """NOT `value`: BASELINE config 4 on this one GPU -- full-width PVDL (118.6 M parameters, channels 64..1024, 13 PVConvs),
     xyz + RGB condition, B clouds of 50000 points, T = 30, the product's own conditional sampler as one hipGraph per step.
     dense-equivalent FLOPs: SURVEY 8d, 486 GFLOP per sample and evaluation at 50000 points. At this batch an evaluation is bound
@@ -514,24 +550,43 @@ def pvdl_leg(B=8, N=50000, T=30, extra=3, reps=2):
                              n_sa_blocks=[2, 3, 2, 2], n_fp_blocks=[2, 3, 2, 2])
     torch.manual_seed(0)
     model = product.build_model(c, device="cuda")
-    x, _ = synthetic_patches(B, N, seed=1)
-    g = torch.Generator().manual_seed(2)
-    cond = torch.rand(B, extra, N, generator=g)
-    x, cond = x.cuda(), cond.cuda()
-    run = lambda: model.sample(x_start=x, x_cond=cond, steps=T, log_count=1, verbose=False, graph=True)
-    out = run()  # weight packs + capture
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        out = run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    assert torch.isfinite(out["x_pred"]).all()
+
+    def timed(Bx, nrep):
+        x, _ = synthetic_patches(Bx, N, seed=1)
+        g = torch.Generator().manual_seed(2)
+        cond = torch.rand(Bx, extra, N, generator=g)
+        x, cond = x.cuda(), cond.cuda()
+        run = lambda: model.sample(x_start=x, x_cond=cond, steps=T, log_count=1, verbose=False, graph=True)
+        out = run()  # weight packs + capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nrep):
+            out = run()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / nrep
+        assert torch.isfinite(out["x_pred"]).all()
+        return dt
+
+    dt = timed(B, reps)
     tf = 486.0 * B * T / dt / 1e3
-    return {"workload": f"PVDL_SNPP xyz+RGB ({3 + extra}-ch), {B} x {N}-pt clouds, T={T}, hipGraph (BASELINE configs[3] on one GPU)",
-            "value": round(B * N / dt, 1), "unit": "points/s", "ms_per_sample_call": round(dt * 1e3, 1),
-            "ms_per_evaluation": round(dt * 1e3 / T, 2), "dense_equivalent_tflops": round(tf, 1),
-            "frac_of_split_ceiling": round(tf / split_peak_tflops(), 4), "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    res = {"workload": f"PVDL_SNPP xyz+RGB ({3 + extra}-ch), {B} x {N}-pt clouds, T={T}, hipGraph (BASELINE configs[3] on one GPU)",
+           "value": round(B * N / dt, 1), "unit": "points/s", "ms_per_sample_call": round(dt * 1e3, 1),
+           "ms_per_evaluation": round(dt * 1e3 / T, 2), "dense_equivalent_tflops": round(tf, 1),
+           "frac_of_split_ceiling": round(tf / split_peak_tflops(), 4), "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    if fit_batch:
+        # BASELINE configs[3] says "as many as fit": the B = 8 figure above is the LATENCY of the path (an evaluation is the level-0
+        # farthest-point sampling's 12499 dependent rounds, one workgroup per cloud); the batch this part's memory takes hides it
+        # (profiles/r03d_pvdl_large_batches.txt). One timed call at `fit_batch` clouds (two sampler chains, the default there).
+        model.clear_graphs()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        dtf = timed(fit_batch, 1)
+        tff = 486.0 * fit_batch * T / dtf / 1e3
+        res["value_at_fit"] = {"clouds": fit_batch, "value": round(fit_batch * N / dtf, 1), "unit": "points/s",
+                               "ms_per_evaluation": round(dtf * 1e3 / T, 2), "dense_equivalent_tflops": round(tff, 1),
+                               "frac_of_split_ceiling": round(tff / split_peak_tflops(), 4),
+                               "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+    return res
 
 
 def result_line(args, world, dt, dist):

@@ -388,6 +388,9 @@ class Voxelization(nn.Module):
         return L.avg_voxelize(features, vox, self.r), norm
 
 
+_AO = os.environ.get('P2PB_DBG_AO', '1') == '1'
+
+
 class PVConv(nn.Module):
     """voxel branch (voxelize -> Conv3d, AdaGN, Swish, Dropout, Conv3d, AdaGN, SE3d -> trilinear
     devoxelize) + point branch (SharedMLP), summed (models/pvcnn.py:237-334)."""
@@ -462,10 +465,10 @@ class PVConv(nn.Module):
             sc1, sh1, a, k = fused.conv3d_far_field_gn(vl[0].bias, vl[4], st1, norm_fin(vl[1], r3, cond), True)
             if pre2:
                 y2, st2 = fused.conv3d_k3_sparse(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
-                                                 out_class=k, channels_last=True, pre=True, active_only=True)
+                                                 out_class=k, channels_last=True, pre=True, active_only=_AO)
             else:  # (y2 is read by the devoxelisation alone: corners within one voxel of an occupied voxel = active bricks)
                 y2, st2 = fused.conv3d_k3_sparse(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
-                                                 channels_last=True, active_only=True)
+                                                 channels_last=True, active_only=_AO)
         else:
             y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)

@@ -144,11 +144,15 @@ def test_every_op_of_an_evaluation_beside_matrix_kernels_is_bitwise_stable():
              if isinstance(v, types.FunctionType) and v.__module__ == m.__name__ and not k.startswith("_") and k not in not_ops]
     ca = _record_evaluation(net, mods, names, x[:16].contiguous(), t)
     cb = _record_evaluation(net, mods, names, x[16:].contiguous(), t)
+    # (a PVConv's second sparse convolution leaves the inactive bricks of its output unwritten -- active_only: nobody reads them --
+    #  so the replay asks for the fully written form of the same launch: same MFMA kernel, the fill writes as well)
+    fix = lambda cs: [(n, f, a, dict(kw, active_only=False) if kw.get("active_only") else kw) for (n, f, a, kw) in cs]
+    ca, cb = fix(ca), fix(cb)
     assert len(ca) == len(cb) > 150, (len(ca), len(cb))
     kinds = {n for n, *_ in ca}
     for must in ("fused.pw_conv", "fused.conv3d_k3_compact", "fused.conv3d_k3_sparse", "fused.conv3d_k3", "fused.devoxelize_affine",
                  "fused.voxelize_cl_gather", "fused.group_sub", "fused.interp_add", "fused.minmax_act", "fused.gn_affine_params",
-                 "fused.conv3d_far_field", "fused.se_gate_affine", "fused.linear_rows", "fused.voxel_sort",
+                 "fused.conv3d_far_field_gn", "fused.pvconv_tail", "fused.linear_rows", "fused.voxel_sort",
                  "ext.furthest_point_sampling_forward", "ext.ball_query", "ext.three_nn"):
         assert must in kinds, (must, sorted(kinds))
 
