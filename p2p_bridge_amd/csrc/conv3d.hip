@@ -2337,6 +2337,22 @@ extern "C" int p2pb_gn_affine_params(int b, int c, int groups, int nslots, doubl
 }
 #endif
 
+// hid[h] = relu(sum_i w1[h][i] * mean[i]) for the SE3d bottleneck (models/pvcnn.py SE3d.fc[0..1]): ONE WAVE PER ROW -- lane l adds
+// the terms i = l, l + 64, ... in that order, then the 64 lane sums through a fixed xor tree. (Round 5: the first form gave a row
+// to ONE THREAD, c dependent loads from global memory in a row: 16-32 busy threads and ~12 of the tail kernel's 16 us.)
+// Both kernels below use it: the same bits whichever runs.
+__device__ __forceinline__ void se_hidden(int c, int hidden, const float *__restrict__ w1, const float *mean, float *hid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int h = wave; h < hidden; h += nw) {
+    float acc = 0.0f;
+    for (int i = lane; i < c; i += 64) acc = __fmaf_rn(w1[(size_t)h * c + i], mean[i], acc);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) hid[h] = fmaxf(acc, 0.0f);
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Squeeze-excite gate (models/modules.py:362-378: Linear(c, c/8, no bias) -> ReLU -> Linear(c/8, c, no bias) ->
 // Sigmoid on the per-channel mean of the normalised grid) folded into the devoxelisation affine:
@@ -2352,11 +2368,7 @@ static __global__ __launch_bounds__(256) void se_gate_affine_kernel(int c, int h
   const int b = blockIdx.x, t = threadIdx.x;
   for (int i = t; i < c; i += 256) mean[i] = chmean[(size_t)b * c + i];
   __syncthreads();
-  for (int h = t; h < hidden; h += 256) {
-    float acc = 0.0f;
-    for (int i = 0; i < c; ++i) acc = __fmaf_rn(w1[(size_t)h * c + i], mean[i], acc);
-    hid[h] = fmaxf(acc, 0.0f);
-  }
+  se_hidden(c, hidden, w1, mean, hid);
   __syncthreads();
   for (int i = t; i < c; i += 256) {
     float acc = 0.0f;
@@ -2395,11 +2407,7 @@ static __global__ __launch_bounds__(1024) void pvconv_tail_kernel(int c, int hid
     }
     return;
   }
-  for (int h = t; h < hidden; h += 1024) {
-    float acc = 0.0f;
-    for (int i = 0; i < c; ++i) acc = __fmaf_rn(w1[(size_t)h * c + i], mean[i], acc);
-    hid[h] = fmaxf(acc, 0.0f);
-  }
+  se_hidden(c, hidden, w1, mean, hid);
   __syncthreads();
   for (int i = t; i < c; i += 1024) {
     float acc = 0.0f;
