@@ -822,26 +822,38 @@ class Geometry:
         vox_plan = {}
         for (lev, r, normalize, eps) in plan.get("voxel", ()):
             vox_plan.setdefault(lev, []).append((r, normalize, eps))
+
+        def voxel_prep(i, c, stream):
+            # per (level, resolution): voxel coordinates, occupancy + sorted point lists, brick lists of the sparse convolutions --
+            # coordinate-only, shared by every PVConv of the level
+            for (r, normalize, eps) in vox_plan.get(i, ()):
+                vcoords, vox = L.voxel_coords(c, r, normalize, eps)
+                cnt, ws = fused.voxel_sort(vox, r)
+                lists = counts = None
+                c1, c2 = compact_plan()
+                if r in c1 or r in c2:
+                    lists, counts = fused.active_lists(cnt, r)
+                elif r >= 32:
+                    lists, counts = fused.brick_lists(cnt, r)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                self.voxel[(i, r)] = (vcoords, cnt, ws, lists, counts, ev)
+
+        c0 = coords.contiguous()
+        # Level 0's voxel preparation runs on the MAIN stream, behind the fork (round 5, tools/exp_stamps.py): in front of the
+        # level-0 farthest-point sampling on the side stream it delayed that 1.7 ms dependent chain by its own 0.25 ms, and once the
+        # main stream's first blocks had become faster the first set abstraction waited 0.5 ms per evaluation for FPS + ball query.
+        # Its consumers (the level's PVConvs) are on the main stream anyway.
+        prep0_side = os.environ.get('P2PB_DBG_PREP0') == 'side'  # (A/B only)
+        if not prep0_side:
+            voxel_prep(0, c0, main)
         with torch.cuda.stream(side):
             level_coords = []
-            c = coords.contiguous()
+            c = c0
             for i, st in enumerate(plan["sa"]):
                 level_coords.append(c)
-                # per (level, resolution): voxel coordinates, occupancy + sorted point lists, brick lists of the
-                # sparse convolutions -- coordinate-only, shared by every PVConv of the level; issued before this
-                # level's FPS so that the first consumer (the level's own PVConv) never waits for it
-                for (r, normalize, eps) in vox_plan.get(i, ()):
-                    vcoords, vox = L.voxel_coords(c, r, normalize, eps)
-                    cnt, ws = fused.voxel_sort(vox, r)
-                    lists = counts = None
-                    c1, c2 = compact_plan()
-                    if r in c1 or r in c2:
-                        lists, counts = fused.active_lists(cnt, r)
-                    elif r >= 32:
-                        lists, counts = fused.brick_lists(cnt, r)
-                    ev = torch.cuda.Event()
-                    ev.record(side)
-                    self.voxel[(i, r)] = (vcoords, cnt, ws, lists, counts, ev)
+                if i > 0 or prep0_side:  # issued before this level's FPS so that the first consumer (the level's own PVConv) never waits for it
+                    voxel_prep(i, c, side)
                 idx = L._ext.furthest_point_sampling_forward(c, st["centers"])
                 cen = L._ext.gather_features_forward(c, idx)
                 nidx = L._ext.ball_query(cen, c, st["radius"], st["neighbors"])
