@@ -11,19 +11,42 @@
 // voxel_coords: one workgroup per cloud. Summation order is part of the contract (see oracle):
 // 256 lane-strided double partials, then a fixed binary tree.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void voxel_coords_kernel(int n, int r, int normalize, float eps,
-                                                           const float *__restrict__ coords,
-                                                           float *__restrict__ norm, int *__restrict__ vox) {
+// (round 5: since the level-0 preparation runs on the sampler's main stream this kernel is on the critical path. The first form --
+//  256 threads, 32 dependent load + add steps per axis, then two more strided passes -- took 44-63 us for 98 KB per cloud. Now 1024
+//  threads; the 256 partials are summed by threads 0..255 in the SAME order, their loads issued eight at a time; the maximum and
+//  the normalisation pass, which have no order, use every thread.)
+__global__ __launch_bounds__(1024) void voxel_coords_kernel(int n, int r, int normalize, float eps,
+                                                            const float *__restrict__ coords,
+                                                            float *__restrict__ norm, int *__restrict__ vox) {
   __shared__ double part[3][256];
-  __shared__ float smax[256];
+  __shared__ float smax[1024];
   const int t = threadIdx.x;
   const float *c = coords + (size_t)blockIdx.x * 3 * n;
   float *o = norm + (size_t)blockIdx.x * 3 * n;
   int *v = vox + (size_t)blockIdx.x * 3 * n;
-  for (int a = 0; a < 3; ++a) {
-    double s = 0.0;
-    for (int k = t; k < n; k += 256) s += (double)c[a * n + k];
-    part[a][t] = s;
+  if (t < 256) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int k0 = t; k0 < n; k0 += 8 * 256) {
+      float x0[8], x1[8], x2[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * 256;
+        const bool ok = k < n;
+        x0[u] = ok ? c[k] : 0.0f;
+        x1[u] = ok ? c[n + k] : 0.0f;
+        x2[u] = ok ? c[2 * n + k] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u * 256 < n) {
+          s0 += (double)x0[u];
+          s1 += (double)x1[u];
+          s2 += (double)x2[u];
+        }
+    }
+    part[0][t] = s0;
+    part[1][t] = s1;
+    part[2][t] = s2;
   }
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
@@ -38,13 +61,14 @@ __global__ __launch_bounds__(256) void voxel_coords_kernel(int n, int r, int nor
   const float m1 = (float)(part[1][0] / (double)n);
   const float m2 = (float)(part[2][0] / (double)n);
   float mx = 0.0f;
-  for (int k = t; k < n; k += 256) {
+#pragma unroll 4
+  for (int k = t; k < n; k += 1024) {
     float s = sqdist3(c[k] - m0, c[n + k] - m1, c[2 * n + k] - m2);
     mx = s > mx ? s : mx;
   }
   smax[t] = mx;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = 512; s > 0; s >>= 1) {  // (a maximum: exact in any order)
     if (t < s) smax[t] = smax[t + s] > smax[t] ? smax[t + s] : smax[t];
     __syncthreads();
   }
@@ -52,7 +76,8 @@ __global__ __launch_bounds__(256) void voxel_coords_kernel(int n, int r, int nor
   const float mean[3] = {m0, m1, m2};
   const float rf = (float)r, hi = (float)(r - 1);
   for (int a = 0; a < 3; ++a)
-    for (int k = t; k < n; k += 256) {
+#pragma unroll 4
+    for (int k = t; k < n; k += 1024) {
       float x = c[a * n + k] - mean[a];
       if (normalize)
         x = __fdiv_rn(x, denom) + 0.5f;
@@ -68,7 +93,7 @@ __global__ __launch_bounds__(256) void voxel_coords_kernel(int n, int r, int nor
 extern "C" int p2pb_voxel_coords(int b, int n, int r, int normalize, float eps, const float *coords, float *norm,
                                  int *vox, void *stream) {
   if (b <= 0 || n <= 0 || r <= 0) return P2PB_EINVAL;
-  hipLaunchKernelGGL(voxel_coords_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, r, normalize, eps, coords,
+  hipLaunchKernelGGL(voxel_coords_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, n, r, normalize, eps, coords,
                      norm, vox);
   return p2pb_launch_status();
 }
@@ -127,13 +152,45 @@ __global__ __launch_bounds__(1024) void vox_scan_kernel(int n, int r3, const int
   int *oc = occ + (size_t)blockIdx.x * n;
   const int per = (r3 + 1023) / 1024;
   const int beg = t * per, end = min(beg + per, r3);
+  int tot;
+  if (per == 32 && r3 == 32768) {  // r = 32: a thread's 32 counts in registers (eight 16-byte loads, issued together) -- the two
+    // scalar passes of the general form were 64 dependent 4-byte loads at a 128-byte lane stride (55 us per launch)
+    typedef int i32x4v __attribute__((ext_vector_type(4)));
+    i32x4v x[8];
+    const i32x4v *c4 = (const i32x4v *)(c + beg);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = c4[q];
+    int s = 0, k = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s += x[q][i];
+        k += x[q][i] > 0;
+      }
+    int run = block_exscan_1024(s, wsum, &tot);
+    int kpos = block_exscan_1024(k, wsum, &tot);
+    if (t == 0) nocc[blockIdx.x] = tot;
+    i32x4v *o4 = (i32x4v *)(o + beg);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      i32x4v w;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w[i] = run;
+        run += x[q][i];
+        if (x[q][i] > 0) oc[kpos++] = beg + 4 * q + i;
+      }
+      o4[q] = w;
+    }
+    return;
+  }
   int s = 0, k = 0;
   for (int v = beg; v < end; ++v) {
     const int x = c[v];
     s += x;
     k += x > 0;
   }
-  int tot;
   int run = block_exscan_1024(s, wsum, &tot);
   int kpos = block_exscan_1024(k, wsum, &tot);
   if (t == 0) nocc[blockIdx.x] = tot;
@@ -169,6 +226,13 @@ __global__ __launch_bounds__(256) void vox_sort_kernel(int n, int r3, const int 
   const int start = cur[(size_t)b * r3 + v] - cn;  // cur points at the segment end after the fill
   const int *seg = list + (size_t)b * n + start;
   int *dst = slist + (size_t)b * n + start;
+  if (cn <= 64) {  // the usual case: the ids sit in the lanes, ranks through lane broadcasts (no load inside the loop)
+    const int mine = lane < cn ? seg[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < cn; ++j) rank += __shfl(mine, j) < mine;
+    if (lane < cn) dst[rank] = mine;
+    return;
+  }
   for (int l0 = 0; l0 < cn; l0 += 64) {
     const int l = l0 + lane;
     const int mine = l < cn ? seg[l] : 0x7fffffff;
