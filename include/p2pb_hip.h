@@ -397,6 +397,12 @@ int p2pb_three_interpolate_add(int b, int c, int m, int n, const float *cz, cons
                                const float *add, const float *bias, float *out, float *stats_part,
                                float *ws /* f32[b*m*c], or NULL if cz is point-major f32[b,m,c] */, void *stream);
 size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u);
+/* The statistics of the grouped tensor alone (two-layer set abstractions: the consuming GEMM, p2pb_pointwise_conv_pool_gather,
+ * gathers its operand itself): zt f32[b,n,c], cxt f32[b,m,c] | NULL point-major, idx i32[b,m,u] ->
+ * stats_part f32[b, p2pb_group_sub_stats_slots(m,u), c, 2] ({sum, sum of squares} of z[idx] - cx per slot of 128 positions). */
+int p2pb_group_sub_stats_slots(int m, int u);
+int p2pb_group_sub_stats(int b, int c, int n, int m, int u, const float *zt, const float *cxt, const int *idx,
+                         float *stats_part, void *stream);
 int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z, const float *cx, const int *idx, float *out,
                    float *stats_part, float *ws /* f32[b*(n+m)*c], or NULL if z, cx are point-major */, void *stream);
 

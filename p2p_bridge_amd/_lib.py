@@ -16,7 +16,7 @@ SYMBOLS = [
     "p2pb_version", "p2pb_target_arch", "p2pb_set_split_terms", "p2pb_set_split_terms_thread", "p2pb_get_split_terms", "p2pb_set_deterministic", "p2pb_get_deterministic", "p2pb_voxel_coords", "p2pb_avg_voxelize_ws_bytes",
     "p2pb_avg_voxelize_forward", "p2pb_avg_voxelize_backward", "p2pb_avg_voxelize_cl_gather_split", "p2pb_conv3d_presplit",
     "p2pb_conv3d_k3_forward_compact_pre", "p2pb_trilinear_devoxelize_forward",
-    "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats",
+    "p2pb_trilinear_devoxelize_backward", "p2pb_ball_query", "p2pb_grouping_forward", "p2pb_grouping_backward", "p2pb_group_concat", "p2pb_group_sub", "p2pb_three_interpolate_add", "p2pb_group_sub_stats_floats", "p2pb_group_sub_stats_slots", "p2pb_group_sub_stats",
     "p2pb_gather_features_forward", "p2pb_gather_features_backward", "p2pb_furthest_point_sampling",
     "p2pb_fps_coop_ws_bytes", "p2pb_furthest_point_sampling_coop", "p2pb_point_face_dist", "p2pb_face_point_dist", "p2pb_knn_points_ws_bytes", "p2pb_knn_points", "p2pb_three_nn_interpolate_forward", "p2pb_three_nn_interpolate_backward", "p2pb_three_nn", "p2pb_three_nn_cells", "p2pb_three_nn_cells_ws_bytes",
     "p2pb_three_interpolate", "p2pb_chamfer_forward",

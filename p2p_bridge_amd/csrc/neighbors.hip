@@ -277,6 +277,69 @@ __global__ __launch_bounds__(256) void group_sub_kernel(int c, int n, int m, int
   }
 }
 
+// STATISTICS ONLY (the two-layer set abstractions: the consumer, pw_wide_kernel<GATHER>, gathers the grouped operand itself and
+// only the GroupNorm partials of the grouped tensor are needed first). Round 5: this used to be group_sub_kernel with out == NULL --
+// the LDS transpose that exists for the output's sake and ten DPP steps per channel row, 114 us for the first level of the bench;
+// here a lane IS a channel: a wave walks its 128 positions, every lane adds its own {v, v * v} (v = z[idx] - cx, group_sub's
+// arithmetic) in position order, and the partial of (sample, slot = wave, channel) is one store -- no LDS, no cross-lane step
+// (two positions per step for c <= 32: the half-waves' sums are added once at the end). Slots of 128 positions: a quarter of the
+// partials gn_affine has to reduce afterwards.
+#define GST_PW 128
+template <int CPL>
+__global__ __launch_bounds__(256) void group_stats_kernel(int c, int n, int m, int u, int nslots, const float *__restrict__ zt,
+                                                          const float *__restrict__ cxt, const int *__restrict__ idx,
+                                                          float *__restrict__ stats) {
+  constexpr int PPS = 64 / CPL;  // positions per step
+  const int b = blockIdx.z, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = blockIdx.x * 4 + wave;
+  if (slot >= nslots) return;
+  const int mu = m * u, p0 = slot * GST_PW;
+  const int sub = lane / CPL, ch = blockIdx.y * CPL + lane % CPL;
+  // the wave's 128 neighbour indices: two per lane, handed round by lane broadcasts
+  const int ia = p0 + lane < mu ? idx[(size_t)b * mu + p0 + lane] : -1;
+  const int ib = p0 + 64 + lane < mu ? idx[(size_t)b * mu + p0 + 64 + lane] : -1;
+  const float *zb = zt + (size_t)b * n * c + ch;
+  const float *cb = cxt ? cxt + (size_t)b * m * c + ch : nullptr;
+  float s1 = 0.0f, s2 = 0.0f;
+  const bool chok = ch < c;
+#pragma unroll 8
+  for (int it = 0; it < GST_PW / PPS; ++it) {
+    const int pl = it * PPS + sub;
+    const int id = pl < 64 ? __shfl(ia, pl) : __shfl(ib, pl - 64);
+    if (id >= 0 && chok) {
+      float v = zb[(size_t)id * c];
+      if (cb) v -= cb[(size_t)((p0 + pl) / u) * c];
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  if (PPS == 2) {
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+  }
+  if (chok && sub == 0) {
+    float *q = stats + (((size_t)b * nslots + slot) * c + ch) * 2;
+    q[0] = s1;
+    q[1] = s2;
+  }
+}
+
+extern "C" int p2pb_group_sub_stats_slots(int m, int u) { return (int)(((long)m * u + GST_PW - 1) / GST_PW); }
+// zt f32[b,n,c], cxt f32[b,m,c] | NULL (point-major), idx i32[b,m,u] -> stats_part f32[b, p2pb_group_sub_stats_slots(m,u), c, 2]
+extern "C" int p2pb_group_sub_stats(int b, int c, int n, int m, int u, const float *zt, const float *cxt, const int *idx,
+                                    float *stats_part, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || !zt || !idx || !stats_part || (long)m * u > 0x7fffffffL) return P2PB_EINVAL;
+  const int nslots = p2pb_group_sub_stats_slots(m, u);
+  hipStream_t s = (hipStream_t)stream;
+  if (c <= 32)
+    hipLaunchKernelGGL(group_stats_kernel<32>, dim3(cdiv(nslots, 4), cdiv(c, 32), b), dim3(256), 0, s, c, n, m, u, nslots, zt, cxt, idx,
+                       stats_part);
+  else
+    hipLaunchKernelGGL(group_stats_kernel<64>, dim3(cdiv(nslots, 4), cdiv(c, 64), b), dim3(256), 0, s, c, n, m, u, nslots, zt, cxt, idx,
+                       stats_part);
+  return p2pb_launch_status();
+}
+
 extern "C" size_t p2pb_group_sub_stats_floats(int b, int c, int m, int u) {
   return (size_t)b * (((size_t)m * u + 63) / 64 * 2) * c * 2;
 }

@@ -663,6 +663,10 @@ def group_sub(z, cx, idx, point_major=False, stats_only=False):
         b, c, n = z.shape
     m, u = idx.shape[1], idx.shape[2]
     # stats_only: only the GroupNorm partials of the grouped tensor (the consumer gathers it itself: pw_conv_pool_gather)
+    if stats_only and point_major:  # lane = channel, no transpose, slots of 128 positions (csrc/neighbors.hip group_stats_kernel)
+        st = torch.empty(b, lib().p2pb_group_sub_stats_slots(_i(m), _i(u)), c, 2, dtype=F32, device=z.device)
+        call("p2pb_group_sub_stats", _i(b), _i(c), _i(n), _i(m), _i(u), ptr(z), ptr(cx), ptr(idx), ptr(st), stream_ptr())
+        return None, st
     y = None if stats_only else torch.empty(b, c, m * u, dtype=F32, device=z.device)
     nfl = lib().p2pb_group_sub_stats_floats(_i(b), _i(c), _i(m), _i(u))
     st = torch.empty(b, nfl // (b * c * 2), c, 2, dtype=F32, device=z.device)
