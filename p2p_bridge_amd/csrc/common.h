@@ -163,11 +163,36 @@ __device__ __forceinline__ void gn_finish_group_v(int c, int nslots, const float
   const int cg = c / f.groups, g0 = g * cg;
   const int nt = 256 / cg;  // partial accumulators per channel
   const int k = t % cg, j = t / cg;
+  // the channel's affine parameters are requested NOW (threads t < cg use them after two barriers: their latency hides behind the
+  // partials' reduction instead of following it)
+  float p_ga = 1.0f, p_be = 0.0f, p_fa = 1.0f, p_bi = 0.0f;
+  if (live && t < cg) {
+    const int ch = g0 + t;
+    if (f.gamma) p_ga = f.gamma[ch];
+    if (f.beta) p_be = f.beta[ch];
+    if (f.style) {
+      p_fa = f.style[(size_t)b * f.style_stride + ch];
+      p_bi = f.style[(size_t)b * f.style_stride + c + ch];
+    }
+  }
   double s = 0.0, q = 0.0;
   if (live && j < nt) {  // (same order, four slots' loads in flight: the plain loop was one L2 round trip per slot)
     const float *p0 = part + ((size_t)b * nslots * c + g0 + k) * 2;
     const size_t pitch = (size_t)c * 2;
     int sl = j;
+    for (; sl + 7 * nt < nslots; sl += 8 * nt) {  // (eight in flight where there are that many: round 5)
+      gnf_f32x2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float *pp = p0 + (size_t)(sl + u * nt) * pitch;
+        v[u] = *(const gnf_f32x2 *)pp;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        s += (double)v[u][0];
+        q += (double)v[u][1];
+      }
+    }
     for (; sl + 3 * nt < nslots; sl += 4 * nt) {
       gnf_f32x2 v[4];
 #pragma unroll
@@ -214,9 +239,7 @@ __device__ __forceinline__ void gn_finish_group_v(int c, int nslots, const float
     double var = gq / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const double rstd = 1.0 / sqrt(var + (double)f.eps);
-    const double ga = f.gamma ? (double)f.gamma[ch] : 1.0, be = f.beta ? (double)f.beta[ch] : 0.0;
-    const double fa = f.style ? (double)f.style[(size_t)b * f.style_stride + ch] : 1.0;
-    const double bi = f.style ? (double)f.style[(size_t)b * f.style_stride + c + ch] : 0.0;
+    const double ga = (double)p_ga, be = (double)p_be, fa = (double)p_fa, bi = (double)p_bi;
     const double sc = rstd * ga * fa;
     const double sh = (be - mean * rstd * ga) * fa + bi;
     const float cm = (float)(sc * (chs[t] / f.count_per_channel) + sh);
