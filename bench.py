@@ -124,7 +124,7 @@ def gemm_roofline(model, B, P, reps=10):
     """Dominant kernel of the sampler (largest share of the critical stream in profiles/r0N*_per_eval.csv): the global
     embedding's last layer (Pnet2Stage mlp2, 512 -> 1024 channels over all P points of every patch;
     models/pvcnn.py:905-932) -- pw_pp512_kernel<XF=true, POOL=true> (csrc/pw_pp512.h: the ping-pong GEMM on 512-channel x
-    128-position tiles; pw_split_kernel under P2PB_PW_PP=0 or for layers without whole 512-channel blocks): split-operand GEMM in the arithmetic fused.conv_math()
+    128-position tiles; pw_split_kernel under P2PB_EXPERIMENT pw_pp=0 or for layers without whole 512-channel blocks): split-operand GEMM in the arithmetic fused.conv_math()
     selects (f16x3 by default) that applies the previous layer's folded GroupNorm + Swish to its operand on load and whose
     epilogue emits the GroupNorm statistics and the per-channel {min, max} the max-pool is formed from -- the
     1024-channel output is never written. Timed live with HIP events on torch's current stream, launched exactly as
@@ -155,7 +155,7 @@ def gemm_roofline(model, B, P, reps=10):
     traffic = None
     try:
         vals = {}
-        pingpong = split and fused.conv_math() == "f16x3" and os.environ.get("P2PB_PW_PP", "1") != "0" and co % 512 == 0 and ci % 64 == 0 and B * ((P + 127) // 128) * (co // 256) >= 1024
+        pingpong = split and fused.conv_math() == "f16x3" and _pw_pp_on() and co % 512 == 0 and ci % 64 == 0 and B * ((P + 127) // 128) * (co // 256) >= 1024
         import glob
 
         cands = (sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_pw_pp512_512_1024_pool.csv")), reverse=True) if pingpong else [])
@@ -252,6 +252,12 @@ def conv_math_note():
         return ("fp32 results; products as bf16x6 split operands (3 bf16 terms each, 6 MFMA products, fp32 accumulate; "
                 "error vs fp64 equal to the fp32 MFMA kernel's)")
     return "exact-fp32 MFMA"
+
+
+def _pw_pp_on():
+    from p2p_bridge_amd import _experiment
+
+    return _experiment.get("pw_pp", "1") != "0"
 
 
 def cpu_model():

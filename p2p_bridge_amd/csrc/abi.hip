@@ -74,6 +74,21 @@ extern "C" int p2pb_debug_pointwise_form(int cin, int cout, int npos, unsigned l
   return -1;
 }
 
+// P2PB_EXPERIMENT="key=value;key=value": the A/B switches of the library (conv_wide_min, am_chunks, pw_wm, pw_pp, fps_mid,
+// fps_coop_test_fallback, vox_onepass); callers cache the answer per site.
+#include <cstdlib>
+#include <cstring>
+long p2pb_experiment_long(const char *key, long dflt) {
+  const char *e = getenv("P2PB_EXPERIMENT");
+  const size_t kl = strlen(key);
+  while (e && *e) {
+    while (*e == ';' || *e == ' ') ++e;
+    if (strncmp(e, key, kl) == 0 && e[kl] == '=') return atol(e + kl + 1);
+    e = strchr(e, ';');
+  }
+  return dflt;
+}
+
 // Zero-fill as an ordinary kernel node. hipMemsetAsync is avoided on purpose: under hipGraph stream
 // capture its memset node did not re-execute reliably on replay here (stale voxel counts -> OOB list
 // writes -> GPU memory fault after a few replays), a kernel node always does.

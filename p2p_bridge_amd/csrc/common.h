@@ -412,6 +412,10 @@ void p2pb_note_pointwise_form(int cin, int cout, int npos, int form);
 bool p2pb_gn_finisher_take(GnFinish *out);
 int p2pb_gn_affine_launch(int b, int c, int nslots, const float *part, const GnFinish &f, hipStream_t s);
 
+// value of `key` in P2PB_EXPERIMENT="key=value;key=value" (the one variable behind every A/B switch: p2p_bridge_amd/_experiment.py), or
+// dflt; abi.hip
+long p2pb_experiment_long(const char *key, long dflt);
+
 // zero-fill `nbytes` (multiple of 4) on stream `s` with a kernel node (see abi.hip)
 int p2pb_zero_async(void *p, size_t nbytes, hipStream_t s);
 

@@ -1551,7 +1551,7 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
   if (flags & 4) {  // wt_packed is the split (3 x bf16) pack; always the compact tiling (same results, same slots)
     // 64 output channels per workgroup, unless that leaves under one workgroup per CU (small grids x small batches:
     // the 8^3 grids of a training batch of 8): 32 channels then double the workgroup count
-    static const long wide_min = getenv("P2PB_CONV_WIDE_MIN") ? atol(getenv("P2PB_CONV_WIDE_MIN")) : 256;  // (A/B switch)
+    static const long wide_min = p2pb_experiment_long("conv_wide_min", 256);  // (A/B switch)
     const bool wide = cout > 32 && (long)conv_bricks(r) * ((cout + 63) / 64) * b >= wide_min;
 #define GOS(RR)                                                                                                       \
   return wide ? conv_launch_split<RR, 2>(b, cin, cout, in, wt_packed, bias, out_class, in_scale, in_shift, in_swish,  \

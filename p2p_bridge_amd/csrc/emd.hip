@@ -179,8 +179,8 @@ __global__ void am_init_kernel(int n, int m, float multiL, float multiR, float *
 
 // chunks of the inner cloud per launch: enough workgroups for ~4 per CU, chunks of whole LDS tiles
 static int am_chunks(int b, int n, int m) {
-  static const char *force = getenv("P2PB_AM_CHUNKS");  // "1": single-pass kernels (A/B and parity experiments)
-  if (force && atoi(force) == 1) return 1;
+  static const long force = p2pb_experiment_long("am_chunks", 0);  // 1: single-pass kernels (A/B and parity experiments)
+  if (force == 1) return 1;
   const long base = (long)cdiv(n < m ? n : m, 256) * b;
   const int inner = n > m ? n : m;
   int c = 1;

@@ -1105,8 +1105,8 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
                            float *out, float *stats_part, float *minmax, int pool_u, int out_pm, hipStream_t s) {
   const bool xf = in_scale != nullptr;
   const int mode = p2pb_g_split_terms;
-  // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_PW_WM=2 / 4 overrides: A/B timing)
-  static const int wm_env = getenv("P2PB_PW_WM") ? atoi(getenv("P2PB_PW_WM")) : 0;
+  // 256-channel workgroups when the grid still holds >= 4 of them per CU (P2PB_EXPERIMENT pw_wm=2 / 4 overrides: A/B timing)
+  static const int wm_env = (int)p2pb_experiment_long("pw_wm", 0);
   const bool wm4 = !out_pm && (wm_env ? wm_env == 4
                                        : (cout >= 512 && (long)((P + 127) / 128) * ((cout + 255) / 256) * b >= 1024));
   // (256-position workgroups of THIS kernel -- half the weight traffic through L2 at one wave per SIMD less -- measured
@@ -1140,8 +1140,8 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   // The layers that qualify for 256-channel workgroups AND come in whole 512-channel blocks with an even number of
   // 32-channel stages run the ping-pong kernel (pw_pp512.h: one 8-wave workgroup per CU on 512 channels x 128 positions, all
   // 160 KB of LDS, weight tiles by LDS-DMA, the two waves of a SIMD in opposite phase; any position count).
-  // P2PB_PW_PP=0 keeps pw_split_kernel (A/B timing).
-  static const int pp_env = getenv("P2PB_PW_PP") ? atoi(getenv("P2PB_PW_PP")) : 1;
+  // P2PB_EXPERIMENT pw_pp=0 keeps pw_split_kernel (A/B timing).
+  static const int pp_env = (int)p2pb_experiment_long("pw_pp", 1);
   if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0)) {
     dim3 pgrid((P + 127) / 128, cout / 512, b);
 #define LAUNCHP5(XF, PL)                                                                                              \

@@ -317,7 +317,7 @@ extern "C" int p2pb_furthest_point_sampling(int b, int n, int m, const float *co
     (void)hipFuncSetAttribute((const void *)fps_kernel<512, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     attr_set = true;
   }
-  static const bool fps_mid_wide = !(getenv("P2PB_FPS_MID") && atoi(getenv("P2PB_FPS_MID")) == 1024);
+  static const bool fps_mid_wide = p2pb_experiment_long("fps_mid", 512) != 1024;
   if (n <= 64) fps_launch<64, 1>(b, n, m, coords, idx, s);
   else if (n <= 128) fps_launch<64, 2>(b, n, m, coords, idx, s);
   else if (n <= 256) fps_launch<64, 4>(b, n, m, coords, idx, s);
@@ -376,7 +376,7 @@ extern "C" int p2pb_furthest_point_sampling_coop(int b, int n, int m, const floa
   float *dist = (float *)((char *)ws + head);
   // test hook: raise every cloud's flag up front, so the on-device fallback recomputes everything (tests/ check that
   // the indices are the same and that the flags report it)
-  static const bool force_fallback = getenv("P2PB_FPS_COOP_TEST_FALLBACK") != nullptr;
+  static const bool force_fallback = p2pb_experiment_long("fps_coop_test_fallback", 0) != 0;
   if (force_fallback) hipLaunchKernelGGL(fps_set_flags_kernel, dim3(1), dim3(64), 0, s, b, err);
   for (int b0 = 0; b0 < b; b0 += per_launch) {
     const int nb = b - b0 < per_launch ? b - b0 : per_launch;

@@ -551,7 +551,7 @@ extern "C" int p2pb_avg_voxelize_cl_gather(int b, int c, int n, int r, const flo
   // rows of whole 16-byte quads: one pass over every voxel (zeros for the empty ones). Other channel counts (the 3 + 32
   // channels of the first PVConv): zero-fill + the occupied voxels only -- measured 181 vs 234 us for the whole
   // voxelisation at the bench's level-0 shape; for aligned rows the one-pass form is as fast or faster (tools/exp_voxelize.py)
-  static const int onepass = getenv("P2PB_VOX_ONEPASS") ? atoi(getenv("P2PB_VOX_ONEPASS")) : -1;  // (A/B switch: 0 / 1 force)
+  static const int onepass = (int)p2pb_experiment_long("vox_onepass", -1);  // (A/B switch: 0 / 1 force)
   if (onepass == 0 || (onepass < 0 && (c & 3) != 0)) {
     const int e = p2pb_zero_async(out, (size_t)b * r3 * c * sizeof(float), s);
     if (e != 0) return e;
@@ -578,7 +578,7 @@ extern "C" int p2pb_avg_voxelize_cl_gather_split(int b, int c, int n, int r, con
   const int *cur = (const int *)ws;
   const int *slist = cur + (size_t)b * r3 + (size_t)b * n;
   hipLaunchKernelGGL(transpose_cn_kernel, dim3(cdiv(n, 32), cdiv(c, 32), b), dim3(256), 0, s, c, n, feat, feat_t);
-  static const int onepass = getenv("P2PB_VOX_ONEPASS") ? atoi(getenv("P2PB_VOX_ONEPASS")) : -1;  // (A/B switch: 0 / 1 force)
+  static const int onepass = (int)p2pb_experiment_long("vox_onepass", -1);  // (A/B switch: 0 / 1 force)
   // zero-fill + occupied voxels only: ragged rows (the rule of p2pb_avg_voxelize_cl_gather) and every grid with at least four
   // voxels per point (r = 32 at 8192 points: <= 25 % occupied)
   if (onepass == 0 || (onepass < 0 && ((c & 3) != 0 || (size_t)r3 >= 4 * (size_t)n))) {

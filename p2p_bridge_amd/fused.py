@@ -9,6 +9,8 @@ Training keeps the unfused autograd graph (pvcnn_unet.PVConv.forward).
 """
 import ctypes
 import os
+
+from . import _experiment
 import threading
 
 import torch
@@ -137,7 +139,7 @@ def conv_pre_plan(r: int):
     P2PB_CONV_PRE="<first>:<second>" lists resolutions, default below; f16x3 arithmetic only."""
     if conv_math() != "f16x3" or lib().p2pb_get_split_terms() != 16:
         return False, False
-    spec = os.environ.get("P2PB_CONV_PRE", CONV_PRE_DEFAULT)
+    spec = _experiment.get("conv_pre", CONV_PRE_DEFAULT)
     parts = (spec.split(":") + [""])[:2]
     first, second = ({int(t) for t in q.split(",") if t.strip()} for q in parts)
     return int(r) in first, int(r) in second
@@ -496,8 +498,8 @@ PW_SPLIT_MIN_CIN, PW_SPLIT_MIN_COUT = 128, 128  # measured crossover (tools/exp_
 
 def use_wide_f16(ci: int, co: int) -> bool:
     """narrow 1x1 layers on the 16-bit matrix pipe too (csrc/pointwise.hip pw_wide_kernel<TERMS = f16x3>): from
-    P2PB_WIDE_F16_MIN_CIN input channels up (default 16: below that a 16-channel step is mostly padding)"""
-    return ci >= int(os.environ.get("P2PB_WIDE_F16_MIN_CIN", "16"))
+    P2PB_EXPERIMENT wide_f16_min_cin input channels up (default 16: below that a 16-channel step is mostly padding)"""
+    return ci >= _experiment.get_int("wide_f16_min_cin", 16)
 
 
 def use_split_pw(ci: int, co: int, npos: int, math=None) -> bool:
@@ -536,7 +538,7 @@ def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias
     b, ci, p = x.shape
     co = conv.out_channels if getattr(conv, "adjoint", False) else conv.weight.shape[0]
     split = use_split_pw(ci, co, p, math)
-    if in_scale is not None and (co + (127 if split else 63)) // (128 if split else 64) >= int(os.environ.get("P2PB_PREPASS_BLOCKS", "9")):
+    if in_scale is not None and (co + (127 if split else 63)) // (128 if split else 64) >= _experiment.get_int("prepass_blocks", 9):
         # every output-channel block re-applies the folded norm+Swish to its operand: for very wide layers one
         # elementwise pre-pass (1 read + 1 write of the input) is cheaper than the recomputations. With the
         # XCD-aware workgroup order the blocks of one activation tile run side by side and up to 8 recomputations
@@ -622,7 +624,7 @@ def gather_pool_supported(ci: int, co: int, m: int, u: int) -> bool:
     operand? (the narrow-layer f16x3 kernel: not the LDS-tiled GEMM's shapes; 32-byte row pieces; a supported pool)"""
     return (conv_math() == "f16x3" and lib().p2pb_get_split_terms() == 16 and ci % 8 == 0
             and not use_split_pw(ci, co, m * u) and use_wide_f16(ci, co) and pool_supported(m * u, u) and u > 0
-            and os.environ.get("P2PB_SA_GATHER", "1") != "0")
+            and _experiment.get("sa_gather", "1") != "0")
 
 
 def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True, fin=None):
@@ -727,8 +729,8 @@ class operand_audit:
         import sys
         # the audit reads fp32 operands: inside it the convolutions stage fp32 themselves (same operand values as the
         # pre-split path, whose grids hold fp16 pairs)
-        self._pre = os.environ.get("P2PB_CONV_PRE")
-        os.environ["P2PB_CONV_PRE"] = ":"
+        self._pre = os.environ.get("P2PB_EXPERIMENT")
+        os.environ["P2PB_EXPERIMENT"] = _experiment.setting(conv_pre=":")
         self.rows, self._mod = [], sys.modules[__name__]
         self._orig = {k: getattr(self._mod, k) for k in ("pw_conv", "conv3d_k3", "conv3d_k3_sparse", "conv3d_k3_compact")}
         names = {"pw_conv": ("in_scale", "in_shift", "swish"), "conv3d_k3": ("in_scale", "in_shift", "swish"),
@@ -761,9 +763,9 @@ class operand_audit:
         for k, o in self._orig.items():
             setattr(self._mod, k, o)
         if self._pre is None:
-            os.environ.pop("P2PB_CONV_PRE", None)
+            os.environ.pop("P2PB_EXPERIMENT", None)
         else:
-            os.environ["P2PB_CONV_PRE"] = self._pre
+            os.environ["P2PB_EXPERIMENT"] = self._pre
 
     @property
     def worst(self):

@@ -9,6 +9,8 @@ import os
 
 import torch
 
+from . import _experiment
+
 from ._lib import call, check, lib, ptr, stream_ptr
 
 _i, _f = ctypes.c_int, ctypes.c_float
@@ -153,7 +155,7 @@ def furthest_point_sampling_forward(coords, num_samples):
     b, _, n = coords.shape
     m = int(num_samples)
     idx = torch.empty(b, m, dtype=I32, device=coords.device)
-    big = os.environ.get("P2PB_FPS_BIG", FPS_BIG_DEFAULT) if os.environ.get("P2PB_FPS_COOP", "1") != "0" else "single"
+    big = _experiment.get("fps_big", FPS_BIG_DEFAULT)  # grid | coop | single
     if n > 16384 and m > 1 and big == "grid":
         # large clouds, pruned: one workgroup per cloud, a round revisits only the grid cells near the new sample
         # (csrc/sampling.hip fps_grid_kernel); same indices as every other FPS kernel here
@@ -220,7 +222,7 @@ def three_nn(points_coords, centers_coords):
     m = centers_coords.shape[2]
     idx = torch.empty(b, 3, n, dtype=I32, device=points_coords.device)
     w = torch.empty(b, 3, n, dtype=F32, device=points_coords.device)
-    if 256 <= m and os.environ.get("P2PB_NN_CELLS", "1") != "0":  # grid search (exact) once brute force is the slower one
+    if 256 <= m and _experiment.get("nn_cells", "1") != "0":  # grid search (exact) once brute force is the slower one
         # (records in LDS up to 8192 centres, L2-resident above: PVDL's 12500-centre level)
         ws = _ws(lib().p2pb_three_nn_cells_ws_bytes(_i(b), _i(m)), points_coords.device)
         call("p2pb_three_nn_cells", _i(b), _i(m), _i(n), ptr(points_coords), ptr(centers_coords), ptr(idx), ptr(w),

@@ -20,6 +20,8 @@ import numpy as np
 import os
 
 import torch
+
+from . import _experiment
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -388,9 +390,6 @@ class Voxelization(nn.Module):
         return L.avg_voxelize(features, vox, self.r), norm
 
 
-_AO = os.environ.get('P2PB_DBG_AO', '1') == '1'
-
-
 class PVConv(nn.Module):
     """voxel branch (voxelize -> Conv3d, AdaGN, Swish, Dropout, Conv3d, AdaGN, SE3d -> trilinear
     devoxelize) + point branch (SharedMLP), summed (models/pvcnn.py:237-334)."""
@@ -465,10 +464,10 @@ class PVConv(nn.Module):
             sc1, sh1, a, k = fused.conv3d_far_field_gn(vl[0].bias, vl[4], st1, norm_fin(vl[1], r3, cond), True)
             if pre2:
                 y2, st2 = fused.conv3d_k3_sparse(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
-                                                 out_class=k, channels_last=True, pre=True, active_only=_AO)
+                                                 out_class=k, channels_last=True, pre=True, active_only=True)
             else:  # (y2 is read by the devoxelisation alone: corners within one voxel of an occupied voxel = active bricks)
                 y2, st2 = fused.conv3d_k3_sparse(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
-                                                 channels_last=True, active_only=_AO)
+                                                 channels_last=True, active_only=True)
         else:
             y1, st1 = fused.conv3d_k3(v, vl[0], compact=True, channels_last=True, pre=pre1)
             sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
@@ -526,7 +525,7 @@ def compact_plan():
 
     if fused.conv_math() not in fused.SPLIT_MATHS:  # the compact kernel exists in the split-operand arithmetic only
         return set(), set()
-    spec = os.environ.get("P2PB_COMPACT", "16:16")
+    spec = _experiment.get("compact", "16:16")
     parts = (spec.split(":") + [""])[:2]
     return tuple({int(t) for t in p.split(",") if t.strip()} for p in parts)
 
@@ -844,15 +843,13 @@ class Geometry:
         # level-0 farthest-point sampling on the side stream it delayed that 1.7 ms dependent chain by its own 0.25 ms, and once the
         # main stream's first blocks had become faster the first set abstraction waited 0.5 ms per evaluation for FPS + ball query.
         # Its consumers (the level's PVConvs) are on the main stream anyway.
-        prep0_side = os.environ.get('P2PB_DBG_PREP0') == 'side'  # (A/B only)
-        if not prep0_side:
-            voxel_prep(0, c0, main)
+        voxel_prep(0, c0, main)
         with torch.cuda.stream(side):
             level_coords = []
             c = c0
             for i, st in enumerate(plan["sa"]):
                 level_coords.append(c)
-                if i > 0 or prep0_side:  # issued before this level's FPS so that the first consumer (the level's own PVConv) never waits for it
+                if i > 0:  # issued before this level's FPS so that the first consumer (the level's own PVConv) never waits for it
                     voxel_prep(i, c, side)
                 idx = L._ext.furthest_point_sampling_forward(c, st["centers"])
                 cen = L._ext.gather_features_forward(c, idx)

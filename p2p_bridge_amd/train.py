@@ -25,6 +25,8 @@ import time
 from typing import Callable, Dict, Iterator, Optional
 
 import torch
+
+from . import _experiment
 import torch.distributed as dist
 from torch import optim
 
@@ -359,7 +361,7 @@ class GraphedStep:
         self.model, self.optimizer, self.sched, self.warmup = model, optimizer, lr_scheduler, int(warmup)
         self.calls, self.graph, self.static = 0, None, None
         self.side = torch.cuda.Stream()
-        self.overlap = os.environ.get("P2PB_WGRAD_OVERLAP", "0") == "1"  # measured: profiles/r03c_wgrad_overlap_ab.txt (slower)
+        self.overlap = _experiment.get("wgrad_overlap", "0") == "1"  # measured: profiles/r03c_wgrad_overlap_ab.txt (slower)
         self.wgrad_stream = torch.cuda.Stream()
         self.distributed = bool(distributed)
         self.buckets = self.buckets_dec = self.graph_b = None

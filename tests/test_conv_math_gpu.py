@@ -208,7 +208,7 @@ def test_training_gradient_pass_is_bf16x6(fused):
 def test_narrow_layers_on_the_f16_pipe(fused, monkeypatch, ci, co, P, pool, xf):
     """pw_wide_kernel<TERMS = f16x3>: the register-tiled kernel of the narrow layers with its products on the 16-bit pipe
     (ragged channel counts, pooling epilogue, statistics): within the f16x3 bound of fp64, statistics and pooled
-    {min, max} consistent with its own outputs; P2PB_WIDE_F16_MIN_CIN switches back to the exact-fp32 MFMA form"""
+    {min, max} consistent with its own outputs; P2PB_EXPERIMENT wide_f16_min_cin switches back to the exact-fp32 MFMA form"""
     torch.manual_seed(ci * co)
     B = 3
     x = torch.randn(B, ci, P, device="cuda") * 2
@@ -224,7 +224,7 @@ def test_narrow_layers_on_the_f16_pipe(fused, monkeypatch, ci, co, P, pool, xf):
         ref = torch.nn.functional.conv1d(xin, conv.weight.double(), conv.bias.double())
         mag = torch.nn.functional.conv1d(xin.abs(), conv.weight.double().abs()) + 1e-300
         a = fused.pw_conv(x, conv, sc, sh, **kw)
-        monkeypatch.setenv("P2PB_WIDE_F16_MIN_CIN", "1000000")
+        monkeypatch.setenv("P2PB_EXPERIMENT", "wide_f16_min_cin=1000000")
         f = fused.pw_conv(x, conv, sc, sh, **kw)
     y, y32 = a[0], f[0]
     assert not torch.equal(y, y32)

@@ -92,7 +92,7 @@ def test_network_evaluation_identical_with_and_without_presplit(fused, monkeypat
     t = torch.full((2,), 500, device="cuda")
     outs = []
     for spec in (":", "4,8,16,32:4,8,16,32"):
-        monkeypatch.setenv("P2PB_CONV_PRE", spec)
+        monkeypatch.setenv("P2PB_EXPERIMENT", "conv_pre=" + spec)
         with torch.no_grad():
             outs.append(model.model(x, t))
     assert torch.equal(outs[0], outs[1])

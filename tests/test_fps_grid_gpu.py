@@ -71,7 +71,7 @@ def make(kind, b, n, seed):
 def test_grid_fps_vs_oracle(ext, kind, b, n, m, monkeypatch):
     c = make(kind, b, n, seed=n + m)
     ref = cpu_ops.furthest_point_sampling_forward(c, m)
-    monkeypatch.setenv("P2PB_FPS_BIG", "grid")
+    monkeypatch.setenv("P2PB_EXPERIMENT", "fps_big=grid")
     got = ext.furthest_point_sampling_forward(c.cuda(), m).cpu()
     assert torch.equal(got, ref), (kind, int((got != ref).sum()))
 
@@ -92,7 +92,7 @@ def test_grid_fps_equals_the_other_large_cloud_kernels(ext, kind, b, n, m, monke
     c = make(kind, b, n, seed=7).cuda()
     out = {}
     for mode in ("grid", "coop") + (("single",) if n <= 50000 and b <= 2 else ()):
-        monkeypatch.setenv("P2PB_FPS_BIG", mode)
+        monkeypatch.setenv("P2PB_EXPERIMENT", "fps_big=" + mode)
         out[mode] = ext.furthest_point_sampling_forward(c, m)
     assert ext.fps_coop_fallbacks() == 0 or True
     for mode, v in out.items():

@@ -220,7 +220,7 @@ def test_bench_workload_generator_matches_oracle_copy():
 def test_exact_fp32_mode_disables_the_split_only_paths(monkeypatch):
     from p2p_bridge_amd import pvcnn_unet
 
-    monkeypatch.delenv("P2PB_COMPACT", raising=False)
+    monkeypatch.delenv("P2PB_EXPERIMENT", raising=False)
     monkeypatch.setenv("P2PB_CONV_MATH", "bf16x6")
     assert pvcnn_unet.compact_plan() == ({16}, {16})
     monkeypatch.setenv("P2PB_CONV_MATH", "fp32")

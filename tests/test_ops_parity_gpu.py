@@ -217,7 +217,7 @@ def test_emd_known_answer_and_parity(met, golden_dir):
 
 def test_approxmatch_chunked_equals_single_pass(tmp_path):
     """small batches split the inner cloud over blockIdx.y and add the partial sums in chunk order (csrc/emd.hip): same
-    match matrix as the single-pass kernels (P2PB_AM_CHUNKS=1) up to the summation order -- checked at sizes where
+    match matrix as the single-pass kernels (P2PB_EXPERIMENT am_chunks=1) up to the summation order -- checked at sizes where
     approxmatch itself is too ill-conditioned (n != m, 4096^2) for a 2e-3 comparison with the expf-based oracle"""
     import subprocess
     import sys
@@ -238,9 +238,9 @@ torch.save(out, sys.argv[1])
     res = {}
     for mode in ("chunked", "single"):
         env = dict(os.environ)
-        env.pop("P2PB_AM_CHUNKS", None)
+        env.pop("P2PB_EXPERIMENT", None)
         if mode == "single":
-            env["P2PB_AM_CHUNKS"] = "1"
+            env["P2PB_EXPERIMENT"] = "am_chunks=1"
         f = str(tmp_path / (mode + ".pt"))
         r = subprocess.run([sys.executable, "-c", code, f], capture_output=True, text=True, cwd=root, env=env, timeout=280)
         assert r.returncode == 0, r.stderr[-2000:]
@@ -310,9 +310,9 @@ def test_three_nn_grid_search_matches_brute_force(ext, B, N, M, kind, monkeypatc
         pts[:, :, :50] = cen[:, :, :50]  # zero distances too
     if kind == "outside":  # query points far outside the centres' bounding box
         pts[:, :, :500] = pts[:, :, :500] * 6 + 3
-    monkeypatch.setenv("P2PB_NN_CELLS", "0")
+    monkeypatch.setenv("P2PB_EXPERIMENT", "nn_cells=0")
     i_ref, w_ref = ext.three_nn(dev(pts), dev(cen))
-    monkeypatch.setenv("P2PB_NN_CELLS", "1")
+    monkeypatch.setenv("P2PB_EXPERIMENT", "nn_cells=1")
     i_got, w_got = ext.three_nn(dev(pts), dev(cen))
     eq(i_got, i_ref, "idx")
     eq(w_got, w_ref, "weights")

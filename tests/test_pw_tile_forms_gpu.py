@@ -54,7 +54,7 @@ print("TILE-FORMS-OK")
 def test_256_channel_forms(pp):
     """pp = 1 (default): shapes with whole 512-channel blocks and an even stage count take the ping-pong kernel
     (pw_pp512.h), the others pw_split_kernel<WM = 4>; pp = 0: pw_split_kernel for all"""
-    env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP=pp)
+    env = dict(os.environ, P2PB_EXPERIMENT=f"pw_wm=4;pw_pp={pp}")
     r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TILE-FORMS-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
@@ -131,6 +131,6 @@ def test_pp512_kernel_shapes():
     extrema, zeroed / masked tails, run-to-run identical; the form table confirms the kernel ran"""
     if os.environ.get("P2PB_CONV_MATH", "f16x3") != "f16x3":
         pytest.skip("pw_pp512_kernel exists in the f16x3 arithmetic only")
-    env = dict(os.environ, P2PB_PW_WM="4", P2PB_PW_PP="1")
+    env = dict(os.environ, P2PB_EXPERIMENT="pw_wm=4;pw_pp=1")
     r = subprocess.run([sys.executable, "-c", P5_CODE], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "PP512-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -256,12 +256,11 @@ got = ext.furthest_point_sampling_forward(x.cuda(), 700)
 assert torch.equal(got.cpu(), ref)
 print("FALLBACKS", ext.fps_coop_fallbacks())
 '''
-    env = dict(os.environ, P2PB_FPS_BIG="coop")  # (the default large-cloud kernel is the pruned one: tests/test_fps_grid_gpu.py)
-    env.pop("P2PB_FPS_COOP_TEST_FALLBACK", None)
+    env = dict(os.environ, P2PB_EXPERIMENT="fps_big=coop")  # (the default large-cloud kernel is the pruned one: tests/test_fps_grid_gpu.py)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=240)
     assert r.returncode == 0 and "FALLBACKS 0" in r.stdout, r.stderr[-2000:]
-    env["P2PB_FPS_COOP_TEST_FALLBACK"] = "1"
+    env["P2PB_EXPERIMENT"] = "fps_big=coop;fps_coop_test_fallback=1"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, env=env, timeout=240)
     assert r.returncode == 0 and "FALLBACKS 6" in r.stdout, r.stderr[-2000:]
 
