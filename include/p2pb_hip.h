@@ -499,6 +499,12 @@ int p2pb_linear_attention_backward(int b, int heads, int dim_head, int n, const 
 size_t p2pb_conv3d_k3_wgrad_ws_floats(int b, int cin, int cout, int r, int math);
 int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float *x, const float *dy, float *dw, float *db,
                          float *ws, int math, void *stream);
+/* The same weight gradient for a PVConv's FIRST convolution, whose operand x is zero outside the occupied voxels: K runs over
+ * the occupied voxels only (cnt i32[b, r^3] = avg_voxelize's counts; n = points per cloud, an upper bound of their number).
+ * Exact fp32 products, deterministic. ws: p2pb_conv3d_k3_wgrad_occ_ws_floats(b, cin, cout, r, n) floats. db may be NULL. */
+size_t p2pb_conv3d_k3_wgrad_occ_ws_floats(int b, int cin, int cout, int r, int n);
+int p2pb_conv3d_k3_wgrad_occ(int b, int cin, int cout, int r, int n, const float *x, const float *dy, const int *cnt, float *dw,
+                             float *db, float *ws, void *stream);
 size_t p2pb_pointwise_wgrad_ws_floats(int b, int cin, int cout, int npos, int math);
 int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const float *x, const float *dy, float *dw, float *db,
                          float *ws, int math, void *stream);

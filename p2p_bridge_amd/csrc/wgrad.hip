@@ -559,3 +559,179 @@ extern "C" int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const fl
                      ws, dw, db);
   return p2pb_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a PVConv's FIRST convolution, sparse in K (round 5; review r4 item 4, first step).
+// Its operand X is the voxelised point features: zero outside the occupied voxels -- 2048 points in a 32^3 grid occupy <= 6 % of
+// it -- so   dW[co][ci][tap] = sum_b sum_{v' occupied} dY[b, co, v' - off(tap)] * X[b, ci, v']   has K = (occupied voxels), not r^3.
+// The dense kernel above spends 399 us per launch on the r = 32 layers of the config-3 step (1.6 ms of its 14.8 ms) multiplying
+// zeros. Here: (1) the occupied voxels of every sample are listed (ascending) from avg_voxelize's counts; (2) X is gathered at
+// them into Xocc[b][k][ci], dY is transposed once to voxel-major dYt[b][v][co] (a voxel's channels contiguous: the 27 shifted
+// reads of an occupied voxel are 27 contiguous rows) and its bias sums are taken on the way; (3) workgroup (sample x K-split, tap,
+// 64 x 64 channel tile) walks its occupied voxels 32 at a time -- rows of dYt (zero outside the grid) and of Xocc through LDS -- and
+// accumulates a 4 x 4 block per thread in exact fp32 FMAs, in voxel order; (4) wgrad_reduce_kernel adds the partials in split order.
+// Deterministic, exact fp32 products (the dense bf16x3 form keeps 16 + 8 bits per operand).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void wg_occ_list_kernel(int r3, int n, const int *__restrict__ cnt, int *__restrict__ occ,
+                                                           int *__restrict__ nocc) {
+  __shared__ int sc[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int *c = cnt + (size_t)b * r3;
+  const int per = (r3 + 1023) / 1024, beg = t * per, end = min(beg + per, r3);
+  int k = 0;
+  for (int v = beg; v < end; ++v) k += c[v] > 0;
+  sc[t] = k;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan (Hillis-Steele)
+    const int y = t >= d ? sc[t - d] : 0;
+    __syncthreads();
+    sc[t] += y;
+    __syncthreads();
+  }
+  int pos = sc[t] - k;
+  if (t == 1023) nocc[b] = min(sc[t], n);
+  for (int v = beg; v < end; ++v)
+    if (c[v] > 0) {
+      if (pos < n) occ[(size_t)b * n + pos] = v;
+      ++pos;
+    }
+}
+
+__global__ __launch_bounds__(256) void wg_xocc_kernel(int cin, int r3, int n, const float *__restrict__ x, const int *__restrict__ occ,
+                                                      const int *__restrict__ nocc, float *__restrict__ xocc) {
+  const int b = blockIdx.y;
+  const size_t total = (size_t)nocc[b] * cin;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    const int k = (int)(e / cin), ci = (int)(e % cin);
+    xocc[((size_t)b * n + k) * cin + ci] = x[((size_t)b * cin + ci) * r3 + occ[(size_t)b * n + k]];
+  }
+}
+
+// dy f32[b, co, r3] -> dyt f32[b, r3, co] (32 x 32 LDS tiles)
+__global__ __launch_bounds__(256) void wg_dyt_kernel(int co, int r3, const float *__restrict__ dy, float *__restrict__ dyt) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, v0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float *src = dy + (size_t)b * co * r3;
+  float *dst = dyt + (size_t)b * co * r3;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int cc = c0 + ty + 8 * k, vv = v0 + tx;
+    t[ty + 8 * k][tx] = (cc < co && vv < r3) ? src[(size_t)cc * r3 + vv] : 0.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int vv = v0 + ty + 8 * k, cc = c0 + tx;
+    if (cc < co && vv < r3) dst[(size_t)vv * co + cc] = t[tx][ty + 8 * k];
+  }
+}
+
+// bias sums of sample b into the partial row of its first K-split, zeros into its other splits (fixed order: 256 strided
+// partials + tree)
+__global__ __launch_bounds__(256) void wg_bias_rows_kernel(int co, int r3, int S, size_t row, size_t nw, const float *__restrict__ dy,
+                                                           float *__restrict__ part) {
+  __shared__ float red[256];
+  const int c = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+  const float *src = dy + ((size_t)b * co + c) * r3;
+  float s = 0.0f;
+  for (int v = t; v < r3; v += 256) s += src[v];
+  red[t] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if (t < d) red[t] += red[t + d];
+    __syncthreads();
+  }
+  if (t < S) part[((size_t)b * S + t) * row + nw + c] = t == 0 ? red[0] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void conv3d_k3_wgrad_occ_kernel(int r, int n, int cin, int cout, int S, size_t row,
+                                                                  const float *__restrict__ dyt, const float *__restrict__ xocc,
+                                                                  const int *__restrict__ occ, const int *__restrict__ nocc,
+                                                                  float *__restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float As[32][64];
+  __shared__ __attribute__((aligned(16))) float Bs[32][64];
+  __shared__ int su[32];
+  const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+  const int b = blockIdx.x / S, s = blockIdx.x % S, tap = blockIdx.y;
+  const int cit = (cin + 63) / 64;
+  const int co0 = (blockIdx.z / cit) * 64, ci0 = (blockIdx.z % cit) * 64;
+  const int r3 = r * r * r;
+  const int od = tap / 9 - 1, oh = (tap / 3) % 3 - 1, ow = tap % 3 - 1;
+  const int no = nocc[b];
+  const int L = (no + S - 1) / S, k0 = s * L, k1 = min(no, k0 + L);
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0f;
+  for (int kk = k0; kk < k1; kk += 32) {
+    __syncthreads();
+    if (t < 32) {  // the dY voxel each of the chunk's occupied voxels meets under this tap, or -1 outside the grid
+      int u = -1;
+      if (kk + t < k1) {
+        const int v = occ[(size_t)b * n + kk + t];
+        const int d = v / (r * r) - od, h = (v / r) % r - oh, w = v % r - ow;
+        if ((unsigned)d < (unsigned)r && (unsigned)h < (unsigned)r && (unsigned)w < (unsigned)r) u = (d * r + h) * r + w;
+      }
+      su[t] = u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = t; e < 32 * 64; e += 256) {
+      const int k = e >> 6, c = e & 63;
+      const int u = su[k];
+      As[k][c] = (u >= 0 && co0 + c < cout) ? dyt[((size_t)b * r3 + u) * cout + co0 + c] : 0.0f;
+      Bs[k][c] = (kk + k < k1 && ci0 + c < cin) ? xocc[((size_t)b * n + kk + k) * cin + ci0 + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const float4 a = *(const float4 *)&As[k][4 * ty], bb = *(const float4 *)&Bs[k][4 * tx];
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __fmaf_rn(av[i], bv[j], acc[i][j]);
+    }
+  }
+  float *po = part + (size_t)blockIdx.x * row + (size_t)tap * cout * cin;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + 4 * ty + i, ci = ci0 + 4 * tx + j;
+      if (co < cout && ci < cin) po[(size_t)co * cin + ci] = acc[i][j];
+    }
+}
+
+static int wg_occ_splits(int b, int cin, int cout) {
+  const long wgs = (long)b * 27 * ((cout + 63) / 64) * ((cin + 63) / 64);
+  long S = (400 + wgs - 1) / wgs;
+  return (int)(S < 1 ? 1 : S > 8 ? 8 : S);
+}
+// floats of workspace: partial rows | dYt | Xocc | occ (ints) | nocc (ints)
+extern "C" size_t p2pb_conv3d_k3_wgrad_occ_ws_floats(int b, int cin, int cout, int r, int n) {
+  const size_t r3 = (size_t)r * r * r, row = (size_t)cout * cin * 27 + cout;
+  return (size_t)b * wg_occ_splits(b, cin, cout) * row + (size_t)b * r3 * cout + (size_t)b * n * cin + (size_t)b * n + b + 16;
+}
+// x f32[b,cin,r,r,r] (zero outside the voxels with cnt > 0), dy f32[b,cout,r,r,r], cnt i32[b,r^3] (avg_voxelize's counts), n = points
+// per cloud (an upper bound of the occupied voxels) -> dw f32[cout,cin,3,3,3], db f32[cout] | NULL
+extern "C" int p2pb_conv3d_k3_wgrad_occ(int b, int cin, int cout, int r, int n, const float *x, const float *dy, const int *cnt,
+                                        float *dw, float *db, float *ws, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || r <= 0 || n <= 0 || !x || !dy || !cnt || !dw || !ws) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int r3 = r * r * r, S = wg_occ_splits(b, cin, cout), ns = b * S;
+  const size_t nw = (size_t)cout * cin * 27, row = nw + cout;
+  float *part = ws, *dyt = part + (size_t)ns * row, *xocc = dyt + (size_t)b * r3 * cout;
+  int *occ = (int *)(xocc + (size_t)b * n * cin), *nocc = occ + (size_t)b * n;
+  hipLaunchKernelGGL(wg_occ_list_kernel, dim3(b), dim3(1024), 0, s, r3, n, cnt, occ, nocc);
+  hipLaunchKernelGGL(wg_xocc_kernel, dim3((unsigned)cdiv((long)n * cin, 256), b), dim3(256), 0, s, cin, r3, n, x, occ, nocc, xocc);
+  hipLaunchKernelGGL(wg_dyt_kernel, dim3(cdiv(r3, 32), cdiv(cout, 32), b), dim3(256), 0, s, cout, r3, dy, dyt);
+  hipLaunchKernelGGL(wg_bias_rows_kernel, dim3(cout, b), dim3(256), 0, s, cout, r3, S, row, nw, dy, part);
+  hipLaunchKernelGGL(conv3d_k3_wgrad_occ_kernel, dim3(ns, 27, ((cout + 63) / 64) * ((cin + 63) / 64)), dim3(256), 0, s, r, n, cin, cout,
+                     S, row, dyt, xocc, occ, nocc, part);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(nw + cout), 256)), dim3(256), 0, s, ns, 27, (size_t)cout * cin,
+                     (size_t)cout, part, dw, db);
+  return p2pb_launch_status();
+}

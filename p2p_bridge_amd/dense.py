@@ -22,6 +22,7 @@ from ._lib import call, lib, ptr, stream_ptr
 
 _i = ctypes.c_int
 F32 = torch.float32
+SPARSE_WGRAD = True  # weight gradient of a PVConv's first convolution over the occupied voxels only (tests flip it to compare)
 USE_HIP = True  # tools/exp_train_step.py flips this to time the torch / MIOpen dense layers on the same graph
 _MATH = {"bf16x3": 0, "bf16x6": 1, "fp32": 2}
 
@@ -121,11 +122,12 @@ class _Conv3dK3(torch.autograd.Function):
     """-> (y, GroupNorm partials of y [B,nslots,Cout,2] or an empty tensor)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, conv, want_stats=False):
+    def forward(ctx, x, weight, bias, conv, want_stats=False, occ=None):
         x = x.contiguous()
         y, st = fused.conv3d_k3(x, conv, stats=want_stats, compact=True)
         ctx.save_for_backward(x)
         ctx.conv = conv
+        ctx.occ = occ  # (counts, points per cloud) of the voxelisation that produced x, or None
         st = st if st is not None else _empty(x)
         ctx.mark_non_differentiable(st)
         ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output's gradient: a fill launch per layer)
@@ -134,7 +136,7 @@ class _Conv3dK3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gst=None):
         if gy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         (x,) = ctx.saved_tensors
         conv = ctx.conv
         gy = gy.contiguous()
@@ -144,9 +146,18 @@ class _Conv3dK3(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             want_b = ctx.needs_input_grad[2]
 
+            occ = ctx.occ if (ctx.occ is not None and r >= 16 and SPARSE_WGRAD) else None
+
             def wgrad():
                 gw = torch.empty(co, ci, 3, 3, 3, dtype=F32, device=x.device)
                 gb = torch.empty(co, dtype=F32, device=x.device) if want_b else None
+                if occ is not None:  # x is zero outside the occupied voxels: K = occupied voxels (csrc/wgrad.hip, exact fp32)
+                    cnt, npts = occ
+                    ws = torch.empty(lib().p2pb_conv3d_k3_wgrad_occ_ws_floats(_i(b), _i(ci), _i(co), _i(r), _i(npts)), dtype=F32,
+                                     device=x.device)
+                    call("p2pb_conv3d_k3_wgrad_occ", _i(b), _i(ci), _i(co), _i(r), _i(npts), ptr(x), ptr(gy), ptr(cnt), ptr(gw),
+                         ptr(gb), ptr(ws), stream_ptr())
+                    return gw, gb
                 math = _i(train_math())
                 ws = torch.empty(lib().p2pb_conv3d_k3_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(r), math), dtype=F32,
                                  device=x.device)
@@ -161,7 +172,7 @@ class _Conv3dK3(torch.autograd.Function):
                 # force_split: the adjoint pack exists only in the split form (the kernel reads the forward weight transposed
                 # and tap-reflected), so the data gradient runs bf16x6 under P2PB_CONV_MATH=fp32 too
                 gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True, force_split=True)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 class _Pointwise(torch.autograd.Function):
@@ -252,7 +263,7 @@ def conv3d_k3(x, conv: torch.nn.Conv3d, want_stats=False):
     """nn.Conv3d(kernel 3, stride 1, padding 1) applied to x f32[B,Cin,r,r,r], r in {4, 8, 16, 32}"""
     if not enabled(x) or x.shape[2] not in (4, 8, 16, 32):
         return (conv(x), None) if want_stats else conv(x)
-    y, st = _Conv3dK3.apply(x, conv.weight, conv.bias, conv, want_stats)
+    y, st = _Conv3dK3.apply(x, conv.weight, conv.bias, conv, want_stats, getattr(x, "_p2pb_occ", None))
     return (y, st) if want_stats else y
 
 

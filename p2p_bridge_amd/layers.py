@@ -26,6 +26,7 @@ class AvgVoxelization(Function):
         b, c, _ = features.shape
         out, indices, counts = _ext.avg_voxelize_forward(features, coords, resolution)
         ctx.save_for_backward(indices, counts)
+        AvgVoxelization.last_occupancy = (counts, features.shape[2])
         return out.view(b, c, resolution, resolution, resolution)
 
     @staticmethod
@@ -109,7 +110,16 @@ class NeighborInterpolation(Function):
         return None, None, g
 
 
-avg_voxelize = AvgVoxelization.apply
+
+
+def avg_voxelize(features, coords, resolution):
+    """AvgVoxelization.apply; the grid carries its occupancy (`_p2pb_occ` = (counts i32[B, r^3], points per cloud)) for the
+    convolution that consumes it: dense.conv3d_k3's weight gradient then runs over the occupied voxels only (csrc/wgrad.hip)"""
+    out = AvgVoxelization.apply(features, coords, resolution)
+    out._p2pb_occ = AvgVoxelization.last_occupancy
+    AvgVoxelization.last_occupancy = None
+    return out
+
 trilinear_devoxelize = TrilinearDevoxelization.apply
 pvcnn_grouping = Grouping.apply
 pvcnn_gather = Gather.apply

@@ -207,3 +207,42 @@ def test_conv_norm_act_forward_backward(kind, b, ci, co, shape, swish):
             assert err < 1e-5 * max(1.0, got["x"].abs().max().item() * x[0, 0].numel() ** 0.5), (k, err)
             continue
         assert _rel(got[k], v.grad) < tol, (k, _rel(got[k], v.grad))
+
+
+@pytest.mark.parametrize("b,ci,co,r,n", [(3, 35, 32, 32, 2048), (2, 64, 64, 32, 1500), (4, 128, 64, 16, 512), (2, 24, 40, 16, 300),
+                                         (1, 8, 8, 32, 1)])
+def test_sparse_weight_gradient_of_a_first_convolution(b, ci, co, r, n):
+    """round 5 (csrc/wgrad.hip conv3d_k3_wgrad_occ_kernel): the weight gradient of a PVConv's first convolution over the occupied
+    voxels only -- x = avg_voxelize(features) is zero elsewhere -- against torch's fp64 convolution backward and against the dense
+    kernel; grid-boundary voxels, ragged channel counts, a single point"""
+    from p2p_bridge_amd import dense, layers as L
+
+    torch.manual_seed(b * 1000 + ci)
+    feats = torch.randn(b, ci, n, device="cuda", requires_grad=True)
+    vox = torch.randint(0, r, (b, 3, n), device="cuda", dtype=torch.int32)
+    vox[:, :, : max(1, n // 8)] = torch.randint(0, 2, (b, 3, max(1, n // 8)), device="cuda", dtype=torch.int32) * (r - 1)  # corners / faces
+    conv = torch.nn.Conv3d(ci, co, 3, padding=1).cuda()
+    gy = torch.randn(b, co, r, r, r, device="cuda")
+    grads = {}
+    for sparse in (True, False):
+        dense.SPARSE_WGRAD = sparse
+        try:
+            x = L.avg_voxelize(feats, vox, r)
+            assert getattr(x, "_p2pb_occ", None) is not None
+            y = dense.conv3d_k3(x, conv)
+            gw, gb, gf = torch.autograd.grad(y, [conv.weight, conv.bias, feats], gy)
+        finally:
+            dense.SPARSE_WGRAD = True
+        grads[sparse] = (gw, gb, gf)
+    x64 = L.avg_voxelize(feats, vox, r).detach().double()
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    b64 = conv.bias.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.conv3d(x64, w64, b64, padding=1)
+    rw, rb = torch.autograd.grad(y64, [w64, b64], gy.double())
+    gw, gb, gf = grads[True]
+    scale = rw.abs().max().item() + 1e-30
+    assert (gw.double() - rw).abs().max().item() < 2e-6 * scale * max(1.0, (n * b) ** 0.5 / 10), (gw.double() - rw).abs().max().item() / scale
+    assert torch.allclose(gb.double(), rb, rtol=1e-4, atol=1e-3 * rb.abs().max().item())
+    # the dense kernel (bf16x3 by default) agrees to its own precision; the data gradient is the same launch either way
+    assert (grads[False][0].double() - rw).abs().max().item() < 2e-2 * scale
+    assert torch.equal(gf, grads[False][2])
