@@ -24,8 +24,9 @@ FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=
          "-Wall", "-Wno-unused-function"]
 
 
-# conv3d.hip is two translation units (its header): the second holds the bf16x6 instantiations of the split kernels
-EXTRA_UNITS = {"conv3d.hip": [("_bf16x6", ["-DCONV_TU=6"])]}
+# conv3d.hip is three translation units (its header): the second holds the bf16x6 instantiations of the split kernels, the third
+# the bf16x3 ones of the training data gradient
+EXTRA_UNITS = {"conv3d.hip": [("_bf16x6", ["-DCONV_TU=6"]), ("_bf16x3", ["-DCONV_TU=3"])]}
 
 
 def _newer(a, bs):

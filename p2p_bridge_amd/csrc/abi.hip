@@ -18,7 +18,9 @@ extern "C" int p2pb_set_split_terms(int terms) {
   return 0;
 }
 extern "C" int p2pb_set_split_terms_thread(int terms) {  // 0 clears the calling thread's override
-  if (terms != 0 && terms != SPLIT_BF16X6 && terms != SPLIT_F16X3) return P2PB_EINVAL;
+  // SPLIT_BF16X3 (two bf16 terms, three products, <= 3 * 2^-18 per product -- above the TF32 the reference trains in): only as
+  // a thread override, only for the plain dense forms the training data gradient launches (anything else refuses it)
+  if (terms != 0 && terms != SPLIT_BF16X6 && terms != SPLIT_F16X3 && terms != SPLIT_BF16X3) return P2PB_EINVAL;
   tl_split_terms = terms;
   return 0;
 }

@@ -34,15 +34,18 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Translation units: this file is compiled TWICE (p2p_bridge_amd/build.py), in parallel. The primary object holds
+// Translation units: this file is compiled THREE times (p2p_bridge_amd/build.py), in parallel. The primary object holds
 // everything and instantiates the split kernels in the default f16x3 arithmetic; -DCONV_TU=6 builds only the bf16x6
-// instantiations of the split kernels behind two bridge functions (conv3d_tu6_split / conv3d_tu6_compact) -- every
-// extern "C" entry point is compiled out there, every non-template kernel is static.
+// instantiations of the split kernels behind two bridge functions (conv3d_tu6_split / conv3d_tu6_compact); -DCONV_TU=3
+// only the bf16x3 instantiations the training data gradient launches (dense split kernel, channel-major, no operand
+// transform: conv3d_tu3_split) -- every extern "C" entry point is compiled out there, every non-template kernel is static.
 #ifndef CONV_TU
 #define CONV_TU 0
 #endif
 #if CONV_TU == 6
 #define CONV_TERMS SPLIT_BF16X6
+#elif CONV_TU == 3
+#define CONV_TERMS SPLIT_BF16X3
 #else
 #define CONV_TERMS SPLIT_F16X3
 #endif
@@ -1018,7 +1021,7 @@ static __global__ void conv3d_pack_kernel(int cout, int cin, int nchunk, int cou
   }
 }
 
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" int p2pb_conv3d_k3_pack_weights(int cout, int cin, const float *w, float *wt_packed, void *stream) {
   if (cout <= 0 || cin <= 0) return P2PB_EINVAL;
   const int nchunk = (cin + CONV_CK - 1) / CONV_CK, cout_pad = (cout + 63) / 64 * 64;
@@ -1072,7 +1075,7 @@ extern "C" int p2pb_conv3d_k3_pack_weights_split_amax(int cout, int cin, const f
 
 static int conv_bricks(int r) { return r == 32 ? 128 : r == 16 ? 16 : r == 8 ? 2 : 1; }  // both geometries
 
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" size_t p2pb_conv3d_k3_stats_floats(int b, int cout, int r) {
   return (size_t)b * conv_bricks(r) * 4 * cout * 2;
 }
@@ -1207,7 +1210,7 @@ static __global__ __launch_bounds__(1024) void far_field_kernel(int cin, int cou
 
 // a f32[b,cin] = far-field operand constants, k_out f32[b,27,cout] = per-boundary-class output constants,
 // tap_ws f32[b,27,cout] scratch
-#if CONV_TU != 6
+#if CONV_TU == 0
 static bool gn_shape_ok(int c, int groups, const float *style, int style_stride) {
   return groups > 0 && c % groups == 0 && c / groups <= 256 && !(style && style_stride < 2 * c);
 }
@@ -1281,8 +1284,12 @@ static int conv_launch(int b, int cin, int cout, const float *in, const float *w
   return p2pb_launch_status();
 }
 
-// the bf16x6 instantiations live in the -DCONV_TU=6 object
+// the bf16x6 / bf16x3 instantiations live in the -DCONV_TU=6 / -DCONV_TU=3 objects
 int conv3d_tu6_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
+                     const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
+                     const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
+                     float *stats_part, bool cl, hipStream_t s);
+int conv3d_tu3_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
                      const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                      const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
                      float *stats_part, bool cl, hipStream_t s);
@@ -1295,10 +1302,15 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
   dim3 grid(conv_bricks(R), (cout + 32 * MT - 1) / (32 * MT), b);
   if (brick_list) grid = dim3(conv_bricks(R) * b, (cout + 32 * MT - 1) / (32 * MT), 1);
   const unsigned short *w = (const unsigned short *)wt;
-#if CONV_TU != 6
+#if CONV_TU == 0
   if (p2pb_g_split_terms == SPLIT_BF16X6) {
     if (pre) return P2PB_EINVAL;  // (the S format is the f16x3 arithmetic's)
     return conv3d_tu6_split(R, MT, b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero,
+                            brick_list, brick_count, out, stats_part, cl, s);
+  }
+  if (p2pb_g_split_terms == SPLIT_BF16X3) {  // the training data gradient's form only: plain operand, channel-major
+    if (pre || in_scale || in_sub || cl || brick_list) return P2PB_EINVAL;
+    return conv3d_tu3_split(R, MT, b, cin, cout, in, wt, bias, out_class, in_scale, in_shift, in_swish, in_sub, skip_zero,
                             brick_list, brick_count, out, stats_part, cl, s);
   }
 #endif
@@ -1308,7 +1320,7 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
                      brick_count, out, stats_part)
 #define LAUNCH(XF, CL) LAUNCHT(XF, CL, CONV_TERMS)
   if (pre) {  // `in` is the pre-split operand grid (S format): f16x3, voxel-major, transform already applied
-#if CONV_TU != 6
+#if CONV_TU == 0
     if constexpr (R >= 8) {
       if (!cl || in_scale || in_sub) return P2PB_EINVAL;
       hipLaunchKernelGGL((conv3d_k3_split_kernel<R, true, MT, false, true, SPLIT_F16X3, true>), grid, dim3(256), 0, s,
@@ -1319,6 +1331,10 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
 #endif
     return P2PB_EINVAL;
   }
+#if CONV_TU == 3
+  if (in_scale != nullptr || cl) return P2PB_EINVAL;
+  LAUNCH(false, false);
+#else
   if (in_scale != nullptr) {
     if (cl) LAUNCH(true, true);
     else LAUNCH(true, false);
@@ -1326,12 +1342,17 @@ static int conv_launch_split(int b, int cin, int cout, const float *in, const vo
     if (cl) LAUNCH(false, true);
     else LAUNCH(false, false);
   }
+#endif
 #undef LAUNCH
 #undef LAUNCHT
   return p2pb_launch_status();
 }
+#if CONV_TU != 0
 #if CONV_TU == 6
 int conv3d_tu6_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
+#else
+int conv3d_tu3_split(int r, int mt, int b, int cin, int cout, const float *in, const void *wt, const float *bias,
+#endif
                      const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                      const float *in_sub, int skip_zero, const int *brick_list, const int *brick_count, float *out,
                      float *stats_part, bool cl, hipStream_t s) {
@@ -1427,7 +1448,7 @@ static __global__ __launch_bounds__(1024) void brick_compact_kernel(int total, c
 
 // lists i32[4][b*NBRICK] = {active conv0, inactive conv0, active conv1, inactive conv1}, counts i32[4];
 // flags_ws: b*NBRICK*2 bytes of scratch. r in {16, 32}.
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" int p2pb_conv3d_brick_lists(int b, int r, const int *cnt, unsigned char *flags_ws, int *lists, int *counts,
                                        void *stream) {
   if (b <= 0 || (r != 16 && r != 32)) return P2PB_EINVAL;
@@ -1527,7 +1548,7 @@ __global__ __launch_bounds__(256) void conv3d_fill_kernel(int cout, const float 
 // bias per boundary class; stats_part (optional) receives per-(b, slot, cout) {sum, sum of squares} of the
 // output. flags: bit 0 = skip all-zero operand tiles (exact), bit 1 = compact 4x8x8 bricks, bit 2 = wt_packed is
 // the split pack (p2pb_conv3d_k3_pack_weights_split) -> bf16x6 kernel. r in {4,8,16,32}.
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" int p2pb_conv3d_k3_forward(int b, int cin, int cout, int r, const float *in, const float *wt_packed,
                                       const float *bias, const float *in_scale, const float *in_shift, int in_swish,
                                       float *out, float *stats_part, void *stream) {
@@ -1588,7 +1609,7 @@ extern "C" int p2pb_conv3d_k3_forward_ex(int b, int cin, int cout, int r, const 
 
 // list-driven sparse form: MFMA workgroups only for the `active` (sample, brick) pairs, constants for the
 // `inactive` ones (lists from p2pb_conv3d_brick_lists). Compact geometry; r in {16, 32}.
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *in, const void *wt_packed,
                                              const float *bias, const float *out_class, const float *in_scale,
                                              const float *in_shift, int in_swish, const float *in_sub, int flags,
@@ -1732,7 +1753,7 @@ __global__ __launch_bounds__(256) void active_lists_kernel(const int *__restrict
 }
 
 // lists u8[2][b][NBRICK][256], counts i32[2][b][NBRICK]; r in {8, 16, 32}
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned char *lists, int *counts, void *stream) {
   if (b <= 0 || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -2124,7 +2145,8 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 
 // in f32[b,r,r,r,cin] -> out f32[b,r,r,r,cout] (voxel-major), wt = split pack; alist/acount = ONE set of
 // p2pb_conv3d_active_lists (D1 for a first convolution, D2 for a second one in far-field form). r in {8,16,32}.
-// the bf16x6 instantiations live in the -DCONV_TU=6 object
+// the bf16x6 instantiations live in the -DCONV_TU=6 object (the -DCONV_TU=3 object has no compact form)
+#if CONV_TU != 3
 int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                        const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                        const float *in_sub, const unsigned char *alist, const int *acount, float *out, float *stats_part,
@@ -2134,7 +2156,8 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
                                const float *in_sub, const unsigned char *alist, const int *acount, float *out,
                                float *stats_part, hipStream_t s, bool pre = false) {
   const bool xf = in_scale != nullptr;
-#if CONV_TU != 6
+#if CONV_TU == 0
+  if (p2pb_g_split_terms == SPLIT_BF16X3) return P2PB_EINVAL;  // (the data gradient's arithmetic: dense form only)
   if (pre && (p2pb_g_split_terms == SPLIT_BF16X6 || xf || in_sub)) return P2PB_EINVAL;
   if (p2pb_g_split_terms == SPLIT_BF16X6)
     return conv3d_tu6_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
@@ -2155,7 +2178,7 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
     if (xf) LAUNCH(RR, 2, true);                                 \
     else LAUNCH(RR, 2, false);                                   \
   }
-#if CONV_TU != 6
+#if CONV_TU == 0
 #define GOPRE(RR)                                                                                                          \
   do {                                                                                                                     \
     if (wm1)                                                                                                               \
@@ -2187,8 +2210,9 @@ int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const v
                              out, stats_part, s);
 }
 #endif
+#endif  // CONV_TU != 3
 
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split,
                                               const float *bias, const float *out_class, const float *in_scale,
                                               const float *in_shift, int in_swish, const float *in_sub,
@@ -2200,7 +2224,7 @@ extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, c
 }
 #endif
 
-#if CONV_TU != 6
+#if CONV_TU == 0
 // the compact form on a pre-split operand grid (S format, see PreStage): in_split u32x4[b][r^3][ceil(cin/16)][4]
 extern "C" int p2pb_conv3d_k3_forward_compact_pre(int b, int cin, int cout, int r, const void *in_split,
                                                   const void *wt_split, const float *bias, const float *out_class,
@@ -2310,7 +2334,7 @@ static __global__ __launch_bounds__(256) void gn_affine_kernel(int c, int groups
 
 // part: f32[b, nslots, c, 2]; gamma/beta f32[c] or NULL; style = rows of (factor[c] | bias[c]) with a row pitch of
 // style_stride floats (a column slice of the one style GEMM of the evaluation), or NULL -> scale/shift/chmean f32[b,c]
-#if CONV_TU != 6
+#if CONV_TU == 0
 // (for the producers of other translation units that were handed a finisher they cannot run themselves)
 int p2pb_gn_affine_launch(int b, int c, int nslots, const float *part, const GnFinish &f, hipStream_t s) {
   hipLaunchKernelGGL(gn_affine_kernel, dim3(f.groups, b), dim3(256), 0, s, c, f.groups, nslots, f.count_per_channel, part, f.gamma,
@@ -2418,7 +2442,7 @@ static __global__ __launch_bounds__(1024) void pvconv_tail_kernel(int c, int hid
   }
 }
 
-#if CONV_TU != 6
+#if CONV_TU == 0
 // part2 f32[b, nslots2, c, 2] + its norm (count2 = positions per channel, groups2, gamma2, beta2, style2 rows of 2c floats or NULL)
 // -> aff_a, aff_b f32[b, c] (SE3d gate from w1 f32[hidden, c], w2 f32[c, hidden]; hidden == 0: none); partp (may be NULL)
 // f32[b, nslotsp, cp, 2] + its norm -> scale_p, shift_p f32[b, cp]
@@ -2444,7 +2468,7 @@ extern "C" int p2pb_pvconv_tail(int b, int c, int hidden, const float *part2, in
 }
 #endif
 
-#if CONV_TU != 6
+#if CONV_TU == 0
 extern "C" int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,
                                    const float *scale, const float *shift, float *aff_a, float *aff_b, void *stream) {
   if (b <= 0 || c <= 0 || hidden <= 0) return P2PB_EINVAL;

@@ -1132,6 +1132,13 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
     if (mode == SPLIT_F16X3) LAUNCHW(XF, PL, WM, NB, SPLIT_F16X3);     \
     else LAUNCHW(XF, PL, WM, NB, 6);                                   \
   } while (0)
+  if (mode == SPLIT_BF16X3) {  // the training data gradient's arithmetic: plain operand, no pooling, channel-major output
+    if (xf || minmax || out_pm) return P2PB_EINVAL;
+    p2pb_note_pointwise_form(cin, cout, P, wm4 ? P2PB_FORM_PW_SPLIT256 : P2PB_FORM_PW_SPLIT128);
+    if (wm4) LAUNCHW(false, 0, 4, 1, SPLIT_BF16X3);
+    else LAUNCHW(false, 0, 2, 1, SPLIT_BF16X3);
+    return p2pb_launch_status();
+  }
 #define LAUNCH(XF, PL)                    \
   do {                                    \
     if (wm4) LAUNCHF(XF, PL, 4, 1);        \

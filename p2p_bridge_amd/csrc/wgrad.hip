@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(int nb, int cin, i
 // Workgroup = 64 co x 64 ci x ONE kd plane (9 taps): wave (m, n) owns the 32 x 32 tile (m, n) for those 9 taps =
 // 144 accumulator registers -> two waves per SIMD hide the load latency. Split over K as above.
 // ================================================================================================
+typedef float f32x4w __attribute__((ext_vector_type(4)));
 template <int NTERM>
 __device__ __forceinline__ void split_pair(float a, float b, unsigned (&t)[NTERM]) {
   unsigned p0, p1, p2;
@@ -249,67 +250,104 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16_kernel(int nb, in
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
   float bsum = 0.0f;
   const int total = nb * KG;
-  for (int g = split; g < total; g += nsplit) {
-    const int b = g / KG, q = (g % KG) * 16 + 8 * khalf;
-    float fa[8];
-    if (cok) load8(dy + ((size_t)b * cout + co) * R3 + q, true, fa);
-    else {
+  if constexpr (R >= 8) {
+    // Round 5: the loop used to wait for every load right behind its issue -- dY, then each of the three kh rows: four
+    // dependent memory round trips per K unit (~3 us) in front of 27 MFMAs (0.4 us); the r = 32 launches ran at 17 % of their
+    // own MFMA time. Now every load of unit g + nsplit is issued while unit g is multiplied: the raw registers of an operand
+    // are re-requested as soon as its fragments are split (one register set, >= 27 MFMAs of cover per load), through buffer
+    // descriptors whose out-of-range offset (0x80000000) returns the zero padding -- no exec-masked branch around a load,
+    // no select behind it. Same values, same order of products and additions: bit-identical partials.
+    const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)((size_t)nb * cout * R3 * 4), 0x00020000);
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)((size_t)nb * cin * R3 * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    float fa[8], f[3][8], lf[3], rt[3];
+    auto ld8 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off, float (&o)[8]) {
+      const f32x4w v0 = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+      const f32x4w v1 = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 16, 0));
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = 0.0f;
-    }
-    u32x4 a[NTERM];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      unsigned t[NTERM];
-      split_pair<NTERM>(fa[2 * i], fa[2 * i + 1], t);
-#pragma unroll
-      for (int s = 0; s < NTERM; ++s) a[s][i] = t[s];
-    }
-    if (want_bias) bsum += ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fa[4] + fa[5]) + (fa[6] + fa[7]));
-    const float *xrow = x + ((size_t)b * cin + (cik ? ci : 0)) * R3;
-    if (R >= 8) {
+      for (int i = 0; i < 4; ++i) o[i] = v0[i], o[4 + i] = v1[i];
+    };
+    auto issue_a = [&](int g) {
+      const int b = g / KG, q = (g % KG) * 16 + 8 * khalf;
+      const unsigned off = (cok && g < total) ? (unsigned)(((size_t)b * cout + co) * R3 + q) * 4u : OOB;
+      ld8(rsa, off, fa);
+    };
+    auto issue_row = [&](int g, int kh) {
+      const int b = g / KG, q = (g % KG) * 16 + 8 * khalf;
       const int d = q / (R * R), h = (q / R) % R, w = q % R;  // w is a multiple of 8
-      const int nd = d + kd - 1;
-      const bool dok = (unsigned)nd < (unsigned)R && cik;
+      const int nd = d + kd - 1, nh = h + kh - 1;
+      const bool rok = cik && g < total && (unsigned)nd < (unsigned)R && (unsigned)nh < (unsigned)R;
+      const unsigned off = rok ? (unsigned)(((size_t)b * cin + ci) * R3 + ((size_t)nd * R + nh) * R + w) * 4u : OOB;
+      ld8(rsx, off, f[kh]);
+      lf[kh] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (rok && w > 0) ? off - 4u : OOB, 0, 0));
+      rt[kh] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (rok && w + 8 < R) ? off + 32u : OOB, 0, 0));
+    };
+    issue_a(split);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) issue_row(split, kh);
+    for (int g = split; g < total; g += nsplit) {
+      const int gn = g + nsplit;
+      u32x4 a[NTERM];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned t[NTERM];
+        split_pair<NTERM>(fa[2 * i], fa[2 * i + 1], t);
+#pragma unroll
+        for (int s = 0; s < NTERM; ++s) a[s][i] = t[s];
+      }
+      if (want_bias) bsum += ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fa[4] + fa[5]) + (fa[6] + fa[7]));
+      __builtin_amdgcn_sched_barrier(0);
+      issue_a(gn);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const int nh = h + kh - 1;
-        const bool rok = dok && (unsigned)nh < (unsigned)R;
-        float f[8], left = 0.0f, right = 0.0f;
-        if (rok) {
-          const float *src = xrow + ((size_t)nd * R + nh) * R + w;
-          load8(src, true, f);
-          if (w > 0) left = src[-1];
-          if (w + 8 < R) right = src[8];
-        } else {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) f[i] = 0.0f;
-        }
         u32x4 fm[NTERM], fz[NTERM], fp[NTERM];  // kw = 0 (dw = -1), 1, 2
         unsigned t[NTERM];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          split_pair<NTERM>(f[2 * i], f[2 * i + 1], t);
+          split_pair<NTERM>(f[kh][2 * i], f[kh][2 * i + 1], t);
 #pragma unroll
           for (int s = 0; s < NTERM; ++s) fz[s][i] = t[s];
         }
-        split_pair<NTERM>(left, f[0], t);
+        split_pair<NTERM>(lf[kh], f[kh][0], t);
 #pragma unroll
         for (int s = 0; s < NTERM; ++s) fm[s][0] = t[s];
 #pragma unroll
         for (int i = 1; i < 4; ++i) {
-          split_pair<NTERM>(f[2 * i - 1], f[2 * i], t);
+          split_pair<NTERM>(f[kh][2 * i - 1], f[kh][2 * i], t);
 #pragma unroll
           for (int s = 0; s < NTERM; ++s) fm[s][i] = t[s], fp[s][i - 1] = t[s];
         }
-        split_pair<NTERM>(f[7], right, t);
+        split_pair<NTERM>(f[kh][7], rt[kh], t);
 #pragma unroll
         for (int s = 0; s < NTERM; ++s) fp[s][3] = t[s];
+        __builtin_amdgcn_sched_barrier(0);
+        issue_row(gn, kh);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_products<NTERM>(acc[kh * 3 + 0], a, fm);
         mfma_products<NTERM>(acc[kh * 3 + 1], a, fz);
         mfma_products<NTERM>(acc[kh * 3 + 2], a, fp);
       }
-    } else {  // R == 4: a fragment spans two h-rows of four voxels; gathered element-wise (64-voxel grids only)
+    }
+  } else {  // R == 4: a fragment spans two h-rows of four voxels; gathered element-wise (64-voxel grids only)
+    for (int g = split; g < total; g += nsplit) {
+      const int b = g / KG, q = (g % KG) * 16 + 8 * khalf;
+      float fa[8];
+      if (cok) load8(dy + ((size_t)b * cout + co) * R3 + q, true, fa);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = 0.0f;
+      }
+      u32x4 a[NTERM];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned t[NTERM];
+        split_pair<NTERM>(fa[2 * i], fa[2 * i + 1], t);
+#pragma unroll
+        for (int s = 0; s < NTERM; ++s) a[s][i] = t[s];
+      }
+      if (want_bias) bsum += ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fa[4] + fa[5]) + (fa[6] + fa[7]));
+      const float *xrow = x + ((size_t)b * cin + (cik ? ci : 0)) * R3;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -368,29 +406,7 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_bf16_kernel(int nb, in
   float bsum = 0.0f;
   const int KG = (npos + 15) / 16;
   const int total = nb * KG;
-  for (int g = split; g < total; g += nsplit) {
-    const int b = g / KG, p = (g % KG) * 16 + 8 * khalf;
-    float fa[8], fb[8];
-    const float *sa = dy + ((size_t)b * cout + (cok ? co : 0)) * npos + p;
-    const float *sb = x + ((size_t)b * cin + (cik ? ci : 0)) * npos + p;
-    if (p + 8 <= npos) {
-      load8(sa, vec, fa);
-      load8(sb, vec, fb);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        fa[i] = p + i < npos ? sa[i] : 0.0f;
-        fb[i] = p + i < npos ? sb[i] : 0.0f;
-      }
-    }
-    if (!cok) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = 0.0f;
-    }
-    if (!cik) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fb[i] = 0.0f;
-    }
+  auto consume = [&](const float (&fa)[8], const float (&fb)[8]) {
     if (want_bias) bsum += ((fa[0] + fa[1]) + (fa[2] + fa[3])) + ((fa[4] + fa[5]) + (fa[6] + fa[7]));
     u32x4 a[NTERM], bq[NTERM];
 #pragma unroll
@@ -404,6 +420,70 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_bf16_kernel(int nb, in
       for (int s = 0; s < NTERM; ++s) bq[s][i] = t[s];
     }
     mfma_products<NTERM>(acc, a, bq);
+  };
+  // rows of 16-byte pieces inside 2 GB tensors (every layer of the networks): the loads of the next three K units are in
+  // flight while one is multiplied (round 5: the loop used to issue two loads, wait a full memory round trip, run three
+  // MFMAs). Buffer descriptors: a piece past the row end, a channel past the tile, a unit past the end has the out-of-range
+  // offset and reads zeros -- adding nothing. Same order of products and additions as the plain loop below.
+  const bool piped = (npos & 3) == 0 && (size_t)nb * (cout > cin ? cout : cin) * npos * 4 < (1ull << 31) &&
+                     (((size_t)x | (size_t)dy) & 15) == 0;
+  if (piped) {
+    const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)((size_t)nb * cout * npos * 4), 0x00020000);
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)((size_t)nb * cin * npos * 4), 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    float ra[4][8], rb[4][8];
+    auto issue = [&](int g, float (&fa)[8], float (&fb)[8]) {
+      const int b = g / KG, p = (g % KG) * 16 + 8 * khalf;
+      const bool in = g < total;
+      const unsigned oa = (unsigned)((b * cout + co) * npos + p) * 4u, ob = (unsigned)((b * cin + ci) * npos + p) * 4u;
+      const bool h0 = in && p + 4 <= npos, h1 = in && p + 8 <= npos;
+      const f32x4w a0 = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsa, (h0 && cok) ? oa : OOB, 0, 0));
+      const f32x4w a1 = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsa, (h1 && cok) ? oa + 16u : OOB, 0, 0));
+      const f32x4w b0 = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsb, (h0 && cik) ? ob : OOB, 0, 0));
+      const f32x4w b1 = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(rsb, (h1 && cik) ? ob + 16u : OOB, 0, 0));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = a0[i], fa[4 + i] = a1[i], fb[i] = b0[i], fb[4 + i] = b1[i];
+    };
+    int g = split;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) issue(g + j * nsplit, ra[j], rb[j]);
+    while (g < total) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        issue(g + 3 * nsplit, ra[(j + 3) & 3], rb[(j + 3) & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(ra[j], rb[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        g += nsplit;
+        if (g >= total) break;
+      }
+    }
+  } else {
+    for (int g = split; g < total; g += nsplit) {
+      const int b = g / KG, p = (g % KG) * 16 + 8 * khalf;
+      float fa[8], fb[8];
+      const float *sa = dy + ((size_t)b * cout + (cok ? co : 0)) * npos + p;
+      const float *sb = x + ((size_t)b * cin + (cik ? ci : 0)) * npos + p;
+      if (p + 8 <= npos) {
+        load8(sa, vec, fa);
+        load8(sb, vec, fb);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          fa[i] = p + i < npos ? sa[i] : 0.0f;
+          fb[i] = p + i < npos ? sb[i] : 0.0f;
+        }
+      }
+      if (!cok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = 0.0f;
+      }
+      if (!cik) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fb[i] = 0.0f;
+      }
+      consume(fa, fb);
+    }
   }
   float *po = part + (size_t)split * ((size_t)cout * cin + cout);
 #pragma unroll
@@ -441,6 +521,78 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int nsplit, int ntap,
   else db[i - n] = s;
 }
 
+// ---- deferred reductions (round 5) -------------------------------------------------------------------------------------------
+// A training step has ~52 weight-gradient launches, each followed by its own wgrad_reduce launch of ~8 us (0.4 ms of a 13 ms step
+// whose chain is bound by the sum of its kernels' durations). Between p2pb_wgrad_defer(1) and p2pb_wgrad_flush() the entry points
+// below only note their reduction {partials, split count, outputs} on the calling thread; the flush adds them all in launches of
+// up to 16 jobs (the job table travels as a kernel argument: nothing to upload, nothing a captured graph would have to re-read).
+// Same sums in the same ascending split order. The caller keeps every workspace and output alive until the flush and does not
+// read a gradient before it (train.GraphedStep: around loss.backward(), in front of the optimiser).
+struct WgReduceJob {
+  const float *part;
+  float *dw, *db;
+  int nsplit, ntap;
+  size_t cc, nbias;
+};
+struct WgReduceBatch {
+  WgReduceJob j[16];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(WgReduceBatch bt) {
+  const WgReduceJob &jb = bt.j[blockIdx.y];
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t n = jb.cc * jb.ntap, row = n + jb.nbias;
+  if (i >= (jb.db ? row : n)) return;
+  const float *part = jb.part;
+  const int nsplit = jb.nsplit;
+  float s = 0.0f;  // (wgrad_reduce_kernel's loop: same order, same bits)
+  int k = 0;
+  for (; k + 8 <= nsplit; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + j) * row + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; k < nsplit; ++k) s += part[(size_t)k * row + i];
+  if (i < n) jb.dw[(i % jb.cc) * jb.ntap + i / jb.cc] = s;
+  else jb.db[i - n] = s;
+}
+#include <vector>
+static thread_local bool tl_wg_defer = false;
+static thread_local std::vector<WgReduceJob> tl_wg_jobs;
+static void wg_reduce(int nsplit, int ntap, size_t cc, size_t nbias, const float *part, float *dw, float *db, hipStream_t s) {
+  if (tl_wg_defer) {
+    tl_wg_jobs.push_back(WgReduceJob{part, dw, db, nsplit, ntap, cc, nbias});
+    return;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(cc * ntap + nbias), 256)), dim3(256), 0, s, nsplit, ntap, cc, nbias, part,
+                     dw, db);
+}
+extern "C" int p2pb_wgrad_defer(int on) {  // -> the previous state; switching off with reductions pending is refused
+  const int prev = tl_wg_defer ? 1 : 0;
+  if (!on && !tl_wg_jobs.empty()) return P2PB_EINVAL;
+  tl_wg_defer = on != 0;
+  return prev;
+}
+extern "C" int p2pb_wgrad_flush(void *stream) {  // -> number of reductions launched (>= 0) or an error (< 0)
+  hipStream_t s = (hipStream_t)stream;
+  const int njobs = (int)tl_wg_jobs.size();
+  for (int j0 = 0; j0 < njobs; j0 += 16) {
+    WgReduceBatch bt;
+    const int nj = njobs - j0 < 16 ? njobs - j0 : 16;
+    size_t most = 0;
+    for (int j = 0; j < 16; ++j) {
+      bt.j[j] = tl_wg_jobs[j0 + (j < nj ? j : 0)];
+      const size_t e = bt.j[j].cc * bt.j[j].ntap + bt.j[j].nbias;
+      if (j < nj && e > most) most = e;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)cdiv((long)most, 256), nj), dim3(256), 0, s, bt);
+  }
+  tl_wg_jobs.clear();
+  const int rc = p2pb_launch_status();
+  return rc != 0 ? (rc < 0 ? rc : -rc) : njobs;
+}
+
 // math: 0 = bf16x3 (default; "high" matmul precision, train.py:221), 1 = bf16x6 (fp32-faithful), 2 = exact fp32 MFMA
 static int conv_wgrad_units(int r, int math) { return math == 2 ? (r >= 8 ? (r / 4) * (r / 8) * (r / 8) : 1) : r * r * r / 16; }
 static int conv_wgrad_wgs_per_split(int cin, int cout, int math) {
@@ -450,7 +602,10 @@ static int conv_wgrad_wgs_per_split(int cin, int cout, int math) {
 // K-splits of a launch: enough workgroups to fill the chip (`target`), but the partials (written once, read once by
 // the reduction) stay below ~48 MB -- wide layers on small grids have few K units and large outputs
 static int wgrad_nsplit(long units, int wgs_per_split, int target, size_t out_floats) {
-  long s = (target + wgs_per_split - 1) / wgs_per_split;
+  // `target` = the workgroup slots of the chip for this kernel (256 CUs x 2 for the bf16 forms): the largest split count whose
+  // grid still fits them at once -- one more workgroup than slots is a second round for one CU and the launch waits for it
+  // (round 5: 384 workgroups of the r = 32 layers on 256 CUs left half the CUs with two and half with one)
+  long s = target >= wgs_per_split ? target / wgs_per_split : 1;
   const long cap = (long)((48u << 20) / (out_floats * sizeof(float)));
   if (s > cap) s = cap;
   if (s > units) s = units;
@@ -460,7 +615,7 @@ static int wgrad_nsplit(long units, int wgs_per_split, int target, size_t out_fl
 
 extern "C" size_t p2pb_conv3d_k3_wgrad_ws_floats(int b, int cin, int cout, int r, int math) {
   const int ns = wgrad_nsplit((long)b * conv_wgrad_units(r, math), conv_wgrad_wgs_per_split(cin, cout, math),
-                              math == 2 ? 512 : 384, (size_t)cout * cin * 27);
+                              512, (size_t)cout * cin * 27);
   return (size_t)ns * ((size_t)cout * cin * 27 + cout);
 }
 
@@ -498,7 +653,7 @@ extern "C" int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float
   if (r != 4 && r != 8 && r != 16 && r != 32) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ns = wgrad_nsplit((long)b * conv_wgrad_units(r, math), conv_wgrad_wgs_per_split(cin, cout, math),
-                              math == 2 ? 512 : 384, (size_t)cout * cin * 27);
+                              512, (size_t)cout * cin * 27);
   const bool bias = db != nullptr;
   if (math == 2) {
     switch (r) {
@@ -515,9 +670,7 @@ extern "C" int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float
       default: conv_wgrad_launch_bf16<4>(b, cin, cout, ns, math, x, dy, ws, bias, s); break;
     }
   }
-  const size_t n = (size_t)cout * cin * 27;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(n + cout), 256)), dim3(256), 0, s, ns, 27,
-                     (size_t)cout * cin, (size_t)cout, ws, dw, db);
+  wg_reduce(ns, 27, (size_t)cout * cin, (size_t)cout, ws, dw, db, s);
   return p2pb_launch_status();
 }
 
@@ -554,9 +707,7 @@ extern "C" int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const fl
     hipLaunchKernelGGL(pointwise_wgrad_bf16_kernel<2>, dim3(ns, cot * cit), dim3(256), 0, s, b, cin, cout, npos, ns, x,
                        dy, ws, bias ? ws : nullptr);
   }
-  const size_t n = (size_t)cout * cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(n + cout), 256)), dim3(256), 0, s, ns, 1, n, (size_t)cout,
-                     ws, dw, db);
+  wg_reduce(ns, 1, (size_t)cout * cin, (size_t)cout, ws, dw, db, s);
   return p2pb_launch_status();
 }
 
@@ -731,7 +882,6 @@ extern "C" int p2pb_conv3d_k3_wgrad_occ(int b, int cin, int cout, int r, int n, 
   hipLaunchKernelGGL(wg_bias_rows_kernel, dim3(cout, b), dim3(256), 0, s, cout, r3, S, row, nw, dy, part);
   hipLaunchKernelGGL(conv3d_k3_wgrad_occ_kernel, dim3(ns, 27, ((cout + 63) / 64) * ((cin + 63) / 64)), dim3(256), 0, s, r, n, cin, cout,
                      S, row, dyt, xocc, occ, nocc, part);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(nw + cout), 256)), dim3(256), 0, s, ns, 27, (size_t)cout * cin,
-                     (size_t)cout, part, dw, db);
+  wg_reduce(ns, 27, (size_t)cout * cin, (size_t)cout, part, dw, db, s);
   return p2pb_launch_status();
 }

@@ -39,6 +39,19 @@ def train_math() -> int:
     return _MATH[m]
 
 
+def dgrad_math() -> str:
+    """arithmetic of the data-gradient GEMMs (the adjoint convolutions), following P2PB_TRAIN_MATH like the weight gradients:
+    "bf16x3" (default) = two bf16 terms per operand, three products, <= 3 * 2^-18 per product -- 100 x finer than the TF32
+    the reference's cuDNN / cuBLAS backward runs under train.py:221, at half the matrix work of "bf16x6" (three terms, six
+    products: fp32-faithful). Gradients have no scale an fp16-pair split could rely on, hence bf16 terms either way."""
+    from . import _experiment
+
+    m = _experiment.get("dgrad_math")  # (A/B switch: "bf16x6" restores the six-product data gradient under the default)
+    if m in ("bf16x3", "bf16x6"):
+        return m
+    return "bf16x3" if train_math() == _MATH["bf16x3"] else "bf16x6"
+
+
 def enabled(x: torch.Tensor) -> bool:
     return USE_HIP and x.is_cuda and x.dtype == F32
 
@@ -86,6 +99,40 @@ def _on_wgrad_stream(fn, *operands):
         out = fn()
     _overlap["pending"].append(operands)
     return out
+
+
+# ---- deferred weight-gradient reductions ------------------------------------------------------------------------------------
+# Every weight-gradient launch ends with a small fixed-order sum of its K-split partials. Inside `deferred_wgrad_reduce()` the
+# library only notes those sums (include/p2pb_hip.h p2pb_wgrad_defer / _flush) and the exit performs them in a few batched
+# launches: ~50 launches of ~8 us less on the chain of a training step. The workspaces and gradient tensors are kept alive here
+# until then (the allocator must not hand a workspace to a later kernel while its partials are unread). Only for a caller that
+# reads no gradient before the exit and uses every weight once per step: train.GraphedStep (single process).
+_deferred = None  # list of tensors kept alive, or None when reductions are immediate
+
+
+class deferred_wgrad_reduce:
+    def __enter__(self):
+        global _deferred
+        if _deferred is not None:
+            raise RuntimeError("deferred_wgrad_reduce does not nest")
+        _deferred = []
+        lib().p2pb_wgrad_defer(1)
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred
+        try:
+            rc = lib().p2pb_wgrad_flush(stream_ptr())
+            if rc < 0:
+                raise RuntimeError(f"p2pb_wgrad_flush -> {rc}")
+        finally:
+            lib().p2pb_wgrad_defer(0)
+            _deferred = None
+
+
+def _keep(*tensors):
+    if _deferred is not None:
+        _deferred.extend(t for t in tensors if t is not None)
 
 
 _ZEROS = {}
@@ -157,20 +204,22 @@ class _Conv3dK3(torch.autograd.Function):
                                      device=x.device)
                     call("p2pb_conv3d_k3_wgrad_occ", _i(b), _i(ci), _i(co), _i(r), _i(npts), ptr(x), ptr(gy), ptr(cnt), ptr(gw),
                          ptr(gb), ptr(ws), stream_ptr())
+                    _keep(ws, gw, gb)
                     return gw, gb
                 math = _i(train_math())
                 ws = torch.empty(lib().p2pb_conv3d_k3_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(r), math), dtype=F32,
                                  device=x.device)
                 call("p2pb_conv3d_k3_wgrad", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
                      math, stream_ptr())
+                _keep(ws, gw, gb)
                 return gw, gb
 
             gw, gb = _on_wgrad_stream(wgrad, x, gy)
         gx = None
         if ctx.needs_input_grad[0]:
-            with fused.split_math("bf16x6"):  # gradients have no scale an fp16-pair split could rely on
+            with fused.split_math(dgrad_math()):  # gradients have no scale an fp16-pair split could rely on
                 # force_split: the adjoint pack exists only in the split form (the kernel reads the forward weight transposed
-                # and tap-reflected), so the data gradient runs bf16x6 under P2PB_CONV_MATH=fp32 too
+                # and tap-reflected), so the data gradient runs on bf16 terms under P2PB_CONV_MATH=fp32 too
                 gx, _ = fused.conv3d_k3(gy, _dgrad_holder(conv, "conv3d"), stats=False, compact=True, force_split=True)
         return gx, gw, gb, None, None, None
 
@@ -210,12 +259,13 @@ class _Pointwise(torch.autograd.Function):
                                  device=x.device)
                 call("p2pb_pointwise_wgrad", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
                      math, stream_ptr())
+                _keep(ws, gw, gb)
                 return gw.view(conv.weight.shape), gb
 
             gw, gb = _on_wgrad_stream(wgrad, x, gy)
         gx = None
         if ctx.needs_input_grad[0]:
-            with fused.split_math("bf16x6"):
+            with fused.split_math(dgrad_math()):
                 gx, _ = fused.pw_conv(gy, _dgrad_holder(conv, "pw"), stats=False, use_bias=False)
         return gx, gw, gb, None, None
 
