@@ -508,14 +508,6 @@ int p2pb_conv3d_k3_wgrad_occ(int b, int cin, int cout, int r, int n, const float
 size_t p2pb_pointwise_wgrad_ws_floats(int b, int cin, int cout, int npos, int math);
 int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const float *x, const float *dy, float *dw, float *db,
                          float *ws, int math, void *stream);
-/* Deferred reductions: every entry point above ends with the fixed-order sum of its K-split partials (one small launch each,
- * ~50 per training step). Between p2pb_wgrad_defer(1) and p2pb_wgrad_flush() -- per calling thread -- those sums are only noted
- * and the flush performs them in launches of up to 16 (same order, same bits). Until the flush the caller keeps every ws / dw /
- * db of the noted calls alive and does not read dw / db. p2pb_wgrad_defer -> the previous state (switching off with reductions
- * pending: P2PB_EINVAL); p2pb_wgrad_flush -> the number of reductions performed (>= 0) or a negative error.
- * (No counterpart in the reference: cuDNN / cuBLAS reduce inside their own launches.) */
-int p2pb_wgrad_defer(int on);
-int p2pb_wgrad_flush(void *stream);
 
 /* ---- room pipeline (denoise_room.py) ---------------------------------------------------------
  * exact radius query = sklearn.neighbors.KDTree.query_radius as used at denoise_room.py:459-464: for every patch

@@ -521,76 +521,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int nsplit, int ntap,
   else db[i - n] = s;
 }
 
-// ---- deferred reductions (round 5) -------------------------------------------------------------------------------------------
-// A training step has ~52 weight-gradient launches, each followed by its own wgrad_reduce launch of ~8 us (0.4 ms of a 13 ms step
-// whose chain is bound by the sum of its kernels' durations). Between p2pb_wgrad_defer(1) and p2pb_wgrad_flush() the entry points
-// below only note their reduction {partials, split count, outputs} on the calling thread; the flush adds them all in launches of
-// up to 16 jobs (the job table travels as a kernel argument: nothing to upload, nothing a captured graph would have to re-read).
-// Same sums in the same ascending split order. The caller keeps every workspace and output alive until the flush and does not
-// read a gradient before it (train.GraphedStep: around loss.backward(), in front of the optimiser).
-struct WgReduceJob {
-  const float *part;
-  float *dw, *db;
-  int nsplit, ntap;
-  size_t cc, nbias;
-};
-struct WgReduceBatch {
-  WgReduceJob j[16];
-};
-__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(WgReduceBatch bt) {
-  const WgReduceJob &jb = bt.j[blockIdx.y];
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t n = jb.cc * jb.ntap, row = n + jb.nbias;
-  if (i >= (jb.db ? row : n)) return;
-  const float *part = jb.part;
-  const int nsplit = jb.nsplit;
-  float s = 0.0f;  // (wgrad_reduce_kernel's loop: same order, same bits)
-  int k = 0;
-  for (; k + 8 <= nsplit; k += 8) {
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + j) * row + i];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
-  }
-  for (; k < nsplit; ++k) s += part[(size_t)k * row + i];
-  if (i < n) jb.dw[(i % jb.cc) * jb.ntap + i / jb.cc] = s;
-  else jb.db[i - n] = s;
-}
-#include <vector>
-static thread_local bool tl_wg_defer = false;
-static thread_local std::vector<WgReduceJob> tl_wg_jobs;
 static void wg_reduce(int nsplit, int ntap, size_t cc, size_t nbias, const float *part, float *dw, float *db, hipStream_t s) {
-  if (tl_wg_defer) {
-    tl_wg_jobs.push_back(WgReduceJob{part, dw, db, nsplit, ntap, cc, nbias});
-    return;
-  }
+  // (round 5: noting these ~50 reductions per step and performing them in batched launches behind backward measured SLOWER --
+  //  12.9 -> 13.1 ms per config-3 step, profiles/r05b_defer_reduce_ab.txt: the partials are read back from HBM instead of L2)
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv((long)(cc * ntap + nbias), 256)), dim3(256), 0, s, nsplit, ntap, cc, nbias, part,
                      dw, db);
-}
-extern "C" int p2pb_wgrad_defer(int on) {  // -> the previous state; switching off with reductions pending is refused
-  const int prev = tl_wg_defer ? 1 : 0;
-  if (!on && !tl_wg_jobs.empty()) return P2PB_EINVAL;
-  tl_wg_defer = on != 0;
-  return prev;
-}
-extern "C" int p2pb_wgrad_flush(void *stream) {  // -> number of reductions launched (>= 0) or an error (< 0)
-  hipStream_t s = (hipStream_t)stream;
-  const int njobs = (int)tl_wg_jobs.size();
-  for (int j0 = 0; j0 < njobs; j0 += 16) {
-    WgReduceBatch bt;
-    const int nj = njobs - j0 < 16 ? njobs - j0 : 16;
-    size_t most = 0;
-    for (int j = 0; j < 16; ++j) {
-      bt.j[j] = tl_wg_jobs[j0 + (j < nj ? j : 0)];
-      const size_t e = bt.j[j].cc * bt.j[j].ntap + bt.j[j].nbias;
-      if (j < nj && e > most) most = e;
-    }
-    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)cdiv((long)most, 256), nj), dim3(256), 0, s, bt);
-  }
-  tl_wg_jobs.clear();
-  const int rc = p2pb_launch_status();
-  return rc != 0 ? (rc < 0 ? rc : -rc) : njobs;
 }
 
 // math: 0 = bf16x3 (default; "high" matmul precision, train.py:221), 1 = bf16x6 (fp32-faithful), 2 = exact fp32 MFMA

@@ -101,40 +101,6 @@ def _on_wgrad_stream(fn, *operands):
     return out
 
 
-# ---- deferred weight-gradient reductions ------------------------------------------------------------------------------------
-# Every weight-gradient launch ends with a small fixed-order sum of its K-split partials. Inside `deferred_wgrad_reduce()` the
-# library only notes those sums (include/p2pb_hip.h p2pb_wgrad_defer / _flush) and the exit performs them in a few batched
-# launches: ~50 launches of ~8 us less on the chain of a training step. The workspaces and gradient tensors are kept alive here
-# until then (the allocator must not hand a workspace to a later kernel while its partials are unread). Only for a caller that
-# reads no gradient before the exit and uses every weight once per step: train.GraphedStep (single process).
-_deferred = None  # list of tensors kept alive, or None when reductions are immediate
-
-
-class deferred_wgrad_reduce:
-    def __enter__(self):
-        global _deferred
-        if _deferred is not None:
-            raise RuntimeError("deferred_wgrad_reduce does not nest")
-        _deferred = []
-        lib().p2pb_wgrad_defer(1)
-        return self
-
-    def __exit__(self, *exc):
-        global _deferred
-        try:
-            rc = lib().p2pb_wgrad_flush(stream_ptr())
-            if rc < 0:
-                raise RuntimeError(f"p2pb_wgrad_flush -> {rc}")
-        finally:
-            lib().p2pb_wgrad_defer(0)
-            _deferred = None
-
-
-def _keep(*tensors):
-    if _deferred is not None:
-        _deferred.extend(t for t in tensors if t is not None)
-
-
 _ZEROS = {}
 
 
@@ -204,14 +170,12 @@ class _Conv3dK3(torch.autograd.Function):
                                      device=x.device)
                     call("p2pb_conv3d_k3_wgrad_occ", _i(b), _i(ci), _i(co), _i(r), _i(npts), ptr(x), ptr(gy), ptr(cnt), ptr(gw),
                          ptr(gb), ptr(ws), stream_ptr())
-                    _keep(ws, gw, gb)
                     return gw, gb
                 math = _i(train_math())
                 ws = torch.empty(lib().p2pb_conv3d_k3_wgrad_ws_floats(_i(b), _i(ci), _i(co), _i(r), math), dtype=F32,
                                  device=x.device)
                 call("p2pb_conv3d_k3_wgrad", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
                      math, stream_ptr())
-                _keep(ws, gw, gb)
                 return gw, gb
 
             gw, gb = _on_wgrad_stream(wgrad, x, gy)
@@ -259,7 +223,6 @@ class _Pointwise(torch.autograd.Function):
                                  device=x.device)
                 call("p2pb_pointwise_wgrad", _i(b), _i(ci), _i(co), _i(p), ptr(x), ptr(gy), ptr(gw), ptr(gb), ptr(ws),
                      math, stream_ptr())
-                _keep(ws, gw, gb)
                 return gw.view(conv.weight.shape), gb
 
             gw, gb = _on_wgrad_stream(wgrad, x, gy)

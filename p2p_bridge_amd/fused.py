@@ -99,79 +99,6 @@ def _amax_slot(w):
     return slot
 
 
-# ---- pack plans: the weight packs of a training step, made beside the start of the step instead of between its layers --------
-# Every optimiser step changes every weight, so a training step re-packs each layer's weight once for the forward pass (f16x3) and
-# once for the data gradient (adjoint, bf16 terms): ~90 launches of 4-6 us plus the slice copies in front of some of them, each one
-# between two layers of a chain that is bound by the sum of its kernels' durations. `record_packs()` notes the requests of one step;
-# `prepack(plan, stream)` replays them on a side stream at the start of the next steps (they depend on nothing but the weights), each
-# pack followed by an event; the layer that asks for a pack then finds it cached and waits for ITS event only. Captured into a hipGraph
-# (train.GraphedStep) the side stream is a parallel branch and the events are edges. A request the plan does not hold is packed in
-# place as before.
-_pack_rec = None  # the list being recorded on this process (training is single-threaded per process), or None
-_pack_events = {}  # id(pack tensor) -> (event, tensor): packs made by prepack() that their first user has not waited for yet
-
-
-class record_packs:
-    """`with record_packs() as plan:` -- plan (a list) receives one entry per weight pack made inside"""
-
-    def __enter__(self):
-        global _pack_rec
-        self.prev, _pack_rec = _pack_rec, []
-        return _pack_rec
-
-    def __exit__(self, *exc):
-        global _pack_rec
-        _pack_rec = self.prev
-
-
-def _note_pack(kind, conv, kw):
-    if _pack_rec is not None:
-        _pack_rec.append((kind, conv, kw, _split_math_depth.get(threading.get_ident(), 0)))
-
-
-def _pack_ready(t):
-    """the current stream waits for the side-stream pack `t` once (its first use)"""
-    ev = _pack_events.pop(id(t), None)
-    if ev is not None:
-        torch.cuda.current_stream().wait_event(ev[0])
-    return t
-
-
-def prepack(plan, stream):
-    """replay the recorded pack requests on `stream` (forked from the current stream here); the caller joins `stream` back
-    before the end of the step (join_prepack)"""
-    global _pack_rec
-    if not plan:
-        return
-    main = torch.cuda.current_stream()
-    stream.wait_stream(main)
-    rec, _pack_rec = _pack_rec, None  # (a replay is not a request)
-    tid = threading.get_ident()
-    prev = _split_math_depth.get(tid, 0)
-    _pack_events.clear()
-    try:
-        with torch.cuda.stream(stream):
-            for kind, conv, kw, terms in plan:
-                if terms != _split_math_depth.get(tid, 0):
-                    _split_math_depth[tid] = terms
-                    lib().p2pb_set_split_terms_thread(terms)
-                t = pack_conv3d_weight(conv, **kw) if kind == "conv3d" else pack_pointwise_weight(conv, **kw)
-                if id(t) not in _pack_events:
-                    ev = torch.cuda.Event()
-                    ev.record(stream)
-                    _pack_events[id(t)] = (ev, t)
-    finally:
-        _split_math_depth[tid] = prev
-        lib().p2pb_set_split_terms_thread(prev)
-        _pack_rec = rec
-
-
-def join_prepack(stream):
-    """the current stream waits for whatever prepack() left on `stream` (packs nobody asked for)"""
-    torch.cuda.current_stream().wait_stream(stream)
-    _pack_events.clear()
-
-
 def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
     """packed copy of a Conv3d weight (fp32 [27][cin_pad][cout_pad], or split=True the 16-bit pack of the split-operand
     kernel), cached on the module and refreshed when the parameter is modified in place (optimizer step /
@@ -202,8 +129,7 @@ def pack_conv3d_weight(conv: torch.nn.Conv3d, split=False) -> torch.Tensor:
             wt = torch.empty(lib().p2pb_conv3d_k3_packed_floats(_i(co), _i(ci)), dtype=F32, device=w.device)
             call("p2pb_conv3d_k3_pack_weights", _i(co), _i(ci), ptr(wc), ptr(wt), stream_ptr())
         packs[split] = wt
-        _note_pack("conv3d", conv, {"split": bool(split)})
-    return _pack_ready(packs[split])
+    return packs[split]
 
 
 def conv_pre_plan(r: int):
@@ -559,8 +485,7 @@ def pack_pointwise_weight(conv, ci_lo=0, ci_hi=None, split=False) -> torch.Tenso
             wp = torch.empty(lib().p2pb_pointwise_packed_floats(_i(co), _i(ci_hi - ci_lo)), dtype=F32, device=w.device)
             call("p2pb_pointwise_pack_weights" + sfx, _i(co), _i(ci_hi - ci_lo), ptr(w2), ptr(wp), stream_ptr())
         packs[k] = wp
-        _note_pack("pw", conv, {"ci_lo": ci_lo, "ci_hi": None if adjoint else ci_hi, "split": bool(split)})
-    return _pack_ready(packs[k])
+    return packs[k]
 
 
 def pool_supported(npos: int, pool_u: int) -> bool:

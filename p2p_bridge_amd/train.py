@@ -361,12 +361,7 @@ class GraphedStep:
         self.model, self.optimizer, self.sched, self.warmup = model, optimizer, lr_scheduler, int(warmup)
         self.calls, self.graph, self.static = 0, None, None
         self.side = torch.cuda.Stream()
-        # the step's weight packs on a side branch at the start of the step (fused.prepack): recorded during the first eager call
-        self.pack_plan, self.pack_stream = None, torch.cuda.Stream()
-        self.prepack = _experiment.get("prepack", "0") == "1"  # measured SLOWER as a side branch (13.3 -> 14.6 ms: ~90 cross-stream edges)
         self.overlap = _experiment.get("wgrad_overlap", "0") == "1"  # measured: profiles/r03c_wgrad_overlap_ab.txt (slower)
-        # (single process only: under distributed=True the decoder's gradients are packed into buckets inside backward)
-        self.defer_reduce = _experiment.get("defer_reduce", "1") == "1" and not distributed
         self.wgrad_stream = torch.cuda.Stream()
         self.distributed = bool(distributed)
         self.buckets = self.buckets_dec = self.graph_b = None
@@ -406,9 +401,6 @@ class GraphedStep:
         if self.overlap:  # weight-gradient GEMMs on a second stream beside the data-gradient chain, joined after backward
             with dense.wgrad_overlap(self.wgrad_stream):
                 loss.backward()
-        elif self.defer_reduce:  # the ~50 partial sums of the weight gradients in a few batched launches behind backward
-            with dense.deferred_wgrad_reduce():
-                loss.backward()
         else:
             loss.backward()
         if self.distributed:
@@ -418,20 +410,7 @@ class GraphedStep:
     def _step(self, x_gt, x_start, x_cond, steps):
         """the captured region: everything up to the optimiser (single process), or up to the end of backward (several
         ranks; with the segmented backward: up to the end of the decoder's backward)"""
-        from . import fused
-
-        if self.prepack and self.pack_plan is None:  # first (eager) call: note which packs a step asks for
-            with fused.record_packs() as plan:
-                loss = self._fwd_bwd(x_gt, x_start, x_cond, steps)
-            self.pack_plan = list(plan)
-        else:
-            if self.pack_plan:
-                fused.prepack(self.pack_plan, self.pack_stream)
-            try:
-                loss = self._fwd_bwd(x_gt, x_start, x_cond, steps)
-            finally:
-                if self.pack_plan:  # (also the segmented backward's second graph must not wait on this graph's events)
-                    fused.join_prepack(self.pack_stream)
+        loss = self._fwd_bwd(x_gt, x_start, x_cond, steps)
         if not self.distributed:
             self.optimizer.step()
         return loss

@@ -250,34 +250,3 @@ def test_sparse_weight_gradient_of_a_first_convolution(b, ci, co, r, n):
     assert (grads[False][0].double() - rw).abs().max().item() < 2e-2 * scale
     assert torch.equal(gf, grads[False][2])
 
-
-def test_deferred_weight_gradient_reductions_same_bits():
-    """dense.deferred_wgrad_reduce(): the fixed-order sums of the K-split partials performed in batched launches at the exit
-    (include/p2pb_hip.h p2pb_wgrad_defer / _flush) -- same bits as the per-layer reductions, for the dense, the occupied-voxel and
-    the 1x1 weight gradients; more jobs than one batch holds (16)."""
-    import contextlib
-
-    from p2p_bridge_amd import dense
-    from p2p_bridge_amd._lib import lib
-
-    torch.manual_seed(11)
-    convs = [nn.Conv3d(16, 32, 3, padding=1).cuda(), nn.Conv3d(24, 40, 3, padding=1).cuda()]
-    pws = [nn.Conv1d(32 + 8 * i, 64 + 16 * i, 1).cuda() for i in range(18)]
-    x3 = [torch.randn(2, 16, 8, 8, 8, device="cuda"), torch.randn(2, 24, 16, 16, 16, device="cuda")]
-    xp = [torch.randn(3, 32 + 8 * i, 512, device="cuda") for i in range(18)]
-    g3 = [torch.randn(2, 32, 8, 8, 8, device="cuda"), torch.randn(2, 40, 16, 16, 16, device="cuda")]
-    gp = [torch.randn(3, 64 + 16 * i, 512, device="cuda") for i in range(18)]
-
-    def run(defer):
-        mods = convs + pws
-        for m in mods:
-            m.weight.grad = m.bias.grad = None
-        ys = [dense.conv3d_k3(x, c) for x, c in zip(x3, convs)] + [dense.pointwise(x, c) for x, c in zip(xp, pws)]
-        with (dense.deferred_wgrad_reduce() if defer else contextlib.nullcontext()):
-            torch.autograd.backward(ys, g3 + gp)
-        torch.cuda.synchronize()
-        return [m.weight.grad.clone() for m in mods] + [m.bias.grad.clone() for m in mods]
-
-    a, b = run(False), run(True)
-    assert all(torch.equal(u, v) for u, v in zip(a, b))
-    assert lib().p2pb_wgrad_defer(0) == 0  # (the context left the thread in the immediate mode, nothing pending)
