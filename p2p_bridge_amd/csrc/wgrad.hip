@@ -386,6 +386,150 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_bf16_kernel(int nb, in
   }
 }
 
+// ---- round 5: the same GEMM with its operands staged through LDS ----------------------------------------------------------------
+// The register form above gives every lane its own 32-byte run of its own channel row: 64 lanes of a load touch 64 different cache
+// lines, and the CU's address path processes ~one line per clock -- 14 such loads per K unit cost ~900 clocks of that path per wave
+// against 864 matrix clocks, for four to eight waves per CU: the r = 32 launches ran at 17-21 % of their own MFMA time whatever the
+// loads' latency. Here a K unit is 32 voxels (whole grid rows: one at r = 32, two at r = 16, four at r = 8), the workgroup brings
+// the unit's dY tile [64 co][32] and the three kh-shifted X tiles [64 ci][32] (zero rows outside the grid: out-of-range buffer
+// offsets) with COALESCED 16-byte loads (8 lanes per 128-byte row segment: 8 lines per load instead of 64), splits every element
+// into its bf16 terms ONCE (the register form split each one in two waves and three kw alignments) and writes the term planes to
+// LDS; a wave's fragments are one ds_read_b128 per plane, the kw = 0 / 2 fragments are the kw = 1 one shifted by a bf16 with
+// v_alignbit and one neighbour word (zero at a row end). The next unit's loads are in flight while a unit is multiplied.
+// Row pitch 80 bytes: the 16 lanes of a service group of a ds_read_b128 fall on all eight 16-byte bank groups twice.
+// Same bf16 terms, products and per-accumulator order of K units within a split as the register form (the split of K over the
+// workgroups differs: partial sums round differently, deterministically).
+template <int R, int NTERM>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_lds_kernel(int nb, int cin, int cout, int nsplit,
+                                                                     const float *__restrict__ x,
+                                                                     const float *__restrict__ dy,
+                                                                     float *__restrict__ part,
+                                                                     float *__restrict__ bpart) {
+  static_assert(R >= 8 && 32 % R == 0 || R == 32, "a K unit is whole grid rows");
+  constexpr int R3 = R * R * R, UPS = R3 / 32;  // units per sample
+  constexpr int P = 80, ROWS = 256, PB = ROWS * P + 32;  // row pitch (bytes), rows per plane (64 dY + 3 x 64 X), plane bytes
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NTERM * PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int split = blockIdx.x, kd = blockIdx.z;
+  const int ncit = (cin + 63) / 64;
+  const int co_blk = (blockIdx.y / ncit) * 64, ci_blk = (blockIdx.y % ncit) * 64;
+  const int co_t = co_blk + (wave & 1) * 32, ci_t = ci_blk + (wave >> 1) * 32;
+  const int ci = ci_t + l31;
+  const bool cik = ci < cin;
+  const bool do_bias = bpart && kd == 0 && (blockIdx.y % ncit) == 0;
+  const int srow = tid >> 3, sp = tid & 7;  // staging role: rows srow, srow + 32 of every tile; piece sp (4 voxels)
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  float bs[2] = {0.0f, 0.0f};
+  const int total = nb * UPS;
+  const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)((size_t)nb * cout * R3 * 4), 0x00020000);
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)((size_t)nb * cin * R3 * 4), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  f32x4w ra[2], rb[3][2];
+  auto issue = [&](int u) {
+    const int b = u / UPS, v = (u % UPS) * 32 + 4 * sp;
+    const int d = v / (R * R), h = (v / R) % R, w = v % R;
+    const bool in = u < total;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int co = co_blk + srow + 32 * j;
+      ra[j] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsa, (in && co < cout) ? (unsigned)(((size_t)b * cout + co) * R3 + v) * 4u : OOB, 0, 0));
+    }
+    const int nd = d + kd - 1;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int nh = h + kh - 1;
+      const bool rok = in && (unsigned)nd < (unsigned)R && (unsigned)nh < (unsigned)R;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = ci_blk + srow + 32 * j;
+        rb[kh][j] = __builtin_bit_cast(
+            f32x4w, __builtin_amdgcn_raw_buffer_load_b128(
+                        rsx, (rok && c < cin) ? (unsigned)(((size_t)b * cin + c) * R3 + ((size_t)nd * R + nh) * R + w) * 4u : OOB, 0, 0));
+      }
+    }
+  };
+  auto put = [&](const f32x4w &v, int row) {  // four voxels of one row -> NTERM planes of 8 bytes at piece sp
+    unsigned t0[NTERM], t1[NTERM];
+    split_pair<NTERM>(v[0], v[1], t0);
+    split_pair<NTERM>(v[2], v[3], t1);
+#pragma unroll
+    for (int s = 0; s < NTERM; ++s) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      *(u32x2 *)(lds + s * PB + 16 + row * P + sp * 8) = u32x2{t0[s], t1[s]};
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      put(ra[j], srow + 32 * j);
+      if (do_bias) bs[j] += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) put(rb[kh][j], 64 + kh * 64 + srow + 32 * j);
+    }
+  };
+  issue(split);
+  for (int u = split; u < total; u += nsplit) {
+    __syncthreads();  // the previous unit's fragments are read
+    stash();
+    __syncthreads();
+    issue(u + nsplit);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int col = 16 * (2 * ks + khalf);  // byte offset of the lane's 8 bf16 inside a row
+      const int wv = (16 * ks + 8 * khalf) % R;  // its first voxel's w
+      const bool wl = wv > 0, wr = wv + 8 < R;
+      u32x4 a[NTERM];
+#pragma unroll
+      for (int s = 0; s < NTERM; ++s) a[s] = *(const u32x4 *)(lds + s * PB + 16 + ((wave & 1) * 32 + l31) * P + col);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        u32x4 fm[NTERM], fz[NTERM], fp[NTERM];  // kw = 0 (dw = -1), 1, 2
+#pragma unroll
+        for (int s = 0; s < NTERM; ++s) {
+          const unsigned char *base = lds + s * PB + 16 + (64 + kh * 64 + (wave >> 1) * 32 + l31) * P + col;
+          fz[s] = *(const u32x4 *)base;
+          const unsigned lw = *(const unsigned *)(base - 4), rw = *(const unsigned *)(base + 16);
+          const unsigned left = wl ? lw >> 16 : 0u, right = wr ? rw << 16 : 0u;
+          fm[s][0] = (fz[s][0] << 16) | left;
+#pragma unroll
+          for (int i = 1; i < 4; ++i) fm[s][i] = __builtin_amdgcn_alignbit(fz[s][i], fz[s][i - 1], 16);
+#pragma unroll
+          for (int i = 0; i < 3; ++i) fp[s][i] = __builtin_amdgcn_alignbit(fz[s][i + 1], fz[s][i], 16);
+          fp[s][3] = (fz[s][3] >> 16) | right;
+        }
+        mfma_products<NTERM>(acc[kh * 3 + 0], a, fm);
+        mfma_products<NTERM>(acc[kh * 3 + 1], a, fz);
+        mfma_products<NTERM>(acc[kh * 3 + 2], a, fp);
+      }
+    }
+  }
+  float *po = part + (size_t)split * ((size_t)cout * cin * 27 + cout);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = co_t + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+      if (oc < cout && cik) po[((size_t)(kd * 9 + t) * cout + oc) * cin + ci] = acc[t][r];
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float v = bs[j];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      const int co = co_blk + srow + 32 * j;
+      if (sp == 0 && co < cout) po[(size_t)cout * cin * 27 + co] = v;
+    }
+  }
+}
+
 template <int NTERM>
 __global__ __launch_bounds__(256, 2) void pointwise_wgrad_bf16_kernel(int nb, int cin, int cout, int npos, int nsplit,
                                                                       const float *__restrict__ x,
@@ -529,7 +673,9 @@ static void wg_reduce(int nsplit, int ntap, size_t cc, size_t nbias, const float
 }
 
 // math: 0 = bf16x3 (default; "high" matmul precision, train.py:221), 1 = bf16x6 (fp32-faithful), 2 = exact fp32 MFMA
-static int conv_wgrad_units(int r, int math) { return math == 2 ? (r >= 8 ? (r / 4) * (r / 8) * (r / 8) : 1) : r * r * r / 16; }
+static int conv_wgrad_units(int r, int math) {  // K units of the form that runs: bricks (fp32), 32 voxels (LDS form), 16 (r = 4)
+  return math == 2 ? (r >= 8 ? (r / 4) * (r / 8) * (r / 8) : 1) : r >= 8 ? r * r * r / 32 : r * r * r / 16;
+}
 static int conv_wgrad_wgs_per_split(int cin, int cout, int math) {
   return math == 2 ? ((cout + WG_COT - 1) / WG_COT) * ((cin + WG_CIT - 1) / WG_CIT)
                    : ((cout + 63) / 64) * ((cin + 63) / 64) * 3;
@@ -574,6 +720,15 @@ template <int R>
 static void conv_wgrad_launch_bf16(int b, int cin, int cout, int ns, int math, const float *x, const float *dy,
                                    float *ws, bool bias, hipStream_t s) {
   const dim3 grid(ns, ((cout + 63) / 64) * ((cin + 63) / 64), 3);
+  if constexpr (R >= 8) {  // operands through LDS (tensors below 2 GB: the launcher checked)
+    if (math == 1)
+      hipLaunchKernelGGL((conv3d_k3_wgrad_lds_kernel<R, 3>), grid, dim3(256), 0, s, b, cin, cout, ns, x, dy, ws,
+                         bias ? ws : nullptr);
+    else
+      hipLaunchKernelGGL((conv3d_k3_wgrad_lds_kernel<R, 2>), grid, dim3(256), 0, s, b, cin, cout, ns, x, dy, ws,
+                         bias ? ws : nullptr);
+    return;
+  }
   if (math == 1)
     hipLaunchKernelGGL((conv3d_k3_wgrad_bf16_kernel<R, 3>), grid, dim3(256), 0, s, b, cin, cout, ns, x, dy, ws,
                        bias ? ws : nullptr);
@@ -586,6 +741,8 @@ extern "C" int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float
                                     float *db, float *ws, int math, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || !x || !dy || !dw || !ws || math < 0 || math > 2) return P2PB_EINVAL;
   if (r != 4 && r != 8 && r != 16 && r != 32) return P2PB_EINVAL;
+  // (the bf16 forms address both tensors through 32-bit buffer offsets)
+  if (math != 2 && (size_t)b * (cin > cout ? cin : cout) * r * r * r * 4 >= (1ull << 31)) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ns = wgrad_nsplit((long)b * conv_wgrad_units(r, math), conv_wgrad_wgs_per_split(cin, cout, math),
                               512, (size_t)cout * cin * 27);

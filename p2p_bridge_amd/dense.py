@@ -159,7 +159,9 @@ class _Conv3dK3(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             want_b = ctx.needs_input_grad[2]
 
-            occ = ctx.occ if (ctx.occ is not None and r >= 16 and SPARSE_WGRAD) else None
+            from . import _experiment
+
+            occ = ctx.occ if (ctx.occ is not None and r >= _experiment.get_int("sparse_wgrad_min_r", 16) and SPARSE_WGRAD) else None
 
             def wgrad():
                 gw = torch.empty(co, ci, 3, 3, 3, dtype=F32, device=x.device)
