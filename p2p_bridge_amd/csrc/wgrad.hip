@@ -641,6 +641,102 @@ __global__ __launch_bounds__(256, 2) void pointwise_wgrad_bf16_kernel(int nb, in
   }
 }
 
+// The 1x1 weight gradient with its operands through LDS (round 5; see conv3d_k3_wgrad_lds_kernel): a K unit is 64 positions of
+// one sample, dY [64 co][64] and X [64 ci][64] arrive by coalesced 16-byte loads (16 lanes per 256-byte row segment), are split into
+// their bf16 terms once and written as term planes (row pitch 144 bytes); four k-steps x three products per unit and wave. Rows of
+// 16-byte pieces only (npos % 4 == 0: every layer of the networks); pieces past the row end read zeros.
+template <int NTERM>
+__global__ __launch_bounds__(256, 2) void pointwise_wgrad_lds_kernel(int nb, int cin, int cout, int npos, int nsplit,
+                                                                     const float *__restrict__ x,
+                                                                     const float *__restrict__ dy,
+                                                                     float *__restrict__ part,
+                                                                     float *__restrict__ bpart) {
+  constexpr int P = 144, PB = 128 * P;  // row pitch (bytes); plane = 64 dY rows + 64 X rows
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NTERM * PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, khalf = lane >> 5;
+  const int split = blockIdx.x;
+  const int ncit = (cin + 63) / 64;
+  const int co_blk = (blockIdx.y / ncit) * 64, ci_blk = (blockIdx.y % ncit) * 64;
+  const int co_t = co_blk + (wave & 1) * 32, ci_t = ci_blk + (wave >> 1) * 32;
+  const int ci = ci_t + l31;
+  const bool cik = ci < cin;
+  const bool do_bias = bpart && (blockIdx.y % ncit) == 0;
+  const int srow = tid >> 4, sp = tid & 15;  // staging role: rows srow + 16 j of both tiles, piece sp (4 positions)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float bs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int UPS = (npos + 63) / 64, total = nb * UPS;
+  const auto rsa = __builtin_amdgcn_make_buffer_rsrc((void *)dy, 0, (int)((size_t)nb * cout * npos * 4), 0x00020000);
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)((size_t)nb * cin * npos * 4), 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  f32x4w ra[4], rb[4];
+  auto issue = [&](int u) {
+    const int b = u / UPS, pos = (u % UPS) * 64 + 4 * sp;
+    const bool in = u < total && pos + 4 <= npos;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co_blk + srow + 16 * j, c = ci_blk + srow + 16 * j;
+      ra[j] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsa, (in && co < cout) ? (unsigned)((b * cout + co) * npos + pos) * 4u : OOB, 0, 0));
+      rb[j] = __builtin_bit_cast(f32x4w, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rsx, (in && c < cin) ? (unsigned)((b * cin + c) * npos + pos) * 4u : OOB, 0, 0));
+    }
+  };
+  auto put = [&](const f32x4w &v, int row) {
+    unsigned t0[NTERM], t1[NTERM];
+    split_pair<NTERM>(v[0], v[1], t0);
+    split_pair<NTERM>(v[2], v[3], t1);
+#pragma unroll
+    for (int s = 0; s < NTERM; ++s) {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      *(u32x2 *)(lds + s * PB + row * P + sp * 8) = u32x2{t0[s], t1[s]};
+    }
+  };
+  issue(split);
+  for (int u = split; u < total; u += nsplit) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      put(ra[j], srow + 16 * j);
+      if (do_bias) bs[j] += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
+      put(rb[j], 64 + srow + 16 * j);
+    }
+    __syncthreads();
+    issue(u + nsplit);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int col = 32 * ks + 16 * khalf;
+      u32x4 a[NTERM], bq[NTERM];
+#pragma unroll
+      for (int s = 0; s < NTERM; ++s) {
+        a[s] = *(const u32x4 *)(lds + s * PB + ((wave & 1) * 32 + l31) * P + col);
+        bq[s] = *(const u32x4 *)(lds + s * PB + (64 + (wave >> 1) * 32 + l31) * P + col);
+      }
+      mfma_products<NTERM>(acc, a, bq);
+    }
+  }
+  float *po = part + (size_t)split * ((size_t)cout * cin + cout);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int oc = co_t + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+    if (oc < cout && cik) po[(size_t)oc * cin + ci] = acc[r];
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v = bs[j];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      const int co = co_blk + srow + 16 * j;
+      if (sp == 0 && co < cout) po[(size_t)cout * cin + co] = v;
+    }
+  }
+}
+
 // out = sum_s part[s], s ascending (deterministic). A partial row is [ntap][cout*cin] weights | cout bias sums; the
 // weights leave in the parameter's layout dw[co][ci][ntap] (coalesced reads of the partials, one scattered write).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int nsplit, int ntap, size_t cc, size_t nbias,
@@ -766,11 +862,17 @@ extern "C" int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float
   return p2pb_launch_status();
 }
 
-static int pw_wgrad_units(int npos, int math) { return math == 2 ? (npos + PW_CH - 1) / PW_CH : (npos + 15) / 16; }
+// does the bf16 weight gradient of a 1x1 layer take the LDS form? (rows of 16-byte pieces, 32-bit buffer offsets)
+static bool pw_wgrad_lds(int b, int cin, int cout, int npos) {
+  return (npos & 3) == 0 && (size_t)b * (cin > cout ? cin : cout) * npos * 4 < (1ull << 31);
+}
+static int pw_wgrad_units(int b, int cin, int cout, int npos, int math) {  // K units per sample of the form that runs
+  return math == 2 ? (npos + PW_CH - 1) / PW_CH : pw_wgrad_lds(b, cin, cout, npos) ? (npos + 63) / 64 : (npos + 15) / 16;
+}
 
 extern "C" size_t p2pb_pointwise_wgrad_ws_floats(int b, int cin, int cout, int npos, int math) {
   const int tiles = ((cout + 63) / 64) * ((cin + 63) / 64);
-  const int ns = wgrad_nsplit((long)b * pw_wgrad_units(npos, math), tiles, 512, (size_t)cout * cin);
+  const int ns = wgrad_nsplit((long)b * pw_wgrad_units(b, cin, cout, npos, math), tiles, 512, (size_t)cout * cin);
   return (size_t)ns * ((size_t)cout * cin + cout);
 }
 
@@ -780,7 +882,7 @@ extern "C" int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const fl
     return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int cot = (cout + 63) / 64, cit = (cin + 63) / 64;
-  const int ns = wgrad_nsplit((long)b * pw_wgrad_units(npos, math), cot * cit, 512, (size_t)cout * cin);
+  const int ns = wgrad_nsplit((long)b * pw_wgrad_units(b, cin, cout, npos, math), cot * cit, 512, (size_t)cout * cin);
   const bool bias = db != nullptr;
   if (math == 2) {
     const size_t lds = (size_t)(2 * 64 * (PW_CH + 1)) * sizeof(float);
@@ -792,6 +894,13 @@ extern "C" int p2pb_pointwise_wgrad(int b, int cin, int cout, int npos, const fl
     }
     hipLaunchKernelGGL(pointwise_wgrad_kernel, dim3(ns, cot, cit), dim3(256), lds, s, b, cin, cout, npos, ns, x, dy,
                        ws, bias ? ws : nullptr);
+  } else if (pw_wgrad_lds(b, cin, cout, npos)) {
+    if (math == 1)
+      hipLaunchKernelGGL(pointwise_wgrad_lds_kernel<3>, dim3(ns, cot * cit), dim3(256), 0, s, b, cin, cout, npos, ns, x, dy, ws,
+                         bias ? ws : nullptr);
+    else
+      hipLaunchKernelGGL(pointwise_wgrad_lds_kernel<2>, dim3(ns, cot * cit), dim3(256), 0, s, b, cin, cout, npos, ns, x, dy, ws,
+                         bias ? ws : nullptr);
   } else if (math == 1) {
     hipLaunchKernelGGL(pointwise_wgrad_bf16_kernel<3>, dim3(ns, cot * cit), dim3(256), 0, s, b, cin, cout, npos, ns, x,
                        dy, ws, bias ? ws : nullptr);
