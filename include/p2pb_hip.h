@@ -486,6 +486,17 @@ int p2pb_linear_attention_forward(int b, int heads, int dim_head, int n, const f
 int p2pb_linear_attention_backward(int b, int heads, int dim_head, int n, const float *qkv, const float *ctx,
                                    const float *grad_out, float *grad_qkv, void *stream);
 
+/* ---- training: the squeeze-excite gate (csrc/normact.hip) ---------------------------------------------------------------
+ * SE3d of the reference (models/modules.py:362-378): gate = sigmoid(W2 relu(W1 mean)); mean f32[b,c] = per-channel mean of the
+ * voxel grid, w1 f32[hidden,c], w2 f32[c,hidden] (the two bias-free nn.Linear weights), c <= 1024, hidden <= 128.
+ * forward -> hid f32[b,hidden] (post-ReLU, kept for backward), gate f32[b,c];
+ * backward (dgate f32[b,c]) -> dmean f32[b,c], dw1 f32[hidden,c], dw2 f32[c,hidden]; ws: b * (c + hidden) floats.
+ * Replaces the two cuBLAS GEMMs + ReLU + sigmoid and their autograd of the eager module; deterministic. */
+int p2pb_se_gate_forward(int b, int c, int hidden, const float *mean, const float *w1, const float *w2, float *hid, float *gate,
+                         void *stream);
+int p2pb_se_gate_backward(int b, int c, int hidden, const float *mean, const float *w1, const float *w2, const float *hid,
+                          const float *gate, const float *dgate, float *dmean, float *dw1, float *dw2, float *ws, void *stream);
+
 /* ---- training: weight gradients of the dense layers (csrc/wgrad.hip) --------------------------------------
  * What cuDNN / cuBLAS compute in the reference's backward pass for nn.Conv3d(k 3, pad 1) (models/pvcnn.py:265-282)
  * and the k = 1 Conv1d / Conv2d layers (models/pvcnn.py:162-205, 803-823): exact-fp32 MFMA GEMMs over the voxel /

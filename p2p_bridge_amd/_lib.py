@@ -34,6 +34,7 @@ SYMBOLS = [
     "p2pb_optim_entry_bytes", "p2pb_optim_chunk", "p2pb_optim_clip_adam_step",
     "p2pb_conv3d_k3_pack_weights_split_adjoint", "p2pb_pointwise_pack_weights_adjoint", "p2pb_pointwise_pack_weights_split_adjoint",
     "p2pb_conv3d_k3_pack_weights_split_amax", "p2pb_pointwise_pack_weights_split_amax",
+    "p2pb_se_gate_forward", "p2pb_se_gate_backward",
 ]
 
 _lib = None

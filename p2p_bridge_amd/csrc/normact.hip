@@ -181,3 +181,108 @@ extern "C" int p2pb_norm_act_backward(int b, int c, int groups, int npos, const 
                      rows, mean_rstd, gamma, beta, style, style_stride, dgamma, dbeta, dstyle, dx);
   return p2pb_launch_status();
 }
+
+// ---- squeeze-excite gate for TRAINING (round 5) ------------------------------------------------------------------------------
+// SE3d (models/modules.py:362-378): gate = sigmoid(W2 relu(W1 mean)), mean f32[b,c] the per-channel mean of the voxel grid, W1
+// [hidden, c], W2 [c, hidden], no biases. Eager autograd runs two hipBLASLt GEMMs of a few hundred MACs, a ReLU and a sigmoid
+// forward and about ten launches backward, per PVConv (eight per step); here: one launch forward, two backward. Fixed summation
+// orders (deterministic): hidden rows by a wave with an xor tree, everything else ascending.
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(int c, int hidden, const float *__restrict__ mean,
+                                                          const float *__restrict__ w1, const float *__restrict__ w2,
+                                                          float *__restrict__ hid, float *__restrict__ gate) {
+  __shared__ float s[1024], h[128];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int k = t; k < c; k += 256) s[k] = mean[(size_t)b * c + k];
+  __syncthreads();
+  for (int j = wave; j < hidden; j += 4) {
+    float a = 0.0f;
+    for (int k = lane; k < c; k += 64) a = __fmaf_rn(w1[(size_t)j * c + k], s[k], a);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m);
+    if (lane == 0) {
+      h[j] = a > 0.0f ? a : 0.0f;
+      hid[(size_t)b * hidden + j] = h[j];
+    }
+  }
+  __syncthreads();
+  for (int k = t; k < c; k += 256) {
+    float a = 0.0f;
+    for (int j = 0; j < hidden; ++j) a = __fmaf_rn(w2[(size_t)k * hidden + j], h[j], a);
+    gate[(size_t)b * c + k] = sigmoid_exact(a);
+  }
+}
+
+// per sample: dz2 = dgate g (1 - g), dh = W2^T dz2, dz1 = dh [hid > 0], dmean = W1^T dz1; dz2 / dz1 also go to ws for the weights
+__global__ __launch_bounds__(256) void se_gate_bwd_sample_kernel(int c, int hidden, const float *__restrict__ w1,
+                                                                 const float *__restrict__ w2, const float *__restrict__ hid,
+                                                                 const float *__restrict__ gate, const float *__restrict__ dgate,
+                                                                 float *__restrict__ dmean, float *__restrict__ dz2o,
+                                                                 float *__restrict__ dz1o) {
+  __shared__ float z2[1024], z1[128];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int k = t; k < c; k += 256) {
+    const float g = gate[(size_t)b * c + k];
+    const float v = dgate[(size_t)b * c + k] * (g * (1.0f - g));
+    z2[k] = v;
+    dz2o[(size_t)b * c + k] = v;
+  }
+  __syncthreads();
+  for (int j = wave; j < hidden; j += 4) {
+    float a = 0.0f;
+    for (int k = lane; k < c; k += 64) a = __fmaf_rn(w2[(size_t)k * hidden + j], z2[k], a);
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) a += __shfl_xor(a, m);
+    if (lane == 0) {
+      const float v = hid[(size_t)b * hidden + j] > 0.0f ? a : 0.0f;
+      z1[j] = v;
+      dz1o[(size_t)b * hidden + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int k = t; k < c; k += 256) {
+    float a = 0.0f;
+    for (int j = 0; j < hidden; ++j) a = __fmaf_rn(w1[(size_t)j * c + k], z1[j], a);
+    dmean[(size_t)b * c + k] = a;
+  }
+}
+
+// dW2[k][j] = sum_b dz2[b,k] hid[b,j] ,  dW1[j][k] = sum_b dz1[b,j] mean[b,k]   (b ascending)
+__global__ __launch_bounds__(256) void se_gate_bwd_weights_kernel(int nb, int c, int hidden, const float *__restrict__ mean,
+                                                                  const float *__restrict__ hid, const float *__restrict__ dz2,
+                                                                  const float *__restrict__ dz1, float *__restrict__ dw1,
+                                                                  float *__restrict__ dw2) {
+  const int e = blockIdx.x * 256 + threadIdx.x, n = c * hidden;
+  if (e >= 2 * n) return;
+  float a = 0.0f;
+  if (e < n) {  // dW2, row-major [c][hidden]
+    const int k = e / hidden, j = e % hidden;
+    for (int b = 0; b < nb; ++b) a = __fmaf_rn(dz2[(size_t)b * c + k], hid[(size_t)b * hidden + j], a);
+    dw2[e] = a;
+  } else {  // dW1, row-major [hidden][c]
+    const int j = (e - n) / c, k = (e - n) % c;
+    for (int b = 0; b < nb; ++b) a = __fmaf_rn(dz1[(size_t)b * hidden + j], mean[(size_t)b * c + k], a);
+    dw1[e - n] = a;
+  }
+}
+
+// mean f32[b,c], w1 f32[hidden,c], w2 f32[c,hidden] -> hid f32[b,hidden] (post-ReLU), gate f32[b,c]
+extern "C" int p2pb_se_gate_forward(int b, int c, int hidden, const float *mean, const float *w1, const float *w2, float *hid,
+                                    float *gate, void *stream) {
+  if (b <= 0 || c <= 0 || c > 1024 || hidden <= 0 || hidden > 128 || !mean || !w1 || !w2 || !hid || !gate) return P2PB_EINVAL;
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, c, hidden, mean, w1, w2, hid, gate);
+  return p2pb_launch_status();
+}
+// + dgate f32[b,c] -> dmean f32[b,c], dw1 f32[hidden,c], dw2 f32[c,hidden]; ws: b * (c + hidden) floats
+extern "C" int p2pb_se_gate_backward(int b, int c, int hidden, const float *mean, const float *w1, const float *w2,
+                                     const float *hid, const float *gate, const float *dgate, float *dmean, float *dw1,
+                                     float *dw2, float *ws, void *stream) {
+  if (b <= 0 || c <= 0 || c > 1024 || hidden <= 0 || hidden > 128 || !mean || !w1 || !w2 || !hid || !gate || !dgate || !dmean ||
+      !dw1 || !dw2 || !ws)
+    return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float *dz2 = ws, *dz1 = ws + (size_t)b * c;
+  hipLaunchKernelGGL(se_gate_bwd_sample_kernel, dim3(b), dim3(256), 0, s, c, hidden, w1, w2, hid, gate, dgate, dmean, dz2, dz1);
+  hipLaunchKernelGGL(se_gate_bwd_weights_kernel, dim3((2 * c * hidden + 255) / 256), dim3(256), 0, s, b, c, hidden, mean, hid, dz2,
+                     dz1, dw1, dw2);
+  return p2pb_launch_status();
+}

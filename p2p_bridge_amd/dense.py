@@ -274,6 +274,41 @@ class _NormAct(torch.autograd.Function):
         return dx.view(gy.shape), dgamma, dbeta, dstyle, None, None, None, None
 
 
+class _SEGate(torch.autograd.Function):
+    """gate = sigmoid(W2 relu(W1 mean)) (SE3d, models/modules.py:362-378): csrc/normact.hip, 1 launch forward, 2 backward"""
+
+    @staticmethod
+    def forward(ctx, mean, w1, w2):
+        b, c = mean.shape
+        hidden = w1.shape[0]
+        mean, w1, w2 = mean.contiguous(), w1.contiguous(), w2.contiguous()
+        hid = torch.empty(b, hidden, dtype=F32, device=mean.device)
+        gate = torch.empty(b, c, dtype=F32, device=mean.device)
+        call("p2pb_se_gate_forward", _i(b), _i(c), _i(hidden), ptr(mean), ptr(w1), ptr(w2), ptr(hid), ptr(gate), stream_ptr())
+        ctx.save_for_backward(mean, w1, w2, hid, gate)
+        return gate
+
+    @staticmethod
+    def backward(ctx, dgate):
+        mean, w1, w2, hid, gate = ctx.saved_tensors
+        b, c = mean.shape
+        hidden = w1.shape[0]
+        dmean, dw1, dw2 = torch.empty_like(mean), torch.empty_like(w1), torch.empty_like(w2)
+        ws = torch.empty(b * (c + hidden), dtype=F32, device=mean.device)
+        call("p2pb_se_gate_backward", _i(b), _i(c), _i(hidden), ptr(mean), ptr(w1), ptr(w2), ptr(hid), ptr(gate),
+             ptr(dgate.contiguous()), ptr(dmean), ptr(dw1), ptr(dw2), ptr(ws), stream_ptr())
+        return dmean, dw1, dw2
+
+
+def se_gate(mean, fc):
+    """SE3d's excitation from the per-channel means f32[B,C]; fc = its Sequential(Linear, ReLU, Linear, Sigmoid) (bias-free)"""
+    w1, w2 = fc[0].weight, fc[2].weight
+    if (enabled(mean) and fc[0].bias is None and fc[2].bias is None and mean.shape[1] <= 1024 and w1.shape[0] <= 128
+            and w1.dtype == F32):
+        return _SEGate.apply(mean, w1, w2)
+    return fc(mean)
+
+
 def conv3d_k3(x, conv: torch.nn.Conv3d, want_stats=False):
     """nn.Conv3d(kernel 3, stride 1, padding 1) applied to x f32[B,Cin,r,r,r], r in {4, 8, 16, 32}"""
     if not enabled(x) or x.shape[2] not in (4, 8, 16, 32):

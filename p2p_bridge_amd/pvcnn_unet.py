@@ -102,9 +102,17 @@ class SE3d(nn.Module):
                                 nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
         self.channel = channel
 
-    def forward(self, x):
+    def gate(self, x):
+        """the excitation f32[B,C] alone"""
         s = x.mean((2, 3, 4))  # (the reference's .mean(-1).mean(-1).mean(-1) in one reduction: same value to rounding)
-        return x * self.fc(s).view(x.shape[0], x.shape[1], 1, 1, 1)
+        if s.is_cuda and torch.is_grad_enabled():  # training: the two tiny Linears + ReLU + sigmoid and their autograd in 1 + 2 launches
+            from . import dense
+
+            return dense.se_gate(s, self.fc)
+        return self.fc(s)
+
+    def forward(self, x):
+        return x * self.gate(x).view(x.shape[0], x.shape[1], 1, 1, 1)
 
 
 class _LinearAttentionCore(torch.autograd.Function):
@@ -507,9 +515,16 @@ class PVConv(nn.Module):
             vl = self.voxel_layers  # conv, norm, Swish, Dropout, conv, norm[, SE3d]: HIP forward + backward (dense.py)
             v = vl[3](dense.conv_norm_act(v, vl[0], vl[1], cond, swish=True))
             v = dense.conv_norm_act(v, vl[4], vl[5], cond, swish=False)
-            if len(vl) > 6:
-                v = vl[6](v)
-            fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
+            if len(vl) > 6 and v.is_cuda:
+                # the squeeze-excite gate is a per-(sample, channel) factor and the devoxelisation is linear in the grid: gate the
+                # N points instead of the r^3 voxels (what the fused inference branch does through devoxelize_affine). Forward
+                # and backward lose their grid-sized multiplies and the grid-sized reduction of d gate (round 5: ~0.4 ms of a
+                # config-3 step in ATen elementwise kernels); the values differ from gating the grid by fp32 rounding only
+                fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training) * vl[6].gate(v).unsqueeze(-1)
+            else:
+                if len(vl) > 6:
+                    v = vl[6](v)
+                fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
         data.features = self.point_features.run(features, cond, residual=fused)
         if self.attn is not None:  # models/pvcnn.py:327-328
             data.features = self.attn(data.features)

@@ -250,3 +250,24 @@ def test_sparse_weight_gradient_of_a_first_convolution(b, ci, co, r, n):
     assert (grads[False][0].double() - rw).abs().max().item() < 2e-2 * scale
     assert torch.equal(gf, grads[False][2])
 
+
+@pytest.mark.parametrize("b,c", [(8, 64), (3, 256), (2, 32), (5, 1024)])
+def test_se_gate_forward_backward(b, c):
+    """dense.se_gate (csrc/normact.hip se_gate_*): SE3d's excitation and every gradient vs the module's own fp64 autograd"""
+    from p2p_bridge_amd import dense
+    from p2p_bridge_amd.pvcnn_unet import SE3d
+
+    torch.manual_seed(c + b)
+    se = SE3d(c).cuda()
+    mean = torch.randn(b, c, device="cuda", requires_grad=True)
+    dg = torch.randn(b, c, device="cuda")
+    g = dense.se_gate(mean, se.fc)
+    g.backward(dg)
+    m64 = mean.detach().double().cpu().requires_grad_(True)
+    w1, w2 = (se.fc[i].weight.detach().double().cpu().requires_grad_(True) for i in (0, 2))
+    g64 = torch.sigmoid(torch.relu(m64 @ w1.t()) @ w2.t())
+    g64.backward(dg.double().cpu())
+    assert _rel(g.detach(), g64.detach()) < 1e-6
+    assert _rel(mean.grad, m64.grad) < 1e-5
+    assert _rel(se.fc[0].weight.grad, w1.grad) < 1e-5
+    assert _rel(se.fc[2].weight.grad, w2.grad) < 1e-5
