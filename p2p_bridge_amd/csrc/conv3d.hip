@@ -463,21 +463,25 @@ __device__ __forceinline__ int lane_w(int l31) {
 // products h1g0, h0g1, h0g0 (<= 3 * 2^-22 |x*y| inside fp16's range); the third plane of tile / pack is then unused.
 // (The same three products of the bf16 split -- TERMS == SPLIT_BF16X3, <= 3 * 2^-18 -- were measured at the same speed
 // and 6.4e-5 network error, at the 1e-4 parity bar instead of inside it: superseded, not instantiated.)
+#ifndef SPLIT_TAPS_AD
+#define SPLIT_TAPS_AD 3  // taps of weight prefetch in split_taps (experiment builds: -DSPLIT_TAPS_AD=1 is the round-4 schedule)
+#endif
 template <int NT, int HH, int HW, int PLANE, int TERMS>
 __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, const u32x4 *wchunk,
                                            size_t wsplit_stride, size_t wtap_stride, const int (&nbase)[NT], int khalf) {
   constexpr int NP = split_planes(TERMS);  // operand planes in use
-  u32x4 a_cur[3], bf[3][NT];
+  // A fragments (weights) in a ring, requested AD taps ahead of their first product (round 5: one tap ahead -- 6 NT MFMAs, 192 NT
+  // cycles -- does not cover an L2 round trip when a SIMD holds ONE wave with NT = 2: the 8^3 layers of a training batch of 8 took
+  // 102 us for 36 us of matrix time)
+  constexpr int AD = TERMS == SPLIT_BF16X6 ? 1 : SPLIT_TAPS_AD;  // (three operand planes: the deeper ring spills the 64-channel forms)
+  u32x4 a_ring[AD + 1][3], bf[3][NT];
 #pragma unroll
-  for (int s = 0; s < NP; ++s) a_cur[s] = wchunk[s * wsplit_stride];
+  for (int t = 0; t < AD; ++t)
+#pragma unroll
+    for (int s = 0; s < NP; ++s) a_ring[t][s] = wchunk[(size_t)t * wtap_stride + s * wsplit_stride];
   auto load_b = [&](int s, int toff) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) bf[s][n] = tile[(s * 2 + khalf) * PLANE + nbase[n] + toff];
-  };
-  auto mfma_term = [&](int pa, int pb) {
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-      acc[n] = split_mfma<TERMS>(a_cur[pa], bf[pb][n], acc[n]);
   };
   if constexpr (TERMS == 6) load_b(2, 0);
   load_b(1, 0);
@@ -485,10 +489,15 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
   for (int tap = 0; tap < CONV_NTAPS; ++tap) {
     const int toff = ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
     const int toff_n = (((tap + 1) / 9) * HH + ((tap + 1) / 3) % 3) * HW + (tap + 1) % 3;
-    u32x4 a_nxt[3];
-    if (tap + 1 < CONV_NTAPS) {
+    const u32x4(&a_cur)[3] = a_ring[tap % (AD + 1)];
+    auto mfma_term = [&](int pa, int pb) {
 #pragma unroll
-      for (int s = 0; s < NP; ++s) a_nxt[s] = wchunk[(size_t)(tap + 1) * wtap_stride + s * wsplit_stride];
+      for (int n = 0; n < NT; ++n)
+        acc[n] = split_mfma<TERMS>(a_cur[pa], bf[pb][n], acc[n]);
+    };
+    if (tap + AD < CONV_NTAPS) {
+#pragma unroll
+      for (int s = 0; s < NP; ++s) a_ring[(tap + AD) % (AD + 1)][s] = wchunk[(size_t)(tap + AD) * wtap_stride + s * wsplit_stride];
     }
     load_b(0, toff);
     __builtin_amdgcn_sched_barrier(0);
@@ -507,10 +516,6 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TERMS != 6) mfma_term(1, 0);
     mfma_term(0, 0);
-    if (tap + 1 < CONV_NTAPS) {
-#pragma unroll
-      for (int s = 0; s < NP; ++s) a_cur[s] = a_nxt[s];
-    }
   }
 }
 

@@ -3,7 +3,7 @@ p2pb_set_split_terms): "f16x3" (default: fp16-pair split of the scaled operands,
 bf16 terms, six products). Both against fp64 with per-product bounds -- f16x3 within 3 * 2^-22 * sum |x||w| plus the fp32
 accumulation, i.e. at the exact-fp32 MFMA kernel's level --, the f16x3 range contract (non-finite beyond 16380, absolute
 floor below 2^-5, any weight scale), a switch re-packs and is reversible bit for bit, a captured graph is keyed by its
-arithmetic, the gradient pass of train() runs on bf16x6 whatever the setting."""
+arithmetic, the gradient pass of train() runs on bf16 terms (P2PB_TRAIN_MATH) whatever the setting."""
 import json
 import os
 
@@ -187,10 +187,15 @@ def test_tiny_network_both_arithmetics(fused):
     assert torch.equal(yh_replay, yh)
 
 
-def test_training_gradient_pass_is_bf16x6(fused):
-    """train(): the data-gradient convolutions see gradients (no usable scale) -> always the bf16 split; a gradient of
-    magnitude 1e-9 comes through with fp32-level relative error"""
+@pytest.mark.parametrize("math", ["bf16x3", "bf16x6"])
+def test_training_gradient_pass_runs_on_bf16_terms(fused, monkeypatch, math):
+    """train(): the data-gradient convolutions see gradients (no scale an fp16-pair split could rely on) -> always bf16 terms,
+    whatever the forward arithmetic: a gradient of magnitude 1e-9 comes through with the relative error of the arithmetic that
+    P2PB_TRAIN_MATH selects -- two terms / three products by default (<= 3 * 2^-18 per product, 1e-5 of the magnitude sum),
+    three terms / six products (fp32-level) under "bf16x6" -- and the forward arithmetic is back afterwards"""
     from p2p_bridge_amd import dense
+    monkeypatch.setenv("P2PB_TRAIN_MATH", math)
+    assert dense.dgrad_math() == math
     torch.manual_seed(3)
     conv = torch.nn.Conv1d(256, 256, 1).cuda()
     x = torch.randn(2, 256, 512, device="cuda", requires_grad=True)
@@ -199,7 +204,7 @@ def test_training_gradient_pass_is_bf16x6(fused):
     (gx,) = torch.autograd.grad(y, x, g)
     ref = torch.einsum("oc,bop->bcp", conv.weight[:, :, 0].double(), g.double())
     mag = torch.einsum("oc,bop->bcp", conv.weight[:, :, 0].double().abs(), g.double().abs())
-    assert ((gx - ref).abs() / mag).max().item() < ACC
+    assert ((gx - ref).abs() / mag).max().item() < (ACC if math == "bf16x6" else 3 * 2.0 ** -18)
     assert fused.lib().p2pb_get_split_terms() == 16
 
 
