@@ -1149,7 +1149,8 @@ static int pw_launch_split(int b, int cin, int cout, int P, const float *in, con
   // 160 KB of LDS, weight tiles by LDS-DMA, the two waves of a SIMD in opposite phase; any position count).
   // P2PB_EXPERIMENT pw_pp=0 keeps pw_split_kernel (A/B timing).
   static const int pp_env = (int)p2pb_experiment_long("pw_pp", 1);
-  if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0)) {
+  if (pp_env && wm4 && mode == SPLIT_F16X3 && cin % 64 == 0 && cout % 512 == 0 && (!minmax || pool_u == 0) &&
+      (size_t)cin * P * 4 < (1ull << 31)) {  // (its operand descriptor holds one sample: 32-bit byte offsets)
     dim3 pgrid((P + 127) / 128, cout / 512, b);
 #define LAUNCHP5(XF, PL)                                                                                              \
   do {                                                                                                                \

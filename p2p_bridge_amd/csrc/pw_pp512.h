@@ -143,7 +143,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
   const u32x4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)inb),
                     (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(inb >> 32)),
                     (unsigned)__builtin_amdgcn_readfirstlane(cin * P * 4), 0x00020000u};
-  const unsigned voff = (unsigned)(pblk + 64 * half + lane) * 4u;
+  // (positions past the row end of a ragged last tile are masked below; their loads are clamped INTO the row: the scalar row
+  //  offset is outside the descriptor's bounds check, so an unclamped one would read past the last row of the last sample --
+  //  ADVICE r4)
+  const int pcl = pblk + 64 * half + lane;
+  const unsigned voff = (unsigned)(pcl < P ? pcl : P - 1) * 4u;
   auto load_b = [&](int s) {
     const int st = s < nstage ? s : nstage - 1;  // past the end: a valid row, never used
     P5_LOAD8(0);

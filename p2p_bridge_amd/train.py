@@ -390,6 +390,9 @@ class GraphedStep:
             # first segment only: the decoder's gradients + the gradients at the cut; _encoder_backward() is the second
             self.cut = net.cut
             net.cut = None
+            if not self.cut:  # (an opaque TypeError inside warm-up / capture otherwise)
+                raise RuntimeError("GraphedStep(distributed=True): the forward pass collected no cut tensors for the segmented "
+                                   "backward (P2PB_SEGMENTED_BACKWARD=0 captures the backward pass as one graph)")
             dec = self.buckets_dec.params
             grads = torch.autograd.grad(loss, self.cut + dec, allow_unused=True)
             self.gcut = grads[:len(self.cut)]
