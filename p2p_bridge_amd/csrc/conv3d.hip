@@ -528,7 +528,13 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
 __device__ __forceinline__ u32x4 conv_wload(__amdgpu_buffer_rsrc_t rs, unsigned wv, unsigned so) {
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wv, so, 0));
 }
-#define CONV_PRE_AD 2  // taps of weight prefetch; the ring has CONV_PRE_AD + 1 slots, which must divide 27 (8 measured +-0)
+#ifndef CONV_PRE_AD
+// taps of weight prefetch; the ring has CONV_PRE_AD + 1 slots, which must divide 27. Round 3 measured 8 against 2 at +-0 -- on one
+// chain of 32 patches, two waves per SIMD. With the sampler's two chains of 16 the 8^3 layers launch 256 workgroups: ONE wave per
+// SIMD with two tiles, 192 cycles of MFMAs per tap, and two taps of cover are less than an L2 round trip (what section 3.7 found in
+// split_taps): 8 taps ahead, bench 223.1 -> 220.6 ms per sample call (profiles/r05b_conv_pre_ad8_ab.txt; 72 ring registers, none spilled)
+#define CONV_PRE_AD 8
+#endif
 static_assert(27 % (CONV_PRE_AD + 1) == 0, "the ring position of tap 0 must be the same in every stage");
 template <int NT, int HH, int HW, int PLANE>
 __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, __amdgpu_buffer_rsrc_t rsw,
