@@ -460,7 +460,10 @@ class P2PB(nn.Module):
                     streams[c].wait_stream(main)
                     if c > 0 and nsteps > 1:
                         with torch.cuda.stream(streams[c]):
-                            torch.cuda._sleep(int(step_ms * c / chains * 1.8e6))  # (~1.8 GHz spin clock; only the phase matters)
+                            from . import _experiment
+
+                            phase = _experiment.get_int("chain_stagger_pct", 100) / 100.0  # (A/B key: scales the offset)
+                            torch.cuda._sleep(int(step_ms * c / chains * phase * 1.8e6))  # (~1.8 GHz spin clock; only the phase matters)
             for c in range(chains):
                 if i == 0 and c == 0:
                     continue
