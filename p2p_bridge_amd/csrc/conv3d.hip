@@ -536,17 +536,6 @@ __device__ __forceinline__ u32x4 conv_wload(__amdgpu_buffer_rsrc_t rs, unsigned 
 #define CONV_PRE_AD 8
 #endif
 static_assert(27 % (CONV_PRE_AD + 1) == 0, "the ring position of tap 0 must be the same in every stage");
-// The wait at the top of a PRE stage. vmcnt(0) also waits for the weight loads of the LAST taps of the previous stage -- the youngest
-// of them was issued one tap earlier: most of an L2 round trip exposed per stage when a SIMD holds one wave. Memory returns are in
-// order per wave and every DMA of stage k was issued before the 54 weight loads of stage k - 1's taps, so (experiment,
-// -DCONV_STAGE_VMCNT=n) waiting until at most n loads are outstanding, n <= 2 * (CONV_PRE_AD - 1), still guarantees the tile AND
-// tap 0's fragments; the compiler's own waits in front of each fragment's first use stay.
-#ifdef CONV_STAGE_VMCNT
-static_assert(CONV_STAGE_VMCNT <= 2 * (CONV_PRE_AD - 1) && CONV_STAGE_VMCNT < 16, "the tile and tap 0's weights must have landed");
-#define CONV_STAGE_WAIT() __builtin_amdgcn_s_waitcnt(0x0f70 | CONV_STAGE_VMCNT)
-#else
-#define CONV_STAGE_WAIT() __builtin_amdgcn_s_waitcnt(0x0f70)  // vmcnt(0)
-#endif
 template <int NT, int HH, int HW, int PLANE>
 __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *__restrict__ tile, __amdgpu_buffer_rsrc_t rsw,
                                                unsigned wv, unsigned sbase, unsigned stage_bytes, unsigned tap_bytes,
@@ -557,46 +546,6 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
   // previous tap's last product had issued, four MFMAs (128 cycles, about one LDS latency under load) ahead of their use.
   //   tap t:  [A loads of tap t + AD]  G1: a0(t) x h1(t)  | read h1(t+1) |  G2: a1(t) x h0(t)  | read h0(t+1) |  G3: a0(t) x h0(t)
   // (same three products in the same order as split_taps: bit-identical accumulators)
-#ifdef CONV_PRE_BRING
-  if constexpr (NT <= CONV_PRE_BRING) {
-    // (experiment) narrow waves (NT <= 2: a tap is only 3 NT MFMAs = 96 NT cycles): both operand planes of tap t + 2 requested at
-    // the top of tap t, three register sets each -- every ds_read_b128 has two taps of MFMAs in front of its first use
-    u32x4 r1[3][NT], r0[3][NT];
-    auto toff_of = [&](int tap) { return ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3; };
-    auto load_t = [&](int slot, int toff) {
-#pragma unroll
-      for (int n = 0; n < NT; ++n) r1[slot][n] = tile[(2 + khalf) * PLANE + nbase[n] + toff];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) r0[slot][n] = tile[khalf * PLANE + nbase[n] + toff];
-    };
-    load_t(0, toff_of(0));
-    load_t(1, toff_of(1));
-#pragma unroll
-    for (int tap = 0; tap < CONV_NTAPS; ++tap) {
-      constexpr int AD = CONV_PRE_AD;
-      const int cur = tap % (AD + 1), nx2 = (tap + AD) % (AD + 1), sl = tap % 3;
-      if (tap + AD < CONV_NTAPS) {
-        const unsigned so = sbase + (unsigned)(tap + AD) * tap_bytes;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) a[nx2][s] = conv_wload(rsw, wv, so + s * plane_bytes);
-      } else if (has_next) {
-        const unsigned so = sbase + stage_bytes + (unsigned)(tap + AD - CONV_NTAPS) * tap_bytes;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) a[nx2][s] = conv_wload(rsw, wv, so + s * plane_bytes);
-      }
-      if (tap + 2 < CONV_NTAPS) load_t((tap + 2) % 3, toff_of(tap + 2));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], r1[sl][n], acc[n]);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][1], r0[sl][n], acc[n]);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][0], r0[sl][n], acc[n]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    return;
-  }
-#endif
   u32x4 b1[NT], b0[2][NT];
   auto load_b1 = [&](int toff) {
 #pragma unroll
@@ -849,7 +798,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 #pragma unroll
       for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
     auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
-      CONV_STAGE_WAIT();                   // my share of stage k has landed (and the weights of its first taps)
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): my share of stage k has landed (and the weights of its first taps)
       __syncthreads();                     // everyone's has; the other buffer is no longer read
       CONV_TL(tid);  // 2 + 2k: stage k released
       if (k + 1 < nchunk) ps.issue(sg, k + 1, nxt, tid);
@@ -1971,8 +1920,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
           for (int s = 0; s < 2; ++s) aring[t][s] = conv_wload(rsw, wv, t * tap_bytes + s * plane_bytes);
       }
       auto stage = [&](int k, const u32x4 *cur, u32x4 *nxt) {
-        if (NTC > 0) CONV_STAGE_WAIT();  // (a wave without a tile has no weight loads behind its DMA share: it waits for all)
-        else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
         __syncthreads();
         if (k < 4) CONV_TL_AT(tid, 3 + 2 * k);  // stage k released (k < 4)
         if (k + 1 < nchunk) ps.issue(sg, k + 1, nxt, tid);

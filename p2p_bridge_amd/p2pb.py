@@ -462,7 +462,11 @@ class P2PB(nn.Module):
                         with torch.cuda.stream(streams[c]):
                             from . import _experiment
 
-                            phase = _experiment.get_int("chain_stagger_pct", 100) / 100.0  # (A/B key: scales the offset)
+                            # small clouds start together: their chains are sums of short kernels and the offset only delays
+                            # chain 1's end (profiles/r05c_launch_shapes_ab.txt: 219.1 -> 217.5 ms per sample call); the large
+                            # clouds of configs 4-5 keep the half step that puts one chain's FPS under the other's dense layers
+                            dflt = 0 if xt.shape[2] <= 16384 else 100
+                            phase = _experiment.get_int("chain_stagger_pct", dflt) / 100.0  # (A/B key: scales the offset)
                             torch.cuda._sleep(int(step_ms * c / chains * phase * 1.8e6))  # (~1.8 GHz spin clock; only the phase matters)
             for c in range(chains):
                 if i == 0 and c == 0:
