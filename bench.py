@@ -194,8 +194,10 @@ HBM_GROUPS = [
     ("devoxelize (a12)", 26.11, ("devox_cl_kernel",),
      "8-corner gather of voxel-major rows (256 B per corner and point at C = 64): L2-resident grid, the point-major -> channel-major "
      "transpose through LDS"),
-    ("grouping (a17: group_sub, the set abstraction's gathered first layer)", 19.86, ("group_sub_kernel",),
-     "row gathers of the ungrouped tensor (L2-resident: 1 MB per sample) + an LDS transpose; writes 32 x what it reads"),
+    ("grouping (a17: group_sub / group_stats, the set abstraction's gathered first layer)", 19.86, ("group_sub_kernel", "group_stats_kernel"),
+     "row gathers of the ungrouped tensor (L2-resident: 1 MB per sample); since round 5 the statistics pass (group_stats) writes "
+     "nothing and the consuming GEMM gathers its own operand, so most of the reference op's bytes are never moved -- a fraction "
+     "near or above 1 here means avoided traffic, not bandwidth"),
     ("3-NN interpolation (a19: cell grid build, search, interpolate + add)", 12.49,
      ("three_nn_kernel", "three_nn_cells_kernel", "nn_cells_build_kernel", "three_interp_add_kernel"),
      "search-bound, not byte-bound: 53.7 M pair distances per sample are the work (cell-grid search for m >= 512 centres, brute force "
@@ -215,8 +217,12 @@ def hbm_kernels(patches_per_chain):
     of profile data, the file it came from is named."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_per_eval.csv")), key=os.path.getmtime)
-    files = [f for f in files if "_c4_" not in f and "_c5_" not in f and "accumul" not in f and "partials" not in f]
+    import re
+
+    # the newest set BY NAME (rNN + letter: r05c > r05b > r04h): file times mean nothing in a fresh checkout -- the driver's box and
+    # every gpurun snapshot -- where sorting by mtime picked an arbitrary round-1 table (found in profiles/r05c_bench_line.json)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_per_eval.csv"))
+                   if re.fullmatch(r"r\d\d[a-z]?_per_eval\.csv", os.path.basename(f)))
     if not files:
         return None
     src = files[-1]
