@@ -447,29 +447,31 @@ class P2PB(nn.Module):
                 for c in range(chains):
                     streams[c].wait_event(drawn)  # (the draw happens on the calling stream, the chains consume it on theirs)
             if i == 0:
-                # chain 0's first step alone, timed: the stagger of the other chains is a fraction of it
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(main)
-                x_c[0], x0 = runners[0](x_c[0], table[0], None if noise is None else noise[parts[0]])
-                e1.record(main)
-                if prev in log_steps:
-                    logs[0][0].append(x_c[0].clone()), logs[0][1].append(x0.clone())
-                e1.synchronize()
-                step_ms = e0.elapsed_time(e1)
+                from . import _experiment
+
+                # small clouds start together: their chains are sums of short kernels and an offset only delays chain 1's end
+                # (profiles/r05c_launch_shapes_ab.txt: 219.1 -> 217.5 ms per sample call, and no host wait for a timed first step);
+                # the large clouds of configs 4-5 keep the half step that puts one chain's FPS under the other's dense layers
+                dflt = 0 if xt.shape[2] <= 16384 else 100
+                phase = _experiment.get_int("chain_stagger_pct", dflt) / 100.0  # (A/B key: scales the offset)
+                timed_first = phase > 0 and chains > 1 and nsteps > 1
+                if timed_first:
+                    # chain 0's first step alone, timed: the stagger of the other chains is a fraction of it
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(main)
+                    x_c[0], x0 = runners[0](x_c[0], table[0], None if noise is None else noise[parts[0]])
+                    e1.record(main)
+                    if prev in log_steps:
+                        logs[0][0].append(x_c[0].clone()), logs[0][1].append(x0.clone())
+                    e1.synchronize()
+                    step_ms = e0.elapsed_time(e1)
                 for c in range(chains):
                     streams[c].wait_stream(main)
-                    if c > 0 and nsteps > 1:
+                    if timed_first and c > 0:
                         with torch.cuda.stream(streams[c]):
-                            from . import _experiment
-
-                            # small clouds start together: their chains are sums of short kernels and the offset only delays
-                            # chain 1's end (profiles/r05c_launch_shapes_ab.txt: 219.1 -> 217.5 ms per sample call); the large
-                            # clouds of configs 4-5 keep the half step that puts one chain's FPS under the other's dense layers
-                            dflt = 0 if xt.shape[2] <= 16384 else 100
-                            phase = _experiment.get_int("chain_stagger_pct", dflt) / 100.0  # (A/B key: scales the offset)
                             torch.cuda._sleep(int(step_ms * c / chains * phase * 1.8e6))  # (~1.8 GHz spin clock; only the phase matters)
             for c in range(chains):
-                if i == 0 and c == 0:
+                if i == 0 and c == 0 and timed_first:
                     continue
                 with torch.cuda.stream(streams[c]):
                     x_c[c], x0 = runners[c](x_c[c], table[i], None if noise is None else noise[parts[c]])
