@@ -148,7 +148,7 @@ def test_every_op_of_an_evaluation_beside_matrix_kernels_is_bitwise_stable():
     #  so the replay asks for the fully written form of the same launch: same MFMA kernel, the fill writes as well)
     fix = lambda cs: [(n, f, a, dict(kw, active_only=False) if kw.get("active_only") else kw) for (n, f, a, kw) in cs]
     ca, cb = fix(ca), fix(cb)
-    assert len(ca) == len(cb) > 150, (len(ca), len(cb))
+    assert len(ca) == len(cb) > 140, (len(ca), len(cb))  # (f16x3: 154 calls; bf16x6 has no pre-split passes: 148)
     kinds = {n for n, *_ in ca}
     for must in ("fused.pw_conv", "fused.conv3d_k3_compact", "fused.conv3d_k3_sparse", "fused.conv3d_k3", "fused.devoxelize_affine",
                  "fused.voxelize_cl_gather", "fused.group_sub", "fused.interp_add", "fused.minmax_act", "fused.gn_affine_params",
