@@ -85,3 +85,25 @@ def test_bench_refuses_more_ranks_than_devices():
 def test_bench_refuses_world_size_mismatch():
     r = _run(["--gpus", "2", "--backend", "gloo", "--dry-run"], {"WORLD_SIZE": "4", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+def test_hbm_table_takes_the_newest_round_by_name():
+    """bench.hbm_kernels reads the newest committed per-evaluation table: newest BY NAME (rNN + letter) -- in a fresh checkout
+    (the driver's box, every gpurun snapshot) file times are arbitrary and once selected a round-1 table"""
+    import glob
+    import os
+    import re
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    names = sorted(os.path.basename(f) for f in glob.glob(os.path.join(root, "profiles", "r*_per_eval.csv"))
+                   if re.fullmatch(r"r\d\d[a-z]?_per_eval\.csv", os.path.basename(f)))
+    assert names, "profiles/ holds no per-evaluation table"
+    oldest = os.path.join(root, "profiles", names[0])
+    os.utime(oldest)  # make the OLDEST round the most recently touched file
+    t = bench.hbm_kernels(16)
+    assert t["source"].startswith(f"profiles/{names[-1]} "), t["source"]
+    assert any(k["group"].startswith("voxelize") and k["ms_per_eval"] > 0 for k in t["kernels"])
