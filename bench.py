@@ -400,6 +400,11 @@ def main():
     def one():
         return model.sample(x_start=x_start, steps=args.T, log_count=1, verbose=False, graph=bool(args.graph))
 
+    # the dominant GEMM once BEFORE the sampler has run (rank 0; reported beside `roofline`, never instead of it): the part clocks to
+    # its power budget, and the same launch is 10-15 % faster on a chip that has not just run twenty sampler calls
+    # (profiles/r05c_gemm_operand_and_batch.txt: neither the operand nor the batch explains the gap)
+    idle = gemm_roofline(model, args.batch, args.points) if rank == 0 else None
+
     for _ in range(args.warmup):
         out = one()
     torch.cuda.synchronize()
@@ -426,6 +431,9 @@ def main():
     res["config"]["conv_math"] = conv_math_note()
     if rank == 0:
         res["roofline"] = gemm_roofline(model, args.batch, args.points)
+        res["roofline"]["idle_chip"] = {"what": "the same launch timed BEFORE the sampler runs (the figure above is taken right behind the "
+                                                "timed sampler calls, on the clock the part holds under that load)",
+                                        "ms_per_launch": idle["ms_per_launch"], "achieved": idle["achieved"], "frac": idle["frac"]}
         res["roofline"]["second_kernel"] = conv_roofline(model, x_start)  # the voxel convolution the sampler runs
         evals = args.T
         res["roofline"]["sampler_dense_tflops"] = round(
