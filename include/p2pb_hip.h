@@ -348,14 +348,6 @@ int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, c
                            const float *shift, const float *mean_rstd, const float *gamma, const float *beta,
                            const float *style, int style_stride, int swish, float *dx, float *dgamma, float *dbeta,
                            float *dstyle, float *ws, void *stream);
-/* The same backward pass in ONE launch for layers whose (sample, group) slice is small: taken when ticket != NULL,
- * npos % 4 == 0 and (c / groups) * npos <= max_slice, else the call above (results are bit-identical either way). ticket:
- * one zero-initialised unsigned that belongs to the calling stream (the last workgroup to arrive adds the per-sample terms of
- * dgamma / dbeta in ascending sample order and leaves the ticket zero for the next launch). */
-int p2pb_norm_act_backward_fused(int b, int c, int groups, int npos, const float *x, const float *gy, const float *scale,
-                                 const float *shift, const float *mean_rstd, const float *gamma, const float *beta,
-                                 const float *style, int style_stride, int swish, float *dx, float *dgamma, float *dbeta,
-                                 float *dstyle, float *ws, unsigned *ticket, long max_slice, void *stream);
 /* SE3d gate (models/modules.py:362-378) folded into the devoxelisation affine: gate = sigmoid(w2 relu(w1 chmean)),
  * aff_a = scale*gate, aff_b = shift*gate. w1 f32[hidden,c], w2 f32[c,hidden] (nn.Linear layouts, no bias). */
 int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,

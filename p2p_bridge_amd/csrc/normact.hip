@@ -161,148 +161,6 @@ __global__ __launch_bounds__(256) void na_bwd_apply_kernel(int nb, int c, int gr
   }
 }
 
-// ONE launch for the layers whose (sample, group) slice is small (round 5, last session: the two launches above are ~10 us each
-// for the point-wise layers of a training batch of 8 x 2048 points, 48 layers per step, and neither fills the chip): workgroup
-// (b, g) of 1024 threads owns the group's cg rows -- pass 1 forms the row sums, four rows at a time, each row by 256 threads in
-// EXACTLY the order of na_bwd_reduce_kernel (per-thread fp32 partials over p = t + 256 j, then the fp64 tree of block_sum_256:
-// (a[t] + a[t+128]) + (a[t+64] + a[t+192]), then halving strides inside one wave), the group coefficients follow as in
-// na_bwd_apply_kernel's prologue, pass 2 applies them to the slice (still in L2). dgamma / dbeta need the rows of ALL samples:
-// every workgroup publishes its rows, takes a ticket, and the last one to arrive adds them in ascending sample order (fixed order
-// whoever arrives last: same bits as the two-launch path, tests/test_dense_train_gpu.py) and resets the ticket for the next launch.
-__device__ __forceinline__ double shfl_down_f64(double v, int s) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__shfl_down((int)(unsigned)u, s), hi = (unsigned)__shfl_down((int)(unsigned)(u >> 32), s);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-__global__ __launch_bounds__(1024) void na_bwd_fused_kernel(int nb, int c, int groups, int P, const float *__restrict__ x,
-                                                            const float *__restrict__ gy,
-                                                            const float *__restrict__ scale,
-                                                            const float *__restrict__ shift, int swish,
-                                                            float *__restrict__ rows,
-                                                            const float *__restrict__ mean_rstd,
-                                                            const float *__restrict__ gamma,
-                                                            const float *__restrict__ beta,
-                                                            const float *__restrict__ style, int style_stride,
-                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                            float *__restrict__ dstyle, float *__restrict__ dx,
-                                                            unsigned *__restrict__ ticket) {
-  __shared__ double sm1[4][256], sm2[4][256], w1[256], w2[256];
-  __shared__ float row_s[256][2], scs[256], shs[256], cf[2];
-  __shared__ int last;
-  const int bg = blockIdx.x, b = bg / groups, g = bg % groups, cg = c / groups;
-  const int tid = threadIdx.x, rs = tid >> 8, t = tid & 255;
-  const size_t row0 = (size_t)b * c + (size_t)g * cg;  // first row (b, channel) of the slice; its rows are contiguous
-  if (tid < cg) {
-    scs[tid] = scale[row0 + tid];
-    shs[tid] = shift[row0 + tid];
-  }
-  __syncthreads();
-  const int P4 = P >> 2;  // (the launcher takes this form for P % 4 == 0 only)
-  for (int k0 = 0; k0 < cg; k0 += 4) {
-    const int k = k0 + rs;
-    float s1 = 0.0f, s2 = 0.0f;
-    if (k < cg) {
-      const float sc = scs[k], sh = shs[k];
-      const f32x4 *x4 = (const f32x4 *)(x + (row0 + k) * P), *g4 = (const f32x4 *)(gy + (row0 + k) * P);
-      for (int p = t; p < P4; p += 256) {
-        const f32x4 xv = x4[p], gv = g4[p];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float gu = act_grad(xv[i] * sc + sh, gv[i], swish);
-          s1 += gu;
-          s2 += gu * xv[i];
-        }
-      }
-    }
-    sm1[rs][t] = (double)s1;
-    sm2[rs][t] = (double)s2;
-    __syncthreads();
-    if (t < 64) {
-      double a = (sm1[rs][t] + sm1[rs][t + 128]) + (sm1[rs][t + 64] + sm1[rs][t + 192]);
-      double q = (sm2[rs][t] + sm2[rs][t + 128]) + (sm2[rs][t + 64] + sm2[rs][t + 192]);
-#pragma unroll
-      for (int s = 32; s > 0; s >>= 1) {
-        a += shfl_down_f64(a, s);
-        q += shfl_down_f64(q, s);
-      }
-      if (t == 0 && k < cg) {
-        row_s[k][0] = (float)a;
-        row_s[k][1] = (float)q;
-        rows[(row0 + k) * 2] = (float)a;
-        rows[(row0 + k) * 2 + 1] = (float)q;
-      }
-    }
-    __syncthreads();
-  }
-  const double mu = (double)mean_rstd[((size_t)b * groups + g) * 2], rstd = (double)mean_rstd[((size_t)b * groups + g) * 2 + 1];
-  if (tid < cg) {
-    const int ch = g * cg + tid;
-    const double ga = gamma ? (double)gamma[ch] : 1.0, be = beta ? (double)beta[ch] : 0.0;
-    const double s1 = (double)row_s[tid][0], s2 = (double)row_s[tid][1];
-    const double f = style ? (double)style[(size_t)b * style_stride + ch] : 1.0;
-    const double t2 = rstd * (s2 - mu * s1);
-    w1[tid] = ga * f * s1;
-    w2[tid] = ga * f * t2;
-    if (style) {
-      dstyle[(size_t)b * 2 * c + ch] = (float)(ga * t2 + be * s1);  // d factor
-      dstyle[(size_t)b * 2 * c + c + ch] = (float)s1;               // d bias
-    }
-  }
-  __threadfence();  // this workgroup's rows are visible device-wide before its ticket is
-  __syncthreads();
-  if (tid == 0) {
-    double m1 = 0.0, m2 = 0.0;
-    for (int k = 0; k < cg; ++k) {
-      m1 += w1[k];
-      m2 += w2[k];
-    }
-    const double n = (double)P * cg;
-    m1 /= n;
-    m2 /= n;
-    cf[0] = (float)(-rstd * rstd * m2);
-    cf[1] = (float)(-rstd * m1 + mu * rstd * rstd * m2);
-  }
-  if (tid == 64) {
-    int l = 0;
-    if (dgamma || dbeta) {
-      l = atomicAdd(ticket, 1u) == gridDim.x - 1;
-      if (l) atomicExch(ticket, 0u);  // (everyone has drawn: the next launch on this stream starts from zero)
-    }
-    last = l;
-  }
-  __syncthreads();
-  if (last) {  // (workgroup-uniform) the parameter gradients: samples in ascending order
-    __threadfence();
-    const volatile float *vr = rows;
-    for (int ch = tid; ch < c; ch += 1024) {
-      const int gg = ch / cg;
-      double dga = 0.0, dbe = 0.0;
-      for (int bb = 0; bb < nb; ++bb) {
-        const double m = (double)mean_rstd[((size_t)bb * groups + gg) * 2], r = (double)mean_rstd[((size_t)bb * groups + gg) * 2 + 1];
-        const double s1 = (double)vr[((size_t)bb * c + ch) * 2], s2 = (double)vr[((size_t)bb * c + ch) * 2 + 1];
-        const double f = style ? (double)style[(size_t)bb * style_stride + ch] : 1.0;
-        dga += f * (r * (s2 - m * s1));
-        dbe += f * s1;
-      }
-      if (dgamma) dgamma[ch] = (float)dga;
-      if (dbeta) dbeta[ch] = (float)dbe;
-    }
-  }
-  const float c2 = cf[0], c3 = cf[1];
-  const f32x4 *x4 = (const f32x4 *)(x + row0 * P), *g4 = (const f32x4 *)(gy + row0 * P);
-  f32x4 *d4 = (f32x4 *)(dx + row0 * P);
-  for (int k = 0; k < cg; ++k) {
-    const float sc = scs[k], sh = shs[k];
-    for (int p = tid; p < P4; p += 1024) {
-      const f32x4 xv = x4[(size_t)k * P4 + p], gv = g4[(size_t)k * P4 + p];
-      f32x4 o;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = act_grad(xv[i] * sc + sh, gv[i], swish) * sc + xv[i] * c2 + c3;
-      d4[(size_t)k * P4 + p] = o;
-    }
-  }
-}
-
 // x, gy f32[b,c,npos]; scale, shift f32[b,c] and mean_rstd f32[b,groups,2] from p2pb_gn_affine_params_ex; gamma, beta
 // f32[c] or NULL; style rows (factor[c] | bias[c]) with pitch style_stride, or NULL. Outputs: dx f32[b,c,npos],
 // dgamma / dbeta f32[c] (may be NULL), dstyle f32[b,2c] (required iff style). ws: 2*b*c + 2*b*groups floats.
@@ -321,27 +179,6 @@ extern "C" int p2pb_norm_act_backward(int b, int c, int groups, int npos, const 
   const unsigned gx = (unsigned)((per + 255) / 256 > 32 ? 32 : (per + 255) / 256);
   hipLaunchKernelGGL(na_bwd_apply_kernel, dim3(gx, b * c), dim3(256), 0, s, b, c, groups, npos, x, gy, scale, shift, swish,
                      rows, mean_rstd, gamma, beta, style, style_stride, dgamma, dbeta, dstyle, dx);
-  return p2pb_launch_status();
-}
-
-// the same in ONE launch (na_bwd_fused_kernel) when the (sample, group) slices are small: npos % 4 == 0 and (c / groups) * npos <=
-// max_slice (0: never). `ticket`: one zero-initialised unsigned that stays with the calling STREAM (the kernel leaves it zero);
-// NULL or a shape outside the conditions: the two-launch path above. Same bits either way.
-extern "C" int p2pb_norm_act_backward_fused(int b, int c, int groups, int npos, const float *x, const float *gy,
-                                            const float *scale, const float *shift, const float *mean_rstd,
-                                            const float *gamma, const float *beta, const float *style, int style_stride,
-                                            int swish, float *dx, float *dgamma, float *dbeta, float *dstyle, float *ws,
-                                            unsigned *ticket, long max_slice, void *stream) {
-  const bool fused = ticket && groups > 0 && c > 0 && c % groups == 0 && npos > 0 && (npos & 3) == 0 &&
-                     (long)(c / groups) * npos <= max_slice;
-  if (!fused)
-    return p2pb_norm_act_backward(b, c, groups, npos, x, gy, scale, shift, mean_rstd, gamma, beta, style, style_stride, swish, dx,
-                                  dgamma, dbeta, dstyle, ws, stream);
-  if (b <= 0 || c / groups > 256 || !x || !gy || !scale || !shift || !mean_rstd || !dx || !ws ||
-      (style && (!dstyle || style_stride < 2 * c)))
-    return P2PB_EINVAL;
-  hipLaunchKernelGGL(na_bwd_fused_kernel, dim3(b * groups), dim3(1024), 0, (hipStream_t)stream, b, c, groups, npos, x, gy, scale,
-                     shift, swish, ws, mean_rstd, gamma, beta, style, style_stride, dgamma, dbeta, dstyle, dx, ticket);
   return p2pb_launch_status();
 }
 

@@ -17,7 +17,7 @@ import types
 
 import torch
 
-from . import _experiment, fused
+from . import fused
 from ._lib import call, lib, ptr, stream_ptr
 
 _i = ctypes.c_int
@@ -235,21 +235,6 @@ class _Pointwise(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
-NA_FUSED_MAX = 32768  # elements of a (sample, group) slice up to which the norm backward is one launch (A/B key na_fused_max)
-_TICKETS = {}
-
-
-def _ticket(device):
-    """the zero-initialised ticket word of p2pb_norm_act_backward_fused for the CURRENT stream of `device` (the kernel leaves it
-    zero; one per stream so that launches on different streams never share one. A first use inside a graph capture allocates
-    from the capture's pool and captures the zero fill with it -- harmless: the word is zero between launches anyway)"""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return t
-
-
 class _NormAct(torch.autograd.Function):
     """y = act(GroupNorm(x) * gamma + beta [* factor + bias]) with the statistics the producing convolution emitted:
     forward = gn_affine (fold to a per-(sample, channel) affine) + affine_act, backward = csrc/normact.hip (3 launches)"""
@@ -283,11 +268,9 @@ class _NormAct(torch.autograd.Function):
         dbeta = torch.empty_like(beta) if beta is not None else None
         dstyle = torch.empty(b, 2 * c, dtype=F32, device=x3.device) if style is not None else None
         ws = torch.empty(2 * b * c + 2 * b * groups, dtype=F32, device=x3.device)
-        # one launch instead of two where a (sample, group) slice is small (csrc/normact.hip na_bwd_fused_kernel: same bits)
-        call("p2pb_norm_act_backward_fused", _i(b), _i(c), _i(groups), _i(p), ptr(x3), ptr(gy), ptr(scale), ptr(shift), ptr(mr),
+        call("p2pb_norm_act_backward", _i(b), _i(c), _i(groups), _i(p), ptr(x3), ptr(gy), ptr(scale), ptr(shift), ptr(mr),
              ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0), _i(int(ctx.swish)),
-             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dstyle), ptr(ws), ptr(_ticket(x3.device)),
-             ctypes.c_long(_experiment.get_int("na_fused_max", NA_FUSED_MAX)), stream_ptr())
+             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dstyle), ptr(ws), stream_ptr())
         return dx.view(gy.shape), dgamma, dbeta, dstyle, None, None, None, None
 
 
