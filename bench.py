@@ -128,8 +128,9 @@ def gemm_roofline(model, B, P, reps=10):
     selects (f16x3 by default) that applies the previous layer's folded GroupNorm + Swish to its operand on load and whose
     epilogue emits the GroupNorm statistics and the per-channel {min, max} the max-pool is formed from -- the
     1024-channel output is never written. Timed live with HIP events on torch's current stream, launched exactly as
-    the sampler launches it, right after the timed sampler runs (a warm chip: 10-15 % slower than the same launch from
-    a cold start). `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
+    the sampler launches it, right after the timed sampler runs (the launch time follows the clock the part holds: 0.82-1.02 ms
+    for the same binary and operands depending on what ran before -- profiles/r05c_gemm_operand_and_batch.txt; behind the
+    sampler it sits in the middle of that range). `achieved` = algorithmic fp32 FLOPs (2*Cin*Cout per position) / mean launch time."""
     from p2p_bridge_amd import fused
 
     conv = model.model.global_pnet.mlp2.shared_mlp_1.mlp[0]
@@ -400,11 +401,6 @@ def main():
     def one():
         return model.sample(x_start=x_start, steps=args.T, log_count=1, verbose=False, graph=bool(args.graph))
 
-    # the dominant GEMM once BEFORE the sampler has run (rank 0; reported beside `roofline`, never instead of it): the part clocks to
-    # its power budget, and the same launch is 10-15 % faster on a chip that has not just run twenty sampler calls
-    # (profiles/r05c_gemm_operand_and_batch.txt: neither the operand nor the batch explains the gap)
-    idle = gemm_roofline(model, args.batch, args.points) if rank == 0 else None
-
     for _ in range(args.warmup):
         out = one()
     torch.cuda.synchronize()
@@ -431,9 +427,6 @@ def main():
     res["config"]["conv_math"] = conv_math_note()
     if rank == 0:
         res["roofline"] = gemm_roofline(model, args.batch, args.points)
-        res["roofline"]["idle_chip"] = {"what": "the same launch timed BEFORE the sampler runs (the figure above is taken right behind the "
-                                                "timed sampler calls, on the clock the part holds under that load)",
-                                        "ms_per_launch": idle["ms_per_launch"], "achieved": idle["achieved"], "frac": idle["frac"]}
         res["roofline"]["second_kernel"] = conv_roofline(model, x_start)  # the voxel convolution the sampler runs
         evals = args.T
         res["roofline"]["sampler_dense_tflops"] = round(
