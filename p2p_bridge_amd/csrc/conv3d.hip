@@ -112,7 +112,6 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(int cin, int cout, int n
   constexpr int PLANE = HD * HH * HW;
   constexpr int NTILES = (G::TD * G::TH * G::TW) / 32;  // N-tiles in the brick (8, or 2 for R=4)
   constexpr int BH = R / G::TH, BW = R / G::TW;          // bricks per sample along h, w
-  constexpr int NE = (CONV_CK * PLANE + 255) / 256;      // staged elements per thread per chunk
   constexpr int R3 = R * R * R;
   __shared__ float tile[CONV_CK * PLANE];
 
@@ -654,7 +653,8 @@ struct PreStage {
           asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
                        :
                        : "v"(off[j]), "s"(rs), "s"(so), "s"(m0v)
-                       : "memory", "m0");
+                       : "memory");  // (m0 is a reserved register: the compiler does not track it as a clobber -- and uses it nowhere in this
+                                     //  object, tools/disasm.sh conv3d: every m0 reference is one of these s_mov_b32)
       }
     }
   }

@@ -476,7 +476,6 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
   // network's fixed tree instead of the 5-step ladder (the partials change in their last bit, deterministically).
   float *outb = out ? out + (size_t)b * cout * P : nullptr;
   const int slot = (blockIdx.x * 4 + wave) * 2;  // this wave fills slot `slot` with its 128-position sums and zeroes slot + 1
-  constexpr int NR = 16 * MT;                    // rows (output channels) per half-wave
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll

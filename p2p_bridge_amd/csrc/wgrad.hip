@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_wgrad_lds_kernel(int nb, int
                                                                      const float *__restrict__ dy,
                                                                      float *__restrict__ part,
                                                                      float *__restrict__ bpart) {
-  static_assert(R >= 8 && 32 % R == 0 || R == 32, "a K unit is whole grid rows");
+  static_assert((R >= 8 && 32 % R == 0) || R == 32, "a K unit is whole grid rows");
   constexpr int R3 = R * R * R, UPS = R3 / 32;  // units per sample
   constexpr int P = 80, ROWS = 256, PB = ROWS * P + 32;  // row pitch (bytes), rows per plane (64 dY + 3 x 64 X), plane bytes
   __shared__ __attribute__((aligned(16))) unsigned char lds[NTERM * PB];
