@@ -818,14 +818,96 @@ __global__ __launch_bounds__(256) void devox_cl_kernel(int c, int n, int r, cons
   }
 }
 
+// the same pass with 16-byte gathers (round 5, last session): a lane owns FOUR channels of one point -- 16 lanes cover the 64-channel
+// chunk, a wave instruction fetches the corner rows of four points -- a quarter of the load instructions for the same bytes; every
+// (point, channel) value goes through the same multiplies and fused adds in the same order: bit-identical. c % 64 == 0.
+__global__ __launch_bounds__(256) void devox_cl4_kernel(int c, int n, int r, const float *__restrict__ coords,
+                                                        const float *__restrict__ grid, const float *__restrict__ aff_a,
+                                                        const float *__restrict__ aff_b, const float *__restrict__ add,
+                                                        const float *__restrict__ add_scale,
+                                                        const float *__restrict__ add_shift, float *__restrict__ outs) {
+  __shared__ float tile[64][65];  // [channel][point]
+  __shared__ __attribute__((aligned(16))) int sidx[64][8];
+  __shared__ __attribute__((aligned(16))) float sw[64][8];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int b = blockIdx.z, p0 = blockIdx.x * 64, t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int r3 = r * r * r;
+  if (lane < 16) {  // (every wave stages its own 16 points with 16-byte LDS stores: see devox_cl_kernel)
+    const int tt = wave * 16 + lane;
+    const int i = min(p0 + tt, n - 1);
+    const float *co = coords + (size_t)b * 3 * n;
+    const Corners k = devox_corners(co[i], co[i + n], co[i + 2 * n], r);
+#define DV_LDS __attribute__((address_space(3)))
+    *(volatile DV_LDS i32x4 *)&sidx[tt][0] = i32x4{k.idx[0], k.idx[1], k.idx[2], k.idx[3]};
+    *(volatile DV_LDS i32x4 *)&sidx[tt][4] = i32x4{k.idx[4], k.idx[5], k.idx[6], k.idx[7]};
+    *(volatile DV_LDS f32x4 *)&sw[tt][0] = f32x4{k.w[0], k.w[1], k.w[2], k.w[3]};
+    *(volatile DV_LDS f32x4 *)&sw[tt][4] = f32x4{k.w[4], k.w[5], k.w[6], k.w[7]};
+#undef DV_LDS
+  }
+  __syncthreads();
+  const float *g = grid + (size_t)b * r3 * c;
+  const int c0 = blockIdx.y * 64;
+  {
+    const int cq = lane & 15, ps = lane >> 4;
+    const int ch4 = c0 + 4 * cq;
+    f32x4 a4 = {1.0f, 1.0f, 1.0f, 1.0f}, b4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (aff_a) {
+      a4 = *(const f32x4 *)(aff_a + (size_t)b * c + ch4);
+      b4 = *(const f32x4 *)(aff_b + (size_t)b * c + ch4);
+    }
+#pragma unroll 2
+    for (int it = 0; it < 4; ++it) {
+      const int pl = wave * 16 + it * 4 + ps;
+      f32x4 fv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fv[q] = *(const f32x4 *)(g + (size_t)sidx[pl][q] * c + ch4);
+      if (aff_a) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) fv[q][i] = fv[q][i] * a4[i] + b4[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float acc = sw[pl][0] * fv[0][i];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) acc = __fmaf_rn(sw[pl][q], fv[q][i], acc);
+        tile[4 * cq + i][pl] = acc;
+      }
+    }
+  }
+  __syncthreads();
+  const int pt = t & 63;
+  if (p0 + pt < n) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int cr = (t >> 6) + 4 * k;
+      const size_t o = ((size_t)b * c + c0 + cr) * n + p0 + pt;
+      float v = tile[cr][pt];
+      if (add) {
+        const float z = add[o] * add_scale[(size_t)b * c + c0 + cr] + add_shift[(size_t)b * c + c0 + cr];
+        v = z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f)) + v;
+      }
+      outs[o] = v;
+    }
+  }
+}
+
 extern "C" int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, const float *coords, const float *grid,
                                                    const float *aff_a, const float *aff_b, const float *add,
                                                    const float *add_scale, const float *add_shift, float *outs,
                                                    void *stream) {
   if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || ((aff_a == nullptr) != (aff_b == nullptr))) return P2PB_EINVAL;
   if (add && (!add_scale || !add_shift)) return P2PB_EINVAL;
-  hipLaunchKernelGGL(devox_cl_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
-                     aff_a, aff_b, add, add_scale, add_shift, outs);
+  static const long wide = p2pb_experiment_long("devox_cl4", 1);  // (A/B switch: 0 = the 4-byte gathers everywhere)
+  if (wide && c % 64 == 0)
+    hipLaunchKernelGGL(devox_cl4_kernel, dim3(cdiv(n, 64), c / 64, b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
+                       aff_a, aff_b, add, add_scale, add_shift, outs);
+  else
+    hipLaunchKernelGGL(devox_cl_kernel, dim3(cdiv(n, 64), cdiv(c, 64), b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
+                       aff_a, aff_b, add, add_scale, add_shift, outs);
   return p2pb_launch_status();
 }
 

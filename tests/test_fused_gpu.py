@@ -260,7 +260,8 @@ def test_gn_affine_params(fused, groups, style):
         assert rel_err(got, ref) < TOL
 
 
-@pytest.mark.parametrize("B,C,N,r", [(2, 64, 2048, 32), (2, 35, 1000, 16), (3, 200, 300, 8), (1, 16, 64, 4)])
+@pytest.mark.parametrize("B,C,N,r", [(2, 64, 2048, 32), (2, 35, 1000, 16), (3, 200, 300, 8), (1, 16, 64, 4),
+                                     (2, 128, 1000, 16), (1, 256, 130, 8)])  # (C % 64 == 0: the 16-byte-gather devoxelisation)
 def test_voxel_major_voxelize_devoxelize(fused, B, C, N, r):
     """the voxel-major forms produce exactly the values of the reference-layout ops (same arithmetic and order)"""
     from p2p_bridge_amd import pointnet2_batch_cuda as ext
