@@ -192,7 +192,7 @@ HBM_GROUPS = [
      "8 small launches per level on 16 clouds: the coordinate half (voxel_coords, count / scan / fill / sort: one workgroup per cloud "
      "for the deterministic reductions and the scan) is latency-bound and runs on the geometry stream beside the dense layers; the "
      "gathers move 60 % of the bytes at ~2 TB/s"),
-    ("devoxelize (a12)", 26.11, ("devox_cl_kernel",),
+    ("devoxelize (a12)", 26.11, ("devox_cl",),  # (devox_cl_kernel and, for C % 64 == 0, devox_cl4_kernel)
      "8-corner gather of voxel-major rows (256 B per corner and point at C = 64): L2-resident grid, the point-major -> channel-major "
      "transpose through LDS"),
     ("grouping (a17: group_sub / group_stats, the set abstraction's gathered first layer)", 19.86, ("group_sub_kernel", "group_stats_kernel"),
