@@ -902,7 +902,7 @@ extern "C" int p2pb_trilinear_devoxelize_cl_affine(int b, int c, int n, int r, c
   if (b <= 0 || c <= 0 || n <= 0 || r <= 0 || ((aff_a == nullptr) != (aff_b == nullptr))) return P2PB_EINVAL;
   if (add && (!add_scale || !add_shift)) return P2PB_EINVAL;
   static const long wide = p2pb_experiment_long("devox_cl4", 1);  // (A/B switch: 0 = the 4-byte gathers everywhere)
-  if (wide && c % 64 == 0)
+  if (wide && c % 64 == 0 && (((size_t)grid | (size_t)aff_a | (size_t)aff_b) & 15) == 0)  // (16-byte loads: rows and tables aligned)
     hipLaunchKernelGGL(devox_cl4_kernel, dim3(cdiv(n, 64), c / 64, b), dim3(256), 0, (hipStream_t)stream, c, n, r, coords, grid,
                        aff_a, aff_b, add, add_scale, add_shift, outs);
   else
