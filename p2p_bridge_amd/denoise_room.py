@@ -11,10 +11,12 @@ sklearn KD-tree, numba and fpsample:
     merge       numba running mean over the overlapping patches                        csrc/room.hip merge_*
 
 Parity: the radius query's SET of points, the normalisation and the merge (a mean) are defined exactly and are tested
-against the oracle. sklearn's list order (tree order), numpy's global RNG and fpsample's bucket FPS (its start point
-is random and comes from its own Rust RNG) are third-party behaviour with no definition in /root/reference: the contract
-restated here -- ascending index lists, every random draw from ONE caller-supplied torch CPU generator in a fixed order,
-exact FPS from a drawn start index -- is "parity unpinned" against the reference and pinned to the test oracle's restatement of the same contract.
+against the oracle; the radius lists are also pinned against scikit-learn's own KDTree.query_radius through a committed fixture
+(tests/golden/room_radius.npz, tools/make_golden_room.py: same sets; ascending here, tree order there). numpy's global RNG and
+fpsample's bucket FPS (its start point is random and comes from its own Rust RNG) are third-party behaviour with no definition in
+/root/reference and not installable here: the contract restated for them -- every random draw from ONE caller-supplied torch CPU
+generator in a fixed order, exact FPS from a drawn start index -- is "parity unpinned" against the reference and pinned to the test
+oracle's restatement of the same contract.
 """
 import ctypes
 from typing import Optional

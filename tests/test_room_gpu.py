@@ -26,6 +26,15 @@ def room(n, seed=0):
     return (p + 0.005 * torch.randn(n, 3, generator=g)).contiguous()
 
 
+def test_radius_query_matches_scikit_learn():
+    """the HIP radius lists against scikit-learn's own KDTree.query_radius (the reference's call, denoise_room.py:454,464)
+    through the committed fixture -- the same check the oracle passes on the CPU (tests/test_room_oracle.py)"""
+    from p2p_bridge_amd import denoise_room as R
+    from test_room_oracle import check_against_sklearn
+
+    check_against_sklearn(lambda cen, pts, r: R.radius_query(cen.cuda(), pts.cuda(), r))
+
+
 @pytest.mark.parametrize("n,s,r", [(20000, 37, 0.5), (5000, 8, 0.3), (1000, 5, 0.0), (777, 3, 10.0), (70000, 64, 0.41)])
 def test_radius_query_exact(n, s, r):
     from p2p_bridge_amd import denoise_room as R

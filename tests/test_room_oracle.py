@@ -1,6 +1,11 @@
 """The oracle's room-pipeline restatement (oracle/cpu_ops.py, denoise_room.py:352-421,263-289) on CPU: the radius
 lists against a float64 brute force, the literal sequential running mean against the plain mean, patch construction
-invariants. (sklearn / fpsample / numpy-RNG are not under /root/reference: parity unpinned there, see DESIGN.md.)"""
+invariants; the radius lists also against scikit-learn's own KDTree.query_radius -- the call the reference makes -- through a
+committed fixture (tests/golden/room_radius.npz, tools/make_golden_room.py). (fpsample / numpy-RNG are not available: parity
+unpinned there, see DESIGN.md.)"""
+import os
+
+import numpy as np
 import torch
 
 from oracle import cpu_ops
@@ -47,3 +52,30 @@ def test_running_mean_is_the_mean_and_patches_are_consistent():
     hit = cnt > 0
     assert (den[hit] - sums[hit] / cnt[hit, None]).abs().max().item() < 1e-12
     assert torch.equal(den[~hit], pts[~hit].double())
+
+
+def check_against_sklearn(radius_query):
+    """radius_query(centers f32[S,3], points f32[N,3], r) -> (flat idx ascending per centre, offsets) against the lists
+    scikit-learn's KDTree.query_radius returned for the same call (denoise_room.py:454,464). scikit-learn measures in float64, the
+    pipeline in fp32: a pair may only differ if its float64 squared distance lies within 1e-6 (relative) of r^2."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "room_radius.npz"))
+    pts, cen = torch.from_numpy(g["points"]), torch.from_numpy(g["centers"])
+    total_ties = 0
+    for tag, r in (("r03", 0.3), ("r05", 0.5)):
+        idx, off = radius_query(cen, pts, r)
+        idx, off = idx.cpu().long(), off.cpu()
+        gi, go = torch.from_numpy(g[f"idx_{tag}"]).long(), torch.from_numpy(g[f"off_{tag}"])
+        for c in range(cen.shape[0]):
+            got, want = idx[off[c]:off[c + 1]], gi[go[c]:go[c + 1]]
+            assert torch.equal(got, torch.sort(got).values)  # ascending, as the contract says
+            if torch.equal(got, want):
+                continue
+            odd = torch.from_numpy(np.setxor1d(got.numpy(), want.numpy())).long()
+            d2 = (pts[odd].double() - cen[c].double()).pow(2).sum(-1)
+            assert ((d2 - r * r).abs() <= 1e-6 * r * r).all(), (tag, c, odd.tolist(), d2.tolist())
+            total_ties += odd.numel()
+    assert total_ties <= 2  # (16751 pairs in the fixture: boundary ties are a rarity, not a habit)
+
+
+def test_radius_query_matches_scikit_learn():
+    check_against_sklearn(cpu_ops.radius_query)
