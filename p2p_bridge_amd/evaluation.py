@@ -139,7 +139,7 @@ def get_metrics(gt, pred, model=None, fast: bool = True) -> Tuple[float, float, 
         gt = gt.transpose(1, 2)
     if fast:
         p3, g3 = _points_last(pred, gt)
-        cd = float(np.mean(M.calculate_cd_cuda(p3.contiguous(), g3.contiguous()).cpu().numpy())) * 1000
+        cd = float(np.mean(M.calculate_cd_cuda(p3.contiguous(), g3.contiguous()))) * 1000
         loss = float(np.mean(model.loss(pred, gt).cpu().numpy())) if model is not None else 0
         # the reference averages the approximate EMD per chunk of four clouds first, then over the chunks
         chunks = [float(np.mean(M.earth_mover_distance_nograd(p, g, transpose=p.shape[-1] > p.shape[-2]).cpu().numpy()))

@@ -132,21 +132,28 @@ class emdModule(nn.Module):
 
 @torch.no_grad()
 def calculate_cd_cuda(pred, gt, batch_size=4):
-    """CD-L2 = mean_i min_j + mean_j min_i, evaluated in chunks (metrics/metrics.py:56-83). pred/gt [B,N,3]"""
+    """CD-L2 = mean_i min_j + mean_j min_i per cloud, evaluated in chunks of four (metrics/metrics.py:56-83): either layout
+    ([B,N,3], or [B,3,N] -- "make sure that last dimension is 3", :68-70), a LIST of B floats like the reference's
+    (tests/golden/metric_wrappers.npz: the reference's own function on seeded clouds)"""
+    if pred.shape[-1] != 3:
+        pred, gt = pred.transpose(-1, -2), gt.transpose(-1, -2)
     out = []
     for s in range(0, pred.shape[0], batch_size):
         d1, d2 = chamfer_dist_nograd(pred[s:s + batch_size].contiguous(), gt[s:s + batch_size].contiguous())
-        out.append(d1.mean(dim=1) + d2.mean(dim=1))
-    return torch.cat(out)
+        out.append((d1.mean(dim=1) + d2.mean(dim=1)).cpu())
+    return torch.cat(out).tolist()
 
 
 @torch.no_grad()
 def calculate_emd_cuda(pred, gt, batch_size=4):
-    """approximate EMD / N in chunks (metrics/metrics.py:86-108). pred/gt [B,N,3]"""
+    """approximate EMD / N (metrics/metrics.py:86-108): either layout (transposed when the last dimension is the longer one,
+    :103), and -- as the reference -- ONE number per chunk of four clouds, the mean over the chunk (:104-106): a list of
+    ceil(B / 4) floats, not of B"""
     out = []
     for s in range(0, pred.shape[0], batch_size):
-        out.append(earth_mover_distance_nograd(pred[s:s + batch_size], gt[s:s + batch_size], transpose=False))
-    return torch.cat(out)
+        p, g = pred[s:s + batch_size], gt[s:s + batch_size]
+        out.append(float(earth_mover_distance_nograd(p, g, transpose=p.shape[-1] > p.shape[-2]).mean().item()))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -117,3 +117,40 @@ def test_point_mesh_pipeline(M):
     pd0, fd0 = M.point_mesh_face_distance(M.normalize_pcl(on.cuda()[None], *M.normalize_sphere(verts.cuda()[None])[1:])[0],
                                           M.normalize_sphere(verts.cuda()[None])[0][0], faces.cuda(), 0.0)
     assert abs(both.item() - (pd0 + fd0).item()) < 1e-9
+
+
+def test_metric_wrappers_match_the_reference_functions(M):
+    """calculate_cd_cuda / normalize_sphere / normalize_pcl / cd_unit_sphere against the values the REFERENCE's own
+    metrics/metrics.py functions returned for the same seeded clouds (tests/golden/metric_wrappers.npz, made by
+    tools/make_golden_metrics.py from the reference's Python with the oracle ops injected): layouts and transposes, chunks of
+    four, which means are added, the reference cloud's sphere applied to the generated one, list return types"""
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metric_wrappers.npz"))
+    gen, ref = torch.from_numpy(g["gen"]).cuda(), torch.from_numpy(g["ref"]).cuda()
+    cd = M.calculate_cd_cuda(gen, ref)
+    assert isinstance(cd, list) and len(cd) == 6 and all(isinstance(v, float) for v in cd)
+    np.testing.assert_allclose(cd, g["cd_bn3"], rtol=2e-6)
+    np.testing.assert_allclose(M.calculate_cd_cuda(gen.transpose(1, 2).contiguous(), ref.transpose(1, 2).contiguous()),
+                               g["cd_b3n"], rtol=2e-6)  # ("make sure that last dimension is 3")
+    pc, center, scale = M.normalize_sphere(ref)
+    assert torch.equal(center.cpu(), torch.from_numpy(g["sphere_center"]))  # (max, min, one add, one halving: exact)
+    np.testing.assert_allclose(scale.cpu().numpy(), g["sphere_scale"], rtol=1e-6)
+    np.testing.assert_allclose(pc.cpu().numpy(), g["sphere_pc"], rtol=0, atol=2e-7)
+    pc2, _, scale2 = M.normalize_sphere(ref, radius=0.5)
+    np.testing.assert_allclose(scale2.cpu().numpy(), g["sphere_scale_r05"], rtol=1e-6)
+    np.testing.assert_allclose(pc2.cpu().numpy(), g["sphere_pc_r05"], rtol=0, atol=2e-7)
+    np.testing.assert_allclose(M.normalize_pcl(gen, center, scale).cpu().numpy(), g["pcl_norm"], rtol=0, atol=3e-7)
+    for i in range(6):
+        got = M.cd_unit_sphere(gen[i:i + 1], ref[i:i + 1])
+        assert isinstance(got, tuple) and isinstance(got[0], float)
+        np.testing.assert_allclose(got, g["cd_unit"][i], rtol=2e-5)  # (squared distances of coordinates rounded at 1e-7)
+        np.testing.assert_allclose(M.cd_unit_sphere(gen[i:i + 1], ref[i:i + 1], normalize=False), g["cd_unit_raw"][i], rtol=2e-6)
+    # the approximate-EMD wrapper returns ONE mean per chunk of four clouds, as the reference does (metrics/metrics.py:104-106)
+    emd = M.calculate_emd_cuda(gen, ref)
+    per = M.earth_mover_distance_nograd(gen, ref, transpose=False).cpu()
+    assert isinstance(emd, list) and len(emd) == 2
+    np.testing.assert_allclose(emd, [per[:4].mean().item(), per[4:].mean().item()], rtol=1e-6)
+    np.testing.assert_allclose(M.calculate_emd_cuda(gen.transpose(1, 2).contiguous(), ref.transpose(1, 2).contiguous()), emd, rtol=1e-6)
