@@ -1,8 +1,12 @@
 """Object patch pipeline (denoise_object.py:65-122): HIP ops vs the oracle's restatements of the
 pytorch3d / torch_cluster contracts. Indices bit-exact, distances bit-exact (same fma chain)."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
+from conftest import GOLDEN
 from oracle import cpu_ops
 
 pytestmark = pytest.mark.gpu
@@ -156,3 +160,51 @@ def test_patch_based_denoise_with_the_network(dn):
     merged = tr["patches_denoised"].reshape(1, -1, 3).contiguous()
     _, idx_ref = cpu_ops.farthest_point_sampling(merged.cpu(), 3 * K)
     assert torch.equal(tr["fps_idx"].cpu(), idx_ref[0])
+
+
+class _ShrinkChain:
+    """the stand-in sampler of tools/make_golden_object.py (tests/test_denoise_oracle.py shrink_chain)"""
+
+    def eval(self):
+        return self
+
+    def sample(self, x_start=None, use_ema=False, steps=None, log_count=None, verbose=False, graph=False):
+        chain = [x_start * (1.0 - 0.1 * (i + 1) / steps) for i in range(steps)]
+        return {"x_pred": chain[-1], "x_chain": torch.stack(chain, 1), "x_start": x_start}
+
+
+def test_patch_based_denoise_matches_the_reference_function(dn):
+    """the product's patch_based_denoise / farthest_point_sampling against the outputs of the REFERENCE's own
+    denoise_object.patch_based_denoise (:65-122) and models.evaluation.farthest_point_sampling (:297-311) on the same seeded
+    cloud and stand-in sampler (tests/golden/object_pipeline.npz, tools/make_golden_object.py): seed count, FPS ratio, one scale
+    per batch, layouts around model.sample, de-normalisation, the FPS merge and the per-step clouds"""
+    g = np.load(os.path.join(GOLDEN, "object_pipeline.npz"))
+    pcl, K = torch.from_numpy(g["pcl"]).cuda(), int(g["patch_size"])
+
+    def nearest(a, b):  # for every row of a: distance to the closest row of b
+        return torch.cdist(a.double(), b.double()).min(1).values
+
+    for seed_k in (3, 2):
+        tr = {}
+        out, steps = dn.patch_based_denoise(_ShrinkChain(), pcl, K, seed_k=seed_k, cfg={"steps": 3, "use_ema": False},
+                                            save_intermediate=(seed_k == 3), trace=tr)
+        want = torch.from_numpy(g[f"denoised_k{seed_k}"])
+        assert out.shape == want.shape and tr["patches_denoised"].shape[0] == int(seed_k * pcl.shape[0] / K)
+        # The merge is FPS, which is chaotic in near-ties: one last-bit difference in a de-normalised coordinate (torch elementwise
+        # ops on the CPU there, on the GPU here) changes every later pick. So: (1) every point the reference function returned is
+        # one of the product's de-normalised patch points -- seeds, K-NN patches, centring, the ONE scale, the sampler's layouts and
+        # the de-normalisation all have to agree for that; (2) the rows agree one by one up to the first flipped pick; (3) the
+        # product's merge is the exact FPS of its own candidates (tests above: index-exact against the oracle, which equals the
+        # reference function bit for bit on the CPU -- tests/test_denoise_oracle.py).
+        cand = tr["patches_denoised"].reshape(-1, 3).cpu()
+        assert nearest(want, cand).max().item() < 2e-6
+        same = ((out.cpu() - want).abs().amax(1) < 2e-6)
+        first_flip = int((~same).nonzero()[0]) if not bool(same.all()) else len(same)
+        assert first_flip >= 1 and same[:first_flip].all()
+        assert nearest(out.cpu(), cand).max().item() == 0.0
+        if seed_k == 3:
+            want_steps = torch.from_numpy(g["steps_k3"])
+            assert steps.shape == want_steps.shape
+            assert nearest(want_steps[-1], cand).max().item() < 2e-6  # (the last step's cloud is drawn from the same candidates)
+    s, idx = dn.farthest_point_sampling(pcl[None].contiguous(), 100)
+    assert torch.equal(idx[0].cpu(), torch.from_numpy(g["fps100_idx"])) and torch.equal(s.cpu(), torch.from_numpy(g["fps100"]))

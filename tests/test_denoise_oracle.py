@@ -41,3 +41,30 @@ def test_pipeline_restatement_shapes():
     # identity "denoiser": every output point is an input point
     d = ((out[:, None] - pcl[None]) ** 2).sum(-1).min(1).values
     assert d.max().item() < 1e-10
+
+
+def _object_golden():
+    import os
+
+    import numpy as np
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "object_pipeline.npz"))
+
+
+def shrink_chain(x_start, steps=3):
+    """the stand-in sampler of tools/make_golden_object.py"""
+    return [x_start * (1.0 - 0.1 * (i + 1) / steps) for i in range(steps)]
+
+
+def test_pipeline_restatement_equals_the_reference_function():
+    """oracle/cpu_ops.patch_based_denoise and farthest_point_sampling against the outputs of the REFERENCE's own
+    denoise_object.patch_based_denoise / models.evaluation.farthest_point_sampling (tests/golden/object_pipeline.npz: the
+    reference's Python run by tools/make_golden_object.py around the same stand-in sampler, its two pip dependencies injected by
+    their published contracts): bit for bit"""
+    g = _object_golden()
+    pcl, K = torch.from_numpy(g["pcl"]), int(g["patch_size"])
+    for seed_k in (3, 2):
+        out = cpu_ops.patch_based_denoise(lambda x: shrink_chain(x)[-1], pcl, K, seed_k=seed_k)
+        assert torch.equal(out, torch.from_numpy(g[f"denoised_k{seed_k}"]))
+    s, idx = cpu_ops.farthest_point_sampling(pcl[None].contiguous(), 100)
+    assert torch.equal(idx[0], torch.from_numpy(g["fps100_idx"])) and torch.equal(s, torch.from_numpy(g["fps100"]))
