@@ -119,3 +119,36 @@ def test_pipeline_with_real_sampler():
     err = (out.cpu() - ref).abs().max().item()
     print(f"\nroom pipeline, real sampler: max|hip - oracle| = {err:.3e} (room extent 4 x 3 x 2.5 m)")
     assert err < 1e-4
+
+
+class _Stand:
+    """the stand-in sampler of tools/make_golden_room_fns.py"""
+
+    def sample(self, x_start=None, x_cond=None, verbose=False, steps=3, use_ema=False, log_count=3, graph=False):
+        bend = 0.0 if x_cond is None else 0.01 * x_cond.mean(dim=1, keepdim=True)
+        chain = [x_start * (1.0 - 0.1 * (i + 1) / steps) + bend for i in range(steps)]
+        return {"x_pred": chain[-1], "x_chain": torch.stack(chain, 1), "x_start": x_start}
+
+
+def test_merge_and_patch_batch_match_the_reference_functions():
+    """RunningMean and denoise_patch_batch against the outputs of the REFERENCE's own update_prediction_noisy_batches
+    (denoise_room.py:263-289) and denoise_patch_batch (:104-174) on seeded inputs (tests/golden/room_functions.npz,
+    tools/make_golden_room_fns.py): update counts exact; the merged cloud, the per-PATCH normalisation, the layouts around
+    model.sample (with and without RGB conditioning), the de-normalised prediction and chain to fp32 rounding"""
+    from p2p_bridge_amd import denoise_room as R
+
+    g = np.load(os.path.join(GOLDEN, "room_functions.npz"))
+    pts, pred = torch.from_numpy(g["points"]).cuda(), torch.from_numpy(g["pred"]).cuda()
+    idx, cuts = torch.from_numpy(g["idx"]).cuda(), torch.from_numpy(g["cuts"])
+    m = R.RunningMean(pts)
+    m.update(pred[:10], idx[:10], cuts[:10])
+    m.update(pred[10:], idx[10:], cuts[10:])
+    assert torch.equal(m.counts.cpu().double(), torch.from_numpy(g["num_updates"]))
+    assert (m.result().cpu() - torch.from_numpy(g["merged"])).abs().max().item() < 2e-6
+    patch, rgb = torch.from_numpy(g["patch"]).cuda(), torch.from_numpy(g["rgb"]).cuda()
+    den, chain = R.denoise_patch_batch(_Stand(), patch, steps=3, return_steps=True)
+    assert (den.cpu() - torch.from_numpy(g["patch_denoised"])).abs().max().item() < 2e-6
+    assert chain.shape == g["patch_chain"].shape and (chain.cpu() - torch.from_numpy(g["patch_chain"])).abs().max().item() < 2e-6
+    den_rgb, _ = R.denoise_patch_batch(_Stand(), patch, patch_rgb=rgb, steps=3, use_rgb_features=True)
+    assert (den_rgb.cpu() - torch.from_numpy(g["patch_denoised_rgb"])).abs().max().item() < 2e-6
+    assert (den_rgb - den).abs().max().item() > 1e-3  # (the conditioning reached the sampler)

@@ -79,3 +79,15 @@ def check_against_sklearn(radius_query):
 
 def test_radius_query_matches_scikit_learn():
     check_against_sklearn(cpu_ops.radius_query)
+
+
+def test_running_mean_equals_the_reference_function():
+    """oracle/cpu_ops.room_merge against the output of the REFERENCE's own update_prediction_noisy_batches
+    (denoise_room.py:263-289, run by tools/make_golden_room_fns.py with numba's @njit as an identity decorator) on seeded patches,
+    two batches into one state: update counts exact, means to fp32 rounding (the reference averages in the cloud's dtype)"""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "room_functions.npz"))
+    pts, pred = torch.from_numpy(g["points"]), torch.from_numpy(g["pred"])
+    den, num = cpu_ops.room_merge(pts, pred, torch.from_numpy(g["idx"]), torch.from_numpy(g["cuts"]))
+    assert torch.equal(num, torch.from_numpy(g["num_updates"]))
+    assert (den - torch.from_numpy(g["merged"]).double()).abs().max().item() < 2e-6
+    assert (num == 0).any() and (num > 1).any()  # untouched points keep their coordinates, shared ones are averaged

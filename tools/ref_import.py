@@ -51,6 +51,7 @@ def _stub(name, **attrs):
 def install():
     if not available():
         raise RuntimeError("reference tree not present at %s" % REF)
+    sys.dont_write_bytecode = True  # the reference tree is read-only for this project: no __pycache__ next to its sources
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
     if REF not in sys.path:
