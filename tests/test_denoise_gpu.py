@@ -208,3 +208,14 @@ def test_patch_based_denoise_matches_the_reference_function(dn):
             assert nearest(want_steps[-1], cand).max().item() < 2e-6  # (the last step's cloud is drawn from the same candidates)
     s, idx = dn.farthest_point_sampling(pcl[None].contiguous(), 100)
     assert torch.equal(idx[0].cpu(), torch.from_numpy(g["fps100_idx"])) and torch.equal(s.cpu(), torch.from_numpy(g["fps100"]))
+
+
+def test_knn_points_matches_scikit_learn(dn):
+    """the HIP K-NN against scikit-learn's brute-force NearestNeighbors (the check the oracle's restated contract passes on the CPU)"""
+    from test_denoise_oracle import check_knn_against_sklearn
+
+    def hip(p1, p2, K):
+        r = dn.knn_points(p1.cuda(), p2.cuda(), K=K)
+        return r.dists, r.idx
+
+    check_knn_against_sklearn(hip)

@@ -68,3 +68,29 @@ def test_pipeline_restatement_equals_the_reference_function():
         assert torch.equal(out, torch.from_numpy(g[f"denoised_k{seed_k}"]))
     s, idx = cpu_ops.farthest_point_sampling(pcl[None].contiguous(), 100)
     assert torch.equal(idx[0], torch.from_numpy(g["fps100_idx"])) and torch.equal(s, torch.from_numpy(g["fps100"]))
+
+
+def check_knn_against_sklearn(knn_points):
+    """knn_points(p1 [1,S,3], p2 [1,N,3], K) -> (dist2, idx, ...) against scikit-learn's brute-force NearestNeighbors on the same
+    cloud (tests/golden/knn_sklearn.npz, tools/make_golden_knn.py): an external anchor for the restated pytorch3d.ops.knn_points
+    contract -- the same neighbours in the same ascending order (positions whose neighbouring distances differ by less than 1e-7
+    may swap: scikit-learn measures in float64), the same squared distances to fp32 rounding"""
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "knn_sklearn.npz"))
+    pts, seeds, K = torch.from_numpy(g["points"]), torch.from_numpy(g["seeds"]), int(g["K"])
+    out = knn_points(seeds[None].contiguous(), pts[None].contiguous(), K)
+    d, i = out[0][0].cpu().double(), out[1][0].cpu().long()
+    gi, gd = torch.from_numpy(g["idx"]).long(), torch.from_numpy(g["dist2"])
+    assert (d - gd).abs().max().item() < 1e-6
+    for q in range(seeds.shape[0]):
+        assert set(i[q].tolist()) == set(gi[q].tolist())
+    gap = torch.minimum(torch.diff(gd, dim=1, prepend=gd[:, :1] - 1), torch.diff(gd, dim=1, append=gd[:, -1:] + 1).abs())
+    sure = gap > 1e-7
+    assert torch.equal(i[sure], gi[sure]) and sure.float().mean().item() > 0.99
+
+
+def test_knn_contract_matches_scikit_learn():
+    check_knn_against_sklearn(cpu_ops.knn_points)
