@@ -12,7 +12,7 @@ Exact ties (lattices, duplicated points -- fp32 arithmetic is exact there too) a
 oracle documents: FPS (d desc, k mod 512 asc, k asc), 3-NN / ball query ascending index.
 
 CPU only, numpy only; six cloud families (the ones tests/test_ops_parity_gpu.py and tests/test_fps_grid_gpu.py use).
-`python tests/test_oracle_bruteforce.py` prints the per-family table kept in profiles/r06_oracle_bruteforce.txt.
+`python -m pytest tests/test_oracle_bruteforce.py -q -s` prints the per-family table kept in profiles/r06_oracle_bruteforce.txt.
 """
 import math
 
@@ -272,8 +272,3 @@ def test_devoxelize_corners_weights_and_values(kind, r):
     record(f"devox(r={r})", kind, B * 8 * N, B * 8 * N, 0, 0, bad)
     assert bad == 0
 
-
-if __name__ == "__main__":  # the table of profiles/r06_oracle_bruteforce.txt
-    import sys
-
-    sys.exit(pytest.main([__file__, "-q", "-s", "-p", "no:cacheprovider"]))
