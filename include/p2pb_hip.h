@@ -30,8 +30,15 @@ extern "C" {
 
 #define P2PB_EINVAL (-22)
 
+/* ABI version of THIS header: bumped whenever an entry point is added, removed or changes meaning (6: round 6 -- since 1:
+ * p2pb_debug_gn_finisher removed, flag bit 5 of p2pb_conv3d_k3_forward_sparse, arithmetic code 3 in
+ * p2pb_set_split_terms_thread, p2pb_group_sub_stats*, p2pb_se_gate_*, p2pb_conv3d_k3_wgrad_occ*, the *_amax / *_adjoint packs).
+ * A binding must compare p2pb_version() with the P2PB_ABI_VERSION it was written against and refuse a mismatch
+ * (p2p_bridge_amd/_lib.py does): a stale library behind P2PB_LIB_PATH otherwise fails late, or silently differently. */
+#define P2PB_ABI_VERSION 6
+
 /* library / device info --------------------------------------------------------------------- */
-int p2pb_version(void);            /* ABI version, bumps on signature change */
+int p2pb_version(void);            /* == P2PB_ABI_VERSION of the header the library was built from */
 const char *p2pb_target_arch(void); /* "gfx950" */
 /* Arithmetic of the split-operand matrix kernels (conv3d_k3 *_forward, pointwise_conv *_forward with >= 128 channels).
  * The reference's layers are cuDNN / cuBLAS convolutions in fp32, which on its Ampere+ targets run as TF32
@@ -55,7 +62,10 @@ int p2pb_get_split_terms(void);
  * p2pb_grouping_backward, p2pb_three_nn_interpolate_backward -- the adjoints of PN2/trilinear_devox_gpu.cu:111,
  * pvcnn_grouping_gpu.cu:51, pvcnn_neighbor_interpolate_gpu.cu:101, whose float atomicAdd order is arbitrary in the reference
  * too) accumulate in a fixed order -- one wave per workgroup over rows held in LDS -- so that a training run is bit-reproducible;
- * slower. A row that does not fit 128 KB of LDS is refused (P2PB_EINVAL) instead of falling back to global atomics. */
+ * slower. A row that does not fit 128 KB of LDS is refused (P2PB_EINVAL) instead of falling back to global atomics.
+ * HARDWARE ASSUMPTION (gfx950, the only architecture this library is built for -- p2pb_target_arch): the 64 lanes of ONE
+ * ds_add_f32 instruction that hit the same LDS address are served in ascending lane order. The ISA manual does not promise
+ * it; tests/test_train_gpu.py::test_deterministic_mode_makes_training_bit_reproducible (two whole training runs, bit for bit) is what holds it on this part. */
 int p2pb_set_deterministic(int on);
 int p2pb_get_deterministic(void);
 /* Test / debug hook: the kernel form the most recent p2pb_pointwise_conv* launch with these (cin, cout, npos) took
@@ -506,7 +516,9 @@ int p2pb_se_gate_backward(int b, int c, int hidden, const float *mean, const flo
  * (data gradients: p2pb_conv3d_k3_forward_ex on dy with the point-reflected, channel-swapped weight;
  *  p2pb_pointwise_conv_forward with the transposed weight)
  * math: 0 = bf16x3 split operands (default: torch's "high" float32 matmul precision, which the reference selects in
- * train.py:221; 16 significand bits, the class of its TF32 kernels), 1 = bf16x6 (fp32-faithful), 2 = exact-fp32 MFMA. */
+ * train.py:221; 16 significand bits, the class of its TF32 kernels), 1 = bf16x6 (fp32-faithful), 2 = exact-fp32 MFMA.
+ * Size limit of the bf16 forms: they use 32-bit buffer offsets, so a convolution batch with b * max(cin, cout) * r^3 * 4 >= 2 GiB
+ * runs form 2 instead (both functions below apply the same rule; nothing is refused). */
 size_t p2pb_conv3d_k3_wgrad_ws_floats(int b, int cin, int cout, int r, int math);
 int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float *x, const float *dy, float *dw, float *db,
                          float *ws, int math, void *stream);

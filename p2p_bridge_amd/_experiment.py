@@ -8,9 +8,31 @@ Keys (default): conv_pre (8,16,32:8,16), compact (16:16), wide_f16_min_cin (16),
 nn_cells (1), wgrad_overlap (0), dgrad_math (follows P2PB_TRAIN_MATH), sparse_wgrad_min_r (16), chain_stagger_pct (0 | 100 by cloud size) -- Python side; conv_wide_min (256), am_chunks (auto), pw_wm (auto), pw_pp (1), fps_mid (512),
 fps_coop_test_fallback (0), vox_onepass (per shape), devox_cl4 (1) -- library side."""
 import os
+import warnings
+
+# Switches that had their own environment variable before round 5 and are keys of P2PB_EXPERIMENT now. Setting one of the old
+# names used to change behaviour and would now be ignored SILENTLY (ADVICE r5): warn once per process, naming the key to use.
+LEGACY = {"P2PB_CONV_PRE": "conv_pre", "P2PB_COMPACT": "compact", "P2PB_FPS_BIG": "fps_big", "P2PB_FPS_COOP": "fps_big",
+          "P2PB_NN_CELLS": "nn_cells", "P2PB_SA_GATHER": "sa_gather", "P2PB_WGRAD_OVERLAP": "wgrad_overlap",
+          "P2PB_VOX_ONEPASS": "vox_onepass", "P2PB_PW_PP": "pw_pp", "P2PB_PW_WM": "pw_wm", "P2PB_AM_CHUNKS": "am_chunks",
+          "P2PB_PREPASS_BLOCKS": "prepass_blocks", "P2PB_DEVOX_CL4": "devox_cl4", "P2PB_FPS_MID": "fps_mid"}
+_warned = False
+
+
+def warn_legacy():
+    """called when the package is imported and by every query until it has fired once"""
+    global _warned
+    if _warned:
+        return
+    stale = [k for k in LEGACY if k in os.environ]
+    if stale:
+        _warned = True
+        warnings.warn("ignored environment switch(es) " + ", ".join(f"{k} (now P2PB_EXPERIMENT=\"{LEGACY[k]}=...\")" for k in stale)
+                      + ": they became keys of P2PB_EXPERIMENT in round 5", RuntimeWarning, stacklevel=3)
 
 
 def _table():
+    warn_legacy()
     out = {}
     for item in os.environ.get("P2PB_EXPERIMENT", "").split(";"):
         if "=" in item:

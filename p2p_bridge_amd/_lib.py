@@ -37,6 +37,8 @@ SYMBOLS = [
     "p2pb_se_gate_forward", "p2pb_se_gate_backward",
 ]
 
+ABI_VERSION = 6  # include/p2pb_hip.h P2PB_ABI_VERSION this binding was written against (tests/test_abi.py compares the two)
+
 _lib = None
 
 
@@ -72,6 +74,12 @@ def lib():
         _lib.p2pb_approxmatch_temp_floats.restype = ctypes.c_size_t
         _lib.p2pb_pointwise_wgrad_ws_floats.restype = ctypes.c_size_t
         _lib.p2pb_optim_entry_bytes.restype = ctypes.c_size_t
+        have = _lib.p2pb_version() if hasattr(_lib, "p2pb_version") else None
+        if have != ABI_VERSION:
+            bad, _lib = _lib, None
+            del bad
+            raise P2PBError(f"{LIB_PATH} is ABI version {have}, this package binds version {ABI_VERSION} (include/p2pb_hip.h): "
+                            "rebuild it with `python -m p2p_bridge_amd.build`")
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here = stale library
         # products per split operand pair (include/p2pb_hip.h; fused.conv_math / set_conv_math)

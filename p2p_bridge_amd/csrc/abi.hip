@@ -1,7 +1,7 @@
 // abi.hip -- library identification for the C ABI (include/p2pb_hip.h) + the zero-fill helper.
 #include "common.h"
 
-extern "C" int p2pb_version(void) { return 1; }
+extern "C" int p2pb_version(void) { return P2PB_ABI_VERSION; }  // include/p2pb_hip.h; _lib.lib() refuses any other
 extern "C" const char *p2pb_target_arch(void) { return "gfx950"; }
 
 // Arithmetic of the split-operand kernels (common.h SPLIT_*): a process-wide default (p2pb_set_split_terms: set_conv_math)
@@ -80,12 +80,21 @@ extern "C" int p2pb_debug_pointwise_form(int cin, int cout, int npos, unsigned l
 // fps_coop_test_fallback, vox_onepass); callers cache the answer per site.
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
+// (same reading as the Python parser, p2p_bridge_amd/_experiment.py: items split at ';', key and value trimmed, keys compared
+//  case-insensitively -- "Pw_Pp = 0" and "pw_pp=0" are the same switch on both sides)
 long p2pb_experiment_long(const char *key, long dflt) {
   const char *e = getenv("P2PB_EXPERIMENT");
   const size_t kl = strlen(key);
   while (e && *e) {
-    while (*e == ';' || *e == ' ') ++e;
-    if (strncmp(e, key, kl) == 0 && e[kl] == '=') return atol(e + kl + 1);
+    while (*e == ';' || isspace((unsigned char)*e)) ++e;
+    size_t i = 0;
+    while (i < kl && e[i] && tolower((unsigned char)e[i]) == tolower((unsigned char)key[i])) ++i;
+    if (i == kl) {
+      const char *q = e + kl;
+      while (*q == ' ' || *q == '\t') ++q;
+      if (*q == '=') return atol(q + 1);  // (atol skips leading blanks itself)
+    }
     e = strchr(e, ';');
   }
   return dflt;

@@ -790,7 +790,15 @@ static int wgrad_nsplit(long units, int wgs_per_split, int target, size_t out_fl
   return s < 1 ? 1 : (int)s;
 }
 
+// The bf16 forms address both tensors through 32-bit buffer offsets (0x80000000 = "outside": the zero padding). A batch whose
+// larger operand reaches 2 GiB therefore runs the exact-fp32 form (64-bit addressing; slower, never less accurate) instead of
+// being refused mid-backward -- decided here, by the launcher AND its workspace helper alike.
+static int conv_wgrad_math_that_runs(int b, int cin, int cout, int r, int math) {
+  return (math != 2 && (size_t)b * (cin > cout ? cin : cout) * r * r * r * 4 >= (1ull << 31)) ? 2 : math;
+}
+
 extern "C" size_t p2pb_conv3d_k3_wgrad_ws_floats(int b, int cin, int cout, int r, int math) {
+  math = conv_wgrad_math_that_runs(b, cin, cout, r, math);
   const int ns = wgrad_nsplit((long)b * conv_wgrad_units(r, math), conv_wgrad_wgs_per_split(cin, cout, math),
                               512, (size_t)cout * cin * 27);
   return (size_t)ns * ((size_t)cout * cin * 27 + cout);
@@ -837,8 +845,7 @@ extern "C" int p2pb_conv3d_k3_wgrad(int b, int cin, int cout, int r, const float
                                     float *db, float *ws, int math, void *stream) {
   if (b <= 0 || cin <= 0 || cout <= 0 || !x || !dy || !dw || !ws || math < 0 || math > 2) return P2PB_EINVAL;
   if (r != 4 && r != 8 && r != 16 && r != 32) return P2PB_EINVAL;
-  // (the bf16 forms address both tensors through 32-bit buffer offsets)
-  if (math != 2 && (size_t)b * (cin > cout ? cin : cout) * r * r * r * 4 >= (1ull << 31)) return P2PB_EINVAL;
+  math = conv_wgrad_math_that_runs(b, cin, cout, r, math);
   hipStream_t s = (hipStream_t)stream;
   const int ns = wgrad_nsplit((long)b * conv_wgrad_units(r, math), conv_wgrad_wgs_per_split(cin, cout, math),
                               512, (size_t)cout * cin * 27);

@@ -140,7 +140,9 @@ class _Conv3dK3(torch.autograd.Function):
         y, st = fused.conv3d_k3(x, conv, stats=want_stats, compact=True)
         ctx.save_for_backward(x)
         ctx.conv = conv
-        ctx.occ = occ  # (counts, points per cloud) of the voxelisation that produced x, or None
+        # layers.Occupancy of the voxelisation that produced x -- trusted only if it still describes THIS tensor (same storage,
+        # same version: an in-place edit since the voxelisation may have made x non-zero outside the occupied voxels)
+        ctx.occ = (occ.counts, occ.npts) if (occ is not None and occ.describes(x)) else None
         st = st if st is not None else _empty(x)
         ctx.mark_non_differentiable(st)
         ctx.set_materialize_grads(False)  # (no zero tensor for the statistics output's gradient: a fill launch per layer)
@@ -309,11 +311,15 @@ def se_gate(mean, fc):
     return fc(mean)
 
 
-def conv3d_k3(x, conv: torch.nn.Conv3d, want_stats=False):
-    """nn.Conv3d(kernel 3, stride 1, padding 1) applied to x f32[B,Cin,r,r,r], r in {4, 8, 16, 32}"""
+def conv3d_k3(x, conv: torch.nn.Conv3d, want_stats=False, occ=None):
+    """nn.Conv3d(kernel 3, stride 1, padding 1) applied to x f32[B,Cin,r,r,r], r in {4, 8, 16, 32}.
+    occ: the `layers.Occupancy` of the voxelisation that produced x (PVConv passes it explicitly; a grid straight from
+    `layers.avg_voxelize` carries one) -- used for the weight gradient only if it still describes x, see _Conv3dK3.forward"""
     if not enabled(x) or x.shape[2] not in (4, 8, 16, 32):
         return (conv(x), None) if want_stats else conv(x)
-    y, st = _Conv3dK3.apply(x, conv.weight, conv.bias, conv, want_stats, getattr(x, "_p2pb_occ", None))
+    if occ is None:
+        occ = getattr(x, "_p2pb_occ", None)
+    y, st = _Conv3dK3.apply(x, conv.weight, conv.bias, conv, want_stats, occ)
     return (y, st) if want_stats else y
 
 
@@ -338,7 +344,7 @@ def _group_norm_of(norm):
     return (norm, None) if isinstance(norm, torch.nn.GroupNorm) else None
 
 
-def conv_norm_act(x, conv, norm, cond=None, swish=True):
+def conv_norm_act(x, conv, norm, cond=None, swish=True, occ=None):
     """the reference's conv -> GroupNorm | AdaGN(cond) -> [Swish] triple (models/pvcnn.py:162-205, 265-283) for training:
     HIP convolution (emitting the norm's statistics) + folded norm / activation with a 3-launch backward.
     cond: the global embedding [B, ctx_dim] for AdaGN (its Linear `emd` stays a torch op: a plain [B, ctx] GEMM)."""
@@ -347,11 +353,11 @@ def conv_norm_act(x, conv, norm, cond=None, swish=True):
     ok = (enabled(x) and gn_emd is not None and gn_emd[0].num_channels == conv.out_channels
           and gn_emd[0].num_channels // gn_emd[0].num_groups <= 256 and (not is3d or x.shape[2] in (4, 8, 16, 32)))
     if not ok:
-        y = conv3d_k3(x, conv) if is3d else pointwise(x, conv)
+        y = conv3d_k3(x, conv, occ=occ) if is3d else pointwise(x, conv)
         y = norm(y, cond) if (gn_emd is not None and gn_emd[1] is not None and cond is not None) else norm(y)
         return y * torch.sigmoid(y) if swish else y
     gn, emd = gn_emd
-    y, st = conv3d_k3(x, conv, True) if is3d else pointwise(x, conv, True)
+    y, st = conv3d_k3(x, conv, True, occ=occ) if is3d else pointwise(x, conv, True)
     style = None
     if emd is not None:
         if cond is None:

@@ -136,7 +136,7 @@ def conv_pre_plan(r: int):
     """(first, second): does the first / second convolution of a PVConv at resolution r take its operand as a pre-split
     grid (S format, include/p2pb_hip.h: the voxeliser / one elementwise pass apply the operand transform and the
     fp16-pair split ONCE per element, the convolution stages with LDS-DMA alone; bit-identical outputs)?
-    P2PB_CONV_PRE="<first>:<second>" lists resolutions, default below; f16x3 arithmetic only."""
+    P2PB_EXPERIMENT="conv_pre=<first>:<second>" lists resolutions, default below; f16x3 arithmetic only."""
     if conv_math() != "f16x3" or lib().p2pb_get_split_terms() != 16:
         return False, False
     spec = _experiment.get("conv_pre", CONV_PRE_DEFAULT)

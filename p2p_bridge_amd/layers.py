@@ -26,11 +26,14 @@ class AvgVoxelization(Function):
         b, c, _ = features.shape
         out, indices, counts = _ext.avg_voxelize_forward(features, coords, resolution)
         ctx.save_for_backward(indices, counts)
-        AvgVoxelization.last_occupancy = (counts, features.shape[2])
-        return out.view(b, c, resolution, resolution, resolution)
+        ctx.mark_non_differentiable(counts)
+        ctx.set_materialize_grads(False)
+        return out.view(b, c, resolution, resolution, resolution), counts  # (counts: a second, non-differentiable output)
 
     @staticmethod
-    def backward(ctx, grad_output):
+    def backward(ctx, grad_output, _gcounts=None):
+        if grad_output is None:
+            return None, None, None
         b, c = grad_output.shape[:2]
         indices, counts = ctx.saved_tensors
         g = _ext.avg_voxelize_backward(grad_output.contiguous().view(b, c, -1), indices, counts)
@@ -112,13 +115,37 @@ class NeighborInterpolation(Function):
 
 
 
+class Occupancy:
+    """Which voxels of ONE particular grid tensor can be non-zero: the voxelisation's counts i32[B, r^3] and the points per
+    cloud, tied to the tensor they describe by its storage pointer and its version counter AT THE TIME IT WAS PRODUCED. A
+    consumer (dense.conv3d_k3's occupied-voxel weight gradient, csrc/wgrad.hip) must call `describes(x)` first: any in-place
+    edit of the grid (`v.add_`, `dropout_`, ...) bumps the version, any out-of-place op yields another tensor, and in both
+    cases the grid may be non-zero where counts == 0 -- the consumer then takes the dense path."""
+
+    __slots__ = ("counts", "npts", "ptr", "version", "shape")
+
+    def __init__(self, counts, npts, grid):
+        self.counts, self.npts = counts, int(npts)
+        self.ptr, self.version, self.shape = grid.data_ptr(), grid._version, tuple(grid.shape)
+
+    def describes(self, x) -> bool:
+        return (x.data_ptr() == self.ptr and x._version == self.version and tuple(x.shape) == self.shape
+                and x.is_contiguous())
+
+
 def avg_voxelize(features, coords, resolution):
-    """AvgVoxelization.apply; the grid carries its occupancy (`_p2pb_occ` = (counts i32[B, r^3], points per cloud)) for the
-    convolution that consumes it: dense.conv3d_k3's weight gradient then runs over the occupied voxels only (csrc/wgrad.hip)"""
-    out = AvgVoxelization.apply(features, coords, resolution)
-    out._p2pb_occ = AvgVoxelization.last_occupancy
-    AvgVoxelization.last_occupancy = None
+    """AvgVoxelization.apply -> the grid f32[B,C,r,r,r] (the reference's single return value). The grid carries an `Occupancy`
+    record (`occupancy_of`) for the convolution that consumes it UNCHANGED: dense.conv3d_k3's weight gradient then runs over
+    the occupied voxels only. No class-level state: the counts are a (non-differentiable) output of the Function."""
+    out, counts = AvgVoxelization.apply(features, coords, resolution)
+    out._p2pb_occ = Occupancy(counts, features.shape[2], out)
     return out
+
+
+def occupancy_of(grid):
+    """the Occupancy record of a grid made by `avg_voxelize`, if it still describes that tensor; else None"""
+    occ = getattr(grid, "_p2pb_occ", None)
+    return occ if (occ is not None and occ.describes(grid)) else None
 
 trilinear_devoxelize = TrilinearDevoxelization.apply
 pvcnn_grouping = Grouping.apply

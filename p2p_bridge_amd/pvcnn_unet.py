@@ -513,7 +513,8 @@ class PVConv(nn.Module):
 
             v, vcoords = self.voxelization(features, coords)
             vl = self.voxel_layers  # conv, norm, Swish, Dropout, conv, norm[, SE3d]: HIP forward + backward (dense.py)
-            v = vl[3](dense.conv_norm_act(v, vl[0], vl[1], cond, swish=True))
+            # (the grid's occupancy goes to the first convolution EXPLICITLY: its weight gradient runs over the occupied voxels)
+            v = vl[3](dense.conv_norm_act(v, vl[0], vl[1], cond, swish=True, occ=L.occupancy_of(v)))
             v = dense.conv_norm_act(v, vl[4], vl[5], cond, swish=False)
             if len(vl) > 6 and v.is_cuda:
                 # the squeeze-excite gate is a per-(sample, channel) factor and the devoxelisation is linear in the grid: gate the
@@ -533,7 +534,7 @@ class PVConv(nn.Module):
 
 def compact_plan():
     """resolutions whose first / second PVConv convolution run in compact (voxel-level sparse) form;
-    default: r = 16 (measured: +2.5 %; at r = 32 the brick-level lists win, at r = 8 the dense kernel); P2PB_COMPACT="32,16:16" overrides, empty = off"""
+    default: r = 16 (measured: +2.5 %; at r = 32 the brick-level lists win, at r = 8 the dense kernel); P2PB_EXPERIMENT="compact=32,16:16" overrides, empty = off"""
     import os
 
     from . import fused
@@ -828,7 +829,10 @@ class Geometry:
     def __init__(self, plan, coords, side):
         main = torch.cuda.current_stream()
         self.main = main
-        side.wait_stream(main)
+        # (a copy, if `coords` is not contiguous, is enqueued on the main stream BEFORE the fork: the side stream's FPS / ball
+        #  query / 3-NN read c0 and are ordered behind it by the wait below -- ADVICE r5)
+        c0 = coords.contiguous()
+        side.wait_stream(main)  # (the evaluation joins `side` back into `main` before it returns: c0 outlives its readers)
         self.sa, self.fp = [], []
         from . import fused
 
@@ -853,7 +857,6 @@ class Geometry:
                 ev.record(stream)
                 self.voxel[(i, r)] = (vcoords, cnt, ws, lists, counts, ev)
 
-        c0 = coords.contiguous()
         # Level 0's voxel preparation runs on the MAIN stream, behind the fork (round 5, tools/exp_stamps.py): in front of the
         # level-0 farthest-point sampling on the side stream it delayed that 1.7 ms dependent chain by its own 0.25 ms, and once the
         # main stream's first blocks had become faster the first set abstraction waited 0.5 ms per evaluation for FPS + ball query.

@@ -114,3 +114,44 @@ def test_split_terms_thread_override_is_per_thread():
     t.join()
     assert seen == {"inside": 6, "other_thread": base, "cleared": base}
     assert lib.p2pb_set_split_terms_thread(5) != 0  # not an arithmetic
+
+
+def test_abi_version_matches_header_and_binding():
+    """p2pb_version() used to return 1 through every ABI change. Header macro == library == binding, and the loader
+    refuses a library of another version (a stale .so behind P2PB_LIB_PATH) with a message instead of failing late."""
+    from p2p_bridge_amd import _lib, build
+
+    build.build()
+    macro = int(re.search(r"#define\s+P2PB_ABI_VERSION\s+(\d+)", open(HDR).read()).group(1))
+    assert macro == _lib.ABI_VERSION
+    assert ctypes.CDLL(_lib.LIB_PATH).p2pb_version() == macro
+    code = ("import p2p_bridge_amd._lib as L\n"
+            "L.ABI_VERSION += 1\n"
+            "try:\n    L.lib()\nexcept L.P2PBError as e:\n    assert 'ABI version' in str(e), e\n    print('refused')\n")
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and "refused" in r.stdout, r.stderr[-2000:]
+
+
+def test_experiment_switch_parsers_agree_and_legacy_names_warn():
+    """the C parser (csrc/abi.hip p2pb_experiment_long) reads P2PB_EXPERIMENT like the Python one
+    (p2p_bridge_amd/_experiment.py; the C function is internal to the library, reached by its mangled name): case-insensitive keys, blanks around key, '=' and value; and a pre-round-5 switch name
+    in the environment (silently ignored since) raises a RuntimeWarning naming its replacement."""
+    code = r'''
+import ctypes, os, warnings
+os.environ["P2PB_EXPERIMENT"] = " Pw_Pp = 0 ;conv_wide_min=77; FPS_MID =9;x=1"
+from p2p_bridge_amd import _lib, _experiment
+so = ctypes.CDLL(_lib.LIB_PATH)
+f = getattr(so, "_Z20p2pb_experiment_longPKcl"); f.restype = ctypes.c_long; f.argtypes = [ctypes.c_char_p, ctypes.c_long]
+for key, dflt in (("pw_pp", 1), ("conv_wide_min", 256), ("fps_mid", 512), ("absent", 5), ("pw", 3), ("x", 0)):
+    assert f(key.encode(), dflt) == _experiment.get_int(key, dflt), (key, f(key.encode(), dflt), _experiment.get_int(key, dflt))
+assert f(b"pw_pp", 1) == 0 and f(b"fps_mid", 512) == 9 and f(b"pw", 3) == 3
+os.environ["P2PB_FPS_BIG"] = "coop"
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    _experiment.get("fps_big")
+    _experiment.get("fps_big")
+assert len(w) == 1 and "fps_big" in str(w[0].message) and issubclass(w[0].category, RuntimeWarning), [str(x.message) for x in w]
+print("ok")
+'''
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-2000:]

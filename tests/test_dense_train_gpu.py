@@ -251,6 +251,52 @@ def test_sparse_weight_gradient_of_a_first_convolution(b, ci, co, r, n):
     assert torch.equal(gf, grads[False][2])
 
 
+@pytest.mark.parametrize("edit", ["inplace_add", "inplace_dropout", "explicit_stale_occ", "untouched"])
+def test_sparse_weight_gradient_is_dropped_when_the_grid_was_edited(edit):
+    """the occupied-voxel weight gradient assumes x == 0 wherever counts == 0. The occupancy record is tied to the
+    grid's storage pointer and version counter, so a drop-in caller that edits the grid between the voxelisation and the
+    convolution (in place: the Python attribute survives) gets the DENSE weight gradient -- the right answer -- instead of a
+    silently wrong one; an untouched grid still takes the sparse kernel"""
+    from p2p_bridge_amd import dense, layers as L
+
+    torch.manual_seed(5)
+    b, ci, co, r, n = 2, 16, 16, 16, 300
+    feats = torch.randn(b, ci, n, device="cuda")
+    vox = torch.randint(0, r, (b, 3, n), device="cuda", dtype=torch.int32)
+    conv = torch.nn.Conv3d(ci, co, 3, padding=1).cuda()
+    gy = torch.randn(b, co, r, r, r, device="cuda")
+    x = L.avg_voxelize(feats, vox, r)
+    occ = L.occupancy_of(x)
+    assert occ is not None and occ.describes(x)
+    if edit == "inplace_add":
+        x.add_(0.5)  # non-zero everywhere now; `_p2pb_occ` is still attached to the tensor object
+    elif edit == "inplace_dropout":
+        torch.nn.functional.dropout(x.add_(1.0), 0.5, training=True, inplace=True)
+    elif edit == "explicit_stale_occ":
+        x = x + 0.25  # another tensor; the caller hands the OLD record over explicitly
+    if edit != "untouched":
+        assert not occ.describes(x) and (edit == "explicit_stale_occ" or L.occupancy_of(x) is None)
+    used = {}
+    real = dense.call
+
+    def spy(name, *a):
+        used[name] = used.get(name, 0) + 1
+        return real(name, *a)
+
+    dense.call = spy
+    try:
+        y = dense.conv3d_k3(x, conv, occ=occ if edit == "explicit_stale_occ" else None)
+        (gw,) = torch.autograd.grad(y, [conv.weight], gy)
+    finally:
+        dense.call = real
+    assert ("p2pb_conv3d_k3_wgrad_occ" in used) == (edit == "untouched"), used
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    y64 = torch.nn.functional.conv3d(x.detach().double(), w64, conv.bias.detach().double(), padding=1)
+    (rw,) = torch.autograd.grad(y64, [w64], gy.double())
+    tol = (2e-5 if edit == "untouched" else 2e-2) * rw.abs().max().item()  # (dense form: bf16x3 products by default)
+    assert (gw.double() - rw).abs().max().item() < tol
+
+
 @pytest.mark.parametrize("b,c", [(8, 64), (3, 256), (2, 32), (5, 1024)])
 def test_se_gate_forward_backward(b, c):
     """dense.se_gate (csrc/normact.hip se_gate_*): SE3d's excitation and every gradient vs the module's own fp64 autograd"""

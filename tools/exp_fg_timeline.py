@@ -11,7 +11,7 @@ from exp_fps_big import clouds  # noqa: E402
 
 buf = torch.zeros(64 * 16 * 8, dtype=torch.int64, device="cuda")
 assert _lib.lib().p2pb_fg_timeline_set(ctypes.c_void_p(buf.data_ptr())) == 0
-os.environ["P2PB_FPS_BIG"] = "grid"
+os.environ["P2PB_EXPERIMENT"] = "fps_big=grid"
 from p2p_bridge_amd.synthetic import synthetic_patches  # noqa: E402
 for kind, b, n, m in [("patches", 4, 50000, 12500), ("room", 4, 50000, 12500), ("volume", 4, 50000, 12500)]:
     x = synthetic_patches(b, n, seed=1)[0].cuda().contiguous() if kind == "patches" else clouds(kind, b, n)

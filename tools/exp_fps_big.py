@@ -27,7 +27,7 @@ def clouds(kind, b, n, seed=0):
 
 
 def run(mode, x, m, reps=2):
-    os.environ["P2PB_FPS_BIG"] = mode
+    os.environ["P2PB_EXPERIMENT"] = f"fps_big={mode}"
     idx = ext.furthest_point_sampling_forward(x, m)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

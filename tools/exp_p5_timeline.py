@@ -1,5 +1,5 @@
 """Phases of a workgroup of pw_pp512_kernel (512 -> 1024, P = 8192, B = 32 as the sampler launches it) from a -DPP_TIMELINE
-build of pointwise.hip (tools/build_pw_variant.sh tl "-DPP_TIMELINE"; P2PB_LIB_PATH=tools/exp/lib_pwtl.so, P2PB_PW_PP=1):
+build of pointwise.hip (tools/build_pw_variant.sh tl "-DPP_TIMELINE"; P2PB_LIB_PATH=tools/exp/lib_pwtl.so, P2PB_EXPERIMENT="pw_pp=1"):
 s_memtime stamps of wave 0 (half 0: multiply, then stage) and wave 4 (half 1: stage, then multiply), stored last."""
 import ctypes, os, sys
 import numpy as np

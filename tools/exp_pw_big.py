@@ -1,5 +1,5 @@
 """the sampler's dominant GEMM (Pnet2Stage mlp2 layer 1: 512 -> 1024 over 8192 positions x 32 patches, folded norm + Swish
-on load, pooling epilogue, output never written) timed alone like bench.py's gemm_roofline; P2PB_PW_WM=2|4 picks the
+on load, pooling epilogue, output never written) timed alone like bench.py's gemm_roofline; P2PB_EXPERIMENT="pw_wm=2|4" picks the
 workgroup width (128 / 256 output channels)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,4 +29,4 @@ with torch.no_grad():
 ms = e0.elapsed_time(e1) / 20
 fl = 2.0 * B * P * ci * co
 peak = 2516.6 / (3 if fused.conv_math() == "f16x3" else 6)
-print(f"WM={os.environ.get('P2PB_PW_WM', 'auto')} {fused.conv_math()}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s fp32-eq  frac {fl / ms / 1e9 / peak:.3f} of {peak:.1f}")
+print(f"WM={__import__('p2p_bridge_amd._experiment', fromlist=['get']).get('pw_wm', 'auto')} {fused.conv_math()}: {ms:.4f} ms  {fl / ms / 1e9:.1f} TFLOP/s fp32-eq  frac {fl / ms / 1e9 / peak:.3f} of {peak:.1f}")
