@@ -104,6 +104,18 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned &p0, unsig
     split3(a, b, p0, p1, p2);
   }
 }
+// "f16x2w" PRICING EXPERIMENT (profiles/r06_f16x2w_ab.txt): activations stay an fp16 pair, a weight becomes ONE
+// fp16 term (11 significand bits) -- two products instead of three. Numerics: P2PB_EXPERIMENT="x2w=1" makes the weight packs
+// write a zero low plane (SPLIT_X2W_FLAG on the pack kernels' mode argument), so the shipped kernels compute exactly that
+// arithmetic (the third product adds exact zeros) and every parity test can be run on it. Time: -DP2PB_X2W_TIMING builds drop
+// the product with the weights' low plane from every split kernel (timing only: with ordinary packs the result is wrong).
+// Verdict of the experiment: 1.0e-3-class network error against the 1e-4 gates -- not shipped, not selectable as a conv_math.
+#define SPLIT_X2W_FLAG 0x100
+#ifdef P2PB_X2W_TIMING
+#define X2W_KEEP_LOW_WEIGHT_PRODUCT 0
+#else
+#define X2W_KEEP_LOW_WEIGHT_PRODUCT 1
+#endif
 constexpr __host__ __device__ int split_planes(int mode) { return mode == SPLIT_BF16X6 ? 3 : 2; }
 template <int MODE>
 __device__ __forceinline__ f32x16 split_mfma(const u32x4 &a, const u32x4 &b, const f32x16 &c) {

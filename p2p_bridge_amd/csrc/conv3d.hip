@@ -402,6 +402,8 @@ static __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, i
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;  // one thread per (tap, chunk, khalf, co, idx)
   // max |w| (bits): from the caller's slot (amax: the optimiser keeps it per tensor, csrc/optim.hip) or from the reduction
   // launched in front of this kernel (trailer[0])
+  const bool x2w = (mode & SPLIT_X2W_FLAG) != 0;  // (pricing experiment, common.h: a zero low plane)
+  mode &= 0xff;
   const float wmax = amax ? __builtin_bit_cast(float, *amax) : trailer[0];
   const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(wmax) : 1.0f;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -421,6 +423,7 @@ static __global__ void conv3d_pack_split_kernel(int cout, int cin, int nchunk, i
     unsigned p0, p1, p2;
     if (mode == SPLIT_F16X3) {
       split2h(x * sw, 0.0f, p0, p1);
+      if (x2w) p1 = 0u;
       p2 = 0u;
     } else {
       split3(x, 0.0f, p0, p1, p2);
@@ -513,7 +516,7 @@ __device__ __forceinline__ void split_taps(f32x16 (&acc)[NT], const u32x4 *__res
     __builtin_amdgcn_sched_barrier(0);
     if (tap + 1 < CONV_NTAPS) load_b(1, toff_n);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (TERMS != 6) mfma_term(1, 0);
+    if constexpr (TERMS != 6 && (X2W_KEEP_LOW_WEIGHT_PRODUCT || TERMS != SPLIT_F16X3)) mfma_term(1, 0);
     mfma_term(0, 0);
   }
 }
@@ -577,7 +580,8 @@ __device__ __forceinline__ void split_taps_pre(f32x16 (&acc)[NT], const u32x4 *_
     if (tap + 1 < CONV_NTAPS) load_b1(toff_n);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][1], b0[par][n], acc[n]);
+    for (int n = 0; n < NT; ++n)
+      if (X2W_KEEP_LOW_WEIGHT_PRODUCT) acc[n] = split_mfma<SPLIT_F16X3>(a[cur][1], b0[par][n], acc[n]);
     __builtin_amdgcn_sched_barrier(0);
     if (tap + 1 < CONV_NTAPS) load_b0(par ^ 1, toff_n);
     __builtin_amdgcn_sched_barrier(0);
@@ -1059,6 +1063,7 @@ static int conv_pack_split(int cout, int cin, const float *w, void *wt_split, bo
   const size_t total = (size_t)27 * nchunk * 2 * cout_pad * 8;
   // the pack is made for the arithmetic selected NOW (p2pb_set_split_terms); callers re-pack after a switch to / from 16
   float *trailer = (float *)((char *)wt_split + conv_split_trailer_bytes(nchunk, cout_pad));
+  static const long x2w = p2pb_experiment_long("x2w", 0);
   const int mode = p2pb_g_split_terms;
   if (mode == SPLIT_F16X3 && !amax) {
     const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
@@ -1067,8 +1072,8 @@ static int conv_pack_split(int cout, int cin, const float *w, void *wt_split, bo
                        (unsigned *)trailer);
   }
   hipLaunchKernelGGL(conv3d_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, (unsigned short *)wt_split, mode,
-                     trailer, adjoint ? 27L : (long)cin * 27, adjoint ? (long)cout * 27 : 27L, adjoint ? 1 : 0,
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, cout_pad, w, (unsigned short *)wt_split,
+                     mode | ((x2w && mode == SPLIT_F16X3 && !adjoint) ? SPLIT_X2W_FLAG : 0), trailer, adjoint ? 27L : (long)cin * 27, adjoint ? (long)cout * 27 : 27L, adjoint ? 1 : 0,
                      mode == SPLIT_F16X3 ? amax : nullptr);
   return p2pb_launch_status();
 }

@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256, 2) void pw_wide_kernel(int cin, int cout, int 
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][1], pl0[t], acc[m][t]);
+        for (int t = 0; t < 4; ++t)
+          if (X2W_KEEP_LOW_WEIGHT_PRODUCT) acc[m][t] = split_mfma<SPLIT_F16X3>(a_cu[m][1], pl0[t], acc[m][t]);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -990,7 +991,8 @@ __global__ __launch_bounds__(128 * WM, NB == 2 ? 2 : (WM == 2 ? 3 : PWS_WM4_WAVE
           for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-              acc[m][2 * nb + n] = split_mfma<TERMS>(af[PA[t]][m], bf[PB[t]][n], acc[m][2 * nb + n]);
+              if (X2W_KEEP_LOW_WEIGHT_PRODUCT || TERMS != SPLIT_F16X3 || PA[t] != 1)
+                acc[m][2 * nb + n] = split_mfma<TERMS>(af[PA[t]][m], bf[PB[t]][n], acc[m][2 * nb + n]);
       }
     }
   }
@@ -1018,6 +1020,8 @@ __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, 
                                      unsigned short *__restrict__ wp, int mode, float *__restrict__ trailer, long s_co, long s_ci,
                                      const unsigned *__restrict__ amax) {
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;  // (chunk, coblk, kstep, khalf, co, idx)
+  const bool x2w = (mode & SPLIT_X2W_FLAG) != 0;  // (pricing experiment, common.h: a zero low plane)
+  mode &= 0xff;
   const float wmax = amax ? __builtin_bit_cast(float, *amax) : trailer[0];  // (conv3d_pack_split_kernel: same convention)
   const float sw = mode == SPLIT_F16X3 ? f16_weight_scale(wmax) : 1.0f;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1039,6 +1043,7 @@ __global__ void pw_pack_split_kernel(int cout, int cin, int nchunk, int ncoblk, 
     unsigned p0, p1, p2;
     if (mode == SPLIT_F16X3) {
       split2h(x * sw, 0.0f, p0, p1);
+      if (x2w) p1 = 0u;
       p2 = 0u;
     } else {
       split3(x, 0.0f, p0, p1, p2);
@@ -1060,6 +1065,7 @@ static int pw_pack_split(int cout, int cin, const float *w, void *wp, bool adjoi
   const size_t total = (size_t)nchunk * ncoblk * 2 * 2 * 128 * 8;
   // the pack is made for the arithmetic selected NOW (p2pb_set_split_terms); callers re-pack after a switch
   float *trailer = (float *)((char *)wp + (size_t)nchunk * ncoblk * PWS_TILE * 16);
+  static const long x2w = p2pb_experiment_long("x2w", 0);
   const int mode = p2pb_g_split_terms;
   if (mode == SPLIT_F16X3 && !amax) {
     const int rc = p2pb_zero_async(trailer, 16, (hipStream_t)stream);
@@ -1068,7 +1074,8 @@ static int pw_pack_split(int cout, int cin, const float *w, void *wp, bool adjoi
                        (unsigned *)trailer);
   }
   hipLaunchKernelGGL(pw_pack_split_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)),
-                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp, mode, trailer,
+                     dim3(256), 0, (hipStream_t)stream, cout, cin, nchunk, ncoblk, w, (unsigned short *)wp,
+                     mode | ((x2w && mode == SPLIT_F16X3 && !adjoint) ? SPLIT_X2W_FLAG : 0), trailer,
                      adjoint ? 1L : (long)cin, adjoint ? (long)cout : 1L, mode == SPLIT_F16X3 ? amax : nullptr);
   return p2pb_launch_status();
 }

@@ -251,7 +251,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(248))) void 
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) acc[m][n] = split_mfma<SPLIT_F16X3>(af[1][m], bf[n][0], acc[m][n]);
+        for (int m = 0; m < 2; ++m)
+          if (X2W_KEEP_LOW_WEIGHT_PRODUCT) acc[m][n] = split_mfma<SPLIT_F16X3>(af[1][m], bf[n][0], acc[m][n]);
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
