@@ -302,13 +302,15 @@ int p2pb_conv3d_k3_forward_sparse(int b, int cin, int cout, int r, const float *
  * (set 0) and D2 = dilate(D1,1) (set 1), followed by the ids outside the set: lists u8[2][b][NBRICK][256], counts
  * i32[2][b][NBRICK]; r in {8,16,32}. p2pb_conv3d_k3_forward_compact computes only the listed outputs of every brick
  * (a first convolution with set 0; a second one in far-field form -- in_sub / out_class -- with set 1) and writes the
- * known constants (+ their exact statistics) elsewhere. Voxel-major tensors, split weight pack. */
+ * known constants (+ their exact statistics) elsewhere. Voxel-major tensors, split weight pack. flags bit 5 (32, as in
+ * p2pb_conv3d_k3_forward_sparse; ABI 6): the constants of the UNLISTED voxels are left unwritten (statistics still exact) --
+ * for a caller that reads `out` at listed voxels alone (a PVConv's second convolution: read by the devoxelisation only). */
 int p2pb_conv3d_active_lists(int b, int r, const int *cnt, unsigned char *lists, int *counts, void *stream);
 int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split,
                                    const float *bias, const float *out_class, const float *in_scale,
                                    const float *in_shift, int in_swish, const float *in_sub,
                                    const unsigned char *alist, const int *acount, float *out, float *stats_part,
-                                   void *stream);
+                                   int flags /* bit 5 */, void *stream);
 /* Pre-split operand grids ("S format", round 3; conv3d.hip PreStage). The split kernels' staging phase -- load, folded
  * norm + Swish, fp16-pair split, LDS write, repeated for every brick halo and channel block that touches a voxel -- can be
  * done ONCE per element by the operand's producer: S = u32x4[b][r^3][ceil(cin/16)][2 planes][2 khalf], 8 fp16 per entry
@@ -322,7 +324,8 @@ int p2pb_conv3d_presplit(int b, int c, long nvox, const float *y, const float *i
                          int in_swish, const float *in_sub, void *out_split, void *stream);
 int p2pb_conv3d_k3_forward_compact_pre(int b, int cin, int cout, int r, const void *in_split, const void *wt_split,
                                        const float *bias, const float *out_class, const unsigned char *alist,
-                                       const int *acount, float *out, float *stats_part, void *stream);
+                                       const int *acount, float *out, float *stats_part, int flags /* bit 5 */,
+                                       void *stream);
 /* a[b,cin] = xf(prev_bias[cin]) (the operand's far-field constant) and k_out[b,27,cout] = conv(a) + bias per
  * boundary class, for p2pb_conv3d_k3_forward_ex */
 int p2pb_conv3d_k3_far_field(int b, int cin, int cout, const float *prev_bias, const float *in_scale,

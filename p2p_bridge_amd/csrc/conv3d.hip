@@ -1980,7 +1980,7 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
           }
         }
       }
-      const int any = skip_zero ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
+      const int any = (skip_zero & 1) ? __syncthreads_or(nonzero) : (__syncthreads(), 1);
       if (ci0 + CONV_SCK < cin) {
         int nxt = ci0 + CONV_SCK;
         asm volatile("" : "+s"(nxt));
@@ -2085,7 +2085,11 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
   __syncthreads();
   const int cw = min(32 * WM, cout - cob);  // channels of this workgroup
   const float *kb = out_class ? out_class + (size_t)b * 27 * cout : nullptr;
-  if ((cout & 3) == 0) {  // 16 bytes per thread; (voxel, channel quad) advance incrementally, no division in the loop
+  // (skip_zero bit 1 = "listed outputs only": the caller reads `out` at listed voxels alone -- a PVConv's second convolution, whose
+  //  only reader is the devoxelisation: its corners lie within one voxel of an occupied voxel, inside D1 -- so the constants are
+  //  not stored; their statistics below stay exact)
+  if (skip_zero & 2) {
+  } else if ((cout & 3) == 0) {  // 16 bytes per thread; (voxel, channel quad) advance incrementally, no division in the loop
     const int cw4 = cw >> 2, dq = 256 / cw4, dr = 256 % cw4;
     int vi = tid / cw4, c4 = tid % cw4;
     f32x4 bq = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -2166,18 +2170,19 @@ __global__ __launch_bounds__(256, TERMS == SPLIT_F16X3 ? CONV_F16_WAVES : 2) voi
 int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                        const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                        const float *in_sub, const unsigned char *alist, const int *acount, float *out, float *stats_part,
-                       hipStream_t s);
+                       hipStream_t s, int listed_only);
 static int conv_launch_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                                const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                                const float *in_sub, const unsigned char *alist, const int *acount, float *out,
-                               float *stats_part, hipStream_t s, bool pre = false) {
+                               float *stats_part, hipStream_t s, bool pre = false, int listed_only = 0) {
+  const int lo = listed_only ? 2 : 0;  // bit 1 of the kernels' skip_zero argument
   const bool xf = in_scale != nullptr;
 #if CONV_TU == 0
   if (p2pb_g_split_terms == SPLIT_BF16X3) return P2PB_EINVAL;  // (the data gradient's arithmetic: dense form only)
   if (pre && (p2pb_g_split_terms == SPLIT_BF16X6 || xf || in_sub)) return P2PB_EINVAL;
   if (p2pb_g_split_terms == SPLIT_BF16X6)
     return conv3d_tu6_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
-                              acount, out, stats_part, s);
+                              acount, out, stats_part, s, listed_only);
 #endif
   const int nchunk = (cin + CONV_SCK - 1) / CONV_SCK, cout_pad = (cout + 63) / 64 * 64;
   const unsigned short *w = (const unsigned short *)wt_split;
@@ -2185,7 +2190,7 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
   dim3 grid(conv_bricks(r), (cout + (wm1 ? 31 : 63)) / (wm1 ? 32 : 64), b);
 #define LAUNCH(RR, WMV, XF)                                                                                           \
   hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, WMV, XF, CONV_TERMS>), grid, dim3(256), 0, s, cin, cout, nchunk, cout_pad, \
-                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1, alist, acount, out, stats_part)
+                     in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 1 | lo, alist, acount, out, stats_part)
 #define GO(RR)                                                   \
   if (wm1) {                                                     \
     if (xf) LAUNCH(RR, 1, true);                                 \
@@ -2199,11 +2204,11 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
   do {                                                                                                                     \
     if (wm1)                                                                                                               \
       hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 1, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
-                         nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0, alist, acount, out, \
+                         nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, lo, alist, acount, out, \
                          stats_part);                                                                                      \
     else                                                                                                                   \
       hipLaunchKernelGGL((conv3d_k3_compact_kernel<RR, 2, false, SPLIT_F16X3, true>), grid, dim3(256), 0, s, cin, cout, \
-                         nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, 0, alist, acount, out, \
+                         nchunk, cout_pad, in, w, bias, out_class, in_scale, in_shift, in_swish, in_sub, lo, alist, acount, out, \
                          stats_part);                                                                                      \
   } while (0)
   if (pre) {
@@ -2221,9 +2226,9 @@ static int conv_launch_compact(int b, int cin, int cout, int r, const float *in,
 int conv3d_tu6_compact(int b, int cin, int cout, int r, const float *in, const void *wt_split, const float *bias,
                        const float *out_class, const float *in_scale, const float *in_shift, int in_swish,
                        const float *in_sub, const unsigned char *alist, const int *acount, float *out, float *stats_part,
-                       hipStream_t s) {
+                       hipStream_t s, int listed_only) {
   return conv_launch_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist, acount,
-                             out, stats_part, s);
+                             out, stats_part, s, false, listed_only);
 }
 #endif
 #endif  // CONV_TU != 3
@@ -2233,10 +2238,10 @@ extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, c
                                               const float *bias, const float *out_class, const float *in_scale,
                                               const float *in_shift, int in_swish, const float *in_sub,
                                               const unsigned char *alist, const int *acount, float *out,
-                                              float *stats_part, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || !alist || !acount || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
+                                              float *stats_part, int flags, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !alist || !acount || (r != 8 && r != 16 && r != 32) || (flags & ~32)) return P2PB_EINVAL;
   return conv_launch_compact(b, cin, cout, r, in, wt_split, bias, out_class, in_scale, in_shift, in_swish, in_sub, alist,
-                             acount, out, stats_part, (hipStream_t)stream);
+                             acount, out, stats_part, (hipStream_t)stream, false, flags & 32);
 }
 #endif
 
@@ -2245,10 +2250,11 @@ extern "C" int p2pb_conv3d_k3_forward_compact(int b, int cin, int cout, int r, c
 extern "C" int p2pb_conv3d_k3_forward_compact_pre(int b, int cin, int cout, int r, const void *in_split,
                                                   const void *wt_split, const float *bias, const float *out_class,
                                                   const unsigned char *alist, const int *acount, float *out,
-                                                  float *stats_part, void *stream) {
-  if (b <= 0 || cin <= 0 || cout <= 0 || !in_split || !alist || !acount || (r != 8 && r != 16 && r != 32)) return P2PB_EINVAL;
+                                                  float *stats_part, int flags, void *stream) {
+  if (b <= 0 || cin <= 0 || cout <= 0 || !in_split || !alist || !acount || (r != 8 && r != 16 && r != 32) || (flags & ~32))
+    return P2PB_EINVAL;
   return conv_launch_compact(b, cin, cout, r, (const float *)in_split, wt_split, bias, out_class, nullptr, nullptr, 0,
-                             nullptr, alist, acount, out, stats_part, (hipStream_t)stream, true);
+                             nullptr, alist, acount, out, stats_part, (hipStream_t)stream, true, flags & 32);
 }
 
 // y f32[b][nvox][c] (voxel-major) -> S format u32x4[b][nvox][ceil(c/16)][2 planes][2 khalf]: the operand transform of

@@ -235,10 +235,12 @@ def active_lists(cnt, r):
 
 
 def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
-                      out_class=None, pre=False):
+                      out_class=None, pre=False, listed_only=False):
     """compact sparse conv on voxel-major grids (csrc/conv3d.hip): only the listed outputs of every brick are computed,
     the others get their constant. which = 0: first convolution of a PVConv (set D1); which = 1: second one in
-    far-field form (set D2; in_sub / out_class from conv3d_far_field). x f32[B,r,r,r,Cin] -> (y f32[B,r,r,r,Cout], stats)"""
+    far-field form (set D2; in_sub / out_class from conv3d_far_field). x f32[B,r,r,r,Cin] -> (y f32[B,r,r,r,Cout], stats).
+    listed_only: y is left UNWRITTEN outside the listed voxels (the statistics stay exact) -- for a caller that reads y inside
+    the set alone (a PVConv's second convolution: the devoxelisation's corners lie within one voxel of an occupied voxel)"""
     check(x, F32, "x")
     b, r, ci = x.shape[0], x.shape[1], x.shape[4]
     co = conv.out_channels
@@ -250,11 +252,11 @@ def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=Non
     if pre:  # x is the pre-split operand grid
         assert in_scale is None and in_sub is None and x.shape[4] == (conv.in_channels + 15) // 16 * 16
         call("p2pb_conv3d_k3_forward_compact_pre", _i(b), _i(conv.in_channels), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
-             ptr(out_class), ptr(al), ptr(ac), ptr(y), ptr(st), stream_ptr())
+             ptr(out_class), ptr(al), ptr(ac), ptr(y), ptr(st), _i(32 if listed_only else 0), stream_ptr())
         return y, st
     call("p2pb_conv3d_k3_forward_compact", _i(b), _i(ci), _i(co), _i(r), ptr(x), ptr(wt), ptr(conv.bias),
          ptr(out_class), ptr(in_scale), ptr(in_shift), _i(int(swish)), ptr(in_sub), ptr(al), ptr(ac), ptr(y), ptr(st),
-         stream_ptr())
+         _i(32 if listed_only else 0), stream_ptr())
     return y, st
 
 

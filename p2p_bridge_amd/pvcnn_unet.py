@@ -455,10 +455,12 @@ class PVConv(nn.Module):
             if r in c2:  # (the norm between the convolutions is folded inside the far-field launch)
                 sc1, sh1, a, k = fused.conv3d_far_field_gn(vl[0].bias, vl[4], st1, norm_fin(vl[1], r3, cond), True)
                 if pre2:
+                    # (listed_only: y2 is read by the devoxelisation alone -- corners within one voxel of an occupied voxel, inside D1)
                     y2, st2 = fused.conv3d_k3_compact(fused.conv3d_presplit(y1, sc1, sh1, True, a), vl[4], lists, counts, 1,
-                                                      out_class=k, pre=True)
+                                                      out_class=k, pre=True, listed_only=True)
                 else:
-                    y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k)
+                    y2, st2 = fused.conv3d_k3_compact(y1, vl[4], lists, counts, 1, sc1, sh1, True, in_sub=a, out_class=k,
+                                                      listed_only=True)
             else:
                 sc1, sh1 = norm_affine(vl[1], st1, r3, cond)
                 if pre2:

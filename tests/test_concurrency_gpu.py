@@ -144,9 +144,18 @@ def test_every_op_of_an_evaluation_beside_matrix_kernels_is_bitwise_stable():
              if isinstance(v, types.FunctionType) and v.__module__ == m.__name__ and not k.startswith("_") and k not in not_ops]
     ca = _record_evaluation(net, mods, names, x[:16].contiguous(), t)
     cb = _record_evaluation(net, mods, names, x[16:].contiguous(), t)
-    # (a PVConv's second sparse convolution leaves the inactive bricks of its output unwritten -- active_only: nobody reads them --
-    #  so the replay asks for the fully written form of the same launch: same MFMA kernel, the fill writes as well)
-    fix = lambda cs: [(n, f, a, dict(kw, active_only=False) if kw.get("active_only") else kw) for (n, f, a, kw) in cs]
+    # (a PVConv's second sparse convolution leaves the inactive bricks -- active_only -- or the unlisted voxels -- listed_only, round 6
+    #  -- of its output unwritten: nobody reads them; the replay asks for the fully written form of the same launch: same MFMA
+    #  kernel, the constants written as well)
+    def fix(cs):
+        out = []
+        for (n, f, a, kw) in cs:
+            for key in ("active_only", "listed_only"):
+                if kw.get(key):
+                    kw = dict(kw, **{key: False})
+            out.append((n, f, a, kw))
+        return out
+
     ca, cb = fix(ca), fix(cb)
     assert len(ca) == len(cb) > 140, (len(ca), len(cb))  # (f16x3: 154 calls; bf16x6 has no pre-split passes: 148)
     kinds = {n for n, *_ in ca}

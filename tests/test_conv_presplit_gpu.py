@@ -55,6 +55,26 @@ def test_presplit_convolutions_are_bit_identical(fused, r, C, C1, C2, N, B):
         c2, s2 = fused.conv3d_k3_compact(c1, conv2, lists, counts, 1, sc, sh, True, in_sub=a, out_class=k)
         c2p, s2p = fused.conv3d_k3_compact(fused.conv3d_presplit(c1, sc, sh, True, a), conv2, lists, counts, 1, out_class=k, pre=True)
         assert torch.equal(c2, c2p) and torch.equal(s2, s2p)
+        # listed_only (round 6; flags bit 5 of the compact entry points): the unlisted voxels' constants are not stored -- what a
+        # PVConv's second convolution asks for --, the statistics and every listed output are the same bits
+        d1 = torch.nn.functional.max_pool3d((cnt.view(B, 1, r, r, r) > 0).float(), 3, 1, 1)
+        d2 = torch.nn.functional.max_pool3d(d1, 3, 1, 1).view(B, r, r, r, 1) > 0
+        for pre_form in (False, True):
+            poison = torch.full_like(c2, float("nan"))
+            operand = fused.conv3d_presplit(c1, sc, sh, True, a) if pre_form else None
+            real_empty = torch.empty
+            torch.empty = lambda *a, **kw: poison if (len(a) == 5 and a[-1] == C2) else real_empty(*a, **kw)
+            try:
+                if pre_form:
+                    c2l, s2l = fused.conv3d_k3_compact(operand, conv2, lists, counts, 1, out_class=k, pre=True, listed_only=True)
+                else:
+                    c2l, s2l = fused.conv3d_k3_compact(c1, conv2, lists, counts, 1, sc, sh, True, in_sub=a, out_class=k,
+                                                       listed_only=True)
+            finally:
+                torch.empty = real_empty
+            assert c2l is poison and torch.equal(s2l, s2)
+            assert torch.equal(torch.where(d2, c2l, torch.zeros_like(c2l)), torch.where(d2, c2, torch.zeros_like(c2)))
+            assert torch.isnan(c2l[(~d2).expand_as(c2l)]).all()  # nothing was written outside the set
         if r >= 16:  # list-driven form (brick lists)
             bl, bc = fused.brick_lists(cnt, r)
             b1, t1 = fused.conv3d_k3_sparse(g, conv1, bl, bc, 0, channels_last=True)
