@@ -209,6 +209,27 @@ HBM_GROUPS = [
     ("gather (a15)", 0.08, ("gather_kernel",), "three coordinates per centre: launch-bound"),
 ]
 
+# The compute-side yardstick of the three search kernels (bytes are the wrong yardstick for L2-resident,
+# latency-bound geometry): the pair-distance evaluations of the REFERENCE's brute-force formulation per sample and evaluation at
+# PVDS / 8192 points (levels 8192 -> 2048 -> 512 -> 128 -> 32), against the fp32 vector pipe: 256 CUs x 4 SIMDs x 16 lanes x
+# 2.4 GHz = 39.3 T lane-instructions/s (MI355X_MICROARCH.md: 157.3 TFLOP/s = 2 FLOP x 2 (packed) x that), 8 instructions per
+# pair (3 subtractions, 1 multiply, 2 fused multiply-adds, compare, select) = 4.9 T pairs/s for the whole chip.
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9
+PAIR_PEAK_PER_S = VALU_LANE_OPS_PER_S / 8.0
+_LEVELS = [(8192, 2048), (2048, 512), (512, 128), (128, 32)]
+PAIR_GROUPS = {
+    # group prefix -> (pair evaluations per sample and evaluation, CUs a launch can occupy at `b` clouds, what the number means)
+    "FPS (a14)": (sum((m - 1) * n for n, m in _LEVELS), lambda b: b,
+                  "(M - 1) N running-distance updates per level, EVERY one performed (nothing to prune below 16384 points); one "
+                  "workgroup = one CU per cloud by construction, so frac_on_occupied_cus is the kernel's VALU efficiency"),
+    "ball query (a16)": (sum(m * n for n, m in _LEVELS), lambda b: 256,
+                         "M N distance tests of the reference's scan; the kernel stops a centre at its 32nd hit, so the rate "
+                         "counts tests it did not need to make"),
+    "3-NN interpolation (a19": (53.7e6, lambda b: 256,
+                                "N M distances of the reference's scan; the cell-grid search visits ~76 candidates per point "
+                                "instead of up to 2048: an EFFECTIVE rate (work avoided counts as work done)"),
+}
+
 
 def hbm_kernels(patches_per_chain):
     """The HBM side of the roofline (SURVEY 8d 'per-kernel HBM fractions from rocprof alongside'): per custom-op group the
@@ -241,8 +262,18 @@ def hbm_kernels(patches_per_chain):
             continue
         nbytes = mb * 1e6 * patches_per_chain
         tbps = nbytes / (ms * 1e-3) / 1e12
-        out.append({"group": name, "algorithmic_bytes": int(nbytes), "ms_per_eval": round(ms, 4), "TB_per_s": round(tbps, 3),
-                    "frac_of_8TBps": round(tbps / HBM_PEAK_TBPS, 4), "note": why})
+        row = {"group": name, "algorithmic_bytes": int(nbytes), "ms_per_eval": round(ms, 4), "TB_per_s": round(tbps, 3),
+               "frac_of_8TBps": round(tbps / HBM_PEAK_TBPS, 4), "note": why}
+        for prefix, (pairs, cus, what) in PAIR_GROUPS.items():
+            if name.startswith(prefix):
+                rate = pairs * patches_per_chain / (ms * 1e-3)
+                occ = min(256, cus(patches_per_chain))
+                row.update({"pair_evaluations": int(pairs * patches_per_chain), "Gpairs_per_s": round(rate / 1e9, 1),
+                            "frac_of_valu_pair_peak": round(rate / PAIR_PEAK_PER_S, 4), "cus_occupied": occ,
+                            "frac_on_occupied_cus": round(rate / (PAIR_PEAK_PER_S * occ / 256.0), 4),
+                            "compute_yardstick": what + f"; peak = {PAIR_PEAK_PER_S / 1e12:.2f} T pairs/s (39.3 T fp32 lane-"
+                                                        "instructions/s / 8 per pair)"})
+        out.append(row)
     return {"source": f"profiles/{os.path.basename(src)} (rocprofv3 --kernel-trace of bench.py, one {patches_per_chain}-patch chain-evaluation)",
             "kernels": out}
 
@@ -451,7 +482,10 @@ def main():
 def train_step_leg(steps=8, warmup=4, B=8, N=2048):
     """NOT `value`: BASELINE config 3's per-GPU training step (PVDS_PUNet, 8 patches x 2048 points = global batch 64 over
     8 GPUs, MSE bridge loss, grad clip 1.0, AdamW) on this one GPU, the reference's order of operations
-    (train.py:107-143; the auction alignment of the data loader is left out: it is timed in profiles/*_metrics_timing.txt).
+    (train.py:107-143). ms_per_step = the captured step on a resident batch; ms_per_step_with_align = the step the reference's
+    PU-Net loop actually runs (train.py:72-82: every batch is auction-aligned first, 100 rounds) -- fresh synthetic batches with
+    the clean patch in random order, batch k + 1 aligned on a side stream as its own hipGraph while step k runs
+    (train.AlignedBatches); ms_per_step_with_align_serial = the same with alignment and step one after the other.
     dense FLOPs of a step = 3 x forward (forward, data gradient, weight gradient) = 3 x 61.35 GFLOP x N / 8192 per patch
     (SURVEY 8d); the forward runs in fused.conv_math(), the data-gradient pass in bf16x6, the weight-gradient GEMMs in
     P2PB_TRAIN_MATH (bf16x3)."""
@@ -499,11 +533,29 @@ def train_step_leg(steps=8, warmup=4, B=8, N=2048):
     # the same step as one captured hipGraph (train.GraphedStep, `python -m p2p_bridge_amd.train --graph`)
     stepper = T.GraphedStep(model, opt, sched, warmup=1)
     dt, loss = timed(lambda: stepper(x0, x1), warmup + 2, steps)
+    # the same step fed by the PU-Net loop's data side: auction alignment of every batch (a23)
+    tcfg["data"] = dict(tcfg.get("data", {}), dataset="PUNet")
+    align = T.make_align_fn()
+    feed = T.AlignedBatches(T.synthetic_punet_batches(B, N, 100, "cuda"), tcfg, align, capture=True)
+
+    def with_align():
+        d = next(feed)
+        return stepper(d["x_gt"], d["x_start"], d["x_cond"])
+
+    dt_al, _ = timed(with_align, warmup + 2, steps)
+    raw = T.synthetic_punet_batches(B, N, 200, "cuda")
+
+    def with_align_serial():
+        d = T.get_data_batch(next(raw), tcfg, align)
+        return stepper(d["x_gt"], d["x_start"], d["x_cond"])
+
+    dt_ser, _ = timed(with_align_serial, 2, steps)
     flop = 3.0 * 61.35e9 * N / 8192.0 * B
     return {"workload": f"PVDS_PUNet training step, {B} patches x {N} points per GPU (BASELINE configs[2] = global batch 64 on 8 GPUs), "
                         "mse bridge loss, clip 1.0, AdamW, scheduler, EMA; hand-written forward / backward / optimiser kernels, the step "
                         "captured as one hipGraph (train.GraphedStep); eager_ms_per_step = the same step launched eagerly",
-            "ms_per_step": round(dt * 1e3, 2), "eager_ms_per_step": round(eager_dt * 1e3, 2), "patches_per_s": round(B / dt, 1), "points_per_s": round(B * N / dt, 1),
+            "ms_per_step": round(dt * 1e3, 2), "ms_per_step_with_align": round(dt_al * 1e3, 2),
+            "ms_per_step_with_align_serial": round(dt_ser * 1e3, 2), "eager_ms_per_step": round(eager_dt * 1e3, 2), "patches_per_s": round(B / dt, 1), "points_per_s": round(B * N / dt, 1),
             "dense_tflops": round(flop / dt / 1e12, 2), "frac_of_f16x3_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 3), 4),
             "frac_of_bf16x6_ceiling": round(flop / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / 6), 4), "steps": steps, "warmup": warmup,
             "final_loss": round(loss, 5)}
