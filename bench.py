@@ -536,14 +536,21 @@ def train_step_leg(steps=8, warmup=4, B=8, N=2048):
     # the same step fed by the PU-Net loop's data side: auction alignment of every batch (a23)
     tcfg["data"] = dict(tcfg.get("data", {}), dataset="PUNet")
     align = T.make_align_fn()
-    feed = T.AlignedBatches(T.synthetic_punet_batches(B, N, 100, "cuda"), tcfg, align, capture=True)
+    # (a pool of device-resident batches, cycled: the host-side synthesis of a batch and its pageable host-to-device copy are a
+    #  data loader's business -- worker processes, pinned memory -- and would otherwise be timed as part of the step)
+    import itertools
+
+    gen = T.synthetic_punet_batches(B, N, 100, "cuda")
+    pool = [next(gen) for _ in range(8)]
+    torch.cuda.synchronize()
+    feed = T.AlignedBatches(itertools.cycle(pool), tcfg, align, capture=True)
 
     def with_align():
         d = next(feed)
         return stepper(d["x_gt"], d["x_start"], d["x_cond"])
 
     dt_al, _ = timed(with_align, warmup + 2, steps)
-    raw = T.synthetic_punet_batches(B, N, 200, "cuda")
+    raw = itertools.cycle(pool)
 
     def with_align_serial():
         d = T.get_data_batch(next(raw), tcfg, align)

@@ -470,6 +470,119 @@ __global__ __launch_bounds__(256) void auction_dist_kernel(int n, const float *_
   dist[(size_t)b * n + j] = sqdist3(p[0] - q[0], p[1] - q[1], p[2] - q[2]);
 }
 
+// Rounds [first, iters) of the auction as ONE launch (round 6): one 1024-thread workgroup per cloud runs the three phases of
+// every remaining round itself, separated by workgroup barriers instead of kernel boundaries. After the first few rounds an
+// auction round is pure latency -- a few dozen unassigned bidders, three dependent launches (19.7 us per round at 8 x 2048:
+// the training alignment's 2.0 ms) -- while the FIRST rounds are n^2 distance evaluations that want the whole chip: the
+// launcher runs those as before and hands the tail to this kernel. Objects (x, y, z, price) live in LDS as 16-byte records; the
+// unassigned bidders are listed (ascending) at the top of every round, so a bidder that loses its object during Assign bids
+// again in the next round -- one of the interleavings the reference's racing Assign kernel can produce. Same arithmetic per
+// bid (double `3.0 - sqrtf - price`, lowest object index on value ties), same GetMax / Assign bodies, same final state in the
+// caller's buffers. n <= 8192 (LDS: 16 n + 2 n bytes).
+#define AUC_T 1024
+__global__ __launch_bounds__(AUC_T) void auction_persist_kernel(int n, const float *__restrict__ xyz1,
+                                                                const float *__restrict__ xyz2, float eps, int *assignment,
+                                                                int *assignment_inv, float *price, int *bid,
+                                                                float *bid_increments, float *max_increments, int *max_idx,
+                                                                int first, int iters) {
+  extern __shared__ float4 auc_lds[];
+  float4 *obj = auc_lds;                             // [n] (x, y, z, price)
+  unsigned short *list = (unsigned short *)(obj + n);  // [n] unassigned bidders, ascending
+  __shared__ int wcnt[AUC_T / 64], total;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t o = (size_t)b * n;
+  for (int k = tid; k < n; k += AUC_T) {
+    const float *q = xyz2 + (o + k) * 3;
+    obj[k] = make_float4(q[0], q[1], q[2], price[o + k]);
+  }
+  __syncthreads();
+  for (int it = first; it < iters; ++it) {
+    const int last = it == iters - 1;
+    // ---- the round's unassigned bidders, ascending (ballot + scan; chunks of AUC_T bidders)
+    int base = 0;
+    for (int j0 = 0; j0 < n; j0 += AUC_T) {
+      const int j = j0 + tid;
+      const bool un = j < n && assignment[o + j] == -1;
+      const unsigned long long m = __ballot(un);
+      if (lane == 0) wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int before = base;
+      for (int w = 0; w < wave; ++w) before += wcnt[w];
+      if (un) list[before + mbcnt(m)] = (unsigned short)j;
+      int all = 0;
+      for (int w = 0; w < AUC_T / 64; ++w) all += wcnt[w];
+      base += all;
+      __syncthreads();
+    }
+    const int nun = base;  // (workgroup-uniform)
+    if (nun == 0) break;   // every bidder holds an object: the remaining rounds change nothing
+    // ---- Bid: one wave per unassigned bidder (auction_bid_kernel's body on the LDS records)
+    for (int u = wave; u < nun; u += AUC_T / 64) {
+      const int j = list[u];
+      const float *p = xyz1 + (o + j) * 3;
+      const float x1 = p[0], y1 = p[1], z1 = p[2];
+      float best = -1e9f, better = -1e9f;
+      int best_i = -1;
+      for (int k = lane; k < n; k += 64) {
+        const float4 q = obj[k];
+        const float d = (float)((3.0 - (double)sqrtf(sqdist3(q.x - x1, q.y - y1, q.z - z1))) - (double)q.w);
+        if (d > best) {
+          better = best;
+          best = d;
+          best_i = k;
+        } else if (d > better) {
+          better = d;
+        }
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off), obt = __shfl_xor(better, off);
+        const int oi = __shfl_xor(best_i, off);
+        const bool take = (ob > best) || (ob == best && oi >= 0 && (best_i < 0 || oi < best_i));
+        if (take) {
+          better = fmaxf(best, obt);
+          best = ob;
+          best_i = oi;
+        } else {
+          better = fmaxf(better, ob);
+        }
+      }
+      if (lane == 0) {
+        const float inc = best - better + eps;
+        bid[o + j] = best_i;
+        bid_increments[o + j] = inc;
+        atomic_max_f32(max_increments + o + best_i, inc);
+      }
+    }
+    __syncthreads();
+    // ---- GetMax (auction_getmax_kernel)
+    for (int u = tid; u < nun; u += AUC_T) {
+      const int j = list[u];
+      const int bid_id = bid[o + j];
+      const float bid_inc = bid_increments[o + j];
+      const float max_inc = max_increments[o + bid_id];
+      if ((double)bid_inc - 1e-6 <= (double)max_inc && (double)max_inc <= (double)bid_inc + 1e-6) max_idx[o + bid_id] = j;
+    }
+    __syncthreads();
+    // ---- Assign (auction_assign_kernel); the winner keeps the LDS price in step with the caller's buffer
+    for (int u = tid; u < nun; u += AUC_T) {
+      const int j = list[u];
+      const int bid_id = bid[o + j];
+      if (last || max_idx[o + bid_id] == j) {
+        const float bid_inc = bid_increments[o + j];
+        const int ass_inv = assignment_inv[o + bid_id];
+        if (!last && ass_inv != -1) assignment[o + ass_inv] = -1;
+        assignment_inv[o + bid_id] = j;
+        assignment[o + j] = bid_id;
+        const float np = price[o + bid_id] + bid_inc;
+        price[o + bid_id] = np;
+        obj[bid_id].w = np;
+        max_increments[o + bid_id] = -1e9f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int p2pb_auction_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist,
                                     int *assignment, float *price, int *assignment_inv, int *bid,
                                     float *bid_increments, float *max_increments, int *unass_idx, int *unass_cnt,
@@ -478,13 +591,27 @@ extern "C" int p2pb_auction_forward(int b, int n, int m, const float *xyz1, cons
   (void)unass_idx, (void)unass_cnt, (void)unass_cnt_sum, (void)cnt_tmp;  // the compaction pass is not needed here
   if (n != m || b > 512 || n % 128 != 0 || b <= 0 || n <= 0) return -1;  // emd_cuda.cu:236-249
   hipStream_t s = (hipStream_t)stream;
-  for (int i = 0; i < iters; ++i) {
+  // the first rounds (n^2 distance evaluations each: the whole chip) as three launches per round, the latency-bound tail as
+  // one persistent launch (auction_persist_kernel); P2PB_EXPERIMENT="auction_persist_from=K" moves the hand-over (K >= iters: off)
+  static const long persist_from = p2pb_experiment_long("auction_persist_from", 10);
+  const int head = (n <= 8192 && persist_from < iters) ? (int)(persist_from < 0 ? 0 : persist_from) : iters;
+  for (int i = 0; i < head; ++i) {
     hipLaunchKernelGGL(auction_bid_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, s, n, xyz1, xyz2, eps, assignment, price,
                        bid, bid_increments, max_increments);
     hipLaunchKernelGGL(auction_getmax_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, assignment, bid,
                        bid_increments, max_increments, max_idx);
     hipLaunchKernelGGL(auction_assign_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, assignment, assignment_inv,
                        price, bid, bid_increments, max_increments, max_idx, (int)(i == iters - 1));
+  }
+  if (head < iters) {
+    const size_t lds = (size_t)n * 18;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void *)auction_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL(auction_persist_kernel, dim3(b), dim3(AUC_T), lds, s, n, xyz1, xyz2, eps, assignment, assignment_inv,
+                       price, bid, bid_increments, max_increments, max_idx, head, iters);
   }
   hipLaunchKernelGGL(auction_dist_kernel, dim3(cdiv(n, 256), b), dim3(256), 0, s, n, xyz1, xyz2, dist, assignment);
   return p2pb_launch_status() == 0 ? 1 : 0;

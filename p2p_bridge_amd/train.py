@@ -178,7 +178,10 @@ class AlignedBatches:
     def __init__(self, batches: Iterator[Dict], cfg, align_fn: Optional[Callable], capture: bool = False, warmup: int = 2):
         self.batches, self.cfg, self.align_fn = batches, cfg, align_fn
         self.capture, self.warmup = bool(capture), int(warmup)
-        self.side = torch.cuda.Stream()
+        from ._streams import concurrent_stream
+
+        # (a stream that shares its hardware queue with the caller's would run the alignment BEHIND the step: _streams.py)
+        self.side = concurrent_stream(torch.cuda.current_stream())
         self.graph = None
         self.calls = 0
         self.pending = None
