@@ -238,7 +238,10 @@ int p2pb_matchcost_backward(int b, int n, int m, const float *grad_cost, const f
  * (metrics/emd_assignment/emd_assignment/emd_cuda.cu:228,305; kernels :23-226,:284). Buffers as
  * allocated by emd_module.py:43-54; assignment/assignment_inv must be -1-filled, price and
  * max_increments zero-filled by the caller, as the reference's Python does.
- * Returns 1 on success (the reference's convention), -1 on n != m / n % 128 / b > 512 (:236-249). */
+ * Returns 1 on success (the reference's convention), -1 on n != m / n % 128 / b > 512 (:236-249).
+ * A round is Bid (one wave per unassigned bidder) / GetMax / Assign; the first ten rounds are three launches each, the
+ * latency-bound rest is ONE launch (one workgroup per cloud, n <= 8192; csrc/emd.hip auction_persist_kernel). The assignment is
+ * schedule dependent in the reference as well (racing atomicMax / Assign): the contract is the invariants + transport cost. */
 int p2pb_auction_forward(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *assignment,
                          float *price, int *assignment_inv, int *bid, float *bid_increments,
                          float *max_increments, int *unass_idx, int *unass_cnt, int *unass_cnt_sum, int *cnt_tmp,

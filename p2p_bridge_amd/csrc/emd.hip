@@ -593,7 +593,7 @@ extern "C" int p2pb_auction_forward(int b, int n, int m, const float *xyz1, cons
   hipStream_t s = (hipStream_t)stream;
   // the first rounds (n^2 distance evaluations each: the whole chip) as three launches per round, the latency-bound tail as
   // one persistent launch (auction_persist_kernel); P2PB_EXPERIMENT="auction_persist_from=K" moves the hand-over (K >= iters: off)
-  static const long persist_from = p2pb_experiment_long("auction_persist_from", 10);
+  const long persist_from = p2pb_experiment_long("auction_persist_from", 10);  // (read per call: tests switch it)
   const int head = (n <= 8192 && persist_from < iters) ? (int)(persist_from < 0 ? 0 : persist_from) : iters;
   for (int i = 0; i < head; ++i) {
     hipLaunchKernelGGL(auction_bid_kernel, dim3(cdiv(n, 4), b), dim3(256), 0, s, n, xyz1, xyz2, eps, assignment, price,

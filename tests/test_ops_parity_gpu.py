@@ -260,11 +260,16 @@ def _auction(mod, x1, x2, eps, iters, device):
     return rc, dist.cpu(), assignment.cpu()
 
 
-def test_auction(met):
+@pytest.mark.parametrize("persist_from", [10, 0, 3, 1000])
+def test_auction(met, persist_from, monkeypatch):
     """emd_module.py:98-117 invariant + the oracle's transport cost; the assignment itself is
-    schedule dependent in the reference, so it is compared by properties."""
+    schedule dependent in the reference, so it is compared by properties. persist_from: the round from which the
+    auction runs as ONE persistent launch (csrc/emd.hip auction_persist_kernel, round 6; 10 = the default, 0 = every round,
+    1000 = never: three launches per round as in round 5) -- every hand-over point is held to the same properties; 8192-point
+    clouds (the largest the persistent form takes) included"""
+    monkeypatch.setenv("P2PB_EXPERIMENT", f"auction_persist_from={persist_from}")
     g = torch.Generator().manual_seed(0)
-    for (B, N) in [(2, 256), (8, 2048)]:
+    for (B, N) in [(2, 256), (8, 2048)] + ([(2, 8192)] if persist_from == 10 else []):
         x1, x2 = torch.rand(B, N, 3, generator=g), torch.rand(B, N, 3, generator=g)
         rc0, d0, a0 = _auction(cpu_ops.emd_assignment, x1, x2, 0.01, 100, "cpu")
         rc1, d1, a1 = _auction(met.emd_assignment, x1, x2, 0.01, 100, "cuda")
