@@ -85,6 +85,45 @@ class split_math:
         lib().p2pb_set_split_terms_thread(self.prev)
 
 
+def pinned_math(conv):
+    """the arithmetic pinned on this layer (`pin_layer_math`), or None: the process-wide one"""
+    return getattr(conv, "_p2pb_math", None)
+
+
+def pin_layer_math(conv, name):
+    """run THIS layer's split kernels in `name` ("bf16x6": fp32's exponent range) whatever the process-wide arithmetic is; None
+    removes the pin. Round 6: a checkpoint whose activations leave the f16x3 range in one or two layers pays
+    six products there instead of repeating every sample() call on bf16x6 -- P2PB.calibrate_ranges() finds and pins them. A
+    pinned layer takes fp32 operands (no pre-split grid: pvcnn_unet asks pinned_math before it plans one). Captured graphs must
+    be re-captured after a change (P2PB.calibrate_ranges clears them)."""
+    if name is None:
+        if hasattr(conv, "_p2pb_math"):
+            del conv._p2pb_math
+        return
+    if name not in SPLIT_MATHS:
+        raise ValueError(f"a layer can be pinned to one of {SPLIT_MATHS}, got {name!r}")
+    conv._p2pb_math = name
+
+
+def _honours_pin(argpos):
+    """decorator of the GEMM-shaped entry points: `conv` (positional argument argpos) may carry a pinned arithmetic"""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def f(*a, **k):
+            conv = a[argpos] if len(a) > argpos else k.get("conv")
+            m = getattr(conv, "_p2pb_math", None)
+            if m is None or k.get("math") is not None or _SPLIT_TERMS[m] == lib().p2pb_get_split_terms():
+                return fn(*a, **k)
+            if k.get("pre"):
+                raise RuntimeError("a layer pinned to another arithmetic was handed a pre-split (f16x3) operand grid")
+            with split_math(m):
+                return fn(*a, **k)
+        return f
+    return deco
+
+
 def use_split(cout: int, math=None) -> bool:
     """split-operand kernel unless P2PB_CONV_MATH=fp32 (or math="fp32") asks for the exact-fp32 MFMA one"""
     return (math or conv_math()) in SPLIT_MATHS
@@ -159,6 +198,7 @@ def conv3d_presplit(y, in_scale=None, in_shift=None, swish=False, in_sub=None):
     return out
 
 
+@_honours_pin(1)
 def conv3d_k3(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, in_sub=None, out_class=None,
               skip_zero=False, compact=False, math=None, force_split=False, channels_last=False, pre=False):
     """x f32[B,Cin,r,r,r] -> (y f32[B,Cout,r,r,r], stats partials f32[B,nslots,Cout,2] | None); with
@@ -196,6 +236,7 @@ def brick_lists(cnt, r):
     return lists, counts
 
 
+@_honours_pin(1)
 def conv3d_k3_sparse(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
                      out_class=None, math=None, channels_last=False, pre=False, active_only=False):
     """list-driven sparse conv (csrc/conv3d.hip): which = 0 for the first conv of a PVConv, 1 for the second;
@@ -234,6 +275,7 @@ def active_lists(cnt, r):
     return lists, counts
 
 
+@_honours_pin(1)
 def conv3d_k3_compact(x, conv, lists, counts, which, in_scale=None, in_shift=None, swish=False, in_sub=None,
                       out_class=None, pre=False, listed_only=False):
     """compact sparse conv on voxel-major grids (csrc/conv3d.hip): only the listed outputs of every brick are computed,
@@ -530,6 +572,7 @@ def arm_finisher(fin, b, c, device):
     return (scale, shift, chmean), style  # (style: kept alive by the caller until the launch is enqueued)
 
 
+@_honours_pin(1)
 def pw_conv(x, conv, in_scale=None, in_shift=None, swish=False, stats=True, bias_b=None, ci_lo=0, ci_hi=None,
             use_bias=True, pool_u=None, store=True, math=None, point_major=False, fin=None):
     """x f32[B,Cin,P] -> (y f32[B,Cout,P], stats partials f32[B,nslots,Cout,2] | None).
@@ -629,6 +672,7 @@ def gather_pool_supported(ci: int, co: int, m: int, u: int) -> bool:
             and _experiment.get("sa_gather", "1") != "0")
 
 
+@_honours_pin(3)
 def pw_conv_pool_gather(zt, cxt, idx, conv, in_scale, in_shift, swish=True, fin=None):
     """the last 1x1 layer of a set abstraction on the grouped tensor WITHOUT building it: operand[ci, (m, u)] =
     zt[b, idx[b,m,u], ci] - cxt[b, m, ci] gathered on load (zt f32[B,N,Ci], cxt f32[B,M,Ci] point-major, idx i32[B,M,U]:
@@ -733,7 +777,7 @@ class operand_audit:
         # pre-split path, whose grids hold fp16 pairs)
         self._pre = os.environ.get("P2PB_EXPERIMENT")
         os.environ["P2PB_EXPERIMENT"] = _experiment.setting(conv_pre=":")
-        self.rows, self._mod = [], sys.modules[__name__]
+        self.rows, self.layers, self._mod = [], [], sys.modules[__name__]  # layers[i]: the module of rows[i]
         self._orig = {k: getattr(self._mod, k) for k in ("pw_conv", "conv3d_k3", "conv3d_k3_sparse", "conv3d_k3_compact")}
         names = {"pw_conv": ("in_scale", "in_shift", "swish"), "conv3d_k3": ("in_scale", "in_shift", "swish"),
                  "conv3d_k3_sparse": (None, None, None, "in_scale", "in_shift", "swish"),
@@ -754,6 +798,7 @@ class operand_audit:
                     if kw.get("swish"):
                         v = v * torch.sigmoid(v)
                 self.rows.append((kind, tuple(x.shape), float(v.abs().max()), float(conv.weight.abs().max())))
+                self.layers.append(conv)
                 return orig(x, conv, *a, **k)
             return f
 

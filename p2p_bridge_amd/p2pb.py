@@ -217,6 +217,7 @@ class P2PB(nn.Module):
         self._graphs: Dict = {}
         self.f16_overflow: Optional[str] = None  # None: P2PB_F16_OVERFLOW or "rerun" (ddpm_sampling)
         self.overflow_reruns = 0
+        self.pinned_layers: list = []  # names of the layers calibrate_ranges() pinned to bf16x6
         self.sample_chains = None  # None: automatic (see _sampler_chains)
 
     # ---- reference API surface ------------------------------------------------------------------
@@ -337,9 +338,21 @@ class P2PB(nn.Module):
             why = "the INPUT holds non-finite values"
         if policy == "raise":
             raise FloatingPointError(f"P2PB.sample: non-finite result under P2PB_CONV_MATH=f16x3: {why}")
+        self.overflow_reruns += 1
+        # the layers that left the range are pinned to bf16x6 (calibrate_ranges: one audited evaluation on this very input), so
+        # that the NEXT call does not overflow; this call is repeated on the pinned network, and only if that is not enough
+        # (nothing to pin, or still non-finite) on bf16x6 as a whole
+        if bool(torch.isfinite(x1).all()) and (x_cond is None or bool(torch.isfinite(x_cond).all())):
+            pinned = self.calibrate_ranges(x1, x_cond, sampling_steps, use_ema=use_ema)
+            if pinned:
+                warnings.warn("P2PB.sample: activations left the f16x3 range; pinned to bf16x6: "
+                              + ", ".join(f"{n} (|x| <= {a:.3g})" for n, _, a in pinned) + " -- repeating the call",
+                              RuntimeWarning)
+                xs, x0s = self._ddpm_once(*args)
+                if bool(torch.isfinite(xs[:, 0]).all()):
+                    return xs, x0s
         warnings.warn(f"P2PB.sample: non-finite result under f16x3 ({why}); repeating the call on bf16x6. "
                       "Set P2PB_CONV_MATH=bf16x6 for this checkpoint to skip the wasted pass.", RuntimeWarning)
-        self.overflow_reruns += 1
         prev = fused._conv_math_override
         fused.set_conv_math("bf16x6")
         try:
@@ -549,6 +562,51 @@ class P2PB(nn.Module):
             return o_x, o_0
 
         return run
+
+    @torch.no_grad()
+    def calibrate_ranges(self, x_start, x_cond=None, steps=None, margin: float = 4.0, use_ema=False):
+        """The f16x3 range contract, enforced PER LAYER (round 6; no reference counterpart -- see ddpm_sampling): evaluate the
+        network once at the first and once at the last bridge step of the sampler on `x_start` (a representative batch: real
+        patches of the checkpoint's data) with every split-operand launch's operand measured -- in bf16x6, so that an overflow
+        cannot hide the layers behind it --, and pin every layer whose operand after the folded norm + Swish reaches
+        16376 / margin to bf16x6 (fused.pin_layer_math: six products in THAT layer, fp32's exponent range) instead of leaving
+        the whole checkpoint to the repeat-the-call-on-bf16x6 fallback. Returns [(layer name, kind, max |operand|)] of the
+        pinned layers; captured sampler graphs are dropped. Call it once after loading a checkpoint; sample() calls it by
+        itself after the first call that overflowed."""
+        from . import fused
+
+        if fused.conv_math() != "f16x3" or self.device.type != "cuda":
+            return []
+        net = self.ema.ema_model if (use_ema and self.ema is not None) else self.model
+        names = {id(m): n for n, m in net.named_modules()}
+        was_training = net.training
+        net.eval()
+        _, table = self.step_tables(steps or self.timesteps - 1)
+        xs = x_start.detach().to(self.device)
+        if self.cond_x1:
+            x_cond = xs if x_cond is None else torch.cat([xs, x_cond], dim=1)
+        worst = {}
+        prev = fused._conv_math_override
+        fused.set_conv_math("bf16x6")
+        try:
+            for row in sorted({0, table.shape[0] - 1}):  # the first and the last reverse step's noise level
+                with fused.operand_audit() as audit:
+                    net(xs, table[row][0].expand(xs.shape[0]), x_cond=x_cond)
+                for (kind, _shape, amax, _w), conv in zip(audit.rows, audit.layers):
+                    if not (amax < worst.get(id(conv), (0.0,))[0]):  # (a NaN counts as out of range)
+                        worst[id(conv)] = (amax, kind, conv)
+        finally:
+            fused.set_conv_math(prev)
+            net.train(was_training)
+        pinned = []
+        for amax, kind, conv in worst.values():
+            if not (amax < fused.operand_audit.LIMIT / margin):
+                fused.pin_layer_math(conv, "bf16x6")
+                pinned.append((names.get(id(conv), "?"), kind, amax))
+        if pinned:
+            self.clear_graphs()
+            self.pinned_layers = sorted(set(self.pinned_layers) | {n for n, _, _ in pinned})
+        return pinned
 
     def clear_graphs(self):
         """drop every captured sampler graph (they are also re-captured automatically when the weights change)"""

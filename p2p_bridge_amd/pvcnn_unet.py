@@ -436,6 +436,8 @@ class PVConv(nn.Module):
         if geo_v is not None:  # coordinate-only half (voxel coordinates, sort, brick lists) came from the geometry stream
             vcoords, cnt, ws, lists, counts = geo_v
             pre1, pre2 = fused.conv_pre_plan(r)
+            # (a layer pinned to bf16x6 -- fused.pin_layer_math, P2PB.calibrate_ranges -- takes its operand as fp32)
+            pre1, pre2 = pre1 and fused.pinned_math(vl[0]) is None, pre2 and fused.pinned_math(vl[4]) is None
             v = fused.voxelize_cl_gather(features.contiguous(), cnt, ws, r, split=pre1)
         else:
             vcoords, vox = L.voxel_coords(coords.detach().contiguous(), r, self.voxelization.normalize,

@@ -269,8 +269,11 @@ def test_f16_range_overflow_cannot_return_clipped_points(tiny):
     """The build's default arithmetic (f16x3) has fp16's exponent range (|activation| < 16380); the reference has fp32's.
     A checkpoint with ONE outlier GroupNorm weight (channel 5 of fp_layers.1.1.voxel_layers.1, x 1e5: the operand of a
     split convolution) leaves that range. Contract: the f16x3 pass then ends NON-FINITE (nothing is clipped), and
-    sample() -- per policy -- repeats the call on bf16x6 with a warning (result bit-identical to a plain bf16x6 run,
-    finite, within 1e-4 of the oracle for one step), raises, or hands the non-finite cloud back."""
+    sample() -- per policy -- hands the non-finite cloud back, raises, or (default, round 6) finds the layer with one audited
+    evaluation (P2PB.calibrate_ranges), pins IT to bf16x6 and repeats the call: finite, the overflowing layer named in the
+    warning, within 1e-5 of a whole-network bf16x6 run, and the NEXT call neither overflows nor repeats. Calibrated at load
+    (calibrate_ranges on a representative batch) no call is ever repeated: overflow_reruns == 0 with parity at 1e-4 against
+    the oracle."""
     import warnings
 
     from p2p_bridge_amd import fused
@@ -290,24 +293,36 @@ def test_f16_range_overflow_cannot_return_clipped_points(tiny):
         model.f16_overflow = "raise"
         with pytest.raises(FloatingPointError):
             s()
-        model.f16_overflow = None  # default: rerun
+        model.f16_overflow = None  # default: pin the layers that left the range, repeat the call
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter("always")
             out = s()
-        assert any("bf16x6" in str(m.message) for m in w) and model.overflow_reruns == 1
-        assert fused.conv_math() == "f16x3"  # the process-wide setting is back
+        assert model.overflow_reruns == 1 and model.pinned_layers == ["fp_layers.1.1.voxel_layers.4"]
+        assert any("pinned to bf16x6" in str(m.message) and "fp_layers.1.1.voxel_layers.4" in str(m.message) for m in w)
+        assert not any("repeating the call on bf16x6" in str(m.message) for m in w)  # (the whole-network fallback was not needed)
+        assert fused.pinned_math(model.model.fp_layers[1][1].voxel_layers[4]) == "bf16x6"
+        assert fused.conv_math() == "f16x3"  # the process-wide setting is untouched
         assert torch.isfinite(out).all()
+        with warnings.catch_warnings(record=True) as w2:
+            warnings.simplefilter("always")
+            again = s()
+        assert model.overflow_reruns == 1 and not w2 and torch.equal(again, out)  # the next call pays nothing
         prev = fused._conv_math_override
         fused.set_conv_math("bf16x6")
         try:
             direct = s()
         finally:
             fused.set_conv_math(prev)
-        assert model.overflow_reruns == 1 and torch.equal(out, direct)
+        assert (out - direct).abs().max().item() < 1e-5 * max(1.0, direct.abs().max().item())
+    # calibrated when the checkpoint is loaded: nothing overflows, nothing is repeated, parity with the oracle
+    model = product.build_model(cfg, sd, device="cuda")
+    pinned = model.calibrate_ranges(x.cuda(), steps=2)
+    assert [n for n, _, _ in pinned] == ["fp_layers.1.1.voxel_layers.4"] and pinned[0][2] > 16376 / 4
     orc = net_ref.RefNet(cfg, sd, vox_mode="tree")
     a = model.sample(x_start=x.cuda(), steps=1, log_count=1, verbose=False)["x_pred"].cpu()
     b = net_ref.sample(orc, cfg, x, steps=1, log_count=1)["x_pred"]
     assert (a - b).abs().max().item() < TOL * max(1.0, b.abs().max().item())
+    assert model.overflow_reruns == 0
     # a non-finite INPUT is reported as such
     bad = x.clone()
     bad[0, 0, 0] = float("nan")
