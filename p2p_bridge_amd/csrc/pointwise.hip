@@ -212,7 +212,7 @@ __device__ __forceinline__ void group_minmax(float &mn, float &mx, int g) {
 // output ever being written or re-read.
 // TERMS == SPLIT_F16X3: the same tiling, operand path and epilogue with the products on the 16-bit matrix pipe (fp16-pair
 // split, three MFMAs of K = 16 instead of eight exact-fp32 ones of K = 2: 5.3x fewer matrix cycles -- the exact-fp32
-// MFMAs were HALF the time of the set-abstraction neighbourhood layers, tools/exp_pw_wide_pool.py). `wp` is then the split
+// MFMAs were HALF the time of the set-abstraction neighbourhood layers; round 2 measurement, docs/history). `wp` is then the split
 // pack of pw_split_kernel (fragments read straight from L1 / L2, output scale in its trailer); 16 input channels per step:
 // lane (l31, khalf) loads rows 8 khalf .. + 7 of the step for its four positions, transforms and splits them once.
 // GATHER (f16x3 form only): the operand is the GROUPED tensor of a set abstraction without ever being built --

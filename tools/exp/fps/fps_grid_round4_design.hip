@@ -6,7 +6,7 @@
 // first experiment of the series had already degraded (26.2 ms), so every later "gain" was measured against the wrong number;
 // the three-way A/B on one box is profiles/r04g_fps_grid.txt. This is the kernel part of csrc/sampling.hip at that point.
 typedef float fg_f32x4 __attribute__((ext_vector_type(4)));
-#ifdef FG_TIMELINE  // experiment builds (tools/exp_fg_timeline.py): the round of a wave that updates exactly one cell, by phase.
+#ifdef FG_TIMELINE  // experiment builds (round 4; the driver script left the tree): the round of a wave that updates exactly one cell, by phase.
 // A stamp waits for the scalar it is given (s_memtime issues in order, but does not wait for the vector pipe by itself)
 __device__ unsigned long long *fg_tl_buf;
 extern "C" int p2pb_fg_timeline_set(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(fg_tl_buf), &p, sizeof(p)); }
