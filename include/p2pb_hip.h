@@ -513,6 +513,13 @@ int p2pb_se_gate_forward(int b, int c, int hidden, const float *mean, const floa
 int p2pb_se_gate_backward(int b, int c, int hidden, const float *mean, const float *w1, const float *w2, const float *hid,
                           const float *gate, const float *dgate, float *dmean, float *dw1, float *dw2, float *ws, void *stream);
 
+/* Max over the last axis with its arg-max, and the backward that writes the whole input gradient (csrc/normact.hip, ABI 6):
+ * the neighbour max of a set abstraction (models/pvcnn.py:414) and Pnet2Stage's global max-pools (:923,930) in train().
+ *   x f32[rows,u] -> y f32[rows], idx i32[rows] (first position of the maximum; a NaN in the row is returned);
+ *   gy f32[rows], idx -> gx f32[rows,u] = gy at idx, 0 elsewhere (no pre-zeroing). */
+int p2pb_row_max_forward(long rows, int u, const float *x, float *y, int *idx, void *stream);
+int p2pb_row_max_backward(long rows, int u, const float *gy, const int *idx, float *gx, void *stream);
+
 /* ---- training: weight gradients of the dense layers (csrc/wgrad.hip) --------------------------------------
  * What cuDNN / cuBLAS compute in the reference's backward pass for nn.Conv3d(k 3, pad 1) (models/pvcnn.py:265-282)
  * and the k = 1 Conv1d / Conv2d layers (models/pvcnn.py:162-205, 803-823): exact-fp32 MFMA GEMMs over the voxel /

@@ -34,7 +34,7 @@ SYMBOLS = [
     "p2pb_optim_entry_bytes", "p2pb_optim_chunk", "p2pb_optim_clip_adam_step",
     "p2pb_conv3d_k3_pack_weights_split_adjoint", "p2pb_pointwise_pack_weights_adjoint", "p2pb_pointwise_pack_weights_split_adjoint",
     "p2pb_conv3d_k3_pack_weights_split_amax", "p2pb_pointwise_pack_weights_split_amax",
-    "p2pb_se_gate_forward", "p2pb_se_gate_backward",
+    "p2pb_se_gate_forward", "p2pb_se_gate_backward", "p2pb_row_max_forward", "p2pb_row_max_backward",
 ]
 
 ABI_VERSION = 6  # include/p2pb_hip.h P2PB_ABI_VERSION this binding was written against (tests/test_abi.py compares the two)

@@ -286,3 +286,93 @@ extern "C" int p2pb_se_gate_backward(int b, int c, int hidden, const float *mean
                      dz1, dw1, dw2);
   return p2pb_launch_status();
 }
+
+// ---- max over the last axis, forward and backward (training, round 6) ---------------------------------------------------------
+// The neighbour max of a set abstraction (models/pvcnn.py:414: x[B,C,M,U].max(-1)) and Pnet2Stage's two global max-pools
+// (:923,930: amax over the N points) were ATen reductions with an eq / mul / div / sum / copy backward each (0.3 ms of the
+// config-3 step: profiles/r05b_train_aten_ops.txt). Here: rows of u contiguous floats, L lanes per row (L = 8 .. 64 by u), 16-byte
+// loads where the rows allow, a shuffle reduction on (value, index) -- first index on ties, a NaN wins (it must reach the loss
+// like torch's max lets it) --, and a backward that WRITES the whole gradient (gy at the arg-max, zero elsewhere: no fill launch).
+__device__ __forceinline__ bool rm_better(float a, int ia, float b, int ib) {  // is (a, ia) the pick over (b, ib)?
+  const bool na = a != a, nb = b != b;
+  if (na || nb) return na && (!nb || ia < ib);
+  return a > b || (a == b && ia < ib);
+}
+template <int L>
+static __global__ __launch_bounds__(256) void row_max_fwd_kernel(long rows, int u, const float *__restrict__ x,
+                                                                 float *__restrict__ y, int *__restrict__ idx) {
+  const long row = ((long)blockIdx.x * 256 + threadIdx.x) / L;
+  const int l = threadIdx.x % L;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  if (row < rows) {
+    const float *p = x + row * (long)u;
+    if ((u & 3) == 0 && (((size_t)x) & 15) == 0) {
+      for (int k = 4 * l; k < u; k += 4 * L) {
+        const float4 v = *(const float4 *)(p + k);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (rm_better(e[i], k + i, best, bi)) best = e[i], bi = k + i;
+      }
+    } else {
+      for (int k = l; k < u; k += L)
+        if (rm_better(p[k], k, best, bi)) best = p[k], bi = k;
+    }
+  }
+#pragma unroll
+  for (int o = L / 2; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o);
+    const int oi = __shfl_xor(bi, o);
+    if (rm_better(ob, oi, best, bi)) best = ob, bi = oi;
+  }
+  if (row < rows && l == 0) {
+    y[row] = best;
+    idx[row] = bi;
+  }
+}
+template <int L>
+static __global__ __launch_bounds__(256) void row_max_bwd_kernel(long rows, int u, const float *__restrict__ gy,
+                                                                 const int *__restrict__ idx, float *__restrict__ gx) {
+  const long row = ((long)blockIdx.x * 256 + threadIdx.x) / L;
+  const int l = threadIdx.x % L;
+  if (row >= rows) return;
+  const float g = gy[row];
+  const int at = idx[row];
+  float *p = gx + row * (long)u;
+  if ((u & 3) == 0 && (((size_t)gx) & 15) == 0) {
+    for (int k = 4 * l; k < u; k += 4 * L)
+      *(float4 *)(p + k) = make_float4(k == at ? g : 0.0f, k + 1 == at ? g : 0.0f, k + 2 == at ? g : 0.0f, k + 3 == at ? g : 0.0f);
+  } else {
+    for (int k = l; k < u; k += L) p[k] = k == at ? g : 0.0f;
+  }
+}
+static int rm_lanes(int u) { return u <= 32 ? 8 : u <= 64 ? 16 : u <= 128 ? 32 : 64; }
+// x f32[rows, u] -> y f32[rows] = max over the row, idx i32[rows] = its first position
+extern "C" int p2pb_row_max_forward(long rows, int u, const float *x, float *y, int *idx, void *stream) {
+  if (rows <= 0 || u <= 0 || !x || !y || !idx) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int L = rm_lanes(u);
+  const unsigned grid = (unsigned)((rows * L + 255) / 256);
+  switch (L) {
+    case 8: hipLaunchKernelGGL(row_max_fwd_kernel<8>, dim3(grid), dim3(256), 0, s, rows, u, x, y, idx); break;
+    case 16: hipLaunchKernelGGL(row_max_fwd_kernel<16>, dim3(grid), dim3(256), 0, s, rows, u, x, y, idx); break;
+    case 32: hipLaunchKernelGGL(row_max_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, rows, u, x, y, idx); break;
+    default: hipLaunchKernelGGL(row_max_fwd_kernel<64>, dim3(grid), dim3(256), 0, s, rows, u, x, y, idx); break;
+  }
+  return p2pb_launch_status();
+}
+// gy f32[rows], idx i32[rows] -> gx f32[rows, u], every element written
+extern "C" int p2pb_row_max_backward(long rows, int u, const float *gy, const int *idx, float *gx, void *stream) {
+  if (rows <= 0 || u <= 0 || !gy || !idx || !gx) return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int L = rm_lanes(u);
+  const unsigned grid = (unsigned)((rows * L + 255) / 256);
+  switch (L) {
+    case 8: hipLaunchKernelGGL(row_max_bwd_kernel<8>, dim3(grid), dim3(256), 0, s, rows, u, gy, idx, gx); break;
+    case 16: hipLaunchKernelGGL(row_max_bwd_kernel<16>, dim3(grid), dim3(256), 0, s, rows, u, gy, idx, gx); break;
+    case 32: hipLaunchKernelGGL(row_max_bwd_kernel<32>, dim3(grid), dim3(256), 0, s, rows, u, gy, idx, gx); break;
+    default: hipLaunchKernelGGL(row_max_bwd_kernel<64>, dim3(grid), dim3(256), 0, s, rows, u, gy, idx, gx); break;
+  }
+  return p2pb_launch_status();
+}

@@ -302,6 +302,40 @@ class _SEGate(torch.autograd.Function):
         return dmean, dw1, dw2
 
 
+class _RowMax(torch.autograd.Function):
+    """max over the LAST axis of a contiguous tensor (csrc/normact.hip row_max_*): forward keeps the arg-max, backward writes the
+    whole gradient in one launch (torch: a reduction forward; eq / mul / div / sum / copy or a zero fill + scatter backward)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        u = x.shape[-1]
+        rows = x.numel() // u
+        y = torch.empty(x.shape[:-1], dtype=F32, device=x.device)
+        idx = torch.empty(x.shape[:-1], dtype=torch.int32, device=x.device)
+        call("p2pb_row_max_forward", ctypes.c_long(rows), _i(u), ptr(x), ptr(y), ptr(idx), stream_ptr())
+        ctx.save_for_backward(idx)
+        ctx.u = u
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty(tuple(idx.shape) + (ctx.u,), dtype=F32, device=gy.device)
+        call("p2pb_row_max_backward", ctypes.c_long(idx.numel()), _i(ctx.u), ptr(gy), ptr(idx), ptr(gx), stream_ptr())
+        return gx
+
+
+def row_max(x):
+    """x[..., u] -> x.max(dim=-1).values (first index on ties, NaN propagates) with a one-launch backward; torch elsewhere"""
+    from . import _experiment
+
+    if not enabled(x) or x.dtype != F32 or x.shape[-1] == 0 or not _experiment.get_int("row_max", 1):  # (A/B key)
+        return x.max(dim=-1).values
+    return _RowMax.apply(x)
+
+
 def se_gate(mean, fc):
     """SE3d's excitation from the per-channel means f32[B,C]; fc = its Sequential(Linear, ReLU, Linear, Sigmoid) (bias-free)"""
     w1, w2 = fc[0].weight, fc[2].weight

@@ -339,7 +339,7 @@ class SharedMLP(nn.Module):
         for i in range(len(self.layers) // 3):  # training: HIP conv + folded norm / Swish, forward and backward
             x = dense.conv_norm_act(x, self.layers[3 * i], self.layers[3 * i + 1], cond, swish=True)
         if reduce_max:
-            x = x.max(dim=-1).values
+            x = dense.row_max(x)  # (csrc/normact.hip: one launch forward, one backward)
         return x if residual is None else residual + x
 
     def _run_fused(self, x, cond, reduce_max, residual, first=None):
@@ -735,10 +735,12 @@ class Pnet2Stage(nn.Module):
 
         if fused.enabled(self, coords) and self._fusable():
             return self._forward_fused(coords)
-        f = self.mlp1(coords.unsqueeze(-1))
-        g = f.amax(dim=2, keepdim=True).expand(-1, -1, f.size(2), -1)
+        from . import dense
+
+        f = self.mlp1(coords.unsqueeze(-1))  # [B,C,N,1]
+        g = dense.row_max(f.squeeze(-1))[:, :, None, None].expand(-1, -1, f.size(2), -1)
         f = self.mlp2(torch.cat([f, g], dim=1))
-        return f.amax(dim=2).squeeze(-1)
+        return dense.row_max(f.squeeze(-1))
 
     def _fusable(self):
         ok = len(self.mlp1.last_mlp_layers) == 0 and len(self.mlp2.last_mlp_layers) == 0

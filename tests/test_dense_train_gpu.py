@@ -317,3 +317,30 @@ def test_se_gate_forward_backward(b, c):
     assert _rel(mean.grad, m64.grad) < 1e-5
     assert _rel(se.fc[0].weight.grad, w1.grad) < 1e-5
     assert _rel(se.fc[2].weight.grad, w2.grad) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 512, 32), (3, 128, 128, 32), (2, 1024, 2048), (5, 7, 33), (4, 9, 100), (2, 3, 1), (1, 2, 300, 6)])
+def test_row_max_forward_backward(shape):
+    """dense.row_max (csrc/normact.hip, round 6): the set abstractions' neighbour max and Pnet2Stage's global max-pools in train()
+    -- values and gradients equal torch's x.max(-1) (first index on exact ties, like torch's index-based backward), ragged and
+    unaligned rows, a NaN in a row reaches the output"""
+    from p2p_bridge_amd import dense
+
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape, device="cuda")
+    x[..., 0, :] = x[..., 0, :].round()  # exact ties in the first row of every slab
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = dense.row_max(xa)
+    vb, ib = xb.max(dim=-1)
+    assert torch.equal(ya, vb)
+    gy = torch.randn_like(ya)
+    ya.backward(gy)
+    # reference gradient with the FIRST maximal index (torch's CUDA reduction may pick any of several equal maxima)
+    first = (x == vb.unsqueeze(-1)).float().argmax(dim=-1)
+    want = torch.zeros_like(x).scatter_(-1, first.unsqueeze(-1), gy.unsqueeze(-1))
+    assert torch.equal(xa.grad, want)
+    assert xa.grad.sum().item() == pytest.approx(gy.sum().item(), rel=1e-5, abs=1e-4)
+    xn = x.clone()
+    xn.view(-1, shape[-1])[0, shape[-1] // 2] = float("nan")
+    assert torch.isnan(dense.row_max(xn).view(-1)[0]) and torch.isfinite(dense.row_max(xn).view(-1)[1:]).all()
