@@ -251,3 +251,16 @@ def test_deterministic_mode_makes_training_bit_reproducible(graph):
     assert h1 == h2, (h1, h2)
     diff = [k for k in w1 if not torch.equal(w1[k], w2[k])]
     assert not diff, (len(diff), diff[:5])
+
+
+def test_concurrent_stream_really_overlaps():
+    """_streams.concurrent_stream (round 6): the returned stream's work runs BESIDE the reference stream's -- a small kernel on it
+    finishes while a millisecond of work on the reference stream is still in flight (two HIP streams mapped to one hardware queue
+    would run it behind: what the first form of the alignment prefetch did)"""
+    from p2p_bridge_amd import _streams
+
+    ref = torch.cuda.current_stream()
+    side = _streams.concurrent_stream(ref)
+    assert side != ref
+    ok = sum(_streams.runs_beside(ref, side) for _ in range(5))
+    assert ok >= 4, ok
