@@ -35,7 +35,7 @@ extern "C" {
  * p2pb_set_split_terms_thread, p2pb_group_sub_stats*, p2pb_se_gate_*, p2pb_conv3d_k3_wgrad_occ*, the *_amax / *_adjoint packs).
  * A binding must compare p2pb_version() with the P2PB_ABI_VERSION it was written against and refuse a mismatch
  * (p2p_bridge_amd/_lib.py does): a stale library behind P2PB_LIB_PATH otherwise fails late, or silently differently. */
-#define P2PB_ABI_VERSION 6
+#define P2PB_ABI_VERSION 7
 
 /* library / device info --------------------------------------------------------------------- */
 int p2pb_version(void);            /* == P2PB_ABI_VERSION of the header the library was built from */
@@ -364,6 +364,28 @@ int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, c
                            const float *shift, const float *mean_rstd, const float *gamma, const float *beta,
                            const float *style, int style_stride, int swish, float *dx, float *dgamma, float *dbeta,
                            float *dstyle, float *ws, void *stream);
+/* The same with the layer's neighbours in a training step folded in (each used to be 1-3 elementwise launches per layer):
+ *   gmean f32[b,c] | NULL    gradient of the per-channel MEAN of the activation-free output (SE3d's squeeze input,
+ *                            models/modules.py:377-378, which the forward pass takes from p2pb_gn_affine_params_ex's chmean):
+ *                            gy_eff = gy + gmean / npos. Requires swish == 0 and drop_p == 0.
+ *   drop_p, seed, salt       nn.Dropout(drop_p) behind the Swish (models/pvcnn.py:268-272): the keep mask is a counter-based hash
+ *                            of (element index, seed[0], seed[1] read from DEVICE memory, salt); pass the forward pass's values.
+ *   residual, rgate          the forward pass added residual f32[b,c,npos] * rgate f32[b,c] (PVConv: devoxelised grid * SE gate,
+ *                            models/pvcnn.py:322-326): dres f32[b,c,npos] = gy * rgate, drgate f32[b,c] = sum_p gy * residual.
+ *                            All four or none (a residual without a gate needs no kernel: its gradient is gy).
+ * Everything NULL / 0 = p2pb_norm_act_backward (same bits). */
+int p2pb_norm_act_backward_ex(int b, int c, int groups, int npos, const float *x, const float *gy, const float *scale,
+                              const float *shift, const float *mean_rstd, const float *gamma, const float *beta,
+                              const float *style, int style_stride, int swish, const float *gmean, const float *residual,
+                              const float *rgate, float drop_p, const unsigned *seed, unsigned salt, float *dx, float *dgamma,
+                              float *dbeta, float *dstyle, float *dres, float *drgate, float *ws, void *stream);
+/* Forward of the folded norm in train(): y = drop(act(x * scale[b,c] + shift[b,c])) + residual * rgate[b,c]; residual, rgate
+ * NULL = none (rgate alone is ignored), drop_p == 0 = no dropout (then p2pb_affine_act's bits). seed: two 32-bit words in
+ * DEVICE memory (drawn once per forward pass by the host framework's generator, so that a captured step replays with fresh
+ * masks), salt: a per-layer constant. */
+int p2pb_affine_act_train(int b, int c, int npos, const float *x, const float *scale, const float *shift, int swish,
+                          const float *residual, const float *rgate, float drop_p, const unsigned *seed, unsigned salt,
+                          float *y, void *stream);
 /* SE3d gate (models/modules.py:362-378) folded into the devoxelisation affine: gate = sigmoid(w2 relu(w1 chmean)),
  * aff_a = scale*gate, aff_b = shift*gate. w1 f32[hidden,c], w2 f32[c,hidden] (nn.Linear layouts, no bias). */
 int p2pb_se_gate_affine(int b, int c, int hidden, const float *chmean, const float *w1, const float *w2,

@@ -17,12 +17,50 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sigmoid_exact(float v) { return 1.0f / (1.0f + expf(-v)); }
+// the FORWARD Swish of the library (pointwise.hip swishf: hardware exp2 / reciprocal; the same bits as p2pb_affine_act)
+__device__ __forceinline__ float na_swishf(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
 
 // gu = gy * d act(u) / du
 __device__ __forceinline__ float act_grad(float u, float gy, int swish) {
   if (!swish) return gy;
   const float s = sigmoid_exact(u);
   return gy * (s * (1.0f + u * (1.0f - s)));
+}
+
+// ---- what the training step folds into the norm's launches (round 6: every line below used to be 1-3 ATen launches per layer) ----
+//   gmean   f32[b,c] | NULL : gradient of the row MEAN of the (activation-free) output, SE3d's squeeze input, which the forward pass
+//                             takes from the statistics (p2pb_gn_affine_params_ex chmean): gy_eff = gy + gmean[b,c] / P
+//   dropout (thresh != 0)   : y = act(u) * m, m = 1/(1-p) with probability 1-p, else 0 (nn.Dropout after the Swish,
+//                             models/pvcnn.py:268-272). m is a counter-based hash of (element index, seed[0..1] from DEVICE memory,
+//                             layer salt): the backward pass regenerates it, a captured step replays with fresh seeds (the seed
+//                             tensor is drawn by torch's graph-safe generator once per forward pass)
+//   residual (+ rgate)      : y += residual * rgate[b,c] (PVConv: point branch + devoxelised grid * SE gate, models/pvcnn.py:322-326
+//                             with the gate moved behind the linear devoxelisation); backward: dres = gy * rgate, drgate = sum_p gy res
+struct NaExtra {
+  const float *gmean, *residual, *rgate;
+  float *dres, *drgate;
+  const unsigned *seed;
+  unsigned salt, thresh;
+  float keep_scale;
+};
+__device__ __forceinline__ unsigned na_hash(unsigned long long idx, unsigned k0, unsigned k1) {
+  unsigned h = (unsigned)idx + (unsigned)(idx >> 32) * 0x85ebca6bu + k0;
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h ^= h >> 15;
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  h += k1;
+  h ^= h >> 15;
+  h *= 0x2c1b3c6du;
+  h ^= h >> 12;
+  return h;
+}
+// the dropout factor of element idx: keep_scale or 0
+__device__ __forceinline__ float na_keep(unsigned long long idx, unsigned k0, unsigned k1, unsigned thresh, float keep_scale) {
+  return na_hash(idx, k0, k1) >= thresh ? keep_scale : 0.0f;
 }
 
 __device__ __forceinline__ double block_sum_256(double v, double *sm) {
@@ -38,24 +76,36 @@ __device__ __forceinline__ double block_sum_256(double v, double *sm) {
   return r;
 }
 
-// one workgroup per row (b,c): rows[bc] = {S1, S2}
+// one workgroup per row (b,c): rows[bc] = {S1, S2}; ex.drgate[bc] = sum_p gy res
 __global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *__restrict__ x,
                                                             const float *__restrict__ gy,
                                                             const float *__restrict__ scale,
                                                             const float *__restrict__ shift, int swish,
-                                                            float *__restrict__ rows) {
+                                                            float *__restrict__ rows, NaExtra ex) {
   __shared__ double sm[256];
   const int bc = blockIdx.x, t = threadIdx.x;
   const float sc = scale[bc], sh = shift[bc];
   const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
-  float s1 = 0.0f, s2 = 0.0f;
+  const float *rr = ex.drgate ? ex.residual + (size_t)bc * P : nullptr;
+  const float gm = ex.gmean ? ex.gmean[bc] / (float)P : 0.0f;
+  const unsigned k0 = ex.thresh ? ex.seed[0] ^ (ex.salt * 0x9e3779b9u) : 0u, k1 = ex.thresh ? ex.seed[1] : 0u;
+  const unsigned long long e0 = (unsigned long long)bc * (unsigned)P;
+  float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
   if ((P & 3) == 0) {
-    const f32x4 *x4 = (const f32x4 *)xr, *g4 = (const f32x4 *)gr;
+    const f32x4 *x4 = (const f32x4 *)xr, *g4 = (const f32x4 *)gr, *r4 = (const f32x4 *)rr;
     for (int p = t; p < P / 4; p += 256) {
       const f32x4 xv = x4[p], gv = g4[p];
+      if (rr) {
+        const f32x4 rv = r4[p];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s3 += gv[i] * rv[i];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float gu = act_grad(xv[i] * sc + sh, gv[i], swish);
+        float g = gv[i];
+        if (ex.gmean) g += gm;
+        if (ex.thresh) g *= na_keep(e0 + 4 * p + i, k0, k1, ex.thresh, ex.keep_scale);
+        const float gu = act_grad(xv[i] * sc + sh, g, swish);
         s1 += gu;
         s2 += gu * xv[i];
       }
@@ -63,7 +113,11 @@ __global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *
   } else {
     for (int p = t; p < P; p += 256) {
       const float xv = xr[p];
-      const float gu = act_grad(xv * sc + sh, gr[p], swish);
+      float g = gr[p];
+      if (rr) s3 += g * rr[p];
+      if (ex.gmean) g += gm;
+      if (ex.thresh) g *= na_keep(e0 + p, k0, k1, ex.thresh, ex.keep_scale);
+      const float gu = act_grad(xv * sc + sh, g, swish);
       s1 += gu;
       s2 += gu * xv;
     }
@@ -72,6 +126,10 @@ __global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *
   if (t == 0) {
     rows[(size_t)bc * 2] = (float)a;
     rows[(size_t)bc * 2 + 1] = (float)b2;
+  }
+  if (ex.drgate) {
+    const double c3 = block_sum_256((double)s3, sm);
+    if (t == 0) ex.drgate[bc] = (float)c3;
   }
 }
 
@@ -91,7 +149,7 @@ __global__ __launch_bounds__(256) void na_bwd_apply_kernel(int nb, int c, int gr
                                                            const float *__restrict__ beta,
                                                            const float *__restrict__ style, int style_stride,
                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                           float *__restrict__ dstyle, float *__restrict__ dx) {
+                                                           float *__restrict__ dstyle, float *__restrict__ dx, NaExtra ex) {
   __shared__ double w1[256], w2[256];
   __shared__ float cf[2];
   const int bc = blockIdx.y, b = bc / c, ch = bc % c, cg = c / groups, g = ch / cg, t = threadIdx.x;
@@ -143,22 +201,71 @@ __global__ __launch_bounds__(256) void na_bwd_apply_kernel(int nb, int c, int gr
   const float c2 = cf[0], c3 = cf[1];
   const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
   float *dr = dx + (size_t)bc * P;
+  float *er = ex.dres ? ex.dres + (size_t)bc * P : nullptr;
+  const float rg = (ex.dres && ex.rgate) ? ex.rgate[bc] : 1.0f;
+  const float gm = ex.gmean ? ex.gmean[bc] / (float)P : 0.0f;
+  const unsigned k0 = ex.thresh ? ex.seed[0] ^ (ex.salt * 0x9e3779b9u) : 0u, k1 = ex.thresh ? ex.seed[1] : 0u;
+  const unsigned long long e0 = (unsigned long long)bc * (unsigned)P;
   if ((P & 3) == 0) {
     const f32x4 *x4 = (const f32x4 *)xr, *g4 = (const f32x4 *)gr;
-    f32x4 *d4 = (f32x4 *)dr;
+    f32x4 *d4 = (f32x4 *)dr, *e4 = (f32x4 *)er;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < P / 4; p += gridDim.x * 256) {
       const f32x4 xv = x4[p], gv = g4[p];
       f32x4 o;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = act_grad(xv[i] * sc + sh, gv[i], swish) * sc + xv[i] * c2 + c3;
+      for (int i = 0; i < 4; ++i) {
+        float g = gv[i];
+        if (ex.gmean) g += gm;
+        if (ex.thresh) g *= na_keep(e0 + 4 * p + i, k0, k1, ex.thresh, ex.keep_scale);
+        o[i] = act_grad(xv[i] * sc + sh, g, swish) * sc + xv[i] * c2 + c3;
+      }
       d4[p] = o;
+      if (er) e4[p] = gv * rg;
     }
   } else {
     for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
       const float xv = xr[p];
-      dr[p] = act_grad(xv * sc + sh, gr[p], swish) * sc + xv * c2 + c3;
+      float g = gr[p];
+      if (er) er[p] = g * rg;
+      if (ex.gmean) g += gm;
+      if (ex.thresh) g *= na_keep(e0 + p, k0, k1, ex.thresh, ex.keep_scale);
+      dr[p] = act_grad(xv * sc + sh, g, swish) * sc + xv * c2 + c3;
     }
   }
+}
+
+static unsigned na_thresh(float drop_p) {
+  const double t = (double)drop_p * 4294967296.0;
+  return t <= 0.0 ? 0u : t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
+}
+
+// The same with the step's neighbours folded in (struct NaExtra above): gmean f32[b,c] | NULL (requires swish == 0 and no
+// dropout: it is the gradient of the mean of the activation-free output); residual f32[b,c,npos] + rgate f32[b,c] | NULL with
+// outputs dres f32[b,c,npos] (NULL without a gate: the residual's gradient is gy itself) and drgate f32[b,c]; dropout
+// 0 <= drop_p < 1 with seed = two 32-bit words in DEVICE memory and the layer's salt (the forward pass's values).
+extern "C" int p2pb_norm_act_backward_ex(int b, int c, int groups, int npos, const float *x, const float *gy,
+                                         const float *scale, const float *shift, const float *mean_rstd,
+                                         const float *gamma, const float *beta, const float *style, int style_stride,
+                                         int swish, const float *gmean, const float *residual, const float *rgate,
+                                         float drop_p, const unsigned *seed, unsigned salt, float *dx, float *dgamma,
+                                         float *dbeta, float *dstyle, float *dres, float *drgate, float *ws, void *stream) {
+  if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || c / groups > 256 || npos <= 0 || !x || !gy || !scale ||
+      !shift || !mean_rstd || !dx || !ws || (style && (!dstyle || style_stride < 2 * c)))
+    return P2PB_EINVAL;
+  if (!(drop_p >= 0.0f && drop_p < 1.0f) || (drop_p > 0.0f && !seed) || (gmean && (swish || drop_p > 0.0f)) ||
+      ((dres || drgate) && (!rgate || !residual || !dres || !drgate)))
+    return P2PB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float *rows = ws;
+  NaExtra ex = {};
+  ex.gmean = gmean, ex.residual = residual, ex.rgate = rgate, ex.dres = dres, ex.drgate = drgate, ex.seed = seed, ex.salt = salt;
+  ex.thresh = na_thresh(drop_p), ex.keep_scale = 1.0f / (1.0f - drop_p);
+  hipLaunchKernelGGL(na_bwd_reduce_kernel, dim3(b * c), dim3(256), 0, s, npos, x, gy, scale, shift, swish, rows, ex);
+  const int per = (npos & 3) == 0 ? npos / 4 : npos;
+  const unsigned gx = (unsigned)((per + 255) / 256 > 32 ? 32 : (per + 255) / 256);
+  hipLaunchKernelGGL(na_bwd_apply_kernel, dim3(gx, b * c), dim3(256), 0, s, b, c, groups, npos, x, gy, scale, shift, swish,
+                     rows, mean_rstd, gamma, beta, style, style_stride, dgamma, dbeta, dstyle, dx, ex);
+  return p2pb_launch_status();
 }
 
 // x, gy f32[b,c,npos]; scale, shift f32[b,c] and mean_rstd f32[b,groups,2] from p2pb_gn_affine_params_ex; gamma, beta
@@ -169,16 +276,59 @@ extern "C" int p2pb_norm_act_backward(int b, int c, int groups, int npos, const 
                                       const float *gamma, const float *beta, const float *style, int style_stride,
                                       int swish, float *dx, float *dgamma, float *dbeta, float *dstyle, float *ws,
                                       void *stream) {
-  if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || c / groups > 256 || npos <= 0 || !x || !gy || !scale ||
-      !shift || !mean_rstd || !dx || !ws || (style && (!dstyle || style_stride < 2 * c)))
+  return p2pb_norm_act_backward_ex(b, c, groups, npos, x, gy, scale, shift, mean_rstd, gamma, beta, style, style_stride, swish,
+                                   nullptr, nullptr, nullptr, 0.0f, nullptr, 0u, dx, dgamma, dbeta, dstyle, nullptr, nullptr, ws,
+                                   stream);
+}
+
+// y = drop(act(x * scale[b,c] + shift[b,c])) + residual * rgate[b,c]: the forward pass of the folded norm in train() with the same
+// neighbours folded in (p2pb_affine_act is the plain form). residual / rgate may be NULL (rgate alone is ignored).
+template <int V>
+static __global__ __launch_bounds__(256) void affine_act_train_kernel(int P, const float *__restrict__ x,
+                                                                      const float *__restrict__ scale,
+                                                                      const float *__restrict__ shift, int swish,
+                                                                      float *__restrict__ y, NaExtra ex) {
+  typedef float vec __attribute__((ext_vector_type(V)));
+  const int bc = blockIdx.y;
+  const float sc = scale[bc], sh = shift[bc];
+  const vec *xr = (const vec *)(x + (size_t)bc * P);
+  const vec *rr = ex.residual ? (const vec *)(ex.residual + (size_t)bc * P) : nullptr;
+  vec *yr = (vec *)(y + (size_t)bc * P);
+  const float rg = ex.rgate ? ex.rgate[bc] : 1.0f;
+  const unsigned k0 = ex.thresh ? ex.seed[0] ^ (ex.salt * 0x9e3779b9u) : 0u, k1 = ex.thresh ? ex.seed[1] : 0u;
+  const unsigned long long e0 = (unsigned long long)bc * (unsigned)P;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < P / V; p += gridDim.x * 256) {
+    vec v = xr[p];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      float t = v[i] * sc + sh;
+      if (swish) t = na_swishf(t);
+      if (ex.thresh) t *= na_keep(e0 + (unsigned long long)V * p + i, k0, k1, ex.thresh, ex.keep_scale);
+      v[i] = t;
+    }
+    if (rr) v += rr[p] * rg;
+    yr[p] = v;
+  }
+}
+
+extern "C" int p2pb_affine_act_train(int b, int c, int npos, const float *x, const float *scale, const float *shift, int swish,
+                                     const float *residual, const float *rgate, float drop_p, const unsigned *seed,
+                                     unsigned salt, float *y, void *stream) {
+  if (b <= 0 || c <= 0 || npos <= 0 || !x || !scale || !shift || !y || !(drop_p >= 0.0f && drop_p < 1.0f) ||
+      (drop_p > 0.0f && !seed))
     return P2PB_EINVAL;
+  NaExtra ex = {};
+  ex.residual = residual, ex.rgate = residual ? rgate : nullptr, ex.seed = seed, ex.salt = salt;
+  ex.thresh = na_thresh(drop_p), ex.keep_scale = 1.0f / (1.0f - drop_p);
   hipStream_t s = (hipStream_t)stream;
-  float *rows = ws;
-  hipLaunchKernelGGL(na_bwd_reduce_kernel, dim3(b * c), dim3(256), 0, s, npos, x, gy, scale, shift, swish, rows);
-  const int per = (npos & 3) == 0 ? npos / 4 : npos;
-  const unsigned gx = (unsigned)((per + 255) / 256 > 32 ? 32 : (per + 255) / 256);
-  hipLaunchKernelGGL(na_bwd_apply_kernel, dim3(gx, b * c), dim3(256), 0, s, b, c, groups, npos, x, gy, scale, shift, swish,
-                     rows, mean_rstd, gamma, beta, style, style_stride, dgamma, dbeta, dstyle, dx);
+  if (npos % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)residual) & 15) == 0) {
+    const int p4 = npos / 4;
+    const unsigned gx = (unsigned)((p4 + 255) / 256 > 64 ? 64 : (p4 + 255) / 256);
+    hipLaunchKernelGGL(affine_act_train_kernel<4>, dim3(gx, b * c), dim3(256), 0, s, npos, x, scale, shift, swish, y, ex);
+  } else {
+    const unsigned gx = (unsigned)((npos + 255) / 256 > 64 ? 64 : (npos + 255) / 256);
+    hipLaunchKernelGGL(affine_act_train_kernel<1>, dim3(gx, b * c), dim3(256), 0, s, npos, x, scale, shift, swish, y, ex);
+  }
   return p2pb_launch_status();
 }
 

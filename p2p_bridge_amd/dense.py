@@ -238,42 +238,77 @@ class _Pointwise(torch.autograd.Function):
 
 
 class _NormAct(torch.autograd.Function):
-    """y = act(GroupNorm(x) * gamma + beta [* factor + bias]) with the statistics the producing convolution emitted:
-    forward = gn_affine (fold to a per-(sample, channel) affine) + affine_act, backward = csrc/normact.hip (3 launches)"""
+    """(y, chmean) = (drop(act(GroupNorm(x) * gamma + beta [* factor + bias])) [+ residual * rgate], per-channel mean of the
+    activation-free output | empty) with the statistics the producing convolution emitted: forward = gn_affine (fold to a
+    per-(sample, channel) affine, also the mean) + one elementwise launch, backward = csrc/normact.hip (2 launches).
+    extras = (residual, rgate, drop, want_mean): what a training step used to run beside this layer as ATen launches --
+    nn.Dropout behind the Swish (drop = (p, seed int32[2] on the device, salt)), PVConv's `point branch + devoxelised grid
+    * SE gate`, SE3d's grid mean and its grid-sized gradient (want_mean; needs swish False, no dropout, no residual)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, style, stats, groups, eps, swish):
+    def forward(ctx, x, gamma, beta, style, stats, groups, eps, swish, residual=None, rgate=None, drop=None, want_mean=False):
         b, c = x.shape[:2]
         p = x.numel() // (b * c)
         x3 = x.reshape(b, c, p)
         if style is not None and (style.stride(1) != 1 or style.shape[1] != 2 * c):
             style = style.contiguous()
+        if want_mean and (swish or drop is not None or residual is not None):
+            raise RuntimeError("the folded channel mean is the mean of the activation-free, residual-free output")
         scale = torch.empty(b, c, dtype=F32, device=x.device)
         shift = torch.empty_like(scale)
         mr = torch.empty(b, groups, 2, dtype=F32, device=x.device)
+        chmean = torch.empty(b, c, dtype=F32, device=x.device) if want_mean else None
         call("p2pb_gn_affine_params_ex", _i(b), _i(c), _i(groups), _i(stats.shape[1]), ctypes.c_double(float(p)),
              ptr(stats), ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0),
-             ctypes.c_float(eps), ptr(scale), ptr(shift), ptr(None), ptr(mr), stream_ptr())
-        y = fused.affine_act(x3, scale, shift, bool(swish), None)
-        ctx.save_for_backward(x3, scale, shift, mr, gamma, beta, style)
-        ctx.groups, ctx.swish = groups, bool(swish)
-        return y.view(x.shape)
+             ctypes.c_float(eps), ptr(scale), ptr(shift), ptr(chmean), ptr(mr), stream_ptr())
+        drop_p, seed, salt = drop if drop is not None else (0.0, None, 0)
+        ctx.res_shape = None
+        if residual is None and drop is None:
+            y = fused.affine_act(x3, scale, shift, bool(swish), None)
+        else:
+            ctx.res_shape = None if residual is None else residual.shape
+            if residual is not None:
+                residual = residual.reshape(b, c, p).contiguous()
+                rgate = rgate.reshape(b, c).contiguous() if rgate is not None else None
+            y = torch.empty_like(x3)
+            call("p2pb_affine_act_train", _i(b), _i(c), _i(p), ptr(x3), ptr(scale), ptr(shift), _i(int(bool(swish))), ptr(residual),
+                 ptr(rgate), ctypes.c_float(drop_p), ptr(seed), ctypes.c_uint(salt), ptr(y), stream_ptr())
+        ctx.save_for_backward(x3, scale, shift, mr, gamma, beta, style, residual if rgate is not None else None, rgate, seed)
+        ctx.groups, ctx.swish, ctx.drop_p, ctx.salt, ctx.has_res = groups, bool(swish), float(drop_p), int(salt), residual is not None
+        ctx.x_shape = x.shape
+        ctx.set_materialize_grads(False)
+        if chmean is None:
+            chmean = _empty(x)
+            ctx.mark_non_differentiable(chmean)
+        return y.view(x.shape), chmean
 
     @staticmethod
-    def backward(ctx, gy):
-        x3, scale, shift, mr, gamma, beta, style = ctx.saved_tensors
+    def backward(ctx, gy, gmean=None):
+        x3, scale, shift, mr, gamma, beta, style, residual, rgate, seed = ctx.saved_tensors
         b, c, p = x3.shape
         groups = ctx.groups
+        if gy is None:  # (only the mean was used)
+            gy = torch.zeros_like(x3)
         gy = gy.contiguous()
         dx = torch.empty_like(x3)
         dgamma = torch.empty_like(gamma) if gamma is not None else None
         dbeta = torch.empty_like(beta) if beta is not None else None
         dstyle = torch.empty(b, 2 * c, dtype=F32, device=x3.device) if style is not None else None
         ws = torch.empty(2 * b * c + 2 * b * groups, dtype=F32, device=x3.device)
-        call("p2pb_norm_act_backward", _i(b), _i(c), _i(groups), _i(p), ptr(x3), ptr(gy), ptr(scale), ptr(shift), ptr(mr),
+        dres = drgate = None
+        if rgate is not None:
+            dres, drgate = torch.empty_like(x3), torch.empty(b, c, dtype=F32, device=x3.device)
+        elif ctx.has_res:
+            dres = gy  # (an ungated residual: its gradient is gy itself)
+        if gmean is not None:
+            gmean = gmean.contiguous()
+        call("p2pb_norm_act_backward_ex", _i(b), _i(c), _i(groups), _i(p), ptr(x3), ptr(gy), ptr(scale), ptr(shift), ptr(mr),
              ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0), _i(int(ctx.swish)),
-             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dstyle), ptr(ws), stream_ptr())
-        return dx.view(gy.shape), dgamma, dbeta, dstyle, None, None, None, None
+             ptr(gmean), ptr(residual), ptr(rgate), ctypes.c_float(ctx.drop_p), ptr(seed), ctypes.c_uint(ctx.salt), ptr(dx),
+             ptr(dgamma), ptr(dbeta), ptr(dstyle), ptr(dres if rgate is not None else None), ptr(drgate), ptr(ws), stream_ptr())
+        if dres is not None:
+            dres = dres.view(ctx.res_shape)
+        return dx.view(ctx.x_shape), dgamma, dbeta, dstyle, None, None, None, None, dres, drgate, None, None
 
 
 class _SEGate(torch.autograd.Function):
@@ -378,18 +413,39 @@ def _group_norm_of(norm):
     return (norm, None) if isinstance(norm, torch.nn.GroupNorm) else None
 
 
-def conv_norm_act(x, conv, norm, cond=None, swish=True, occ=None):
+def fold_step_neighbours() -> bool:
+    """A/B key `train_fold` (default 1): Dropout, SE3d's grid mean and PVConv's gated residual sum run inside the folded norm's
+    launches; 0 = as separate torch operators (the round-5 step)"""
+    from . import _experiment
+
+    return bool(_experiment.get_int("train_fold", 1))
+
+
+def conv_norm_act(x, conv, norm, cond=None, swish=True, occ=None, residual=None, rgate=None, dropout=None, want_mean=False):
     """the reference's conv -> GroupNorm | AdaGN(cond) -> [Swish] triple (models/pvcnn.py:162-205, 265-283) for training:
-    HIP convolution (emitting the norm's statistics) + folded norm / activation with a 3-launch backward.
-    cond: the global embedding [B, ctx_dim] for AdaGN (its Linear `emd` stays a torch op: a plain [B, ctx] GEMM)."""
+    HIP convolution (emitting the norm's statistics) + folded norm / activation with a 2-launch backward.
+    cond: the global embedding [B, ctx_dim] for AdaGN (its Linear `emd` stays a torch op: a plain [B, ctx] GEMM).
+    The layer's neighbours in the reference's graph, folded into the same launches (`_NormAct`):
+      dropout = (p, seed, salt) | None   nn.Dropout(p) behind the Swish (seed: int32[2] device tensor, `dropout_seed`)
+      residual, rgate                    + residual [* rgate[B,C] broadcast over the positions]
+      want_mean                          -> (y, mean of y over the positions f32[B,C]) -- SE3d's squeeze input"""
     gn_emd = _group_norm_of(norm)
     is3d = isinstance(conv, torch.nn.Conv3d)
     ok = (enabled(x) and gn_emd is not None and gn_emd[0].num_channels == conv.out_channels
           and gn_emd[0].num_channels // gn_emd[0].num_groups <= 256 and (not is3d or x.shape[2] in (4, 8, 16, 32)))
-    if not ok:
-        y = conv3d_k3(x, conv, occ=occ) if is3d else pointwise(x, conv)
-        y = norm(y, cond) if (gn_emd is not None and gn_emd[1] is not None and cond is not None) else norm(y)
-        return y * torch.sigmoid(y) if swish else y
+    if not ok or not fold_step_neighbours() and (residual is not None or dropout is not None or want_mean):
+        if ok:
+            y = conv_norm_act(x, conv, norm, cond, swish, occ)
+        else:
+            y = conv3d_k3(x, conv, occ=occ) if is3d else pointwise(x, conv)
+            y = norm(y, cond) if (gn_emd is not None and gn_emd[1] is not None and cond is not None) else norm(y)
+            y = y * torch.sigmoid(y) if swish else y
+        if dropout is not None:
+            y = torch.nn.functional.dropout(y, dropout[0], True)
+        mean = y.reshape(y.shape[0], y.shape[1], -1).mean(-1) if want_mean else None
+        if residual is not None:
+            y = y + (residual if rgate is None else residual * rgate.reshape(rgate.shape[0], rgate.shape[1], *([1] * (y.dim() - 2))))
+        return (y, mean) if want_mean else y
     gn, emd = gn_emd
     y, st = conv3d_k3(x, conv, True, occ=occ) if is3d else pointwise(x, conv, True)
     style = None
@@ -397,4 +453,14 @@ def conv_norm_act(x, conv, norm, cond=None, swish=True, occ=None):
         if cond is None:
             raise RuntimeError("AdaGN needs the global embedding")
         style = cond.style(norm) if hasattr(cond, "style") else emd(cond)
-    return _NormAct.apply(y, gn.weight, gn.bias, style, st, gn.num_groups, gn.eps, swish)
+    if dropout is not None and (dropout[0] <= 0.0 or y.numel() >= 2 ** 40):
+        dropout = None
+    y, mean = _NormAct.apply(y, gn.weight, gn.bias, style, st, gn.num_groups, gn.eps, swish, residual, rgate, dropout, want_mean)
+    return (y, mean) if want_mean else y
+
+
+def dropout_seed(device):
+    """the dropout seed of ONE forward pass: int32[2] on the device, drawn from torch's generator (torch.manual_seed replays it;
+    inside a captured step torch's graph-safe generator state gives every replay a fresh pair). One launch per pass instead of
+    one mask kernel per Dropout module."""
+    return torch.randint(0, 2 ** 31 - 1, (2,), dtype=torch.int32, device=device)

@@ -194,17 +194,20 @@ class StyleBank:
         self.weight = self.bias = None
         self.slices = {}
 
-    def _refresh(self):
-        key = tuple((m.emd.weight.data_ptr(), m.emd.weight._version, m.emd.bias._version) for m in self.mods)
-        if key != self.key:
-            self.weight = torch.cat([m.emd.weight.detach() for m in self.mods], dim=0).contiguous()
-            self.bias = torch.cat([m.emd.bias.detach() for m in self.mods], dim=0).contiguous()
+    def _ensure_slices(self):
+        if not self.slices:  # (the column ranges only depend on the shapes)
             off = 0
-            self.slices = {}
             for m in self.mods:
                 n2 = m.emd.weight.shape[0]
                 self.slices[id(m)] = (off, off + n2)
                 off += n2
+
+    def _refresh(self):
+        self._ensure_slices()
+        key = tuple((m.emd.weight.data_ptr(), m.emd.weight._version, m.emd.bias._version) for m in self.mods)
+        if key != self.key:
+            self.weight = torch.cat([m.emd.weight.detach() for m in self.mods], dim=0).contiguous()
+            self.bias = torch.cat([m.emd.bias.detach() for m in self.mods], dim=0).contiguous()
             self.key = key
 
     def evaluate(self, cond):
@@ -219,8 +222,8 @@ class StyleBank:
         decoder_ids (the segmented backward, PVCNN2Unet.collect_cut): TWO products, the decoder's AdaGNs on an alias of the
         embedding -- the weight gradients of the decoder's style Linears are then complete when the decoder's backward is
         (train.segmented_backward ships them with the first all-reduce); the alias joins the cut (_Styles.cut)."""
-        self._refresh()  # (slices only depend on the shapes)
-        parts, cut = {}, []
+        self._ensure_slices()  # (NOT _refresh: the inference table would be re-concatenated every step -- the optimiser
+        parts, cut = {}, []    #  bumps every weight's version --, 2 x 54 MB of copies per config-3 step that nobody reads)
         groups = [(self.mods, cond)]
         if decoder_ids:
             alias = cond.view_as(cond) if cond.requires_grad else cond
@@ -327,20 +330,27 @@ class SharedMLP(nn.Module):
             in_channels = oc
         self.layers = nn.ModuleList(mods)
 
-    def run(self, x, cond, reduce_max=False, residual=None):
+    def run(self, x, cond, reduce_max=False, residual=None, rgate=None, dropout=None):
         """the chain on x[B,C,...]; reduce_max: max over the last axis afterwards (set abstraction);
-        residual: tensor added to the result (PVConv's voxel branch)"""
+        residual: tensor added to the result (PVConv's voxel branch), training: times rgate[B,C] (its SE gate);
+        dropout (training): (p, seed, salt) of an nn.Dropout that FOLLOWS the chain (the classifier's), dense.conv_norm_act"""
         from . import fused
 
         if fused.enabled(self, x):
             return self._run_fused(x, cond, reduce_max, residual)
         from . import dense
 
-        for i in range(len(self.layers) // 3):  # training: HIP conv + folded norm / Swish, forward and backward
-            x = dense.conv_norm_act(x, self.layers[3 * i], self.layers[3 * i + 1], cond, swish=True)
+        n = len(self.layers) // 3
+        fold = residual is not None and not reduce_max and n > 0  # (PVConv: + voxel branch [* SE gate] inside the last norm's launches)
+        for i in range(n):  # training: HIP conv + folded norm / Swish, forward and backward
+            last = fold and i == n - 1
+            x = dense.conv_norm_act(x, self.layers[3 * i], self.layers[3 * i + 1], cond, swish=True,
+                                    residual=residual if last else None, rgate=rgate if last else None, dropout=dropout if i == n - 1 else None)
         if reduce_max:
             x = dense.row_max(x)  # (csrc/normact.hip: one launch forward, one backward)
-        return x if residual is None else residual + x
+        if residual is None or fold:
+            return x
+        return (residual if rgate is None else residual * rgate.unsqueeze(-1)) + x
 
     def _run_fused(self, x, cond, reduce_max, residual, first=None):
         """inference: every norm+Swish is folded into the next kernel's operand load (fused.py).
@@ -418,6 +428,9 @@ class PVConv(nn.Module):
         self.sparse_conv = True  # inference: exact sparse convolution for r >= 16 (fused._voxel_branch_fused)
         self.level = -1  # set by PVCNN2Unet: index of the coordinate level this block works on (Geometry.take_voxel)
         self.point_features = SharedMLP(in_channels, out_channels, gn_groups=gn_groups, cond_dim=cond_dim)
+        # set by PVCNN2Unet: the per-pass state it shares with its blocks ({"drop_seed": int32[2] | None}) and this block's
+        # dropout salt; standalone (None) the block's Dropout stays torch's
+        self._pass, self.drop_salt = None, 0
 
     def _voxel_branch_fused(self, features, coords, cond, point=None, geo=None):
         """inference: voxelize -> conv -> [AdaGN,Swish folded] -> conv -> [AdaGN,SE folded] -> devoxelize; grid
@@ -517,19 +530,31 @@ class PVConv(nn.Module):
 
             v, vcoords = self.voxelization(features, coords)
             vl = self.voxel_layers  # conv, norm, Swish, Dropout, conv, norm[, SE3d]: HIP forward + backward (dense.py)
+            # Dropout runs inside the first norm's launches (dense._NormAct) when the network drew a seed for this pass
+            seed = self._pass.get("drop_seed") if (self._pass is not None and self.training and vl[3].p > 0 and v.is_cuda) else None
             # (the grid's occupancy goes to the first convolution EXPLICITLY: its weight gradient runs over the occupied voxels)
-            v = vl[3](dense.conv_norm_act(v, vl[0], vl[1], cond, swish=True, occ=L.occupancy_of(v)))
-            v = dense.conv_norm_act(v, vl[4], vl[5], cond, swish=False)
+            v = dense.conv_norm_act(v, vl[0], vl[1], cond, swish=True, occ=L.occupancy_of(v),
+                                    dropout=None if seed is None else (float(vl[3].p), seed, self.drop_salt))
+            if seed is None:
+                v = vl[3](v)
             if len(vl) > 6 and v.is_cuda:
                 # the squeeze-excite gate is a per-(sample, channel) factor and the devoxelisation is linear in the grid: gate the
                 # N points instead of the r^3 voxels (what the fused inference branch does through devoxelize_affine). Forward
                 # and backward lose their grid-sized multiplies and the grid-sized reduction of d gate (round 5: ~0.4 ms of a
-                # config-3 step in ATen elementwise kernels); the values differ from gating the grid by fp32 rounding only
-                fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training) * vl[6].gate(v).unsqueeze(-1)
-            else:
-                if len(vl) > 6:
-                    v = vl[6](v)
-                fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
+                # config-3 step in ATen elementwise kernels); the values differ from gating the grid by fp32 rounding only.
+                # Round 6: the grid mean comes from the convolution's statistics and its gradient goes into the norm's backward
+                # (no grid-sized mean / div / add), the gate and the sum with the point branch into the point branch's last norm
+                v, vmean = dense.conv_norm_act(v, vl[4], vl[5], cond, swish=False, want_mean=True)
+                gate = dense.se_gate(vmean, vl[6].fc)
+                dv = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
+                data.features = self.point_features.run(features, cond, residual=dv, rgate=gate)
+                if self.attn is not None:  # models/pvcnn.py:327-328
+                    data.features = self.attn(data.features)
+                return data
+            v = dense.conv_norm_act(v, vl[4], vl[5], cond, swish=False)
+            if len(vl) > 6:
+                v = vl[6](v)
+            fused = L.trilinear_devoxelize(v, vcoords, self.resolution, self.training)
         data.features = self.point_features.run(features, cond, residual=fused)
         if self.attn is not None:  # models/pvcnn.py:327-328
             data.features = self.attn(data.features)
@@ -1012,6 +1037,10 @@ class PVCNN2Unet(nn.Module):
         self.overlap_geometry = True  # inference: run FPS / ball query / 3-NN on a side stream (Geometry)
         self.collect_cut, self.cut = False, None  # training: train.segmented_backward's encoder | decoder boundary
         self._dec_adagn = None
+        # training: ONE dropout seed per forward pass, shared with the blocks (dense.dropout_seed); salts number the Dropouts
+        self._pass = {"drop_seed": None}
+        for k, m in enumerate(m for m in self.modules() if isinstance(m, PVConv)):
+            m._pass, m.drop_salt = self._pass, k + 1
 
     def get_timestep_embedding(self, timesteps, device=None):
         if timesteps.dim() == 2 and timesteps.shape[1] == 1:
@@ -1067,6 +1096,12 @@ class PVCNN2Unet(nn.Module):
             else:
                 cond = self._style_bank.evaluate_train(cond, self._decoder_adagns() if self.collect_cut else None)
         feats = torch.cat([coords, feats], dim=1)
+        self._pass["drop_seed"] = None
+        if not use_fused and self.training and x.is_cuda and self.classifier[1].p > 0:
+            from . import dense
+
+            if dense.fold_step_neighbours():
+                self._pass["drop_seed"] = dense.dropout_seed(x.device)
         time_emb = None
         if t is not None:
             if t.dim() == 0:
@@ -1134,5 +1169,9 @@ class PVCNN2Unet(nn.Module):
             return fused.pw_conv(h, self.classifier[2], sc, sh, swish=True, stats=False)[0]
         from . import dense
 
-        h = self.classifier[0].run(data.features, None)
-        return dense.pointwise(self.classifier[1](h), self.classifier[2])
+        seed = self._pass["drop_seed"]
+        if seed is not None:  # the classifier's Dropout inside its SharedMLP's last norm
+            h = self.classifier[0].run(data.features, None, dropout=(float(self.classifier[1].p), seed, 0))
+        else:
+            h = self.classifier[1](self.classifier[0].run(data.features, None))
+        return dense.pointwise(h, self.classifier[2])

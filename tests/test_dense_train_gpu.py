@@ -344,3 +344,179 @@ def test_row_max_forward_backward(shape):
     xn = x.clone()
     xn.view(-1, shape[-1])[0, shape[-1] // 2] = float("nan")
     assert torch.isnan(dense.row_max(xn).view(-1)[0]) and torch.isfinite(dense.row_max(xn).view(-1)[1:]).all()
+
+
+def _fold_case(kind, b, ci, co, shape):
+    from p2p_bridge_amd.pvcnn_unet import AdaGN
+
+    conv = {"3d": nn.Conv3d(ci, co, 3, padding=1), "1d": nn.Conv1d(ci, co, 1)}[kind[-2:]].cuda()
+    if kind.startswith("adagn"):
+        norm = AdaGN(co, 48, len(shape), 8).cuda()
+        cond = torch.randn(b, 48, device="cuda", requires_grad=True)
+    else:
+        norm, cond = nn.GroupNorm(8, co).cuda(), None
+    gn = norm.norm if isinstance(norm, AdaGN) else norm
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.normal_()
+    x = torch.randn(b, ci, *shape, device="cuda", requires_grad=True)
+    return conv, norm, gn, cond, x
+
+
+def _fp64_chain(kind, conv, norm, gn, cond, x, swish, shape):
+    """fp64 leaves + the conv -> norm -> [Swish] value on the CPU"""
+    from p2p_bridge_amd.pvcnn_unet import AdaGN
+
+    d = lambda t: t.detach().double().cpu().requires_grad_(True)  # noqa: E731
+    leaves = {"x": d(x), "w": d(conv.weight), "cb": d(conv.bias), "gamma": d(gn.weight), "beta": d(gn.bias)}
+    h = F.conv3d(leaves["x"], leaves["w"], leaves["cb"], padding=1) if kind.endswith("3d") else F.conv1d(leaves["x"], leaves["w"], leaves["cb"])
+    h = F.group_norm(h, gn.num_groups, leaves["gamma"], leaves["beta"], gn.eps)
+    if isinstance(norm, AdaGN):
+        leaves.update(cond=d(cond), ew=d(norm.emd.weight), eb=d(norm.emd.bias))
+        fac, bia = F.linear(leaves["cond"], leaves["ew"], leaves["eb"]).reshape(x.shape[0], -1, *([1] * len(shape))).chunk(2, 1)
+        h = h * fac + bia
+    return leaves, (h * torch.sigmoid(h) if swish else h)
+
+
+def _got(conv, norm, gn, cond, x):
+    from p2p_bridge_amd.pvcnn_unet import AdaGN
+
+    got = {"x": x.grad, "w": conv.weight.grad, "gamma": gn.weight.grad, "beta": gn.bias.grad}
+    if isinstance(norm, AdaGN):
+        got.update(cond=cond.grad, ew=norm.emd.weight.grad, eb=norm.emd.bias.grad)
+    return got
+
+
+@pytest.mark.parametrize("kind,b,ci,co,shape,gated", [("adagn1d", 2, 32, 64, (2048,), True), ("gn1d", 3, 35, 32, (333,), True),
+                                                      ("adagn1d", 2, 16, 128, (512,), False), ("adagn3d", 2, 8, 16, (8, 8, 8), True)])
+def test_folded_residual_and_gate(kind, b, ci, co, shape, gated):
+    """y = Swish(norm(conv x)) + residual [* rgate] inside the folded norm's launches (PVConv: point branch + devoxelised grid *
+    SE gate) vs fp64 autograd of the same expression: value and every gradient, the residual's and the gate's included"""
+    from p2p_bridge_amd import dense
+
+    torch.manual_seed(co + len(shape))
+    conv, norm, gn, cond, x = _fold_case(kind, b, ci, co, shape)
+    res = torch.randn(b, co, *shape, device="cuda", requires_grad=True)
+    gate = torch.rand(b, co, device="cuda", requires_grad=True) if gated else None
+    y = dense.conv_norm_act(x, conv, norm, cond, True, residual=res, rgate=gate)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = _got(conv, norm, gn, cond, x)
+    got["res"] = res.grad
+    leaves, h = _fp64_chain(kind, conv, norm, gn, cond, x, True, shape)
+    leaves["res"] = res.detach().double().cpu().requires_grad_(True)
+    r = leaves["res"]
+    if gated:
+        got["gate"] = gate.grad
+        leaves["gate"] = gate.detach().double().cpu().requires_grad_(True)
+        r = r * leaves["gate"].reshape(b, co, *([1] * len(shape)))
+    y64 = h + r
+    y64.backward(gy.double().cpu())
+    assert _rel(y.detach(), y64.detach()) < 1e-5
+    for k, v in leaves.items():
+        if k == "cb":
+            continue
+        assert _rel(got[k], v.grad) < (2e-4 if k == "w" else 5e-5), (k, _rel(got[k], v.grad))
+
+
+@pytest.mark.parametrize("kind,b,ci,co,shape", [("adagn3d", 2, 16, 64, (8, 8, 8)), ("adagn3d", 3, 8, 32, (16, 16, 16)), ("gn1d", 2, 24, 40, (300,))])
+def test_folded_channel_mean(kind, b, ci, co, shape):
+    """(y, mean of y over the positions) from ONE pass -- the mean out of the convolution's statistics, its gradient folded into the
+    norm's backward (SE3d's squeeze without a grid-sized mean / div / add) -- vs fp64 autograd of y and y.mean over the grid"""
+    from p2p_bridge_amd import dense
+
+    torch.manual_seed(co)
+    conv, norm, gn, cond, x = _fold_case(kind, b, ci, co, shape)
+    y, m = dense.conv_norm_act(x, conv, norm, cond, False, want_mean=True)
+    assert m.shape == (b, co)
+    gy, gm = torch.randn_like(y), torch.randn_like(m) * 30
+    torch.autograd.backward([y, m], [gy, gm])
+    got = _got(conv, norm, gn, cond, x)
+    leaves, h = _fp64_chain(kind, conv, norm, gn, cond, x, False, shape)
+    m64 = h.reshape(b, co, -1).mean(-1)
+    torch.autograd.backward([h, m64], [gy.double().cpu(), gm.double().cpu()])
+    assert _rel(y.detach(), h.detach()) < 1e-5 and (m.detach().double().cpu() - m64.detach()).abs().max().item() < 2e-6
+    for k, v in leaves.items():
+        if k == "cb":
+            continue
+        assert _rel(got[k], v.grad) < (2e-4 if k == "w" else 5e-5), (k, _rel(got[k], v.grad))
+    # only the mean is used (no gradient reaches y)
+    for t in (x, conv.weight, gn.weight):
+        t.grad = None
+    y2, m2 = dense.conv_norm_act(x, conv, norm, cond, False, want_mean=True)
+    m2.backward(gm)
+    leaves2, h2 = _fp64_chain(kind, conv, norm, gn, cond, x, False, shape)
+    h2.reshape(b, co, -1).mean(-1).backward(gm.double().cpu())
+    assert _rel(x.grad, leaves2["x"].grad) < 5e-5
+
+
+@pytest.mark.parametrize("kind,b,ci,co,shape,p", [("adagn3d", 2, 8, 32, (16, 16, 16), 0.1), ("gn1d", 2, 64, 128, (2048,), 0.15),
+                                                  ("adagn3d", 2, 8, 16, (8, 8, 8), 0.5), ("gn1d", 2, 24, 40, (333,), 0.1)])
+def test_folded_dropout(kind, b, ci, co, shape, p):
+    """nn.Dropout(p) behind the Swish inside the folded norm's launches: every element is 0 or the undropped value / (1 - p), the
+    kept fraction is 1 - p to 4 sigma, the backward pass regenerates the same mask (every gradient equals fp64 autograd of the
+    chain with the mask read off the forward pass), the same (seed, salt) replays the mask, another seed / salt draws another"""
+    from p2p_bridge_amd import dense
+
+    torch.manual_seed(co)
+    conv, norm, gn, cond, x = _fold_case(kind, b, ci, co, shape)
+    seed = dense.dropout_seed(x.device)
+    plain = dense.conv_norm_act(x, conv, norm, cond, True).detach()
+    y = dense.conv_norm_act(x, conv, norm, cond, True, dropout=(p, seed, 3))
+    keep = y.detach() != 0
+    scale = torch.tensor(1.0, device="cuda") / (1.0 - torch.tensor(p, dtype=torch.float32, device="cuda"))
+    assert torch.equal(y.detach()[keep], (plain * scale)[keep])
+    dropped = ~keep & (plain != 0)
+    n = y.numel()
+    assert abs(dropped.sum().item() / n - p) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-6
+    # per-row fractions too (a hash that only mixed the low index bits would pass the global count)
+    rows = dropped.reshape(b * co, -1).float().mean(1)
+    assert (rows - p).abs().max().item() < 6 * (p * (1 - p) / rows.numel() ** 0 / dropped[0, 0].numel()) ** 0.5 + 1e-6
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = _got(conv, norm, gn, cond, x)
+    leaves, h = _fp64_chain(kind, conv, norm, gn, cond, x, True, shape)
+    (h * (~dropped).double().cpu() * float(scale)).backward(gy.double().cpu())
+    for k, v in leaves.items():
+        if k == "cb":
+            continue
+        assert _rel(got[k], v.grad) < (2e-4 if k == "w" else 5e-5), (k, _rel(got[k], v.grad))
+    again = dense.conv_norm_act(x, conv, norm, cond, True, dropout=(p, seed, 3)).detach()
+    assert torch.equal(again, y.detach())
+    other_salt = dense.conv_norm_act(x, conv, norm, cond, True, dropout=(p, seed, 4)).detach()
+    other_seed = dense.conv_norm_act(x, conv, norm, cond, True, dropout=(p, dense.dropout_seed(x.device), 3)).detach()
+    for o in (other_salt, other_seed):
+        both = ((o == 0) & dropped).sum().item() / n  # independent masks: P(both dropped) = p^2
+        assert abs(both - p * p) < 5 * (p * p * (1 - p * p) / n) ** 0.5 + 1e-6
+
+
+def test_dropout_seed_follows_the_generator_and_replays_fresh_in_a_graph():
+    from p2p_bridge_amd import dense
+
+    torch.manual_seed(5)
+    a = dense.dropout_seed("cuda")
+    torch.manual_seed(5)
+    assert torch.equal(a, dense.dropout_seed("cuda")) and not torch.equal(a, dense.dropout_seed("cuda"))
+    torch.manual_seed(1)
+    conv, norm, gn, cond, x = _fold_case("gn1d", 2, 16, 32, (256,))
+    x = x.detach()
+    out = torch.empty(2, 32, 256, device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        for _ in range(2):
+            out.copy_(dense._NormAct.apply(*_norm_args(dense, conv, gn, x), True, None, None, (0.3, dense.dropout_seed("cuda"), 1), False)[0])
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        out.copy_(dense._NormAct.apply(*_norm_args(dense, conv, gn, x), True, None, None, (0.3, dense.dropout_seed("cuda"), 1), False)[0])
+    g.replay()
+    m1 = out == 0
+    g.replay()
+    m2 = out == 0
+    assert 0.2 < m1.float().mean().item() < 0.4 and not torch.equal(m1, m2)
+
+
+def _norm_args(dense, conv, gn, x):
+    y, st = dense.pointwise(x, conv, True)
+    return y, gn.weight, gn.bias, None, st, gn.num_groups, gn.eps
