@@ -130,6 +130,10 @@ int p2pb_grouping_forward(int b, int c, int n, int m, int u, const float *feat, 
                           void *stream);
 int p2pb_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *idx,
                            float *grad_x, void *stream);
+/* the same with sample b of grad_y at grad_y + b * gy_pitch floats (gy_pitch >= c*m*u): a channel slice of a wider tensor -- one
+ * part of the gradient of a concatenation (models/pvcnn.py:126) -- is read in place (build addition; training) */
+int p2pb_grouping_backward_pitched(int b, int c, int n, int m, int u, const float *grad_y, long gy_pitch, const int *idx,
+                                   float *grad_x, void *stream);
 
 /* fused set-abstraction operand (BallQuery.forward, models/pvcnn.py:116-126, inference): out f32[b,3+c,m,u] =
  * [coords[:, idx] - centers (3 ch) | feat[:, idx] (c ch)] in one pass */
@@ -202,6 +206,9 @@ int p2pb_three_nn_cells(int b, int m, int n, const float *points, const float *c
                         void *stream);
 int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
                                        const float *w, float *grad_x, void *stream);
+/* (gy_pitch >= c*n: as p2pb_grouping_backward_pitched; the slice of models/pvcnn.py:219's concatenation) */
+int p2pb_three_nn_interpolate_backward_pitched(int b, int c, int n, int m, const float *grad_y, long gy_pitch, const int *idx,
+                                               const float *w, float *grad_x, void *stream);
 
 /* chamfer_3D: replaces chamfer_cuda_forward/backward (metrics/chamfer3D/chamfer3D.cu:135,176;
  * kernels :12,:155). xyz are POINT-major f32[b,n,3] / f32[b,m,3]. Lowest index wins distance ties.
@@ -373,11 +380,13 @@ int p2pb_norm_act_backward(int b, int c, int groups, int npos, const float *x, c
  *   residual, rgate          the forward pass added residual f32[b,c,npos] * rgate f32[b,c] (PVConv: devoxelised grid * SE gate,
  *                            models/pvcnn.py:322-326): dres f32[b,c,npos] = gy * rgate, drgate f32[b,c] = sum_p gy * residual.
  *                            All four or none (a residual without a gate needs no kernel: its gradient is gy).
+ *   gy_pitch                 floats between two samples of gy (0 = c * npos): a channel slice of a wider tensor -- one part of a
+ *                            concatenation's gradient -- is read in place instead of through a contiguous copy.
  * Everything NULL / 0 = p2pb_norm_act_backward (same bits). */
 int p2pb_norm_act_backward_ex(int b, int c, int groups, int npos, const float *x, const float *gy, const float *scale,
                               const float *shift, const float *mean_rstd, const float *gamma, const float *beta,
-                              const float *style, int style_stride, int swish, const float *gmean, const float *residual,
-                              const float *rgate, float drop_p, const unsigned *seed, unsigned salt, float *dx, float *dgamma,
+                              const float *style, int style_stride, int swish, long gy_pitch, const float *gmean,
+                              const float *residual, const float *rgate, float drop_p, const unsigned *seed, unsigned salt, float *dx, float *dgamma,
                               float *dbeta, float *dstyle, float *dres, float *drgate, float *ws, void *stream);
 /* Forward of the folded norm in train(): y = drop(act(x * scale[b,c] + shift[b,c])) + residual * rgate[b,c]; residual, rgate
  * NULL = none (rgate alone is ignored), drop_p == 0 = no dropout (then p2pb_affine_act's bits). seed: two 32-bit words in

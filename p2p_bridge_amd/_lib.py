@@ -29,7 +29,7 @@ SYMBOLS = [
     "p2pb_pointwise_stats_floats", "p2pb_pointwise_conv_forward", "p2pb_affine_act", "p2pb_affine_act_max",
     "p2pb_pointwise_split_packed_bytes", "p2pb_pointwise_pack_weights_split", "p2pb_pointwise_pool_supported", "p2pb_pointwise_minmax_floats", "p2pb_pointwise_conv_pool_forward",
     "p2pb_minmax_act", "p2pb_linear_attention_forward", "p2pb_linear_attention_backward",
-    "p2pb_approxmatch_temp_floats", "p2pb_approxmatch_forward_ws", "p2pb_pointwise_conv_pool_gather", "p2pb_chamfer_ws_bytes", "p2pb_chamfer_forward_ws", "p2pb_radius_count", "p2pb_radius_fill", "p2pb_merge_accumulate", "p2pb_merge_finish", "p2pb_gn_affine_params_ex", "p2pb_norm_act_backward", "p2pb_norm_act_backward_ex", "p2pb_affine_act_train", "p2pb_conv3d_k3_wgrad_ws_floats", "p2pb_conv3d_k3_wgrad", "p2pb_conv3d_k3_wgrad_occ_ws_floats", "p2pb_conv3d_k3_wgrad_occ", "p2pb_pointwise_wgrad_ws_floats", "p2pb_pointwise_wgrad",
+    "p2pb_approxmatch_temp_floats", "p2pb_approxmatch_forward_ws", "p2pb_pointwise_conv_pool_gather", "p2pb_chamfer_ws_bytes", "p2pb_chamfer_forward_ws", "p2pb_radius_count", "p2pb_radius_fill", "p2pb_merge_accumulate", "p2pb_merge_finish", "p2pb_gn_affine_params_ex", "p2pb_norm_act_backward", "p2pb_norm_act_backward_ex", "p2pb_grouping_backward_pitched", "p2pb_three_nn_interpolate_backward_pitched", "p2pb_affine_act_train", "p2pb_conv3d_k3_wgrad_ws_floats", "p2pb_conv3d_k3_wgrad", "p2pb_conv3d_k3_wgrad_occ_ws_floats", "p2pb_conv3d_k3_wgrad_occ", "p2pb_pointwise_wgrad_ws_floats", "p2pb_pointwise_wgrad",
     "p2pb_debug_pointwise_form", "p2pb_linear_rows", "p2pb_gn_finisher_arm", "p2pb_gn_finisher_armed", "p2pb_gn_finisher_disarm", "p2pb_fps_grid_ws_bytes", "p2pb_furthest_point_sampling_grid",
     "p2pb_optim_entry_bytes", "p2pb_optim_chunk", "p2pb_optim_clip_adam_step",
     "p2pb_conv3d_k3_pack_weights_split_adjoint", "p2pb_pointwise_pack_weights_adjoint", "p2pb_pointwise_pack_weights_split_adjoint",

@@ -364,25 +364,25 @@ extern "C" int p2pb_group_sub(int b, int c, int n, int m, int u, const float *z,
 }
 
 template <int CC>
-__global__ __launch_bounds__(256) void grouping_grad_kernel(int c, int n, int mu, const float *__restrict__ gy,
+__global__ __launch_bounds__(256) void grouping_grad_kernel(int c, int n, int mu, const float *__restrict__ gy, size_t gyp,
                                                             const int *__restrict__ idx, float *__restrict__ gx) {
   const int b = blockIdx.z;
   const int q = blockIdx.x * 256 + threadIdx.x;
   if (q >= mu) return;
   const int id = idx[(size_t)b * mu + q];
   const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
-  for (int l = c0; l < c1; ++l) atomicAdd(gx + ((size_t)b * c + l) * n + id, gy[((size_t)b * c + l) * mu + q]);
+  for (int l = c0; l < c1; ++l) atomicAdd(gx + ((size_t)b * c + l) * n + id, gy[(size_t)b * gyp + (size_t)l * mu + q]);
 }
 
 // rows of CH channels in LDS (common.h "scatter-add backward passes")
 template <int CH>
 __global__ __launch_bounds__(SCAT_THREADS) void grouping_grad_lds_kernel(int c, int n, int Lp, int mu, const float *__restrict__ gy,
-                                                                        const int *__restrict__ idx, float *__restrict__ gx) {
+                                                                        size_t gyp, const int *__restrict__ idx, float *__restrict__ gx) {
   extern __shared__ float rows[];
   const int b = blockIdx.y, c0 = blockIdx.x * CH, nch = min(CH, c - c0);
   scat_zero(rows, CH * Lp);
   const int *ib = idx + (size_t)b * mu;
-  const float *g0 = gy + ((size_t)b * c + c0) * mu;
+  const float *g0 = gy + (size_t)b * gyp + (size_t)c0 * mu;  // (gyp: floats between two samples of gy, >= c * mu)
   for (int q = threadIdx.x; q < mu; q += blockDim.x) {
     const int id = ib[q];
 #pragma unroll
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void grouping_grad_lds_kernel(int c, 
 }
 
 template <int CH>
-static int grouping_grad_lds_launch(int b, int c, int n, int mu, const float *gy, const int *idx, float *gx, hipStream_t s) {
+static int grouping_grad_lds_launch(int b, int c, int n, int mu, const float *gy, size_t gyp, const int *idx, float *gx, hipStream_t s) {
   const int Lp = (n + 3) & ~3;
   static bool once = false;
   if (!once) {
@@ -401,28 +401,35 @@ static int grouping_grad_lds_launch(int b, int c, int n, int mu, const float *gy
     once = true;
   }
   hipLaunchKernelGGL(grouping_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(scat_threads()), sizeof(float) * (size_t)CH * Lp, s, c, n,
-                     Lp, mu, gy, idx, gx);
+                     Lp, mu, gy, gyp, idx, gx);
   return p2pb_launch_status();
 }
 
-extern "C" int p2pb_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *idx,
-                                      float *grad_x, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0) return P2PB_EINVAL;
+// grad_y: sample b starts at grad_y + b * gy_pitch floats (gy_pitch >= c*m*u; a channel slice of a wider tensor, e.g. one part of
+// a concatenation's gradient, is read in place instead of through a contiguous copy)
+extern "C" int p2pb_grouping_backward_pitched(int b, int c, int n, int m, int u, const float *grad_y, long gy_pitch, const int *idx,
+                                              float *grad_x, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || u <= 0 || gy_pitch < (long)c * m * u) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const size_t gyp = (size_t)gy_pitch;
   switch (scat_rows(n, c, 8)) {
     case 0: break;
-    case 1: return grouping_grad_lds_launch<1>(b, c, n, m * u, grad_y, idx, grad_x, s);
-    case 2: case 3: return grouping_grad_lds_launch<2>(b, c, n, m * u, grad_y, idx, grad_x, s);
-    case 8: return grouping_grad_lds_launch<8>(b, c, n, m * u, grad_y, idx, grad_x, s);
-    default: return grouping_grad_lds_launch<4>(b, c, n, m * u, grad_y, idx, grad_x, s);
+    case 1: return grouping_grad_lds_launch<1>(b, c, n, m * u, grad_y, gyp, idx, grad_x, s);
+    case 2: case 3: return grouping_grad_lds_launch<2>(b, c, n, m * u, grad_y, gyp, idx, grad_x, s);
+    case 8: return grouping_grad_lds_launch<8>(b, c, n, m * u, grad_y, gyp, idx, grad_x, s);
+    default: return grouping_grad_lds_launch<4>(b, c, n, m * u, grad_y, gyp, idx, grad_x, s);
   }
   if (p2pb_deterministic()) return P2PB_EINVAL;  // (rows beyond the LDS: only the global-atomic kernel is left)
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * n, s);
   if (e != 0) return e;
   constexpr int CC = 8;
   hipLaunchKernelGGL(grouping_grad_kernel<CC>, dim3(cdiv((long)m * u, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n,
-                     m * u, grad_y, idx, grad_x);
+                     m * u, grad_y, gyp, idx, grad_x);
   return p2pb_launch_status();
+}
+extern "C" int p2pb_grouping_backward(int b, int c, int n, int m, int u, const float *grad_y, const int *idx,
+                                      float *grad_x, void *stream) {
+  return p2pb_grouping_backward_pitched(b, c, n, m, u, grad_y, (long)c * m * u, idx, grad_x, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -910,7 +917,7 @@ extern "C" int p2pb_three_interpolate_add(int b, int c, int m, int n, const floa
 }
 
 template <int CC>
-__global__ __launch_bounds__(256) void three_interp_grad_kernel(int c, int n, int m, const float *__restrict__ gy,
+__global__ __launch_bounds__(256) void three_interp_grad_kernel(int c, int n, int m, const float *__restrict__ gy, size_t gyp,
                                                                 const int *__restrict__ indices,
                                                                 const float *__restrict__ weights,
                                                                 float *__restrict__ gx) {
@@ -923,7 +930,7 @@ __global__ __launch_bounds__(256) void three_interp_grad_kernel(int c, int n, in
   const float w0 = w[j], w1 = w[j + n], w2 = w[j + 2 * n];
   const int c0 = blockIdx.y * CC, c1 = min(c0 + CC, c);
   for (int l = c0; l < c1; ++l) {
-    const float g = gy[((size_t)b * c + l) * n + j];
+    const float g = gy[(size_t)b * gyp + (size_t)l * n + j];
     float *o = gx + ((size_t)b * c + l) * m;
     atomicAdd(o + a0, g * w0);
     atomicAdd(o + a1, g * w1);
@@ -933,14 +940,14 @@ __global__ __launch_bounds__(256) void three_interp_grad_kernel(int c, int n, in
 
 template <int CH>
 __global__ __launch_bounds__(SCAT_THREADS) void three_interp_grad_lds_kernel(int c, int n, int m, int Lp, const float *__restrict__ gy,
-                                                                            const int *__restrict__ indices,
+                                                                            size_t gyp, const int *__restrict__ indices,
                                                                             const float *__restrict__ weights, float *__restrict__ gx) {
   extern __shared__ float rows[];
   const int b = blockIdx.y, c0 = blockIdx.x * CH, nch = min(CH, c - c0);
   scat_zero(rows, CH * Lp);
   const int *id = indices + (size_t)b * 3 * n;
   const float *w = weights + (size_t)b * 3 * n;
-  const float *g0 = gy + ((size_t)b * c + c0) * n;
+  const float *g0 = gy + (size_t)b * gyp + (size_t)c0 * n;
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
     const int a0 = id[j], a1 = id[j + n], a2 = id[j + 2 * n];
     const float w0 = w[j], w1 = w[j + n], w2 = w[j + 2 * n];
@@ -959,8 +966,8 @@ __global__ __launch_bounds__(SCAT_THREADS) void three_interp_grad_lds_kernel(int
 }
 
 template <int CH>
-static int three_interp_grad_lds_launch(int b, int c, int n, int m, const float *gy, const int *idx, const float *w, float *gx,
-                                        hipStream_t s) {
+static int three_interp_grad_lds_launch(int b, int c, int n, int m, const float *gy, size_t gyp, const int *idx, const float *w,
+                                        float *gx, hipStream_t s) {
   const int Lp = (m + 3) & ~3;
   static bool once = false;
   if (!once) {
@@ -969,26 +976,32 @@ static int three_interp_grad_lds_launch(int b, int c, int n, int m, const float 
     once = true;
   }
   hipLaunchKernelGGL(three_interp_grad_lds_kernel<CH>, dim3(cdiv(c, CH), b), dim3(scat_threads()), sizeof(float) * (size_t)CH * Lp, s, c,
-                     n, m, Lp, gy, idx, w, gx);
+                     n, m, Lp, gy, gyp, idx, w, gx);
   return p2pb_launch_status();
 }
 
-extern "C" int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
-                                                  const float *w, float *grad_x, void *stream) {
-  if (b <= 0 || c <= 0 || n <= 0 || m <= 0) return P2PB_EINVAL;
+// (gy_pitch: as p2pb_grouping_backward_pitched, >= c*n)
+extern "C" int p2pb_three_nn_interpolate_backward_pitched(int b, int c, int n, int m, const float *grad_y, long gy_pitch,
+                                                          const int *idx, const float *w, float *grad_x, void *stream) {
+  if (b <= 0 || c <= 0 || n <= 0 || m <= 0 || gy_pitch < (long)c * n) return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  const size_t gyp = (size_t)gy_pitch;
   switch (scat_rows(m, c, 8)) {
     case 0: break;
-    case 1: return three_interp_grad_lds_launch<1>(b, c, n, m, grad_y, idx, w, grad_x, s);
-    case 2: case 3: return three_interp_grad_lds_launch<2>(b, c, n, m, grad_y, idx, w, grad_x, s);
-    case 8: return three_interp_grad_lds_launch<8>(b, c, n, m, grad_y, idx, w, grad_x, s);
-    default: return three_interp_grad_lds_launch<4>(b, c, n, m, grad_y, idx, w, grad_x, s);
+    case 1: return three_interp_grad_lds_launch<1>(b, c, n, m, grad_y, gyp, idx, w, grad_x, s);
+    case 2: case 3: return three_interp_grad_lds_launch<2>(b, c, n, m, grad_y, gyp, idx, w, grad_x, s);
+    case 8: return three_interp_grad_lds_launch<8>(b, c, n, m, grad_y, gyp, idx, w, grad_x, s);
+    default: return three_interp_grad_lds_launch<4>(b, c, n, m, grad_y, gyp, idx, w, grad_x, s);
   }
   if (p2pb_deterministic()) return P2PB_EINVAL;  // (rows beyond the LDS: only the global-atomic kernel is left)
   int e = p2pb_zero_async(grad_x, sizeof(float) * (size_t)b * c * m, s);
   if (e != 0) return e;
   constexpr int CC = 16;
   hipLaunchKernelGGL(three_interp_grad_kernel<CC>, dim3(cdiv(n, 256), cdiv(c, CC), b), dim3(256), 0, s, c, n, m,
-                     grad_y, idx, w, grad_x);
+                     grad_y, gyp, idx, w, grad_x);
   return p2pb_launch_status();
+}
+extern "C" int p2pb_three_nn_interpolate_backward(int b, int c, int n, int m, const float *grad_y, const int *idx,
+                                                  const float *w, float *grad_x, void *stream) {
+  return p2pb_three_nn_interpolate_backward_pitched(b, c, n, m, grad_y, (long)c * n, idx, w, grad_x, stream);
 }

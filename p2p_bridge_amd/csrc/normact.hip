@@ -39,6 +39,8 @@ __device__ __forceinline__ float act_grad(float u, float gy, int swish) {
 //   residual (+ rgate)      : y += residual * rgate[b,c] (PVConv: point branch + devoxelised grid * SE gate, models/pvcnn.py:322-326
 //                             with the gate moved behind the linear devoxelisation); backward: dres = gy * rgate, drgate = sum_p gy res
 struct NaExtra {
+  size_t gy_pitch;  // floats between two samples of gy (>= c * P: gy may be a channel slice of a wider tensor, read in place)
+  int c;
   const float *gmean, *residual, *rgate;
   float *dres, *drgate;
   const unsigned *seed;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void na_bwd_reduce_kernel(int P, const float *
   __shared__ double sm[256];
   const int bc = blockIdx.x, t = threadIdx.x;
   const float sc = scale[bc], sh = shift[bc];
-  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
+  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)(bc / ex.c) * ex.gy_pitch + (size_t)(bc % ex.c) * P;
   const float *rr = ex.drgate ? ex.residual + (size_t)bc * P : nullptr;
   const float gm = ex.gmean ? ex.gmean[bc] / (float)P : 0.0f;
   const unsigned k0 = ex.thresh ? ex.seed[0] ^ (ex.salt * 0x9e3779b9u) : 0u, k1 = ex.thresh ? ex.seed[1] : 0u;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(256) void na_bwd_apply_kernel(int nb, int c, int gr
   __syncthreads();
   const float sc = scale[bc], sh = shift[bc];
   const float c2 = cf[0], c3 = cf[1];
-  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)bc * P;
+  const float *xr = x + (size_t)bc * P, *gr = gy + (size_t)b * ex.gy_pitch + (size_t)ch * P;
   float *dr = dx + (size_t)bc * P;
   float *er = ex.dres ? ex.dres + (size_t)bc * P : nullptr;
   const float rg = (ex.dres && ex.rgate) ? ex.rgate[bc] : 1.0f;
@@ -239,25 +241,29 @@ static unsigned na_thresh(float drop_p) {
   return t <= 0.0 ? 0u : t >= 4294967295.0 ? 0xffffffffu : (unsigned)t;
 }
 
-// The same with the step's neighbours folded in (struct NaExtra above): gmean f32[b,c] | NULL (requires swish == 0 and no
+// The same with the step's neighbours folded in (struct NaExtra above): gy_pitch = floats between two samples of gy (0 = c * npos;
+// a channel slice of a concatenation's gradient is read in place), gmean f32[b,c] | NULL (requires swish == 0 and no
 // dropout: it is the gradient of the mean of the activation-free output); residual f32[b,c,npos] + rgate f32[b,c] | NULL with
 // outputs dres f32[b,c,npos] (NULL without a gate: the residual's gradient is gy itself) and drgate f32[b,c]; dropout
 // 0 <= drop_p < 1 with seed = two 32-bit words in DEVICE memory and the layer's salt (the forward pass's values).
 extern "C" int p2pb_norm_act_backward_ex(int b, int c, int groups, int npos, const float *x, const float *gy,
                                          const float *scale, const float *shift, const float *mean_rstd,
                                          const float *gamma, const float *beta, const float *style, int style_stride,
-                                         int swish, const float *gmean, const float *residual, const float *rgate,
+                                         int swish, long gy_pitch, const float *gmean, const float *residual, const float *rgate,
                                          float drop_p, const unsigned *seed, unsigned salt, float *dx, float *dgamma,
                                          float *dbeta, float *dstyle, float *dres, float *drgate, float *ws, void *stream) {
   if (b <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || c / groups > 256 || npos <= 0 || !x || !gy || !scale ||
       !shift || !mean_rstd || !dx || !ws || (style && (!dstyle || style_stride < 2 * c)))
     return P2PB_EINVAL;
+  if (gy_pitch == 0) gy_pitch = (long)c * npos;
+  if (gy_pitch < (long)c * npos || ((npos & 3) == 0 && (gy_pitch & 3) != 0)) return P2PB_EINVAL;
   if (!(drop_p >= 0.0f && drop_p < 1.0f) || (drop_p > 0.0f && !seed) || (gmean && (swish || drop_p > 0.0f)) ||
       ((dres || drgate) && (!rgate || !residual || !dres || !drgate)))
     return P2PB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   float *rows = ws;
   NaExtra ex = {};
+  ex.gy_pitch = (size_t)gy_pitch, ex.c = c;
   ex.gmean = gmean, ex.residual = residual, ex.rgate = rgate, ex.dres = dres, ex.drgate = drgate, ex.seed = seed, ex.salt = salt;
   ex.thresh = na_thresh(drop_p), ex.keep_scale = 1.0f / (1.0f - drop_p);
   hipLaunchKernelGGL(na_bwd_reduce_kernel, dim3(b * c), dim3(256), 0, s, npos, x, gy, scale, shift, swish, rows, ex);
@@ -276,7 +282,7 @@ extern "C" int p2pb_norm_act_backward(int b, int c, int groups, int npos, const 
                                       const float *gamma, const float *beta, const float *style, int style_stride,
                                       int swish, float *dx, float *dgamma, float *dbeta, float *dstyle, float *ws,
                                       void *stream) {
-  return p2pb_norm_act_backward_ex(b, c, groups, npos, x, gy, scale, shift, mean_rstd, gamma, beta, style, style_stride, swish,
+  return p2pb_norm_act_backward_ex(b, c, groups, npos, x, gy, scale, shift, mean_rstd, gamma, beta, style, style_stride, swish, 0,
                                    nullptr, nullptr, nullptr, 0.0f, nullptr, 0u, dx, dgamma, dbeta, dstyle, nullptr, nullptr, ws,
                                    stream);
 }

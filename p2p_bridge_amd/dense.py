@@ -289,7 +289,11 @@ class _NormAct(torch.autograd.Function):
         groups = ctx.groups
         if gy is None:  # (only the mean was used)
             gy = torch.zeros_like(x3)
-        gy = gy.contiguous()
+        from .pointnet2_batch_cuda import sample_pitch
+
+        pitch = sample_pitch(gy)  # (a channel slice of a concatenation's gradient is read in place)
+        if pitch is None or (p % 4 == 0 and (pitch % 4 != 0 or gy.data_ptr() % 16 != 0)) or pitch < c * p:
+            gy, pitch = gy.contiguous(), c * p
         dx = torch.empty_like(x3)
         dgamma = torch.empty_like(gamma) if gamma is not None else None
         dbeta = torch.empty_like(beta) if beta is not None else None
@@ -299,12 +303,12 @@ class _NormAct(torch.autograd.Function):
         if rgate is not None:
             dres, drgate = torch.empty_like(x3), torch.empty(b, c, dtype=F32, device=x3.device)
         elif ctx.has_res:
-            dres = gy  # (an ungated residual: its gradient is gy itself)
+            dres = gy.contiguous()  # (an ungated residual: its gradient is gy itself)
         if gmean is not None:
             gmean = gmean.contiguous()
         call("p2pb_norm_act_backward_ex", _i(b), _i(c), _i(groups), _i(p), ptr(x3), ptr(gy), ptr(scale), ptr(shift), ptr(mr),
              ptr(gamma), ptr(beta), ptr(style), _i(style.stride(0) if style is not None else 0), _i(int(ctx.swish)),
-             ptr(gmean), ptr(residual), ptr(rgate), ctypes.c_float(ctx.drop_p), ptr(seed), ctypes.c_uint(ctx.salt), ptr(dx),
+             ctypes.c_long(pitch), ptr(gmean), ptr(residual), ptr(rgate), ctypes.c_float(ctx.drop_p), ptr(seed), ctypes.c_uint(ctx.salt), ptr(dx),
              ptr(dgamma), ptr(dbeta), ptr(dstyle), ptr(dres if rgate is not None else None), ptr(drgate), ptr(ws), stream_ptr())
         if dres is not None:
             dres = dres.view(ctx.res_shape)

@@ -73,7 +73,7 @@ class Grouping(Function):
     @staticmethod
     def backward(ctx, grad_output):
         (indices,) = ctx.saved_tensors
-        return _ext.grouping_backward(grad_output.contiguous(), indices, ctx.num_points), None
+        return _ext.grouping_backward_pitched(grad_output, indices, ctx.num_points), None  # (a slice of a cat's gradient: read in place)
 
 
 class Gather(Function):
@@ -108,8 +108,7 @@ class NeighborInterpolation(Function):
     @staticmethod
     def backward(ctx, grad_output):
         indices, weights = ctx.saved_tensors
-        g = _ext.three_nearest_neighbors_interpolate_backward(grad_output.contiguous(), indices, weights,
-                                                              ctx.num_centers)
+        g = _ext.three_nearest_neighbors_interpolate_backward_pitched(grad_output, indices, weights, ctx.num_centers)
         return None, None, g
 
 

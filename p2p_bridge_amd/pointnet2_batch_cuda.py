@@ -123,6 +123,43 @@ def grouping_backward(grad_y, indices, n):
     return gx
 
 
+def sample_pitch(t):
+    """floats between two samples of t if t[b] is contiguous for every b and the samples do not overlap (a contiguous tensor, or a
+    channel slice t = big[:, lo:hi] of one), else None"""
+    inner = 1
+    for size, stride in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+        if size != 1 and stride != inner:
+            return None
+        inner *= size
+    return t.stride(0) if (t.shape[0] == 1 or t.stride(0) >= inner) else None
+
+
+def grouping_backward_pitched(grad_y, indices, n):
+    """build addition (training): grouping_backward reading a sample-pitched grad_y (`sample_pitch`) in place"""
+    check(indices, I32, "indices")
+    pitch = sample_pitch(grad_y)
+    if pitch is None or grad_y.dtype != F32 or not grad_y.is_cuda:
+        return grouping_backward(grad_y.contiguous(), indices, n)
+    b, c, m, u = grad_y.shape
+    gx = torch.empty(b, c, int(n), dtype=F32, device=grad_y.device)
+    call("p2pb_grouping_backward_pitched", _i(b), _i(c), _i(int(n)), _i(m), _i(u), ptr(grad_y), ctypes.c_long(max(pitch, c * m * u)),
+         ptr(indices), ptr(gx), stream_ptr())
+    return gx
+
+
+def three_nearest_neighbors_interpolate_backward_pitched(grad_y, indices, weights, m):
+    """build addition (training): the same for three_nearest_neighbors_interpolate_backward"""
+    check(indices, I32, "indices"), check(weights, F32, "weights")
+    pitch = sample_pitch(grad_y)
+    if pitch is None or grad_y.dtype != F32 or not grad_y.is_cuda:
+        return three_nearest_neighbors_interpolate_backward(grad_y.contiguous(), indices, weights, m)
+    b, c, n = grad_y.shape
+    gx = torch.empty(b, c, int(m), dtype=F32, device=grad_y.device)
+    call("p2pb_three_nn_interpolate_backward_pitched", _i(b), _i(c), _i(n), _i(int(m)), ptr(grad_y), ctypes.c_long(max(pitch, c * n)),
+         ptr(indices), ptr(weights), ptr(gx), stream_ptr())
+    return gx
+
+
 def gather_features_forward(features, indices):
     """PN2/pvcnn_sampling.cpp:6-23"""
     check(features, F32, "features"), check(indices, I32, "indices")

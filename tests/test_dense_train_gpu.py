@@ -520,3 +520,45 @@ def test_dropout_seed_follows_the_generator_and_replays_fresh_in_a_graph():
 def _norm_args(dense, conv, gn, x):
     y, st = dense.pointwise(x, conv, True)
     return y, gn.weight, gn.bias, None, st, gn.num_groups, gn.eps
+
+
+def test_backward_reads_a_channel_slice_of_a_concatenation_in_place():
+    """the gradient that reaches a layer through torch.cat is a channel slice of a wider tensor (sample-pitched, not contiguous):
+    the folded norm's backward, the grouping adjoint and the 3-NN interpolation adjoint read it in place -- same results as from a
+    contiguous copy (the LDS scatter kernels add in a different order: 1e-6), and no copy is made"""
+    from p2p_bridge_amd import dense
+    from p2p_bridge_amd import pointnet2_batch_cuda as ext
+
+    torch.manual_seed(2)
+    big = torch.randn(4, 96 + 35, 128, 32, device="cuda")
+    g = big[:, 35:]
+    assert not g.is_contiguous() and ext.sample_pitch(g) == big.stride(0) and ext.sample_pitch(big) == big.stride(0)
+    assert ext.sample_pitch(big[:, :, ::2]) is None and ext.sample_pitch(big.transpose(1, 2)) is None
+    idx = torch.randint(0, 512, (4, 128, 32), device="cuda", dtype=torch.int32)
+    a, b = ext.grouping_backward_pitched(g, idx, 512), ext.grouping_backward(g.contiguous(), idx, 512)
+    assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item()
+    big3 = torch.randn(3, 64 + 200, 2048, device="cuda")
+    g3 = big3[:, :200]
+    idx3 = torch.randint(0, 512, (3, 3, 2048), device="cuda", dtype=torch.int32)
+    w3 = torch.rand(3, 3, 2048, device="cuda")
+    a, b = ext.three_nearest_neighbors_interpolate_backward_pitched(g3, idx3, w3, 512), \
+        ext.three_nearest_neighbors_interpolate_backward(g3.contiguous(), idx3, w3, 512)
+    assert (a - b).abs().max().item() <= 1e-6 * b.abs().max().item()
+    # the folded norm: y -> cat -> loss, against the same with the slice copied first (bit-identical: fixed summation orders)
+    for shape, p in (((512,), 0.0), ((333,), 0.0), ((8, 8, 8), 0.2)):
+        conv, norm, gn, cond, x = _fold_case("adagn3d" if len(shape) == 3 else "adagn1d", 2, 16, 32, shape)
+        seed = dense.dropout_seed("cuda")
+        other = torch.randn(2, 5, *shape, device="cuda")
+        gz = torch.randn(2, 37, *shape, device="cuda")
+        res = []
+        for copy in (False, True):
+            for t in (x, conv.weight, gn.weight, cond):
+                t.grad = None
+            y = dense.conv_norm_act(x, conv, norm, cond, True, dropout=(p, seed, 1) if p else None)
+            if copy:
+                y.backward(gz[:, 5:].contiguous())
+            else:
+                torch.cat([other, y], 1).backward(gz)
+            res.append([t.grad.clone() for t in (x, conv.weight, gn.weight, cond)])
+        for u, v in zip(*res):
+            assert torch.equal(u, v)
