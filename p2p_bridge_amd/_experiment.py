@@ -5,7 +5,7 @@ The switches a USER may need keep their own variables: P2PB_LIB
 P2PB_SAMPLE_CHAINS, P2PB_SEGMENTED_BACKWARD, P2PB_FUSED_OPTIM, P2PB_F16_OVERFLOW (and bench.py's P2PB_CPU_THREADS / P2PB_CPU_PROCS).
 
 Keys (default): conv_pre (8,16,32:8,16), compact (16:16), wide_f16_min_cin (16), prepass_blocks (9), sa_gather (1), fps_big (grid),
-nn_cells (1), wgrad_overlap (0), dgrad_math (follows P2PB_TRAIN_MATH), sparse_wgrad_min_r (16), chain_stagger_pct (0 | 100 by cloud size) -- Python side; conv_wide_min (256), am_chunks (auto), pw_wm (auto), pw_pp (1), fps_mid (512),
+nn_cells (1), wgrad_overlap (0), dgrad_math (follows P2PB_TRAIN_MATH), sparse_wgrad_min_r (16), chain_stagger_pct (0 | 100 by cloud size), row_max (1), train_fold (1) -- Python side; conv_wide_min (256), am_chunks (auto), pw_wm (auto), pw_pp (1), fps_mid (512),
 fps_coop_test_fallback (0), vox_onepass (per shape), devox_cl4 (1) -- library side."""
 import os
 import warnings
