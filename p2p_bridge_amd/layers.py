@@ -76,6 +76,26 @@ class Grouping(Function):
         return _ext.grouping_backward_pitched(grad_output, indices, ctx.num_points), None  # (a slice of a cat's gradient: read in place)
 
 
+class GroupConcat(Function):
+    """[coords[:, idx] - centers | features[:, idx]] f32[B,3+C,M,U] in ONE launch (BallQuery.forward, models/pvcnn.py:116-126: two
+    groupings, a subtraction and a concatenation in the reference's graph); backward: the grouping adjoint reading the feature
+    rows of the gradient in place (coordinates carry no gradient on this path: the reference detaches nothing here, but its
+    coordinates never require one -- a coordinate tensor that does takes the unfused operators)"""
+
+    @staticmethod
+    def forward(ctx, points_coords, centers_coords, points_features, indices):
+        points_coords, centers_coords = points_coords.contiguous(), centers_coords.contiguous()
+        points_features, indices = points_features.contiguous(), indices.contiguous()
+        ctx.save_for_backward(indices)
+        ctx.num_points = points_features.size(-1)
+        return _ext.group_concat(points_coords, centers_coords, points_features, indices)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        (indices,) = ctx.saved_tensors
+        return None, None, _ext.grouping_backward_pitched(grad_output[:, 3:], indices, ctx.num_points), None
+
+
 class Gather(Function):
     @staticmethod
     def forward(ctx, features, indices):

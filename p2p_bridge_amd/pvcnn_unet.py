@@ -586,6 +586,9 @@ class BallQuery(nn.Module):
         points_coords = points_coords.contiguous()
         centers_coords = centers_coords.contiguous()
         idx = L.ball_query(centers_coords, points_coords, self.radius, self.num_neighbors)
+        if (points_features is not None and self.include_coordinates and points_features.is_cuda and points_features.dtype == torch.float32
+                and not points_coords.requires_grad and not centers_coords.requires_grad and _experiment.get_int("group_concat", 1)):
+            return L.GroupConcat.apply(points_coords, centers_coords, points_features, idx)  # (one launch; layers.GroupConcat)
         rel = L.pvcnn_grouping(points_coords, idx) - centers_coords.unsqueeze(-1)
         if points_features is None:
             return rel

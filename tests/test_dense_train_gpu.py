@@ -562,3 +562,31 @@ def test_backward_reads_a_channel_slice_of_a_concatenation_in_place():
             res.append([t.grad.clone() for t in (x, conv.weight, gn.weight, cond)])
         for u, v in zip(*res):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("b,c,n,m,u", [(8, 32, 2048, 512, 32), (3, 64, 512, 128, 32), (2, 320, 32, 8, 32), (2, 5, 300, 77, 16)])
+def test_group_concat_one_launch_equals_the_reference_graph(b, c, n, m, u):
+    """BallQuery's [grouped coordinates - centres | grouped features] as ONE autograd node (layers.GroupConcat) against the
+    reference's graph of two groupings, a subtraction and a concatenation: the same bits forward, the same feature gradient
+    (LDS scatter order: 1e-6)"""
+    from p2p_bridge_amd import layers as L
+    from p2p_bridge_amd.pvcnn_unet import BallQuery
+
+    torch.manual_seed(n)
+    pts = torch.rand(b, 3, n, device="cuda")
+    cen = pts[:, :, :m].contiguous()
+    feat = torch.randn(b, c, n, device="cuda", requires_grad=True)
+    bq = BallQuery(0.3, u)
+    y = bq(pts, cen, feat)
+    assert y.grad_fn.__class__.__name__.startswith("GroupConcat")
+    idx = L.ball_query(cen, pts, 0.3, u)
+    f2 = feat.detach().clone().requires_grad_(True)
+    ref = torch.cat([L.pvcnn_grouping(pts, idx) - cen.unsqueeze(-1), L.pvcnn_grouping(f2, idx)], dim=1)
+    assert torch.equal(y, ref)
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref.backward(g)
+    assert (feat.grad - f2.grad).abs().max().item() <= 1e-6 * f2.grad.abs().max().item()
+    # coordinates that require a gradient keep the unfused operators
+    pts_g = pts.clone().requires_grad_(True)
+    assert not bq(pts_g, cen, feat).grad_fn.__class__.__name__.startswith("GroupConcat")
