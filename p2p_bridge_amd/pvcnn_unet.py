@@ -56,6 +56,25 @@ class PVCData:
     lower_temb: torch.Tensor = None  # build addition (fused inference): the time embedding [B, E] that `lower_features` leaves out
 
 
+def temb_broadcast(base, m):
+    """the time embedding [B,E] -> its broadcast over m positions [B,E,m] (models/unet_pvc.py:254: `[:, :, None].expand`), tagged
+    with its base"""
+    out = base[:, :, None].expand(-1, -1, m)
+    out._p2pb_base = base
+    return out
+
+
+def temb_at(time_emb, m):
+    """the reference's `time_emb[:, :, :m]` (models/pvcnn.py:392) / `time_emb[:, :, 0:1].expand(-1, -1, m)` (:225): the same
+    values, but as a FRESH broadcast of the [B,E] base when the tensor carries one (`temb_broadcast`). Under autograd the
+    reference's slices of the [B,E,N] expansion cost a zero fill + a copy of the N-wide tensor per use and an N-wide accumulation
+    per level on the way back (16 launches per config-3 step); a fresh broadcast's backward is one row sum."""
+    base = getattr(time_emb, "_p2pb_base", None)
+    if base is not None:
+        return temb_broadcast(base, m)
+    return time_emb[:, :, :m] if m <= time_emb.shape[-1] else time_emb[:, :, 0:1].expand(-1, -1, m)
+
+
 # ------------------------------------------------------------------------------------ small modules
 
 
@@ -647,7 +666,7 @@ class PointNetSAModule(nn.Module):
             return data
         centers = L.furthest_point_sample_pvcnn(coords, self.num_centers)
         if data.time_emb is not None:
-            data.time_emb = data.time_emb[:, :, : centers.shape[-1]]
+            data.time_emb = temb_at(data.time_emb, centers.shape[-1])
         grouped = self.groupers[0](coords, centers, data.features)
         data.features = self.mlps[0].run(grouped, data.cond, reduce_max=True)
         data.coords = centers
@@ -700,7 +719,7 @@ class PointNetFPModule(nn.Module):
         if data.features is not None:
             x = torch.cat([x, data.features], dim=1)
         if data.time_emb is not None:
-            data.time_emb = data.time_emb[:, :, 0:1].expand(-1, -1, data.coords.shape[-1])
+            data.time_emb = temb_at(data.time_emb, data.coords.shape[-1])
         data.features = self.mlp.run(x, data.cond)
         return data
 
@@ -1115,7 +1134,7 @@ class PVCNN2Unet(nn.Module):
                 te = fused.linear_rows(F.leaky_relu(te, self.embedf[1].negative_slope), self.embedf[2].weight, self.embedf[2].bias)
             else:
                 te = self.embedf(te)
-            time_emb = te[:, :, None].expand(-1, -1, N)
+            time_emb = temb_broadcast(te, N)
         data = PVCData(features=feats, coords=coords, time_emb=time_emb, cond=cond, geo=geo)
 
         skips, level_coords = [feats], []
@@ -1144,7 +1163,7 @@ class PVCNN2Unet(nn.Module):
             cut = [data.features] + skips
             if data.time_emb is not None and te.requires_grad:
                 te_c = alias(te)
-                data.time_emb = te_c[:, :, None].expand(-1, -1, data.coords.shape[-1])
+                data.time_emb = temb_broadcast(te_c, data.coords.shape[-1])
                 cut.append(te_c)
             if isinstance(cond, _Styles):
                 cut += cond.cut  # (the embedding as the decoder's style Linears see it: StyleBank.evaluate_train)
