@@ -38,7 +38,18 @@ def test_degenerate_sizes_are_einval(L):
         "p2pb_linear_attention_forward": (_i(1), _i(2), _i(16), _i(8), p, p, NULL, s),        # dim_head != 32
         "p2pb_knn_points": (_i(1), _i(1), _i(4), _i(9), p, p, p, p, NULL, p, s),              # k > n
         "p2pb_three_nn": (_i(1), _i(0), _i(4), p, p, p, p, s),
+        # round 6: the training step's folded entry points
+        "p2pb_affine_act_train": (_i(1), _i(8), _i(8), p, p, p, _i(1), NULL, NULL, _f(0.1), NULL, ctypes.c_uint(1), p, s),  # dropout without a seed
+        "p2pb_grouping_backward_pitched": (_i(1), _i(2), _i(8), _i(2), _i(2), p, ctypes.c_long(7), p, p, s),           # pitch < c*m*u
+        "p2pb_three_nn_interpolate_backward_pitched": (_i(1), _i(2), _i(8), _i(4), p, ctypes.c_long(15), p, p, p, s),  # pitch < c*n
     }
+    nab = lambda **k: (_i(1), _i(8), _i(2), _i(8), p, p, p, p, p, NULL, NULL, NULL, _i(0), _i(k.get("swish", 0)),  # noqa: E731
+                       ctypes.c_long(k.get("pitch", 0)), k.get("gmean", NULL), k.get("res", NULL), k.get("rgate", NULL),
+                       _f(k.get("drop", 0.0)), k.get("seed", NULL), ctypes.c_uint(0), p, NULL, NULL, NULL, k.get("dres", NULL),
+                       k.get("drgate", NULL), p, s)
+    for bad in (dict(drop=1.0, seed=p), dict(drop=0.2), dict(gmean=p, swish=1), dict(gmean=p, drop=0.1, seed=p), dict(pitch=63),
+                dict(pitch=66), dict(dres=p, drgate=p), dict(res=p, rgate=p, dres=p)):
+        assert lib.p2pb_norm_act_backward_ex(*nab(**bad)) == -22, bad
     for name, args in calls.items():
         rc = getattr(lib, name)(*args)
         assert rc == -22, (name, rc)
