@@ -68,6 +68,8 @@ def conv_roofline(model, x_start, reps=10):
     `achieved` counts the ALGORITHMIC FLOPs of what the layer must produce with this formulation: 2*27*Cin*Cout per LISTED
     output voxel (the exact-constant voxels cost no matrix work by construction); `dense_equivalent` is the same
     launch priced as the dense convolution the reference runs (all 16^3 voxels)."""
+    import glob
+
     from p2p_bridge_amd import fused
 
     pv = model.model.fp_layers[2][1]
@@ -109,8 +111,23 @@ def conv_roofline(model, x_start, reps=10):
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM-side traffic of this launch from the committed PMC passes (tools/pmc_conv_instances.sh: the same launch, B = 32), the
+    # counters read as for the first kernel: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch
+    traffic, basis = None, None
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_conv_compact.csv")), reverse=True)
+    if cands and B == 32 and r == 16 and C == 128:
+        vals = {}
+        for line in open(cands[0]).read().splitlines()[1:]:
+            k, v = line.split(",")[:2]
+            vals[k] = float(v)
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            traffic = round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0)
+            algo = 4 * B * r ** 3 * C + 4 * listed * conv.out_channels + 4 * 27 * conv.in_channels * conv.out_channels
+            basis = (f"profiles/{os.path.basename(cands[0])}: (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch; algorithmic = the pre-split operand "
+                     f"grid once + the listed outputs + the weight pack = {algo} B (a brick's 6x10x10 halo overlaps its neighbours' 2.34 x: "
+                     "the re-reads are served by the XCD's L2 as far as the brick order keeps them there)")
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": round(split_peak_tflops(), 1), "unit": "TFLOP/s",
-            "frac": round(achieved / split_peak_tflops(), 4), "traffic": None,
+            "frac": round(achieved / split_peak_tflops(), 4), "traffic": traffic, "traffic_basis": basis,
             "kernel": f"conv3d_k3_compact_kernel<{r},XF> C{conv.in_channels}->{conv.out_channels} r{r} B{B} "
                       f"(fp_layers.2.1.voxel_layers.4, the launch the sampler issues)",
             "listed_output_voxels": listed, "grid_voxels": B * r ** 3,
